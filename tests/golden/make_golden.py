@@ -1,0 +1,378 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the Python reference.
+
+Runs only in the build container, where the reference tree is mounted read-only at
+/root/reference (it never travels to the GPU box).  Nothing of the reference's source is
+copied: only numeric inputs/outputs of its functions are stored, as small .npz files.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Versions that produced the committed fixtures: numpy 2.2.6, scipy 1.15.3, python 3.10.12,
+reference cobaya v3.6.2 (no numba => scipy special_ortho_group fallback).  The third-party
+`getdist` is absent here; a 4-name stand-in (tests/golden/_getdist_stub) satisfies the
+import in cobaya/collection.py:18-19 and is never called.
+
+Fixture ids follow SURVEY.md §8c (G1..G9).
+"""
+import copy
+import json
+import logging
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("COBAYA_REFERENCE", "/root/reference")
+sys.path[:0] = [os.path.join(HERE, "_getdist_stub"), REF]
+
+import numpy as np  # noqa: E402
+
+from cobaya.likelihoods.gaussian_mixture import (  # noqa: E402
+    info_random_gaussian_mixture,
+    random_cov,
+)
+from cobaya.model import get_model  # noqa: E402
+from cobaya.sampler import get_sampler  # noqa: E402
+from cobaya.samplers.mcmc.proposal import BlockedProposer  # noqa: E402
+
+logging.disable(logging.CRITICAL)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", os.path.relpath(path), os.path.getsize(path), "bytes")
+
+
+def rng_state_json(rng):
+    st = copy.deepcopy(rng.bit_generator.state)
+    return json.dumps(st, default=lambda o: int(o))
+
+
+# ---------------------------------------------------------------------------- targets
+def make_targets():
+    """Targets of BASELINE configs 2/4: info_random_gaussian_mixture with
+    default_rng(0), O_std in [0.01, 0.05], unit box; plus a 3-mode d=4 mixture."""
+    out = {}
+    for d in (30, 100):
+        info = info_random_gaussian_mixture(
+            ranges=[[0, 1]] * d, n_modes=1, input_params_prefix="a_", O_std_min=0.01,
+            O_std_max=0.05, mpi_aware=False, random_state=np.random.default_rng(0),
+            add_ref=True)
+        gm = info["likelihood"]["gaussian_mixture"]
+        out[f"mean_d{d}"] = np.array(gm["means"][0])
+        out[f"cov_d{d}"] = np.array(gm["covs"][0])
+    save("targets", **out)
+
+
+# ---------------------------------------------------------------------------- G1
+def g1_transforms():
+    """a1: BlockedProposer.set_covariance -> transform[b] (proposal.py:226-260)."""
+    out = {}
+    rs = np.random.default_rng(11)
+    cases = []
+    for d in (2, 3, 30, 100):
+        cov = random_cov([[0, 1]] * d, O_std_min=0.01, O_std_max=0.5, random_state=rs)
+        cases.append((f"d{d}", cov, [list(range(d))]))
+    cov5 = random_cov([[0, 1]] * 5, O_std_min=0.1, O_std_max=2.0, random_state=rs)
+    cases.append(("d5_2blocks", cov5, [[3, 1], [0, 2, 4]]))
+    cases.append(("d5_3blocks", cov5, [[4], [0, 1], [2, 3]]))
+    for name, cov, blocks in cases:
+        bp = BlockedProposer(blocks, np.random.default_rng(0),
+                             oversampling_factors=np.ones(len(blocks), dtype=int))
+        bp.set_covariance(cov)
+        out[name + "_cov"] = cov
+        out[name + "_blocks"] = np.array(sum(blocks, []))
+        out[name + "_blocklens"] = np.array([len(b) for b in blocks])
+        for i, t in enumerate(bp.transform):
+            out[f"{name}_transform{i}"] = t
+    save("g1_transforms", **out)
+
+
+# ---------------------------------------------------------------------------- G4
+def g4_prior():
+    """a7/a6: Prior.logps_internal (prior.py:733-763) and reduce_periodic (658-676)."""
+    params = {
+        "u0": {"prior": {"min": -0.5, "max": 3.0}},
+        "n0": {"prior": {"dist": "norm", "loc": 0.3, "scale": 1.7}},
+        "u1": {"prior": {"min": 0.0, "max": 1.0}, "periodic": True},
+        "n1": {"prior": {"dist": "norm", "loc": -2.0, "scale": 0.05}},
+        "u2": {"prior": {"dist": "uniform", "loc": -1.0, "scale": 2.0}},
+    }
+    model = get_model({"likelihood": {"one": None}, "params": params})
+    pr = model.prior
+    rs = np.random.default_rng(4)
+    pts = rs.normal(size=(96, 5)) * np.array([1.5, 2.0, 0.8, 0.1, 0.9]) + np.array(
+        [1.0, 0.3, 0.5, -2.0, 0.0])
+    # exact boundary points
+    pts[0] = [-0.5, 0.0, 0.0, -2.0, -1.0]
+    pts[1] = [3.0, 0.0, 1.0, -2.0, 1.0]
+    pts[2] = [np.nextafter(3.0, 4.0), 0.0, 0.5, -2.0, 0.0]
+    pts[3] = [1.0, 0.0, 0.5, -2.0, np.nextafter(-1.0, -2.0)]
+    logp = np.array([pr.logps_internal(p) for p in pts])
+    wrapped = np.array([pr.reduce_periodic(p, copy=True) for p in pts])
+    save("g4_prior", points=pts, logprior=logp, wrapped=wrapped,
+         bounds=np.array(pr.bounds()), kinds=np.array([0, 1, 0, 1, 0]),
+         loc=np.array([0, 0.3, 0, -2.0, 0]), scale=np.array([0, 1.7, 0, 0.05, 0]),
+         periodic=np.array([0, 0, 1, 0, 0]), uniform_logp=np.array(pr._uniform_logp))
+
+
+# ---------------------------------------------------------------------------- G5
+def g5_loglike():
+    """a9/a10: GaussianMixture.logp (gaussian_mixture.py:138-163) incl. derived params;
+    Gaussian.logp (gaussian.py:96-112) normalized on/off."""
+    out = {}
+    rs = np.random.default_rng(5)
+    for d, K in ((2, 1), (3, 1), (3, 3), (4, 2), (30, 1), (30, 3), (100, 1)):
+        info = info_random_gaussian_mixture(
+            ranges=[[0, 1]] * d, n_modes=K, input_params_prefix="a_",
+            output_params_prefix="b_", O_std_min=0.02, O_std_max=0.2, derived=True,
+            mpi_aware=False, random_state=rs)
+        if K > 1:
+            w = rs.uniform(0.2, 1.0, size=K)
+            info["likelihood"]["gaussian_mixture"]["weights"] = list(w / w.sum())
+        model = get_model(info)
+        gm = model.likelihood["gaussian_mixture"]
+        means, covs = np.array(gm.means), np.array(gm.covs)
+        pts = means[rs.integers(K, size=64)] + rs.normal(size=(64, d)) * np.sqrt(
+            covs[0].diagonal()) * rs.uniform(0.2, 3.0, size=(64, 1))
+        pts = np.clip(pts, 1e-9, 1 - 1e-9)
+        ll = np.empty(64)
+        der = np.empty((64, K * d))
+        for i, p in enumerate(pts):
+            res = model.logposterior(p)
+            ll[i] = res.loglikes[0]
+            der[i] = res.derived
+        tag = f"gm_d{d}_K{K}"
+        out[tag + "_means"], out[tag + "_covs"] = means, covs
+        out[tag + "_weights"] = (np.atleast_1d(gm.weights) if K > 1 else np.array([1.0]))
+        out[tag + "_points"], out[tag + "_loglike"], out[tag + "_derived"] = pts, ll, der
+    for d, normalized in ((3, True), (27, True), (27, False)):
+        cov = random_cov([[0, 1]] * d, O_std_min=0.05, O_std_max=0.5, random_state=rs)
+        mean = rs.uniform(0.3, 0.7, size=d)
+        info = {"likelihood": {"gaussian": {"mean": mean, "cov": cov,
+                                            "normalized": normalized}},
+                "params": {f"p{i}": {"prior": {"min": -10, "max": 10}} for i in range(d)}}
+        model = get_model(info)
+        pts = mean + rs.normal(size=(64, d)) * np.sqrt(cov.diagonal())
+        ll = np.array([model.logposterior(p).loglikes[0] for p in pts])
+        tag = f"gauss_d{d}_norm{int(normalized)}"
+        out[tag + "_mean"], out[tag + "_cov"] = mean, cov
+        out[tag + "_points"], out[tag + "_loglike"] = pts, ll
+    save("g5_loglike", **out)
+
+
+# ---------------------------------------------------------------------------- G6/G7
+QUICKSTART = {
+    "likelihood": {"gaussian_mixture": {"means": [0.2, 0],
+                                        "covs": [[0.1, 0.05], [0.05, 0.2]],
+                                        "derived": True}},
+    "params": {"a": {"prior": {"min": -0.5, "max": 3}, "latex": r"\alpha"},
+               "b": {"prior": {"dist": "norm", "loc": 0, "scale": 1}, "ref": 0,
+                     "proposal": 0.5, "latex": r"\beta"},
+               "derived_a": {"latex": r"\alpha^\prime"},
+               "derived_b": {"latex": r"\beta^\prime"}},
+}  # values of docs/src_examples/quickstart/gaussian.yaml (BASELINE config 1)
+
+FIXED3 = {
+    "likelihood": {"gaussian_mixture": {
+        "means": [np.array([-0.48591462, 0.10064559, 0.64406749])],
+        "covs": [np.array([[0.00078333, 0.00033134, -0.0002923],
+                           [0.00033134, 0.00218118, -0.00170728],
+                           [-0.0002923, -0.00170728, 0.00676922]])],
+        "input_params_prefix": "a_", "output_params_prefix": "", "derived": True}},
+    "params": {"a__0": {"prior": {"min": -1, "max": 1}},
+               "a__1": {"prior": {"min": -1, "max": 1}},
+               "a__2": {"prior": {"min": -1, "max": 1}},
+               "_0": None, "_1": None, "_2": None},
+}  # values of tests/common_sampler.py:24-50
+
+
+def run_chain(info, sampler_opts):
+    """Initialise the reference `mcmc` sampler, snapshot (rng state, initial point,
+    initial proposal covariance), run it, and return everything needed to replay it."""
+    info = copy.deepcopy(info)
+    model = get_model(info)
+    opts = {"measure_speeds": False, "Rminus1_stop": 0.0, "Rminus1_cl_stop": 0.0}
+    opts.update(sampler_opts)
+    sampler = get_sampler({"mcmc": opts}, model)
+    state0 = rng_state_json(sampler._rng)
+    x0 = sampler.current_point.values.copy()
+    lp0 = sampler.current_point.logpost
+    cov0 = sampler.proposer.get_covariance()
+    learned = []
+    orig = sampler.proposer.set_covariance
+
+    def spy(m):
+        orig(m)
+        learned.append(np.array(m, copy=True))
+
+    sampler.proposer.set_covariance = spy
+    sampler.run()
+    data = sampler.collection.data
+    cols = list(data.columns)
+    prog = sampler.progress
+    out = {
+        "rng_state": np.array(state0),
+        "x0": x0, "logpost0": np.array(lp0), "cov0": cov0,
+        "columns": np.array(cols),
+        "data": data.to_numpy(dtype=np.float64),
+        "n_steps_raw": np.array(sampler.n_steps_raw),
+        "final_x": sampler.current_point.values.copy(),
+        "final_weight": np.array(sampler.current_point.weight),
+        "learned_covs": np.array(learned) if learned else np.zeros((0, 1, 1)),
+        "progress_N": prog["N"].to_numpy(dtype=np.float64),
+        "progress_acc": prog["acceptance_rate"].to_numpy(dtype=np.float64),
+        "progress_Rminus1": prog["Rminus1"].to_numpy(dtype=np.float64),
+        "learn_every": np.array(sampler.learn_every.value),
+        "max_tries": np.array(sampler.max_tries.value),
+        "burn_in": np.array(sampler.burn_in.value),
+        "temperature": np.array(float(sampler.temperature)),
+        "proposal_scale": np.array(float(sampler.proposal_scale)),
+    }
+    return out
+
+
+def g6_traces():
+    """a12-a16: full chain traces of the reference sampler (mcmc.py:451-1032)."""
+    out = {}
+    cases = {
+        "quick_nolearn": (QUICKSTART, {"seed": 1, "max_samples": 400,
+                                       "learn_proposal": False}),
+        "quick_learn": (QUICKSTART, {"seed": 2, "max_samples": 600}),
+        "fixed3_T1": (FIXED3, {"seed": 3, "max_samples": 500, "learn_proposal": False,
+                               "burn_in": 20}),
+        "fixed3_T2": (FIXED3, {"seed": 4, "max_samples": 500, "temperature": 2,
+                               "learn_proposal": True}),
+    }
+    info30 = info_random_gaussian_mixture(
+        ranges=[[0, 1]] * 30, n_modes=1, input_params_prefix="a_", O_std_min=0.01,
+        O_std_max=0.05, mpi_aware=False, random_state=np.random.default_rng(0),
+        add_ref=True)
+    cov30 = np.array(info30["likelihood"]["gaussian_mixture"]["covs"][0])
+    cases["d30_covmat"] = (info30, {
+        "seed": 5, "max_samples": 300, "learn_proposal": False, "covmat": cov30,
+        "covmat_params": list(info30["params"])})
+    info4 = info_random_gaussian_mixture(
+        ranges=[[0, 1]] * 4, n_modes=2, input_params_prefix="a_", O_std_min=0.02,
+        O_std_max=0.08, mpi_aware=False, random_state=np.random.default_rng(7))
+    info4["likelihood"]["gaussian_mixture"]["weights"] = [0.3, 0.7]
+    cases["d4_K2"] = (info4, {"seed": 6, "max_samples": 400, "learn_proposal": True})
+    for name, (info, opts) in cases.items():
+        res = run_chain(info, opts)
+        gm = info["likelihood"]["gaussian_mixture"]
+        res["means"] = np.atleast_2d(np.array(gm["means"], dtype=float))
+        covs = np.array(gm["covs"], dtype=float)
+        res["covs"] = covs if covs.ndim == 3 else covs[None]
+        res["weights"] = np.array(gm.get("weights") or [1.0], dtype=float)
+        for k, v in res.items():
+            out[f"{name}__{k}"] = v
+        print(name, "rows", res["data"].shape, "steps", int(res["n_steps_raw"]))
+    save("g6_traces", **out)
+
+
+def g7_multichain():
+    """a16 multi-chain branch (mcmc.py:787-793, 856-889, 1021-1023) driven without MPI:
+    m samplers in one process, `more_than_one_process` and `mpi.array_gather` patched so
+    that sampler 0 sees the m chains (recipe of SURVEY Appendix C)."""
+    import cobaya.mpi as cmpi
+    import cobaya.samplers.mcmc.mcmc as mm
+
+    m = 6
+    samplers = []
+    for i in range(m):
+        model = get_model(copy.deepcopy(FIXED3))
+        s = get_sampler({"mcmc": {"seed": 100 + i, "max_samples": 600,
+                                  "covmat": FIXED3["likelihood"]["gaussian_mixture"][
+                                      "covs"][0],
+                                  "covmat_params": ["a__0", "a__1", "a__2"],
+                                  "measure_speeds": False, "learn_proposal": False,
+                                  "Rminus1_stop": 0.0, "Rminus1_cl_stop": 0.0}}, model)
+        s.run()
+        samplers.append(s)
+    stats = []
+    for s in samplers:
+        first = int(s.n() / 2)
+        stats.append([s.n(), s.collection.mean(first=first, tempered=True),
+                      s.collection.cov(first=first, tempered=True),
+                      s.get_acceptance_rate(first)])
+    Ns = np.array([st[0] for st in stats], dtype=float)
+    means = np.array([st[1] for st in stats])
+    covs = np.array([st[2] for st in stats])
+    accs = np.array([st[3] for st in stats])
+    old_more, old_gather = mm.more_than_one_process, cmpi.array_gather
+    mm.more_than_one_process = lambda: True
+    cmpi.array_gather = lambda _lst: [Ns, means, covs, accs]
+    mm.mpi.array_gather = cmpi.array_gather
+    s0 = samplers[0]
+    s0.learn_proposal = True
+    s0.i_learn = 1
+    try:
+        s0.check_convergence_and_learn_proposal()
+    finally:
+        mm.more_than_one_process, cmpi.array_gather = old_more, old_gather
+        mm.mpi.array_gather = old_gather
+    chains = {}
+    for i, s in enumerate(samplers):
+        chains[f"chain{i}"] = s.collection.data.to_numpy(dtype=np.float64)
+    save("g7_multichain", Ns=Ns, means=means, covs=covs, acceptance_rates=accs,
+         Rminus1=np.array(s0.Rminus1_last),
+         new_proposal_cov=s0.proposer.get_covariance(),
+         progress_acc=np.array(float(s0.progress.at[1, "acceptance_rate"])),
+         columns=np.array(list(samplers[0].collection.data.columns)), **chains)
+
+
+# ---------------------------------------------------------------------------- G9
+def g9_initial_covmat():
+    """a17: CovmatSampler.initial_proposal_covmat precedence (sampler.py:485-685), with
+    the construction of tests/test_mcmc_initial_covmat.py (dim 40)."""
+    dim = 40
+    rs = np.random.default_rng(9)
+    i_s = list(range(dim))
+    rs.shuffle(i_s)
+    cov = random_cov(dim * [[0, 1]], random_state=rs)
+    n_alt = dim // 4
+    i_prop, i_ref, i_pri = i_s[:n_alt], i_s[n_alt:2 * n_alt], i_s[2 * n_alt:3 * n_alt]
+    removed = i_prop + i_ref + i_pri
+    i_cov = [i for i in range(dim) if i not in removed]
+    for i in removed:
+        diag = cov[i, i]
+        cov[:, i] = 0
+        cov[i, :] = 0
+        cov[i, i] = diag
+    order = list(range(dim))
+    rs.shuffle(order)
+    params = {}
+    kind = np.zeros(dim, dtype=int)  # 0 covmat, 1 proposal, 2 ref, 3 prior
+    for i in order:
+        p = f"a_{i}"
+        params[p] = {"prior": {"dist": "norm", "loc": 0, "scale": 1000}}
+        sigma = np.sqrt(cov[i, i])
+        if i in i_prop:
+            params[p]["proposal"] = sigma
+            kind[i] = 1
+        elif i in i_ref:
+            params[p]["ref"] = {"dist": "norm", "scale": sigma * 2}
+            kind[i] = 2
+        elif i in i_pri:
+            params[p]["prior"]["scale"] = sigma * 2
+            kind[i] = 3
+    reduced = cov[np.ix_(i_cov, i_cov)]
+    model = get_model({"likelihood": {"one": None}, "params": params})
+    s = get_sampler({"mcmc": {"covmat": reduced,
+                              "covmat_params": [f"a_{i}" for i in i_cov],
+                              "measure_speeds": False}}, model)
+    save("g9_initial_covmat", full_cov=cov, order=np.array(order), kind=kind,
+         i_cov=np.array(i_cov), reduced=reduced,
+         expected=cov[np.ix_(order, order)],
+         got=s.proposer.get_covariance())
+
+
+if __name__ == "__main__":
+    make_targets()
+    g1_transforms()
+    g4_prior()
+    g5_loglike()
+    g6_traces()
+    g7_multichain()
+    g9_initial_covmat()
