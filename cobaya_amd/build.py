@@ -1,0 +1,108 @@
+"""Builds libmcmc_hip.so (hipcc, gfx950 only) in-tree under cobaya_amd/csrc/.
+
+One object per compiled dimension (walker_kernels.hip with -DMCMC_D=<d>), compiled in
+parallel, plus capi.hip; linked into cobaya_amd/csrc/libmcmc_hip.so.  hipcc cross-compiles
+without a GPU, so this runs in the CPU-only build container.
+
+    python -m cobaya_amd.build            # all dimensions 1..32
+    MCMC_HIP_DIMS=2,3,30 python -m cobaya_amd.build   # quick developer build
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(CSRC, "libmcmc_hip.so")
+ARCH = "gfx950"
+ALL_DIMS = list(range(1, 33))
+
+# -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
+# operations are written as fma()); see DESIGN.md "Ensemble specification".
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
+         "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the mcmc_hip engine can only be built with ROCm")
+    return exe
+
+
+def _digest(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _compile(src, obj, defines, stamp):
+    stamp_file = obj + ".stamp"
+    if os.path.exists(obj) and os.path.exists(stamp_file):
+        with open(stamp_file) as f:
+            if f.read() == stamp:
+                return False
+    cmd = [hipcc(), *FLAGS, *defines, "-c", src, "-o", obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return True
+
+
+def selected_dims():
+    env = os.environ.get("MCMC_HIP_DIMS")
+    if env:
+        return sorted({int(s) for s in env.split(",") if s.strip()})
+    return ALL_DIMS
+
+
+def build(dims=None, jobs=None, verbose=True):
+    """Compile every selected dimension and link the shared library. Returns its path."""
+    dims = list(dims) if dims is not None else selected_dims()
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in ("det_math.h", "kernels.h")]
+    root_hdr = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "mcmc_hip.h")
+    wk = os.path.join(CSRC, "walker_kernels.hip")
+    capi = os.path.join(CSRC, "capi.hip")
+    tasks = []
+    for d in dims:
+        stamp = _digest([wk] + hdrs, extra=f"{d}|{' '.join(FLAGS)}")
+        tasks.append((wk, os.path.join(OBJ, f"walker_d{d}.o"), [f"-DMCMC_D={d}"], stamp))
+    tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
+                  _digest([capi, root_hdr] + hdrs, extra=" ".join(FLAGS))))
+    jobs = jobs or min(len(tasks), os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        rebuilt = list(ex.map(lambda t: _compile(*t), tasks))
+    objs = [t[1] for t in tasks]
+    link_stamp = _digest(objs)
+    stamp_file = LIB + ".stamp"
+    need_link = any(rebuilt) or not os.path.exists(LIB)
+    if not need_link and os.path.exists(stamp_file):
+        with open(stamp_file) as f:
+            need_link = f.read() != link_stamp
+    if need_link:
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"link failed: {' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        with open(stamp_file, "w") as f:
+            f.write(link_stamp)
+    if verbose:
+        print(f"[cobaya_amd.build] {LIB}: dims {dims[0]}..{dims[-1]} ({len(dims)}), "
+              f"{sum(rebuilt)} objects rebuilt")
+    return LIB
+
+
+if __name__ == "__main__":
+    build()
+    sys.exit(0)

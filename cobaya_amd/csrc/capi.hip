@@ -1,0 +1,907 @@
+// libmcmc_hip.so: engine context, host-side small dense linear algebra and the C ABI
+// declared in include/mcmc_hip.h.  gfx950 only; no CPU fallback.
+#include "../../include/mcmc_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+MCMC_DECLARE_DIM(1) MCMC_DECLARE_DIM(2) MCMC_DECLARE_DIM(3) MCMC_DECLARE_DIM(4)
+MCMC_DECLARE_DIM(5) MCMC_DECLARE_DIM(6) MCMC_DECLARE_DIM(7) MCMC_DECLARE_DIM(8)
+MCMC_DECLARE_DIM(9) MCMC_DECLARE_DIM(10) MCMC_DECLARE_DIM(11) MCMC_DECLARE_DIM(12)
+MCMC_DECLARE_DIM(13) MCMC_DECLARE_DIM(14) MCMC_DECLARE_DIM(15) MCMC_DECLARE_DIM(16)
+MCMC_DECLARE_DIM(17) MCMC_DECLARE_DIM(18) MCMC_DECLARE_DIM(19) MCMC_DECLARE_DIM(20)
+MCMC_DECLARE_DIM(21) MCMC_DECLARE_DIM(22) MCMC_DECLARE_DIM(23) MCMC_DECLARE_DIM(24)
+MCMC_DECLARE_DIM(25) MCMC_DECLARE_DIM(26) MCMC_DECLARE_DIM(27) MCMC_DECLARE_DIM(28)
+MCMC_DECLARE_DIM(29) MCMC_DECLARE_DIM(30) MCMC_DECLARE_DIM(31) MCMC_DECLARE_DIM(32)
+
+namespace {
+
+using mcmc::ConstLayout;
+using mcmc::DimKernels;
+
+const DimKernels* kernels_for_dim(int d)
+{
+    typedef const DimKernels* (*getter)();
+    static const getter table[33] = {
+        nullptr,          mcmc_hip_dim_1,  mcmc_hip_dim_2,  mcmc_hip_dim_3,  mcmc_hip_dim_4,
+        mcmc_hip_dim_5,   mcmc_hip_dim_6,  mcmc_hip_dim_7,  mcmc_hip_dim_8,  mcmc_hip_dim_9,
+        mcmc_hip_dim_10,  mcmc_hip_dim_11, mcmc_hip_dim_12, mcmc_hip_dim_13, mcmc_hip_dim_14,
+        mcmc_hip_dim_15,  mcmc_hip_dim_16, mcmc_hip_dim_17, mcmc_hip_dim_18, mcmc_hip_dim_19,
+        mcmc_hip_dim_20,  mcmc_hip_dim_21, mcmc_hip_dim_22, mcmc_hip_dim_23, mcmc_hip_dim_24,
+        mcmc_hip_dim_25,  mcmc_hip_dim_26, mcmc_hip_dim_27, mcmc_hip_dim_28, mcmc_hip_dim_29,
+        mcmc_hip_dim_30,  mcmc_hip_dim_31, mcmc_hip_dim_32};
+    if (d < 1 || d > 32 || table[d] == nullptr) return nullptr;
+    return table[d]();
+}
+
+std::string g_create_error;
+
+// ------------------------------------------------------------------ small dense LA (host)
+// lower Cholesky, row-major; false if not positive definite (np.linalg.cholesky semantics)
+bool cholesky_lower(int n, const double* A, double* L)
+{
+    std::fill(L, L + (size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        const double ljj = std::sqrt(s);
+        L[j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = A[i * n + j];
+            for (int k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = t / ljj;
+        }
+    }
+    return true;
+}
+
+// inverse of a lower-triangular matrix (LAPACK dtrtri semantics, functions.py:81-89)
+void tri_inverse_lower(int n, const double* L, double* Li)
+{
+    std::fill(Li, Li + (size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        Li[j * n + j] = 1.0 / L[j * n + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s += L[i * n + k] * Li[k * n + j];
+            Li[i * n + j] = -s / L[i * n + i];
+        }
+    }
+}
+
+// eigenvalues of a symmetric matrix by cyclic Jacobi rotations (A destroyed)
+void jacobi_eigenvalues(int n, double* A, double* ev)
+{
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = 0; j < i; ++j) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-32 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) /
+                                 (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) ev[i] = A[i * n + i];
+}
+
+// np.allclose(A.T, A) (rtol 1e-5, atol 1e-8), proposal.py:243
+bool is_symmetric(int n, const double* A)
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const double a = A[j * n + i], b = A[i * n + j];
+            if (!(std::fabs(a - b) <= 1e-8 + 1e-5 * std::fabs(b))) return false;
+        }
+    return true;
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t resize(size_t count)
+    {
+        if (count <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void**)&p, sizeof(T) * count);
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct mcmc_hip_ctx {
+    mcmc_hip_config cfg{};
+    const DimKernels* k = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int d = 0, W = 0, G = 0, gs = 0, K = -1;
+    bool have_prior = false, have_target = false, have_cov = false, have_state = false;
+    // host copies of the problem
+    std::vector<int32_t> kind, periodic;
+    std::vector<double> lo, hi, loc, scale, mls;
+    double uniform_logp = 0.0;
+    uint32_t norm_mask = 0, periodic_mask = 0;
+    std::vector<double> mean, Linv, cnorm, weight;  // Linv: [K][d*d] row-major
+    std::vector<double> cov, T;                     // proposal
+    std::vector<double> shift;                      // moment shift
+    // device
+    DevBuf<double> x, logpost, logprior, loglike, cblock, dT, V, rows, gsum, Sg, pooled, dshift;
+    DevBuf<double> ex, elp, ell, eder;
+    DevBuf<int> weight_i, prej, burn, stuck, nrows;
+    DevBuf<long long> nacc;
+    unsigned long long step = 0;
+    int64_t n_snapshots = 0;
+    // timing
+    bool timing = false;
+    struct Ev {
+        hipEvent_t a, b;
+        int kind;
+    };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[3] = {0, 0, 0};
+    int64_t n_step_launches = 0;
+};
+
+namespace {
+
+int fail(mcmc_hip_ctx* h, int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(h, MCMC_HIP_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+hipEvent_t get_event(mcmc_hip_ctx* h)
+{
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {
+    mcmc_hip_ctx* h;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(mcmc_hip_ctx* h_, int kind_) : h(h_), kind(kind_)
+    {
+        if (h->timing) {
+            a = get_event(h);
+            b = get_event(h);
+            (void)hipEventRecord(a, h->stream);
+        }
+    }
+    ~Timed()
+    {
+        if (h->timing) {
+            (void)hipEventRecord(b, h->stream);
+            h->pending.push_back({a, b, kind});
+        }
+    }
+};
+
+void resolve_timing(mcmc_hip_ctx* h)
+{
+    for (auto& e : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) h->ms[e.kind] += ms;
+        h->pool.push_back(e.a);
+        h->pool.push_back(e.b);
+    }
+    h->pending.clear();
+}
+
+int upload_constants(mcmc_hip_ctx* h)
+{
+    if (!h->have_prior || !h->have_target) return MCMC_HIP_OK;
+    const int d = h->d, K = h->K;
+    const ConstLayout cl{d, K};
+    std::vector<double> c((size_t)cl.size() + 2, 0.0);
+    for (int i = 0; i < d; ++i) {
+        c[cl.lo() + i] = h->lo[i];
+        c[cl.hi() + i] = h->hi[i];
+        c[cl.loc() + i] = h->loc[i];
+        c[cl.scale() + i] = h->scale[i];
+        c[cl.mls() + i] = h->mls[i];
+    }
+    for (int k = 0; k < K; ++k) {
+        for (int i = 0; i < d; ++i) c[cl.mean(k) + i] = h->mean[(size_t)k * d + i];
+        c[cl.cnorm() + k] = h->cnorm[k];
+        c[cl.weight() + k] = h->weight[k];
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i <= j; ++i)
+                c[cl.linv(k) + mcmc::tri_row_off(j) + i] = h->Linv[((size_t)k * d + j) * d + i];
+    }
+    HIP_TRY(h, h->cblock.resize(c.size()));
+    HIP_TRY(h, hipMemcpyAsync(h->cblock.p, c.data(), sizeof(double) * c.size(),
+                              hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MCMC_HIP_OK;
+}
+
+int lds_check(mcmc_hip_ctx* h)
+{
+    const ConstLayout cl{h->d, h->K};
+    const size_t lds = sizeof(double) * ((size_t)cl.size() + 2 + (size_t)h->d * h->d + 1 +
+                                         (h->K > 1 ? (size_t)h->K * h->gs : 0));
+    if (lds > 64 * 1024)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "problem constants need %zu bytes of LDS per workgroup (> 64 KiB): fewer "
+                    "mixture modes or a smaller group_size are required", lds);
+    return MCMC_HIP_OK;
+}
+
+int set_target_common(mcmc_hip_ctx* h, int K, const double* means, const double* covs,
+                      const double* weights, bool normalized)
+{
+    const int d = h->d;
+    if (K < 1 || K > mcmc::kMaxModes)
+        return fail(h, MCMC_HIP_ERR_ARG, "n_modes must be in 1..%d, got %d", mcmc::kMaxModes, K);
+    std::vector<double> L((size_t)d * d), Li((size_t)d * d);
+    h->mean.assign(means, means + (size_t)K * d);
+    h->Linv.assign((size_t)K * d * d, 0.0);
+    h->cnorm.assign(K, 0.0);
+    h->weight.assign(K, 1.0 / K);
+    for (int k = 0; k < K; ++k) {
+        const double* C = covs + (size_t)k * d * d;
+        if (!is_symmetric(d, C) || !cholesky_lower(d, C, L.data()))
+            return fail(h, MCMC_HIP_ERR_NOT_PD,
+                        "covariance of mode %d is not a symmetric positive-definite matrix", k);
+        tri_inverse_lower(d, L.data(), Li.data());
+        std::copy(Li.begin(), Li.end(), h->Linv.begin() + (size_t)k * d * d);
+        double logdet = 0.0;
+        for (int i = 0; i < d; ++i) logdet += std::log(L[i * d + i]);
+        logdet *= 2.0;
+        h->cnorm[k] = normalized ? d * std::log(2.0 * M_PI) + logdet : 0.0;
+    }
+    if (weights) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            if (!(weights[k] >= 0.0)) return fail(h, MCMC_HIP_ERR_ARG, "negative mixture weight");
+            s += weights[k];
+        }
+        if (!(s > 0.0)) return fail(h, MCMC_HIP_ERR_ARG, "mixture weights sum to zero");
+        const bool renorm = !(std::fabs(s - 1.0) <= 1e-8 + 1e-5);  // np.isclose(sum, 1)
+        for (int k = 0; k < K; ++k) h->weight[k] = renorm ? weights[k] / s : weights[k];
+    }
+    h->K = K;
+    h->have_target = true;
+    h->have_state = false;
+    int rc = lds_check(h);
+    if (rc) return rc;
+    return upload_constants(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mcmc_hip_version(void) { return "mcmc_hip 0.1 (gfx950)"; }
+
+const char* mcmc_hip_last_error(const mcmc_hip_ctx* h)
+{
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int mcmc_hip_dim_supported(int d) { return kernels_for_dim(d) != nullptr; }
+
+int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
+{
+    if (!cfg || !out) return fail(nullptr, MCMC_HIP_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->d < 1) return fail(nullptr, MCMC_HIP_ERR_ARG, "d must be >= 1, got %d", cfg->d);
+    const DimKernels* k = kernels_for_dim(cfg->d);
+    if (!k)
+        return fail(nullptr, MCMC_HIP_ERR_ARG,
+                    "no kernels compiled for d=%d (this build covers the lane-per-walker "
+                    "dimensions 1..32 that were selected at build time)", cfg->d);
+    if (cfg->group_size != 64 && cfg->group_size != 128 && cfg->group_size != 256)
+        return fail(nullptr, MCMC_HIP_ERR_ARG, "group_size must be 64, 128 or 256, got %d",
+                    cfg->group_size);
+    if (cfg->n_walkers < cfg->group_size || cfg->n_walkers % cfg->group_size)
+        return fail(nullptr, MCMC_HIP_ERR_ARG,
+                    "n_walkers (%d) must be a positive multiple of group_size (%d)",
+                    cfg->n_walkers, cfg->group_size);
+    if (cfg->walker_offset % (uint32_t)cfg->group_size)
+        return fail(nullptr, MCMC_HIP_ERR_ARG, "walker_offset must be a multiple of group_size");
+    if (!(cfg->temperature > 0) || !(cfg->proposal_scale > 0))
+        return fail(nullptr, MCMC_HIP_ERR_ARG, "temperature and proposal_scale must be > 0");
+    if (cfg->emit_capacity < 0 || cfg->burn_in < 0)
+        return fail(nullptr, MCMC_HIP_ERR_ARG, "emit_capacity and burn_in must be >= 0");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, MCMC_HIP_ERR_DEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MCMC_HIP_ERR_ARG, "device %d out of range (0..%d)", cfg->device,
+                    ndev - 1);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, MCMC_HIP_ERR_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MCMC_HIP_ERR_DEVICE,
+                    "device %d is %s; this library is built for gfx950 only", cfg->device,
+                    prop.gcnArchName);
+    if (hipSetDevice(cfg->device) != hipSuccess)
+        return fail(nullptr, MCMC_HIP_ERR_DEVICE, "hipSetDevice(%d) failed", cfg->device);
+    mcmc_hip_ctx* h = new mcmc_hip_ctx();
+    h->cfg = *cfg;
+    h->k = k;
+    h->d = cfg->d;
+    h->W = cfg->n_walkers;
+    h->gs = cfg->group_size;
+    h->G = h->W / h->gs;
+    h->shift.assign(h->d, 0.0);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, MCMC_HIP_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    const size_t W = h->W, d = h->d, G = h->G, np = d * (d + 1) / 2;
+    hipError_t r = hipSuccess;
+    auto acc = [&](hipError_t x) { if (r == hipSuccess) r = x; };
+    acc(h->x.resize(W * d)); acc(h->logpost.resize(W)); acc(h->logprior.resize(W));
+    acc(h->loglike.resize(W)); acc(h->weight_i.resize(W)); acc(h->prej.resize(W));
+    acc(h->burn.resize(W)); acc(h->nacc.resize(W)); acc(h->stuck.resize(1));
+    acc(h->dT.resize(d * d)); acc(h->gsum.resize(G * d)); acc(h->Sg.resize(G * np));
+    acc(h->pooled.resize(np)); acc(h->dshift.resize(d));
+    if (cfg->emit_capacity > 0) {
+        acc(h->rows.resize(W * (size_t)cfg->emit_capacity * (d + 4)));
+        acc(h->nrows.resize(W));
+    }
+    if (r == hipSuccess) r = hipMemsetAsync(h->gsum.p, 0, sizeof(double) * G * d, h->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, h->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(h->dshift.p, 0, sizeof(double) * d, h->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(h->stuck.p, 0, sizeof(int), h->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(h->stream);
+    if (r != hipSuccess) {
+        fail(nullptr, MCMC_HIP_ERR_DEVICE, "device allocation failed: %s", hipGetErrorString(r));
+        mcmc_hip_destroy(h);
+        return MCMC_HIP_ERR_DEVICE;
+    }
+    *out = h;
+    return MCMC_HIP_OK;
+}
+
+void mcmc_hip_destroy(mcmc_hip_ctx* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    resolve_timing(h);
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    h->x.release(); h->logpost.release(); h->logprior.release(); h->loglike.release();
+    h->cblock.release(); h->dT.release(); h->V.release(); h->rows.release(); h->gsum.release();
+    h->Sg.release(); h->pooled.release(); h->dshift.release(); h->ex.release(); h->elp.release();
+    h->ell.release(); h->eder.release(); h->weight_i.release(); h->prej.release();
+    h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, const double* b,
+                       const int32_t* periodic)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!kind || !a || !b) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    const int d = h->d;
+    const double inf = std::numeric_limits<double>::infinity();
+    h->kind.assign(kind, kind + d);
+    h->periodic.assign(d, 0);
+    h->lo.assign(d, -inf); h->hi.assign(d, inf);
+    h->loc.assign(d, 0.0); h->scale.assign(d, 1.0); h->mls.assign(d, 0.0);
+    h->norm_mask = h->periodic_mask = 0;
+    double ulp = 0.0;
+    for (int i = 0; i < d; ++i) {
+        if (kind[i] == 0) {
+            if (!(b[i] > a[i]) || !std::isfinite(a[i]) || !std::isfinite(b[i]))
+                return fail(h, MCMC_HIP_ERR_ARG, "uniform prior %d needs finite min < max", i);
+            h->lo[i] = a[i]; h->hi[i] = b[i];
+            ulp += std::log(b[i] - a[i]);
+            if (periodic && periodic[i]) { h->periodic[i] = 1; h->periodic_mask |= 1u << i; }
+        } else if (kind[i] == 1) {
+            if (!(b[i] > 0) || !std::isfinite(a[i]) || !std::isfinite(b[i]))
+                return fail(h, MCMC_HIP_ERR_ARG, "normal prior %d needs finite loc, scale > 0", i);
+            if (periodic && periodic[i])
+                return fail(h, MCMC_HIP_ERR_ARG,
+                            "parameter %d cannot be periodic if it is not bounded", i);
+            h->loc[i] = a[i]; h->scale[i] = b[i];
+            h->mls[i] = -std::log(b[i]) - std::log(2.0 * M_PI) / 2.0;  // tools.py:723
+            h->norm_mask |= 1u << i;
+        } else {
+            return fail(h, MCMC_HIP_ERR_ARG,
+                        "prior kind %d of parameter %d is not supported (0 uniform, 1 norm)",
+                        kind[i], i);
+        }
+    }
+    h->uniform_logp = -ulp;  // prior.py:528-533
+    h->have_prior = true;
+    h->have_state = false;
+    return upload_constants(h);
+}
+
+int mcmc_hip_set_target_gaussian_mixture(mcmc_hip_ctx* h, int32_t n_modes, const double* means,
+                                         const double* covs, const double* weights)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!means || !covs) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    return set_target_common(h, n_modes, means, covs, weights, true);
+}
+
+int mcmc_hip_set_target_gaussian(mcmc_hip_ctx* h, const double* mean, const double* cov,
+                                 int32_t normalized)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!mean || !cov) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    return set_target_common(h, 1, mean, cov, nullptr, normalized != 0);
+}
+
+int mcmc_hip_set_target_one(mcmc_hip_ctx* h)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    h->K = 0;
+    h->mean.clear(); h->Linv.clear(); h->cnorm.clear(); h->weight.clear();
+    h->have_target = true;
+    h->have_state = false;
+    return upload_constants(h);
+}
+
+int mcmc_hip_get_derived_constants(const mcmc_hip_ctx* h, double* uniform_logp, double* mls,
+                                   double* Linv, double* cnorm, double* weight)
+{
+    if (!h || !h->have_prior || !h->have_target) return MCMC_HIP_ERR_STATE;
+    if (uniform_logp) *uniform_logp = h->uniform_logp;
+    if (mls) std::copy(h->mls.begin(), h->mls.end(), mls);
+    if (Linv) std::copy(h->Linv.begin(), h->Linv.end(), Linv);
+    if (cnorm) std::copy(h->cnorm.begin(), h->cnorm.end(), cnorm);
+    if (weight) std::copy(h->weight.begin(), h->weight.end(), weight);
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!cov) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    const int d = h->d;
+    std::vector<double> corr((size_t)d * d), L((size_t)d * d), sd(d);
+    if (!is_symmetric(d, cov))
+        return fail(h, MCMC_HIP_ERR_NOT_PD,
+                    "The given covmat is not a positive-definite, symmetric square matrix.");
+    for (int i = 0; i < d; ++i) {
+        if (!(cov[i * d + i] > 0.0) || !std::isfinite(cov[i * d + i]))
+            return fail(h, MCMC_HIP_ERR_NOT_PD,
+                        "The given covmat is not a positive-definite, symmetric square matrix.");
+        sd[i] = std::sqrt(cov[i * d + i]);
+    }
+    // tools.py:779-788: corr = cov / std / std^T with unit diagonal
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            corr[i * d + j] = (i == j) ? 1.0 : (1.0 / sd[i]) * cov[i * d + j] * (1.0 / sd[j]);
+    if (!cholesky_lower(d, corr.data(), L.data()))
+        return fail(h, MCMC_HIP_ERR_NOT_PD,
+                    "The given covmat is not a positive-definite, symmetric square matrix.");
+    h->cov.assign(cov, cov + (size_t)d * d);
+    h->T.assign((size_t)d * d, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) h->T[i * d + j] = h->cfg.proposal_scale * (sd[i] * L[i * d + j]);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // queued steps keep the old transform
+    HIP_TRY(h, hipMemcpyAsync(h->dT.p, h->T.data(), sizeof(double) * d * d, hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->have_cov = true;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_get_proposal_cov(const mcmc_hip_ctx* h, double* cov)
+{
+    if (!h || !cov || !h->have_cov) return MCMC_HIP_ERR_STATE;
+    std::copy(h->cov.begin(), h->cov.end(), cov);
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_get_proposal_transform(const mcmc_hip_ctx* h, double* T)
+{
+    if (!h || !T || !h->have_cov) return MCMC_HIP_ERR_STATE;
+    std::copy(h->T.begin(), h->T.end(), T);
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_evaluate(mcmc_hip_ctx* h, int32_t n, const double* x, double* logprior,
+                      double* loglike, double* derived)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_prior || !h->have_target)
+        return fail(h, MCMC_HIP_ERR_STATE, "set_prior and set_target_* must precede evaluate");
+    if (n <= 0 || !x || !logprior || !loglike) return fail(h, MCMC_HIP_ERR_ARG, "bad argument");
+    const size_t d = h->d, Kd = (size_t)std::max(h->K, 1) * d;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, h->ex.resize((size_t)n * d));
+    HIP_TRY(h, h->elp.resize(n));
+    HIP_TRY(h, h->ell.resize(n));
+    if (derived) HIP_TRY(h, h->eder.resize((size_t)n * Kd));
+    HIP_TRY(h, hipMemcpyAsync(h->ex.p, x, sizeof(double) * n * d, hipMemcpyHostToDevice, h->stream));
+    mcmc::EvalArgs a{};
+    a.x = h->ex.p; a.logprior = h->elp.p; a.loglike = h->ell.p;
+    a.derived = (derived && h->K > 0) ? h->eder.p : nullptr;
+    a.cblock = h->cblock.p; a.n = n; a.n_modes = h->K;
+    a.norm_mask = h->norm_mask; a.periodic_mask = h->periodic_mask;
+    a.uniform_logp = h->uniform_logp;
+    HIP_TRY(h, h->k->evaluate(a, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(logprior, h->elp.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(loglike, h->ell.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    if (a.derived)
+        HIP_TRY(h, hipMemcpyAsync(derived, h->eder.p, sizeof(double) * n * Kd, hipMemcpyDeviceToHost,
+                                  h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_prior || !h->have_target)
+        return fail(h, MCMC_HIP_ERR_STATE, "set_prior and set_target_* must precede set_state");
+    if (!x) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    const size_t W = h->W, d = h->d;
+    std::vector<double> lp(W), ll(W), lpost(W), xt(W * d);
+    int rc = mcmc_hip_evaluate(h, (int)W, x, lp.data(), ll.data(), nullptr);
+    if (rc) return rc;
+    int bad = 0;
+    for (size_t w = 0; w < W; ++w) {
+        lpost[w] = lp[w] + ll[w];
+        if (!std::isfinite(lpost[w])) ++bad;
+        for (size_t i = 0; i < d; ++i) xt[i * W + w] = x[w * d + i];
+    }
+    if (n_bad) *n_bad = bad;
+    if (bad)
+        return fail(h, MCMC_HIP_ERR_ARG, "%d initial points have a non-finite log-posterior", bad);
+    std::vector<int> ones(W, 1), zeros(W, 0), burn(W, h->cfg.burn_in + 1);  // mcmc.py:265
+    std::vector<long long> z64(W, 0);
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->x.p, xt.data(), sizeof(double) * W * d, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->logpost.p, lpost.data(), sizeof(double) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->logprior.p, lp.data(), sizeof(double) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->loglike.p, ll.data(), sizeof(double) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->weight_i.p, ones.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->prej.p, zeros.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->burn.p, burn.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->nacc.p, z64.data(), sizeof(long long) * W, hipMemcpyHostToDevice, s));
+    if (h->nrows.p)
+        HIP_TRY(h, hipMemcpyAsync(h->nrows.p, zeros.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemsetAsync(h->stuck.p, 0, sizeof(int), s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    h->step = 0;
+    h->have_state = true;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
+                       double* loglike, int32_t* weight)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state: call set_state first");
+    const size_t W = h->W, d = h->d;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    std::vector<double> xt;
+    if (x) {
+        xt.resize(W * d);
+        HIP_TRY(h, hipMemcpyAsync(xt.data(), h->x.p, sizeof(double) * W * d, hipMemcpyDeviceToHost, s));
+    }
+    if (logpost) HIP_TRY(h, hipMemcpyAsync(logpost, h->logpost.p, sizeof(double) * W, hipMemcpyDeviceToHost, s));
+    if (logprior) HIP_TRY(h, hipMemcpyAsync(logprior, h->logprior.p, sizeof(double) * W, hipMemcpyDeviceToHost, s));
+    if (loglike) HIP_TRY(h, hipMemcpyAsync(loglike, h->loglike.p, sizeof(double) * W, hipMemcpyDeviceToHost, s));
+    if (weight) HIP_TRY(h, hipMemcpyAsync(weight, h->weight_i.p, sizeof(int) * W, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (x)
+        for (size_t w = 0; w < W; ++w)
+            for (size_t i = 0; i < d; ++i) x[w * d + i] = xt[i * W + w];
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_state || !h->have_cov)
+        return fail(h, MCMC_HIP_ERR_STATE, "set_state and set_proposal_cov must precede step");
+    if (n_steps <= 0) return fail(h, MCMC_HIP_ERR_ARG, "n_steps must be > 0");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const unsigned long long d = (unsigned long long)h->d;
+    const size_t dd = (size_t)h->d * h->d;
+    // directions buffer: at most ~256 MiB of cycles per launch
+    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    int left = n_steps;
+    while (left > 0) {
+        const unsigned long long c0 = h->step / d;
+        const unsigned long long room = (c0 + (unsigned long long)max_cyc) * d - h->step;
+        const int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        const unsigned long long c1 = (h->step + (unsigned long long)n - 1) / d;
+        const int ncyc = (int)(c1 - c0 + 1);
+        HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+        {
+            Timed t(h, 1);
+            mcmc::BasisArgs b{};
+            b.T = h->dT.p; b.V = h->V.p;
+            b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+            b.cycle0 = (uint32_t)c0;
+            b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+            b.ncyc = ncyc;
+            HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+        }
+        {
+            Timed t(h, 0);
+            mcmc::StepArgs a{};
+            a.x = h->x.p; a.logpost = h->logpost.p; a.logprior = h->logprior.p;
+            a.loglike = h->loglike.p; a.weight = h->weight_i.p; a.prior_rej = h->prej.p;
+            a.burn_left = h->burn.p; a.n_accept = h->nacc.p; a.stuck = h->stuck.p;
+            a.rows = h->rows.p; a.n_rows = h->nrows.p; a.row_cap = h->cfg.emit_capacity;
+            a.cblock = h->cblock.p; a.V = h->V.p; a.W = h->W; a.n_modes = h->K;
+            a.norm_mask = h->norm_mask; a.periodic_mask = h->periodic_mask;
+            a.walker0 = h->cfg.walker_offset;
+            a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32);
+            a.step0 = h->step; a.n_steps = n; a.ncyc = ncyc;
+            a.uniform_logp = h->uniform_logp; a.temperature = h->cfg.temperature;
+            a.max_tries = h->cfg.max_tries;
+            HIP_TRY(h, h->k->step(a, h->gs, h->stream));
+            h->n_step_launches += 1;
+        }
+        h->step += (unsigned long long)n;
+        left -= n;
+    }
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_sync(mcmc_hip_ctx* h)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    resolve_timing(h);
+    int stuck = 0;
+    HIP_TRY(h, hipMemcpy(&stuck, h->stuck.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (stuck)
+        return fail(h, MCMC_HIP_ERR_STUCK,
+                    "The chain has been stuck for %g attempts (walker %d), stopping sampling.",
+                    h->cfg.max_tries, stuck - 1);
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4])
+{
+    if (!h || !counters) return MCMC_HIP_ERR_ARG;
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<long long> na(h->W);
+    HIP_TRY(h, hipMemcpy(na.data(), h->nacc.p, sizeof(long long) * h->W, hipMemcpyDeviceToHost));
+    int64_t tot = 0;
+    for (auto v : na) tot += v;
+    int stuck = 0;
+    HIP_TRY(h, hipMemcpy(&stuck, h->stuck.p, sizeof(int), hipMemcpyDeviceToHost));
+    int64_t dropped = 0;
+    if (h->nrows.p) {
+        std::vector<int> nr(h->W);
+        HIP_TRY(h, hipMemcpy(nr.data(), h->nrows.p, sizeof(int) * h->W, hipMemcpyDeviceToHost));
+        for (auto v : nr) dropped += std::max(0, v - h->cfg.emit_capacity);
+    }
+    counters[0] = (int64_t)h->step;
+    counters[1] = tot;
+    counters[2] = stuck;
+    counters[3] = dropped;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int64_t* n_rows)
+{
+    if (!h || !n_rows) return MCMC_HIP_ERR_ARG;
+    *n_rows = 0;
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    if (h->cfg.emit_capacity <= 0) return MCMC_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t W = h->W, d = h->d, cap = h->cfg.emit_capacity, rl = d + 4;
+    std::vector<int> nr(W);
+    HIP_TRY(h, hipMemcpy(nr.data(), h->nrows.p, sizeof(int) * W, hipMemcpyDeviceToHost));
+    int64_t total = 0;
+    for (size_t w = 0; w < W; ++w) total += std::min<int>(nr[w], (int)cap);
+    *n_rows = total;
+    if (!rows) return MCMC_HIP_OK;  // size query
+    if (cap_rows < total)
+        return fail(h, MCMC_HIP_ERR_ARG, "drain buffer holds %lld rows, %lld are pending",
+                    (long long)cap_rows, (long long)total);
+    std::vector<double> buf(W * cap * rl);
+    HIP_TRY(h, hipMemcpy(buf.data(), h->rows.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (size_t w = 0; w < W; ++w) {
+        const int n = std::min<int>(nr[w], (int)cap);
+        for (int r = 0; r < n; ++r) {
+            const double* src = buf.data() + (w * cap + r) * rl;
+            double* dst = rows + o * (d + 5);
+            dst[0] = (double)(h->cfg.walker_offset + w);
+            std::copy(src, src + rl, dst + 1);
+            ++o;
+        }
+    }
+    HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_moment_shift(mcmc_hip_ctx* h, const double* shift)
+{
+    if (!h || !shift) return MCMC_HIP_ERR_ARG;
+    if (h->n_snapshots != 0)
+        return fail(h, MCMC_HIP_ERR_STATE, "the moment shift can only change right after a reset");
+    h->shift.assign(shift, shift + h->d);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpyAsync(h->dshift.p, h->shift.data(), sizeof(double) * h->d,
+                              hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_accumulate_moments(mcmc_hip_ctx* h)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    Timed t(h, 2);
+    mcmc::MomentArgs a{};
+    a.x = h->x.p; a.shift = h->dshift.p; a.group_sum = h->gsum.p; a.Sg = h->Sg.p;
+    a.pooled = h->pooled.p; a.W = h->W; a.G = h->G;
+    HIP_TRY(h, h->k->moments(a, h->gs, h->stream));
+    h->n_snapshots += 1;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
+                          double* pooled_S, int32_t reset)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    resolve_timing(h);
+    const size_t d = h->d, G = h->G, np = d * (d + 1) / 2;
+    if (n_snapshots) *n_snapshots = h->n_snapshots;
+    if (group_sum)
+        HIP_TRY(h, hipMemcpy(group_sum, h->gsum.p, sizeof(double) * G * d, hipMemcpyDeviceToHost));
+    if (pooled_S) {
+        std::vector<double> p(np);
+        HIP_TRY(h, hipMemcpy(p.data(), h->pooled.p, sizeof(double) * np, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < d; ++i)
+            for (size_t j = 0; j <= i; ++j)
+                pooled_S[i * d + j] = pooled_S[j * d + i] = p[i * (i + 1) / 2 + j];
+    }
+    if (reset) {
+        HIP_TRY(h, hipMemset(h->gsum.p, 0, sizeof(double) * G * d));
+        HIP_TRY(h, hipMemset(h->pooled.p, 0, sizeof(double) * np));
+        h->n_snapshots = 0;
+    }
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double* sum_Ncov,
+                          const double* sum_mean, const double* sum_mm, double* Rminus1,
+                          double* mean_of_covs)
+{
+    if (d < 1 || !sum_Ncov || !sum_mean || !sum_mm || !Rminus1 || !mean_of_covs)
+        return MCMC_HIP_ERR_ARG;
+    if (!(n_chains >= 2) || !(sum_N > 0)) return MCMC_HIP_ERR_ARG;
+    const size_t n = d;
+    std::vector<double> W(n * n), B(n * n), sd(n), nW(n * n), cB(n * n), L(n * n), Li(n * n),
+        M(n * n), tmp(n * n), ev(n);
+    for (size_t i = 0; i < n * n; ++i) W[i] = mean_of_covs[i] = sum_Ncov[i] / sum_N;  // mcmc.py:856
+    // np.cov(means.T): (sum m m^T - n mbar mbar^T) / (n - 1)                        mcmc.py:860
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j)
+            B[i * n + j] = (sum_mm[i * n + j] - sum_mean[i] * sum_mean[j] / n_chains) /
+                           (n_chains - 1.0);
+    for (size_t i = 0; i < n; ++i) {
+        if (!(B[i * n + i] > 0.0)) return MCMC_HIP_ERR_NOT_PD;
+        sd[i] = std::sqrt(B[i * n + i]);
+    }
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) {
+            cB[i * n + j] = B[i * n + j] / sd[i] / sd[j];   // mcmc.py:865
+            nW[i * n + j] = W[i * n + j] / sd[i] / sd[j];   // mcmc.py:866
+        }
+    if (!cholesky_lower(d, nW.data(), L.data())) return MCMC_HIP_ERR_NOT_PD;  // mcmc.py:871
+    tri_inverse_lower(d, L.data(), Li.data());
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (size_t k = 0; k < n; ++k) s += Li[i * n + k] * cB[k * n + j];
+            tmp[i * n + j] = s;
+        }
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (size_t k = 0; k < n; ++k) s += tmp[i * n + k] * Li[j * n + k];
+            M[i * n + j] = s;
+        }
+    for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < i; ++j) M[i * n + j] = M[j * n + i] = 0.5 * (M[i * n + j] + M[j * n + i]);
+    jacobi_eigenvalues(d, M.data(), ev.data());  // mcmc.py:881
+    double r = 0.0;
+    for (size_t i = 0; i < n; ++i) r = std::max(r, std::fabs(ev[i]));
+    if (!std::isfinite(r)) return MCMC_HIP_ERR_NOT_PD;
+    *Rminus1 = r;  // mcmc.py:889
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    h->timing = on != 0;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset)
+{
+    if (!h || !ms) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    resolve_timing(h);
+    for (int i = 0; i < 3; ++i) ms[i] = h->ms[i];
+    if (n_step_launches) *n_step_launches = h->n_step_launches;
+    if (reset) {
+        h->ms[0] = h->ms[1] = h->ms[2] = 0.0;
+        h->n_step_launches = 0;
+    }
+    return MCMC_HIP_OK;
+}
+
+}  // extern "C"

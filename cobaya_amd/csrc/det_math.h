@@ -1,0 +1,130 @@
+// Fixed-operation-order device math for the mcmc_hip kernels (gfx950).
+//
+// Everything the walker kernels need beyond IEEE + - * / sqrt fma: the Philox4x32-10
+// counter-based generator (the algorithm rocRAND ships as ROCRAND_RNG_PSEUDO_PHILOX4_32_10),
+// exact 52-bit uniforms, and log / exp / sincos(2 pi u) with every operation spelled out so
+// that the result is a pure function of the input bits (compiled with -ffp-contract=off;
+// fused operations are written as fma()).  DESIGN.md "Ensemble specification" is the
+// normative text; tests/test_gpu_parity.py checks these bit for bit against the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcmc {
+
+constexpr uint32_t kStreamStep = 0u;
+constexpr uint32_t kStreamBasis = 1u;
+constexpr uint32_t kBranchExp24 = 5536481u;  // floor(0.33 * 2^24), proposal.py:79
+
+struct u32x4 {
+    uint32_t w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0,
+                                               uint32_t c1, uint32_t c2, uint32_t c3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// u = (2k+1) 2^-53 for k < 2^52, built without an int->fp conversion:
+// [1 + k 2^-52] - 1 is exact, adding 2^-53 lands on an odd multiple of 2^-53 below 1.
+__device__ __forceinline__ double u52(uint64_t k)
+{
+    return (__longlong_as_double((long long)(0x3FF0000000000000ull | k)) - 1.0) + 0x1p-53;
+}
+
+// ln(x), x a positive normal double (fdlibm e_log.c reduction + minimax polynomial)
+__device__ __forceinline__ double dlog(double x)
+{
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                     Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                     Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                     Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(b >> 32);
+    int k = (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    const uint64_t nb = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (b & 0xffffffffull);
+    k += (int)(i >> 20);
+    const double f = __longlong_as_double((long long)nb) - 1.0;
+    const double dk = (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+// exp(x) for x <= 0; x < -708 -> 0 (fdlibm e_exp.c reduction + polynomial)
+__device__ __forceinline__ double dexp(double x)
+{
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                     invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                     P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                     P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (!(x >= -708.0)) return 0.0;
+    const double kf = rint(x * invln2);
+    const double hi = fma(-kf, ln2_hi, x);
+    const double lo = kf * ln2_lo;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1);
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const int k = (int)kf;
+    return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
+}
+
+__device__ __forceinline__ double ksin(double x)
+{
+    constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                     S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                     S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x;
+    const double v = z * x;
+    const double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    return fma(v, fma(z, r, S1), x);
+}
+
+__device__ __forceinline__ double kcos(double x)
+{
+    constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                     C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                     C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    return 1.0 - (0.5 * z - z * r);
+}
+
+// (sin, cos)(2 pi u), u = (2k+1) 2^-53
+__device__ __forceinline__ void sincos2pi(uint64_t k, double& sn, double& cs)
+{
+    constexpr double PIO4 = 7.85398163397448278999e-01;
+    const unsigned o = (unsigned)(k >> 49);
+    const uint64_t rem = k & ((1ull << 49) - 1);
+    // (2 rem + 1) 2^-50 = [1 + (2 rem + 1) 2^-52 ... ] built exactly like u52
+    double phi = (__longlong_as_double((long long)(0x3FF0000000000000ull | (rem << 3) | 4ull)) -
+                  1.0);
+    if (o & 1u) phi = 1.0 - phi;
+    const double a = phi * PIO4;
+    const double s = ksin(a), c = kcos(a);
+    const bool swap = ((o + 1u) & 2u) != 0u;           // octants 1,2,5,6
+    const double ss = swap ? c : s, cc = swap ? s : c;
+    sn = (o & 4u) ? -ss : ss;                           // octants 4..7
+    cs = ((o + 2u) & 4u) ? -cc : cc;                    // octants 2..5
+}
+
+}  // namespace mcmc

@@ -1,0 +1,111 @@
+// Host/device shared declarations for the mcmc_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcmc {
+
+constexpr int kMaxDimLane = 32;   // lane-per-walker kernels: d <= 32 (state in VGPRs)
+constexpr int kMaxModes = 16;
+
+// Packed lower-triangular storage with rows padded to an even number of doubles so that
+// every row starts 16-byte aligned (ds_read_b128-able): row j holds i = 0..j.
+__host__ __device__ constexpr int tri_row_off(int j)
+{
+    int o = 0;
+    for (int r = 0; r < j; ++r) o += (r + 2) & ~1;
+    return o;
+}
+__host__ __device__ constexpr int tri_size(int d) { return tri_row_off(d); }
+
+// Constant block (doubles), identical in HBM and in LDS:
+//   lo[d] hi[d] loc[d] scale[d] mls[d] | per mode k: mean[d] | cnorm[K] weight[K] |
+//   per mode k: Linv packed (tri_size(d))
+struct ConstLayout {
+    int d, K;
+    __host__ __device__ int lo() const { return 0; }
+    __host__ __device__ int hi() const { return d; }
+    __host__ __device__ int loc() const { return 2 * d; }
+    __host__ __device__ int scale() const { return 3 * d; }
+    __host__ __device__ int mls() const { return 4 * d; }
+    __host__ __device__ int mean(int k) const { return 5 * d + k * d; }
+    __host__ __device__ int cnorm() const { return 5 * d + K * d; }
+    __host__ __device__ int weight() const { return cnorm() + K; }
+    __host__ __device__ int linv(int k) const
+    {
+        return ((weight() + K + 1) & ~1) + k * tri_size(d);
+    }
+    __host__ __device__ int size() const { return linv(K); }
+};
+
+struct StepArgs {
+    // walker state (HBM): x is dimension-major [d][W] so that lane w reads x[i*W + w]
+    double* x;
+    double* logpost;
+    double* logprior;
+    double* loglike;
+    int* weight;
+    int* prior_rej;
+    int* burn_left;
+    long long* n_accept;
+    int* stuck;
+    // optional emission of accepted rows: rows[W][row_cap][d+4], n_rows[W]
+    double* rows;
+    int* n_rows;
+    int row_cap;
+    // problem
+    const double* cblock;
+    const double* V;  // [G][ncyc][d*d] direction vectors of the cycles this launch spans
+    int W;
+    int n_modes;
+    uint32_t norm_mask, periodic_mask;
+    uint32_t walker0;
+    uint32_t key0, key1;
+    unsigned long long step0;
+    int n_steps;
+    int ncyc;
+    double uniform_logp, temperature, max_tries;
+};
+
+struct BasisArgs {
+    const double* T;  // [d*d] row-major lower-triangular proposal transform (scale folded in)
+    double* V;        // [G][ncyc][d*d]
+    uint32_t group0;
+    uint32_t cycle0;
+    uint32_t key0, key1;
+    int ncyc;
+};
+
+struct EvalArgs {
+    const double* x;  // [n][d] point-major
+    double* logprior;
+    double* loglike;
+    double* derived;  // [n][K*d] or null
+    const double* cblock;
+    int n;
+    int n_modes;
+    uint32_t norm_mask, periodic_mask;
+    double uniform_logp;
+};
+
+struct MomentArgs {
+    const double* x;    // [d][W]
+    const double* shift;  // [d] subtracted before accumulating (conditioning)
+    double* group_sum;  // [G][d]   accumulated
+    double* Sg;         // [G][npairs] scratch (this call)
+    double* pooled;     // [npairs] accumulated (lower triangle, i>=j, index i(i+1)/2+j)
+    int W;
+    int G;
+};
+
+// Per-dimension launchers (one translation unit per d, see walker_kernels.hip).
+struct DimKernels {
+    hipError_t (*step)(const StepArgs&, int group_size, hipStream_t);
+    hipError_t (*basis)(const BasisArgs&, int n_groups, hipStream_t);
+    hipError_t (*evaluate)(const EvalArgs&, hipStream_t);
+    hipError_t (*moments)(const MomentArgs&, int group_size, hipStream_t);
+};
+
+}  // namespace mcmc
+
+#define MCMC_DECLARE_DIM(D) extern "C" const mcmc::DimKernels* mcmc_hip_dim_##D() __attribute__((weak));

@@ -1,0 +1,455 @@
+// Lane-per-walker Metropolis kernels for one compile-time dimension MCMC_D (gfx950).
+//
+// One wavefront lane owns one walker: its parameter vector x[D] and trial t[D] live in
+// VGPRs (all loops over D are fully unrolled), the cycle's proposal directions V, the
+// inverse-Cholesky whitening rows, means and prior bounds are staged once in LDS and read
+// as wave-uniform broadcasts, and n_steps Metropolis steps are fused into one launch so
+// that the state crosses HBM once per launch (coalesced, dimension-major).
+//
+// Restates (paths relative to the reference checkout):
+//   cobaya/samplers/mcmc/mcmc.py:545-562 (step) 670-683 (accept) 685-748 (bookkeeping)
+//   cobaya/samplers/mcmc/proposal.py:59-82,222-224 ; cobaya/functions.py:35-61 (Haar basis)
+//   cobaya/prior.py:658-676,733-763 ; cobaya/tools.py:720-729
+//   cobaya/likelihoods/gaussian_mixture/gaussian_mixture.py:138-163 ; gaussian/gaussian.py:96-112
+//   cobaya/collection.py:926-934,970-981 (moments, as streaming sufficient statistics)
+// The arithmetic order is the one fixed in DESIGN.md "Ensemble specification".
+#include "det_math.h"
+#include "kernels.h"
+
+#ifndef MCMC_D
+#error "compile with -DMCMC_D=<dimension>"
+#endif
+
+namespace mcmc {
+namespace {
+
+constexpr int D = MCMC_D;
+constexpr int TRI = tri_size(D);
+constexpr int NPAIR = D * (D + 1) / 2;
+
+// ---------------------------------------------------------------- log-posterior of a point
+// Single-mode / `one` (K <= 1) body: prior support test, separable prior, triangular
+// whitening y = L^-1 (t - mu) and chi2 = |y|^2 as fma chains in ascending index order.
+template <bool DERIVED>
+__device__ __forceinline__ double mode_logpdf(const double (&t)[D], const double* __restrict__ mu,
+                                              const double* __restrict__ Lk, double cnorm,
+                                              double* derived)
+{
+    double dev[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) dev[i] = t[i] - mu[i];
+    // Rows are walked RB at a time so that RB independent fma chains are in flight (one wave
+    // per SIMD has no other latency cover); each chain still runs i = 0..j in order.
+    constexpr int RB = 4;
+    double y[D];
+#pragma unroll
+    for (int jb = 0; jb < D; jb += RB) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (jb + r < D) y[jb + r] = 0.0;
+#pragma unroll
+        for (int i = 0; i < jb + RB; ++i) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (jb + r < D && i <= jb + r)
+                    y[jb + r] = fma(Lk[tri_row_off(jb + r) + i], dev[i], y[jb + r]);
+        }
+    }
+    double chi2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (DERIVED) derived[j] = y[j];
+        chi2 = fma(y[j], y[j], chi2);
+    }
+    return -0.5 * (cnorm + chi2);
+}
+
+template <bool MULTI, bool DERIVED, bool GENERAL>
+__device__ __forceinline__ void eval_point(const double (&t)[D], const double* __restrict__ sC,
+                                           const ConstLayout& cl, uint32_t norm_mask,
+                                           double uniform_logp, double* __restrict__ sA,
+                                           int astride, bool& inb, double& lp, double& ll,
+                                           double* derived)
+{
+    bool in = true;
+#pragma unroll
+    for (int i = 0; i < D; ++i) in = in & (t[i] <= sC[cl.hi() + i]) & (t[i] >= sC[cl.lo() + i]);
+    inb = in;
+    double s = 0.0;
+    if (GENERAL && norm_mask) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if ((norm_mask >> i) & 1u) {
+                const double q = (t[i] - sC[cl.loc() + i]) / sC[cl.scale() + i];
+                s = s + fma(-0.5 * q, q, sC[cl.mls() + i]);
+            }
+    }
+    lp = uniform_logp + s;
+    if (!MULTI) {
+        if (cl.K == 0) {
+            ll = 0.0;
+        } else {
+            ll = mode_logpdf<DERIVED>(t, sC + cl.mean(0), sC + cl.linv(0), sC[cl.cnorm()], derived);
+        }
+    } else {
+        double amax = -INFINITY;
+        for (int k = 0; k < cl.K; ++k) {
+            const double a = mode_logpdf<DERIVED>(t, sC + cl.mean(k), sC + cl.linv(k),
+                                                  sC[cl.cnorm() + k],
+                                                  DERIVED ? derived + k * D : nullptr);
+            sA[k * astride] = a;
+            amax = (a > amax) ? a : amax;
+        }
+        double S = 0.0;
+        for (int k = 0; k < cl.K; ++k) S = fma(sC[cl.weight() + k], dexp(sA[k * astride] - amax), S);
+        ll = dlog(S) + amax;
+    }
+}
+
+__device__ __forceinline__ double wrap_periodic(double t, double lo, double hi)
+{
+    const double w = hi - lo;
+    const double y = (t - lo) / w;
+    const double m = y - floor(y);
+    return m * w + lo;
+}
+
+// ---------------------------------------------------------------- the Metropolis kernel
+// GENERAL = false is the hot variant: uniform priors only, nothing periodic; the trial is
+// not kept in registers but recomputed (same fma) when the step is accepted.
+template <bool MULTI, bool GENERAL>
+__global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const ConstLayout cl{D, a.n_modes};
+    const int csz = (cl.size() + 1) & ~1;
+    double* __restrict__ sC = smem;
+    double* __restrict__ sV = smem + csz;
+    double* __restrict__ sA = sV + D * D + (D & 1);
+    const int tid = threadIdx.x, gs = blockDim.x;
+    const int w = blockIdx.x * gs + tid;
+    const int W = a.W;
+
+    for (int i = tid; i < cl.size(); i += gs) sC[i] = a.cblock[i];
+    const double* __restrict__ Vg = a.V + (size_t)blockIdx.x * a.ncyc * (D * D);
+    for (int i = tid; i < D * D; i += gs) sV[i] = Vg[i];
+
+    double x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = a.x[(size_t)i * W + w];
+    double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
+    int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
+    long long nacc = a.n_accept[w];
+    int nrow = a.rows ? a.n_rows[w] : 0;
+    const uint32_t gid = a.walker0 + (uint32_t)w;
+    unsigned long long step = a.step0;
+    int col = (int)(step % (unsigned long long)D);
+    int cyc = 0;
+    __syncthreads();
+
+    for (int s = 0; s < a.n_steps; ++s) {
+        // ---- random variates of (walker, step): one Philox block
+        const u32x4 r4 = philox4x32_10(a.key0, a.key1, gid, kStreamStep, (uint32_t)step,
+                                       (uint32_t)(step >> 32));
+        const uint64_t kr = ((uint64_t)r4.w1 << 20) | (r4.w2 >> 12);
+        const uint64_t ka = ((uint64_t)r4.w3 << 20) | ((uint64_t)(r4.w2 & 0xFFFu) << 8) |
+                            (r4.w0 & 0xFFu);
+        const double Er = -dlog(u52(kr));
+        const bool expo = (r4.w0 >> 8) < kBranchExp24;
+        double r, Ea;
+        if (D == 1) {
+            double sn, cs;
+            sincos2pi(ka, sn, cs);
+            const double rr = expo ? Er : sqrt(2.0 * Er) * fabs(cs);
+            r = (r4.w0 & 0x80u) ? rr : -rr;
+            const u32x4 q4 = philox4x32_10(a.key0, a.key1, gid, kStreamStep | 0x100u,
+                                           (uint32_t)step, (uint32_t)(step >> 32));
+            Ea = -dlog(u52(((uint64_t)q4.w0 << 20) | (q4.w1 >> 12)));
+        } else {
+            r = expo ? Er : sqrt(2.0 * Er);
+            Ea = -dlog(u52(ka));
+        }
+        // ---- proposal: t = x + r * v, v = T R[:, col] shared by the group
+        const double* __restrict__ v = sV + col * D;
+        double t[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) t[i] = fma(r, v[i], x[i]);
+        if (GENERAL && a.periodic_mask) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if ((a.periodic_mask >> i) & 1u)
+                    t[i] = wrap_periodic(t[i], sC[cl.lo() + i], sC[cl.hi() + i]);
+        }
+        // ---- log-posterior of the trial
+        bool inb;
+        double lp, ll;
+        eval_point<MULTI, false, GENERAL>(t, sC, cl, a.norm_mask, a.uniform_logp, sA + tid, gs, inb,
+                                          lp, ll, nullptr);
+        const double lt = inb ? lp + ll : -INFINITY;
+        // ---- Metropolis test (mcmc.py:678-683)
+        const bool accept = inb & (lt != -INFINITY) &
+                            ((lt > lpost) | (Ea > (lpost - lt) / a.temperature));
+        // ---- bookkeeping (mcmc.py:685-748)
+        if (accept) {
+            if (burn <= 0) {
+                if (a.rows) {
+                    if (nrow < a.row_cap) {
+                        double* row = a.rows + ((size_t)w * a.row_cap + nrow) * (D + 4);
+                        row[0] = (double)wt; row[1] = lpost; row[2] = lpri; row[3] = llik;
+#pragma unroll
+                        for (int i = 0; i < D; ++i) row[4 + i] = x[i];
+                    }
+                    ++nrow;  // rows beyond the capacity are counted as dropped
+                }
+            } else {
+                --burn;
+            }
+        }
+        if (GENERAL) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = accept ? t[i] : x[i];
+        } else {
+            const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly (v finite)
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] = fma(ra, v[i], x[i]);
+        }
+        lpri = accept ? lp : lpri;
+        llik = accept ? ll : llik;
+        lpost = accept ? lt : lpost;
+        prej = accept ? 0 : (prej + (inb ? 0 : 1));
+        wt = accept ? 1 : wt + 1;
+        nacc += accept ? 1 : 0;
+        if (!accept) {
+            const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
+            if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
+        }
+        // ---- next step / next cycle's directions
+        ++step;
+        if (++col == D) {
+            col = 0;
+            ++cyc;
+            if (s + 1 < a.n_steps) {
+                __syncthreads();
+                for (int i = tid; i < D * D; i += gs) sV[i] = Vg[(size_t)cyc * (D * D) + i];
+                __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < D; ++i) a.x[(size_t)i * W + w] = x[i];
+    a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
+    a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
+    a.n_accept[w] = nacc;
+    if (a.rows) a.n_rows[w] = nrow;
+}
+
+// ---------------------------------------------------------------- Haar basis kernel
+// One 64-lane workgroup per (group, cycle): Box-Muller normals on the basis Philox stream,
+// Householder construction of functions.py:45-61 with lane i owning row i of H in VGPRs,
+// then V[c][i] = sum_{k<=i} T[i][k] R[k][c] (proposal.py:222-224, 256-260).
+__global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a)
+{
+    constexpr int NZ = (D + 2) * (D - 1) / 2;
+    constexpr int LDH = D | 1;  // odd leading dimension: conflict-free column reads
+    __shared__ double sz[NZ + 2];
+    __shared__ double sx[D + 1];
+    __shared__ double sR[D * LDH];
+    __shared__ double sT[D * D];
+    const int lane = threadIdx.x;
+    const uint32_t group = a.group0 + blockIdx.x;
+    const uint32_t cycle = a.cycle0 + blockIdx.y;
+    double* __restrict__ Vout = a.V + ((size_t)blockIdx.x * a.ncyc + blockIdx.y) * (D * D);
+
+    for (int i = lane; i < D * D; i += 64) sT[i] = a.T[i];
+    if (D == 1) {
+        if (lane == 0) Vout[0] = a.T[0];
+        return;
+    }
+    for (int j = lane; 2 * j < NZ; j += 64) {
+        const u32x4 w4 = philox4x32_10(a.key0, a.key1, group, kStreamBasis, cycle, (uint32_t)j);
+        const uint64_t ka = ((uint64_t)w4.w0 << 20) | (w4.w1 >> 12);
+        const uint64_t kb = ((uint64_t)w4.w2 << 20) | (w4.w3 >> 12);
+        const double rad = sqrt(-2.0 * dlog(u52(ka)));
+        double sn, cs;
+        sincos2pi(kb, sn, cs);
+        sz[2 * j] = rad * cs;
+        sz[2 * j + 1] = rad * sn;  // sz has room for the unused odd tail
+    }
+    __syncthreads();
+
+    double H[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) H[k] = (k == lane) ? 1.0 : 0.0;
+    double dprod = 1.0, Dmine = 1.0;
+    int ix = 0;
+#pragma unroll
+    for (int n = 0; n < D - 1; ++n) {
+        const int m = D - n;
+        double norm2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
+        const double x0 = sz[ix];
+        const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
+        dprod *= Dn;
+        if (lane == n) Dmine = Dn;
+        const double x0n = x0 + Dn * sqrt(norm2);
+        double tt = norm2 - x0 * x0;
+        tt = tt + x0n * x0n;
+        const double den = sqrt(0.5 * tt);
+        __syncthreads();
+        if (lane < m) sx[lane] = ((lane == 0) ? x0n : sz[ix + lane]) / den;
+        __syncthreads();
+        double tmp = 0.0;
+#pragma unroll
+        for (int k = 0; k < m; ++k) tmp = fma(H[n + k], sx[k], tmp);
+#pragma unroll
+        for (int k = 0; k < m; ++k) H[n + k] = fma(-tmp, sx[k], H[n + k]);
+        ix += m;
+    }
+    if (lane == D - 1) Dmine = (((D - 1) & 1) ? -1.0 : 1.0) * dprod;
+    if (lane < D) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) sR[lane * LDH + k] = Dmine * H[k];
+    }
+    __syncthreads();
+    if (lane < D) {
+        // lane = column c of R; V[c][i] for i ascending
+        double Rc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) Rc[k] = sR[k * LDH + lane];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) s = fma(sT[i * D + k], Rc[k], s);
+            Vout[lane * D + i] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- batch evaluator
+// logprior / loglike / derived of n arbitrary points through the same device functions as
+// the step kernel: the parity hook for model.logposterior (model.py:579-678).
+template <bool MULTI, bool DERIVED>
+__global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const ConstLayout cl{D, a.n_modes};
+    const int csz = (cl.size() + 1) & ~1;
+    double* __restrict__ sC = smem;
+    double* __restrict__ sA = smem + csz;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < cl.size(); i += 64) sC[i] = a.cblock[i];
+    __syncthreads();
+    const int p = blockIdx.x * 64 + tid;
+    if (p >= a.n) return;
+    double t[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) t[i] = a.x[(size_t)p * D + i];
+    bool inb;
+    double lp, ll;
+    double* der = DERIVED ? a.derived + (size_t)p * (cl.K > 0 ? cl.K : 1) * D : nullptr;
+    eval_point<MULTI, DERIVED, true>(t, sC, cl, a.norm_mask, a.uniform_logp, sA + tid, 64, inb, lp,
+                                     ll, der);
+    a.logprior[p] = inb ? lp : -INFINITY;
+    a.loglike[p] = inb ? ll : -INFINITY;
+}
+
+// ---------------------------------------------------------------- moments
+// Per group: sum_x[i] and S_g[i][j] = sum_l x_i x_j over the group's walkers in ascending
+// order (sequential fma chains: deterministic), X tile staged in LDS.
+__global__ void __launch_bounds__(256) group_moments_kernel(const MomentArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sX[];  // [gs][D|1]
+    constexpr int LDX = D | 1;
+    const int tid = threadIdx.x, gs = blockDim.x, g = blockIdx.x;
+    const int w = g * gs + tid;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sX[tid * LDX + i] = a.x[(size_t)i * a.W + w] - a.shift[i];
+    __syncthreads();
+    if (tid < D) {
+        double s = 0.0;
+        for (int l = 0; l < gs; ++l) s = s + sX[l * LDX + tid];
+        a.group_sum[(size_t)g * D + tid] += s;
+    }
+    for (int p = tid; p < NPAIR; p += gs) {
+        // p -> (i, j), i >= j, p = i(i+1)/2 + j
+        int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= p) ++i;
+        while (i * (i + 1) / 2 > p) --i;
+        const int j = p - i * (i + 1) / 2;
+        double s = 0.0;
+        for (int l = 0; l < gs; ++l) s = fma(sX[l * LDX + i], sX[l * LDX + j], s);
+        a.Sg[(size_t)g * NPAIR + p] = s;
+    }
+}
+
+__global__ void __launch_bounds__(64) pool_moments_kernel(const MomentArgs a)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= NPAIR) return;
+    double acc = a.pooled[p];
+    for (int g = 0; g < a.G; ++g) acc += a.Sg[(size_t)g * NPAIR + p];
+    a.pooled[p] = acc;
+}
+
+// ---------------------------------------------------------------- launchers
+hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
+{
+    const ConstLayout cl{D, a.n_modes};
+    const int csz = (cl.size() + 1) & ~1;
+    const bool multi = a.n_modes > 1;
+    const size_t lds = sizeof(double) * (size_t)(csz + D * D + (D & 1) +
+                                                 (multi ? a.n_modes * group_size : 0));
+    const dim3 grid(a.W / group_size), block(group_size);
+    const bool general = (a.norm_mask | a.periodic_mask) != 0u;
+    if (multi) {
+        if (general) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((step_kernel<true, false>), grid, block, lds, st, a);
+    } else {
+        if (general) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_basis(const BasisArgs& a, int n_groups, hipStream_t st)
+{
+    hipLaunchKernelGGL(basis_kernel, dim3(n_groups, a.ncyc), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_evaluate(const EvalArgs& a, hipStream_t st)
+{
+    const ConstLayout cl{D, a.n_modes};
+    const int csz = (cl.size() + 1) & ~1;
+    const bool multi = a.n_modes > 1;
+    const size_t lds = sizeof(double) * (size_t)(csz + (multi ? a.n_modes * 64 : 0));
+    const dim3 grid((a.n + 63) / 64), block(64);
+    if (multi) {
+        if (a.derived) hipLaunchKernelGGL((evaluate_kernel<true, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((evaluate_kernel<true, false>), grid, block, lds, st, a);
+    } else {
+        if (a.derived) hipLaunchKernelGGL((evaluate_kernel<false, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((evaluate_kernel<false, false>), grid, block, lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_moments(const MomentArgs& a, int group_size, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (size_t)group_size * (D | 1);
+    hipLaunchKernelGGL(group_moments_kernel, dim3(a.G), dim3(group_size), lds, st, a);
+    hipLaunchKernelGGL(pool_moments_kernel, dim3((NPAIR + 63) / 64), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+const DimKernels kKernels = {launch_step, launch_basis, launch_evaluate, launch_moments};
+
+}  // namespace
+}  // namespace mcmc
+
+#define MCMC_CAT2(a, b) a##b
+#define MCMC_CAT(a, b) MCMC_CAT2(a, b)
+extern "C" const mcmc::DimKernels* MCMC_CAT(mcmc_hip_dim_, MCMC_D)() { return &mcmc::kKernels; }

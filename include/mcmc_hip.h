@@ -1,0 +1,156 @@
+/*
+ * mcmc_hip.h -- C ABI of libmcmc_hip.so, the MI355X (gfx950) walker-ensemble Metropolis
+ * engine behind Cobaya's sampler plugin surface.
+ *
+ * The reference (CobayaSampler/cobaya v3.6.2) is pure Python and has no FFI on this path;
+ * each entry point below names the reference interface it stands in for (paths relative to
+ * the reference checkout).  The Python class cobaya_amd.sampler.MCMCHip (registered as
+ * sampler `mcmc_hip`) is the only caller: initialize() -> create/set_*, run() -> loop of
+ * step/accumulate_moments/read_moments/gelman_rubin/set_proposal_cov/drain_samples,
+ * products() -> get_state/drain_samples.  See INTEGRATION.md for the ctypes binding.
+ *
+ * Conventions: opaque handle; all buffers are caller-owned C-contiguous host arrays
+ * (the library copies in/out and never retains a pointer); every function returns 0 on
+ * success and a negative code on error, with a message available from
+ * mcmc_hip_last_error(); nothing throws across the boundary; a handle is not thread-safe;
+ * all calls may be made with the GIL released.  There is NO CPU fallback: create() fails
+ * if no gfx950 device is usable.
+ */
+#ifndef MCMC_HIP_H
+#define MCMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcmc_hip_ctx mcmc_hip_ctx;
+
+enum {
+    MCMC_HIP_OK = 0,
+    MCMC_HIP_ERR_ARG = -1,       /* invalid argument / unsupported configuration */
+    MCMC_HIP_ERR_DEVICE = -2,    /* HIP runtime error or no usable gfx950 device */
+    MCMC_HIP_ERR_NOT_PD = -3,    /* matrix not symmetric positive definite */
+    MCMC_HIP_ERR_STATE = -4,     /* call order violated (e.g. step before set_state) */
+    MCMC_HIP_ERR_STUCK = -5      /* a walker exceeded max_tries (mcmc.py:717-743) */
+};
+
+/* Options fixed at creation.  Mirrors the attributes cobaya/samplers/mcmc/mcmc.py:111-271
+ * (MCMC.initialize) reads from mcmc.yaml, plus the ensemble geometry. */
+typedef struct mcmc_hip_config {
+    int32_t d;               /* number of sampled parameters (1..32 in this build) */
+    int32_t n_walkers;       /* walkers on this device; multiple of group_size */
+    int32_t group_size;      /* walkers sharing one Haar basis: 64, 128 or 256 */
+    int32_t device;          /* HIP device ordinal */
+    uint64_t seed;           /* mcmc.yaml:75 `seed` (Philox key; sampler.py:369-384) */
+    uint32_t walker_offset;  /* global id of this device's first walker (multi-GPU shard) */
+    int32_t burn_in;         /* accepted steps discarded per walker (mcmc.py:265, 691-707) */
+    double temperature;      /* mcmc.yaml:24 (mcmc.py:127-130, 438-440, 682) */
+    double proposal_scale;   /* mcmc.yaml:17 (proposal.py:223) */
+    double max_tries;        /* mcmc.yaml:9, already multiplied by d (mcmc.py:717-743) */
+    int32_t emit_capacity;   /* accepted rows kept per walker between drains; 0 = none */
+    int32_t reserved;
+} mcmc_hip_config;
+
+const char* mcmc_hip_version(void);
+/* message of the last error on this handle (or of the last failed create if h == NULL) */
+const char* mcmc_hip_last_error(const mcmc_hip_ctx* h);
+/* 1 if the lane-per-walker kernels for dimension d were compiled into this library */
+int mcmc_hip_dim_supported(int d);
+
+/* Sampler.__init__ + MCMC.initialize (cobaya/sampler.py:257-322, mcmc.py:111-271) */
+int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out);
+void mcmc_hip_destroy(mcmc_hip_ctx* h);
+
+/* Prior.__init__ constants (cobaya/prior.py:464-533): kind[i] 0 = uniform on [a,b],
+ * 1 = normal(loc=a, scale=b); periodic[i] != 0 wraps into [a,b) (prior.py:658-676). */
+int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, const double* b,
+                       const int32_t* periodic);
+
+/* GaussianMixture.initialize_with_params (gaussian_mixture.py:45-136): means[K*d],
+ * covs[K*d*d] row-major, weights[K] (NULL = equal; renormalised if they do not sum to 1). */
+int mcmc_hip_set_target_gaussian_mixture(mcmc_hip_ctx* h, int32_t n_modes, const double* means,
+                                         const double* covs, const double* weights);
+/* Gaussian.initialize_with_params (gaussian/gaussian.py:30-94) */
+int mcmc_hip_set_target_gaussian(mcmc_hip_ctx* h, const double* mean, const double* cov,
+                                 int32_t normalized);
+/* likelihoods/one/one.py:27-29: loglike = 0 (prior-only sampling) */
+int mcmc_hip_set_target_one(mcmc_hip_ctx* h);
+
+/* BlockedProposer.set_covariance (proposal.py:226-260) for one block of all parameters:
+ * checks symmetric positive definite, builds T = scale * diag(std) * chol(corr).  `cov`
+ * must already carry the temperature factor (mcmc.py:438-440), as in the reference. */
+int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov);
+int mcmc_hip_get_proposal_cov(const mcmc_hip_ctx* h, double* cov);          /* proposal.py:262 */
+int mcmc_hip_get_proposal_transform(const mcmc_hip_ctx* h, double* T);      /* transform[0] * scale */
+
+/* Model.logposterior for a batch (cobaya/model.py:579-678): x[n*d] point-major ->
+ * logprior[n], loglike[n] (-inf outside the prior support), derived[n*K*d] or NULL =
+ * L_k^-1 (x - mu_k) (gaussian_mixture.py:146-156). */
+int mcmc_hip_evaluate(mcmc_hip_ctx* h, int32_t n, const double* x, double* logprior,
+                      double* loglike, double* derived);
+
+/* OneSamplePoint.add of the initial points (mcmc.py:219-222): x[n_walkers*d] walker-major.
+ * Evaluates their log-posterior on the device; n_bad (may be NULL) receives the number of
+ * walkers with a non-finite posterior (an error, as in model.py:707-754). */
+int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad);
+/* current point of every walker: x[W*d], logpost[W], logprior[W], loglike[W], weight[W];
+ * any pointer may be NULL */
+int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
+                       double* loglike, int32_t* weight);
+
+/* n_steps iterations of MCMC.get_new_sample_metropolis (mcmc.py:545-562) for every walker,
+ * asynchronously on the engine's stream; generates the Haar bases the steps need. */
+int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps);
+/* wait for queued work; returns MCMC_HIP_ERR_STUCK if a walker tripped max_tries */
+int mcmc_hip_sync(mcmc_hip_ctx* h);
+
+/* counters[0] steps per walker so far, [1] accepted steps summed over walkers (n_steps_raw /
+ * acceptance of mcmc.py:311-318, 472), [2] id+1 of a stuck walker or 0, [3] rows dropped
+ * because emit_capacity was exceeded */
+int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4]);
+
+/* SampleCollection.add rows accumulated since the last drain (mcmc.py:691-707,
+ * collection.py:402-427): rows[n][d+5] = (walker id, weight, logpost, logprior, loglike,
+ * x[0..d)), walker-major then in chain order.  cap_rows = capacity of `rows` in rows. */
+int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int64_t* n_rows);
+
+/* Constants the engine derived from set_prior / set_target_* (uniform_logp of prior.py:528-533,
+ * mls[d] of tools.py:723, Linv[K*d*d] row-major of functions.py:81-89, cnorm[K] =
+ * d log 2pi + log|S_k|, weight[K]); any pointer may be NULL.  Lets tests hand the CPU oracle
+ * exactly the problem the kernels evaluate. */
+int mcmc_hip_get_derived_constants(const mcmc_hip_ctx* h, double* uniform_logp, double* mls,
+                                   double* Linv, double* cnorm, double* weight);
+
+/* Vector subtracted from every walker before its moments are accumulated (numerical
+ * conditioning only; R-1 and covariances are shift invariant).  Only right after a reset. */
+int mcmc_hip_set_moment_shift(mcmc_hip_ctx* h, const double* shift);
+
+/* Streaming replacement of SampleCollection.mean/cov (collection.py:893-981): adds the
+ * current state of every walker to the interval accumulators (one "snapshot"). */
+int mcmc_hip_accumulate_moments(mcmc_hip_ctx* h);
+/* n_snapshots since the last reset; group_sum[G*d] = sum over snapshots and the group's
+ * walkers of x; pooled_S[d*d] = sum over everything of x x^T.  reset != 0 clears them. */
+int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
+                          double* pooled_S, int32_t reset);
+
+/* The R-1 arithmetic of MCMC.check_convergence_and_learn_proposal (mcmc.py:856-889) on
+ * reduced sufficient statistics (what the RCCL all-reduce of SURVEY 8e carries):
+ * n_chains, sum_N = sum_c N_c, sum_Ncov[d*d] = sum_c N_c cov_c, sum_mean[d] = sum_c m_c,
+ * sum_mm[d*d] = sum_c m_c m_c^T.  Outputs Rminus1 and mean_of_covs[d*d].
+ * Returns MCMC_HIP_ERR_NOT_PD where the reference catches LinAlgError (mcmc.py:870-887). */
+int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double* sum_Ncov,
+                          const double* sum_mean, const double* sum_mm, double* Rminus1,
+                          double* mean_of_covs);
+
+/* HIP-event time (ms) spent in step kernels / basis kernels / moment kernels since the last
+ * call with reset != 0, and the number of step-kernel launches: the live measurement
+ * bench.py's roofline block uses.  Timing is enabled by mcmc_hip_enable_timing(h, 1). */
+int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
+int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_HIP_H */

@@ -1,0 +1,293 @@
+"""ORACLE (test infrastructure): ctypes binding of oracle/mcmc_oracle.c.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+def build():
+    """(Re)compile the oracle with gcc; cheap, incremental through make."""
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+class _Problem(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("n_modes", C.c_int32), ("group_size", C.c_int32),
+        ("has_periodic", C.c_int32), ("seed", C.c_uint64), ("temperature", C.c_double),
+        ("max_tries", C.c_double),
+        ("kind", c_int32_p), ("lo", c_double_p), ("hi", c_double_p), ("loc", c_double_p),
+        ("scale", c_double_p), ("mls", c_double_p), ("periodic", c_int32_p),
+        ("uniform_logp", C.c_double),
+        ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
+        ("weight", c_double_p), ("T", c_double_p),
+    ]
+
+
+class _State(C.Structure):
+    _fields_ = [
+        ("x", c_double_p), ("logprior", c_double_p), ("loglike", c_double_p),
+        ("logpost", c_double_p), ("weight", c_int32_p), ("prior_rej", c_int32_p),
+        ("burn_left", c_int32_p), ("n_accept", c_int64_p), ("stuck", c_int32_p),
+        ("rows", c_double_p), ("n_rows", c_int32_p), ("row_cap", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        name = "libmcmc_oracle_fma.so" if _cpu_has_fma() else "libmcmc_oracle.so"
+        path = os.path.join(BUILD, name)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        L.orc_dlog.restype = C.c_double
+        L.orc_dlog.argtypes = [C.c_double]
+        L.orc_dexp.restype = C.c_double
+        L.orc_dexp.argtypes = [C.c_double]
+        L.orc_sincos2pi.argtypes = [C.c_uint64, c_double_p, c_double_p]
+        L.orc_haar_from_normals.argtypes = [C.c_int, c_double_p, c_double_p]
+        L.orc_basis.argtypes = [C.POINTER(_Problem), C.c_uint32, C.c_uint32, c_double_p]
+        L.orc_evaluate.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p,
+                                   c_double_p, c_double_p]
+        L.orc_step_injected.restype = C.c_int
+        L.orc_step_injected.argtypes = [C.POINTER(_Problem), C.POINTER(_State), c_double_p,
+                                        C.c_double]
+        L.orc_run.restype = C.c_int64
+        L.orc_run.argtypes = [C.POINTER(_Problem), C.POINTER(_State), C.c_int, C.c_uint32,
+                              C.c_uint64, C.c_int, C.c_int]
+        L.orc_moments.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
+                                  c_double_p, c_double_p]
+        L.orc_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int32_p)
+
+
+def philox(k0, k1, c0, c1, c2, c3):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox(k0, k1, c0, c1, c2, c3, out)
+    return [int(v) for v in out]
+
+
+def dlog(x):
+    return lib().orc_dlog(float(x))
+
+
+def dexp(x):
+    return lib().orc_dexp(float(x))
+
+
+def sincos2pi(k):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos2pi(int(k), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def haar_from_normals(d, z):
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    H = np.empty((d, d))
+    lib().orc_haar_from_normals(d, _dp(z), _dp(H))
+    return H
+
+
+def proposal_transform(cov, scale):
+    """T = scale * diag(std) * chol(corr)  (proposal.py:256-260 for one block)."""
+    cov = np.asarray(cov, dtype=np.float64)
+    std = np.sqrt(np.diag(cov))
+    corr = cov / std[:, None] / std[None, :]
+    np.fill_diagonal(corr, 1.0)
+    return scale * (np.diag(std) @ np.linalg.cholesky(corr))
+
+
+class Problem:
+    """Owns the arrays behind an `orc_problem`.  All derived constants may be passed in
+    (e.g. the ones the HIP engine reports) so that oracle and engine see one problem."""
+
+    def __init__(self, d, kinds, a, b, periodic=None, means=None, covs=None, weights=None,
+                 normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
+                 max_tries=None, derived=None):
+        self.d = d
+        kinds = np.asarray(kinds, dtype=np.int32)
+        a = np.asarray(a, dtype=np.float64)
+        b = np.asarray(b, dtype=np.float64)
+        self.kind = np.ascontiguousarray(kinds)
+        self.lo = np.where(kinds == 0, a, -np.inf).astype(np.float64)
+        self.hi = np.where(kinds == 0, b, np.inf).astype(np.float64)
+        self.loc = np.where(kinds == 1, a, 0.0).astype(np.float64)
+        self.scale = np.where(kinds == 1, b, 1.0).astype(np.float64)
+        self.periodic = (np.zeros(d, np.int32) if periodic is None
+                         else np.ascontiguousarray(periodic, dtype=np.int32))
+        if means is None:
+            K = 0
+            self.mean = np.zeros(1)
+            Linv = np.zeros(1)
+            cnorm = np.zeros(1)
+            w = np.zeros(1)
+        else:
+            self.mean = np.ascontiguousarray(np.atleast_2d(means), dtype=np.float64)
+            covs = np.asarray(covs, dtype=np.float64)
+            covs = covs if covs.ndim == 3 else covs[None]
+            K = len(self.mean)
+            Ls = [np.linalg.cholesky(c) for c in covs]
+            Linv = np.array([np.linalg.inv(L) for L in Ls])
+            cnorm = np.array([d * np.log(2 * np.pi) + 2 * np.sum(np.log(np.diag(L)))
+                              if normalized else 0.0 for L in Ls])
+            w = (np.full(K, 1.0 / K) if weights is None
+                 else np.asarray(weights, dtype=np.float64))
+            if not np.isclose(w.sum(), 1):
+                w = w / w.sum()
+        self.K = K
+        uni = kinds == 0
+        self.uniform_logp = float(-np.sum(np.log(self.hi[uni] - self.lo[uni])))
+        self.mls = -np.log(self.scale) - np.log(2 * np.pi) / 2
+        self.Linv, self.cnorm, self.weight = Linv, cnorm, w
+        if derived is not None:  # constants reported by the engine
+            self.uniform_logp = float(derived["uniform_logp"])
+            self.mls = np.array(derived["mls"], dtype=np.float64)
+            if K:
+                self.Linv = np.array(derived["Linv"], dtype=np.float64)
+                self.cnorm = np.array(derived["cnorm"], dtype=np.float64)
+                self.weight = np.array(derived["weight"], dtype=np.float64)
+        self.Linv = np.ascontiguousarray(self.Linv, dtype=np.float64)
+        self.cnorm = np.ascontiguousarray(self.cnorm, dtype=np.float64)
+        self.weight = np.ascontiguousarray(self.weight, dtype=np.float64)
+        self.mls = np.ascontiguousarray(self.mls, dtype=np.float64)
+        self.T = (np.zeros((d, d)) if T is None
+                  else np.ascontiguousarray(np.tril(T), dtype=np.float64))
+        self.group_size, self.seed, self.temperature = group_size, seed, temperature
+        self.max_tries = float(max_tries if max_tries is not None else 40 * d)
+        self._refresh()
+
+    def _refresh(self):
+        p = _Problem()
+        p.d, p.n_modes, p.group_size = self.d, self.K, self.group_size
+        p.has_periodic = int(self.periodic.any())
+        p.seed, p.temperature, p.max_tries = self.seed, self.temperature, self.max_tries
+        p.kind, p.lo, p.hi, p.loc = _ip(self.kind), _dp(self.lo), _dp(self.hi), _dp(self.loc)
+        p.scale, p.mls, p.periodic = _dp(self.scale), _dp(self.mls), _ip(self.periodic)
+        p.uniform_logp = self.uniform_logp
+        p.mean, p.Linv, p.cnorm = _dp(self.mean), _dp(self.Linv), _dp(self.cnorm)
+        p.weight, p.T = _dp(self.weight), _dp(self.T)
+        self.c = p
+
+    def set_T(self, T):
+        self.T = np.ascontiguousarray(np.tril(T), dtype=np.float64)
+        self._refresh()
+
+    def evaluate(self, x, derived=False):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        n = len(x)
+        lp, ll = np.empty(n), np.empty(n)
+        der = np.empty((n, max(self.K, 1) * self.d)) if derived else None
+        lib().orc_evaluate(C.byref(self.c), n, _dp(x), _dp(lp), _dp(ll),
+                           _dp(der) if derived else None)
+        return (lp, ll, der) if derived else (lp, ll)
+
+    def basis(self, group, cycle):
+        V = np.empty((self.d, self.d))
+        lib().orc_basis(C.byref(self.c), group, cycle, _dp(V))
+        return V  # V[c] = direction of column c
+
+
+class State:
+    """Walker state arrays of the oracle (walker-major x)."""
+
+    def __init__(self, problem, x0, burn_in=0, row_cap=0):
+        self.p = problem
+        x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+        self.W, d = x0.shape
+        self.x = x0.copy()
+        lp, ll = problem.evaluate(x0)
+        self.logprior, self.loglike = lp, ll
+        self.logpost = lp + ll
+        self.weight = np.ones(self.W, np.int32)
+        self.prior_rej = np.zeros(self.W, np.int32)
+        self.burn_left = np.full(self.W, burn_in + 1, np.int32)
+        self.n_accept = np.zeros(self.W, np.int64)
+        self.stuck = np.zeros(1, np.int32)
+        self.row_cap = row_cap
+        self.rows = np.zeros((self.W, max(row_cap, 1), d + 4)) if row_cap else None
+        self.n_rows = np.zeros(self.W, np.int32)
+        self.step = 0
+        s = _State()
+        s.x, s.logprior, s.loglike = _dp(self.x), _dp(self.logprior), _dp(self.loglike)
+        s.logpost, s.weight, s.prior_rej = _dp(self.logpost), _ip(self.weight), _ip(self.prior_rej)
+        s.burn_left = _ip(self.burn_left)
+        s.n_accept = self.n_accept.ctypes.data_as(c_int64_p)
+        s.stuck = _ip(self.stuck)
+        s.rows = _dp(self.rows) if row_cap else None
+        s.n_rows = _ip(self.n_rows)
+        s.row_cap = row_cap
+        self.c = s
+
+    def run(self, n_steps, walker0=0, n_threads=1):
+        acc = lib().orc_run(C.byref(self.p.c), C.byref(self.c), self.W, walker0, self.step,
+                            n_steps, n_threads)
+        self.step += n_steps
+        return acc
+
+    def step_injected(self, vec, exp_draw):
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        return lib().orc_step_injected(C.byref(self.p.c), C.byref(self.c), _dp(vec),
+                                       float(exp_draw))
+
+    def drain(self):
+        """rows as (walker, weight, logpost, logprior, loglike, x...) like the engine."""
+        out = []
+        for w in range(self.W):
+            n = min(int(self.n_rows[w]), self.row_cap)
+            for r in range(n):
+                out.append(np.concatenate(([w], self.rows[w, r])))
+        self.n_rows[:] = 0
+        d = self.x.shape[1]
+        return np.array(out) if out else np.zeros((0, d + 5))
+
+
+def moments(x, group_size, shift=None, group_sum=None, pooled=None):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    W, d = x.shape
+    G = W // group_size
+    shift = np.zeros(d) if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
+    group_sum = np.zeros((G, d)) if group_sum is None else group_sum
+    pooled = np.zeros((d, d)) if pooled is None else pooled
+    lib().orc_moments(d, W, group_size, _dp(x), _dp(shift), _dp(group_sum), _dp(pooled))
+    return group_sum, pooled
+
+
+def max_threads():
+    return lib().orc_max_threads()

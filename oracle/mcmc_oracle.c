@@ -1,0 +1,502 @@
+/*
+ * ORACLE (test infrastructure, never shipped, never on the product path).
+ *
+ * Flavour (b) of the oracle: a plain-C CPU restatement of the walker-ensemble Metropolis
+ * step that the HIP kernels implement (DESIGN.md "Ensemble specification"), on the same
+ * counter-based Philox4x32-10 stream, written so that every floating-point operation is
+ * fixed (explicit fma(), -ffp-contract=off): the HIP path must match it BIT FOR BIT
+ * ("Tier B" of SURVEY.md 8c).  It is tied to the reference two ways:
+ *   - orc_step_injected() replays a reference chain when fed the reference's own random
+ *     draws (tests/test_oracle_c.py, against oracle/ref_numpy.py == golden G6);
+ *   - orc_evaluate() reproduces the reference's logprior / loglike golden vectors G4/G5.
+ * It is also the timed "cpu_baseline" (kind "port") of bench.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Reference restated (paths relative to /root/reference):
+ *   proposal   cobaya/samplers/mcmc/proposal.py:59-82,222-224 ; cobaya/functions.py:35-61
+ *   prior      cobaya/prior.py:658-676,733-763 ; cobaya/tools.py:720-729
+ *   likelihood cobaya/likelihoods/gaussian_mixture/gaussian_mixture.py:138-163,
+ *              cobaya/likelihoods/gaussian/gaussian.py:96-112
+ *   accept     cobaya/samplers/mcmc/mcmc.py:670-683 ; bookkeeping mcmc.py:685-748
+ *   moments    cobaya/collection.py:926-934,970-981 (as streaming sufficient statistics)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11); the generator
+ * rocRAND/cuRAND ship as PHILOX4_32_10. */
+static inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                 uint32_t c2, uint32_t c3, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                uint32_t c3, uint32_t out[4])
+{
+    philox4x32_10(k0, k1, c0, c1, c2, c3, out);
+}
+
+enum { STREAM_STEP = 0, STREAM_BASIS = 1 };
+#define BRANCH_EXP_24 5536481u /* floor(0.33 * 2^24): proposal.py:79 */
+
+/* u = (2k+1) 2^-53, k < 2^52: an odd multiple of 2^-53 in (0,1), exact in binary64 */
+static inline double u52(uint64_t k) { return (double)(2 * k + 1) * 0x1p-53; }
+
+/* ------------------------------------------------------------------ fixed-order math */
+static inline double bits2d(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static inline uint64_t d2bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+/* natural log of a positive normal double; argument reduction and minimax polynomial of
+ * Sun's fdlibm e_log.c (public algorithm), every operation fixed. < 1 ulp. */
+double orc_dlog(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+        Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+        Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+    uint64_t b = d2bits(x);
+    uint32_t hx = (uint32_t)(b >> 32);
+    int k = (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    b = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (b & 0xffffffffu);
+    k += (int)(i >> 20);
+    double f = bits2d(b) - 1.0;
+    double dk = (double)k;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+/* exp(x) for x <= 0 (mixture log-sum-exp terms); fdlibm e_exp.c reduction/polynomial.
+ * x < -708 returns 0 (the term is below 1e-307 of the leading one). */
+double orc_dexp(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+        P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (!(x >= -708.0)) return 0.0;
+    double kf = rint(x * invln2);
+    double hi = fma(-kf, ln2_hi, x);
+    double lo = kf * ln2_lo;
+    double r = hi - lo;
+    double t = r * r;
+    double c = r - t * fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1);
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    int k = (int)kf; /* -1022 <= k <= 0 here */
+    return bits2d(d2bits(y) + ((uint64_t)(int64_t)k << 52));
+}
+
+/* sin/cos kernels on [0, pi/4] (fdlibm k_sin.c / k_cos.c polynomials, y = 0) */
+static inline double ksin(double x)
+{
+    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double v = z * x;
+    double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
+    return fma(v, fma(z, r, S1), x);
+}
+static inline double kcos(double x)
+{
+    static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double r = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    return 1.0 - (0.5 * z - z * r);
+}
+
+/* (sin, cos)(2 pi u) for u = (2k+1) 2^-53: octant from the top 3 bits of k, exact
+ * in-octant fraction phi = (2 rem + 1) 2^-50, reflected (1 - phi, exact) in odd octants */
+void orc_sincos2pi(uint64_t k, double* sn, double* cs)
+{
+    static const double PIO4 = 7.85398163397448278999e-01;
+    unsigned o = (unsigned)(k >> 49);
+    uint64_t rem = k & ((1ull << 49) - 1);
+    double phi = (double)(2 * rem + 1) * 0x1p-50;
+    if (o & 1) phi = 1.0 - phi;
+    double a = phi * PIO4;
+    double s = ksin(a), c = kcos(a);
+    double ss, cc;
+    switch (o) {
+    case 0: ss = s; cc = c; break;
+    case 1: ss = c; cc = s; break;
+    case 2: ss = c; cc = -s; break;
+    case 3: ss = s; cc = -c; break;
+    case 4: ss = -s; cc = -c; break;
+    case 5: ss = -c; cc = -s; break;
+    case 6: ss = -c; cc = s; break;
+    default: ss = -s; cc = c; break;
+    }
+    *sn = ss; *cs = cc;
+}
+
+/* ------------------------------------------------------------------ problem description */
+typedef struct {
+    int32_t d;           /* sampled dimension */
+    int32_t n_modes;     /* 0 = `one` likelihood (loglike 0), >=1 Gaussian mixture */
+    int32_t group_size;  /* walkers sharing one Haar basis */
+    int32_t has_periodic;
+    uint64_t seed;
+    double temperature;
+    double max_tries;    /* mcmc.yaml:9 (already scaled by d) */
+    /* prior (prior.py:514-533): kind 0 uniform [lo,hi], kind 1 normal(loc,scale) with
+     * lo/hi = -/+inf; mls = -log(scale) - log(2pi)/2 */
+    const int32_t* kind; const double* lo; const double* hi; const double* loc;
+    const double* scale; const double* mls; const int32_t* periodic;
+    double uniform_logp;
+    /* target: per mode k: mean[k*d+i]; Linv row-major lower-triangular [k][j][i] (d*d per
+     * mode, upper part ignored); cnorm[k] = d log 2pi + log|S_k| (0 if unnormalised);
+     * weight[k] */
+    const double* mean; const double* Linv; const double* cnorm; const double* weight;
+    /* proposal transform T = scale * diag(std) * chol(corr), row-major lower-tri d*d */
+    const double* T;
+} orc_problem;
+
+/* ------------------------------------------------------------------ Haar basis (a3) */
+/* Householder construction of functions.py:45-61 with a fixed operation order.
+ * z: (d+2)(d-1)/2 standard normals; H: d*d row-major output (rows scaled by D). */
+void orc_haar_from_normals(int d, const double* z, double* H)
+{
+    double* x = (double*)malloc(sizeof(double) * (size_t)d);
+    double* D = (double*)malloc(sizeof(double) * (size_t)d);
+    for (int i = 0; i < d * d; ++i) H[i] = 0.0;
+    for (int i = 0; i < d; ++i) H[i * d + i] = 1.0;
+    int ix = 0;
+    double dprod = 1.0;
+    for (int n = 0; n < d - 1; ++n) {
+        int m = d - n;
+        double norm2 = 0.0;
+        for (int k = 0; k < m; ++k) { x[k] = z[ix + k]; norm2 = fma(x[k], x[k], norm2); }
+        ix += m;
+        double x0 = x[0];
+        double Dn = (x0 < 0.0) ? -1.0 : 1.0;
+        D[n] = Dn; dprod *= Dn;
+        x[0] = x0 + Dn * sqrt(norm2);
+        double t = norm2 - x0 * x0;
+        t = t + x[0] * x[0];
+        double den = sqrt(0.5 * t);
+        for (int k = 0; k < m; ++k) x[k] = x[k] / den;
+        for (int i = 0; i < d; ++i) {
+            double tmp = 0.0;
+            for (int k = 0; k < m; ++k) tmp = fma(H[i * d + n + k], x[k], tmp);
+            for (int k = 0; k < m; ++k) H[i * d + n + k] = fma(-tmp, x[k], H[i * d + n + k]);
+        }
+    }
+    D[d - 1] = (((d - 1) & 1) ? -1.0 : 1.0) * dprod;
+    for (int i = 0; i < d; ++i)
+        for (int k = 0; k < d; ++k) H[i * d + k] = D[i] * H[i * d + k];
+    free(x); free(D);
+}
+
+/* normals of the basis stream for (group, cycle): Box-Muller on Philox pairs */
+static void basis_normals(uint64_t seed, uint32_t group, uint32_t cycle, int n, double* z)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int j = 0; 2 * j < n; ++j) {
+        uint32_t w[4];
+        philox4x32_10(k0, k1, group, STREAM_BASIS, cycle, (uint32_t)j, w);
+        uint64_t ka = ((uint64_t)w[0] << 20) | (w[1] >> 12);
+        uint64_t kb = ((uint64_t)w[2] << 20) | (w[3] >> 12);
+        double rad = sqrt(-2.0 * orc_dlog(u52(ka)));
+        double sn, cs;
+        orc_sincos2pi(kb, &sn, &cs);
+        z[2 * j] = rad * cs;
+        if (2 * j + 1 < n) z[2 * j + 1] = rad * sn;
+    }
+}
+
+/* V[c*d + i] = sum_{k<=i} T[i][k] R[k][c]: the d proposal direction vectors of one cycle
+ * (proposal.py:222-224 with transform of 256-260); column c is used at step cycle*d+c. */
+void orc_basis(const orc_problem* p, uint32_t group, uint32_t cycle, double* V)
+{
+    int d = p->d;
+    if (d == 1) { V[0] = p->T[0]; return; }
+    int nz = (d + 2) * (d - 1) / 2;
+    double* z = (double*)malloc(sizeof(double) * (size_t)(nz + 1));
+    double* H = (double*)malloc(sizeof(double) * (size_t)d * d);
+    basis_normals(p->seed, group, cycle, nz, z);
+    orc_haar_from_normals(d, z, H);
+    for (int c = 0; c < d; ++c)
+        for (int i = 0; i < d; ++i) {
+            double s = 0.0;
+            for (int k = 0; k <= i; ++k) s = fma(p->T[i * d + k], H[k * d + c], s);
+            V[c * d + i] = s;
+        }
+    free(z); free(H);
+}
+
+/* ------------------------------------------------------------------ log-posterior (a6-a10) */
+static inline double wrap_periodic(double t, double lo, double hi)
+{
+    /* prior.py:675: ((x - a) / (b - a)) % 1 * (b - a) + a, Python float modulo */
+    double w = hi - lo;
+    double y = (t - lo) / w;
+    double m = y - floor(y);
+    return m * w + lo;
+}
+
+/* returns 1 if inside the prior support; fills lp, ll (ll only if inside) and optionally
+ * derived[k*d + j] = (L_k^-1 (t - mu_k))_j */
+static int eval_point(const orc_problem* p, const double* t, double* lp_out, double* ll_out,
+                      double* derived)
+{
+    int d = p->d;
+    int inb = 1;
+    for (int i = 0; i < d; ++i) inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
+    if (!inb) { *lp_out = -INFINITY; *ll_out = -INFINITY; return 0; }
+    double s = 0.0;
+    for (int i = 0; i < d; ++i)
+        if (p->kind[i] == 1) {
+            double q = (t[i] - p->loc[i]) / p->scale[i];
+            s = s + fma(-0.5 * q, q, p->mls[i]);
+        }
+    *lp_out = p->uniform_logp + s;
+    int K = p->n_modes;
+    if (K == 0) { *ll_out = 0.0; return 1; }
+    double a[64];
+    double amax = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const double* Li = p->Linv + (size_t)k * d * d;
+        const double* mu = p->mean + (size_t)k * d;
+        double chi2 = 0.0;
+        for (int j = 0; j < d; ++j) {
+            double y = 0.0;
+            for (int i = 0; i <= j; ++i) y = fma(Li[j * d + i], t[i] - mu[i], y);
+            if (derived) derived[k * d + j] = y;
+            chi2 = fma(y, y, chi2);
+        }
+        a[k] = -0.5 * (p->cnorm[k] + chi2);
+        if (a[k] > amax) amax = a[k];
+    }
+    if (K == 1) { *ll_out = a[0]; return 1; }
+    double S = 0.0;
+    for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp(a[k] - amax), S);
+    *ll_out = orc_dlog(S) + amax;
+    return 1;
+}
+
+void orc_evaluate(const orc_problem* p, int n, const double* x, double* logprior,
+                  double* loglike, double* derived)
+{
+    int d = p->d, K = p->n_modes;
+    for (int w = 0; w < n; ++w)
+        eval_point(p, x + (size_t)w * d, logprior + w, loglike + w,
+                   derived ? derived + (size_t)w * K * d : NULL);
+}
+
+/* ------------------------------------------------------------------ walker state */
+typedef struct {
+    double* x;         /* [W][d] walker-major */
+    double* logprior;  /* [W] */
+    double* loglike;   /* [W] */
+    double* logpost;   /* [W] */
+    int32_t* weight;   /* [W] multiplicity of the current point (collection.py:1353-1383) */
+    int32_t* prior_rej;/* [W] mcmc.py:712-713 */
+    int32_t* burn_left;/* [W] mcmc.py:265 */
+    int64_t* n_accept; /* [W] accepted steps */
+    int32_t* stuck;    /* [1] set to 1 + walker if a walker trips max_tries (mcmc.py:717-743) */
+    /* optional emission of accepted rows (mcmc.py:691-707): rows[W][cap][d+4] =
+     * (weight, logpost, logprior, loglike, x...), n_rows[W] */
+    double* rows; int32_t* n_rows; int32_t row_cap;
+} orc_state;
+
+/* the Metropolis bookkeeping shared by the Philox and the injected drivers */
+static inline void commit(const orc_problem* p, orc_state* st, int w, const double* t,
+                          int inb, double lp, double ll, double lt, int accept)
+{
+    int d = p->d;
+    double* x = st->x + (size_t)w * d;
+    if (accept) {
+        if (st->burn_left[w] <= 0) {
+            if (st->rows) {
+                if (st->n_rows[w] < st->row_cap) {
+                    double* row = st->rows + ((size_t)w * st->row_cap + st->n_rows[w]) * (d + 4);
+                    row[0] = (double)st->weight[w]; row[1] = st->logpost[w];
+                    row[2] = st->logprior[w]; row[3] = st->loglike[w];
+                    for (int i = 0; i < d; ++i) row[4 + i] = x[i];
+                }
+                st->n_rows[w] += 1; /* rows beyond the capacity are counted as dropped */
+            }
+        } else {
+            st->burn_left[w] -= 1;
+        }
+        for (int i = 0; i < d; ++i) x[i] = t[i];
+        st->logprior[w] = lp; st->loglike[w] = ll; st->logpost[w] = lt;
+        st->weight[w] = 1; st->prior_rej[w] = 0; st->n_accept[w] += 1;
+    } else {
+        st->weight[w] += 1;
+        if (!inb) st->prior_rej[w] += 1;
+        double max_now = p->max_tries * (st->burn_left[w] > 0 ? 10.0 : 1.0);
+        if ((double)(st->weight[w] - st->prior_rej[w]) > max_now && st->stuck && !*st->stuck)
+            *st->stuck = 1 + w;
+    }
+}
+
+/* one step of walker w with the proposal increment `delta` and the Exp(1) variate
+ * `exp_draw` for the accept test supplied by the caller */
+static inline int step_core(const orc_problem* p, orc_state* st, int w, const double* delta,
+                            double r, double exp_draw)
+{
+    int d = p->d;
+    double t[128];
+    const double* x = st->x + (size_t)w * d;
+    for (int i = 0; i < d; ++i) t[i] = fma(r, delta[i], x[i]);
+    if (p->has_periodic)
+        for (int i = 0; i < d; ++i)
+            if (p->periodic[i]) t[i] = wrap_periodic(t[i], p->lo[i], p->hi[i]);
+    double lp, ll;
+    int inb = eval_point(p, t, &lp, &ll, NULL);
+    double lt = inb ? lp + ll : -INFINITY;
+    int accept;
+    if (!inb || lt == -INFINITY) accept = 0;
+    else if (lt > st->logpost[w]) accept = 1;
+    else accept = exp_draw > (st->logpost[w] - lt) / p->temperature;
+    commit(p, st, w, t, inb, lp, ll, lt, accept);
+    return accept;
+}
+
+/* Tier-A link: walker 0 advances by x += T vec (vec = R[:,i] r scale as drawn by the
+ * reference, proposal.py:69) with the reference's own accept variate (NaN if not drawn) */
+int orc_step_injected(const orc_problem* p, orc_state* st, const double* vec, double exp_draw)
+{
+    int d = p->d;
+    double delta[128];
+    for (int i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (int k = 0; k <= i; ++k) s = fma(p->T[i * d + k], vec[k], s);
+        delta[i] = s;
+    }
+    return step_core(p, st, 0, delta, 1.0, exp_draw);
+}
+
+/* ------------------------------------------------------------------ the ensemble driver */
+/* Advance walkers [0, W) (global ids walker0 + w, groups of p->group_size) by n_steps
+ * steps starting at global step index step0.  Returns total accepts. */
+int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, uint64_t step0,
+                int n_steps, int n_threads)
+{
+    int d = p->d, gs = p->group_size;
+    int G = W / gs;
+    uint32_t k0 = (uint32_t)p->seed, k1 = (uint32_t)(p->seed >> 32);
+    int64_t total = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(static) reduction(+ : total)
+#endif
+    for (int g = 0; g < G; ++g) {
+        uint32_t group = walker0 / (uint32_t)gs + (uint32_t)g;
+        double* V = (double*)malloc(sizeof(double) * (size_t)d * d);
+        uint64_t have_cycle = UINT64_MAX;
+        for (int s = 0; s < n_steps; ++s) {
+            uint64_t step = step0 + (uint64_t)s;
+            uint64_t cycle = step / (uint64_t)d;
+            int col = (int)(step % (uint64_t)d);
+            if (cycle != have_cycle) { orc_basis(p, group, (uint32_t)cycle, V); have_cycle = cycle; }
+            const double* v = V + (size_t)col * d;
+            for (int l = 0; l < gs; ++l) {
+                int w = g * gs + l;
+                uint32_t wd[4];
+                philox4x32_10(k0, k1, walker0 + (uint32_t)w, STREAM_STEP, (uint32_t)step,
+                              (uint32_t)(step >> 32), wd);
+                uint64_t kr = ((uint64_t)wd[1] << 20) | (wd[2] >> 12);
+                uint64_t ka = ((uint64_t)wd[3] << 20) | ((uint64_t)(wd[2] & 0xFFFu) << 8) |
+                              (wd[0] & 0xFFu);
+                double Er = -orc_dlog(u52(kr));
+                double r;
+                if (d == 1) {
+                    /* RandProposer1D (proposal.py:85-93): |N(0,1)| radial part of the
+                     * mixture, random sign; chi(1) = sqrt(2 E) |cos| of a Box-Muller pair */
+                    double sn, cs;
+                    orc_sincos2pi(ka, &sn, &cs);
+                    double rr = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er) * fabs(cs);
+                    r = (wd[0] & 0x80u) ? rr : -rr;
+                } else {
+                    r = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er);
+                }
+                double Ea;
+                if (d == 1) {
+                    uint32_t w2[4];
+                    philox4x32_10(k0, k1, walker0 + (uint32_t)w, STREAM_STEP | 0x100u,
+                                  (uint32_t)step, (uint32_t)(step >> 32), w2);
+                    Ea = -orc_dlog(u52(((uint64_t)w2[0] << 20) | (w2[1] >> 12)));
+                } else {
+                    Ea = -orc_dlog(u52(ka));
+                }
+                total += step_core(p, st, w, v, r, Ea);
+            }
+        }
+        free(V);
+    }
+    return total;
+}
+
+/* ------------------------------------------------------------------ moments (a15) */
+/* Sufficient statistics of the current ensemble state, in the fixed order the device
+ * uses: per group g (walkers ascending) sum_x[g][i] = sum x_i, S_g[i][j] = sum x_i x_j
+ * (fma chains from 0) of x - shift, then pooled S[i][j] += S_g[i][j] over groups ascending. */
+void orc_moments(int d, int W, int gs, const double* x, const double* shift,
+                 double* group_sum, double* pooled_S)
+{
+    int G = W / gs;
+    double* Sg = (double*)malloc(sizeof(double) * (size_t)d * d);
+    for (int g = 0; g < G; ++g) {
+        for (int i = 0; i < d; ++i) {
+            double s = 0.0;
+            for (int l = 0; l < gs; ++l) s = s + (x[((size_t)g * gs + l) * d + i] - shift[i]);
+            group_sum[(size_t)g * d + i] += s;
+        }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = 0.0;
+                for (int l = 0; l < gs; ++l) {
+                    const double* xw = x + ((size_t)g * gs + l) * d;
+                    s = fma(xw[i] - shift[i], xw[j] - shift[j], s);
+                }
+                Sg[i * d + j] = s;
+            }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j <= i; ++j) {
+                pooled_S[i * d + j] += Sg[i * d + j];
+                if (j != i) pooled_S[j * d + i] = pooled_S[i * d + j];
+            }
+    }
+    free(Sg);
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,216 @@
+"""Pins oracle/mcmc_oracle.c (flavour b: C restatement on a Philox stream) to the reference:
+known answers for the generator, libm for the fixed-order math, golden vectors G4/G5 for the
+log-posterior, and a step-by-step replay of reference chains with the reference's own random
+draws injected (through oracle/ref_numpy.py, itself pinned to golden G6)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import cbind as O
+from oracle import ref_numpy as R
+from tests.test_oracle_numpy import PRIORS, replay
+
+
+def ulp_diff(a, b):
+    return abs(a - b) / math.ulp(b) if b != 0 else abs(a - b)
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    assert O.philox(0, 0, 0, 0, 0, 0) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    f = 0xFFFFFFFF
+    assert O.philox(f, f, f, f, f, f) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert O.philox(0xA4093822, 0x299F31D0, 0x243F6A88, 0x85A308D3, 0x13198A2E,
+                    0x03707344) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_dlog_dexp_sincos_against_libm():
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(0, 1, 4000), 10 ** rng.uniform(-300, 300, 2000),
+                         [2.0 ** -53, 1 - 2.0 ** -53, 1.0, 0.5, math.sqrt(0.5), 1e-16]])
+    assert max(ulp_diff(O.dlog(x), math.log(x)) for x in xs) <= 1.0
+    es = np.concatenate([-rng.uniform(0, 40, 4000), -(10 ** rng.uniform(-10, 2.8, 2000)),
+                         [0.0, -1e-300, -707.9]])
+    assert max(ulp_diff(O.dexp(x), math.exp(x)) for x in es) <= 1.0
+    assert O.dexp(-709.0) == 0.0 and O.dexp(-np.inf) == 0.0
+    ks = np.concatenate([rng.integers(0, 2 ** 52, 5000), [0, 2 ** 52 - 1, 2 ** 49, 2 ** 51]])
+    for k in ks:
+        u = (2 * int(k) + 1) * 2.0 ** -53
+        s, c = O.sincos2pi(int(k))
+        # mpmath-free reference: reduce exactly in integers first
+        assert abs(s - math.sin(2 * math.pi * u)) < 5e-16 + 4e-16 * 2 * math.pi * u
+        assert abs(c - math.cos(2 * math.pi * u)) < 5e-16 + 4e-16 * 2 * math.pi * u
+        assert abs(s * s + c * c - 1) < 5e-16
+
+
+def test_haar_matches_numpy_restatement():
+    class FixedNormals:
+        def __init__(self, z):
+            self.z = z
+
+        def standard_normal(self, size):
+            assert size == len(self.z)
+            return self.z.copy()
+
+    rng = np.random.default_rng(1)
+    for d in (2, 3, 7, 30):
+        z = rng.standard_normal((d + 2) * (d - 1) // 2)
+        H = O.haar_from_normals(d, z)
+        Href = R.haar_so_n(d, FixedNormals(z))
+        np.testing.assert_allclose(H, Href, rtol=0, atol=5e-15)
+        np.testing.assert_allclose(H @ H.T, np.eye(d), atol=1e-14)
+        assert np.linalg.det(H) == pytest.approx(1.0, abs=1e-12)
+
+
+def test_basis_is_T_times_haar_and_streams_differ():
+    d = 5
+    cov = np.diag([1.0, 4.0, 0.25, 9.0, 1.0]) + 0.1
+    T = O.proposal_transform(cov, 2.4)
+    p = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, T=T, seed=11)
+    V = p.basis(3, 7)
+    Rm = np.linalg.solve(T, V.T)  # V[c] = T R[:, c]
+    np.testing.assert_allclose(Rm @ Rm.T, np.eye(d), atol=1e-12)
+    assert np.linalg.det(Rm) == pytest.approx(1.0, abs=1e-10)
+    assert not np.allclose(V, p.basis(3, 8)) and not np.allclose(V, p.basis(4, 7))
+    np.testing.assert_array_equal(V, p.basis(3, 7))
+
+
+def test_g4_prior_and_periodic(golden):
+    g = golden("g4_prior")
+    kinds = g["kinds"]
+    a = np.where(kinds == 0, g["bounds"][:, 0], g["loc"])
+    b = np.where(kinds == 0, g["bounds"][:, 1], g["scale"])
+    p = O.Problem(5, kinds, a, b)
+    lp, ll = p.evaluate(g["points"])
+    ref = g["logprior"]
+    assert np.array_equal(np.isinf(lp), np.isinf(ref))
+    m = ~np.isinf(ref)
+    np.testing.assert_allclose(lp[m], ref[m], rtol=4e-16)
+    assert np.all(ll[m] == 0.0) and np.all(np.isinf(ll[~m]))
+
+
+def test_g5_loglike(golden):
+    g = golden("g5_loglike")
+    for tag in ("gm_d2_K1", "gm_d3_K1", "gm_d3_K3", "gm_d4_K2", "gm_d30_K1", "gm_d30_K3",
+                "gm_d100_K1"):
+        means = g[tag + "_means"]
+        K, d = means.shape
+        p = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=means, covs=g[tag + "_covs"],
+                      weights=g[tag + "_weights"] if K > 1 else None)
+        lp, ll, der = p.evaluate(g[tag + "_points"], derived=True)
+        np.testing.assert_allclose(ll, g[tag + "_loglike"], rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(der, g[tag + "_derived"], rtol=1e-9, atol=1e-10)
+    for tag in ("gauss_d3_norm1", "gauss_d27_norm1", "gauss_d27_norm0"):
+        mean = g[tag + "_mean"]
+        d = len(mean)
+        p = O.Problem(d, [0] * d, [-10.0] * d, [10.0] * d, means=mean, covs=g[tag + "_cov"],
+                      normalized=tag.endswith("1"))
+        lp, ll = p.evaluate(g[tag + "_points"])
+        np.testing.assert_allclose(ll, g[tag + "_loglike"], rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize("name,learn", [("quick_nolearn", False), ("fixed3_T2", True),
+                                        ("d30_covmat", False), ("d4_K2", True)])
+def test_injected_replay_of_reference_chains(golden, name, learn):
+    """Tier-A link of the C oracle: fed the reference's own draws (direction*r*scale and the
+    Exp(1) accept variate, in the reference's consumption order), orc_step_injected reproduces
+    the reference chain: identical accept/reject sequence and weights, values to a few ulp,
+    across proposal-covariance updates."""
+    g = golden("g6_traces")
+    chain = replay(g, name, learn, record_draws=True)
+    key = lambda k: g[f"{name}__{k}"]  # noqa: E731
+    pri = PRIORS[name.split("_")[0]]
+    d = len(pri["kinds"])
+    T = float(key("temperature"))
+    prob = O.Problem(d, pri["kinds"], pri["a"], pri["b"], means=key("means"),
+                     covs=key("covs"), weights=key("weights") if len(key("weights")) > 1 else None,
+                     temperature=T, max_tries=float(key("max_tries")),
+                     T=O.proposal_transform(key("cov0"), 1.0))
+    st = O.State(prob, key("x0")[None, :], burn_in=int(key("burn_in")), row_cap=1000)
+    assert st.logpost[0] == pytest.approx(float(key("logpost0")), rel=1e-13)
+    # proposal updates happen when the reference learned: replay them at the same row counts
+    learn_every = int(key("learn_every"))
+    learned = list(g[f"{name}__learned_covs"]) if learn else []
+    prog_R = list(g[f"{name}__progress_Rminus1"])
+    i_check = 0
+    for vec, e in chain.draws:
+        before = int(st.n_rows[0])
+        st.step_injected(vec, e)  # vec already carries r * proposal_scale
+        n = int(st.n_rows[0])
+        if learn and n != before and n % learn_every == 0 and i_check < len(prog_R):
+            # the reference refreshes the proposal when 0 <= R-1 <= 30 here
+            if np.isfinite(prog_R[i_check]) and prog_R[i_check] <= 30.0 and learned:
+                prob.set_T(O.proposal_transform(learned.pop(0), 1.0))
+            i_check += 1
+    rows = st.drain()
+    data = key("data")
+    cols = [str(c) for c in key("columns")]
+    assert len(rows) == len(data)
+    assert np.array_equal(rows[:, 1], data[:, cols.index("weight")])
+    np.testing.assert_allclose(rows[:, 5:], data[:, 2:2 + d], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(-rows[:, 2] / T, data[:, cols.index("minuslogpost")],
+                               rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(-rows[:, 3], data[:, cols.index("minuslogprior")],
+                               rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(-2 * rows[:, 4], data[:, cols.index("chi2")], rtol=1e-11,
+                               atol=1e-10)
+
+
+def test_radial_law_of_the_philox_stream():
+    """G3: P(exponential branch) = 0.33, and the mixture's moments (proposal.py:71-82):
+    E r = 0.33*1 + 0.67*sqrt(pi/2), E r^2 = 0.33*2 + 0.67*2."""
+    n = 200_000
+    r = np.empty(n)
+    expo = np.empty(n, bool)
+    for i in range(n):
+        w = O.philox(5, 6, i, 0, 0, 0)
+        kr = (w[1] << 20) | (w[2] >> 12)
+        E = -O.dlog((2 * kr + 1) * 2.0 ** -53)
+        expo[i] = (w[0] >> 8) < 5536481
+        r[i] = E if expo[i] else math.sqrt(2 * E)
+    assert abs(expo.mean() - 0.33) < 4 * math.sqrt(0.33 * 0.67 / n)
+    assert r.mean() == pytest.approx(0.33 + 0.67 * math.sqrt(math.pi / 2), abs=0.01)
+    assert (r ** 2).mean() == pytest.approx(2.0, abs=0.03)
+
+
+def test_ensemble_recovers_gaussian_target():
+    """Tier C on the CPU: posterior mean/cov of the d=3 target of tests/common_sampler.py and
+    KL(truth || sample) <= 0.07, the reference's own bar (common_sampler.py:18,152-161)."""
+    mean = np.array([-0.48591462, 0.10064559, 0.64406749])
+    cov = np.array([[0.00078333, 0.00033134, -0.0002923],
+                    [0.00033134, 0.00218118, -0.00170728],
+                    [-0.0002923, -0.00170728, 0.00676922]])
+    d, W = 3, 1024
+    prob = O.Problem(d, [0] * d, [-1.0] * d, [1.0] * d, means=mean, covs=cov,
+                     T=O.proposal_transform(cov, 2.4), seed=42)
+    rng = np.random.default_rng(0)
+    x0 = mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov))
+    st = O.State(prob, x0)
+    st.run(300, n_threads=4)
+    gs, S, n = None, None, 0
+    for _ in range(60):
+        st.run(3 * d, n_threads=4)
+        gs, S = O.moments(st.x, 64, group_sum=gs, pooled=S)
+        n += W
+    m = gs.sum(0) / n
+    c = S / n - np.outer(m, m)
+    acc = st.n_accept.sum() / (W * st.step)
+    assert 0.15 < acc < 0.5
+    assert np.all(np.abs(m - mean) < 4 * np.sqrt(np.diag(cov) / (n / 10)))
+    kl = 0.5 * (np.trace(np.linalg.solve(c, cov)) + (m - mean) @ np.linalg.solve(c, m - mean)
+                - d + np.linalg.slogdet(c)[1] - np.linalg.slogdet(cov)[1])
+    assert kl < 0.07 and kl < 0.005
+    np.testing.assert_allclose(c, cov, rtol=0.08, atol=2e-5)
+
+
+def test_moments_fixed_order_matches_numpy():
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(256, 5))
+    shift = x.mean(0)
+    gs, S = O.moments(x, 64, shift=shift)
+    xc = x - shift
+    np.testing.assert_allclose(gs, xc.reshape(4, 64, 5).sum(1), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(S, xc.T @ xc, rtol=1e-13)
+    gs2, S2 = O.moments(x, 64, shift=shift, group_sum=gs.copy(), pooled=S.copy())
+    np.testing.assert_allclose(S2, 2 * S, rtol=1e-15)
