@@ -1,0 +1,314 @@
+"""ctypes binding of libmcmc_hip.so (include/mcmc_hip.h) and a thin object wrapper.
+
+The engine has NO CPU fallback: if the shared library is missing, or no gfx950 device is
+usable, construction raises `EngineError` -- loudly, by design.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libmcmc_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+OK, ERR_ARG, ERR_DEVICE, ERR_NOT_PD, ERR_STATE, ERR_STUCK = 0, -1, -2, -3, -4, -5
+
+
+class EngineError(RuntimeError):
+    """Any failure reported by libmcmc_hip (carries the C error code in `.code`)."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+class NotPositiveDefinite(EngineError):
+    pass
+
+
+class ChainStuck(EngineError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("d", C.c_int32), ("n_walkers", C.c_int32), ("group_size", C.c_int32),
+        ("device", C.c_int32), ("seed", C.c_uint64), ("walker_offset", C.c_uint32),
+        ("burn_in", C.c_int32), ("temperature", C.c_double), ("proposal_scale", C.c_double),
+        ("max_tries", C.c_double), ("emit_capacity", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/mcmc_hip.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = [
+    ("mcmc_hip_version", C.c_char_p, []),
+    ("mcmc_hip_last_error", C.c_char_p, [_H]),
+    ("mcmc_hip_dim_supported", C.c_int, [C.c_int]),
+    ("mcmc_hip_create", C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    ("mcmc_hip_destroy", None, [_H]),
+    ("mcmc_hip_set_prior", C.c_int, [_H, c_int32_p, c_double_p, c_double_p, c_int32_p]),
+    ("mcmc_hip_set_target_gaussian_mixture", C.c_int,
+     [_H, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    ("mcmc_hip_set_target_gaussian", C.c_int, [_H, c_double_p, c_double_p, C.c_int32]),
+    ("mcmc_hip_set_target_one", C.c_int, [_H]),
+    ("mcmc_hip_set_proposal_cov", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_get_proposal_cov", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_get_proposal_transform", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_evaluate", C.c_int, [_H, C.c_int32, c_double_p, c_double_p, c_double_p,
+                                    c_double_p]),
+    ("mcmc_hip_set_state", C.c_int, [_H, c_double_p, c_int32_p]),
+    ("mcmc_hip_get_state", C.c_int, [_H, c_double_p, c_double_p, c_double_p, c_double_p,
+                                     c_int32_p]),
+    ("mcmc_hip_step", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_sync", C.c_int, [_H]),
+    ("mcmc_hip_get_counters", C.c_int, [_H, c_int64_p]),
+    ("mcmc_hip_drain_samples", C.c_int, [_H, c_double_p, C.c_int64, c_int64_p]),
+    ("mcmc_hip_get_derived_constants", C.c_int, [_H, c_double_p, c_double_p, c_double_p,
+                                                 c_double_p, c_double_p]),
+    ("mcmc_hip_set_moment_shift", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_accumulate_moments", C.c_int, [_H]),
+    ("mcmc_hip_read_moments", C.c_int, [_H, c_int64_p, c_double_p, c_double_p, C.c_int32]),
+    ("mcmc_hip_gelman_rubin", C.c_int, [C.c_int32, C.c_double, C.c_double, c_double_p,
+                                        c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("mcmc_hip_enable_timing", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
+]
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libmcmc_hip.so and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise EngineError(ERR_DEVICE,
+                          f"{path} not found: build it with `python -m cobaya_amd.build` "
+                          "(hipcc, gfx950). mcmc_hip has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int32_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected array of shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm):
+    """R-1 of means and the N-weighted mean of covariances from reduced sufficient
+    statistics (mcmc.py:856-889).  Raises NotPositiveDefinite where the reference skips the
+    update on LinAlgError (mcmc.py:870-887)."""
+    lib = load_library()
+    sum_mean = _f64(sum_mean)
+    d = len(sum_mean)
+    sum_Ncov, sum_mm = _f64(sum_Ncov, (d, d)), _f64(sum_mm, (d, d))
+    R = C.c_double()
+    W = np.empty((d, d))
+    rc = lib.mcmc_hip_gelman_rubin(d, float(n_chains), float(sum_N), _dp(sum_Ncov),
+                                   _dp(sum_mean), _dp(sum_mm), C.byref(R), _dp(W))
+    if rc == ERR_NOT_PD:
+        raise NotPositiveDefinite(rc, "Negative covariance eigenvectors / not enough "
+                                      "information in the samples to compute R-1")
+    if rc:
+        raise EngineError(rc, "gelman_rubin: invalid arguments")
+    return R.value, W
+
+
+class Engine:
+    """One walker ensemble on one MI355X (one handle of the C ABI)."""
+
+    def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
+                 burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
+                 emit_capacity=0):
+        self._lib = load_library()
+        self._h = _H()
+        self.d, self.W, self.group_size = int(d), int(n_walkers), int(group_size)
+        self.G = self.W // self.group_size if self.group_size else 0
+        self.K = None
+        self.walker_offset = int(walker_offset)
+        cfg = Config(d=d, n_walkers=n_walkers, group_size=group_size, device=device,
+                     seed=int(seed) & (2 ** 64 - 1), walker_offset=walker_offset,
+                     burn_in=int(burn_in), temperature=float(temperature),
+                     proposal_scale=float(proposal_scale),
+                     max_tries=float(max_tries if max_tries is not None else 40 * d),
+                     emit_capacity=int(emit_capacity), reserved=0)
+        self.cfg = cfg
+        rc = self._lib.mcmc_hip_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            msg = self._lib.mcmc_hip_last_error(None).decode()
+            self._h = _H()
+            raise EngineError(rc, f"mcmc_hip_create failed: {msg}")
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.mcmc_hip_last_error(self._h).decode()
+        cls = {ERR_NOT_PD: NotPositiveDefinite, ERR_STUCK: ChainStuck}.get(rc, EngineError)
+        raise cls(rc, msg)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mcmc_hip_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- problem
+    def set_prior(self, kinds, a, b, periodic=None):
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        a, b = _f64(a, (self.d,)), _f64(b, (self.d,))
+        per = (np.zeros(self.d, np.int32) if periodic is None
+               else np.ascontiguousarray(periodic, dtype=np.int32))
+        self._check(self._lib.mcmc_hip_set_prior(self._h, _ip(kinds), _dp(a), _dp(b), _ip(per)))
+
+    def set_target_gaussian_mixture(self, means, covs, weights=None):
+        means = _f64(np.atleast_2d(means))
+        K = len(means)
+        covs = _f64(covs).reshape(K, self.d, self.d)
+        w = None if weights is None else _f64(np.atleast_1d(weights), (K,))
+        self._check(self._lib.mcmc_hip_set_target_gaussian_mixture(
+            self._h, K, _dp(means), _dp(covs), _dp(w) if w is not None else None))
+        self.K = K
+
+    def set_target_gaussian(self, mean, cov, normalized=True):
+        mean, cov = _f64(mean, (self.d,)), _f64(cov, (self.d, self.d))
+        self._check(self._lib.mcmc_hip_set_target_gaussian(self._h, _dp(mean), _dp(cov),
+                                                           int(bool(normalized))))
+        self.K = 1
+
+    def set_target_one(self):
+        self._check(self._lib.mcmc_hip_set_target_one(self._h))
+        self.K = 0
+
+    def derived_constants(self):
+        d, K = self.d, max(self.K or 0, 0)
+        u = C.c_double()
+        mls = np.empty(d)
+        Linv, cn, w = np.empty((max(K, 1), d, d)), np.empty(max(K, 1)), np.empty(max(K, 1))
+        self._check(self._lib.mcmc_hip_get_derived_constants(
+            self._h, C.byref(u), _dp(mls), _dp(Linv) if K else None, _dp(cn) if K else None,
+            _dp(w) if K else None))
+        return {"uniform_logp": u.value, "mls": mls, "Linv": Linv[:K], "cnorm": cn[:K],
+                "weight": w[:K]}
+
+    def set_proposal_cov(self, cov):
+        cov = _f64(cov, (self.d, self.d))
+        self._check(self._lib.mcmc_hip_set_proposal_cov(self._h, _dp(cov)))
+
+    def get_proposal_cov(self):
+        out = np.empty((self.d, self.d))
+        self._check(self._lib.mcmc_hip_get_proposal_cov(self._h, _dp(out)))
+        return out
+
+    def get_proposal_transform(self):
+        out = np.empty((self.d, self.d))
+        self._check(self._lib.mcmc_hip_get_proposal_transform(self._h, _dp(out)))
+        return out
+
+    # -- evaluation / state
+    def evaluate(self, x, derived=False):
+        x = _f64(np.atleast_2d(x))
+        n = len(x)
+        lp, ll = np.empty(n), np.empty(n)
+        der = np.empty((n, max(self.K or 0, 1) * self.d)) if derived else None
+        self._check(self._lib.mcmc_hip_evaluate(self._h, n, _dp(x), _dp(lp), _dp(ll),
+                                                _dp(der) if derived else None))
+        return (lp, ll, der) if derived else (lp, ll)
+
+    def set_state(self, x):
+        x = _f64(x, (self.W, self.d))
+        bad = C.c_int32()
+        self._check(self._lib.mcmc_hip_set_state(self._h, _dp(x), C.byref(bad)))
+
+    def get_state(self):
+        x = np.empty((self.W, self.d))
+        lpost, lpri, llik = np.empty(self.W), np.empty(self.W), np.empty(self.W)
+        wt = np.empty(self.W, np.int32)
+        self._check(self._lib.mcmc_hip_get_state(self._h, _dp(x), _dp(lpost), _dp(lpri),
+                                                 _dp(llik), _ip(wt)))
+        return {"x": x, "logpost": lpost, "logprior": lpri, "loglike": llik, "weight": wt}
+
+    # -- sampling
+    def step(self, n_steps):
+        self._check(self._lib.mcmc_hip_step(self._h, int(n_steps)))
+
+    def sync(self):
+        self._check(self._lib.mcmc_hip_sync(self._h))
+
+    def counters(self):
+        c = np.zeros(4, np.int64)
+        self._check(self._lib.mcmc_hip_get_counters(self._h, c.ctypes.data_as(c_int64_p)))
+        return {"steps": int(c[0]), "accepted": int(c[1]), "stuck": int(c[2]),
+                "dropped_rows": int(c[3])}
+
+    def drain_samples(self):
+        n = C.c_int64()
+        self._check(self._lib.mcmc_hip_drain_samples(self._h, None, 0, C.byref(n)))
+        rows = np.empty((n.value, self.d + 5))
+        if n.value:
+            self._check(self._lib.mcmc_hip_drain_samples(self._h, _dp(rows), n.value,
+                                                         C.byref(n)))
+        return rows
+
+    # -- moments
+    def set_moment_shift(self, shift):
+        shift = _f64(shift, (self.d,))
+        self._check(self._lib.mcmc_hip_set_moment_shift(self._h, _dp(shift)))
+
+    def accumulate_moments(self):
+        self._check(self._lib.mcmc_hip_accumulate_moments(self._h))
+
+    def read_moments(self, reset=False):
+        n = C.c_int64()
+        gs = np.empty((self.G, self.d))
+        S = np.empty((self.d, self.d))
+        self._check(self._lib.mcmc_hip_read_moments(self._h, C.byref(n), _dp(gs), _dp(S),
+                                                    int(bool(reset))))
+        return n.value, gs, S
+
+    # -- timing
+    def enable_timing(self, on=True):
+        self._check(self._lib.mcmc_hip_enable_timing(self._h, int(bool(on))))
+
+    def kernel_times(self, reset=False):
+        ms = np.zeros(3)
+        n = C.c_int64()
+        self._check(self._lib.mcmc_hip_kernel_times(self._h, _dp(ms), C.byref(n),
+                                                    int(bool(reset))))
+        return {"step_ms": ms[0], "basis_ms": ms[1], "moments_ms": ms[2],
+                "step_launches": n.value}

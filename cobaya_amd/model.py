@@ -1,0 +1,310 @@
+"""Host-side description of the posterior the engine samples: the subset of Cobaya's input
+format the analytic hot path covers (SURVEY.md 8b "Python counterpart").
+
+`ProblemSpec.from_info(info)` reads a Cobaya-style info dict (the form of
+docs/src_examples/quickstart/gaussian.yaml and tests/common_sampler.py:24-50 in the
+reference); `ProblemSpec.from_cobaya_model(model)` introspects a real `cobaya.model.Model`
+when Cobaya itself is importable.  Anything outside the supported subset raises
+`UnsupportedModel` -- never a silent fallback.
+
+Reference behaviour mirrored here (paths relative to the reference checkout):
+  parameter classes        cobaya/parameterization.py (sampled = has `prior`; derived = no value)
+  likelihood param routing cobaya/model.py:1115-1335 (prefix rule 1169-1172)
+  1-d priors               cobaya/prior.py:464-533 ; cobaya/tools.py:611-717 (min/max | dist,loc,scale)
+  reference pdf            cobaya/prior.py:866-961 (initial points), 963-985 (variances)
+  gaussian_mixture         cobaya/likelihoods/gaussian_mixture/gaussian_mixture.py:45-163
+  gaussian / one           cobaya/likelihoods/gaussian/gaussian.py:30-112 ; likelihoods/one/one.py
+"""
+from __future__ import annotations
+
+import numbers
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+class UnsupportedModel(ValueError):
+    """The model is outside what the mcmc_hip kernels cover (analytic Gaussian targets,
+    uniform/normal separable priors, one parameter block)."""
+
+
+@dataclass
+class RefPdf:
+    """Reference pdf of one parameter (prior.py:866-961): a fixed number, a normal, a
+    uniform, or None (= sample the prior)."""
+    kind: str | None = None  # None | "point" | "norm" | "uniform"
+    a: float = np.nan  # point value | loc | min
+    b: float = np.nan  # scale | max
+
+    def variance(self):
+        if self.kind == "norm":
+            return self.b ** 2
+        if self.kind == "uniform":
+            return (self.b - self.a) ** 2 / 12.0
+        return np.nan  # point-like or absent: prior variance is used (prior.py:963-985)
+
+
+def _parse_1d(info, what, allow_number=False):
+    """min/max or dist/loc/scale -> (kind, a, b) with kind in {"uniform","norm"}
+    (tools.py:611-717: `min`/`max` are translated to loc/scale of scipy's uniform)."""
+    if info is None:
+        return None
+    if allow_number and isinstance(info, numbers.Real):
+        return ("point", float(info), np.nan)
+    if isinstance(info, (list, tuple)) and len(info) == 2:
+        return ("uniform", float(info[0]), float(info[1]))
+    if not isinstance(info, dict):
+        raise UnsupportedModel(f"{what}: cannot interpret {info!r}")
+    info = dict(info)
+    dist = str(info.pop("dist", "uniform")).lower()
+    if dist == "uniform":
+        if "min" in info or "max" in info:
+            lo, hi = float(info.pop("min", 0.0)), float(info.pop("max", 1.0))
+        else:
+            lo = float(info.pop("loc", 0.0))
+            hi = lo + float(info.pop("scale", 1.0))
+        if info:
+            raise UnsupportedModel(f"{what}: unknown keys {sorted(info)}")
+        if not hi > lo:
+            raise UnsupportedModel(f"{what}: needs min < max")
+        return ("uniform", lo, hi)
+    if dist == "norm":
+        if "min" in info or "max" in info:
+            raise UnsupportedModel(f"{what}: 'min'|'max' used for an unbounded distribution")
+        loc, scale = float(info.pop("loc", 0.0)), float(info.pop("scale", 1.0))
+        if info:
+            raise UnsupportedModel(f"{what}: unknown keys {sorted(info)}")
+        return ("norm", loc, scale)
+    raise UnsupportedModel(f"{what}: distribution '{dist}' is not supported by mcmc_hip "
+                           "(uniform and norm are)")
+
+
+@dataclass
+class ProblemSpec:
+    sampled: list  # parameter names in info order (= sampler order, mcmc.py:392-393)
+    derived: list
+    kinds: np.ndarray  # 0 uniform, 1 norm
+    a: np.ndarray
+    b: np.ndarray
+    periodic: np.ndarray
+    refs: list  # RefPdf per sampled parameter
+    proposal: list  # `proposal` width or None
+    like_name: str = "one"
+    like_kind: str = "one"  # one | gaussian_mixture | gaussian
+    means: np.ndarray | None = None
+    covs: np.ndarray | None = None
+    weights: np.ndarray | None = None
+    normalized: bool = True
+    has_derived: bool = False
+    labels: dict = field(default_factory=dict)
+
+    @property
+    def d(self):
+        return len(self.sampled)
+
+    @property
+    def n_modes(self):
+        return 0 if self.like_kind == "one" else len(self.means)
+
+    # ----------------------------------------------------------------- prior facts
+    def prior_variances(self):
+        return np.where(self.kinds == 0, (self.b - self.a) ** 2 / 12.0, self.b ** 2)
+
+    def reference_variances(self):
+        """prior.py:963-985: variance of the ref pdf, prior variance where absent."""
+        v = np.array([r.variance() for r in self.refs])
+        return np.where(np.isnan(v), self.prior_variances(), v)
+
+    def bounds(self):
+        inf = np.inf
+        lo = np.where(self.kinds == 0, self.a, -inf)
+        hi = np.where(self.kinds == 0, self.b, inf)
+        return lo, hi
+
+    def sample_reference(self, n, rng, max_tries=1000):
+        """n initial points from the reference pdf, falling back to the prior where no ref
+        is given, redrawn until inside the prior support (prior.py:866-961, vectorised over
+        walkers; model.get_valid_point's finite-posterior retry is done by the caller)."""
+        d = self.d
+        lo, hi = self.bounds()
+        out = np.empty((n, d))
+        todo = np.arange(n)
+        for _ in range(max_tries):
+            m = len(todo)
+            x = np.empty((m, d))
+            for i, r in enumerate(self.refs):
+                if r.kind == "point":
+                    x[:, i] = r.a
+                elif r.kind == "norm":
+                    x[:, i] = r.a + r.b * rng.standard_normal(m)
+                elif r.kind == "uniform":
+                    x[:, i] = rng.uniform(r.a, r.b, m)
+                elif self.kinds[i] == 0:
+                    x[:, i] = rng.uniform(self.a[i], self.b[i], m)
+                else:
+                    x[:, i] = self.a[i] + self.b[i] * rng.standard_normal(m)
+            ok = np.all((x <= hi) & (x >= lo), axis=1)
+            out[todo[ok]] = x[ok]
+            todo = todo[~ok]
+            if not len(todo):
+                return out
+        if all(r.kind == "point" for r in self.refs):
+            raise UnsupportedModel("The reference point provided has null prior. "
+                                   "Set 'ref' to a different point or a pdf.")
+        raise UnsupportedModel("Could not sample from the reference pdf a point with "
+                               f"non-null prior density after {max_tries} tries.")
+
+    # ----------------------------------------------------------------- construction
+    @classmethod
+    def from_info(cls, info):
+        params = info.get("params") or {}
+        if info.get("prior"):
+            raise UnsupportedModel("external priors (`prior:` block) are arbitrary Python "
+                                   "and cannot run on the device")
+        if info.get("theory"):
+            raise UnsupportedModel("theory codes are out of scope for mcmc_hip")
+        sampled, derived, fixed = [], [], {}
+        kinds, a, b, per, refs, props, labels = [], [], [], [], [], [], {}
+        for name, p in params.items():
+            if isinstance(p, numbers.Real):
+                fixed[name] = float(p)
+                continue
+            if isinstance(p, str) or callable(p):
+                raise UnsupportedModel(f"parameter '{name}': function-valued parameters are "
+                                       "not supported")
+            p = dict(p or {})
+            if "value" in p:
+                if isinstance(p["value"], numbers.Real):
+                    fixed[name] = float(p["value"])
+                    continue
+                raise UnsupportedModel(f"parameter '{name}': function-valued parameters are "
+                                       "not supported")
+            if p.get("latex"):
+                labels[name] = p["latex"]
+            if p.get("prior") is None:
+                if p.get("derived", True) is not True:
+                    raise UnsupportedModel(f"parameter '{name}': derived functions are not "
+                                           "supported")
+                derived.append(name)
+                continue
+            if p.get("drop") or p.get("renames"):
+                raise UnsupportedModel(f"parameter '{name}': drop/renames are not supported")
+            kind, pa, pb = _parse_1d(p["prior"], f"prior of '{name}'")
+            sampled.append(name)
+            kinds.append(0 if kind == "uniform" else 1)
+            a.append(pa)
+            b.append(pb)
+            periodic = bool(p.get("periodic", False))
+            if periodic and kind != "uniform":
+                raise UnsupportedModel(f"Parameter '{name}' cannot be periodic if it is not "
+                                       "bounded.")
+            per.append(int(periodic))
+            ref = _parse_1d(p.get("ref"), f"ref of '{name}'", allow_number=True)
+            refs.append(RefPdf(*ref) if ref else RefPdf())
+            props.append(p.get("proposal"))
+        if fixed:
+            raise UnsupportedModel(f"fixed parameters {sorted(fixed)} are not supported by "
+                                   "the analytic likelihoods handled here")
+        if not sampled:
+            raise UnsupportedModel("No parameters being varied for sampler")
+        spec = cls(sampled, derived, np.array(kinds), np.array(a, float), np.array(b, float),
+                   np.array(per), refs, props, labels=labels)
+        likes = info.get("likelihood") or {}
+        if len(likes) != 1:
+            raise UnsupportedModel("exactly one likelihood (gaussian_mixture, gaussian or "
+                                   f"one) is supported, got {list(likes)}")
+        (lname, linfo), = likes.items()
+        linfo = dict(linfo or {})
+        lclass = linfo.pop("class", lname)
+        lclass = str(lclass).split(".")[-1].lower().replace("_", "")
+        spec.like_name = lname
+        d = spec.d
+        in_prefix = linfo.pop("input_params_prefix", "") or ""
+        out_prefix = linfo.pop("output_params_prefix", "") or ""
+        linfo.pop("speed", None)
+        linfo.pop("stop_at_error", None)
+        if lclass == "one":
+            linfo.pop("noise", None)
+            spec.like_kind = "one"
+            if derived:
+                raise UnsupportedModel("derived parameters need a gaussian_mixture with "
+                                       "`derived: True`")
+        elif lclass in ("gaussianmixture", "gaussian"):
+            inputs = [p for p in sampled if p.startswith(in_prefix)]  # model.py:1169-1172
+            if inputs != sampled:
+                raise UnsupportedModel(
+                    f"input_params_prefix '{in_prefix}' selects {inputs} but all sampled "
+                    f"parameters {sampled} must feed the likelihood")
+            if lclass == "gaussianmixture":
+                means, covs = linfo.pop("means", None), linfo.pop("covs", None)
+                if means is None or covs is None:
+                    raise UnsupportedModel("You must specify both a mean (or a list of them) "
+                                           "and a covariance matrix, or a list of them.")
+                means = np.atleast_1d(np.array(means, dtype=float))
+                while means.ndim < 2:
+                    means = means[None]
+                covs = np.atleast_1d(np.array(covs, dtype=float))
+                while covs.ndim < 3:
+                    covs = covs[None]
+                weights = linfo.pop("weights", None)
+                spec.has_derived = bool(linfo.pop("derived", False))
+                spec.like_kind = "gaussian_mixture"
+            else:
+                mean, cov = linfo.pop("mean", None), linfo.pop("cov", None)
+                if mean is None or cov is None:
+                    raise UnsupportedModel("You must specify both a mean and a covariance "
+                                           "matrix.")
+                means = np.atleast_1d(np.array(mean, dtype=float))[None]
+                covs = np.atleast_2d(np.array(cov, dtype=float))[None]
+                weights = None
+                spec.normalized = bool(linfo.pop("normalized", True))
+                spec.like_kind = "gaussian"
+            if linfo:
+                raise UnsupportedModel(f"unknown options for likelihood '{lname}': "
+                                       f"{sorted(linfo)}")
+            K = len(means)
+            if covs.shape != (K, means.shape[1], means.shape[1]):
+                raise UnsupportedModel("The dimensionalities guessed from mean(s) and "
+                                       "cov(s) do not match!")
+            if means.shape[1] != d:
+                raise UnsupportedModel(
+                    f"The dimensionality is {means.shape[1]} (guessed from given means and "
+                    f"covmats) but was passed {d} parameters instead.")
+            if weights is not None and not np.isscalar(weights):
+                weights = np.array(weights, dtype=float)
+                if len(weights) != K:
+                    raise UnsupportedModel("There must be as many weights as components.")
+            else:
+                weights = None
+            spec.means, spec.covs, spec.weights = means, covs, weights
+            outs = [p for p in derived if p.startswith(out_prefix)]
+            if spec.has_derived:
+                if len(outs) != d * K or outs != derived:
+                    raise UnsupportedModel(
+                        "The number of derived parameters must be equal to the "
+                        f"dimensionality times the number of modes, i.e. {d} x {K} = "
+                        f"{d * K}, but was given {len(derived)} derived parameters.")
+            elif derived:
+                raise UnsupportedModel("Derived parameters were requested, but 'derived' "
+                                       "option is False.")
+        else:
+            raise UnsupportedModel(f"likelihood '{lname}' is not one of gaussian_mixture, "
+                                   "gaussian, one")
+        return spec
+
+    @classmethod
+    def from_cobaya_model(cls, model):
+        """Introspect a real cobaya.model.Model (attributes of SURVEY.md 8b)."""
+        info = model.info()
+        return cls.from_info({"params": info["params"], "likelihood": info["likelihood"],
+                              "prior": info.get("prior"), "theory": info.get("theory")})
+
+    # ----------------------------------------------------------------- engine hookup
+    def configure(self, engine):
+        engine.set_prior(self.kinds, self.a, self.b, self.periodic)
+        if self.like_kind == "one":
+            engine.set_target_one()
+        elif self.like_kind == "gaussian":
+            engine.set_target_gaussian(self.means[0], self.covs[0], self.normalized)
+        else:
+            engine.set_target_gaussian_mixture(self.means, self.covs, self.weights)

@@ -1,0 +1,268 @@
+"""GPU parity (Tier B): the HIP path, called through the C ABI, against the CPU oracle
+(oracle/mcmc_oracle.c) on the same seeded inputs -- BIT-EXACT for the walker state, the
+log-posterior values, integer weights, accept counts and emitted rows; and against the golden
+vectors generated from the reference (G4/G5) for the batch evaluator."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from cobaya_amd import engine as E  # noqa: E402
+from oracle import cbind as O  # noqa: E402
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    bad = bits(a) != bits(b)
+    assert not bad.any(), (f"{what}: {bad.sum()} of {bad.size} values differ; first "
+                           f"{a[bad][:3]} vs {b[bad][:3]}")
+
+
+def random_target(d, K, rng, spread=0.05):
+    means = rng.uniform(0.35, 0.65, size=(K, d))
+    covs = []
+    for _ in range(K):
+        A = rng.normal(size=(d, d))
+        c = A @ A.T / d + np.eye(d) * 0.5
+        s = rng.uniform(0.5, 1.5, size=d) * spread
+        covs.append(c * np.outer(s, s))
+    return means, np.array(covs)
+
+
+def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, T=1.0,
+              burn_in=0, cap=0, weights=None, normalized=True, rng=None, walker_offset=0,
+              max_tries=None):
+    rng = rng or np.random.default_rng(100 + d)
+    kinds = [0] * d if kinds is None else kinds
+    a = [0.0] * d if a is None else a
+    b = [1.0] * d if b is None else b
+    eng = E.Engine(d, W, group_size=gs, seed=seed, temperature=T, burn_in=burn_in,
+                   emit_capacity=cap, walker_offset=walker_offset, max_tries=max_tries)
+    eng.set_prior(kinds, a, b, periodic)
+    if K == 0:
+        eng.set_target_one()
+        means = covs = None
+    else:
+        means, covs = random_target(d, K, rng)
+        if K == 1 and not normalized:
+            eng.set_target_gaussian(means[0], covs[0], normalized=False)
+        else:
+            eng.set_target_gaussian_mixture(means, covs, weights)
+    pcov = (covs[0] if K else np.diag(np.full(d, 0.01))) * T
+    eng.set_proposal_cov(pcov)
+    prob = O.Problem(d, kinds, a, b, periodic=periodic, means=means, covs=covs,
+                     weights=weights, normalized=normalized, T=eng.get_proposal_transform(),
+                     group_size=gs, seed=seed, temperature=T, max_tries=max_tries,
+                     derived=eng.derived_constants())
+    m0 = means[0] if K else np.full(d, 0.5)
+    s0 = np.sqrt(np.diag(covs[0])) if K else np.full(d, 0.1)
+    x0 = np.clip(m0 + rng.normal(size=(W, d)) * s0, 1e-3, 1 - 1e-3)
+    if kinds is not None:
+        for i, k in enumerate(kinds):
+            if k == 1:
+                x0[:, i] = a[i] + rng.normal(size=W) * b[i]
+    eng.set_state(x0)
+    st = O.State(prob, x0, burn_in=burn_in, row_cap=cap)
+    return eng, prob, st
+
+
+def compare_state(eng, st):
+    s = eng.get_state()
+    assert_bit_equal(s["x"], st.x, "x")
+    assert_bit_equal(s["logpost"], st.logpost, "logpost")
+    assert_bit_equal(s["logprior"], st.logprior, "logprior")
+    assert_bit_equal(s["loglike"], st.loglike, "loglike")
+    assert np.array_equal(s["weight"], st.weight)
+
+
+def test_library_reports_gfx950():
+    lib = E.load_library()
+    assert b"gfx950" in lib.mcmc_hip_version()
+
+
+def test_initial_evaluation_bit_exact():
+    eng, prob, st = make_pair(30, 256, 64)
+    compare_state(eng, st)
+
+
+@pytest.mark.parametrize("d,W,gs,K,steps", [
+    (30, 512, 64, 1, 95), (2, 256, 64, 1, 41), (3, 256, 128, 1, 50), (30, 512, 256, 1, 61),
+    (4, 256, 64, 2, 60), (30, 256, 64, 3, 45), (5, 256, 64, 0, 40), (1, 256, 64, 1, 30),
+    (27, 256, 64, 1, 60), (32, 256, 64, 1, 40)])
+def test_steps_bit_exact(d, W, gs, K, steps):
+    eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.2, 0.8] if K == 2 else None)
+    # several launches that start and stop mid-cycle
+    for n in (1, steps // 3, steps - steps // 3 - 1):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+    c = eng.counters()
+    assert c["steps"] == steps and c["accepted"] == int(st.n_accept.sum())
+    assert 0.05 < c["accepted"] / (W * steps) < 0.9
+
+
+def test_general_priors_periodic_temperature_bit_exact():
+    d = 6
+    kinds = [0, 1, 0, 1, 0, 0]
+    a = [0.0, 0.5, 0.0, 0.45, -1.0, 0.0]
+    b = [1.0, 0.2, 1.0, 0.02, 2.0, 1.0]
+    periodic = [0, 0, 1, 0, 0, 0]
+    eng, prob, st = make_pair(d, 256, 64, kinds=kinds, a=a, b=b, periodic=periodic, T=2.0,
+                              burn_in=3)
+    eng.step(77)
+    eng.sync()
+    st.run(77, n_threads=4)
+    compare_state(eng, st)
+
+
+def test_emitted_rows_and_burn_in_bit_exact():
+    eng, prob, st = make_pair(3, 128, 64, burn_in=2, cap=64)
+    for n in (40, 37):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=2)
+        rows, ref = eng.drain_samples(), st.drain()
+        assert rows.shape == ref.shape and len(rows) > 128
+        assert_bit_equal(rows, ref, "rows")
+    assert eng.counters()["dropped_rows"] == 0
+    # weights are multiplicities: per walker they sum to the steps spent at emitted points
+    assert rows[:, 1].min() >= 1
+
+
+def test_walker_offset_shards_reproduce_the_whole():
+    """Multi-GPU sharding: walkers [256, 512) run as a shard with
+    walker_offset=256 are bit-identical to the same walkers inside a 512-walker ensemble."""
+    full, _, _ = make_pair(8, 512, 64, rng=np.random.default_rng(5))
+    x0 = full.get_state()["x"]
+    full.step(50)
+    full.sync()
+    part, _, _ = make_pair(8, 256, 64, rng=np.random.default_rng(5), walker_offset=256)
+    part.set_state(x0[256:])
+    part.step(50)
+    part.sync()
+    assert_bit_equal(part.get_state()["x"], full.get_state()["x"][256:], "shard")
+
+
+def test_moments_bit_exact():
+    eng, prob, st = make_pair(30, 512, 64)
+    shift = st.x.mean(0)
+    eng.set_moment_shift(shift)
+    gs = S = None
+    for _ in range(3):
+        eng.step(30)
+        eng.accumulate_moments()
+        st.run(30, n_threads=4)
+        gs, S = O.moments(st.x, 64, shift=shift, group_sum=gs, pooled=S)
+    n, g_gs, g_S = eng.read_moments(reset=True)
+    assert n == 3
+    assert_bit_equal(g_gs, gs, "group sums")
+    assert_bit_equal(g_S, S, "pooled second moments")
+    n, g_gs, g_S = eng.read_moments()
+    assert n == 0 and not g_gs.any() and not g_S.any()
+
+
+def test_evaluator_against_reference_goldens(golden):
+    """model.logposterior parity: device evaluator vs values produced by the reference."""
+    g = golden("g5_loglike")
+    for tag in ("gm_d2_K1", "gm_d3_K3", "gm_d4_K2", "gm_d30_K1", "gm_d30_K3"):
+        means = g[tag + "_means"]
+        K, d = means.shape
+        eng = E.Engine(d, 64, group_size=64)
+        eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
+        eng.set_target_gaussian_mixture(means, g[tag + "_covs"],
+                                        g[tag + "_weights"] if K > 1 else None)
+        lp, ll, der = eng.evaluate(g[tag + "_points"], derived=True)
+        assert np.all(lp == 0.0)
+        np.testing.assert_allclose(ll, g[tag + "_loglike"], rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(der, g[tag + "_derived"], rtol=1e-9, atol=1e-10)
+    for tag in ("gauss_d3_norm1", "gauss_d27_norm1", "gauss_d27_norm0"):
+        mean = g[tag + "_mean"]
+        d = len(mean)
+        eng = E.Engine(d, 64, group_size=64)
+        eng.set_prior([0] * d, [-10.0] * d, [10.0] * d)
+        eng.set_target_gaussian(mean, g[tag + "_cov"], normalized=tag.endswith("1"))
+        lp, ll = eng.evaluate(g[tag + "_points"])
+        np.testing.assert_allclose(ll, g[tag + "_loglike"], rtol=1e-12, atol=1e-11)
+    g4 = golden("g4_prior")
+    kinds = g4["kinds"]
+    a = np.where(kinds == 0, g4["bounds"][:, 0], g4["loc"])
+    b = np.where(kinds == 0, g4["bounds"][:, 1], g4["scale"])
+    eng = E.Engine(5, 64, group_size=64)
+    eng.set_prior(kinds, a, b, g4["periodic"])
+    eng.set_target_one()
+    lp, ll = eng.evaluate(g4["points"])
+    ref = g4["logprior"]
+    assert np.array_equal(np.isinf(lp), np.isinf(ref))
+    m = ~np.isinf(ref)
+    np.testing.assert_allclose(lp[m], ref[m], rtol=4e-16)
+
+
+def test_errors_are_loud():
+    with pytest.raises(E.EngineError):
+        E.Engine(30, 100, group_size=64)  # not a multiple of the group size
+    eng = E.Engine(3, 64)
+    eng.set_prior([0] * 3, [0.0] * 3, [1.0] * 3)
+    with pytest.raises(E.NotPositiveDefinite):
+        eng.set_target_gaussian_mixture([[0.5] * 3], [np.array([[1, 2, 0], [2, 1, 0],
+                                                                 [0, 0, 1.0]])])
+    eng.set_target_one()
+    with pytest.raises(E.NotPositiveDefinite):
+        eng.set_proposal_cov(np.array([[1, 2, 0], [2, 1, 0], [0, 0, 1.0]]))
+    with pytest.raises(E.EngineError):
+        eng.step(1)  # no state yet
+    with pytest.raises(E.EngineError):
+        eng.set_state(np.full((64, 3), 2.0))  # outside the prior: non-finite posterior
+
+
+def test_stuck_chain_is_reported():
+    """mcmc.py:717-743: a proposal far too wide trips max_tries."""
+    d = 3
+    eng = E.Engine(d, 64, max_tries=20)
+    eng.set_prior([0] * d, [-50.0] * d, [50.0] * d)
+    eng.set_target_gaussian_mixture([[0.0] * d], [np.eye(d) * 1e-6])
+    eng.set_proposal_cov(np.eye(d) * 100.0)
+    eng.set_state(np.zeros((64, d)))
+    eng.step(400)
+    with pytest.raises(E.ChainStuck):
+        eng.sync()
+
+
+def test_posterior_moments_full_size():
+    """Tier C at BASELINE config-2 size: 65 536 walkers, d=30 target of the golden fixture;
+    mean within 1% of sigma and covariance within 1% (north star) after >= 1e6 accepted."""
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden",
+                                           "targets.npz"))
+    mean, cov = g["mean_d30"], g["cov_d30"]
+    d, W = 30, 65536
+    eng = E.Engine(d, W, group_size=64, seed=1)
+    eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
+    eng.set_target_gaussian_mixture([mean], [cov])
+    eng.set_proposal_cov(cov)
+    rng = np.random.default_rng(1)
+    x0 = mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov))
+    eng.set_state(np.clip(x0, 1e-6, 1 - 1e-6))
+    eng.step(40 * d)  # burn-in from the (narrower than posterior) ref pdf
+    eng.set_moment_shift(mean)
+    for _ in range(24):
+        eng.step(4 * d)
+        eng.accumulate_moments()
+    eng.sync()
+    n, gs, S = eng.read_moments()
+    N = n * W
+    m = gs.sum(0) / N
+    c = S / N - np.outer(m, m)
+    acc = eng.counters()["accepted"]
+    assert acc >= 1e6
+    sig = np.sqrt(np.diag(cov))
+    assert np.max(np.abs(m) / sig) < 0.01           # shift = true mean
+    corr_err = (c - cov) / np.outer(sig, sig)
+    assert np.max(np.abs(corr_err)) < 0.01
+    kl = 0.5 * (np.trace(np.linalg.solve(c, cov)) + m @ np.linalg.solve(c, m) - d
+                + np.linalg.slogdet(c)[1] - np.linalg.slogdet(cov)[1])
+    assert kl < 0.07 and kl < 1e-3

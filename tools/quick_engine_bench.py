@@ -1,0 +1,35 @@
+"""Developer probe: raw engine throughput (no learn checkpoints). Not the judged bench."""
+import sys, time, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cobaya_amd import engine as E
+
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+gs = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+spl = int(sys.argv[4]) if len(sys.argv) > 4 else 10 * d
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "targets.npz"))
+if d in (30, 100):
+    mean, cov = g[f"mean_d{d}"], g[f"cov_d{d}"]
+else:
+    rng = np.random.default_rng(d); A = rng.normal(size=(d, d)); cov = (A @ A.T / d + np.eye(d)) * 1e-3; mean = np.full(d, 0.5)
+eng = E.Engine(d, W, group_size=gs, seed=1)
+eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
+eng.set_target_gaussian_mixture([mean], [cov])
+eng.set_proposal_cov(cov)
+rng = np.random.default_rng(1)
+eng.set_state(np.clip(mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov)), 1e-6, 1 - 1e-6))
+eng.enable_timing(True)
+eng.step(spl); eng.sync(); eng.kernel_times(reset=True)
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    eng.step(spl)
+    eng.accumulate_moments()
+eng.sync()
+dt = time.perf_counter() - t0
+kt = eng.kernel_times()
+ev = W * spl * n
+print(f"d={d} W={W} gs={gs} spl={spl}: {ev/dt:.3e} evals/s wall; step kernel {kt['step_ms']/n:.3f} ms/launch "
+      f"=> {W*spl/(kt['step_ms']/n*1e-3):.3e} evals/s; basis {kt['basis_ms']/n:.3f} ms; moments {kt['moments_ms']/n:.3f} ms; "
+      f"acc={eng.counters()['accepted']/(W*spl*(n+1)):.3f}")
