@@ -250,7 +250,7 @@ int upload_constants(mcmc_hip_ctx* h)
     if (!h->have_prior || !h->have_target) return MCMC_HIP_OK;
     const int d = h->d, K = h->K;
     const ConstLayout cl{d, K};
-    std::vector<double> c((size_t)cl.size() + 2, 0.0);
+    std::vector<double> c((size_t)cl.size() + 16, 0.0);
     for (int i = 0; i < d; ++i) {
         c[cl.lo() + i] = h->lo[i];
         c[cl.hi() + i] = h->hi[i];
@@ -262,9 +262,9 @@ int upload_constants(mcmc_hip_ctx* h)
         for (int i = 0; i < d; ++i) c[cl.mean(k) + i] = h->mean[(size_t)k * d + i];
         c[cl.cnorm() + k] = h->cnorm[k];
         c[cl.weight() + k] = h->weight[k];
-        for (int j = 0; j < d; ++j)
-            for (int i = 0; i <= j; ++i)
-                c[cl.linv(k) + mcmc::tri_row_off(j) + i] = h->Linv[((size_t)k * d + j) * d + i];
+        const double* Lk = h->Linv.data() + (size_t)k * d * d;
+        double* dst = c.data() + cl.linv(k);
+        mcmc::tri_stream_for_each(d, [&](int idx, int j, int i) { dst[idx] = Lk[(size_t)j * d + i]; });
     }
     HIP_TRY(h, h->cblock.resize(c.size()));
     HIP_TRY(h, hipMemcpyAsync(h->cblock.p, c.data(), sizeof(double) * c.size(),
@@ -276,8 +276,8 @@ int upload_constants(mcmc_hip_ctx* h)
 int lds_check(mcmc_hip_ctx* h)
 {
     const ConstLayout cl{h->d, h->K};
-    const size_t lds = sizeof(double) * ((size_t)cl.size() + 2 + (size_t)h->d * h->d + 1 +
-                                         (h->K > 1 ? (size_t)h->K * h->gs : 0));
+    (void)cl;
+    const size_t lds = sizeof(double) * (h->K > 1 ? (size_t)h->K * h->gs : 0);
     if (lds > 64 * 1024)
         return fail(h, MCMC_HIP_ERR_ARG,
                     "problem constants need %zu bytes of LDS per workgroup (> 64 KiB): fewer "

@@ -8,19 +8,27 @@ namespace mcmc {
 constexpr int kMaxDimLane = 32;   // lane-per-walker kernels: d <= 32 (state in VGPRs)
 constexpr int kMaxModes = 16;
 
-// Packed lower-triangular storage with rows padded to an even number of doubles so that
-// every row starts 16-byte aligned (ds_read_b128-able): row j holds i = 0..j.
-__host__ __device__ constexpr int tri_row_off(int j)
-{
-    int o = 0;
-    for (int r = 0; r < j; ++r) o += (r + 2) & ~1;
-    return o;
-}
-__host__ __device__ constexpr int tri_size(int d) { return tri_row_off(d); }
+// Whitening factor L_k^-1 (lower triangular) packed in the order the kernels consume it, so
+// that the wave-uniform operand stream is read front to back with wide scalar loads:
+//   for jb = 0, RB, 2RB, ... (row blocks of RB rows)
+//     for i = 0 .. min(jb + RB, d) - 1
+//       for r = 0 .. RB-1 with jb + r < d and i <= jb + r:   L[jb + r][i]
+constexpr int kRowBlock = 4;
+__host__ __device__ constexpr int tri_size(int d) { return d * (d + 1) / 2; }
 
-// Constant block (doubles), identical in HBM and in LDS:
+template <typename F>
+__host__ __device__ inline void tri_stream_for_each(int d, F&& f)
+{
+    int idx = 0;
+    for (int jb = 0; jb < d; jb += kRowBlock)
+        for (int i = 0; i < jb + kRowBlock && i < d; ++i)
+            for (int r = 0; r < kRowBlock; ++r)
+                if (jb + r < d && i <= jb + r) f(idx++, jb + r, i);
+}
+
+// Constant block (doubles) in HBM, read through the scalar data cache:
 //   lo[d] hi[d] loc[d] scale[d] mls[d] | per mode k: mean[d] | cnorm[K] weight[K] |
-//   per mode k: Linv packed (tri_size(d))
+//   per mode k: Linv stream (tri_size(d))
 struct ConstLayout {
     int d, K;
     __host__ __device__ int lo() const { return 0; }
@@ -33,7 +41,7 @@ struct ConstLayout {
     __host__ __device__ int weight() const { return cnorm() + K; }
     __host__ __device__ int linv(int k) const
     {
-        return ((weight() + K + 1) & ~1) + k * tri_size(d);
+        return ((weight() + K + 7) & ~7) + k * ((tri_size(d) + 7) & ~7);
     }
     __host__ __device__ int size() const { return linv(K); }
 };

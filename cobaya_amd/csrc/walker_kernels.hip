@@ -1,10 +1,11 @@
 // Lane-per-walker Metropolis kernels for one compile-time dimension MCMC_D (gfx950).
 //
 // One wavefront lane owns one walker: its parameter vector x[D] and trial t[D] live in
-// VGPRs (all loops over D are fully unrolled), the cycle's proposal directions V, the
-// inverse-Cholesky whitening rows, means and prior bounds are staged once in LDS and read
-// as wave-uniform broadcasts, and n_steps Metropolis steps are fused into one launch so
-// that the state crosses HBM once per launch (coalesced, dimension-major).
+// VGPRs (all loops over D are fully unrolled); everything the 64 lanes share -- the cycle's
+// proposal directions V, the inverse-Cholesky whitening stream, means and prior bounds --
+// comes in through the scalar data cache as SGPR operands; and n_steps Metropolis steps are
+// fused into one launch so that the state crosses HBM once per launch (coalesced,
+// dimension-major).
 //
 // Restates (paths relative to the reference checkout):
 //   cobaya/samplers/mcmc/mcmc.py:545-562 (step) 670-683 (accept) 685-748 (bookkeeping)
@@ -24,64 +25,68 @@ namespace mcmc {
 namespace {
 
 constexpr int D = MCMC_D;
-constexpr int TRI = tri_size(D);
 constexpr int NPAIR = D * (D + 1) / 2;
 
+// Wave-uniform read-only operands (problem constants, proposal directions) are read through
+// the SCALAR data path: pointers in the constant address space make every load an s_load into
+// SGPRs, which v_fma_f64 / v_cmp_f64 take directly as a source -- no LDS traffic, no VGPRs,
+// no vector-memory issue slots for data that all 64 lanes share.
+typedef const double __attribute__((address_space(4))) * cptr;
+__device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(unsigned long long)p; }
+
 // ---------------------------------------------------------------- log-posterior of a point
-// Single-mode / `one` (K <= 1) body: prior support test, separable prior, triangular
-// whitening y = L^-1 (t - mu) and chi2 = |y|^2 as fma chains in ascending index order.
+// One mode: triangular whitening y = L^-1 (t - mu), chi2 = |y|^2, as fma chains in ascending
+// index order.  Rows are walked kRowBlock at a time so that several independent chains are
+// in flight (one wave per SIMD has no other latency cover); Lk is the operand stream packed
+// in exactly this order (kernels.h tri_stream_for_each).
 template <bool DERIVED>
-__device__ __forceinline__ double mode_logpdf(const double (&t)[D], const double* __restrict__ mu,
-                                              const double* __restrict__ Lk, double cnorm,
-                                              double* derived)
+__device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cptr Lk,
+                                              double cnorm, double* derived)
 {
+    constexpr int RB = kRowBlock;
     double dev[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) dev[i] = t[i] - mu[i];
-    // Rows are walked RB at a time so that RB independent fma chains are in flight (one wave
-    // per SIMD has no other latency cover); each chain still runs i = 0..j in order.
-    constexpr int RB = 4;
-    double y[D];
+    double chi2 = 0.0;
+    int idx = 0;
 #pragma unroll
     for (int jb = 0; jb < D; jb += RB) {
+        double y[RB];
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-            if (jb + r < D) y[jb + r] = 0.0;
+        for (int r = 0; r < RB; ++r) y[r] = 0.0;
 #pragma unroll
-        for (int i = 0; i < jb + RB; ++i) {
+        for (int i = 0; i < jb + RB && i < D; ++i) {
 #pragma unroll
             for (int r = 0; r < RB; ++r)
-                if (jb + r < D && i <= jb + r)
-                    y[jb + r] = fma(Lk[tri_row_off(jb + r) + i], dev[i], y[jb + r]);
+                if (jb + r < D && i <= jb + r) y[r] = fma(Lk[idx++], dev[i], y[r]);
         }
-    }
-    double chi2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        if (DERIVED) derived[j] = y[j];
-        chi2 = fma(y[j], y[j], chi2);
+        for (int r = 0; r < RB; ++r)
+            if (jb + r < D) {
+                if (DERIVED) derived[jb + r] = y[r];
+                chi2 = fma(y[r], y[r], chi2);
+            }
     }
     return -0.5 * (cnorm + chi2);
 }
 
 template <bool MULTI, bool DERIVED, bool GENERAL>
-__device__ __forceinline__ void eval_point(const double (&t)[D], const double* __restrict__ sC,
-                                           const ConstLayout& cl, uint32_t norm_mask,
-                                           double uniform_logp, double* __restrict__ sA,
-                                           int astride, bool& inb, double& lp, double& ll,
-                                           double* derived)
+__device__ __forceinline__ void eval_point(const double (&t)[D], cptr C, const ConstLayout& cl,
+                                           uint32_t norm_mask, double uniform_logp,
+                                           double* __restrict__ sA, int astride, bool& inb,
+                                           double& lp, double& ll, double* derived)
 {
     bool in = true;
 #pragma unroll
-    for (int i = 0; i < D; ++i) in = in & (t[i] <= sC[cl.hi() + i]) & (t[i] >= sC[cl.lo() + i]);
+    for (int i = 0; i < D; ++i) in = in & (t[i] <= C[cl.hi() + i]) & (t[i] >= C[cl.lo() + i]);
     inb = in;
     double s = 0.0;
     if (GENERAL && norm_mask) {
 #pragma unroll
         for (int i = 0; i < D; ++i)
             if ((norm_mask >> i) & 1u) {
-                const double q = (t[i] - sC[cl.loc() + i]) / sC[cl.scale() + i];
-                s = s + fma(-0.5 * q, q, sC[cl.mls() + i]);
+                const double q = (t[i] - C[cl.loc() + i]) / C[cl.scale() + i];
+                s = s + fma(-0.5 * q, q, C[cl.mls() + i]);
             }
     }
     lp = uniform_logp + s;
@@ -89,19 +94,19 @@ __device__ __forceinline__ void eval_point(const double (&t)[D], const double* _
         if (cl.K == 0) {
             ll = 0.0;
         } else {
-            ll = mode_logpdf<DERIVED>(t, sC + cl.mean(0), sC + cl.linv(0), sC[cl.cnorm()], derived);
+            ll = mode_logpdf<DERIVED>(t, C + cl.mean(0), C + cl.linv(0), C[cl.cnorm()], derived);
         }
     } else {
         double amax = -INFINITY;
         for (int k = 0; k < cl.K; ++k) {
-            const double a = mode_logpdf<DERIVED>(t, sC + cl.mean(k), sC + cl.linv(k),
-                                                  sC[cl.cnorm() + k],
+            const double a = mode_logpdf<DERIVED>(t, C + cl.mean(k), C + cl.linv(k),
+                                                  C[cl.cnorm() + k],
                                                   DERIVED ? derived + k * D : nullptr);
             sA[k * astride] = a;
             amax = (a > amax) ? a : amax;
         }
         double S = 0.0;
-        for (int k = 0; k < cl.K; ++k) S = fma(sC[cl.weight() + k], dexp(sA[k * astride] - amax), S);
+        for (int k = 0; k < cl.K; ++k) S = fma(C[cl.weight() + k], dexp(sA[k * astride] - amax), S);
         ll = dlog(S) + amax;
     }
 }
@@ -120,19 +125,13 @@ __device__ __forceinline__ double wrap_periodic(double t, double lo, double hi)
 template <bool MULTI, bool GENERAL>
 __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    extern __shared__ __attribute__((aligned(16))) double sA[];  // MULTI only: [K][gs]
     const ConstLayout cl{D, a.n_modes};
-    const int csz = (cl.size() + 1) & ~1;
-    double* __restrict__ sC = smem;
-    double* __restrict__ sV = smem + csz;
-    double* __restrict__ sA = sV + D * D + (D & 1);
+    const cptr C = as_const(a.cblock);
     const int tid = threadIdx.x, gs = blockDim.x;
     const int w = blockIdx.x * gs + tid;
     const int W = a.W;
-
-    for (int i = tid; i < cl.size(); i += gs) sC[i] = a.cblock[i];
-    const double* __restrict__ Vg = a.V + (size_t)blockIdx.x * a.ncyc * (D * D);
-    for (int i = tid; i < D * D; i += gs) sV[i] = Vg[i];
+    const cptr Vg = as_const(a.V) + (size_t)blockIdx.x * a.ncyc * (D * D);
 
     double x[D];
 #pragma unroll
@@ -145,7 +144,6 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     unsigned long long step = a.step0;
     int col = (int)(step % (unsigned long long)D);
     int cyc = 0;
-    __syncthreads();
 
     for (int s = 0; s < a.n_steps; ++s) {
         // ---- random variates of (walker, step): one Philox block
@@ -170,7 +168,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             Ea = -dlog(u52(ka));
         }
         // ---- proposal: t = x + r * v, v = T R[:, col] shared by the group
-        const double* __restrict__ v = sV + col * D;
+        const cptr v = Vg + (size_t)cyc * (D * D) + col * D;
         double t[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) t[i] = fma(r, v[i], x[i]);
@@ -178,12 +176,12 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 #pragma unroll
             for (int i = 0; i < D; ++i)
                 if ((a.periodic_mask >> i) & 1u)
-                    t[i] = wrap_periodic(t[i], sC[cl.lo() + i], sC[cl.hi() + i]);
+                    t[i] = wrap_periodic(t[i], C[cl.lo() + i], C[cl.hi() + i]);
         }
         // ---- log-posterior of the trial
         bool inb;
         double lp, ll;
-        eval_point<MULTI, false, GENERAL>(t, sC, cl, a.norm_mask, a.uniform_logp, sA + tid, gs, inb,
+        eval_point<MULTI, false, GENERAL>(t, C, cl, a.norm_mask, a.uniform_logp, sA + tid, gs, inb,
                                           lp, ll, nullptr);
         const double lt = inb ? lp + ll : -INFINITY;
         // ---- Metropolis test (mcmc.py:678-683)
@@ -223,16 +221,10 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
             if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
         }
-        // ---- next step / next cycle's directions
         ++step;
         if (++col == D) {
             col = 0;
             ++cyc;
-            if (s + 1 < a.n_steps) {
-                __syncthreads();
-                for (int i = tid; i < D * D; i += gs) sV[i] = Vg[(size_t)cyc * (D * D) + i];
-                __syncthreads();
-            }
         }
     }
 
@@ -334,14 +326,10 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a)
 template <bool MULTI, bool DERIVED>
 __global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    extern __shared__ __attribute__((aligned(16))) double sA[];  // MULTI only: [K][64]
     const ConstLayout cl{D, a.n_modes};
-    const int csz = (cl.size() + 1) & ~1;
-    double* __restrict__ sC = smem;
-    double* __restrict__ sA = smem + csz;
+    const cptr C = as_const(a.cblock);
     const int tid = threadIdx.x;
-    for (int i = tid; i < cl.size(); i += 64) sC[i] = a.cblock[i];
-    __syncthreads();
     const int p = blockIdx.x * 64 + tid;
     if (p >= a.n) return;
     double t[D];
@@ -350,7 +338,7 @@ __global__ void __launch_bounds__(64) evaluate_kernel(const EvalArgs a)
     bool inb;
     double lp, ll;
     double* der = DERIVED ? a.derived + (size_t)p * (cl.K > 0 ? cl.K : 1) * D : nullptr;
-    eval_point<MULTI, DERIVED, true>(t, sC, cl, a.norm_mask, a.uniform_logp, sA + tid, 64, inb, lp,
+    eval_point<MULTI, DERIVED, true>(t, C, cl, a.norm_mask, a.uniform_logp, sA + tid, 64, inb, lp,
                                      ll, der);
     a.logprior[p] = inb ? lp : -INFINITY;
     a.loglike[p] = inb ? ll : -INFINITY;
@@ -397,11 +385,8 @@ __global__ void __launch_bounds__(64) pool_moments_kernel(const MomentArgs a)
 // ---------------------------------------------------------------- launchers
 hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
 {
-    const ConstLayout cl{D, a.n_modes};
-    const int csz = (cl.size() + 1) & ~1;
     const bool multi = a.n_modes > 1;
-    const size_t lds = sizeof(double) * (size_t)(csz + D * D + (D & 1) +
-                                                 (multi ? a.n_modes * group_size : 0));
+    const size_t lds = sizeof(double) * (size_t)(multi ? a.n_modes * group_size : 0);
     const dim3 grid(a.W / group_size), block(group_size);
     const bool general = (a.norm_mask | a.periodic_mask) != 0u;
     if (multi) {
@@ -422,10 +407,8 @@ hipError_t launch_basis(const BasisArgs& a, int n_groups, hipStream_t st)
 
 hipError_t launch_evaluate(const EvalArgs& a, hipStream_t st)
 {
-    const ConstLayout cl{D, a.n_modes};
-    const int csz = (cl.size() + 1) & ~1;
     const bool multi = a.n_modes > 1;
-    const size_t lds = sizeof(double) * (size_t)(csz + (multi ? a.n_modes * 64 : 0));
+    const size_t lds = sizeof(double) * (size_t)(multi ? a.n_modes * 64 : 0);
     const dim3 grid((a.n + 63) / 64), block(64);
     if (multi) {
         if (a.derived) hipLaunchKernelGGL((evaluate_kernel<true, true>), grid, block, lds, st, a);

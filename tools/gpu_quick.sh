@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 300 python tools/quick_engine_bench.py 30 65536 64 300 2>&1 | tail -2
+timeout 300 python tools/quick_engine_bench.py 30 65536 256 300 2>&1 | tail -2
