@@ -1,0 +1,83 @@
+"""Process-group plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" for the CPU tests).  Replaces the mpi4py calls of the reference's
+mcmc path: the only data-path collective is ONE all-reduce(sum) of the pooled
+sufficient statistics per learn/convergence checkpoint (mcmc.py:791-793, 914, 1005, 1021).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def _td():
+    import torch.distributed as td
+    return td
+
+
+def is_initialized() -> bool:
+    try:
+        td = _td()
+        return td.is_available() and td.is_initialized()
+    except Exception:
+        return False
+
+
+def rank() -> int:
+    return _td().get_rank() if is_initialized() else 0
+
+
+def size() -> int:
+    return _td().get_world_size() if is_initialized() else 1
+
+
+def local_rank() -> int:
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None):
+    """Initialise the default group from RANK/WORLD_SIZE/MASTER_* (torch.distributed.run)
+    when WORLD_SIZE > 1; a no-op for single-process runs."""
+    if is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    import torch
+    td = _td()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    td.init_process_group(backend=backend)
+
+
+def all_reduce_sum(buf: np.ndarray) -> np.ndarray:
+    """In-place sum over ranks of a float64 host buffer; through the GPU (RCCL) when the
+    group's backend is nccl, on the CPU for gloo.  Identity for one process."""
+    if size() == 1:
+        return buf
+    import torch
+    td = _td()
+    t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64))
+    if td.get_backend() == "nccl":
+        g = t.cuda(local_rank())
+        td.all_reduce(g, op=td.ReduceOp.SUM)
+        t = g.cpu()
+    else:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    buf[...] = t.numpy().reshape(buf.shape)
+    return buf
+
+
+def barrier():
+    if size() > 1:
+        _td().barrier()
+
+
+def gather_rows(rows: np.ndarray):
+    """All ranks' 2-d row blocks on rank 0 (host-side concatenation of per-GPU sample
+    buffers: mcmc.py:1136-1183); None elsewhere."""
+    if size() == 1:
+        return [rows]
+    out = [None] * size() if rank() == 0 else None
+    _td().gather_object(rows, out, dst=0)
+    return out

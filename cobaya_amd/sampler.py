@@ -1,0 +1,521 @@
+"""`mcmc_hip`: the walker-ensemble Metropolis sampler behind Cobaya's sampler plugin surface.
+
+Host-side mirror of `cobaya.samplers.mcmc.MCMC` (reference: cobaya/samplers/mcmc/mcmc.py)
+for the path the HIP engine accelerates.  Same constructor signature as
+`cobaya.sampler.Sampler.__init__` (sampler.py:257-264), same life cycle
+(`initialize()` -> `run()` -> `products()` / `samples()`), same option names and defaults as
+cobaya/samplers/mcmc/mcmc.yaml, same `progress` table and collection columns.  What differs,
+by design:
+
+  * a "chain" is a GROUP of `group_size` walkers that share one Haar proposal basis; all
+    walkers advance in lockstep on the GPU (one wavefront lane per walker);
+  * covariance learning and R-1 use streaming sufficient statistics accumulated on the
+    device (snapshots of the ensemble) instead of stored rows, and ranks exchange ONE
+    all-reduce per checkpoint (RCCL over xGMI) instead of gather/bcast of means and covs
+    (mcmc.py:791-793, 914, 1005, 1021);
+  * `max_samples` counts accepted steps over ALL walkers; the R-1 of confidence-interval
+    bounds (mcmc.py:918-1002, GetDist) is not evaluated: convergence = R-1 of means below
+    `Rminus1_stop` twice in a row (mcmc.py:908).
+
+There is no CPU fallback: constructing the sampler without a usable gfx950 device raises.
+"""
+from __future__ import annotations
+
+import copy
+import datetime
+import logging
+import math
+import os
+import re
+
+import numpy as np
+import pandas as pd
+
+from . import dist
+from .collection import SampleCollection
+from .engine import ChainStuck, Engine, EngineError, NotPositiveDefinite, gelman_rubin
+from .model import ProblemSpec, UnsupportedModel
+
+log = logging.getLogger("mcmc_hip")
+
+
+class LoggedError(Exception):
+    """Stand-in for cobaya.log.LoggedError when Cobaya is not importable: logs, then raises
+    (log.py:22-46)."""
+
+    def __init__(self, logger, msg, *args):
+        text = msg % args if args else msg
+        logger.error(text)
+        super().__init__(text)
+
+
+# cobaya/samplers/mcmc/mcmc.yaml:1-80, verbatim defaults
+MCMC_DEFAULTS = {
+    "burn_in": 0, "max_tries": "40d", "covmat": None, "covmat_params": None,
+    "proposal_scale": 2.4, "output_every": "60s", "learn_every": "40d", "temperature": 1,
+    "learn_proposal": True, "learn_proposal_Rminus1_max": 2.0,
+    "learn_proposal_Rminus1_max_early": 30.0, "learn_proposal_Rminus1_min": 0.0,
+    "max_samples": math.inf, "Rminus1_stop": 0.01, "Rminus1_cl_stop": 0.2,
+    "Rminus1_cl_level": 0.95, "Rminus1_single_split": 4, "measure_speeds": True,
+    "oversample_power": 0.4, "oversample_thin": True, "drag": False, "blocking": None,
+    "callback_function": None, "callback_every": None, "seed": None,
+    "check_every": None, "oversample": None, "drag_limits": None,
+}
+# options of the ensemble engine (new; typed class attributes in the Cobaya subclass)
+HIP_DEFAULTS = {
+    "n_walkers": 65536,       # walkers PER PROCESS (= per GPU)
+    "group_size": 64,         # walkers sharing one Haar basis = one R-1 "chain"
+    "device": None,           # HIP ordinal; default LOCAL_RANK
+    "steps_per_launch": "10d",  # Metropolis steps fused per kernel launch
+    "moments_every": 1,       # launches between moment snapshots
+    "emit": "snapshots",      # "snapshots": ensemble state every snapshot_every steps,
+                              # "chains": every accepted row with its integer weight
+    "snapshot_every": None,   # steps; default = one checkpoint interval
+    "max_rows": 1 << 21,      # cap on stored rows per process
+}
+
+
+def _number_with_units(value, unit, scale):
+    """tools.py:454-511 NumberWithUnits: '40d' -> 40*scale, plain numbers unchanged."""
+    if isinstance(value, str):
+        m = re.fullmatch(r"\s*([0-9.eE+-]+|\.?inf)\s*(%s)?\s*" % unit, value)
+        if not m:
+            raise ValueError(f"cannot parse {value!r} (expected a number, optionally "
+                             f"followed by '{unit}')")
+        num = float(m.group(1).lstrip(".") if "inf" in m.group(1) else m.group(1))
+        return num * scale if m.group(2) else num
+    return value
+
+
+class MCMCHip:
+    """Adaptive Metropolis MCMC on a walker ensemble (HIP engine)."""
+
+    file_base_name = "mcmc_hip"
+    sampler_type = "mcmc"
+    supports_periodic_params = True
+    fallback_covmat_scale = 4.0  # sampler.py:474
+
+    # ------------------------------------------------------------------ construction
+    def __init__(self, info_sampler=None, model=None, output=None, packages_path=None,
+                 name=None):
+        info_sampler = dict(info_sampler or {})
+        known = {**MCMC_DEFAULTS, **HIP_DEFAULTS}
+        unknown = set(info_sampler) - set(known)
+        if unknown:  # input.py:403-435: unknown options are rejected
+            raise LoggedError(log, "mcmc_hip does not recognise the option(s) %s. Valid "
+                                   "options: %s", sorted(unknown), sorted(known))
+        for k, v in known.items():
+            setattr(self, k, copy.deepcopy(info_sampler.get(k, v)))
+        self._name = name or "mcmc_hip"
+        self.output = output
+        self.packages_path = packages_path
+        if isinstance(model, ProblemSpec):
+            self.spec = model
+            self.model = None
+        elif model is not None:  # a real cobaya.model.Model
+            self.model = model
+            try:
+                self.spec = ProblemSpec.from_cobaya_model(model)
+            except UnsupportedModel as e:
+                raise LoggedError(log, "mcmc_hip cannot sample this model: %s", str(e)) from e
+        else:
+            raise LoggedError(log, "mcmc_hip needs a model")
+        self.converged = False
+        self.Rminus1_last = np.inf
+        self.engine = None
+        self.initialize()
+
+    def get_name(self):
+        return self._name
+
+    # ------------------------------------------------------------------ MCMC.initialize
+    def initialize(self):
+        """mcmc.py:111-271."""
+        spec = self.spec
+        d = spec.d
+        for key in ("drag", "blocking"):
+            if getattr(self, key):
+                raise LoggedError(log, "`%s` (fast/slow blocking) is not supported by mcmc_hip: "
+                                       "analytic targets form a single parameter block", key)
+        if self.temperature is None:
+            self.temperature = 1
+        if self.temperature < 1:
+            log.warning("Sampling temperatures <1 can lead to innacurate inference.")
+        self.temperature = float(self.temperature)
+        # 'd' units: one cycle = d steps (single block, oversampling 1; mcmc.py:405-410)
+        self.cycle_length = d
+        self.max_tries = _number_with_units(self.max_tries, "d", d)
+        self.learn_every = int(_number_with_units(self.learn_every, "d", d))
+        self.burn_in = int(_number_with_units(self.burn_in, "d", d))
+        self.steps_per_launch = max(1, int(_number_with_units(self.steps_per_launch, "d", d)))
+        if self.callback_every is None:
+            self.callback_every = self.learn_every
+        if self.emit not in ("snapshots", "chains"):
+            raise LoggedError(log, "emit must be 'snapshots' or 'chains', got %r", self.emit)
+        dist.init_from_env()
+        self.rank, self.size = dist.rank(), dist.size()
+        # seed: one key for the whole job; walkers are keyed by their global id
+        if self.seed is None:
+            seed = np.array([float(int.from_bytes(os.urandom(4), "little"))])
+            if self.rank != 0:
+                seed[:] = 0
+            self.seed = int(dist.all_reduce_sum(seed)[0])
+        else:
+            log.warning("This run has been SEEDED with seed %s", self.seed)
+        ss = np.random.SeedSequence(self.seed).spawn(self.size)[self.rank]  # sampler.py:378-384
+        self._rng = np.random.default_rng(ss)
+        W = int(self.n_walkers)
+        device = self.device if self.device is not None else dist.local_rank()
+        cap = self.steps_per_launch if self.emit == "chains" else 0
+        try:
+            self.engine = Engine(d, W, group_size=int(self.group_size), device=int(device),
+                                 seed=self.seed, walker_offset=self.rank * W,
+                                 burn_in=self.burn_in, temperature=self.temperature,
+                                 proposal_scale=float(self.proposal_scale),
+                                 max_tries=float(self.max_tries), emit_capacity=cap)
+            spec.configure(self.engine)
+        except EngineError as e:
+            raise LoggedError(log, "%s", str(e)) from e
+        # initial proposal covariance (sampler.py:485-685), tempered (mcmc.py:438-440)
+        self._initial_covmat, where_nan = self.initial_proposal_covmat()
+        if np.any(where_nan) and self.learn_proposal:
+            log.info("Covariance matrix %s. We will start learning the covariance of the "
+                     "proposal earlier: R-1 = %g (would be %g if all params loaded).",
+                     "not present" if np.all(where_nan) else "not complete",
+                     self.learn_proposal_Rminus1_max_early, self.learn_proposal_Rminus1_max)
+            self.learn_proposal_Rminus1_max = self.learn_proposal_Rminus1_max_early
+        try:
+            self.engine.set_proposal_cov(self._initial_covmat * self.temperature)
+        except NotPositiveDefinite as e:
+            raise LoggedError(log, "%s", str(e)) from e
+        # initial points (model.py:707-754 get_valid_point, one per walker)
+        log.info("Getting initial points... (%d walkers)", W)
+        x0 = spec.sample_reference(W, self._rng)
+        for _ in range(int(min(self.max_tries, 1000))):
+            lp, ll = self.engine.evaluate(x0)
+            bad = ~np.isfinite(lp + ll)
+            if not bad.any():
+                break
+            x0[bad] = spec.sample_reference(int(bad.sum()), self._rng)
+        else:
+            raise LoggedError(log, "Could not find random point giving finite posterior after "
+                                   "%g tries", self.max_tries)
+        self.engine.set_state(x0)
+        shift = np.concatenate((x0.sum(0), [W]))
+        dist.all_reduce_sum(shift)
+        self._shift = shift[:d] / shift[d]
+        self.engine.set_moment_shift(self._shift)
+        # bookkeeping
+        self.collection = SampleCollection(spec.sampled, spec.derived, spec.like_name,
+                                           self.temperature, name=str(1 + self.rank))
+        self._rows = []          # (walker, weight, logpost, logprior, loglike, x...) blocks
+        self._n_rows = 0
+        self._intervals = []     # per checkpoint: (n_snapshots, group_sum[G,d], pooled_S[d,d])
+        self._dropped_snapshots = 0
+        self.progress = pd.DataFrame(columns=["N", "timestamp", "acceptance_rate", "Rminus1",
+                                              "Rminus1_cl"])
+        self.i_learn = 1
+        self.n_steps_raw = 0     # Metropolis steps per walker (mcmc.py:472)
+        self._accepted_total = 0
+        self._acc_last = 0
+        self._steps_last = 0
+        self._acc_rate = 0.25
+        self._launches = 0
+        self._since_snapshot = 0
+
+    # ------------------------------------------------------------------ a17
+    def initial_proposal_covmat(self):
+        """sampler.py:485-685: `covmat` (matrix or file) > `proposal`^2 > ref variance / 4 >
+        prior variance / 4; off-diagonals only from the given matrix."""
+        spec = self.spec
+        names = spec.sampled
+        d = spec.d
+        cov = np.diag([np.nan] * d)
+        covmat, covmat_params = self.covmat, self.covmat_params
+        if isinstance(covmat, str):
+            if covmat.lower() == "auto":
+                raise LoggedError(log, "covmat: auto (cosmology database) is not available in "
+                                       "mcmc_hip")
+            try:
+                with open(covmat, encoding="utf-8-sig") as f:
+                    header = f.readline()
+                loaded = np.atleast_2d(np.loadtxt(covmat))
+            except OSError as e:
+                raise LoggedError(log, "Can't open covmat file '%s'.", covmat) from e
+            if header[0] != "#":
+                raise LoggedError(log, "The first line of the covmat file '%s' must be one "
+                                       "list of parameter names separated by spaces and "
+                                       "staring with '#'", covmat)
+            covmat_params = header.strip("#").strip().split()
+            covmat = loaded
+        if covmat is not None:
+            if not covmat_params:
+                raise LoggedError(log, "If a covariance matrix is passed as a numpy array, you "
+                                       "also need to pass the parameters it corresponds to via "
+                                       "'covmat_params: [name1, name2, ...]'.")
+            covmat = np.atleast_2d(np.array(covmat, dtype=float))
+            covmat_params = list(covmat_params)
+            if len(covmat_params) != len(set(covmat_params)):
+                raise LoggedError(log, "Parameter(s) appear more than once in `covmat_params`")
+            if covmat.shape != (len(covmat_params),) * 2:
+                raise LoggedError(log, "The number of parameters in `covmat_params` and the "
+                                       "dimensions of the matrix do not agree: %d vs %r",
+                                  len(covmat_params), covmat.shape)
+            if not np.allclose(covmat.T, covmat):
+                raise LoggedError(log, "The covariance matrix passed is not a symmetric square "
+                                       "matrix.")
+            idx_l = [j for j, p in enumerate(covmat_params) if p in names]
+            idx_s = [names.index(covmat_params[j]) for j in idx_l]
+            if not idx_s:
+                raise LoggedError(log, "A proposal covariance matrix has been loaded, but none "
+                                       "of its parameters are actually sampled here.")
+            cov[np.ix_(idx_s, idx_s)] = covmat[np.ix_(idx_l, idx_l)]
+        where_nan = np.isnan(cov.diagonal())
+        if np.any(where_nan):
+            prop = np.array([(p or np.nan) ** 2 if p is not None else np.nan
+                             for p in spec.proposal], dtype=float)
+            cov[where_nan, where_nan] = prop[where_nan]
+        where_nan2 = np.isnan(cov.diagonal())
+        if np.any(where_nan2):
+            cov[where_nan2, where_nan2] = (spec.reference_variances()[where_nan2]
+                                           / self.fallback_covmat_scale)
+        return cov, where_nan
+
+    # ------------------------------------------------------------------ MCMC.run
+    def n(self):
+        """Accepted steps so far, over all walkers of all processes."""
+        return self._accepted_total
+
+    def _checkpoint_steps(self):
+        """Steps per walker between checkpoints: `learn_every` ACCEPTED rows per chain
+        (mcmc.py:757-760) at the measured acceptance rate, rounded up to whole launches."""
+        steps = self.learn_every / max(self._acc_rate, 0.02)
+        return max(1, math.ceil(steps / self.steps_per_launch)) * self.steps_per_launch
+
+    def run(self):
+        """mcmc.py:451-528."""
+        log.info("Sampling!%s", (" (NB: no accepted step will be saved until %d burn-in "
+                                 "samples have been obtained)" % self.burn_in)
+                 if self.burn_in else "")
+        next_ckpt = self._checkpoint_steps()
+        snap_every = (int(self.snapshot_every) if self.snapshot_every
+                      else None)
+        try:
+            while self._accepted_total < self.max_samples and not self.converged:
+                self.engine.step(self.steps_per_launch)
+                self.n_steps_raw += self.steps_per_launch
+                self._launches += 1
+                self._since_snapshot += self.steps_per_launch
+                if self._launches % max(1, int(self.moments_every)) == 0:
+                    self.engine.accumulate_moments()
+                if self.emit == "chains":
+                    self._store_rows(self.engine.drain_samples())
+                elif snap_every and self._since_snapshot >= snap_every:
+                    self._snapshot()
+                if self.n_steps_raw >= next_ckpt:
+                    self.check_convergence_and_learn_proposal()
+                    self.i_learn += 1
+                    if self.emit == "snapshots" and not snap_every:
+                        self._snapshot()
+                    if self.callback_function:
+                        self.callback_function(self)
+                    next_ckpt = self.n_steps_raw + self._checkpoint_steps()
+            self.engine.sync()
+            self._update_counters()
+        except ChainStuck as e:
+            raise LoggedError(log, "%s Make sure the reference point is sensible and initial "
+                                   "covmat. (see `max_tries`)", str(e)) from e
+        if self._accepted_total >= self.max_samples:
+            log.info("Reached maximum number of accepted steps allowed (%s). Stopping.",
+                     self.max_samples)
+        log.info("Sampling complete after %d accepted steps.", self._accepted_total)
+        if self.output:
+            self._write_output()
+
+    # ------------------------------------------------------------------ storage
+    def _store_rows(self, rows):
+        if len(rows) and self._n_rows < self.max_rows:
+            self._rows.append(rows)
+            self._n_rows += len(rows)
+
+    def _snapshot(self):
+        """Thinned sample emission: the current point of every walker with weight 1 (the
+        ensemble analogue of `output_thin`, collection.py:1362-1372)."""
+        self._since_snapshot = 0
+        if self._n_rows >= self.max_rows:
+            return
+        s = self.engine.get_state()
+        W = len(s["x"])
+        ids = self.rank * W + np.arange(W, dtype=np.float64)
+        rows = np.column_stack((ids, np.ones(W), s["logpost"], s["logprior"], s["loglike"],
+                                s["x"]))
+        self._store_rows(rows)
+
+    def _update_counters(self):
+        c = self.engine.counters()
+        buf = np.array([float(c["accepted"])])
+        dist.all_reduce_sum(buf)
+        self._accepted_total = int(buf[0])
+        return c
+
+    # ------------------------------------------------------------------ a15 + a16
+    def _window(self):
+        """Statistics over the later half of the run ([n/2:], mcmc.py:787-790) at interval
+        granularity: the shortest suffix of checkpoint intervals holding >= half of all
+        snapshots taken so far.  The window start only moves forward, so earlier intervals
+        are dropped (their snapshot count is remembered)."""
+        ivs = self._intervals
+        total = self._dropped_snapshots + sum(iv[0] for iv in ivs)
+        k = 0
+        while k + 1 < len(ivs) and sum(iv[0] for iv in ivs[k + 1:]) >= total / 2:
+            k += 1
+        self._dropped_snapshots += sum(iv[0] for iv in ivs[:k])
+        self._intervals = ivs = ivs[k:]
+        return (sum(iv[0] for iv in ivs), sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs))
+
+    def check_convergence_and_learn_proposal(self):
+        """mcmc.py:773-1032 on pooled sufficient statistics; one all-reduce."""
+        d, eng = self.spec.d, self.engine
+        n_snap, gs, S = eng.read_moments(reset=True)  # synchronises the stream
+        eng.sync()
+        c = eng.counters()
+        if n_snap:
+            self._intervals.append((n_snap, gs, S))
+        if not self._intervals:
+            return
+        n, gsum, Ssum = self._window()
+        gsz = eng.group_size
+        N_c = float(n * gsz)                       # samples per chain (= group)
+        means = gsum / N_c                         # [G, d], relative to the shift
+        sum_mm = means.T @ means
+        payload = np.concatenate((
+            [float(eng.G), N_c * eng.G, float(c["accepted"] - self._acc_last),
+             float((c["steps"] - self._steps_last) * eng.W)],
+            (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
+        dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
+        n_chains, sum_N, d_acc, d_steps = payload[:4]
+        sum_Ncov = payload[4:4 + d * d].reshape(d, d)
+        sum_mean = payload[4 + d * d:4 + d * d + d]
+        sum_mm = payload[4 + d * d + d:].reshape(d, d)
+        self._acc_last, self._steps_last = c["accepted"], c["steps"]
+        acceptance_rate = d_acc / max(d_steps, 1.0)
+        self._acc_rate = acceptance_rate
+        self._update_counters()
+        i = self.i_learn
+        self.progress.at[i, "N"] = self._accepted_total
+        self.progress.at[i, "timestamp"] = datetime.datetime.now().isoformat()
+        self.progress.at[i, "acceptance_rate"] = acceptance_rate
+        log.info("Learn + convergence test @ %d samples accepted.", self._accepted_total)
+        log.info(" - Acceptance rate: %.3f", acceptance_rate)
+        try:
+            Rminus1, mean_of_covs = gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm)
+        except NotPositiveDefinite:
+            log.warning("Negative covariance eigenvectors. This may mean that the covariance of "
+                        "the samples does not contain enough information at this point. "
+                        "Skipping learning a new covmat for now.")
+            return
+        self.progress.at[i, "Rminus1"] = Rminus1
+        log.info(" - Convergence of means: R-1 = %f after %d accepted steps", Rminus1,
+                 self._accepted_total)
+        # twice in a row (mcmc.py:908); the bounds criterion (918-1002) is not evaluated
+        if max(Rminus1, self.Rminus1_last) < self.Rminus1_stop:
+            self.converged = True
+            log.info("The run has converged!")
+        self.Rminus1_last = Rminus1
+        if self.learn_proposal and not self.converged:
+            if Rminus1 > self.learn_proposal_Rminus1_max:
+                log.info("Convergence less than requested for updates: waiting until the next "
+                         "convergence check.")
+            elif Rminus1 < self.learn_proposal_Rminus1_min:
+                log.info("Convergence better than `learn_proposal_Rminus1_min`: covmat will "
+                         "not be updated.")
+            else:
+                try:
+                    eng.set_proposal_cov(mean_of_covs)  # is already tempered (mcmc.py:1023)
+                    log.info(" - Updated covariance matrix of proposal pdf.")
+                except NotPositiveDefinite:
+                    log.debug("Updating covariance matrix failed unexpectedly. waiting until "
+                              "next covmat learning attempt.")
+
+    # ------------------------------------------------------------------ products
+    def _build_collection(self):
+        spec = self.spec
+        d = spec.d
+        rows = (np.vstack(self._rows) if self._rows else np.zeros((0, d + 5)))
+        if self.emit == "chains" and len(rows):
+            rows = rows[np.argsort(rows[:, 0], kind="stable")]  # chain after chain
+        coll = SampleCollection(spec.sampled, spec.derived, spec.like_name, self.temperature,
+                                name=str(1 + self.rank))
+        if len(rows):
+            derived = None
+            if spec.derived:
+                derived = np.vstack([self.engine.evaluate(rows[i:i + 65536, 5:], derived=True)[2]
+                                     for i in range(0, len(rows), 65536)])
+            coll.add_rows(rows[:, 1], rows[:, 2], rows[:, 5:], rows[:, 3], rows[:, 4], derived)
+        self._chain_ids = rows[:, 0].astype(np.int64) if len(rows) else np.zeros(0, np.int64)
+        return coll
+
+    def samples(self, combined=False, skip_samples=0, to_getdist=False):
+        """mcmc.py:1092-1148 (no GetDist export here)."""
+        if to_getdist:
+            raise LoggedError(log, "GetDist export is not available in mcmc_hip; write the "
+                                   "chain with `output` and load it with GetDist instead")
+        coll = self._build_collection()
+        if skip_samples:
+            n0 = int(skip_samples * len(coll)) if skip_samples < 1 else int(skip_samples)
+            arr = coll.data.to_numpy()[n0:]
+            coll._blocks, coll._data = [arr], None
+        if combined and self.size > 1:
+            blocks = dist.gather_rows(coll.data.to_numpy())
+            if self.rank == 0:
+                coll._blocks, coll._data = [np.vstack(blocks)], None
+        return coll
+
+    def products(self, combined=False, skip_samples=0, to_getdist=False):
+        """mcmc.py:1150-1184: {"sample": SampleCollection, "progress": DataFrame}."""
+        self.collection = self.samples(combined, skip_samples, to_getdist)
+        return {"sample": self.collection, "progress": self.progress}
+
+    # ------------------------------------------------------------------ reference-style views
+    class _ProposerView:
+        def __init__(self, engine, scale):
+            self._e, self._s = engine, scale
+
+        def get_covariance(self):
+            return self._e.get_proposal_cov()
+
+        def get_scale(self):
+            return self._s
+
+    @property
+    def proposer(self):
+        return self._ProposerView(self.engine, float(self.proposal_scale))
+
+    @property
+    def current_point(self):
+        return self.engine.get_state()
+
+    def info(self):
+        return {k: getattr(self, k) for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}
+
+    # ------------------------------------------------------------------ output
+    def _write_output(self):
+        prefix = str(self.output)
+        folder = os.path.dirname(prefix)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        coll = self._build_collection()
+        coll.to_txt(f"{prefix}.{1 + self.rank}.txt")
+        if self.rank == 0:
+            np.savetxt(prefix + ".covmat",
+                       self.engine.get_proposal_cov() / self.temperature,  # mcmc.py:1049-1051
+                       header=" ".join(self.spec.sampled))
+            with open(prefix + ".progress", "w", encoding="utf-8") as f:
+                f.write("# " + " ".join(f"{c:>15}" for c in self.progress.columns) + "\n")
+                if len(self.progress):
+                    f.write(self.progress.to_string(header=False, index=False) + "\n")
+
+    def close(self):
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None

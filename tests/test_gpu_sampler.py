@@ -1,0 +1,127 @@
+"""GPU tests of the drop-in boundary: `run(info)` with `sampler: mcmc_hip` on the inputs the
+reference's own tests use (docs quickstart = BASELINE config 1; tests/common_sampler.py fixed
+3-d Gaussian with a deliberately bad initial proposal), judged by the reference's own bar
+KL(truth || sample) <= 0.07 (tests/common_sampler.py:18,152-161) and much tighter ones."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from cobaya_amd import run  # noqa: E402
+from cobaya_amd.sampler import LoggedError  # noqa: E402
+from tests.test_host_logic import QUICK  # noqa: E402
+
+
+def kl_norm(m1, S1, m2, S2):
+    """KL(N1 || N2), cobaya/tools.py:732-743."""
+    d = len(m1)
+    S2i = np.linalg.inv(S2)
+    return 0.5 * (np.trace(S2i @ S1) + (m1 - m2) @ S2i @ (m1 - m2) - d
+                  + np.linalg.slogdet(S2)[1] - np.linalg.slogdet(S1)[1])
+
+
+def test_quickstart_chains_mode(tmp_path):
+    """BASELINE config 1 through the plugin surface, every accepted row kept with its
+    integer weight (reference semantics), derived parameters, chain file."""
+    info = dict(QUICK)
+    info["sampler"] = {"mcmc_hip": {"seed": 3, "n_walkers": 256, "group_size": 64,
+                                    "steps_per_launch": 50, "emit": "chains",
+                                    "max_samples": 150000, "Rminus1_stop": 0.0,
+                                    "burn_in": 20}}
+    info["output"] = str(tmp_path / "chains" / "quick")
+    updated, sampler = run(info)
+    assert updated["sampler"]["mcmc_hip"]["proposal_scale"] == 2.4
+    prod = sampler.products()
+    coll, prog = prod["sample"], prod["progress"]
+    df = coll.data
+    assert list(df.columns) == ["weight", "minuslogpost", "a", "b", "derived_a", "derived_b",
+                                "minuslogprior", "minuslogprior__0", "chi2",
+                                "chi2__gaussian_mixture"]
+    assert len(df) >= 100000 and sampler.n() >= 150000
+    w = df["weight"].to_numpy()
+    assert np.all(w == np.round(w)) and w.min() >= 1
+    acc = len(df) / w.sum()
+    assert 0.15 < acc < 0.6
+    mean, cov = coll.mean(), coll.cov()
+    tm, tc = np.array([0.2, 0.0]), np.array([[0.1, 0.05], [0.05, 0.2]])
+    assert kl_norm(tm, tc, mean, cov) < 0.07  # the reference's own bar, vs the likelihood
+    # the actual posterior = likelihood x N(0,1) prior on b (x the mild truncation a > -0.5)
+    P = np.linalg.inv(tc) + np.diag([0.0, 1.0])
+    pc = np.linalg.inv(P)
+    pm = pc @ np.linalg.inv(tc) @ tm
+    assert kl_norm(pm, pc, mean, cov) < 0.003
+    # stored row quantities reproduce (tests/common_sampler.py:346-372)
+    x = df[["a", "b"]].to_numpy()[:200]
+    Linv = np.linalg.inv(np.linalg.cholesky(tc))
+    np.testing.assert_allclose(df[["derived_a", "derived_b"]].to_numpy()[:200],
+                               (x - tm) @ Linv.T, rtol=1e-10, atol=1e-12)
+    chi2 = np.einsum("ni,ij,nj->n", x - tm, np.linalg.inv(tc), x - tm) + np.log(
+        (2 * np.pi) ** 2 * np.linalg.det(tc))
+    np.testing.assert_allclose(df["chi2"].to_numpy()[:200], chi2, rtol=1e-10)
+    lp = -np.log(3.5) - 0.5 * np.log(2 * np.pi) - 0.5 * x[:, 1] ** 2
+    np.testing.assert_allclose(-df["minuslogprior"].to_numpy()[:200], lp, rtol=1e-12)
+    np.testing.assert_allclose(df["minuslogpost"].to_numpy()[:200],
+                               df["minuslogprior"].to_numpy()[:200] + 0.5 * chi2, rtol=1e-10)
+    assert {"N", "timestamp", "acceptance_rate", "Rminus1", "Rminus1_cl"} == set(prog.columns)
+    assert len(prog) >= 2 and np.all(prog["Rminus1"].to_numpy(dtype=float) > 0)
+    # chain file in the reference's text format
+    back = np.loadtxt(tmp_path / "chains" / "quick.1.txt")
+    assert back.shape == df.shape
+    np.testing.assert_allclose(back[:, 2:4], df[["a", "b"]].to_numpy(), rtol=1e-7)
+    cm = np.loadtxt(tmp_path / "chains" / "quick.covmat")
+    assert cm.shape == (2, 2)
+    sampler.close()
+
+
+def test_fixed3_learns_from_bad_initial_proposal():
+    """tests/test_mcmc.py:22-82 / common_sampler.py:24-50,78-161 of the reference: fixed 3-d
+    Gaussian, initial proposal deliberately bad (3x too wide, no correlations), covariance
+    learning on, run to convergence of R-1 of means; KL <= 0.07."""
+    tm = np.array([-0.48591462, 0.10064559, 0.64406749])
+    tc = np.array([[0.00078333, 0.00033134, -0.0002923],
+                   [0.00033134, 0.00218118, -0.00170728],
+                   [-0.0002923, -0.00170728, 0.00676922]])
+    info = {
+        "likelihood": {"gaussian_mixture": {"means": [tm], "covs": [tc],
+                                            "input_params_prefix": "a_",
+                                            "output_params_prefix": "", "derived": True}},
+        "params": {**{f"a__{i}": {"prior": {"min": -1, "max": 1},
+                                  "ref": {"dist": "norm", "loc": float(tm[i]), "scale": 0.2},
+                                  "proposal": float(3 * np.sqrt(tc[i, i]))} for i in range(3)},
+                   "_0": None, "_1": None, "_2": None},
+        "sampler": {"mcmc_hip": {"seed": 11, "n_walkers": 1024, "group_size": 64,
+                                 "steps_per_launch": "20d", "max_tries": ".inf",
+                                 "burn_in": "100d", "Rminus1_stop": 0.005,
+                                 "max_samples": 5e6}},
+    }
+    updated, sampler = run(info)
+    assert sampler.converged
+    learned = sampler.proposer.get_covariance()
+    np.testing.assert_allclose(learned, tc, rtol=0.25, atol=2e-5)
+    # keep sampling with the learned proposal and judge the snapshots
+    sampler.converged = False
+    sampler.Rminus1_stop = 0.0
+    sampler.snapshot_every = 60
+    sampler._rows.clear()
+    sampler._n_rows = 0
+    sampler.max_samples = sampler.n() + 2e6
+    sampler.run()
+    coll = sampler.products()["sample"]
+    assert len(coll) >= 20 * 1024
+    assert np.all(coll["weight"] == 1)
+    mean, cov = coll.mean(), coll.cov()
+    assert kl_norm(tm, tc, mean, cov) < 0.07
+    assert kl_norm(tm, tc, mean, cov) < 0.01
+    prog = sampler.progress
+    assert prog["acceptance_rate"].iloc[-1] > 0.2
+    sampler.close()
+
+
+def test_unsupported_inputs_raise():
+    info = dict(QUICK)
+    info["sampler"] = {"mcmc_hip": {"drag": True, "n_walkers": 64}}
+    with pytest.raises(LoggedError, match="not supported"):
+        run(info)
+    info["sampler"] = {"mcmc": {}}
+    with pytest.raises(LoggedError, match="only runs"):
+        run(info)

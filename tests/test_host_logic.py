@@ -1,0 +1,211 @@
+"""CPU-only tests of the product's host side: the C-ABI library loads and exports every
+symbol include/mcmc_hip.h declares (no GPU compute calls), the host R-1 arithmetic matches the
+reference-pinned oracle, and the Python mirror of the reference interface (model parsing,
+initial covmat, collection, option handling) behaves like the reference."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cobaya_amd import engine as E
+from cobaya_amd.collection import SampleCollection
+from cobaya_amd.model import ProblemSpec, UnsupportedModel
+from cobaya_amd.sampler import MCMCHip, LoggedError, _number_with_units
+from oracle import ref_numpy as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "mcmc_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = set(re.findall(r"\b(mcmc_hip_[a-z_0-9]+)\s*\(", text))
+    assert len(declared) >= 25
+    lib = E.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in mcmc_hip.h but not exported"
+    assert declared == {s[0] for s in E.SYMBOLS}
+    assert b"gfx950" in lib.mcmc_hip_version()
+    assert all(lib.mcmc_hip_dim_supported(d) for d in range(1, 33))
+    assert not lib.mcmc_hip_dim_supported(33) and not lib.mcmc_hip_dim_supported(0)
+
+
+def test_engine_fails_loudly_without_gpu_or_with_bad_config():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(E.EngineError) as ei:
+        E.Engine(3, 64)
+    assert "device" in str(ei.value).lower()
+    with pytest.raises(E.EngineError):
+        E.load_library("/nonexistent/libmcmc_hip.so")
+
+
+def test_gelman_rubin_matches_reference_arithmetic(golden):
+    g = golden("g7_multichain")
+    Ns, means, covs = g["Ns"], g["means"], g["covs"]
+    Rref, Wref = R.rminus1_of_means(Ns, means, covs)
+    assert Rref == pytest.approx(float(g["Rminus1"]), rel=1e-10)
+    Rm1, W = E.gelman_rubin(len(Ns), Ns.sum(), np.einsum("c,cij->ij", Ns, covs),
+                            means.sum(0), means.T @ means)
+    assert Rm1 == pytest.approx(Rref, rel=1e-9)
+    np.testing.assert_allclose(W, Wref, rtol=1e-13)
+    np.testing.assert_allclose(W, g["new_proposal_cov"], rtol=1e-13)
+    # random larger problem, incl. a shift of the means (R-1 is shift invariant)
+    rng = np.random.default_rng(0)
+    d, m = 30, 64
+    A = rng.normal(size=(d, d))
+    base = A @ A.T / d + np.eye(d)
+    covs = np.array([base * rng.uniform(0.8, 1.2) for _ in range(m)])
+    means = rng.multivariate_normal(np.zeros(d), base / 50, size=m) + 3.0
+    Ns = rng.integers(500, 900, size=m).astype(float)
+    Rref, Wref = R.rminus1_of_means(Ns, means, covs)
+    mc = means - means.mean(0)
+    Rm1, W = E.gelman_rubin(m, Ns.sum(), np.einsum("c,cij->ij", Ns, covs), mc.sum(0),
+                            mc.T @ mc)
+    assert Rm1 == pytest.approx(Rref, rel=1e-8)
+    # not positive definite "within" covariance -> the reference's LinAlgError branch
+    bad = covs.copy()
+    bad[:, 0, 0] = -1.0
+    with pytest.raises(E.NotPositiveDefinite):
+        E.gelman_rubin(m, Ns.sum(), np.einsum("c,cij->ij", Ns, bad), mc.sum(0), mc.T @ mc)
+
+
+QUICK = {
+    "likelihood": {"gaussian_mixture": {"means": [0.2, 0], "covs": [[0.1, 0.05], [0.05, 0.2]],
+                                        "derived": True}},
+    "params": {"a": {"prior": {"min": -0.5, "max": 3}, "latex": r"\alpha"},
+               "b": {"prior": {"dist": "norm", "loc": 0, "scale": 1}, "ref": 0,
+                     "proposal": 0.5, "latex": r"\beta"},
+               "derived_a": {"latex": r"\alpha^\prime"}, "derived_b": None},
+}
+
+
+def test_problem_spec_from_quickstart_info():
+    s = ProblemSpec.from_info(QUICK)
+    assert s.sampled == ["a", "b"] and s.derived == ["derived_a", "derived_b"]
+    assert list(s.kinds) == [0, 1] and list(s.a) == [-0.5, 0.0] and list(s.b) == [3.0, 1.0]
+    assert s.like_kind == "gaussian_mixture" and s.n_modes == 1 and s.has_derived
+    assert s.refs[1].kind == "point" and s.refs[0].kind is None
+    assert s.proposal == [None, 0.5]
+    np.testing.assert_allclose(s.prior_variances(), [3.5 ** 2 / 12, 1.0])
+    np.testing.assert_allclose(s.reference_variances(), [3.5 ** 2 / 12, 1.0])
+    x = s.sample_reference(500, np.random.default_rng(0))
+    assert np.all(x[:, 1] == 0.0) and np.all((x[:, 0] >= -0.5) & (x[:, 0] <= 3))
+
+
+def test_problem_spec_prefix_routing_and_errors():
+    info = {"likelihood": {"gaussian_mixture": {"means": [[0.1, 0.2, 0.3]],
+                                                "covs": [np.eye(3) * 0.01],
+                                                "input_params_prefix": "a_",
+                                                "output_params_prefix": "", "derived": True}},
+            "params": {"a__0": {"prior": {"min": -1, "max": 1}},
+                       "a__1": {"prior": {"min": -1, "max": 1}},
+                       "a__2": {"prior": [-1, 1]}, "_0": None, "_1": None, "_2": None}}
+    s = ProblemSpec.from_info(info)
+    assert s.d == 3 and s.derived == ["_0", "_1", "_2"]
+    bad = {**info, "prior": {"ext": "lambda a__0: 0"}}
+    with pytest.raises(UnsupportedModel):
+        ProblemSpec.from_info(bad)
+    bad = {"likelihood": {"gaussian_mixture": {"means": [0.1, 0.2], "covs": np.eye(2)}},
+           "params": info["params"]}
+    with pytest.raises(UnsupportedModel, match="dimensionality"):
+        ProblemSpec.from_info(bad)
+    bad = {"likelihood": {"one": None},
+           "params": {"p": {"prior": {"dist": "beta", "a": 1, "b": 2}}}}
+    with pytest.raises(UnsupportedModel, match="not supported"):
+        ProblemSpec.from_info(bad)
+    bad = {"likelihood": {"one": None}, "params": {"p": {"prior": {"dist": "norm", "loc": 0,
+                                                                   "scale": 1},
+                                                         "periodic": True}}}
+    with pytest.raises(UnsupportedModel, match="periodic"):
+        ProblemSpec.from_info(bad)
+    g = ProblemSpec.from_info({"likelihood": {"gaussian": {"mean": [0.0, 1.0], "cov": np.eye(2),
+                                                           "normalized": False}},
+                               "params": {"x": {"prior": [-5, 5]}, "y": {"prior": [-5, 5]}}})
+    assert g.like_kind == "gaussian" and g.normalized is False
+
+
+def bare_sampler(spec, **opts):
+    """An MCMCHip with options set but no engine (initialize() needs a GPU)."""
+    s = MCMCHip.__new__(MCMCHip)
+    from cobaya_amd.sampler import HIP_DEFAULTS, MCMC_DEFAULTS
+    for k, v in {**MCMC_DEFAULTS, **HIP_DEFAULTS, **opts}.items():
+        setattr(s, k, v)
+    s.spec = spec
+    return s
+
+
+def test_g9_initial_covmat_precedence(golden):
+    """tests/test_mcmc_initial_covmat.py of the reference, against the reference's output."""
+    g = golden("g9_initial_covmat")
+    order, kind, full = g["order"], g["kind"], g["full_cov"]
+    sig = np.sqrt(np.diag(full))
+    params = {}
+    for i in order:
+        p = {"prior": {"dist": "norm", "loc": 0, "scale": 1000}}
+        if kind[i] == 1:
+            p["proposal"] = sig[i]
+        elif kind[i] == 2:
+            p["ref"] = {"dist": "norm", "scale": sig[i] * 2}
+        elif kind[i] == 3:
+            p["prior"]["scale"] = sig[i] * 2
+        params[f"a_{i}"] = p
+    spec = ProblemSpec.from_info({"likelihood": {"one": None}, "params": params})
+    s = bare_sampler(spec, covmat=g["reduced"], covmat_params=[f"a_{i}" for i in g["i_cov"]])
+    cov, where_nan = s.initial_proposal_covmat()
+    np.testing.assert_allclose(cov, g["got"], rtol=1e-13)
+    assert where_nan.sum() == 30
+    s = bare_sampler(spec, covmat=g["reduced"], covmat_params=None)
+    with pytest.raises(LoggedError):
+        s.initial_proposal_covmat()
+
+
+def test_initial_covmat_from_file(tmp_path):
+    spec = ProblemSpec.from_info(QUICK)
+    f = tmp_path / "c.covmat"
+    np.savetxt(f, np.array([[0.1, 0.05], [0.05, 0.2]]), header="a b")
+    s = bare_sampler(spec, covmat=str(f))
+    cov, where_nan = s.initial_proposal_covmat()
+    np.testing.assert_allclose(cov, [[0.1, 0.05], [0.05, 0.2]])
+    assert not where_nan.any()
+    s = bare_sampler(spec)
+    cov, where_nan = s.initial_proposal_covmat()
+    np.testing.assert_allclose(cov, np.diag([3.5 ** 2 / 12 / 4, 0.25]))
+    assert list(where_nan) == [True, True]
+
+
+def test_options_and_units():
+    assert _number_with_units("40d", "d", 30) == 1200 and _number_with_units(7, "d", 30) == 7
+    assert _number_with_units("60s", "s", 1) == 60 and _number_with_units(".inf", "d", 3) == math.inf
+    with pytest.raises(ValueError):
+        _number_with_units("40x", "d", 3)
+    with pytest.raises(LoggedError, match="does not recognise"):
+        MCMCHip({"not_an_option": 1}, ProblemSpec.from_info(QUICK))
+
+
+def test_collection_columns_stats_and_txt(tmp_path):
+    c = SampleCollection(["a", "b"], ["da", "db"], "gaussian_mixture", temperature=2.0)
+    rng = np.random.default_rng(0)
+    n = 50
+    x = rng.normal(size=(n, 2))
+    w = rng.integers(1, 6, size=n)
+    c.add_rows(w, -np.arange(n, dtype=float), x, -np.ones(n), -2 * np.ones(n),
+               rng.normal(size=(n, 2)))
+    assert list(c.data.columns) == ["weight", "minuslogpost", "a", "b", "da", "db",
+                                    "minuslogprior", "minuslogprior__0", "chi2",
+                                    "chi2__gaussian_mixture"]
+    assert len(c) == n and c["minuslogpost"][3] == 1.5 and c["chi2"][0] == 4.0
+    np.testing.assert_allclose(c.mean(), R.weighted_mean(x, w), rtol=1e-14)
+    np.testing.assert_allclose(c.cov(first=10, last=40), R.weighted_cov(x[10:40], w[10:40]),
+                               rtol=1e-13)
+    path = tmp_path / "chain.1.txt"
+    c.to_txt(path)
+    lines = open(path).read().splitlines()
+    assert lines[0].startswith("#") and lines[0].split()[1:3] == ["minuslogpost", "a"] \
+        or lines[0].split()[0] == "#weight" or "weight" in lines[0]
+    back = np.loadtxt(path)
+    np.testing.assert_allclose(back, c.data.to_numpy(), rtol=1e-7)
+    assert len(lines[1]) == len(lines[0])
