@@ -378,7 +378,16 @@ __global__ void __launch_bounds__(64) pool_moments_kernel(const MomentArgs a)
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= NPAIR) return;
     double acc = a.pooled[p];
-    for (int g = 0; g < a.G; ++g) acc += a.Sg[(size_t)g * NPAIR + p];
+    // loads batched 16 deep (latency), additions strictly in ascending group order (spec)
+    int g = 0;
+    for (; g + 16 <= a.G; g += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = a.Sg[(size_t)(g + u) * NPAIR + p];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; g < a.G; ++g) acc += a.Sg[(size_t)g * NPAIR + p];
     a.pooled[p] = acc;
 }
 

@@ -209,3 +209,42 @@ def test_collection_columns_stats_and_txt(tmp_path):
     back = np.loadtxt(path)
     np.testing.assert_allclose(back, c.data.to_numpy(), rtol=1e-7)
     assert len(lines[1]) == len(lines[0])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cobaya"),
+                    reason="the Cobaya reference tree is only mounted in the build container")
+def test_plugin_resolution_inside_real_cobaya():
+    """a real Cobaya resolves `sampler: mcmc_hip` to our class through the
+    top-level `mcmc_hip` module and merges mcmc.yaml defaults with the new options.  Runs in a
+    subprocess so that importing Cobaya does not leak into the other tests."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, %r, "/root/reference"]
+from cobaya.component import get_component_class
+from cobaya.input import update_info
+cls = get_component_class("mcmc_hip", kind="sampler")
+import mcmc_hip
+assert cls is mcmc_hip.MCMCHip, cls
+from cobaya.samplers.mcmc import MCMC
+assert issubclass(cls, MCMC)
+info = update_info({"likelihood": {"one": None}, "params": {"a": {"prior": {"min": 0, "max": 1}}},
+                    "sampler": {"mcmc_hip": {"n_walkers": 128, "Rminus1_stop": 0.02}}})
+s = info["sampler"]["mcmc_hip"]
+assert s["n_walkers"] == 128 and s["group_size"] == 64 and s["emit"] == "snapshots"
+assert s["learn_every"] == "40d" and s["proposal_scale"] == 2.4 and s["Rminus1_stop"] == 0.02
+try:
+    update_info({"likelihood": {"one": None}, "params": {"a": {"prior": {"min": 0, "max": 1}}},
+                 "sampler": {"mcmc_hip": {"no_such_option": 1}}})
+    raise SystemExit("unknown option accepted")
+except SystemExit:
+    raise
+except Exception:
+    pass  # rejected (the fuzzy-suggestion helper needs rapidfuzz, absent here: any error is a rejection)
+print("RESOLVED")
+''' % (ROOT, os.path.join(ROOT, "tests", "golden", "_getdist_stub"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "RESOLVED" in out.stdout, out.stdout + out.stderr
