@@ -33,39 +33,121 @@ constexpr int NPAIR = D * (D + 1) / 2;
 // no vector-memory issue slots for data that all 64 lanes share.
 typedef const double __attribute__((address_space(4))) * cptr;
 __device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(unsigned long long)p; }
+// The operands are invariant over the step loop, so LICM would hoist ALL their loads out of it
+// (hundreds of SGPRs -> spilled to VGPR lanes).  Passing the base pointer through an empty asm
+// once per step makes the loads belong to that step.
+__device__ __forceinline__ cptr launder(cptr p)
+{
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("; operand base of this step" : "+s"(v));
+    return (cptr)v;
+}
+
+// ---------------------------------------------------------------- operand streaming
+// With W = 65 536 walkers there is exactly ONE wave per SIMD, so nothing but the wave's own
+// instruction stream can hide the latency of the scalar loads.  The operand streams are
+// therefore consumed in chunks with an explicit software pipeline:
+//     [use FIRST operand of chunk c]  -> the only s_waitcnt, for chunk c alone
+//     [issue the loads of chunk c+1]  -> in flight behind ...
+//     [use the rest of chunk c]       -> ... a chunk's worth of FP64 work
+// The order is pinned by DATA dependences the compiler cannot break: the base pointer of
+// chunk c+1 is passed through an empty asm together with the result of the first operation of
+// chunk c (`after`), so those loads can neither be hoisted to the top (SGPR spills) nor out
+// of the step loop (LICM), and nothing of chunk c+1 can start before chunk c was waited for.
+__device__ __forceinline__ cptr after(cptr p, double& anchor)
+{
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("; next operand chunk" : "+s"(v), "+v"(anchor));
+    return (cptr)v;
+}
+
+constexpr int NT = D * (D + 1) / 2;  // operands of one whitening factor
+constexpr int CH = 16;               // doubles per chunk = two s_load_dwordx16
+constexpr int NCH = (NT + CH - 1) / CH;
+
+struct TriMap {
+    unsigned char j[NT];
+    unsigned char i[NT];
+};
+constexpr TriMap make_tri_map()
+{
+    TriMap m{};
+    int idx = 0;
+    for (int jb = 0; jb < D; jb += kRowBlock)
+        for (int i = 0; i < jb + kRowBlock && i < D; ++i)
+            for (int r = 0; r < kRowBlock; ++r)
+                if (jb + r < D && i <= jb + r) {
+                    m.j[idx] = (unsigned char)(jb + r);
+                    m.i[idx] = (unsigned char)i;
+                    ++idx;
+                }
+    return m;
+}
+__device__ constexpr TriMap kTriMap = make_tri_map();
 
 // ---------------------------------------------------------------- log-posterior of a point
 // One mode: triangular whitening y = L^-1 (t - mu), chi2 = |y|^2, as fma chains in ascending
-// index order.  Rows are walked kRowBlock at a time so that several independent chains are
-// in flight (one wave per SIMD has no other latency cover); Lk is the operand stream packed
-// in exactly this order (kernels.h tri_stream_for_each).
+// index order; kRowBlock rows advance together (independent chains in flight); Lk is the
+// operand stream packed in exactly this order (kernels.h tri_stream_for_each).
 template <bool DERIVED>
 __device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cptr Lk,
                                               double cnorm, double* derived)
 {
     constexpr int RB = kRowBlock;
     double dev[D];
+    {   // dev = t - mu, 16 dimensions per chunk
+        constexpr int NC = (D + 15) / 16;
+        double cur[16], nxt[16];
 #pragma unroll
-    for (int i = 0; i < D; ++i) dev[i] = t[i] - mu[i];
+        for (int k = 0; k < 16; ++k) cur[k] = (k < D) ? mu[k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int b = c * 16;
+            dev[b] = t[b] - cur[0];
+            if (c + 1 < NC) {
+                const cptr m2 = after(mu + b + 16, dev[b]);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? m2[k] : 0.0;
+            }
+#pragma unroll
+            for (int k = 1; k < 16; ++k)
+                if (b + k < D) dev[b + k] = t[b + k] - cur[k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+        }
+    }
     double chi2 = 0.0;
-    int idx = 0;
+    double y[RB];
 #pragma unroll
-    for (int jb = 0; jb < D; jb += RB) {
-        double y[RB];
+    for (int r = 0; r < RB; ++r) y[r] = 0.0;
+    double cur[CH], nxt[CH];
+    {
+        const cptr L0 = after(Lk, dev[D - 1]);
 #pragma unroll
-        for (int r = 0; r < RB; ++r) y[r] = 0.0;
+        for (int k = 0; k < CH; ++k) cur[k] = (k < NT) ? L0[k] : 0.0;
+    }
 #pragma unroll
-        for (int i = 0; i < jb + RB && i < D; ++i) {
+    for (int c = 0; c < NCH; ++c) {
+        const int base = c * CH;
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
-                if (jb + r < D && i <= jb + r) y[r] = fma(Lk[idx++], dev[i], y[r]);
+        for (int k = 0; k < CH; ++k) {
+            if (base + k < NT) {
+                const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
+                y[r] = fma(cur[k], dev[i], (i == 0) ? 0.0 : y[r]);
+                if (k == 0 && c + 1 < NCH) {
+                    const cptr L2 = after(Lk + base + CH, y[r]);
+#pragma unroll
+                    for (int q = 0; q < CH; ++q)
+                        nxt[q] = (base + CH + q < NT) ? L2[q] : 0.0;
+                }
+                if (i == j) {
+                    if (DERIVED) derived[j] = y[r];
+                    chi2 = fma(y[r], y[r], chi2);
+                }
+            }
         }
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-            if (jb + r < D) {
-                if (DERIVED) derived[jb + r] = y[r];
-                chi2 = fma(y[r], y[r], chi2);
-            }
+        for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
     return -0.5 * (cnorm + chi2);
 }
@@ -77,8 +159,40 @@ __device__ __forceinline__ void eval_point(const double (&t)[D], cptr C, const C
                                            double& lp, double& ll, double* derived)
 {
     bool in = true;
+    {   // prior support, 8 dimensions (lo, hi) per chunk
+        constexpr int NC = (D + 7) / 8;
+        const cptr lo = C + cl.lo(), hi = C + cl.hi();
+        double cl_[8], ch_[8], nl_[8], nh_[8];
 #pragma unroll
-    for (int i = 0; i < D; ++i) in = in & (t[i] <= C[cl.hi() + i]) & (t[i] >= C[cl.lo() + i]);
+        for (int k = 0; k < 8; ++k) {
+            cl_[k] = (k < D) ? lo[k] : 0.0;
+            ch_[k] = (k < D) ? hi[k] : 0.0;
+        }
+        double anchor = t[0];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int b = c * 8;
+            in = in & (anchor <= ch_[0]) & (anchor >= cl_[0]);
+            if (c + 1 < NC) {
+                anchor = t[b + 8];
+                const cptr lo2 = after(lo + b + 8, anchor);
+                const cptr hi2 = hi + ((lo2 - lo) - 0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    nl_[k] = (b + 8 + k < D) ? lo2[k] : 0.0;
+                    nh_[k] = (b + 8 + k < D) ? hi2[k] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 8; ++k)
+                if (b + k < D) in = in & (t[b + k] <= ch_[k]) & (t[b + k] >= cl_[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cl_[k] = nl_[k];
+                ch_[k] = nh_[k];
+            }
+        }
+    }
     inb = in;
     double s = 0.0;
     if (GENERAL && norm_mask) {
@@ -119,6 +233,31 @@ __device__ __forceinline__ double wrap_periodic(double t, double lo, double hi)
     return m * w + lo;
 }
 
+// out[i] = fma(r, v[i], x[i]) with v streamed 16 dimensions per chunk (out may alias x)
+__device__ __forceinline__ void axpy_stream(double (&out)[D], double r, cptr v,
+                                            const double (&x)[D])
+{
+    constexpr int NC = (D + 15) / 16;
+    double cur[16], nxt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cur[k] = (k < D) ? v[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int b = c * 16;
+        out[b] = fma(r, cur[0], x[b]);
+        if (c + 1 < NC) {
+            const cptr v2 = after(v + b + 16, out[b]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? v2[k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+            if (b + k < D) out[b + k] = fma(r, cur[k], x[b + k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    }
+}
+
 // ---------------------------------------------------------------- the Metropolis kernel
 // GENERAL = false is the hot variant: uniform priors only, nothing periodic; the trial is
 // not kept in registers but recomputed (same fma) when the step is accepted.
@@ -127,7 +266,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sA[];  // MULTI only: [K][gs]
     const ConstLayout cl{D, a.n_modes};
-    const cptr C = as_const(a.cblock);
+    const cptr C0 = as_const(a.cblock);
     const int tid = threadIdx.x, gs = blockDim.x;
     const int w = blockIdx.x * gs + tid;
     const int W = a.W;
@@ -168,10 +307,10 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             Ea = -dlog(u52(ka));
         }
         // ---- proposal: t = x + r * v, v = T R[:, col] shared by the group
-        const cptr v = Vg + (size_t)cyc * (D * D) + col * D;
+        const cptr v = launder(Vg + (size_t)cyc * (D * D) + col * D);
+        const cptr C = launder(C0);
         double t[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) t[i] = fma(r, v[i], x[i]);
+        axpy_stream(t, r, v, x);
         if (GENERAL && a.periodic_mask) {
 #pragma unroll
             for (int i = 0; i < D; ++i)
@@ -208,8 +347,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             for (int i = 0; i < D; ++i) x[i] = accept ? t[i] : x[i];
         } else {
             const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly (v finite)
-#pragma unroll
-            for (int i = 0; i < D; ++i) x[i] = fma(ra, v[i], x[i]);
+            axpy_stream(x, ra, v, x);
         }
         lpri = accept ? lp : lpri;
         llik = accept ? ll : llik;

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-timeout 900 python bench.py 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -5
+timeout 300 python tools/quick_engine_bench.py 30 65536 64 300 2>&1 | tail -1
+timeout 300 python tools/quick_engine_bench.py 30 65536 256 300 2>&1 | tail -1
