@@ -69,6 +69,9 @@ def selected_dims():
 def build(dims=None, jobs=None, verbose=True):
     """Compile every selected dimension and link the shared library. Returns its path."""
     dims = list(dims) if dims is not None else selected_dims()
+    extra = os.environ.get("MCMC_HIP_EXTRA_FLAGS", "").split()  # developer experiments
+    if extra:
+        FLAGS.extend(f for f in extra if f not in FLAGS)
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in ("det_math.h", "kernels.h")]
     root_hdr = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "mcmc_hip.h")

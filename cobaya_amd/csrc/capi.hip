@@ -257,6 +257,9 @@ int upload_constants(mcmc_hip_ctx* h)
         c[cl.loc() + i] = h->loc[i];
         c[cl.scale() + i] = h->scale[i];
         c[cl.mls() + i] = h->mls[i];
+        c[cl.elem() + 3 * i + 0] = h->lo[i];
+        c[cl.elem() + 3 * i + 1] = h->hi[i];
+        c[cl.elem() + 3 * i + 2] = K > 0 ? h->mean[i] : 0.0;
     }
     for (int k = 0; k < K; ++k) {
         for (int i = 0; i < d; ++i) c[cl.mean(k) + i] = h->mean[(size_t)k * d + i];
@@ -277,10 +280,11 @@ int lds_check(mcmc_hip_ctx* h)
 {
     const ConstLayout cl{h->d, h->K};
     (void)cl;
-    const size_t lds = sizeof(double) * (h->K > 1 ? (size_t)h->K * h->gs : 0);
-    if (lds > 64 * 1024)
+    const size_t lds = sizeof(double) * ((h->K > 1 ? (size_t)h->K * 256 : 0) +
+                                         2 * (size_t)(256 / h->gs) * mcmc::v_slab(h->d));
+    if (lds > 160 * 1024)
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "problem constants need %zu bytes of LDS per workgroup (> 64 KiB): fewer "
+                    "the step kernel needs %zu bytes of LDS per workgroup (> 160 KiB): fewer "
                     "mixture modes or a smaller group_size are required", lds);
     return MCMC_HIP_OK;
 }
@@ -661,7 +665,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     if (n_steps <= 0) return fail(h, MCMC_HIP_ERR_ARG, "n_steps must be > 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const unsigned long long d = (unsigned long long)h->d;
-    const size_t dd = (size_t)h->d * h->d;
+    const size_t dd = (size_t)mcmc::v_slab(h->d);  // doubles per (group, cycle) slab
     // directions buffer: at most ~256 MiB of cycles per launch
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
     int left = n_steps;
@@ -690,12 +694,14 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             a.burn_left = h->burn.p; a.n_accept = h->nacc.p; a.stuck = h->stuck.p;
             a.rows = h->rows.p; a.n_rows = h->nrows.p; a.row_cap = h->cfg.emit_capacity;
             a.cblock = h->cblock.p; a.V = h->V.p; a.W = h->W; a.n_modes = h->K;
+            a.group_size = h->gs;
             a.norm_mask = h->norm_mask; a.periodic_mask = h->periodic_mask;
             a.walker0 = h->cfg.walker_offset;
             a.key0 = (uint32_t)h->cfg.seed; a.key1 = (uint32_t)(h->cfg.seed >> 32);
             a.step0 = h->step; a.n_steps = n; a.ncyc = ncyc;
             a.uniform_logp = h->uniform_logp; a.temperature = h->cfg.temperature;
             a.max_tries = h->cfg.max_tries;
+            a.cnorm0 = h->K > 0 ? h->cnorm[0] : 0.0;
             HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;
         }

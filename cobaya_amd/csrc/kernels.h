@@ -26,8 +26,13 @@ __host__ __device__ inline void tri_stream_for_each(int d, F&& f)
                 if (jb + r < d && i <= jb + r) f(idx++, jb + r, i);
 }
 
+// Doubles per (group, cycle) slab of proposal directions V[col][i]: d*d rounded up to whole
+// KiB so that the step kernel can move a slab into LDS with 1 KiB global->LDS DMA pieces.
+__host__ __device__ constexpr int v_slab(int d) { return ((d * d * 8 + 1023) / 1024) * 128; }
+
 // Constant block (doubles) in HBM, read through the scalar data cache:
-//   lo[d] hi[d] loc[d] scale[d] mls[d] | per mode k: mean[d] | cnorm[K] weight[K] |
+//   lo[d] hi[d] loc[d] scale[d] mls[d] | elem[d][3] = {lo_i, hi_i, mean0_i} (the interleaved
+//   stream of the fused proposal pass) | per mode k: mean[d] | cnorm[K] weight[K] |
 //   per mode k: Linv stream (tri_size(d))
 struct ConstLayout {
     int d, K;
@@ -36,8 +41,9 @@ struct ConstLayout {
     __host__ __device__ int loc() const { return 2 * d; }
     __host__ __device__ int scale() const { return 3 * d; }
     __host__ __device__ int mls() const { return 4 * d; }
-    __host__ __device__ int mean(int k) const { return 5 * d + k * d; }
-    __host__ __device__ int cnorm() const { return 5 * d + K * d; }
+    __host__ __device__ int elem() const { return 5 * d; }
+    __host__ __device__ int mean(int k) const { return 8 * d + k * d; }
+    __host__ __device__ int cnorm() const { return 8 * d + K * d; }
     __host__ __device__ int weight() const { return cnorm() + K; }
     __host__ __device__ int linv(int k) const
     {
@@ -63,8 +69,9 @@ struct StepArgs {
     int row_cap;
     // problem
     const double* cblock;
-    const double* V;  // [G][ncyc][d*d] direction vectors of the cycles this launch spans
+    const double* V;  // [G][ncyc][v_slab(d)] direction vectors of the cycles this launch spans
     int W;
+    int group_size;
     int n_modes;
     uint32_t norm_mask, periodic_mask;
     uint32_t walker0;
@@ -73,11 +80,12 @@ struct StepArgs {
     int n_steps;
     int ncyc;
     double uniform_logp, temperature, max_tries;
+    double cnorm0;  // d log 2pi + log|S_0| of mode 0 (kernarg copy for the hot variant)
 };
 
 struct BasisArgs {
     const double* T;  // [d*d] row-major lower-triangular proposal transform (scale folded in)
-    double* V;        // [G][ncyc][d*d]
+    double* V;        // [G][ncyc][v_slab(d)]
     uint32_t group0;
     uint32_t cycle0;
     uint32_t key0, key1;

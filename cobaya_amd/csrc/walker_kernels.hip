@@ -17,6 +17,9 @@
 #include "det_math.h"
 #include "kernels.h"
 
+#ifndef MCMC_CH
+#define MCMC_CH 16
+#endif
 #ifndef MCMC_D
 #error "compile with -DMCMC_D=<dimension>"
 #endif
@@ -61,8 +64,33 @@ __device__ __forceinline__ cptr after(cptr p, double& anchor)
     return (cptr)v;
 }
 
+__device__ __forceinline__ void after2(cptr& p, cptr& q, double& anchor)
+{
+    unsigned long long v = (unsigned long long)p, u = (unsigned long long)q;
+    asm volatile("; next operand chunk" : "+s"(v), "+s"(u), "+v"(anchor));
+    p = (cptr)v;
+    q = (cptr)u;
+}
+// The proposal directions of the current cycle live in LDS (staged by DMA one cycle ahead):
+// wave-uniform LDS addresses, read as broadcasts.
+typedef const double __attribute__((address_space(3))) * lptr;
+__device__ __forceinline__ lptr after(lptr p, double& anchor)
+{
+    unsigned v = (unsigned)(unsigned long long)p;
+    asm volatile("; next operand chunk" : "+s"(v), "+v"(anchor));
+    return (lptr)(unsigned long long)v;
+}
+__device__ __forceinline__ void after2(lptr& p, cptr& q, double& anchor)
+{
+    unsigned v = (unsigned)(unsigned long long)p;
+    unsigned long long u = (unsigned long long)q;
+    asm volatile("; next operand chunk" : "+s"(v), "+s"(u), "+v"(anchor));
+    p = (lptr)(unsigned long long)v;
+    q = (cptr)u;
+}
+
 constexpr int NT = D * (D + 1) / 2;  // operands of one whitening factor
-constexpr int CH = 16;               // doubles per chunk = two s_load_dwordx16
+constexpr int CH = MCMC_CH;           // doubles per chunk (16 = two s_load_dwordx16)
 constexpr int NCH = (NT + CH - 1) / CH;
 
 struct TriMap {
@@ -86,43 +114,87 @@ constexpr TriMap make_tri_map()
 __device__ constexpr TriMap kTriMap = make_tri_map();
 
 // ---------------------------------------------------------------- log-posterior of a point
+// prior support test, 8 dimensions (lo, hi) per chunk
+__device__ __forceinline__ void bounds_stream(const double (&t)[D], cptr lo, cptr hi, bool& inb)
+{
+    bool in = true;
+    constexpr int NC = (D + 7) / 8;
+    double cl_[8], ch_[8], nl_[8], nh_[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cl_[k] = (k < D) ? lo[k] : 0.0;
+        ch_[k] = (k < D) ? hi[k] : 0.0;
+    }
+    double anchor = t[0];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int b = c * 8;
+        in = in & (anchor <= ch_[0]) & (anchor >= cl_[0]);
+        if (c + 1 < NC) {
+            anchor = t[b + 8];
+            cptr lo2 = lo + b + 8, hi2 = hi + b + 8;
+            after2(lo2, hi2, anchor);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                nl_[k] = (b + 8 + k < D) ? lo2[k] : 0.0;
+                nh_[k] = (b + 8 + k < D) ? hi2[k] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (b + k < D) in = in & (t[b + k] <= ch_[k]) & (t[b + k] >= cl_[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cl_[k] = nl_[k];
+            ch_[k] = nh_[k];
+        }
+    }
+    inb = in;
+}
+
+// dev = t - mu, 16 dimensions per chunk
+__device__ __forceinline__ void dev_stream(double (&dev)[D], const double (&t)[D], cptr mu)
+{
+    constexpr int NC = (D + 15) / 16;
+    double cur[16], nxt[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cur[k] = (k < D) ? mu[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int b = c * 16;
+        dev[b] = t[b] - cur[0];
+        if (c + 1 < NC) {
+            const cptr m2 = after(mu + b + 16, dev[b]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? m2[k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+            if (b + k < D) dev[b + k] = t[b + k] - cur[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    }
+}
+
 // One mode: triangular whitening y = L^-1 (t - mu), chi2 = |y|^2, as fma chains in ascending
 // index order; kRowBlock rows advance together (independent chains in flight); Lk is the
 // operand stream packed in exactly this order (kernels.h tri_stream_for_each).
-template <bool DERIVED>
-__device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cptr Lk,
-                                              double cnorm, double* derived)
+// chi2 = |L^-1 dev|^2 from the operand stream Lk.  `anchor` is any value computed just before
+// (its producer precedes the first chunk's loads).  TAIL: while the LAST chunk is being
+// consumed, the first 16 doubles at `tail_ptr` are fetched into `tail` (the next phase's
+// first chunk).
+template <bool DERIVED, bool TAIL, typename TP>
+__device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, double& anchor,
+                                             double* derived, TP tail_ptr, double (&tail)[16])
 {
     constexpr int RB = kRowBlock;
-    double dev[D];
-    {   // dev = t - mu, 16 dimensions per chunk
-        constexpr int NC = (D + 15) / 16;
-        double cur[16], nxt[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cur[k] = (k < D) ? mu[k] : 0.0;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int b = c * 16;
-            dev[b] = t[b] - cur[0];
-            if (c + 1 < NC) {
-                const cptr m2 = after(mu + b + 16, dev[b]);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? m2[k] : 0.0;
-            }
-#pragma unroll
-            for (int k = 1; k < 16; ++k)
-                if (b + k < D) dev[b + k] = t[b + k] - cur[k];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
-        }
-    }
     double chi2 = 0.0;
     double y[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) y[r] = 0.0;
     double cur[CH], nxt[CH];
     {
-        const cptr L0 = after(Lk, dev[D - 1]);
+        const cptr L0 = after(Lk, anchor);
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = (k < NT) ? L0[k] : 0.0;
     }
@@ -135,10 +207,23 @@ __device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cpt
                 const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
                 y[r] = fma(cur[k], dev[i], (i == 0) ? 0.0 : y[r]);
                 if (k == 0 && c + 1 < NCH) {
-                    const cptr L2 = after(Lk + base + CH, y[r]);
+#ifdef MCMC_FAKE_HALF  // timing experiment only (wrong results): skip every other chunk's loads
+                    if (c & 1) {
 #pragma unroll
-                    for (int q = 0; q < CH; ++q)
-                        nxt[q] = (base + CH + q < NT) ? L2[q] : 0.0;
+                        for (int q = 0; q < CH; ++q) nxt[q] = cur[q] * 1.0000001;
+                    } else
+#endif
+                    {
+                        const cptr L2 = after(Lk + base + CH, y[r]);
+#pragma unroll
+                        for (int q = 0; q < CH; ++q)
+                            nxt[q] = (base + CH + q < NT) ? L2[q] : 0.0;
+                    }
+                }
+                if (TAIL && k == 0 && c + 1 == NCH) {
+                    const TP T2 = after(tail_ptr, y[r]);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) tail[q] = (q < D) ? T2[q] : 0.0;
                 }
                 if (i == j) {
                     if (DERIVED) derived[j] = y[r];
@@ -149,7 +234,63 @@ __device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cpt
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
+    return chi2;
+}
+
+// One mode: triangular whitening y = L^-1 (t - mu), chi2 = |y|^2, as fma chains in ascending
+// index order; kRowBlock rows advance together (independent chains in flight); Lk is the
+// operand stream packed in exactly this order (kernels.h tri_stream_for_each).
+template <bool DERIVED>
+__device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cptr Lk,
+                                              double cnorm, double* derived)
+{
+    double dev[D];
+    dev_stream(dev, t, mu);
+    double tail[16];
+    const double chi2 = tri_stream<DERIVED, false, cptr>(dev, Lk, dev[D - 1], derived, Lk, tail);
     return -0.5 * (cnorm + chi2);
+}
+
+// Hot path (one mode, uniform priors): ONE pass over the dimensions computes the trial
+// t_i = fma(r, v_i, x_i), tests the prior support and forms dev_i = t_i - mu_i, 4 dimensions
+// per chunk from the interleaved stream elem[i] = {lo_i, hi_i, mu_i}.  A dimension outside
+// its bounds gets dev_i = +inf, which makes chi2 non-finite: "outside the prior support" is
+// recovered as !(chi2 < inf) with no mask reduction over the dimensions.
+__device__ __forceinline__ void propose_fused(double (&dev)[D], double r, lptr v, cptr E,
+                                              const double (&x)[D])
+{
+    constexpr int NC = (D + 3) / 4;
+    double cv[4], ce[12], nv[4], ne[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cv[k] = (k < D) ? v[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) ce[k] = (k < 3 * D) ? E[k] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int b = 4 * c;
+        double t0 = fma(r, cv[0], x[b]);
+        if (c + 1 < NC) {
+            lptr v2 = v + b + 4;
+            cptr e2 = E + 3 * (b + 4);
+            after2(v2, e2, t0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nv[k] = (b + 4 + k < D) ? v2[k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) ne[k] = (3 * (b + 4) + k < 3 * D) ? e2[k] : 0.0;
+        }
+        dev[b] = ((t0 <= ce[1]) & (t0 >= ce[0])) ? t0 - ce[2] : INFINITY;
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (b + k < D) {
+                const double tk = fma(r, cv[k], x[b + k]);
+                dev[b + k] = ((tk <= ce[3 * k + 1]) & (tk >= ce[3 * k])) ? tk - ce[3 * k + 2]
+                                                                        : INFINITY;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cv[k] = nv[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ce[k] = ne[k];
+    }
 }
 
 template <bool MULTI, bool DERIVED, bool GENERAL>
@@ -158,41 +299,8 @@ __device__ __forceinline__ void eval_point(const double (&t)[D], cptr C, const C
                                            double* __restrict__ sA, int astride, bool& inb,
                                            double& lp, double& ll, double* derived)
 {
-    bool in = true;
-    {   // prior support, 8 dimensions (lo, hi) per chunk
-        constexpr int NC = (D + 7) / 8;
-        const cptr lo = C + cl.lo(), hi = C + cl.hi();
-        double cl_[8], ch_[8], nl_[8], nh_[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            cl_[k] = (k < D) ? lo[k] : 0.0;
-            ch_[k] = (k < D) ? hi[k] : 0.0;
-        }
-        double anchor = t[0];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int b = c * 8;
-            in = in & (anchor <= ch_[0]) & (anchor >= cl_[0]);
-            if (c + 1 < NC) {
-                anchor = t[b + 8];
-                const cptr lo2 = after(lo + b + 8, anchor);
-                const cptr hi2 = hi + ((lo2 - lo) - 0);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    nl_[k] = (b + 8 + k < D) ? lo2[k] : 0.0;
-                    nh_[k] = (b + 8 + k < D) ? hi2[k] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int k = 1; k < 8; ++k)
-                if (b + k < D) in = in & (t[b + k] <= ch_[k]) & (t[b + k] >= cl_[k]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                cl_[k] = nl_[k];
-                ch_[k] = nh_[k];
-            }
-        }
-    }
+    bounds_stream(t, C + cl.lo(), C + cl.hi(), inb);
+    bool in = inb;
     inb = in;
     double s = 0.0;
     if (GENERAL && norm_mask) {
@@ -233,20 +341,22 @@ __device__ __forceinline__ double wrap_periodic(double t, double lo, double hi)
     return m * w + lo;
 }
 
-// out[i] = fma(r, v[i], x[i]) with v streamed 16 dimensions per chunk (out may alias x)
-__device__ __forceinline__ void axpy_stream(double (&out)[D], double r, cptr v,
-                                            const double (&x)[D])
+// out[i] = fma(r, v[i], x[i]) with v streamed 16 dimensions per chunk (out may alias x);
+// PRELOADED: the first chunk is already in `first` (fetched by the previous phase).
+template <bool PRELOADED>
+__device__ __forceinline__ void axpy_stream(double (&out)[D], double r, lptr v,
+                                            const double (&x)[D], const double (&first)[16])
 {
     constexpr int NC = (D + 15) / 16;
     double cur[16], nxt[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) cur[k] = (k < D) ? v[k] : 0.0;
+    for (int k = 0; k < 16; ++k) cur[k] = PRELOADED ? first[k] : ((k < D) ? v[k] : 0.0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int b = c * 16;
         out[b] = fma(r, cur[0], x[b]);
         if (c + 1 < NC) {
-            const cptr v2 = after(v + b + 16, out[b]);
+            const lptr v2 = after(v + b + 16, out[b]);
 #pragma unroll
             for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? v2[k] : 0.0;
         }
@@ -259,18 +369,48 @@ __device__ __forceinline__ void axpy_stream(double (&out)[D], double r, cptr v,
 }
 
 // ---------------------------------------------------------------- the Metropolis kernel
-// GENERAL = false is the hot variant: uniform priors only, nothing periodic; the trial is
-// not kept in registers but recomputed (same fma) when the step is accepted.
+// FAST (= !MULTI && !GENERAL) is the hot variant: exactly one mode, uniform priors only,
+// nothing periodic, no row emission; no control flow inside a step, the trial is not kept in
+// registers but recomputed (same fma) when the step is accepted.  The GENERAL variants cover
+// everything else (normal priors, periodic parameters, `one`, mixtures, emitted rows).
 template <bool MULTI, bool GENERAL>
 __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double sA[];  // MULTI only: [K][gs]
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int SLAB = v_slab(D);
     const ConstLayout cl{D, a.n_modes};
     const cptr C0 = as_const(a.cblock);
     const int tid = threadIdx.x, gs = blockDim.x;
     const int w = blockIdx.x * gs + tid;
     const int W = a.W;
-    const cptr Vg = as_const(a.V) + (size_t)blockIdx.x * a.ncyc * (D * D);
+    // workgroup != group: the block is as wide as W allows (4 waves = one per SIMD of a CU, so
+    // the dispatcher cannot pile single-wave workgroups onto one SIMD); the basis group of a
+    // wave is wave-uniform, hence the readfirstlane.
+    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
+    const int gpb = gs / a.group_size;                       // groups per block
+    const int gib = __builtin_amdgcn_readfirstlane(tid / a.group_size);   // group in block
+    const int wpg = a.group_size >> 6;                       // waves per group
+    const int part = __builtin_amdgcn_readfirstlane((tid >> 6) % wpg);
+    // LDS: two slabs of proposal directions per group of the block (current cycle and the
+    // next one, which a global->LDS DMA fills while the current one is used), then sA.
+    double* sV[2] = {smem, smem + gpb * SLAB};
+    double* const sA = smem + 2 * gpb * SLAB;                // MULTI only: [K][blockDim]
+    const double* const Vgrp = a.V + (size_t)group * a.ncyc * SLAB;
+    auto stage_dma = [&](int cycle, double* dst) {
+        // this wave moves every wpg-th KiB of its group's slab; each lane carries 16 bytes
+        for (int kb = part; kb < SLAB / 128; kb += wpg) {
+            const char* g = (const char*)(Vgrp + (size_t)cycle * SLAB) + kb * 1024 + (tid & 63) * 16;
+            char* l = (char*)(dst + gib * SLAB) + kb * 1024;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)g,
+                (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    stage_dma(0, sV[0]);
+    if (a.ncyc > 1) stage_dma(1, sV[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur_buf = 0;
 
     double x[D];
 #pragma unroll
@@ -307,27 +447,41 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             Ea = -dlog(u52(ka));
         }
         // ---- proposal: t = x + r * v, v = T R[:, col] shared by the group
-        const cptr v = launder(Vg + (size_t)cyc * (D * D) + col * D);
+        const lptr v = (lptr)(sV[cur_buf] + gib * SLAB + col * D);
         const cptr C = launder(C0);
-        double t[D];
-        axpy_stream(t, r, v, x);
-        if (GENERAL && a.periodic_mask) {
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-                if ((a.periodic_mask >> i) & 1u)
-                    t[i] = wrap_periodic(t[i], C[cl.lo() + i], C[cl.hi() + i]);
-        }
-        // ---- log-posterior of the trial
         bool inb;
         double lp, ll;
-        eval_point<MULTI, false, GENERAL>(t, C, cl, a.norm_mask, a.uniform_logp, sA + tid, gs, inb,
-                                          lp, ll, nullptr);
+        double t[D];
+        double vhead[16];  // FAST: first chunk of v, re-fetched for the commit
+        constexpr bool FAST = !MULTI && !GENERAL;
+        if (FAST) {
+            double dev[D];
+            propose_fused(dev, r, v, C + cl.elem(), x);
+            lp = a.uniform_logp + 0.0;
+            const double chi2 = tri_stream<false, true, lptr>(dev, C + cl.linv(0), dev[D - 1],
+                                                              nullptr, v, vhead);
+            inb = chi2 < INFINITY;  // false for +inf and NaN: some dimension was out of bounds
+            ll = -0.5 * (a.cnorm0 + chi2);
+        } else {
+            axpy_stream<false>(t, r, v, x, vhead);
+            if (GENERAL && a.periodic_mask) {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    if ((a.periodic_mask >> i) & 1u)
+                        t[i] = wrap_periodic(t[i], C[cl.lo() + i], C[cl.hi() + i]);
+            }
+            // ---- log-posterior of the trial
+            eval_point<MULTI, false, GENERAL>(t, C, cl, a.norm_mask, a.uniform_logp, sA + tid, gs,
+                                              inb, lp, ll, nullptr);
+        }
         const double lt = inb ? lp + ll : -INFINITY;
         // ---- Metropolis test (mcmc.py:678-683)
         const bool accept = inb & (lt != -INFINITY) &
                             ((lt > lpost) | (Ea > (lpost - lt) / a.temperature));
         // ---- bookkeeping (mcmc.py:685-748)
-        if (accept) {
+        if (FAST) {
+            burn -= (accept & (burn > 0)) ? 1 : 0;
+        } else if (accept) {
             if (burn <= 0) {
                 if (a.rows) {
                     if (nrow < a.row_cap) {
@@ -342,12 +496,12 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
                 --burn;
             }
         }
-        if (GENERAL) {
+        if (FAST) {
+            const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly (v finite)
+            axpy_stream<true>(x, ra, v, x, vhead);
+        } else {
 #pragma unroll
             for (int i = 0; i < D; ++i) x[i] = accept ? t[i] : x[i];
-        } else {
-            const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly (v finite)
-            axpy_stream(x, ra, v, x);
         }
         lpri = accept ? lp : lpri;
         llik = accept ? ll : llik;
@@ -360,18 +514,31 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
         }
         ++step;
-        if (++col == D) {
+        if (++col == D) {  // next cycle: its slab was DMA'd during this one
             col = 0;
             ++cyc;
+            if (s + 1 < a.n_steps) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (cyc + 1 < a.ncyc) stage_dma(cyc + 1, sV[cur_buf]);
+                cur_buf ^= 1;
+            }
         }
     }
 
+    // The output pointers are re-read from the kernarg segment here (behind an asm the loads
+    // cannot be hoisted over) so that they do not occupy ~30 SGPRs for the whole step loop.
+    typedef const StepArgs __attribute__((address_space(4))) * kaptr;
+    unsigned long long kav = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; epilogue" : "+s"(kav));
+    const kaptr ka = (kaptr)kav;
+    double* const ox = ka->x;
 #pragma unroll
-    for (int i = 0; i < D; ++i) a.x[(size_t)i * W + w] = x[i];
-    a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
-    a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
-    a.n_accept[w] = nacc;
-    if (a.rows) a.n_rows[w] = nrow;
+    for (int i = 0; i < D; ++i) ox[(size_t)i * W + w] = x[i];
+    ka->logpost[w] = lpost; ka->logprior[w] = lpri; ka->loglike[w] = llik;
+    ka->weight[w] = wt; ka->prior_rej[w] = prej; ka->burn_left[w] = burn;
+    ka->n_accept[w] = nacc;
+    if (ka->rows) ka->n_rows[w] = nrow;
 }
 
 // ---------------------------------------------------------------- Haar basis kernel
@@ -389,7 +556,7 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a)
     const int lane = threadIdx.x;
     const uint32_t group = a.group0 + blockIdx.x;
     const uint32_t cycle = a.cycle0 + blockIdx.y;
-    double* __restrict__ Vout = a.V + ((size_t)blockIdx.x * a.ncyc + blockIdx.y) * (D * D);
+    double* __restrict__ Vout = a.V + ((size_t)blockIdx.x * a.ncyc + blockIdx.y) * v_slab(D);
 
     for (int i = lane; i < D * D; i += 64) sT[i] = a.T[i];
     if (D == 1) {
@@ -533,9 +700,31 @@ __global__ void __launch_bounds__(64) pool_moments_kernel(const MomentArgs a)
 hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
 {
     const bool multi = a.n_modes > 1;
-    const size_t lds = sizeof(double) * (size_t)(multi ? a.n_modes * group_size : 0);
-    const dim3 grid(a.W / group_size), block(group_size);
-    const bool general = (a.norm_mask | a.periodic_mask) != 0u;
+    size_t lds = 0;
+    const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
+    const dim3 grid(a.W / bs), block(bs);
+    lds = sizeof(double) * (size_t)(2 * (bs / a.group_size) * v_slab(D) + (multi ? a.n_modes * bs : 0));
+    // Placement: the waves of this kernel run for the whole launch, and at W = 65 536 there
+    // are exactly as many waves as SIMDs.  Requesting (otherwise unused) LDS so that only
+    // ceil(#workgroups / 256 CUs) workgroups fit on a CU makes the dispatcher spread them
+    // evenly instead of doubling up waves on some SIMDs while others idle.
+    {
+        const int per_cu = (int)((grid.x + 255) / 256);
+        size_t want = (size_t)(160 * 1024) / (size_t)per_cu;
+        want = (want / 1024) * 1024;
+        if (want > 64 * 1024) want = 64 * 1024;
+        if (want > lds) lds = want;
+    }
+    const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
+                         a.rows != nullptr;
+    const void* fn = multi ? (general ? (const void*)step_kernel<true, true>
+                                      : (const void*)step_kernel<true, false>)
+                           : (general ? (const void*)step_kernel<false, true>
+                                      : (const void*)step_kernel<false, false>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (multi) {
         if (general) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((step_kernel<true, false>), grid, block, lds, st, a);
