@@ -24,8 +24,10 @@ ALL_DIMS = list(range(1, 33))
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
 # operations are written as fma()); see DESIGN.md "Ensemble specification".
+# -pragma-unroll-threshold: the operand-stream loops must be unrolled completely (their
+# register arrays are only addressable with compile-time indices).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
+         "-fno-fast-math", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
          "-Wno-unused-result"]
 
 

@@ -127,4 +127,82 @@ __device__ __forceinline__ void sincos2pi(uint64_t k, double& sn, double& cs)
     cs = ((o + 2u) & 4u) ? -cc : cc;                    // octants 2..5
 }
 
+// ---------------------------------------------------------------------------------------
+// The random variates of one Metropolis step -- r (radial proposal distance) and Ea (the
+// Exp(1) variate of the accept test) -- as a STAGED computation: the same operations as
+// philox4x32_10 + u52 + dlog + sqrt above, cut into kStages pieces so that the hot kernel can
+// spread the next step's RNG arithmetic over the operand-stream chunks of the current step
+// (filling its scalar-load waits).  run_all() == the un-staged sequence, bit for bit.
+struct StepRng {
+    static constexpr int kStages = 18;
+    uint32_t c0, c1, c2, c3, k0, k1;
+    uint64_t kr, ka;
+    bool expo;
+    double f, dk, s, Er, Ea, r;
+
+    __device__ __forceinline__ void begin(uint32_t key0, uint32_t key1, uint32_t gid,
+                                          unsigned long long step)
+    {
+        k0 = key0; k1 = key1;
+        c0 = gid; c1 = kStreamStep; c2 = (uint32_t)step; c3 = (uint32_t)(step >> 32);
+    }
+    __device__ __forceinline__ void round()
+    {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    // dlog split in two: (a) reduction + the division s = f / (2 + f); (b) polynomial
+    __device__ __forceinline__ void log_a(double x)
+    {
+        const uint64_t b = (uint64_t)__double_as_longlong(x);
+        uint32_t hx = (uint32_t)(b >> 32);
+        int k = (int)(hx >> 20) - 1023;
+        hx &= 0x000fffffu;
+        const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+        const uint64_t nb = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (b & 0xffffffffull);
+        k += (int)(i >> 20);
+        f = __longlong_as_double((long long)nb) - 1.0;
+        dk = (double)k;
+        s = f / (2.0 + f);
+    }
+    __device__ __forceinline__ double log_b() const
+    {
+        constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                         Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                         Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                         Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                         Lg7 = 1.479819860511658591e-01;
+        const double z = s * s;
+        const double w = z * z;
+        const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+        const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+        const double R = t2 + t1;
+        const double hfsq = 0.5 * f * f;
+        return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+    }
+    __device__ __forceinline__ void stage(int k)
+    {
+        if (k >= 0 && k < 10) round();
+        else if (k == 10) {
+            kr = ((uint64_t)c1 << 20) | (c2 >> 12);
+            ka = ((uint64_t)c3 << 20) | ((uint64_t)(c2 & 0xFFFu) << 8) | (c0 & 0xFFu);
+            expo = (c0 >> 8) < kBranchExp24;
+        } else if (k == 11) log_a(u52(kr));
+        else if (k == 12) Er = -log_b();
+        else if (k == 13) log_a(u52(ka));
+        else if (k == 14) Ea = -log_b();
+        else if (k == 15) r = sqrt(2.0 * Er);
+        else if (k == 16) r = expo ? Er : r;
+    }
+    __device__ __forceinline__ void run_all()
+    {
+#pragma unroll
+        for (int k = 0; k < kStages; ++k) stage(k);
+    }
+};
+
 }  // namespace mcmc

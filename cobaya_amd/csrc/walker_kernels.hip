@@ -20,6 +20,9 @@
 #ifndef MCMC_CH
 #define MCMC_CH 16
 #endif
+#ifndef MCMC_RNGPIPE
+#define MCMC_RNGPIPE true
+#endif
 #ifndef MCMC_D
 #error "compile with -DMCMC_D=<dimension>"
 #endif
@@ -183,9 +186,10 @@ __device__ __forceinline__ void dev_stream(double (&dev)[D], const double (&t)[D
 // (its producer precedes the first chunk's loads).  TAIL: while the LAST chunk is being
 // consumed, the first 16 doubles at `tail_ptr` are fetched into `tail` (the next phase's
 // first chunk).
-template <bool DERIVED, bool TAIL, typename TP>
+template <bool DERIVED, bool TAIL, bool PRELOADED, bool RNG, typename TP>
 __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, double& anchor,
-                                             double* derived, TP tail_ptr, double (&tail)[16])
+                                             double* derived, TP tail_ptr, double (&tail)[16],
+                                             const double (&first)[CH], StepRng& rng)
 {
     constexpr int RB = kRowBlock;
     double chi2 = 0.0;
@@ -193,7 +197,10 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
 #pragma unroll
     for (int r = 0; r < RB; ++r) y[r] = 0.0;
     double cur[CH], nxt[CH];
-    {
+    if (PRELOADED) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) cur[k] = first[k];
+    } else {
         const cptr L0 = after(Lk, anchor);
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = (k < NT) ? L0[k] : 0.0;
@@ -201,36 +208,45 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int base = c * CH;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            if (base + k < NT) {
-                const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
-                y[r] = fma(cur[k], dev[i], (i == 0) ? 0.0 : y[r]);
-                if (k == 0 && c + 1 < NCH) {
-#ifdef MCMC_FAKE_HALF  // timing experiment only (wrong results): skip every other chunk's loads
-                    if (c & 1) {
-#pragma unroll
-                        for (int q = 0; q < CH; ++q) nxt[q] = cur[q] * 1.0000001;
-                    } else
-#endif
-                    {
-                        const cptr L2 = after(Lk + base + CH, y[r]);
-#pragma unroll
-                        for (int q = 0; q < CH; ++q)
-                            nxt[q] = (base + CH + q < NT) ? L2[q] : 0.0;
-                    }
-                }
-                if (TAIL && k == 0 && c + 1 == NCH) {
-                    const TP T2 = after(tail_ptr, y[r]);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) tail[q] = (q < D) ? T2[q] : 0.0;
-                }
-                if (i == j) {
-                    if (DERIVED) derived[j] = y[r];
-                    chi2 = fma(y[r], y[r], chi2);
-                }
+        auto op = [&](int k) {
+            const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
+            y[r] = fma(cur[k], dev[i], (i == 0) ? 0.0 : y[r]);
+            return r;
+        };
+        auto fin = [&](int k) {
+            const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
+            if (i == j) {
+                if (DERIVED) derived[j] = y[r];
+                chi2 = fma(y[r], y[r], chi2);
             }
+        };
+        // first operand of the chunk: the only wait; then the next chunk's loads go out
+        const int r0 = op(0);
+        if (c + 1 < NCH) {
+            const cptr L2 = after(Lk + base + CH, y[r0]);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) nxt[q] = (base + CH + q < NT) ? L2[q] : 0.0;
         }
+        if (TAIL && c + 1 == NCH) {
+            const TP T2 = after(tail_ptr, y[r0]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tail[q] = (q < D) ? T2[q] : 0.0;
+        }
+        if (RNG) {  // the next step's RNG arithmetic rides behind this chunk's loads
+#pragma unroll
+            for (int st = 0; st < StepRng::kStages; ++st)
+                if ((st * NCH) / StepRng::kStages == c) rng.stage(st);
+        }
+        fin(0);
+#pragma unroll
+        for (int k = 1; k < CH; ++k)
+            if (base + k < NT) {
+                op(k);
+                fin(k);
+            }
+        // chunk fence: every accumulator passes through an empty asm, so no FMA of this chunk
+        // can be delayed past it (its SGPR operands die here) and none of the next can start
+        asm volatile("; chunk end" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(chi2));
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
@@ -246,8 +262,10 @@ __device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cpt
 {
     double dev[D];
     dev_stream(dev, t, mu);
-    double tail[16];
-    const double chi2 = tri_stream<DERIVED, false, cptr>(dev, Lk, dev[D - 1], derived, Lk, tail);
+    double tail[16], first[CH];
+    StepRng none;
+    const double chi2 = tri_stream<DERIVED, false, false, false, cptr>(dev, Lk, dev[D - 1], derived,
+                                                                      Lk, tail, first, none);
     return -0.5 * (cnorm + chi2);
 }
 
@@ -257,7 +275,7 @@ __device__ __forceinline__ double mode_logpdf(const double (&t)[D], cptr mu, cpt
 // its bounds gets dev_i = +inf, which makes chi2 non-finite: "outside the prior support" is
 // recovered as !(chi2 < inf) with no mask reduction over the dimensions.
 __device__ __forceinline__ void propose_fused(double (&dev)[D], double r, lptr v, cptr E,
-                                              const double (&x)[D])
+                                              const double (&x)[D], cptr Lk, double (&lfirst)[CH])
 {
     constexpr int NC = (D + 3) / 4;
     double cv[4], ce[12], nv[4], ne[12];
@@ -277,6 +295,10 @@ __device__ __forceinline__ void propose_fused(double (&dev)[D], double r, lptr v
             for (int k = 0; k < 4; ++k) nv[k] = (b + 4 + k < D) ? v2[k] : 0.0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) ne[k] = (3 * (b + 4) + k < 3 * D) ? e2[k] : 0.0;
+        } else {  // last chunk: fetch the first chunk of the whitening stream behind it
+            const cptr L0 = after(Lk, t0);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) lfirst[k] = (k < NT) ? L0[k] : 0.0;
         }
         dev[b] = ((t0 <= ce[1]) & (t0 >= ce[0])) ? t0 - ce[2] : INFINITY;
 #pragma unroll
@@ -423,28 +445,34 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     unsigned long long step = a.step0;
     int col = (int)(step % (unsigned long long)D);
     int cyc = 0;
+    StepRng rng;
+    if (!MULTI && !GENERAL && D >= 2) {  // hot variant: the first step's variates up front
+        rng.begin(a.key0, a.key1, gid, step);
+        rng.run_all();
+    }
 
     for (int s = 0; s < a.n_steps; ++s) {
         // ---- random variates of (walker, step): one Philox block
-        const u32x4 r4 = philox4x32_10(a.key0, a.key1, gid, kStreamStep, (uint32_t)step,
-                                       (uint32_t)(step >> 32));
-        const uint64_t kr = ((uint64_t)r4.w1 << 20) | (r4.w2 >> 12);
-        const uint64_t ka = ((uint64_t)r4.w3 << 20) | ((uint64_t)(r4.w2 & 0xFFFu) << 8) |
-                            (r4.w0 & 0xFFu);
-        const double Er = -dlog(u52(kr));
-        const bool expo = (r4.w0 >> 8) < kBranchExp24;
+        constexpr bool FAST = !MULTI && !GENERAL && D >= 2;
         double r, Ea;
-        if (D == 1) {
-            double sn, cs;
-            sincos2pi(ka, sn, cs);
-            const double rr = expo ? Er : sqrt(2.0 * Er) * fabs(cs);
-            r = (r4.w0 & 0x80u) ? rr : -rr;
-            const u32x4 q4 = philox4x32_10(a.key0, a.key1, gid, kStreamStep | 0x100u,
-                                           (uint32_t)step, (uint32_t)(step >> 32));
-            Ea = -dlog(u52(((uint64_t)q4.w0 << 20) | (q4.w1 >> 12)));
+        if (FAST) {  // computed during the previous step's whitening stream (or the prologue)
+            r = rng.r;
+            Ea = rng.Ea;
+            rng.begin(a.key0, a.key1, gid, step + 1);
         } else {
-            r = expo ? Er : sqrt(2.0 * Er);
-            Ea = -dlog(u52(ka));
+            rng.begin(a.key0, a.key1, gid, step);
+            rng.run_all();
+            r = rng.r;
+            Ea = rng.Ea;
+            if (D == 1) {
+                double sn, cs;
+                sincos2pi(rng.ka, sn, cs);
+                const double rr = rng.expo ? rng.Er : sqrt(2.0 * rng.Er) * fabs(cs);
+                r = (rng.c0 & 0x80u) ? rr : -rr;
+                const u32x4 q4 = philox4x32_10(a.key0, a.key1, gid, kStreamStep | 0x100u,
+                                               (uint32_t)step, (uint32_t)(step >> 32));
+                Ea = -dlog(u52(((uint64_t)q4.w0 << 20) | (q4.w1 >> 12)));
+            }
         }
         // ---- proposal: t = x + r * v, v = T R[:, col] shared by the group
         const lptr v = (lptr)(sV[cur_buf] + gib * SLAB + col * D);
@@ -453,13 +481,12 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
         double lp, ll;
         double t[D];
         double vhead[16];  // FAST: first chunk of v, re-fetched for the commit
-        constexpr bool FAST = !MULTI && !GENERAL;
         if (FAST) {
-            double dev[D];
-            propose_fused(dev, r, v, C + cl.elem(), x);
+            double dev[D], lfirst[CH];
+            propose_fused(dev, r, v, C + cl.elem(), x, C + cl.linv(0), lfirst);
             lp = a.uniform_logp + 0.0;
-            const double chi2 = tri_stream<false, true, lptr>(dev, C + cl.linv(0), dev[D - 1],
-                                                              nullptr, v, vhead);
+            const double chi2 = tri_stream<false, true, true, MCMC_RNGPIPE, lptr>(
+                dev, C + cl.linv(0), dev[D - 1], nullptr, v, vhead, lfirst, rng);
             inb = chi2 < INFINITY;  // false for +inf and NaN: some dimension was out of bounds
             ll = -0.5 * (a.cnorm0 + chi2);
         } else {
@@ -716,7 +743,7 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
         if (want > lds) lds = want;
     }
     const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
-                         a.rows != nullptr;
+                         a.rows != nullptr || D == 1;
     const void* fn = multi ? (general ? (const void*)step_kernel<true, true>
                                       : (const void*)step_kernel<true, false>)
                            : (general ? (const void*)step_kernel<false, true>
