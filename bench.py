@@ -41,12 +41,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU")
     ap.add_argument("--dim", type=int, default=30)
-    ap.add_argument("--group-size", type=int, default=64)
-    ap.add_argument("--steps-per-launch", type=int, default=None, help="default 10*d")
+    ap.add_argument("--group-size", type=int, default=256,
+                    help="walkers per Haar-basis group (the sampler's default at this size)")
+    ap.add_argument("--steps-per-launch", type=int, default=None,
+                    help="default 40*d (the sampler's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -117,7 +119,7 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={size}; launch with "
               "torch.distributed.run for N > 1", file=sys.stderr)
     d = a.dim
-    spl = a.steps_per_launch or 10 * d
+    spl = a.steps_per_launch or 40 * d
     mean, cov = target(d)
     info = make_info(d, mean, cov, a.walkers, a.group_size, spl)
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))

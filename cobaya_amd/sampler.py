@@ -64,9 +64,10 @@ MCMC_DEFAULTS = {
 # options of the ensemble engine (new; typed class attributes in the Cobaya subclass)
 HIP_DEFAULTS = {
     "n_walkers": 65536,       # walkers PER PROCESS (= per GPU)
-    "group_size": 64,         # walkers sharing one Haar basis = one R-1 "chain"
+    "group_size": None,       # walkers sharing one Haar basis = one R-1 "chain";
+                              # default: 256 from 16384 walkers per process up, else 64
     "device": None,           # HIP ordinal; default LOCAL_RANK
-    "steps_per_launch": "10d",  # Metropolis steps fused per kernel launch
+    "steps_per_launch": "40d",  # Metropolis steps fused per kernel launch
     "moments_every": 1,       # launches between moment snapshots
     "emit": "snapshots",      # "snapshots": ensemble state every snapshot_every steps,
                               # "chains": every accepted row with its integer weight
@@ -165,8 +166,16 @@ class MCMCHip:
         ss = np.random.SeedSequence(self.seed).spawn(self.size)[self.rank]  # sampler.py:378-384
         self._rng = np.random.default_rng(ss)
         W = int(self.n_walkers)
+        if self.group_size is None:
+            self.group_size = 256 if (W >= 16384 and W % 256 == 0) else 64
         device = self.device if self.device is not None else dist.local_rank()
-        cap = self.steps_per_launch if self.emit == "chains" else 0
+        cap = 0
+        if self.emit == "chains":
+            # every accepted row is kept on the device between drains: bound the buffer
+            row_bytes = 8 * (d + 4) * W
+            self.steps_per_launch = int(max(1, min(self.steps_per_launch,
+                                                   (1 << 30) // row_bytes)))
+            cap = self.steps_per_launch
         try:
             self.engine = Engine(d, W, group_size=int(self.group_size), device=int(device),
                                  seed=self.seed, walker_offset=self.rank * W,

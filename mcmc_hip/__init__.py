@@ -28,7 +28,7 @@ else:
 
         file_base_name = "mcmc_hip"
         n_walkers: int = HIP_DEFAULTS["n_walkers"]
-        group_size: int = HIP_DEFAULTS["group_size"]
+        group_size: int | None = HIP_DEFAULTS["group_size"]
         device: int | None = HIP_DEFAULTS["device"]
         steps_per_launch: int | str = HIP_DEFAULTS["steps_per_launch"]
         moments_every: int = HIP_DEFAULTS["moments_every"]

@@ -233,7 +233,7 @@ assert issubclass(cls, MCMC)
 info = update_info({"likelihood": {"one": None}, "params": {"a": {"prior": {"min": 0, "max": 1}}},
                     "sampler": {"mcmc_hip": {"n_walkers": 128, "Rminus1_stop": 0.02}}})
 s = info["sampler"]["mcmc_hip"]
-assert s["n_walkers"] == 128 and s["group_size"] == 64 and s["emit"] == "snapshots"
+assert s["n_walkers"] == 128 and s["group_size"] is None and s["emit"] == "snapshots"
 assert s["learn_every"] == "40d" and s["proposal_scale"] == 2.4 and s["Rminus1_stop"] == 0.02
 try:
     update_info({"likelihood": {"one": None}, "params": {"a": {"prior": {"min": 0, "max": 1}}},
