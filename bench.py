@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU")
     ap.add_argument("--dim", type=int, default=30)
-    ap.add_argument("--group-size", type=int, default=256,
-                    help="walkers per Haar-basis group (the sampler's default at this size)")
+    ap.add_argument("--group-size", type=int, default=None,
+                    help="walkers per Haar-basis group (default: the sampler's choice, 256 at "
+                         "the benchmark size)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
                     help="default 40*d (the sampler's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +185,7 @@ def main():
                              "65536 walkers per MI355X" if (d, a.walkers) == (30, 65536)
                              else f"{d}-dim single-mode gaussian_mixture, {a.walkers} walkers "
                                   "per GPU (non-default)"),
-                "d": d, "walkers_per_gpu": a.walkers, "group_size": a.group_size,
+                "d": d, "walkers_per_gpu": a.walkers, "group_size": int(sampler.group_size),
                 "metropolis_steps_per_launch": spl,
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": sampler.i_learn - n_ckpt0,
@@ -193,7 +194,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "kernel": "mcmc::step_kernel<false,false> (d=%d)" % d,
+                "kernel": ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
+                else ("mcmc::step_big_kernel (d=%d)" % d),
                 "kernel_ms_per_launch": step_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": ("achieved = algorithmic bytes (16d+24 B per evaluation, state "
@@ -210,7 +212,8 @@ def main():
                 "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1)},
         }
         if size == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, mean, cov, a.group_size, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(d, mean, cov, int(sampler.group_size),
+                                               a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -21,6 +21,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libmcmc_hip.so")
 ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
+BIG_DPS = [48, 64, 80, 100, 112]  # accumulator counts of the d > 32 column-sweep kernels
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
 # operations are written as fma()); see DESIGN.md "Ensemble specification".
@@ -83,6 +84,11 @@ def build(dims=None, jobs=None, verbose=True):
     for d in dims:
         stamp = _digest([wk] + hdrs, extra=f"{d}|{' '.join(FLAGS)}")
         tasks.append((wk, os.path.join(OBJ, f"walker_d{d}.o"), [f"-DMCMC_D={d}"], stamp))
+    big = os.path.join(CSRC, "walker_kernels_big.hip")
+    big_dps = [] if os.environ.get("MCMC_HIP_NO_BIG") else BIG_DPS
+    for dp in big_dps:
+        stamp = _digest([big] + hdrs, extra=f"big{dp}|{' '.join(FLAGS)}")
+        tasks.append((big, os.path.join(OBJ, f"walker_big{dp}.o"), [f"-DMCMC_DP={dp}"], stamp))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

@@ -22,10 +22,28 @@ MCMC_DECLARE_DIM(21) MCMC_DECLARE_DIM(22) MCMC_DECLARE_DIM(23) MCMC_DECLARE_DIM(
 MCMC_DECLARE_DIM(25) MCMC_DECLARE_DIM(26) MCMC_DECLARE_DIM(27) MCMC_DECLARE_DIM(28)
 MCMC_DECLARE_DIM(29) MCMC_DECLARE_DIM(30) MCMC_DECLARE_DIM(31) MCMC_DECLARE_DIM(32)
 
+MCMC_DECLARE_BIG(48) MCMC_DECLARE_BIG(64) MCMC_DECLARE_BIG(80) MCMC_DECLARE_BIG(100)
+MCMC_DECLARE_BIG(112)
+
 namespace {
 
+using mcmc::BigKernels;
 using mcmc::ConstLayout;
 using mcmc::DimKernels;
+
+constexpr int kMaxDimBig = 112;  // basis_big_kernel keeps H and the normals in 160 KiB of LDS
+
+// smallest compiled accumulator count that serves dimension d (32 < d <= 112)
+const BigKernels* big_for_dim(int d)
+{
+    typedef const BigKernels* (*getter)();
+    static const getter table[] = {mcmc_hip_big_48, mcmc_hip_big_64, mcmc_hip_big_80,
+                                   mcmc_hip_big_100, mcmc_hip_big_112};
+    if (d <= mcmc::kMaxDimLane || d > kMaxDimBig) return nullptr;
+    for (getter g : table)
+        if (g != nullptr && g()->dp >= d) return g();
+    return nullptr;
+}
 
 const DimKernels* kernels_for_dim(int d)
 {
@@ -148,7 +166,8 @@ struct DevBuf {
 
 struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
-    const DimKernels* k = nullptr;
+    const DimKernels* k = nullptr;    // d <= 32: lane-per-walker kernels of that dimension
+    const BigKernels* kb = nullptr;   // 32 < d <= 112: column-sweep kernels
     hipStream_t stream = nullptr;
     std::string err;
     int d = 0, W = 0, G = 0, gs = 0, K = -1;
@@ -158,12 +177,14 @@ struct mcmc_hip_ctx {
     std::vector<double> lo, hi, loc, scale, mls;
     double uniform_logp = 0.0;
     uint32_t norm_mask = 0, periodic_mask = 0;
+    uint32_t norm_mask4[4] = {0, 0, 0, 0};
+    bool any_periodic = false;
     std::vector<double> mean, Linv, cnorm, weight;  // Linv: [K][d*d] row-major
     std::vector<double> cov, T;                     // proposal
     std::vector<double> shift;                      // moment shift
     // device
     DevBuf<double> x, logpost, logprior, loglike, cblock, dT, V, rows, gsum, Sg, pooled, dshift;
-    DevBuf<double> ex, elp, ell, eder;
+    DevBuf<double> ex, elp, ell, eder, escratch, dLrow, dLcol;
     DevBuf<int> weight_i, prej, burn, stuck, nrows;
     DevBuf<long long> nacc;
     unsigned long long step = 0;
@@ -272,6 +293,25 @@ int upload_constants(mcmc_hip_ctx* h)
     HIP_TRY(h, h->cblock.resize(c.size()));
     HIP_TRY(h, hipMemcpyAsync(h->cblock.p, c.data(), sizeof(double) * c.size(),
                               hipMemcpyHostToDevice, h->stream));
+    std::vector<double> lcol;
+    if (h->kb && K > 0) {
+        // row-major L^-1 per mode (evaluator) and the column-major, zero-padded [dp][dp]
+        // copy of mode 0 that the column-sweep step kernel stages in LDS
+        const int dp = h->kb->dp;
+        HIP_TRY(h, h->dLrow.resize(h->Linv.size()));
+        HIP_TRY(h, hipMemcpyAsync(h->dLrow.p, h->Linv.data(), sizeof(double) * h->Linv.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+        // 4x4 tiles [column block][row block][col][row], zero above the diagonal and in the pad
+        const int nb = dp / 4;
+        lcol.assign((size_t)dp * dp, 0.0);
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i <= j; ++i)
+                lcol[(((size_t)(i / 4) * nb + (j / 4)) * 4 + (i % 4)) * 4 + (j % 4)] =
+                    h->Linv[(size_t)j * d + i];
+        HIP_TRY(h, h->dLcol.resize(lcol.size()));
+        HIP_TRY(h, hipMemcpyAsync(h->dLcol.p, lcol.data(), sizeof(double) * lcol.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MCMC_HIP_OK;
 }
@@ -280,6 +320,7 @@ int lds_check(mcmc_hip_ctx* h)
 {
     const ConstLayout cl{h->d, h->K};
     (void)cl;
+    if (h->kb) return MCMC_HIP_OK;  // the big step kernel's LDS does not depend on K
     const size_t lds = sizeof(double) * ((h->K > 1 ? (size_t)h->K * 256 : 0) +
                                          2 * (size_t)(256 / h->gs) * mcmc::v_slab(h->d));
     if (lds > 160 * 1024)
@@ -341,7 +382,10 @@ const char* mcmc_hip_last_error(const mcmc_hip_ctx* h)
     return h ? h->err.c_str() : g_create_error.c_str();
 }
 
-int mcmc_hip_dim_supported(int d) { return kernels_for_dim(d) != nullptr; }
+int mcmc_hip_dim_supported(int d)
+{
+    return kernels_for_dim(d) != nullptr || big_for_dim(d) != nullptr;
+}
 
 int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
 {
@@ -349,10 +393,15 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     *out = nullptr;
     if (cfg->d < 1) return fail(nullptr, MCMC_HIP_ERR_ARG, "d must be >= 1, got %d", cfg->d);
     const DimKernels* k = kernels_for_dim(cfg->d);
-    if (!k)
+    const BigKernels* kb = k ? nullptr : big_for_dim(cfg->d);
+    if (!k && !kb)
         return fail(nullptr, MCMC_HIP_ERR_ARG,
-                    "no kernels compiled for d=%d (this build covers the lane-per-walker "
-                    "dimensions 1..32 that were selected at build time)", cfg->d);
+                    "no kernels compiled for d=%d (this build covers d = 1..32 lane-per-walker "
+                    "and 33..%d column-sweep, as selected at build time)", cfg->d, kMaxDimBig);
+    if (kb && (size_t)cfg->group_size * (size_t)(cfg->d | 1) * sizeof(double) > 160 * 1024)
+        return fail(nullptr, MCMC_HIP_ERR_ARG,
+                    "group_size %d is too large for d=%d (moment tile exceeds LDS): use %d",
+                    cfg->group_size, cfg->d, cfg->d > 80 ? 128 : 256);
     if (cfg->group_size != 64 && cfg->group_size != 128 && cfg->group_size != 256)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "group_size must be 64, 128 or 256, got %d",
                     cfg->group_size);
@@ -386,6 +435,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     mcmc_hip_ctx* h = new mcmc_hip_ctx();
     h->cfg = *cfg;
     h->k = k;
+    h->kb = kb;
     h->d = cfg->d;
     h->W = cfg->n_walkers;
     h->gs = cfg->group_size;
@@ -431,7 +481,8 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->x.release(); h->logpost.release(); h->logprior.release(); h->loglike.release();
     h->cblock.release(); h->dT.release(); h->V.release(); h->rows.release(); h->gsum.release();
     h->Sg.release(); h->pooled.release(); h->dshift.release(); h->ex.release(); h->elp.release();
-    h->ell.release(); h->eder.release(); h->weight_i.release(); h->prej.release();
+    h->ell.release(); h->eder.release(); h->escratch.release(); h->dLrow.release();
+    h->dLcol.release(); h->weight_i.release(); h->prej.release();
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -449,6 +500,8 @@ int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, co
     h->lo.assign(d, -inf); h->hi.assign(d, inf);
     h->loc.assign(d, 0.0); h->scale.assign(d, 1.0); h->mls.assign(d, 0.0);
     h->norm_mask = h->periodic_mask = 0;
+    h->norm_mask4[0] = h->norm_mask4[1] = h->norm_mask4[2] = h->norm_mask4[3] = 0;
+    h->any_periodic = false;
     double ulp = 0.0;
     for (int i = 0; i < d; ++i) {
         if (kind[i] == 0) {
@@ -456,7 +509,11 @@ int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, co
                 return fail(h, MCMC_HIP_ERR_ARG, "uniform prior %d needs finite min < max", i);
             h->lo[i] = a[i]; h->hi[i] = b[i];
             ulp += std::log(b[i] - a[i]);
-            if (periodic && periodic[i]) { h->periodic[i] = 1; h->periodic_mask |= 1u << i; }
+            if (periodic && periodic[i]) {
+                h->periodic[i] = 1;
+                h->any_periodic = true;
+                if (i < 32) h->periodic_mask |= 1u << i;
+            }
         } else if (kind[i] == 1) {
             if (!(b[i] > 0) || !std::isfinite(a[i]) || !std::isfinite(b[i]))
                 return fail(h, MCMC_HIP_ERR_ARG, "normal prior %d needs finite loc, scale > 0", i);
@@ -465,7 +522,8 @@ int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, co
                             "parameter %d cannot be periodic if it is not bounded", i);
             h->loc[i] = a[i]; h->scale[i] = b[i];
             h->mls[i] = -std::log(b[i]) - std::log(2.0 * M_PI) / 2.0;  // tools.py:723
-            h->norm_mask |= 1u << i;
+            h->norm_mask4[i >> 5] |= 1u << (i & 31);
+            if (i < 32) h->norm_mask |= 1u << i;
         } else {
             return fail(h, MCMC_HIP_ERR_ARG,
                         "prior kind %d of parameter %d is not supported (0 uniform, 1 norm)",
@@ -584,7 +642,13 @@ int mcmc_hip_evaluate(mcmc_hip_ctx* h, int32_t n, const double* x, double* logpr
     a.cblock = h->cblock.p; a.n = n; a.n_modes = h->K;
     a.norm_mask = h->norm_mask; a.periodic_mask = h->periodic_mask;
     a.uniform_logp = h->uniform_logp;
-    HIP_TRY(h, h->k->evaluate(a, h->stream));
+    for (int q = 0; q < 4; ++q) a.norm_mask4[q] = h->norm_mask4[q];
+    if (h->kb) {
+        HIP_TRY(h, h->escratch.resize((size_t)n * std::max(h->K, 1)));
+        HIP_TRY(h, h->kb->evaluate(a, h->dLrow.p, h->d, h->escratch.p, h->stream));
+    } else {
+        HIP_TRY(h, h->k->evaluate(a, h->stream));
+    }
     HIP_TRY(h, hipMemcpyAsync(logprior, h->elp.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(loglike, h->ell.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     if (a.derived)
@@ -665,7 +729,13 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     if (n_steps <= 0) return fail(h, MCMC_HIP_ERR_ARG, "n_steps must be > 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const unsigned long long d = (unsigned long long)h->d;
-    const size_t dd = (size_t)mcmc::v_slab(h->d);  // doubles per (group, cycle) slab
+    // doubles per (group, cycle) slab of proposal directions
+    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(h->d) : (size_t)mcmc::v_slab(h->d);
+    if (h->kb && (h->K != 1 || h->norm_mask4[0] || h->norm_mask4[1] || h->norm_mask4[2] ||
+                  h->norm_mask4[3] || h->any_periodic || h->cfg.emit_capacity > 0))
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "for d > 32 this build samples a single Gaussian mode with uniform, "
+                    "non-periodic priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
     // directions buffer: at most ~256 MiB of cycles per launch
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
     int left = n_steps;
@@ -684,7 +754,8 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             b.cycle0 = (uint32_t)c0;
             b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
             b.ncyc = ncyc;
-            HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+            if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
+            else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
         }
         {
             Timed t(h, 0);
@@ -702,7 +773,8 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             a.uniform_logp = h->uniform_logp; a.temperature = h->cfg.temperature;
             a.max_tries = h->cfg.max_tries;
             a.cnorm0 = h->K > 0 ? h->cnorm[0] : 0.0;
-            HIP_TRY(h, h->k->step(a, h->gs, h->stream));
+            if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->stream));
+            else HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;
         }
         h->step += (unsigned long long)n;
@@ -808,7 +880,8 @@ int mcmc_hip_accumulate_moments(mcmc_hip_ctx* h)
     mcmc::MomentArgs a{};
     a.x = h->x.p; a.shift = h->dshift.p; a.group_sum = h->gsum.p; a.Sg = h->Sg.p;
     a.pooled = h->pooled.p; a.W = h->W; a.G = h->G;
-    HIP_TRY(h, h->k->moments(a, h->gs, h->stream));
+    if (h->kb) HIP_TRY(h, h->kb->moments(a, h->gs, h->d, h->stream));
+    else HIP_TRY(h, h->k->moments(a, h->gs, h->stream));
     h->n_snapshots += 1;
     return MCMC_HIP_OK;
 }

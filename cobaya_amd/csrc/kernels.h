@@ -30,6 +30,14 @@ __host__ __device__ inline void tri_stream_for_each(int d, F&& f)
 // KiB so that the step kernel can move a slab into LDS with 1 KiB global->LDS DMA pieces.
 __host__ __device__ constexpr int v_slab(int d) { return ((d * d * 8 + 1023) / 1024) * 128; }
 
+// d > 32 ("big" kernels): columns of V are padded to an even number of doubles (16-byte aligned
+// for the per-step 1 KiB global->LDS DMA), and a slab keeps >= 1 KiB behind its last column.
+__host__ __device__ constexpr int v_ld(int d) { return (d + 1) & ~1; }
+__host__ __device__ constexpr int v_slab_big(int d)
+{
+    return ((d * v_ld(d) * 8 + 1024 + 1023) / 1024) * 128;
+}
+
 // Constant block (doubles) in HBM, read through the scalar data cache:
 //   lo[d] hi[d] loc[d] scale[d] mls[d] | elem[d][3] = {lo_i, hi_i, mean0_i} (the interleaved
 //   stream of the fused proposal pass) | per mode k: mean[d] | cnorm[K] weight[K] |
@@ -101,6 +109,7 @@ struct EvalArgs {
     int n;
     int n_modes;
     uint32_t norm_mask, periodic_mask;
+    uint32_t norm_mask4[4];  // d > 32: one bit per dimension
     double uniform_logp;
 };
 
@@ -122,6 +131,16 @@ struct DimKernels {
     hipError_t (*moments)(const MomentArgs&, int group_size, hipStream_t);
 };
 
+// Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).
+struct BigKernels {
+    int dp;  // largest dimension this instantiation serves
+    hipError_t (*step)(const StepArgs&, const double* Lcol, int d, hipStream_t);
+    hipError_t (*basis)(const BasisArgs&, int n_groups, int d, hipStream_t);
+    hipError_t (*evaluate)(const EvalArgs&, const double* Lrow, int d, double* scratch, hipStream_t);
+    hipError_t (*moments)(const MomentArgs&, int group_size, int d, hipStream_t);
+};
+
 }  // namespace mcmc
 
+#define MCMC_DECLARE_BIG(DP) extern "C" const mcmc::BigKernels* mcmc_hip_big_##DP() __attribute__((weak));
 #define MCMC_DECLARE_DIM(D) extern "C" const mcmc::DimKernels* mcmc_hip_dim_##D() __attribute__((weak));

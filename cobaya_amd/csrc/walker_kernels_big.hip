@@ -1,0 +1,465 @@
+// Walker kernels for 32 < d <= MCMC_DP (gfx950): the state no longer fits a lane's VGPRs.
+//
+// Still one lane per walker, but organised as a COLUMN SWEEP: the DP whitened accumulators
+// y_j live in VGPRs (static indices), the parameter vector x stays in HBM/L2 (dimension-major,
+// so lane w reads x[i*W + w]: coalesced) and is streamed once per step; for each dimension i
+// the lane forms t_i = fma(r, v_i, x_i) and tests the prior support; four columns at a time
+// are then added to every y_j below them (a switch with fall-through over 4-row blocks:
+// triangular work with a single jump per 4 columns, 16 operands and 16 FMAs per block).  y_j therefore accumulates i = 0..j in ascending order from +0 --
+// the same fma chain as the oracle and as the small-d kernels.  L^-1 (in 4x4 tiles, zero above
+// the diagonal) is staged once per launch in LDS and read as wave-uniform broadcasts; the
+// proposal direction of the NEXT step is brought into LDS by a 1 KiB global->LDS DMA while
+// the current step runs.
+//
+// Scope of this variant: one Gaussian mode, uniform priors, nothing periodic, no emitted rows
+// (BASELINE config 4).  Everything else at d > 32 is refused by the host with a clear error.
+//
+// One translation unit per accumulator count DP (-DMCMC_DP=48|64|80|100|128); the actual d is
+// a run-time argument <= DP (rows/columns beyond d are zero operands: exact no-ops).
+#include "det_math.h"
+#include "kernels.h"
+
+#ifndef MCMC_DP
+#error "compile with -DMCMC_DP=<max dimension>"
+#endif
+
+namespace mcmc {
+namespace {
+
+constexpr int DP = MCMC_DP;
+constexpr int NB = DP / 4;
+constexpr int XCH = (DP <= 100) ? 16 : 8;  // dimensions of x per LDS ring slot (per wave)
+static_assert(DP % 4 == 0 && DP <= 128, "DP must be a multiple of 4, at most 128");
+
+// ---------------------------------------------------------------- Haar basis (run-time d)
+// Same arithmetic, same order as basis_kernel / orc_haar_from_normals; H lives in LDS (row i
+// owned by thread i), T is read through the scalar path.  blockDim = d rounded up to 64.
+__global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int nz = (d + 2) * (d - 1) / 2;
+    const int ldh = d | 1;
+    double* sz = smem;                  // [nz + 2]
+    double* sx = sz + ((nz + 3) & ~1);  // [d + 1]
+    double* sH = sx + ((d + 2) & ~1);   // [d][ldh]
+    const int t = threadIdx.x, nt = blockDim.x;
+    const uint32_t group = a.group0 + blockIdx.x;
+    const uint32_t cycle = a.cycle0 + blockIdx.y;
+    const int ldv = v_ld(d);
+    double* __restrict__ Vout = a.V + ((size_t)blockIdx.x * a.ncyc + blockIdx.y) * v_slab_big(d);
+    typedef const double __attribute__((address_space(4))) * cptr;
+    const cptr T = (cptr)(unsigned long long)a.T;
+
+    for (int j = t; 2 * j < nz; j += nt) {
+        const u32x4 w4 = philox4x32_10(a.key0, a.key1, group, kStreamBasis, cycle, (uint32_t)j);
+        const uint64_t ka = ((uint64_t)w4.w0 << 20) | (w4.w1 >> 12);
+        const uint64_t kb = ((uint64_t)w4.w2 << 20) | (w4.w3 >> 12);
+        const double rad = sqrt(-2.0 * dlog(u52(ka)));
+        double sn, cs;
+        sincos2pi(kb, sn, cs);
+        sz[2 * j] = rad * cs;
+        sz[2 * j + 1] = rad * sn;
+    }
+    if (t < d)
+        for (int k = 0; k < d; ++k) sH[t * ldh + k] = (k == t) ? 1.0 : 0.0;
+    __syncthreads();
+    double dprod = 1.0, Dmine = 1.0;
+    int ix = 0;
+    for (int n = 0; n < d - 1; ++n) {
+        const int m = d - n;
+        double norm2 = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
+        const double x0 = sz[ix];
+        const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
+        dprod *= Dn;
+        if (t == n) Dmine = Dn;
+        const double x0n = x0 + Dn * sqrt(norm2);
+        double tt = norm2 - x0 * x0;
+        tt = tt + x0n * x0n;
+        const double den = sqrt(0.5 * tt);
+        __syncthreads();
+        if (t < m) sx[t] = ((t == 0) ? x0n : sz[ix + t]) / den;
+        __syncthreads();
+        if (t < d) {
+            double* row = sH + t * ldh + n;
+            double tmp = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < m; ++k) tmp = fma(row[k], sx[k], tmp);
+#pragma unroll 8
+            for (int k = 0; k < m; ++k) row[k] = fma(-tmp, sx[k], row[k]);
+        }
+        ix += m;
+    }
+    if (t == d - 1) Dmine = (((d - 1) & 1) ? -1.0 : 1.0) * dprod;
+    if (t < d)
+        for (int k = 0; k < d; ++k) sH[t * ldh + k] = Dmine * sH[t * ldh + k];
+    __syncthreads();
+    if (t < d) {  // thread = column c of R; V[c][i] = sum_{k<=i} T[i][k] R[k][c]
+        for (int i = 0; i < d; ++i) {
+            double s = 0.0;
+#pragma unroll 8
+            for (int k = 0; k <= i; ++k) s = fma(T[i * d + k], sH[k * ldh + t], s);
+            Vout[(size_t)t * ldv + i] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- the Metropolis kernel
+struct BigStepArgs {
+    StepArgs s;
+    const double* Lcol;  // [DP/4 column blocks][DP/4 row blocks][4 cols][4 rows] tiles of L^-1
+    int d;
+};
+
+// One 4x4 tile: rows 4B..4B+3 of columns 4cb..4cb+3, stored [c][q] (16 contiguous doubles).
+// Each y_j takes its four columns in ascending order.
+#define MCMC_BLK(B)                                                                      \
+    case B:                                                                              \
+        if constexpr (4 * B + 3 < DPX) {                                                 \
+            const double* __restrict__ tl = tiles + B * 16;                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                \
+            {                                                                            \
+                double acc = y[4 * B + q];                                               \
+                acc = fma(tl[0 * 4 + q], dev[0], acc);                                   \
+                acc = fma(tl[1 * 4 + q], dev[1], acc);                                   \
+                acc = fma(tl[2 * 4 + q], dev[2], acc);                                   \
+                acc = fma(tl[3 * 4 + q], dev[3], acc);                                   \
+                y[4 * B + q] = acc;                                                      \
+            }                                                                            \
+        }                                                                                \
+        [[fallthrough]];
+
+template <int DPX>
+__device__ __forceinline__ void column_block_update(double (&y)[DPX],
+                                                    const double* __restrict__ tiles,
+                                                    const double (&dev)[4], int cb)
+{
+    switch (cb) {
+        MCMC_BLK(0) MCMC_BLK(1) MCMC_BLK(2) MCMC_BLK(3) MCMC_BLK(4) MCMC_BLK(5) MCMC_BLK(6)
+        MCMC_BLK(7) MCMC_BLK(8) MCMC_BLK(9) MCMC_BLK(10) MCMC_BLK(11) MCMC_BLK(12) MCMC_BLK(13)
+        MCMC_BLK(14) MCMC_BLK(15) MCMC_BLK(16) MCMC_BLK(17) MCMC_BLK(18) MCMC_BLK(19)
+        MCMC_BLK(20) MCMC_BLK(21) MCMC_BLK(22) MCMC_BLK(23) MCMC_BLK(24) MCMC_BLK(25)
+        MCMC_BLK(26) MCMC_BLK(27) MCMC_BLK(28) MCMC_BLK(29) MCMC_BLK(30) MCMC_BLK(31)
+    default:
+        break;
+    }
+}
+
+__global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const StepArgs& a = b.s;
+    const int d = b.d;
+    const int tid = threadIdx.x, bs = blockDim.x;
+    const int w = blockIdx.x * bs + tid;
+    const int W = a.W;
+    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
+    const int gpb = bs / a.group_size;
+    const int gib = __builtin_amdgcn_readfirstlane(tid / a.group_size);
+    const int wpg = a.group_size >> 6;
+    const int part = __builtin_amdgcn_readfirstlane((tid >> 6) % wpg);
+    const ConstLayout cl{d, 1};
+    // LDS: L^-1 columns [DP*DP] | elem {lo,hi,mu,0}[DP] | v ring [2][gpb][128] |
+    //      x ring [waves][2][XCH][64]: this wave's slice of x, XCH dimensions at a time
+    double* sL = smem;
+    double* sE = sL + DP * DP;
+    double* sVr = sE + 4 * DP;
+    double* sXr = sVr + 2 * gpb * 128 + (tid >> 6) * (2 * XCH * 64);
+    for (int i = tid; i < DP * DP; i += bs) sL[i] = b.Lcol[i];
+    for (int i = tid; i < DP; i += bs) {
+        const bool in = i < d;
+        sE[4 * i + 0] = in ? a.cblock[cl.lo() + i] : -INFINITY;
+        sE[4 * i + 1] = in ? a.cblock[cl.hi() + i] : INFINITY;
+        sE[4 * i + 2] = in ? a.cblock[cl.mean(0) + i] : 0.0;
+        sE[4 * i + 3] = 0.0;
+    }
+    const int ldv = v_ld(d);
+    const double* const Vgrp = a.V + (size_t)group * a.ncyc * v_slab_big(d);
+    auto stage_col = [&](int cycle, int column, int slot) {
+        // 1 KiB (>= ldv * 8 bytes) of the column, moved by the first wave of the group
+        if (part == 0) {
+            const char* g = (const char*)(Vgrp + (size_t)cycle * v_slab_big(d) + (size_t)column * ldv) +
+                            (tid & 63) * 16;
+            char* l = (char*)(sVr + (slot * gpb + gib) * 128);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    // x[i][w0 .. w0+63] is 512 contiguous bytes per dimension: one 1 KiB DMA piece carries two
+    // dimensions (lanes 0-31 the first, 32-63 the second) straight into the ring layout
+    const double* const xwave = a.x + (size_t)(w & ~63);
+    auto stage_x = [&](int chunk, int buf) {
+        const int lane = tid & 63;
+        for (int p2 = 0; p2 < XCH / 2; ++p2) {
+            int dim = chunk * XCH + 2 * p2 + (lane >> 5);
+            if (dim >= d) dim = d - 1;  // tail: harmless duplicate read
+            const char* g = (const char*)(xwave + (size_t)dim * W) + (lane & 31) * 16;
+            char* l = (char*)(sXr + buf * (XCH * 64) + 2 * p2 * 64);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    unsigned long long step = a.step0;
+    int col = (int)(step % (unsigned long long)d);
+    int cyc = 0;
+    stage_col(0, col, 0);
+    stage_x(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int slot = 0;
+
+    double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
+    int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
+    long long nacc = a.n_accept[w];
+    const uint32_t gid = a.walker0 + (uint32_t)w;
+    double* const xg = a.x + w;
+
+    for (int s = 0; s < a.n_steps; ++s) {
+        // next step's direction: DMA into the other ring slot while this step computes
+        {
+            int ncol = col + 1, ncyc = cyc;
+            if (ncol == d) { ncol = 0; ++ncyc; }
+            if (s + 1 < a.n_steps) stage_col(ncyc, ncol, slot ^ 1);
+        }
+        StepRng rng;
+        rng.begin(a.key0, a.key1, gid, step);
+        rng.run_all();
+        const double r = rng.r, Ea = rng.Ea;
+        const double* __restrict__ v = sVr + (slot * gpb + gib) * 128;
+
+        double y[DP];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) y[j] = 0.0;
+        // x streams through the wave's LDS ring, one chunk of XCH dimensions ahead
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0 (issued below / at entry)
+        for (int c = 0; c * XCH < d; ++c) {
+            if ((c + 1) * XCH < d) stage_x(c + 1, (c + 1) & 1);
+            const double* __restrict__ xs = sXr + (c & 1) * (XCH * 64) + (tid & 63);
+            const int i0 = c * XCH;
+#pragma unroll
+            for (int q4 = 0; q4 < XCH / 4; ++q4) {
+                const int ib = i0 + 4 * q4;  // first of four columns
+                if (ib < d) {
+                    double dev[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = ib + u;
+                        const double ti = fma(r, v[i], xs[(4 * q4 + u) * 64]);
+                        const double dv = ((ti <= sE[4 * i + 1]) & (ti >= sE[4 * i + 0]))
+                                              ? ti - sE[4 * i + 2] : INFINITY;
+                        dev[u] = (i < d) ? dv : 0.0;  // padded columns carry zero operands
+                    }
+                    const int cb = ib >> 2;
+                    column_block_update<DP>(y, sL + (size_t)cb * NB * 16, dev, cb);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c + 1 has landed
+        }
+        double chi2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) chi2 = fma(y[j], y[j], chi2);
+        const bool inb = chi2 < INFINITY;
+        const double lp = a.uniform_logp + 0.0;
+        const double ll = -0.5 * (a.cnorm0 + chi2);
+        const double lt = inb ? lp + ll : -INFINITY;
+        const bool accept = inb & (lt != -INFINITY) &
+                            ((lt > lpost) | (Ea > (lpost - lt) / a.temperature));
+        burn -= (accept & (burn > 0)) ? 1 : 0;
+        // commit: second pass through the ring; only accepting lanes store
+        stage_x(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int c = 0; c * XCH < d; ++c) {
+            if ((c + 1) * XCH < d) stage_x(c + 1, (c + 1) & 1);
+            const double* __restrict__ xs = sXr + (c & 1) * (XCH * 64) + (tid & 63);
+            const int i0 = c * XCH, i1 = (i0 + XCH < d) ? i0 + XCH : d;
+            if (accept)
+                for (int i = i0; i < i1; ++i) xg[(size_t)i * W] = fma(r, v[i], xs[(i - i0) * 64]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (s + 1 < a.n_steps) stage_x(0, 0);  // first chunk of the next step (after the stores)
+        lpri = accept ? lp : lpri;
+        llik = accept ? ll : llik;
+        lpost = accept ? lt : lpost;
+        prej = accept ? 0 : (prej + (inb ? 0 : 1));
+        wt = accept ? 1 : wt + 1;
+        nacc += accept ? 1 : 0;
+        if (!accept) {
+            const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
+            if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
+        }
+        ++step;
+        if (++col == d) { col = 0; ++cyc; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed, own x stores issued
+        __syncthreads();
+        slot ^= 1;
+    }
+    a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
+    a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
+    a.n_accept[w] = nacc;
+}
+
+// ---------------------------------------------------------------- batch evaluator (run-time d)
+// General: normal priors and mixtures included.  One thread per point; operands from the
+// "big" constant block (row-major L^-1 per mode) through global memory.
+struct BigEvalArgs {
+    EvalArgs e;
+    const double* Lrow;  // [K][d][d] row-major L^-1
+    int d;
+    double* scratch;     // [n][K] mode log-pdfs for the log-sum-exp
+};
+
+__global__ void __launch_bounds__(64) evaluate_big_kernel(const BigEvalArgs b)
+{
+    const EvalArgs& a = b.e;
+    const int d = b.d, K = a.n_modes;
+    const ConstLayout cl{d, K};
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.n) return;
+    const double* __restrict__ t = a.x + (size_t)p * d;
+    const double* __restrict__ C = a.cblock;
+    bool in = true;
+    for (int i = 0; i < d; ++i) in = in & (t[i] <= C[cl.hi() + i]) & (t[i] >= C[cl.lo() + i]);
+    double s = 0.0;
+    if (a.norm_mask4[0] | a.norm_mask4[1] | a.norm_mask4[2] | a.norm_mask4[3]) {
+        for (int i = 0; i < d; ++i)
+            if ((a.norm_mask4[i >> 5] >> (i & 31)) & 1u) {
+                const double q = (t[i] - C[cl.loc() + i]) / C[cl.scale() + i];
+                s = s + fma(-0.5 * q, q, C[cl.mls() + i]);
+            }
+    }
+    const double lp = a.uniform_logp + s;
+    double ll = 0.0;
+    if (K >= 1) {
+        double amax = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const double* __restrict__ Lk = b.Lrow + (size_t)k * d * d;
+            const double* __restrict__ mu = C + cl.mean(k);
+            double chi2 = 0.0;
+            for (int j = 0; j < d; ++j) {
+                double y = 0.0;
+                for (int i = 0; i <= j; ++i) y = fma(Lk[j * d + i], t[i] - mu[i], y);
+                if (a.derived) a.derived[((size_t)p * K + k) * d + j] = y;
+                chi2 = fma(y, y, chi2);
+            }
+            const double ak = -0.5 * (C[cl.cnorm() + k] + chi2);
+            b.scratch[(size_t)p * K + k] = ak;
+            amax = (ak > amax) ? ak : amax;
+        }
+        if (K == 1) {
+            ll = amax;
+        } else {
+            double S = 0.0;
+            for (int k = 0; k < K; ++k)
+                S = fma(C[cl.weight() + k], dexp(b.scratch[(size_t)p * K + k] - amax), S);
+            ll = dlog(S) + amax;
+        }
+    }
+    a.logprior[p] = in ? lp : -INFINITY;
+    a.loglike[p] = in ? ll : -INFINITY;
+}
+
+// ---------------------------------------------------------------- moments (run-time d)
+__global__ void __launch_bounds__(256) group_moments_big_kernel(const MomentArgs a, int d)
+{
+    extern __shared__ __attribute__((aligned(16))) double sX[];  // [gs][d|1]
+    const int ldx = d | 1;
+    const int npair = d * (d + 1) / 2;
+    const int tid = threadIdx.x, gs = blockDim.x, g = blockIdx.x;
+    const int w = g * gs + tid;
+    for (int i = 0; i < d; ++i) sX[tid * ldx + i] = a.x[(size_t)i * a.W + w] - a.shift[i];
+    __syncthreads();
+    for (int i = tid; i < d; i += gs) {
+        double s = 0.0;
+        for (int l = 0; l < gs; ++l) s = s + sX[l * ldx + i];
+        a.group_sum[(size_t)g * d + i] += s;
+    }
+    for (int p = tid; p < npair; p += gs) {
+        int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= p) ++i;
+        while (i * (i + 1) / 2 > p) --i;
+        const int j = p - i * (i + 1) / 2;
+        double s = 0.0;
+        for (int l = 0; l < gs; ++l) s = fma(sX[l * ldx + i], sX[l * ldx + j], s);
+        a.Sg[(size_t)g * npair + p] = s;
+    }
+}
+
+__global__ void __launch_bounds__(64) pool_moments_big_kernel(const MomentArgs a, int d)
+{
+    const int npair = d * (d + 1) / 2;
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= npair) return;
+    double acc = a.pooled[p];
+    int g = 0;
+    for (; g + 16 <= a.G; g += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = a.Sg[(size_t)(g + u) * npair + p];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; g < a.G; ++g) acc += a.Sg[(size_t)g * npair + p];
+    a.pooled[p] = acc;
+}
+
+// ---------------------------------------------------------------- launchers
+hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, hipStream_t st)
+{
+    BigStepArgs b{a, Lcol, d};
+    const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
+    const size_t lds = sizeof(double) * (size_t)(DP * DP + 4 * DP + 2 * (bs / a.group_size) * 128 +
+                                                 (bs / 64) * 2 * XCH * 64);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)step_big_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(step_big_kernel, dim3(a.W / bs), dim3(bs), lds, st, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_basis(const BasisArgs& a, int n_groups, int d, hipStream_t st)
+{
+    const int nz = (d + 2) * (d - 1) / 2;
+    const size_t lds = sizeof(double) * (size_t)(((nz + 3) & ~1) + ((d + 2) & ~1) + d * (d | 1));
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)basis_big_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(basis_big_kernel, dim3(n_groups, a.ncyc), dim3(d <= 64 ? 64 : 128), lds, st,
+                       a, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_evaluate(const EvalArgs& a, const double* Lrow, int d, double* scratch,
+                           hipStream_t st)
+{
+    BigEvalArgs b{a, Lrow, d, scratch};
+    hipLaunchKernelGGL(evaluate_big_kernel, dim3((a.n + 63) / 64), dim3(64), 0, st, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_moments(const MomentArgs& a, int group_size, int d, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * (size_t)group_size * (d | 1);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)group_moments_big_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(group_moments_big_kernel, dim3(a.G), dim3(group_size), lds, st, a, d);
+    const int npair = d * (d + 1) / 2;
+    hipLaunchKernelGGL(pool_moments_big_kernel, dim3((npair + 63) / 64), dim3(64), 0, st, a, d);
+    return hipGetLastError();
+}
+
+const BigKernels kKernels = {DP, launch_step, launch_basis, launch_evaluate, launch_moments};
+
+}  // namespace
+}  // namespace mcmc
+
+#define MCMC_CAT2(a, b) a##b
+#define MCMC_CAT(a, b) MCMC_CAT2(a, b)
+extern "C" const mcmc::BigKernels* MCMC_CAT(mcmc_hip_big_, MCMC_DP)() { return &mcmc::kKernels; }

@@ -167,7 +167,13 @@ class MCMCHip:
         self._rng = np.random.default_rng(ss)
         W = int(self.n_walkers)
         if self.group_size is None:
-            self.group_size = 256 if (W >= 16384 and W % 256 == 0) else 64
+            # large ensembles: wide groups (fewer Haar bases to generate, still >> d chains);
+            # for d > 32 the group's moment tile must fit the 160 KiB of LDS
+            self.group_size = 64
+            for gs in (256, 128):
+                if W >= 16384 and W % gs == 0 and (d <= 32 or gs * (d | 1) * 8 <= 160 * 1024):
+                    self.group_size = gs
+                    break
         device = self.device if self.device is not None else dist.local_rank()
         cap = 0
         if self.emit == "chains":

@@ -107,6 +107,49 @@ def test_steps_bit_exact(d, W, gs, K, steps):
     assert 0.05 < c["accepted"] / (W * steps) < 0.9
 
 
+@pytest.mark.parametrize("d,W,gs,steps", [(33, 256, 64, 70), (48, 256, 128, 60),
+                                          (64, 512, 64, 70), (100, 256, 64, 130),
+                                          (112, 256, 128, 40)])
+def test_big_dimension_steps_bit_exact(d, W, gs, steps):
+    """32 < d <= 112 (BASELINE config 4 is d = 100): the column-sweep kernels against the
+    oracle, bit for bit, across launches that start and stop mid-cycle."""
+    eng, prob, st = make_pair(d, W, gs, rng=np.random.default_rng(1000 + d))
+    compare_state(eng, st)
+    for n in (1, steps // 2, steps - steps // 2 - 1):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+    c = eng.counters()
+    assert c["accepted"] == int(st.n_accept.sum())
+    assert 0.05 < c["accepted"] / (W * steps) < 0.9
+    shift = st.x.mean(0)
+    eng2, prob2, st2 = make_pair(d, W, gs, rng=np.random.default_rng(1000 + d))
+    eng2.set_moment_shift(shift)
+    eng2.step(d)
+    eng2.accumulate_moments()
+    st2.run(d, n_threads=8)
+    gsum, S = O.moments(st2.x, gs, shift=shift)
+    n, g_gs, g_S = eng2.read_moments()
+    assert_bit_equal(g_gs, gsum, "group sums")
+    assert_bit_equal(g_S, S, "pooled second moments")
+
+
+def test_big_dimension_unsupported_features_are_refused():
+    d = 40
+    eng = E.Engine(d, 64)
+    eng.set_prior([1] + [0] * (d - 1), [0.5] + [0.0] * (d - 1), [0.1] + [1.0] * (d - 1))
+    eng.set_target_gaussian_mixture([[0.5] * d], [np.eye(d) * 1e-3])
+    eng.set_proposal_cov(np.eye(d) * 1e-3)
+    lp, ll = eng.evaluate(np.full((3, d), 0.5))  # the evaluator is general ...
+    assert np.all(np.isfinite(lp + ll))
+    eng.set_state(np.full((64, d), 0.5))
+    with pytest.raises(E.EngineError, match="d > 32"):
+        eng.step(5)                                # ... the step kernel is not (yet)
+    with pytest.raises(E.EngineError):
+        E.Engine(113, 64)
+
+
 def test_general_priors_periodic_temperature_bit_exact():
     d = 6
     kinds = [0, 1, 0, 1, 0, 0]
@@ -170,7 +213,7 @@ def test_moments_bit_exact():
 def test_evaluator_against_reference_goldens(golden):
     """model.logposterior parity: device evaluator vs values produced by the reference."""
     g = golden("g5_loglike")
-    for tag in ("gm_d2_K1", "gm_d3_K3", "gm_d4_K2", "gm_d30_K1", "gm_d30_K3"):
+    for tag in ("gm_d2_K1", "gm_d3_K3", "gm_d4_K2", "gm_d30_K1", "gm_d30_K3", "gm_d100_K1"):
         means = g[tag + "_means"]
         K, d = means.shape
         eng = E.Engine(d, 64, group_size=64)
