@@ -309,3 +309,19 @@ def test_posterior_moments_full_size():
     kl = 0.5 * (np.trace(np.linalg.solve(c, cov)) + m @ np.linalg.solve(c, m) - d
                 + np.linalg.slogdet(c)[1] - np.linalg.slogdet(cov)[1])
     assert kl < 0.07 and kl < 1e-3
+
+
+def test_config5_shape_d27_bit_exact():
+    """d = 27, `gaussian` (normalized) likelihood, 6 uniform + 21 normal priors: the GENERAL
+    kernel variant against the oracle."""
+    d = 27
+    rng = np.random.default_rng(27)
+    kinds = [0] * 6 + [1] * 21
+    a = [0.0] * 6 + list(rng.uniform(0.45, 0.55, 21))
+    b = [1.0] * 6 + list(rng.uniform(0.05, 0.2, 21))
+    eng, prob, st = make_pair(d, 256, 64, kinds=kinds, a=a, b=b, rng=rng)
+    for n in (30, 51):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)

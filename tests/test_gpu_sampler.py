@@ -125,3 +125,82 @@ def test_unsupported_inputs_raise():
     info["sampler"] = {"mcmc": {}}
     with pytest.raises(LoggedError, match="only runs"):
         run(info)
+
+
+def test_config5_standin_d27_gaussian_with_normal_priors():
+    """BASELINE config 5 stand-in: 27-d `gaussian` likelihood (delta^T S^-1 delta
+    form) with 6 uniform + 21 `norm` priors -- SYNTHETIC: the real plik-lite data and a
+    Boltzmann code are not available.  Posterior = likelihood x normal priors, analytic."""
+    d = 27
+    rng = np.random.default_rng(27)
+    A = rng.normal(size=(d, d))
+    corr = A @ A.T / d + np.eye(d)
+    s = 10 ** rng.uniform(-2, -1.3, size=d)
+    cov = corr / np.sqrt(np.outer(np.diag(corr), np.diag(corr))) * np.outer(s, s)
+    mean = rng.uniform(0.4, 0.6, size=d)
+    names = [f"p{i}" for i in range(d)]
+    params, prior_prec, prior_mu = {}, np.zeros(d), np.zeros(d)
+    for i, n in enumerate(names):
+        if i < 6:
+            params[n] = {"prior": {"min": 0.0, "max": 1.0},
+                         "ref": {"dist": "norm", "loc": float(mean[i]), "scale": float(s[i])}}
+        else:
+            loc, sc = float(mean[i] + 0.5 * s[i]), float(2.0 * s[i])
+            params[n] = {"prior": {"dist": "norm", "loc": loc, "scale": sc},
+                         "ref": {"dist": "norm", "loc": float(mean[i]), "scale": float(s[i])}}
+            prior_prec[i], prior_mu[i] = 1 / sc ** 2, loc
+    info = {"likelihood": {"gaussian": {"mean": mean, "cov": cov, "normalized": True}},
+            "params": params,
+            "sampler": {"mcmc_hip": {"seed": 5, "n_walkers": 16384, "steps_per_launch": "10d",
+                                     "covmat": cov, "covmat_params": names,
+                                     "Rminus1_stop": 0.0, "max_samples": 6e7,
+                                     "snapshot_every": 270, "burn_in": 0}}}
+    updated, sampler = run(info)
+    coll = sampler.products()["sample"]
+    P = np.linalg.inv(cov) + np.diag(prior_prec)
+    pc = np.linalg.inv(P)
+    pm = pc @ (np.linalg.inv(cov) @ mean + prior_prec * prior_mu)
+    # drop the first third (walkers start from the ref pdf, not the posterior)
+    n0 = len(coll) // 3
+    m, c = coll.mean(first=n0), coll.cov(first=n0)
+    sig = np.sqrt(np.diag(pc))
+    assert len(coll) - n0 >= 10 * 16384
+    assert np.max(np.abs(m - pm) / sig) < 0.04
+    assert np.max(np.abs(c - pc) / np.outer(sig, sig)) < 0.05
+    assert kl_norm(pm, pc, m, c) < 0.07 and kl_norm(pm, pc, m, c) < 0.01
+    # stored prior/likelihood columns are consistent with the definitions
+    x = coll.data[names].to_numpy()[-50:]
+    lp = -6 * 0.0 + np.sum(-np.log(2.0 * s[6:]) - 0.5 * np.log(2 * np.pi)
+                           - 0.5 * ((x[:, 6:] - prior_mu[6:]) * np.sqrt(prior_prec[6:])) ** 2,
+                           axis=1)
+    np.testing.assert_allclose(-coll["minuslogprior"].to_numpy()[-50:], lp, rtol=1e-11)
+    sampler.close()
+
+
+def test_config4_d100_posterior():
+    """BASELINE config 4: 100-dim single-mode gaussian_mixture (golden target fixture), column-
+    sweep kernels; mean/cov of the ensemble against the analytic target."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
+    mean, cov = g["mean_d100"], g["cov_d100"]
+    d = 100
+    names = [f"a__{i}" for i in range(d)]
+    sig = np.sqrt(np.diag(cov))
+    info = {"likelihood": {"gaussian_mixture": {"means": [mean], "covs": [cov],
+                                                "input_params_prefix": "a_"}},
+            "params": {n: {"prior": {"min": 0.0, "max": 1.0},
+                           "ref": {"dist": "norm", "loc": float(mean[i]), "scale": float(sig[i])}}
+                       for i, n in enumerate(names)},
+            "sampler": {"mcmc_hip": {"seed": 9, "n_walkers": 16384, "steps_per_launch": "4d",
+                                     "covmat": cov, "covmat_params": names, "Rminus1_stop": 0.0,
+                                     "max_samples": 2.2e7, "snapshot_every": 800}}}
+    updated, sampler = run(info)
+    assert sampler.group_size == 128
+    coll = sampler.products()["sample"]
+    n0 = len(coll) // 2
+    m, c = coll.mean(first=n0), coll.cov(first=n0)
+    assert len(coll) - n0 >= 2 * 16384
+    assert np.max(np.abs(m - mean) / sig) < 0.05
+    assert np.max(np.abs(c - cov) / np.outer(sig, sig)) < 0.08
+    assert float(sampler.progress["acceptance_rate"].iloc[-1]) > 0.2
+    sampler.close()

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3
-timeout 300 python tools/quick_engine_bench.py 100 65536 64 200 2>&1 | tail -1
-timeout 300 python tools/quick_engine_bench.py 100 65536 128 200 2>&1 | tail -1
-timeout 300 python tools/quick_engine_bench.py 64 65536 256 128 2>&1 | tail -1
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
