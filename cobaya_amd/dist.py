@@ -35,6 +35,17 @@ def local_rank() -> int:
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def default_device() -> int:
+    """HIP ordinal for this process: LOCAL_RANK, wrapped onto the visible devices (ranks may
+    share a GPU in tests)."""
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 0
+    return local_rank() % n if n else local_rank()
+
+
 def init_from_env(backend=None):
     """Initialise the default group from RANK/WORLD_SIZE/MASTER_* (torch.distributed.run)
     when WORLD_SIZE > 1; a no-op for single-process runs."""
@@ -43,7 +54,9 @@ def init_from_env(backend=None):
     import torch
     td = _td()
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # MCMC_HIP_BACKEND=gloo forces the CPU collective (e.g. several ranks sharing one GPU)
+        backend = os.environ.get("MCMC_HIP_BACKEND") or (
+            "nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local_rank())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -174,7 +174,7 @@ class MCMCHip:
                 if W >= 16384 and W % gs == 0 and (d <= 32 or gs * (d | 1) * 8 <= 160 * 1024):
                     self.group_size = gs
                     break
-        device = self.device if self.device is not None else dist.local_rank()
+        device = self.device if self.device is not None else dist.default_device()
         cap = 0
         if self.emit == "chains":
             # every accepted row is kept on the device between drains: bound the buffer

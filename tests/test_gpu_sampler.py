@@ -204,3 +204,31 @@ def test_config4_d100_posterior():
     assert np.max(np.abs(c - cov) / np.outer(sig, sig)) < 0.08
     assert float(sampler.progress["acceptance_rate"].iloc[-1]) > 0.2
     sampler.close()
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """The N > 1 launch path of bench.py end to end (torch.distributed.run, walker sharding by
+    rank, the per-checkpoint all-reduce, MAX-over-ranks timing) with 2 ranks on this one GPU
+    and the gloo backend (RCCL needs one GPU per rank)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MCMC_HIP_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "6",
+           "--walkers", "16384", "--steps-per-launch", "900"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["evals_per_step"] == 2 * 16384 * 900
+    assert res["config"]["learn_checkpoints_in_timed_region"] >= 1
+    assert res["value"] > 1e8 and res["cpu_baseline"] is None
