@@ -130,12 +130,12 @@ def main():
         eng.step(spl)
         eng.accumulate_moments()
         sampler.n_steps_raw += spl
-        if sampler.n_steps_raw >= one_step.next_ckpt:
+        if sampler.n_steps_raw >= sampler._next_ckpt:
             sampler.check_convergence_and_learn_proposal()
             sampler.i_learn += 1
-            one_step.next_ckpt = sampler.n_steps_raw + sampler._checkpoint_steps()
+            sampler._next_ckpt = sampler.n_steps_raw + sampler._checkpoint_steps()
 
-    one_step.next_ckpt = sampler._checkpoint_steps()
+    sampler._next_ckpt = sampler._checkpoint_steps()
     for _ in range(a.warmup):
         one_step()
     eng.sync()

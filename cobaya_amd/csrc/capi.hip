@@ -721,6 +721,58 @@ int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logp
     return MCMC_HIP_OK;
 }
 
+int mcmc_hip_get_full_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
+                            double* loglike, int32_t* weight, int32_t* prior_rej,
+                            int32_t* burn_left, int64_t* n_accept, uint64_t* step)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    int rc = mcmc_hip_get_state(h, x, logpost, logprior, loglike, weight);
+    if (rc) return rc;
+    const size_t W = h->W;
+    if (prior_rej) HIP_TRY(h, hipMemcpy(prior_rej, h->prej.p, sizeof(int) * W, hipMemcpyDeviceToHost));
+    if (burn_left) HIP_TRY(h, hipMemcpy(burn_left, h->burn.p, sizeof(int) * W, hipMemcpyDeviceToHost));
+    if (n_accept) {
+        static_assert(sizeof(long long) == sizeof(int64_t), "n_accept layout");
+        HIP_TRY(h, hipMemcpy(n_accept, h->nacc.p, sizeof(int64_t) * W, hipMemcpyDeviceToHost));
+    }
+    if (step) *step = h->step;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logpost,
+                            const double* logprior, const double* loglike, const int32_t* weight,
+                            const int32_t* prior_rej, const int32_t* burn_left,
+                            const int64_t* n_accept, uint64_t step)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_prior || !h->have_target)
+        return fail(h, MCMC_HIP_ERR_STATE, "set_prior and set_target_* must precede set_full_state");
+    if (!x || !logpost || !logprior || !loglike || !weight || !prior_rej || !burn_left || !n_accept)
+        return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    const size_t W = h->W, d = h->d;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::vector<double> xt(W * d);
+    for (size_t w = 0; w < W; ++w) {
+        if (!std::isfinite(logpost[w]))
+            return fail(h, MCMC_HIP_ERR_ARG, "walker %zu has a non-finite log-posterior", w);
+        for (size_t i = 0; i < d; ++i) xt[i * W + w] = x[w * d + i];
+    }
+    HIP_TRY(h, hipMemcpy(h->x.p, xt.data(), sizeof(double) * W * d, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->logpost.p, logpost, sizeof(double) * W, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->logprior.p, logprior, sizeof(double) * W, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->loglike.p, loglike, sizeof(double) * W, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->weight_i.p, weight, sizeof(int) * W, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->prej.p, prior_rej, sizeof(int) * W, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->burn.p, burn_left, sizeof(int) * W, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->nacc.p, n_accept, sizeof(int64_t) * W, hipMemcpyHostToDevice));
+    if (h->nrows.p) HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
+    HIP_TRY(h, hipMemset(h->stuck.p, 0, sizeof(int)));
+    h->step = step;
+    h->have_state = true;
+    return MCMC_HIP_OK;
+}
+
 int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
 {
     if (!h) return MCMC_HIP_ERR_ARG;

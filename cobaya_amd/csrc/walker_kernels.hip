@@ -1,11 +1,12 @@
 // Lane-per-walker Metropolis kernels for one compile-time dimension MCMC_D (gfx950).
 //
 // One wavefront lane owns one walker: its parameter vector x[D] and trial t[D] live in
-// VGPRs (all loops over D are fully unrolled); everything the 64 lanes share -- the cycle's
-// proposal directions V, the inverse-Cholesky whitening stream, means and prior bounds --
-// comes in through the scalar data cache as SGPR operands; and n_steps Metropolis steps are
-// fused into one launch so that the state crosses HBM once per launch (coalesced,
-// dimension-major).
+// VGPRs (all loops over D are fully unrolled); the problem constants the 64 lanes share -- the
+// inverse-Cholesky whitening stream, means and prior bounds -- come in through the scalar
+// data cache as SGPR operands, the cycle's proposal directions V through LDS (DMA'd one cycle
+// ahead); and n_steps Metropolis steps are fused into one launch so that the state crosses
+// HBM once per launch (coalesced, dimension-major).  DESIGN.md section 4 has the reasoning
+// and the measurements behind each of these choices.
 //
 // Restates (paths relative to the reference checkout):
 //   cobaya/samplers/mcmc/mcmc.py:545-562 (step) 670-683 (accept) 685-748 (bookkeeping)
@@ -19,9 +20,6 @@
 
 #ifndef MCMC_CH
 #define MCMC_CH 16
-#endif
-#ifndef MCMC_RNGPIPE
-#define MCMC_RNGPIPE true
 #endif
 #ifndef MCMC_D
 #error "compile with -DMCMC_D=<dimension>"
@@ -485,7 +483,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             double dev[D], lfirst[CH];
             propose_fused(dev, r, v, C + cl.elem(), x, C + cl.linv(0), lfirst);
             lp = a.uniform_logp + 0.0;
-            const double chi2 = tri_stream<false, true, true, MCMC_RNGPIPE, lptr>(
+            const double chi2 = tri_stream<false, true, true, true, lptr>(
                 dev, C + cl.linv(0), dev[D - 1], nullptr, v, vhead, lfirst, rng);
             inb = chi2 < INFINITY;  // false for +inf and NaN: some dimension was out of bounds
             ll = -0.5 * (a.cnorm0 + chi2);

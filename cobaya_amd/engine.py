@@ -66,6 +66,12 @@ SYMBOLS = [
     ("mcmc_hip_set_state", C.c_int, [_H, c_double_p, c_int32_p]),
     ("mcmc_hip_get_state", C.c_int, [_H, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_int32_p]),
+    ("mcmc_hip_get_full_state", C.c_int, [_H, c_double_p, c_double_p, c_double_p, c_double_p,
+                                          c_int32_p, c_int32_p, c_int32_p, c_int64_p,
+                                          C.POINTER(C.c_uint64)]),
+    ("mcmc_hip_set_full_state", C.c_int, [_H, c_double_p, c_double_p, c_double_p, c_double_p,
+                                          c_int32_p, c_int32_p, c_int32_p, c_int64_p,
+                                          C.c_uint64]),
     ("mcmc_hip_step", C.c_int, [_H, C.c_int32]),
     ("mcmc_hip_sync", C.c_int, [_H]),
     ("mcmc_hip_get_counters", C.c_int, [_H, c_int64_p]),
@@ -262,6 +268,33 @@ class Engine:
         self._check(self._lib.mcmc_hip_get_state(self._h, _dp(x), _dp(lpost), _dp(lpri),
                                                  _dp(llik), _ip(wt)))
         return {"x": x, "logpost": lpost, "logprior": lpri, "loglike": llik, "weight": wt}
+
+    def get_full_state(self):
+        """Everything needed to resume bit-identically (see mcmc_hip_get_full_state)."""
+        W = self.W
+        out = {"x": np.empty((W, self.d)), "logpost": np.empty(W), "logprior": np.empty(W),
+               "loglike": np.empty(W), "weight": np.empty(W, np.int32),
+               "prior_rej": np.empty(W, np.int32), "burn_left": np.empty(W, np.int32),
+               "n_accept": np.empty(W, np.int64)}
+        step = C.c_uint64()
+        self._check(self._lib.mcmc_hip_get_full_state(
+            self._h, _dp(out["x"]), _dp(out["logpost"]), _dp(out["logprior"]),
+            _dp(out["loglike"]), _ip(out["weight"]), _ip(out["prior_rej"]),
+            _ip(out["burn_left"]), out["n_accept"].ctypes.data_as(c_int64_p), C.byref(step)))
+        out["step"] = np.uint64(step.value)
+        return out
+
+    def set_full_state(self, st):
+        W = self.W
+        x = _f64(st["x"], (W, self.d))
+        f = {k: _f64(st[k], (W,)) for k in ("logpost", "logprior", "loglike")}
+        i = {k: np.ascontiguousarray(st[k], dtype=np.int32) for k in
+             ("weight", "prior_rej", "burn_left")}
+        na = np.ascontiguousarray(st["n_accept"], dtype=np.int64)
+        self._check(self._lib.mcmc_hip_set_full_state(
+            self._h, _dp(x), _dp(f["logpost"]), _dp(f["logprior"]), _dp(f["loglike"]),
+            _ip(i["weight"]), _ip(i["prior_rej"]), _ip(i["burn_left"]),
+            na.ctypes.data_as(c_int64_p), int(st["step"])))
 
     # -- sampling
     def step(self, n_steps):

@@ -39,7 +39,8 @@ def run(info_or_yaml, **overrides):
         spec = ProblemSpec.from_info(info)
     except UnsupportedModel as e:
         raise LoggedError(log, "mcmc_hip cannot sample this model: %s", str(e)) from e
-    sampler = MCMCHip(opts or {}, spec, output=info.get("output"), name=name)
+    sampler = MCMCHip(opts or {}, spec, output=info.get("output"), name=name,
+                      resume=bool(info.get("resume")))
     updated = copy.deepcopy(info)
     updated["sampler"] = {name: {k: getattr(sampler, k)
                                  for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}}

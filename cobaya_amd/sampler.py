@@ -98,7 +98,7 @@ class MCMCHip:
 
     # ------------------------------------------------------------------ construction
     def __init__(self, info_sampler=None, model=None, output=None, packages_path=None,
-                 name=None):
+                 name=None, resume=False):
         info_sampler = dict(info_sampler or {})
         known = {**MCMC_DEFAULTS, **HIP_DEFAULTS}
         unknown = set(info_sampler) - set(known)
@@ -109,6 +109,7 @@ class MCMCHip:
             setattr(self, k, copy.deepcopy(info_sampler.get(k, v)))
         self._name = name or "mcmc_hip"
         self.output = output
+        self._resume = bool(resume)
         self.packages_path = packages_path
         if isinstance(model, ProblemSpec):
             self.spec = model
@@ -203,6 +204,12 @@ class MCMCHip:
             self.engine.set_proposal_cov(self._initial_covmat * self.temperature)
         except NotPositiveDefinite as e:
             raise LoggedError(log, "%s", str(e)) from e
+        self.output_every = _number_with_units(self.output_every, "s", 1)
+        self._last_state_dump = 0.0
+        if self._resume and self.output and os.path.exists(self._state_file()):
+            self._init_bookkeeping()
+            self._load_checkpoint()
+            return
         # initial points (model.py:707-754 get_valid_point, one per walker)
         log.info("Getting initial points... (%d walkers)", W)
         x0 = spec.sample_reference(W, self._rng)
@@ -220,7 +227,10 @@ class MCMCHip:
         dist.all_reduce_sum(shift)
         self._shift = shift[:d] / shift[d]
         self.engine.set_moment_shift(self._shift)
-        # bookkeeping
+        self._init_bookkeeping()
+
+    def _init_bookkeeping(self):
+        spec = self.spec
         self.collection = SampleCollection(spec.sampled, spec.derived, spec.like_name,
                                            self.temperature, name=str(1 + self.rank))
         self._rows = []          # (walker, weight, logpost, logprior, loglike, x...) blocks
@@ -237,6 +247,7 @@ class MCMCHip:
         self._acc_rate = 0.25
         self._launches = 0
         self._since_snapshot = 0
+        self._next_ckpt = None   # steps per walker at which the next learn checkpoint is due
 
     # ------------------------------------------------------------------ a17
     def initial_proposal_covmat(self):
@@ -312,7 +323,8 @@ class MCMCHip:
         log.info("Sampling!%s", (" (NB: no accepted step will be saved until %d burn-in "
                                  "samples have been obtained)" % self.burn_in)
                  if self.burn_in else "")
-        next_ckpt = self._checkpoint_steps()
+        if self._next_ckpt is None:
+            self._next_ckpt = self._checkpoint_steps()
         snap_every = (int(self.snapshot_every) if self.snapshot_every
                       else None)
         try:
@@ -327,14 +339,16 @@ class MCMCHip:
                     self._store_rows(self.engine.drain_samples())
                 elif snap_every and self._since_snapshot >= snap_every:
                     self._snapshot()
-                if self.n_steps_raw >= next_ckpt:
+                if self.n_steps_raw >= self._next_ckpt:
                     self.check_convergence_and_learn_proposal()
                     self.i_learn += 1
                     if self.emit == "snapshots" and not snap_every:
                         self._snapshot()
                     if self.callback_function:
                         self.callback_function(self)
-                    next_ckpt = self.n_steps_raw + self._checkpoint_steps()
+                    self._next_ckpt = self.n_steps_raw + self._checkpoint_steps()
+                    if self.output:
+                        self.write_checkpoint()
             self.engine.sync()
             self._update_counters()
         except ChainStuck as e:
@@ -346,6 +360,91 @@ class MCMCHip:
         log.info("Sampling complete after %d accepted steps.", self._accepted_total)
         if self.output:
             self._write_output()
+            self.write_checkpoint(force_state=True)
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def _state_file(self):
+        return f"{self.output}.{1 + self.rank}.state.npz"
+
+    def write_checkpoint(self, force_state=False):
+        """mcmc.py:1045-1078: `prefix.checkpoint` (yaml), `prefix.covmat`, `prefix.progress` on
+        the root; plus, per process and at most every `output_every` seconds, the complete
+        ensemble state `prefix.<rank+1>.state.npz` (walkers, counters, Philox step counter,
+        moment window) from which `resume` continues bit-identically -- the reference can
+        only restart from its last stored row and does not save its RNG state
+        (sampler.py:373)."""
+        import time
+
+        import yaml
+        prefix = str(self.output)
+        folder = os.path.dirname(prefix)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        if self.rank == 0:
+            np.savetxt(prefix + ".covmat",
+                       self.engine.get_proposal_cov() / self.temperature,  # mcmc.py:1049-1051
+                       header=" ".join(self.spec.sampled))
+            ck = {"sampler": {self.get_name(): {
+                "converged": bool(self.converged), "Rminus1_last": float(self.Rminus1_last),
+                "burn_in": 0, "mpi_size": int(self.size), "n_walkers": int(self.n_walkers),
+                "group_size": int(self.group_size), "seed": int(self.seed),
+                "n_steps_raw": int(self.n_steps_raw)}}}
+            with open(prefix + ".checkpoint", "w", encoding="utf-8") as f:
+                yaml.safe_dump(ck, f)
+            with open(prefix + ".progress", "w", encoding="utf-8") as f:
+                f.write("# " + " ".join(f"{c:>15}" for c in self.progress.columns) + "\n")
+                if len(self.progress):
+                    f.write(self.progress.to_string(header=False, index=False) + "\n")
+        now = time.time()
+        if force_state or now - self._last_state_dump >= float(self.output_every):
+            self._last_state_dump = now
+            st = self.engine.get_full_state()
+            ivs = self._intervals
+            np.savez(self._state_file(), **st,
+                     proposal_cov=self.engine.get_proposal_cov(), shift=self._shift,
+                     iv_n=np.array([iv[0] for iv in ivs], dtype=np.int64),
+                     iv_gs=np.array([iv[1] for iv in ivs]), iv_S=np.array([iv[2] for iv in ivs]),
+                     book=np.array([self.n_steps_raw, self.i_learn, self._acc_last,
+                                    self._steps_last, self._launches, self._dropped_snapshots,
+                                    self._accepted_total, self.seed, self.size,
+                                    int(self.n_walkers), int(self._next_ckpt or 0)],
+                                   dtype=np.int64),
+                     fbook=np.array([self._acc_rate, self.Rminus1_last, float(self.converged),
+                                     self.learn_proposal_Rminus1_max]),
+                     progress=self.progress.to_numpy(dtype=object).astype(str))
+
+    def _load_checkpoint(self):
+        """Resume (sampler.py:291-310, mcmc.py:131-139, 189-214): same number of processes and
+        walkers required; seed, proposal covariance, walkers, counters and the R-1 window come
+        back from the state file."""
+        z = np.load(self._state_file(), allow_pickle=False)
+        book, fbook = z["book"], z["fbook"]
+        if int(book[8]) != self.size or int(book[9]) != int(self.n_walkers):
+            raise LoggedError(log, "Cannot resume a run with a different number of chains: was "
+                                   "%d processes x %d walkers and now is %d x %d.",
+                              int(book[8]), int(book[9]), self.size, int(self.n_walkers))
+        self.engine.set_proposal_cov(z["proposal_cov"])
+        self.engine.set_full_state({k: z[k] for k in ("x", "logpost", "logprior", "loglike",
+                                                      "weight", "prior_rej", "burn_left",
+                                                      "n_accept", "step")})
+        self._shift = z["shift"]
+        self.engine.set_moment_shift(self._shift)
+        self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]
+        (self.n_steps_raw, self.i_learn, self._acc_last, self._steps_last, self._launches,
+         self._dropped_snapshots, self._accepted_total) = (int(v) for v in book[:7])
+        self._next_ckpt = int(book[10]) or None
+        if int(book[7]) != int(self.seed):
+            log.warning("Resuming with the seed of the checkpoint (%d), not %d", int(book[7]),
+                        int(self.seed))
+        self._acc_rate, self.Rminus1_last = float(fbook[0]), float(fbook[1])
+        self.converged = bool(fbook[2])
+        self.learn_proposal_Rminus1_max = float(fbook[3])
+        prog = z["progress"]
+        for row in prog:
+            i = len(self.progress) + 1
+            for c, v in zip(self.progress.columns, row):
+                self.progress.at[i, c] = v if c == "timestamp" else float(v)
+        log.info("Resumed from %s at %d steps per walker.", self._state_file(), self.n_steps_raw)
 
     # ------------------------------------------------------------------ storage
     def _store_rows(self, rows):
@@ -520,15 +619,13 @@ class MCMCHip:
         if folder:
             os.makedirs(folder, exist_ok=True)
         coll = self._build_collection()
-        coll.to_txt(f"{prefix}.{1 + self.rank}.txt")
-        if self.rank == 0:
-            np.savetxt(prefix + ".covmat",
-                       self.engine.get_proposal_cov() / self.temperature,  # mcmc.py:1049-1051
-                       header=" ".join(self.spec.sampled))
-            with open(prefix + ".progress", "w", encoding="utf-8") as f:
-                f.write("# " + " ".join(f"{c:>15}" for c in self.progress.columns) + "\n")
-                if len(self.progress):
-                    f.write(self.progress.to_string(header=False, index=False) + "\n")
+        path = f"{prefix}.{1 + self.rank}.txt"
+        if self._resume and os.path.exists(path) and len(coll):
+            with open(path, "a", encoding="utf-8") as out:  # rows of the resumed leg
+                np.savetxt(out, coll.data.to_numpy(dtype=np.float64),
+                           fmt=[f"%{max(15, len(c))}.8g" for c in coll.columns])
+        else:
+            coll.to_txt(path)
 
     def close(self):
         if self.engine is not None:

@@ -100,6 +100,20 @@ int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad);
 int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
                        double* loglike, int32_t* weight);
 
+/* Complete per-walker state for checkpoint/resume (mcmc.py:189-214, 1045-1078 -- the reference
+ * restarts from the last stored row and cannot save its RNG state, sampler.py:373; here the
+ * Philox counter is just `step`, so a resumed run continues bit-identically): x[W*d]
+ * walker-major, logpost/logprior/loglike[W], weight/prior_rej/burn_left[W] (int32),
+ * n_accept[W] (int64), *step = Metropolis steps taken per walker.  set_ restores all of it
+ * without re-evaluating anything (set_prior, a set_target call and set_proposal_cov must precede). */
+int mcmc_hip_get_full_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
+                            double* loglike, int32_t* weight, int32_t* prior_rej,
+                            int32_t* burn_left, int64_t* n_accept, uint64_t* step);
+int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logpost,
+                            const double* logprior, const double* loglike, const int32_t* weight,
+                            const int32_t* prior_rej, const int32_t* burn_left,
+                            const int64_t* n_accept, uint64_t step);
+
 /* n_steps iterations of MCMC.get_new_sample_metropolis (mcmc.py:545-562) for every walker,
  * asynchronously on the engine's stream; generates the Haar bases the steps need. */
 int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps);

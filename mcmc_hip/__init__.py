@@ -49,24 +49,16 @@ else:
             self.engine = None
             _Standalone.initialize(self)
 
-        # engine-backed implementation (same method objects as the standalone class)
-        initial_proposal_covmat = _Standalone.initial_proposal_covmat
-        n = _Standalone.n
-        run = _Standalone.run
-        check_convergence_and_learn_proposal = _Standalone.check_convergence_and_learn_proposal
-        samples = _Standalone.samples
-        products = _Standalone.products
-        _checkpoint_steps = _Standalone._checkpoint_steps
-        _store_rows = _Standalone._store_rows
-        _snapshot = _Standalone._snapshot
-        _update_counters = _Standalone._update_counters
-        _window = _Standalone._window
-        _build_collection = _Standalone._build_collection
-        _write_output = _Standalone._write_output
-        _ProposerView = _Standalone._ProposerView
-        proposer = _Standalone.proposer
-        current_point = _Standalone.current_point
-        close = _Standalone.close
+        _resume = False
+
+    # engine-backed implementation: every method/property of the standalone class that the
+    # Cobaya base does not have to keep (life-cycle hooks above excepted) is shared verbatim
+    for _name, _attr in vars(_Standalone).items():
+        if _name.startswith("__") or _name in ("initialize", "file_base_name", "info",
+                                                "get_name"):
+            continue
+        setattr(MCMCHip, _name, _attr)
+    del _name, _attr
 
 
 def get_cobaya_class():

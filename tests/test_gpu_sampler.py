@@ -232,3 +232,47 @@ def test_bench_two_ranks_share_one_gpu():
     assert res["config"]["evals_per_step"] == 2 * 16384 * 900
     assert res["config"]["learn_checkpoints_in_timed_region"] >= 1
     assert res["value"] > 1e8 and res["cpu_baseline"] is None
+
+
+def test_resume_continues_bit_identically(tmp_path):
+    """checkpoint files + resume.  One run of 2N launches equals a run of N
+    launches, a checkpoint, a fresh process-like restart (`resume: True`) and N more: walkers,
+    counters and the R-1 window all come back (the reference cannot do this: its RNG state is
+    not saved, sampler.py:373)."""
+    from cobaya_amd.sampler import MCMCHip
+    from cobaya_amd.model import ProblemSpec
+
+    def make(prefix, resume, max_samples):
+        info = dict(QUICK)
+        opts = {"seed": 21, "n_walkers": 512, "group_size": 64, "steps_per_launch": 40,
+                "max_samples": max_samples, "Rminus1_stop": 0.0, "learn_every": "20d"}
+        return MCMCHip(opts, ProblemSpec.from_info(info), output=prefix, resume=resume)
+
+    a = make(str(tmp_path / "a"), False, 60000)
+    a.run()
+    ref = a.engine.get_full_state()
+    steps_total = a.n_steps_raw
+    n_prog = len(a.progress)
+    a.close()
+
+    b1 = make(str(tmp_path / "b"), False, 30000)
+    b1.run()
+    assert b1.n_steps_raw < steps_total
+    b1.close()
+    for ext in (".checkpoint", ".covmat", ".progress", ".1.state.npz", ".1.txt"):
+        assert (tmp_path / ("b" + ext)).exists(), ext
+    b2 = make(str(tmp_path / "b"), True, 60000)
+    assert b2.n_steps_raw == b1.n_steps_raw and len(b2.progress) == len(b1.progress)
+    b2.run()
+    got = b2.engine.get_full_state()
+    assert b2.n_steps_raw == steps_total and len(b2.progress) == n_prog
+    for k in ("x", "logpost", "weight", "n_accept", "burn_left", "prior_rej"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert int(got["step"]) == int(ref["step"])
+    pa = a.progress["Rminus1"].to_numpy(dtype=float)
+    pb = b2.progress["Rminus1"].to_numpy(dtype=float)
+    np.testing.assert_allclose(pb, pa, rtol=1e-12)
+    with pytest.raises(LoggedError, match="different number of chains"):
+        MCMCHip({"seed": 21, "n_walkers": 256, "group_size": 64}, ProblemSpec.from_info(QUICK),
+                output=str(tmp_path / "b"), resume=True)
+    b2.close()
