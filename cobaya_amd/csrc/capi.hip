@@ -96,37 +96,95 @@ void tri_inverse_lower(int n, const double* L, double* Li)
     }
 }
 
-// eigenvalues of a symmetric matrix by cyclic Jacobi rotations (A destroyed)
-void jacobi_eigenvalues(int n, double* A, double* ev)
+// eigenvalues of a symmetric matrix (np.linalg.eigvalsh, mcmc.py:881): Householder reduction
+// to tridiagonal form followed by the implicit-shift QL iteration (the classic EISPACK
+// tred1 / tql1 pair, eigenvalues only).  A is destroyed; returns false if QL fails to converge.
+bool symmetric_eigenvalues(int n, double* A, double* ev)
 {
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < n; ++i) {
-            diag += A[i * n + i] * A[i * n + i];
-            for (int j = 0; j < i; ++j) off += A[i * n + j] * A[i * n + j];
-        }
-        if (off <= 1e-32 * diag || off == 0.0) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) /
-                                 (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - s * akq;
-                    A[k * n + q] = s * akp + c * akq;
+    std::vector<double> e(n, 0.0);
+    double* d = ev;
+    for (int i = n - 1; i > 0; --i) {
+        const int l = i - 1;
+        double h = 0.0, scale = 0.0;
+        if (l > 0) {
+            for (int k = 0; k <= l; ++k) scale += std::fabs(A[i * n + k]);
+            if (scale == 0.0) {
+                e[i] = A[i * n + l];
+            } else {
+                for (int k = 0; k <= l; ++k) {
+                    A[i * n + k] /= scale;
+                    h += A[i * n + k] * A[i * n + k];
                 }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - s * aqk;
-                    A[q * n + k] = s * apk + c * aqk;
+                double f = A[i * n + l];
+                const double g = (f >= 0.0) ? -std::sqrt(h) : std::sqrt(h);
+                e[i] = scale * g;
+                h -= f * g;
+                A[i * n + l] = f - g;
+                f = 0.0;
+                for (int j = 0; j <= l; ++j) {
+                    double gg = 0.0;
+                    for (int k = 0; k <= j; ++k) gg += A[j * n + k] * A[i * n + k];
+                    for (int k = j + 1; k <= l; ++k) gg += A[k * n + j] * A[i * n + k];
+                    e[j] = gg / h;
+                    f += e[j] * A[i * n + j];
+                }
+                const double hh = f / (h + h);
+                for (int j = 0; j <= l; ++j) {
+                    f = A[i * n + j];
+                    const double gg = e[j] - hh * f;
+                    e[j] = gg;
+                    for (int k = 0; k <= j; ++k) A[j * n + k] -= f * e[k] + gg * A[i * n + k];
                 }
             }
+        } else {
+            e[i] = A[i * n + l];
+        }
+        d[i] = h;
     }
-    for (int i = 0; i < n; ++i) ev[i] = A[i * n + i];
+    for (int i = 0; i < n; ++i) d[i] = A[i * n + i];
+    // QL with implicit shifts on (d, e)
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= std::numeric_limits<double>::epsilon() * dd) break;
+            }
+            if (m != l) {
+                if (++iter > 60) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    r = std::hypot(f, g);
+                    e[i + 1] = r;
+                    if (r == 0.0) {
+                        d[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    d[i + 1] = g + p;
+                    g = c * r - b;
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return true;
 }
 
 // np.allclose(A.T, A) (rtol 1e-5, atol 1e-8), proposal.py:243
@@ -187,6 +245,7 @@ struct mcmc_hip_ctx {
     DevBuf<double> ex, elp, ell, eder, escratch, dLrow, dLcol;
     DevBuf<int> weight_i, prej, burn, stuck, nrows;
     DevBuf<long long> nacc;
+    DevBuf<unsigned long long> acc_total;
     unsigned long long step = 0;
     int64_t n_snapshots = 0;
     // timing
@@ -451,6 +510,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     acc(h->x.resize(W * d)); acc(h->logpost.resize(W)); acc(h->logprior.resize(W));
     acc(h->loglike.resize(W)); acc(h->weight_i.resize(W)); acc(h->prej.resize(W));
     acc(h->burn.resize(W)); acc(h->nacc.resize(W)); acc(h->stuck.resize(1));
+    acc(h->acc_total.resize(1));
     acc(h->dT.resize(d * d)); acc(h->gsum.resize(G * d)); acc(h->Sg.resize(G * np));
     acc(h->pooled.resize(np)); acc(h->dshift.resize(d));
     if (cfg->emit_capacity > 0) {
@@ -461,6 +521,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     if (r == hipSuccess) r = hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->dshift.p, 0, sizeof(double) * d, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->stuck.p, 0, sizeof(int), h->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(h->acc_total.p, 0, sizeof(unsigned long long), h->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(h->stream);
     if (r != hipSuccess) {
         fail(nullptr, MCMC_HIP_ERR_DEVICE, "device allocation failed: %s", hipGetErrorString(r));
@@ -484,6 +545,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->ell.release(); h->eder.release(); h->escratch.release(); h->dLrow.release();
     h->dLcol.release(); h->weight_i.release(); h->prej.release();
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
+    h->acc_total.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -691,6 +753,7 @@ int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad)
     if (h->nrows.p)
         HIP_TRY(h, hipMemcpyAsync(h->nrows.p, zeros.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemsetAsync(h->stuck.p, 0, sizeof(int), s));
+    HIP_TRY(h, hipMemsetAsync(h->acc_total.p, 0, sizeof(unsigned long long), s));
     HIP_TRY(h, hipStreamSynchronize(s));
     h->step = 0;
     h->have_state = true;
@@ -768,6 +831,11 @@ int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logp
     HIP_TRY(h, hipMemcpy(h->nacc.p, n_accept, sizeof(int64_t) * W, hipMemcpyHostToDevice));
     if (h->nrows.p) HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
     HIP_TRY(h, hipMemset(h->stuck.p, 0, sizeof(int)));
+    {
+        unsigned long long tot = 0;
+        for (size_t w = 0; w < W; ++w) tot += (unsigned long long)n_accept[w];
+        HIP_TRY(h, hipMemcpy(h->acc_total.p, &tot, sizeof tot, hipMemcpyHostToDevice));
+    }
     h->step = step;
     h->have_state = true;
     return MCMC_HIP_OK;
@@ -815,6 +883,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             a.x = h->x.p; a.logpost = h->logpost.p; a.logprior = h->logprior.p;
             a.loglike = h->loglike.p; a.weight = h->weight_i.p; a.prior_rej = h->prej.p;
             a.burn_left = h->burn.p; a.n_accept = h->nacc.p; a.stuck = h->stuck.p;
+            a.accept_total = h->acc_total.p;
             a.rows = h->rows.p; a.n_rows = h->nrows.p; a.row_cap = h->cfg.emit_capacity;
             a.cblock = h->cblock.p; a.V = h->V.p; a.W = h->W; a.n_modes = h->K;
             a.group_size = h->gs;
@@ -856,10 +925,8 @@ int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4])
     if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::vector<long long> na(h->W);
-    HIP_TRY(h, hipMemcpy(na.data(), h->nacc.p, sizeof(long long) * h->W, hipMemcpyDeviceToHost));
-    int64_t tot = 0;
-    for (auto v : na) tot += v;
+    unsigned long long tot = 0;
+    HIP_TRY(h, hipMemcpy(&tot, h->acc_total.p, sizeof tot, hipMemcpyDeviceToHost));
     int stuck = 0;
     HIP_TRY(h, hipMemcpy(&stuck, h->stuck.p, sizeof(int), hipMemcpyDeviceToHost));
     int64_t dropped = 0;
@@ -869,7 +936,7 @@ int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4])
         for (auto v : nr) dropped += std::max(0, v - h->cfg.emit_capacity);
     }
     counters[0] = (int64_t)h->step;
-    counters[1] = tot;
+    counters[1] = (int64_t)tot;
     counters[2] = stuck;
     counters[3] = dropped;
     return MCMC_HIP_OK;
@@ -1005,7 +1072,7 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
         }
     for (size_t i = 0; i < n; ++i)
         for (size_t j = 0; j < i; ++j) M[i * n + j] = M[j * n + i] = 0.5 * (M[i * n + j] + M[j * n + i]);
-    jacobi_eigenvalues(d, M.data(), ev.data());  // mcmc.py:881
+    if (!symmetric_eigenvalues(d, M.data(), ev.data())) return MCMC_HIP_ERR_NOT_PD;  // mcmc.py:881-887
     double r = 0.0;
     for (size_t i = 0; i < n; ++i) r = std::max(r, std::fabs(ev[i]));
     if (!std::isfinite(r)) return MCMC_HIP_ERR_NOT_PD;

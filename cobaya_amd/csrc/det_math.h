@@ -205,4 +205,13 @@ struct StepRng {
     }
 };
 
+// accepted steps of this launch: summed over the wave, one atomic per wave
+__device__ __forceinline__ void wave_add_accepts(unsigned long long* total, long long mine)
+{
+    unsigned v = (unsigned)mine;  // < 2^32 per launch
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(total, (unsigned long long)v);
+}
+
 }  // namespace mcmc

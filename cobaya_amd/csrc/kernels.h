@@ -70,6 +70,7 @@ struct StepArgs {
     int* prior_rej;
     int* burn_left;
     long long* n_accept;
+    unsigned long long* accept_total;  // [1] accepted steps of all walkers (one atomic per wave)
     int* stuck;
     // optional emission of accepted rows: rows[W][row_cap][d+4], n_rows[W]
     double* rows;

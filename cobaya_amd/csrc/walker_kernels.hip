@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
     int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
     long long nacc = a.n_accept[w];
+    const long long nacc0 = nacc;
     int nrow = a.rows ? a.n_rows[w] : 0;
     const uint32_t gid = a.walker0 + (uint32_t)w;
     unsigned long long step = a.step0;
@@ -563,6 +564,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     ka->logpost[w] = lpost; ka->logprior[w] = lpri; ka->loglike[w] = llik;
     ka->weight[w] = wt; ka->prior_rej[w] = prej; ka->burn_left[w] = burn;
     ka->n_accept[w] = nacc;
+    wave_add_accepts(ka->accept_total, nacc - nacc0);
     if (ka->rows) ka->n_rows[w] = nrow;
 }
 

@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
     double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
     int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
     long long nacc = a.n_accept[w];
+    const long long nacc0 = nacc;
     const uint32_t gid = a.walker0 + (uint32_t)w;
     double* const xg = a.x + w;
 
@@ -297,6 +298,7 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
     a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
     a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
     a.n_accept[w] = nacc;
+    wave_add_accepts(a.accept_total, nacc - nacc0);
 }
 
 // ---------------------------------------------------------------- batch evaluator (run-time d)

@@ -237,8 +237,7 @@ class MCMCHip:
         self._n_rows = 0
         self._intervals = []     # per checkpoint: (n_snapshots, group_sum[G,d], pooled_S[d,d])
         self._dropped_snapshots = 0
-        self.progress = pd.DataFrame(columns=["N", "timestamp", "acceptance_rate", "Rminus1",
-                                              "Rminus1_cl"])
+        self._progress_rows = {}  # i_learn -> row dict (DataFrame built on demand: `progress`)
         self.i_learn = 1
         self.n_steps_raw = 0     # Metropolis steps per walker (mcmc.py:472)
         self._accepted_total = 0
@@ -306,6 +305,16 @@ class MCMCHip:
             cov[where_nan2, where_nan2] = (spec.reference_variances()[where_nan2]
                                            / self.fallback_covmat_scale)
         return cov, where_nan
+
+    PROGRESS_COLUMNS = ["N", "timestamp", "acceptance_rate", "Rminus1", "Rminus1_cl"]
+
+    @property
+    def progress(self):
+        """mcmc.py:165-181: table (N, timestamp, acceptance_rate, Rminus1, Rminus1_cl), one row
+        per learn/convergence checkpoint, indexed from 1."""
+        df = pd.DataFrame.from_dict(self._progress_rows, orient="index",
+                                    columns=self.PROGRESS_COLUMNS)
+        return df.astype({c: float for c in self.PROGRESS_COLUMNS if c != "timestamp"})
 
     # ------------------------------------------------------------------ MCMC.run
     def n(self):
@@ -439,11 +448,9 @@ class MCMCHip:
         self._acc_rate, self.Rminus1_last = float(fbook[0]), float(fbook[1])
         self.converged = bool(fbook[2])
         self.learn_proposal_Rminus1_max = float(fbook[3])
-        prog = z["progress"]
-        for row in prog:
-            i = len(self.progress) + 1
-            for c, v in zip(self.progress.columns, row):
-                self.progress.at[i, c] = v if c == "timestamp" else float(v)
+        for i, prow in enumerate(z["progress"], start=1):
+            self._progress_rows[i] = {c: (v if c == "timestamp" else float(v))
+                                      for c, v in zip(self.PROGRESS_COLUMNS, prow)}
         log.info("Resumed from %s at %d steps per walker.", self._state_file(), self.n_steps_raw)
 
     # ------------------------------------------------------------------ storage
@@ -504,21 +511,22 @@ class MCMCHip:
         sum_mm = means.T @ means
         payload = np.concatenate((
             [float(eng.G), N_c * eng.G, float(c["accepted"] - self._acc_last),
-             float((c["steps"] - self._steps_last) * eng.W)],
+             float((c["steps"] - self._steps_last) * eng.W), float(c["accepted"])],
             (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
         dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
-        n_chains, sum_N, d_acc, d_steps = payload[:4]
-        sum_Ncov = payload[4:4 + d * d].reshape(d, d)
-        sum_mean = payload[4 + d * d:4 + d * d + d]
-        sum_mm = payload[4 + d * d + d:].reshape(d, d)
+        n_chains, sum_N, d_acc, d_steps, n_acc_all = payload[:5]
+        sum_Ncov = payload[5:5 + d * d].reshape(d, d)
+        sum_mean = payload[5 + d * d:5 + d * d + d]
+        sum_mm = payload[5 + d * d + d:].reshape(d, d)
         self._acc_last, self._steps_last = c["accepted"], c["steps"]
         acceptance_rate = d_acc / max(d_steps, 1.0)
         self._acc_rate = acceptance_rate
-        self._update_counters()
-        i = self.i_learn
-        self.progress.at[i, "N"] = self._accepted_total
-        self.progress.at[i, "timestamp"] = datetime.datetime.now().isoformat()
-        self.progress.at[i, "acceptance_rate"] = acceptance_rate
+        self._accepted_total = int(n_acc_all)
+        row = {"N": float(self._accepted_total),
+               "timestamp": datetime.datetime.now().isoformat(),
+               "acceptance_rate": float(acceptance_rate), "Rminus1": np.nan,
+               "Rminus1_cl": np.nan}
+        self._progress_rows[self.i_learn] = row
         log.info("Learn + convergence test @ %d samples accepted.", self._accepted_total)
         log.info(" - Acceptance rate: %.3f", acceptance_rate)
         try:
@@ -528,7 +536,7 @@ class MCMCHip:
                         "the samples does not contain enough information at this point. "
                         "Skipping learning a new covmat for now.")
             return
-        self.progress.at[i, "Rminus1"] = Rminus1
+        row["Rminus1"] = float(Rminus1)
         log.info(" - Convergence of means: R-1 = %f after %d accepted steps", Rminus1,
                  self._accepted_total)
         # twice in a row (mcmc.py:908); the bounds criterion (918-1002) is not evaluated

@@ -59,9 +59,7 @@ def main():
         setattr(s, k, v)
     s.spec = spec
     s.rank, s.size = rank, 2
-    import pandas as pd
-    s.progress = pd.DataFrame(columns=["N", "timestamp", "acceptance_rate", "Rminus1",
-                                       "Rminus1_cl"])
+    s._progress_rows = {}
     s.i_learn, s._intervals, s._dropped_snapshots = 1, [], 0
     s._acc_last = s._steps_last = 0
     s._accepted_total, s.converged, s.Rminus1_last = 0, False, np.inf
@@ -73,8 +71,10 @@ def main():
     buf = np.arange(6, dtype=float).reshape(2, 3) * (rank + 1)
     dist.all_reduce_sum(buf)
     rows = dist.gather_rows(np.full((2, 2), float(rank)))
-    res = {"rank": rank, "Rminus1": float(s.progress.at[1, "Rminus1"]),
-           "acc": float(s.progress.at[1, "acceptance_rate"]), "N": int(s.progress.at[1, "N"]),
+    prog = s.progress
+    assert list(prog.columns) == ["N", "timestamp", "acceptance_rate", "Rminus1", "Rminus1_cl"]
+    res = {"rank": rank, "Rminus1": float(prog.at[1, "Rminus1"]),
+           "acc": float(prog.at[1, "acceptance_rate"]), "N": int(prog.at[1, "N"]),
            "new_cov": s.engine.new_cov.tolist(), "buf": buf.tolist(),
            "gathered": None if rows is None else [r.tolist() for r in rows]}
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
