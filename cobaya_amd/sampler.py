@@ -14,8 +14,8 @@ by design:
     all-reduce per checkpoint (RCCL over xGMI) instead of gather/bcast of means and covs
     (mcmc.py:791-793, 914, 1005, 1021);
   * `max_samples` counts accepted steps over ALL walkers; the R-1 of confidence-interval
-    bounds (mcmc.py:918-1002, GetDist) is not evaluated: convergence = R-1 of means below
-    `Rminus1_stop` twice in a row (mcmc.py:908).
+    bounds (mcmc.py:918-1002) is restated with weighted quantiles of the stored samples in
+    place of GetDist's `confidence` (absent here; parity unpinned for that number).
 
 There is no CPU fallback: constructing the sampler without a usable gfx950 device raises.
 """
@@ -539,10 +539,20 @@ class MCMCHip:
         row["Rminus1"] = float(Rminus1)
         log.info(" - Convergence of means: R-1 = %f after %d accepted steps", Rminus1,
                  self._accepted_total)
-        # twice in a row (mcmc.py:908); the bounds criterion (918-1002) is not evaluated
+        # means criterion twice in a row (mcmc.py:908), then the bounds criterion (918-1002)
         if max(Rminus1, self.Rminus1_last) < self.Rminus1_stop:
-            self.converged = True
-            log.info("The run has converged!")
+            Rcl = self._rminus1_of_bounds(mean_of_covs)
+            if Rcl is None:
+                log.info("Computation of the bounds was not possible (no stored samples): "
+                         "convergence judged on the means only.")
+                self.converged = True
+            else:
+                row["Rminus1_cl"] = float(Rcl)
+                log.info(" - Convergence of bounds: R-1 = %f after %d accepted steps", Rcl,
+                         self._accepted_total)
+                self.converged = Rcl < self.Rminus1_cl_stop
+            if self.converged:
+                log.info("The run has converged!")
         self.Rminus1_last = Rminus1
         if self.learn_proposal and not self.converged:
             if Rminus1 > self.learn_proposal_Rminus1_max:
@@ -558,6 +568,54 @@ class MCMCHip:
                 except NotPositiveDefinite:
                     log.debug("Updating covariance matrix failed unexpectedly. waiting until "
                               "next covmat learning attempt.")
+
+    def _rminus1_of_bounds(self, mean_of_covs, min_per_chain=40):
+        """R-1 of the confidence-interval bounds (mcmc.py:918-1002): per chain (= walker group)
+        the lower/upper `Rminus1_cl_level` bounds of every parameter, from the stored rows of
+        the later half of the run; statistic = max_i std_chains(bound_i) / sigma_i.  The
+        reference takes the bounds from GetDist's `MCSamples.confidence` (absent here): they
+        are restated as weighted quantiles of the chain's samples -- PARITY UNPINNED for this
+        number.  Returns None when no samples are stored."""
+        d, eng = self.spec.d, self.engine
+        rows = [r for r in self._rows if len(r)]
+        n_rows = sum(len(r) for r in rows)
+        stats = np.zeros(1 + 4 * d)  # n_chains, sum b_lo, sum b_hi, sum b_lo^2, sum b_hi^2
+        if n_rows:
+            keep, acc = [], 0
+            for r in reversed(rows):          # later half, whole blocks
+                keep.append(r)
+                acc += len(r)
+                if acc >= n_rows / 2:
+                    break
+            data = np.vstack(keep)
+            grp = ((data[:, 0].astype(np.int64) - self.rank * eng.W) // eng.group_size)
+            q = (1 - self.Rminus1_cl_level) / 2.0
+            order = np.argsort(grp, kind="stable")
+            data, grp = data[order], grp[order]
+            starts = np.flatnonzero(np.diff(np.concatenate(([-1], grp)))).tolist() + [len(grp)]
+            for a_, b_ in zip(starts[:-1], starts[1:]):
+                if b_ - a_ < min_per_chain:
+                    continue
+                w, x = data[a_:b_, 1], data[a_:b_, 5:5 + d]
+                lo, hi = np.empty(d), np.empty(d)
+                for i in range(d):
+                    o = np.argsort(x[:, i])
+                    cw = (np.cumsum(w[o]) - 0.5 * w[o]) / w.sum()
+                    lo[i], hi[i] = np.interp([q, 1 - q], cw, x[o, i])
+                stats[0] += 1
+                stats[1:1 + d] += lo
+                stats[1 + d:1 + 2 * d] += hi
+                stats[1 + 2 * d:1 + 3 * d] += lo ** 2
+                stats[1 + 3 * d:] += hi ** 2
+        dist.all_reduce_sum(stats)
+        m = stats[0]
+        if m < 2:
+            return None
+        mean_lo, mean_hi = stats[1:1 + d] / m, stats[1 + d:1 + 2 * d] / m
+        var_lo = np.maximum(stats[1 + 2 * d:1 + 3 * d] / m - mean_lo ** 2, 0.0)  # np.std: ddof 0
+        var_hi = np.maximum(stats[1 + 3 * d:] / m - mean_hi ** 2, 0.0)
+        sig = np.sqrt(np.diag(mean_of_covs))
+        return float(max(np.max(np.sqrt(var_lo) / sig), np.max(np.sqrt(var_hi) / sig)))
 
     # ------------------------------------------------------------------ products
     def _build_collection(self):

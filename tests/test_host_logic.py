@@ -248,3 +248,43 @@ print("RESOLVED")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0 and "RESOLVED" in out.stdout, out.stdout + out.stderr
+
+
+def test_rminus1_of_bounds_statistic():
+    """mcmc.py:918-1002 restated with weighted quantiles: for chains that sample the same
+    N(0,1), std over chains of the 2.5 % bound ~ sqrt(q(1-q)/n)/pdf(z_q); identical chains give
+    0; shifted chains are flagged."""
+    d = 3
+    spec = ProblemSpec.from_info({"likelihood": {"one": None},
+                                  "params": {f"p{i}": {"prior": [-10, 10]} for i in range(d)}})
+    s = bare_sampler(spec)
+    s.rank, s.size = 0, 1
+
+    class Eng:
+        W, group_size, G = 1024, 64, 16
+
+    s.engine = Eng()
+    rng = np.random.default_rng(0)
+
+    def blocks(shift_group0=0.0, n_snap=40):
+        out = []
+        for _ in range(n_snap):
+            x = rng.normal(size=(1024, d))
+            x[:64] += shift_group0
+            out.append(np.column_stack((np.arange(1024), np.ones(1024), np.zeros((1024, 3)), x)))
+        return out
+
+    s._rows = blocks()
+    R = s._rminus1_of_bounds(np.eye(d))
+    n = 20 * 64  # later half of 40 snapshots, 64 walkers per chain
+    expect = np.sqrt(0.025 * 0.975 / n) / 0.0584
+    assert 0.5 * expect < R < 2.5 * expect and R < 0.2
+    s._rows = blocks(shift_group0=3.0)
+    assert s._rminus1_of_bounds(np.eye(d)) > 0.5
+    one = blocks(n_snap=2)[0]
+    s._rows = [one, one.copy()]
+    s.engine.group_size, s.engine.G = 512, 2   # two identical chains
+    s._rows = [np.vstack((one[:512], np.column_stack((one[:512, :1] + 512, one[:512, 1:]))))]
+    assert s._rminus1_of_bounds(np.eye(d)) == 0.0
+    s._rows = []
+    assert s._rminus1_of_bounds(np.eye(d)) is None
