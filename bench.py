@@ -96,13 +96,13 @@ def cpu_baseline(d, mean, cov, group_size, seconds):
     W = group_size * max(threads, 1) * 4
     x0 = np.clip(mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov)), 1e-6, 1 - 1e-6)
     st = O.State(prob, x0)
-    t0 = time.perf_counter()
-    st.run(d, n_threads=threads)  # calibration
-    rate = W * d / (time.perf_counter() - t0)
-    steps = int(max(d, min(seconds * rate / W, 50000)))
-    t0 = time.perf_counter()
-    st.run(steps, n_threads=threads)
-    dt = time.perf_counter() - t0
+    st.run(d, n_threads=threads)  # warm the thread pool and the caches (untimed)
+    steps, dt, chunk = 0, 0.0, 4 * d
+    while dt < seconds:           # whole cycles until the time budget is used
+        t0 = time.perf_counter()
+        st.run(chunk, n_threads=threads)
+        dt += time.perf_counter() - t0
+        steps += chunk
     return {"value": W * steps / dt, "unit": "evals/s", "cores": threads, "kind": "port",
             "sample": f"{W} walkers x {steps} steps of the same d={d} workload, "
                       f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c)"}
