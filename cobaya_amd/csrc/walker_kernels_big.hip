@@ -1,20 +1,20 @@
-// Walker kernels for 32 < d <= MCMC_DP (gfx950): the state no longer fits a lane's VGPRs.
+// Walker kernels for 32 < d <= MCMC_DP (gfx950).
 //
-// Still one lane per walker, but organised as a COLUMN SWEEP: the DP whitened accumulators
-// y_j live in VGPRs (static indices), the parameter vector x stays in HBM/L2 (dimension-major,
-// so lane w reads x[i*W + w]: coalesced) and is streamed once per step; for each dimension i
-// the lane forms t_i = fma(r, v_i, x_i) and tests the prior support; four columns at a time
-// are then added to every y_j below them (a switch with fall-through over 4-row blocks:
-// triangular work with a single jump per 4 columns, 16 operands and 16 FMAs per block).  y_j therefore accumulates i = 0..j in ascending order from +0 --
-// the same fma chain as the oracle and as the small-d kernels.  L^-1 (in 4x4 tiles, zero above
-// the diagonal) is staged once per launch in LDS and read as wave-uniform broadcasts; the
-// proposal direction of the NEXT step is brought into LDS by a 1 KiB global->LDS DMA while
-// the current step runs.
+// Still one lane per walker and n_steps fused per launch, but 2*d doubles of state no longer
+// fit the 256 architectural VGPRs: the whitened accumulators y_j take them (in two passes over
+// half of the rows each, so that the other half of the VGPRs can hold L^-1 tiles in flight),
+// and the parameter vector x lives in the accumulation half of the unified register file.
+// The sweep goes column block by column block: t_i = fma(r, v_i, x_i), prior support, dev_i
+// for four columns, then every 4x4 tile of L^-1 below them (16 FMAs per tile; tiles staged in
+// LDS once per launch, zero above the diagonal, read as wave-uniform broadcasts two tiles
+// ahead).  Each y_j accumulates i = 0..j in ascending order from +0 -- the same fma chain as
+// the oracle and the small-d kernels, so parity stays bit-exact.  The proposal direction of
+// the NEXT step arrives in LDS by a 1 KiB global->LDS DMA while the current step runs.
 //
 // Scope of this variant: one Gaussian mode, uniform priors, nothing periodic, no emitted rows
 // (BASELINE config 4).  Everything else at d > 32 is refused by the host with a clear error.
 //
-// One translation unit per accumulator count DP (-DMCMC_DP=48|64|80|100|128); the actual d is
+// One translation unit per accumulator count DP (-DMCMC_DP=48|64|80|100|112); the actual d is
 // a run-time argument <= DP (rows/columns beyond d are zero operands: exact no-ops).
 #include "det_math.h"
 #include "kernels.h"
@@ -28,7 +28,6 @@ namespace {
 
 constexpr int DP = MCMC_DP;
 constexpr int NB = DP / 4;
-constexpr int XCH = (DP <= 100) ? 16 : 8;  // dimensions of x per LDS ring slot (per wave)
 static_assert(DP % 4 == 0 && DP <= 128, "DP must be a multiple of 4, at most 128");
 
 // ---------------------------------------------------------------- Haar basis (run-time d)
@@ -112,43 +111,123 @@ struct BigStepArgs {
     int d;
 };
 
-// One 4x4 tile: rows 4B..4B+3 of columns 4cb..4cb+3, stored [c][q] (16 contiguous doubles).
-// Each y_j takes its four columns in ascending order.
-#define MCMC_BLK(B)                                                                      \
-    case B:                                                                              \
-        if constexpr (4 * B + 3 < DPX) {                                                 \
-            const double* __restrict__ tl = tiles + B * 16;                              \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                \
-            {                                                                            \
-                double acc = y[4 * B + q];                                               \
-                acc = fma(tl[0 * 4 + q], dev[0], acc);                                   \
-                acc = fma(tl[1 * 4 + q], dev[1], acc);                                   \
-                acc = fma(tl[2 * 4 + q], dev[2], acc);                                   \
-                acc = fma(tl[3 * 4 + q], dev[3], acc);                                   \
-                y[4 * B + q] = acc;                                                      \
-            }                                                                            \
-        }                                                                                \
-        [[fallthrough]];
-
-template <int DPX>
-__device__ __forceinline__ void column_block_update(double (&y)[DPX],
-                                                    const double* __restrict__ tiles,
-                                                    const double (&dev)[4], int cb)
+// x and the accumulators both stay in registers for the whole launch (the compiler parks x in
+// the accumulation half of the unified 512-entry register file and moves an element through
+// v_accvgpr_read/write only a few times per step), every loop is static, and n_steps are
+// fused: nothing but the direction column crosses the memory system inside a launch.  Needs
+// 2 * DP doubles of registers per lane: DP <= 112.
+// The 4x4 tiles a pass touches, in the order it touches them (column block ascending, then
+// row block ascending), as a compile-time table.
+template <int RB0, int RB1>
+struct TileSeq {
+    static constexpr int count()
+    {
+        int n = 0;
+        for (int cb = 0; cb < RB1; ++cb)
+            for (int B = (cb > RB0 ? cb : RB0); B < RB1; ++B) ++n;
+        return n;
+    }
+    static constexpr int N = count();
+    unsigned char cb[N];
+    unsigned char rb[N];
+};
+template <int RB0, int RB1>
+constexpr TileSeq<RB0, RB1> make_tile_seq()
 {
-    switch (cb) {
-        MCMC_BLK(0) MCMC_BLK(1) MCMC_BLK(2) MCMC_BLK(3) MCMC_BLK(4) MCMC_BLK(5) MCMC_BLK(6)
-        MCMC_BLK(7) MCMC_BLK(8) MCMC_BLK(9) MCMC_BLK(10) MCMC_BLK(11) MCMC_BLK(12) MCMC_BLK(13)
-        MCMC_BLK(14) MCMC_BLK(15) MCMC_BLK(16) MCMC_BLK(17) MCMC_BLK(18) MCMC_BLK(19)
-        MCMC_BLK(20) MCMC_BLK(21) MCMC_BLK(22) MCMC_BLK(23) MCMC_BLK(24) MCMC_BLK(25)
-        MCMC_BLK(26) MCMC_BLK(27) MCMC_BLK(28) MCMC_BLK(29) MCMC_BLK(30) MCMC_BLK(31)
-    default:
-        break;
+    TileSeq<RB0, RB1> t{};
+    int n = 0;
+    for (int cb = 0; cb < RB1; ++cb)
+        for (int B = (cb > RB0 ? cb : RB0); B < RB1; ++B) {
+            t.cb[n] = (unsigned char)cb;
+            t.rb[n] = (unsigned char)B;
+            ++n;
+        }
+    return t;
+}
+template <int RB0, int RB1>
+__device__ constexpr TileSeq<RB0, RB1> kTileSeq = make_tile_seq<RB0, RB1>();
+
+typedef const double __attribute__((address_space(3))) * lptr;
+// LDS tile pointer passed through an empty asm together with a value computed just before:
+// the tile's loads can be issued neither earlier (all 2500 of them hoisted to the top and
+// spilled) nor later (latency exposed) than this point of the instruction stream.
+__device__ __forceinline__ lptr after(lptr p, double& anchor)
+{
+    unsigned v = (unsigned)(unsigned long long)p;
+    asm volatile("; next tile" : "+v"(v), "+v"(anchor));
+    return (lptr)__builtin_assume_aligned((lptr)(unsigned long long)v, 16);
+}
+
+// One pass over all columns for the row blocks [RB0, RB1): with only half of the accumulators
+// live, the other half of the VGPRs holds L^-1 tiles in flight: tile k+2 is requested while
+// tile k is consumed (LDS returns in order, so the waits are counted, not drained).  dev is
+// recomputed per pass (cheap) rather than kept.  Columns beyond d carry dev = 0 and zero tiles.
+template <int RB0, int RB1>
+__device__ __forceinline__ void sweep_pass(double (&y)[4 * (RB1 - RB0)], const double (&x)[DP],
+                                           double r, lptr v, lptr sE, lptr sL, int d)
+{
+    constexpr int N = TileSeq<RB0, RB1>::N;
+    const auto& seq = kTileSeq<RB0, RB1>;
+    auto tile_ptr = [&](int k) { return sL + (seq.cb[k] * NB + seq.rb[k]) * 16; };
+    double cur[16], n1[16], n2[16];
+    double anchor0 = r;
+    {
+        const lptr p0 = after(tile_ptr(0), anchor0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[e] = p0[e];
+        if (N > 1) {
+            const lptr p1 = after(tile_ptr(1), anchor0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) n1[e] = p1[e];
+        }
+    }
+    double dev[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int cb = seq.cb[k], B = seq.rb[k];
+        if (k == 0 || seq.cb[k - 1] != cb) {  // first tile of a column block: its four dev
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = 4 * cb + u;
+                const double ti = fma(r, v[i], x[i]);
+                const double dv = ((ti <= sE[4 * i + 1]) & (ti >= sE[4 * i + 0])) ? ti - sE[4 * i + 2]
+                                                                              : INFINITY;
+                dev[u] = (i < d) ? dv : 0.0;
+            }
+        }
+        double* yy = y + 4 * (B - RB0);
+        yy[0] = fma(cur[0], dev[0], yy[0]);
+        if (k + 2 < N) {
+            const lptr p2 = after(tile_ptr(k + 2), yy[0]);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) n2[e] = p2[e];
+        }
+        yy[0] = fma(cur[4], dev[1], yy[0]);
+        yy[0] = fma(cur[8], dev[2], yy[0]);
+        yy[0] = fma(cur[12], dev[3], yy[0]);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            double acc = yy[q];
+            acc = fma(cur[0 * 4 + q], dev[0], acc);
+            acc = fma(cur[1 * 4 + q], dev[1], acc);
+            acc = fma(cur[2 * 4 + q], dev[2], acc);
+            acc = fma(cur[3 * 4 + q], dev[3], acc);
+            yy[q] = acc;
+        }
+        asm volatile("; tile end" : "+v"(yy[0]), "+v"(yy[1]), "+v"(yy[2]), "+v"(yy[3]));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            cur[e] = n1[e];
+            n1[e] = n2[e];
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
+__global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const lptr lsm = (lptr)__builtin_assume_aligned(
+        (const __attribute__((address_space(3))) double*)smem, 16);
     const StepArgs& a = b.s;
     const int d = b.d;
     const int tid = threadIdx.x, bs = blockDim.x;
@@ -160,12 +239,9 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
     const int wpg = a.group_size >> 6;
     const int part = __builtin_amdgcn_readfirstlane((tid >> 6) % wpg);
     const ConstLayout cl{d, 1};
-    // LDS: L^-1 columns [DP*DP] | elem {lo,hi,mu,0}[DP] | v ring [2][gpb][128] |
-    //      x ring [waves][2][XCH][64]: this wave's slice of x, XCH dimensions at a time
-    double* sL = smem;
-    double* sE = sL + DP * DP;
-    double* sVr = sE + 4 * DP;
-    double* sXr = sVr + 2 * gpb * 128 + (tid >> 6) * (2 * XCH * 64);
+    double* sL = smem;           // L^-1 tiles [DP*DP]
+    double* sE = sL + DP * DP;   // {lo, hi, mu, 0}[DP]
+    double* sVr = sE + 4 * DP;   // direction ring [2][gpb][128]
     for (int i = tid; i < DP * DP; i += bs) sL[i] = b.Lcol[i];
     for (int i = tid; i < DP; i += bs) {
         const bool in = i < d;
@@ -177,7 +253,6 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
     const int ldv = v_ld(d);
     const double* const Vgrp = a.V + (size_t)group * a.ncyc * v_slab_big(d);
     auto stage_col = [&](int cycle, int column, int slot) {
-        // 1 KiB (>= ldv * 8 bytes) of the column, moved by the first wave of the group
         if (part == 0) {
             const char* g = (const char*)(Vgrp + (size_t)cycle * v_slab_big(d) + (size_t)column * ldv) +
                             (tid & 63) * 16;
@@ -186,25 +261,13 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
         }
     };
-    // x[i][w0 .. w0+63] is 512 contiguous bytes per dimension: one 1 KiB DMA piece carries two
-    // dimensions (lanes 0-31 the first, 32-63 the second) straight into the ring layout
-    const double* const xwave = a.x + (size_t)(w & ~63);
-    auto stage_x = [&](int chunk, int buf) {
-        const int lane = tid & 63;
-        for (int p2 = 0; p2 < XCH / 2; ++p2) {
-            int dim = chunk * XCH + 2 * p2 + (lane >> 5);
-            if (dim >= d) dim = d - 1;  // tail: harmless duplicate read
-            const char* g = (const char*)(xwave + (size_t)dim * W) + (lane & 31) * 16;
-            char* l = (char*)(sXr + buf * (XCH * 64) + 2 * p2 * 64);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-        }
-    };
     unsigned long long step = a.step0;
     int col = (int)(step % (unsigned long long)d);
     int cyc = 0;
     stage_col(0, col, 0);
-    stage_x(0, 0);
+    double x[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) x[i] = (i < d) ? a.x[(size_t)i * W + w] : 0.0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int slot = 0;
@@ -214,10 +277,8 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
     long long nacc = a.n_accept[w];
     const long long nacc0 = nacc;
     const uint32_t gid = a.walker0 + (uint32_t)w;
-    double* const xg = a.x + w;
 
     for (int s = 0; s < a.n_steps; ++s) {
-        // next step's direction: DMA into the other ring slot while this step computes
         {
             int ncol = col + 1, ncyc = cyc;
             if (ncol == d) { ncol = 0; ++ncyc; }
@@ -228,38 +289,27 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
         rng.run_all();
         const double r = rng.r, Ea = rng.Ea;
         const double* __restrict__ v = sVr + (slot * gpb + gib) * 128;
-
-        double y[DP];
-#pragma unroll
-        for (int j = 0; j < DP; ++j) y[j] = 0.0;
-        // x streams through the wave's LDS ring, one chunk of XCH dimensions ahead
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0 (issued below / at entry)
-        for (int c = 0; c * XCH < d; ++c) {
-            if ((c + 1) * XCH < d) stage_x(c + 1, (c + 1) & 1);
-            const double* __restrict__ xs = sXr + (c & 1) * (XCH * 64) + (tid & 63);
-            const int i0 = c * XCH;
-#pragma unroll
-            for (int q4 = 0; q4 < XCH / 4; ++q4) {
-                const int ib = i0 + 4 * q4;  // first of four columns
-                if (ib < d) {
-                    double dev[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = ib + u;
-                        const double ti = fma(r, v[i], xs[(4 * q4 + u) * 64]);
-                        const double dv = ((ti <= sE[4 * i + 1]) & (ti >= sE[4 * i + 0]))
-                                              ? ti - sE[4 * i + 2] : INFINITY;
-                        dev[u] = (i < d) ? dv : 0.0;  // padded columns carry zero operands
-                    }
-                    const int cb = ib >> 2;
-                    column_block_update<DP>(y, sL + (size_t)cb * NB * 16, dev, cb);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c + 1 has landed
-        }
+        const lptr lv = lsm + (DP * DP + 4 * DP) + (slot * gpb + gib) * 128;
+        const lptr lE = lsm + DP * DP;
         double chi2 = 0.0;
+        {
+            constexpr int H = (NB + 1) / 2;
+            double y[4 * H];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) chi2 = fma(y[j], y[j], chi2);
+            for (int j = 0; j < 4 * H; ++j) y[j] = 0.0;
+            sweep_pass<0, H>(y, x, r, lv, lE, lsm, d);
+#pragma unroll
+            for (int j = 0; j < 4 * H; ++j) chi2 = fma(y[j], y[j], chi2);
+        }
+        {
+            constexpr int H = (NB + 1) / 2;
+            double y[4 * (NB - H)];
+#pragma unroll
+            for (int j = 0; j < 4 * (NB - H); ++j) y[j] = 0.0;
+            sweep_pass<H, NB>(y, x, r, lv, lE, lsm, d);
+#pragma unroll
+            for (int j = 0; j < 4 * (NB - H); ++j) chi2 = fma(y[j], y[j], chi2);
+        }
         const bool inb = chi2 < INFINITY;
         const double lp = a.uniform_logp + 0.0;
         const double ll = -0.5 * (a.cnorm0 + chi2);
@@ -267,18 +317,9 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
         const bool accept = inb & (lt != -INFINITY) &
                             ((lt > lpost) | (Ea > (lpost - lt) / a.temperature));
         burn -= (accept & (burn > 0)) ? 1 : 0;
-        // commit: second pass through the ring; only accepting lanes store
-        stage_x(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int c = 0; c * XCH < d; ++c) {
-            if ((c + 1) * XCH < d) stage_x(c + 1, (c + 1) & 1);
-            const double* __restrict__ xs = sXr + (c & 1) * (XCH * 64) + (tid & 63);
-            const int i0 = c * XCH, i1 = (i0 + XCH < d) ? i0 + XCH : d;
-            if (accept)
-                for (int i = i0; i < i1; ++i) xg[(size_t)i * W] = fma(r, v[i], xs[(i - i0) * 64]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (s + 1 < a.n_steps) stage_x(0, 0);  // first chunk of the next step (after the stores)
+        const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly
+#pragma unroll
+        for (int i = 0; i < DP; ++i) x[i] = fma(ra, v[i], x[i]);
         lpri = accept ? lp : lpri;
         llik = accept ? ll : llik;
         lpost = accept ? lt : lpost;
@@ -291,10 +332,13 @@ __global__ void __launch_bounds__(256) step_big_kernel(const BigStepArgs b)
         }
         ++step;
         if (++col == d) { col = 0; ++cyc; }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA landed, own x stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next direction has landed
         __syncthreads();
         slot ^= 1;
     }
+#pragma unroll
+    for (int i = 0; i < DP; ++i)
+        if (i < d) a.x[(size_t)i * W + w] = x[i];
     a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
     a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
     a.n_accept[w] = nacc;
@@ -410,14 +454,13 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, hipStream_t
 {
     BigStepArgs b{a, Lcol, d};
     const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
-    const size_t lds = sizeof(double) * (size_t)(DP * DP + 4 * DP + 2 * (bs / a.group_size) * 128 +
-                                                 (bs / 64) * 2 * XCH * 64);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)step_big_kernel,
+    const size_t lds = sizeof(double) * (size_t)(DP * DP + 4 * DP + 2 * (bs / a.group_size) * 128);
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)step_big_reg_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(step_big_kernel, dim3(a.W / bs), dim3(bs), lds, st, b);
+    hipLaunchKernelGGL(step_big_reg_kernel, dim3(a.W / bs), dim3(bs), lds, st, b);
     return hipGetLastError();
 }
 
