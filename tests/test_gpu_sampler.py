@@ -276,3 +276,33 @@ def test_resume_continues_bit_identically(tmp_path):
         MCMCHip({"seed": 21, "n_walkers": 256, "group_size": 64}, ProblemSpec.from_info(QUICK),
                 output=str(tmp_path / "b"), resume=True)
     b2.close()
+
+
+def test_temperature_2_samples_the_tempered_posterior():
+    """tests/test_mcmc.py:22-82 runs the reference at temperature 1 and 2; at T the chain
+    samples p^(1/T) (mcmc.py:127-130, 438-440, 682): for a Gaussian target the covariance is
+    T times larger, and the stored minuslogpost is -logpost/T (collection.py:530-532)."""
+    tm = np.array([-0.48591462, 0.10064559, 0.64406749])
+    tc = np.array([[0.00078333, 0.00033134, -0.0002923],
+                   [0.00033134, 0.00218118, -0.00170728],
+                   [-0.0002923, -0.00170728, 0.00676922]])
+    names = ["a__0", "a__1", "a__2"]
+    info = {"likelihood": {"gaussian_mixture": {"means": [tm], "covs": [tc],
+                                                "input_params_prefix": "a_"}},
+            "params": {n: {"prior": {"min": -2, "max": 2},
+                           "ref": {"dist": "norm", "loc": float(tm[i]), "scale": 0.05}}
+                       for i, n in enumerate(names)},
+            "sampler": {"mcmc_hip": {"seed": 2, "temperature": 2, "n_walkers": 4096,
+                                     "group_size": 64, "steps_per_launch": "10d",
+                                     "covmat": tc, "covmat_params": names, "Rminus1_stop": 0.0,
+                                     "max_samples": 4e6, "snapshot_every": 60}}}
+    updated, sampler = run(info)
+    np.testing.assert_allclose(sampler.proposer.get_covariance(), 2 * tc, rtol=0.3, atol=1e-5)
+    coll = sampler.products()["sample"]
+    n0 = len(coll) // 3
+    m, c = coll.mean(first=n0), coll.cov(first=n0)
+    assert kl_norm(tm, 2 * tc, m, c) < 0.01
+    row = coll.data.iloc[-1]
+    logpost = -(row["minuslogprior"] + 0.5 * row["chi2"])
+    assert row["minuslogpost"] == pytest.approx(-logpost / 2.0, rel=1e-12)
+    sampler.close()
