@@ -569,42 +569,48 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 }
 
 // ---------------------------------------------------------------- Haar basis kernel
-// One 64-lane workgroup per (group, cycle): Box-Muller normals on the basis Philox stream,
-// Householder construction of functions.py:45-61 with lane i owning row i of H in VGPRs,
-// then V[c][i] = sum_{k<=i} T[i][k] R[k][c] (proposal.py:222-224, 256-260).
-__global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a)
+// Two (group, cycle) problems per 64-lane workgroup, one per half-wave (D <= 32 rows each):
+// Box-Muller normals on the basis Philox stream, Householder construction of
+// functions.py:45-61 with lane l owning row l of H in VGPRs, then
+// V[c][i] = sum_{k<=i} T[i][k] R[k][c] (proposal.py:222-224, 256-260).
+__global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_problems)
 {
     constexpr int NZ = (D + 2) * (D - 1) / 2;
     constexpr int LDH = D | 1;  // odd leading dimension: conflict-free column reads
-    __shared__ double sz[NZ + 2];
-    __shared__ double sx[D + 1];
-    __shared__ double sR[D * LDH];
+    __shared__ double sz[2][NZ + 2];
+    __shared__ double sx[2][D + 1];
+    __shared__ double sR[2][D * LDH];
     __shared__ double sT[D * D];
-    const int lane = threadIdx.x;
-    const uint32_t group = a.group0 + blockIdx.x;
-    const uint32_t cycle = a.cycle0 + blockIdx.y;
-    double* __restrict__ Vout = a.V + ((size_t)blockIdx.x * a.ncyc + blockIdx.y) * v_slab(D);
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+    const int prob = 2 * blockIdx.x + half;          // (group, cycle) pair of this half-wave
+    const bool valid = prob < n_problems;
+    const int pg = valid ? prob / a.ncyc : 0, pc = valid ? prob % a.ncyc : 0;
+    const uint32_t group = a.group0 + (uint32_t)pg;
+    const uint32_t cycle = a.cycle0 + (uint32_t)pc;
+    double* __restrict__ Vout = a.V + ((size_t)pg * a.ncyc + pc) * v_slab(D);
 
     for (int i = lane; i < D * D; i += 64) sT[i] = a.T[i];
     if (D == 1) {
-        if (lane == 0) Vout[0] = a.T[0];
+        if (valid && l == 0) Vout[0] = a.T[0];
         return;
     }
-    for (int j = lane; 2 * j < NZ; j += 64) {
+    for (int j = l; 2 * j < NZ; j += 32) {
         const u32x4 w4 = philox4x32_10(a.key0, a.key1, group, kStreamBasis, cycle, (uint32_t)j);
         const uint64_t ka = ((uint64_t)w4.w0 << 20) | (w4.w1 >> 12);
         const uint64_t kb = ((uint64_t)w4.w2 << 20) | (w4.w3 >> 12);
         const double rad = sqrt(-2.0 * dlog(u52(ka)));
         double sn, cs;
         sincos2pi(kb, sn, cs);
-        sz[2 * j] = rad * cs;
-        sz[2 * j + 1] = rad * sn;  // sz has room for the unused odd tail
+        sz[half][2 * j] = rad * cs;
+        sz[half][2 * j + 1] = rad * sn;  // sz has room for the unused odd tail
     }
     __syncthreads();
 
+    const double* __restrict__ z = sz[half];
+    double* __restrict__ xs = sx[half];
     double H[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) H[k] = (k == lane) ? 1.0 : 0.0;
+    for (int k = 0; k < D; ++k) H[k] = (k == l) ? 1.0 : 0.0;
     double dprod = 1.0, Dmine = 1.0;
     int ix = 0;
 #pragma unroll
@@ -612,42 +618,42 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a)
         const int m = D - n;
         double norm2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
-        const double x0 = sz[ix];
+        for (int k = 0; k < m; ++k) norm2 = fma(z[ix + k], z[ix + k], norm2);
+        const double x0 = z[ix];
         const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
         dprod *= Dn;
-        if (lane == n) Dmine = Dn;
+        if (l == n) Dmine = Dn;
         const double x0n = x0 + Dn * sqrt(norm2);
         double tt = norm2 - x0 * x0;
         tt = tt + x0n * x0n;
         const double den = sqrt(0.5 * tt);
         __syncthreads();
-        if (lane < m) sx[lane] = ((lane == 0) ? x0n : sz[ix + lane]) / den;
+        if (l < m) xs[l] = ((l == 0) ? x0n : z[ix + l]) / den;
         __syncthreads();
         double tmp = 0.0;
 #pragma unroll
-        for (int k = 0; k < m; ++k) tmp = fma(H[n + k], sx[k], tmp);
+        for (int k = 0; k < m; ++k) tmp = fma(H[n + k], xs[k], tmp);
 #pragma unroll
-        for (int k = 0; k < m; ++k) H[n + k] = fma(-tmp, sx[k], H[n + k]);
+        for (int k = 0; k < m; ++k) H[n + k] = fma(-tmp, xs[k], H[n + k]);
         ix += m;
     }
-    if (lane == D - 1) Dmine = (((D - 1) & 1) ? -1.0 : 1.0) * dprod;
-    if (lane < D) {
+    if (l == D - 1) Dmine = (((D - 1) & 1) ? -1.0 : 1.0) * dprod;
+    if (l < D) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) sR[lane * LDH + k] = Dmine * H[k];
+        for (int k = 0; k < D; ++k) sR[half][l * LDH + k] = Dmine * H[k];
     }
     __syncthreads();
-    if (lane < D) {
-        // lane = column c of R; V[c][i] for i ascending
+    if (valid && l < D) {
+        // l = column c of R; V[c][i] for i ascending
         double Rc[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) Rc[k] = sR[k * LDH + lane];
+        for (int k = 0; k < D; ++k) Rc[k] = sR[half][k * LDH + l];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k <= i; ++k) s = fma(sT[i * D + k], Rc[k], s);
-            Vout[lane * D + i] = s;
+            Vout[l * D + i] = s;
         }
     }
 }
@@ -764,7 +770,8 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
 
 hipError_t launch_basis(const BasisArgs& a, int n_groups, hipStream_t st)
 {
-    hipLaunchKernelGGL(basis_kernel, dim3(n_groups, a.ncyc), dim3(64), 0, st, a);
+    const int n_problems = n_groups * a.ncyc;
+    hipLaunchKernelGGL(basis_kernel, dim3((n_problems + 1) / 2), dim3(64), 0, st, a, n_problems);
     return hipGetLastError();
 }
 

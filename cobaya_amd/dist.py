@@ -38,6 +38,8 @@ def local_rank() -> int:
 def default_device() -> int:
     """HIP ordinal for this process: LOCAL_RANK, wrapped onto the visible devices (ranks may
     share a GPU in tests)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "LOCAL_RANK" not in os.environ:
+        return 0  # single process: no need to import torch at all
     try:
         import torch
         n = torch.cuda.device_count()
