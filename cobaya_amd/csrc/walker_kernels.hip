@@ -75,6 +75,7 @@ __device__ __forceinline__ void after2(cptr& p, cptr& q, double& anchor)
 // The proposal directions of the current cycle live in LDS (staged by DMA one cycle ahead):
 // wave-uniform LDS addresses, read as broadcasts.
 typedef const double __attribute__((address_space(3))) * lptr;
+typedef double __attribute__((address_space(3))) * lds_t;
 __device__ __forceinline__ lptr after(lptr p, double& anchor)
 {
     unsigned v = (unsigned)(unsigned long long)p;
@@ -133,12 +134,11 @@ __device__ __forceinline__ void bounds_stream(const double (&t)[D], cptr lo, cpt
         in = in & (anchor <= ch_[0]) & (anchor >= cl_[0]);
         if (c + 1 < NC) {
             anchor = t[b + 8];
-            cptr lo2 = lo + b + 8, hi2 = hi + b + 8;
-            after2(lo2, hi2, anchor);
+            after2(lo, hi, anchor);  // the (unchanged) bases; offsets stay immediates
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                nl_[k] = (b + 8 + k < D) ? lo2[k] : 0.0;
-                nh_[k] = (b + 8 + k < D) ? hi2[k] : 0.0;
+                nl_[k] = (b + 8 + k < D) ? lo[b + 8 + k] : 0.0;
+                nh_[k] = (b + 8 + k < D) ? hi[b + 8 + k] : 0.0;
             }
         }
 #pragma unroll
@@ -165,9 +165,9 @@ __device__ __forceinline__ void dev_stream(double (&dev)[D], const double (&t)[D
         const int b = c * 16;
         dev[b] = t[b] - cur[0];
         if (c + 1 < NC) {
-            const cptr m2 = after(mu + b + 16, dev[b]);
+            mu = after(mu, dev[b]);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? m2[k] : 0.0;
+            for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? mu[b + 16 + k] : 0.0;
         }
 #pragma unroll
         for (int k = 1; k < 16; ++k)
@@ -184,12 +184,16 @@ __device__ __forceinline__ void dev_stream(double (&dev)[D], const double (&t)[D
 // (its producer precedes the first chunk's loads).  TAIL: while the LAST chunk is being
 // consumed, the first 16 doubles at `tail_ptr` are fetched into `tail` (the next phase's
 // first chunk).
-template <bool DERIVED, bool TAIL, bool PRELOADED, bool RNG, typename TP>
+// [S0, S1) is the part of the operand stream this call consumes (whole row blocks; the paired
+// kernel splits the rows between two waves); SUMSQ = false only delivers the y_j (`derived`).
+template <bool DERIVED, bool TAIL, bool PRELOADED, bool RNG, typename TP, int S0 = 0, int S1 = NT,
+          bool SUMSQ = true>
 __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, double& anchor,
                                              double* derived, TP tail_ptr, double (&tail)[16],
                                              const double (&first)[CH], StepRng& rng)
 {
     constexpr int RB = kRowBlock;
+    constexpr int NCH = (S1 - S0 + CH - 1) / CH;
     double chi2 = 0.0;
     double y[RB];
 #pragma unroll
@@ -199,13 +203,13 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = first[k];
     } else {
-        const cptr L0 = after(Lk, anchor);
+        Lk = after(Lk, anchor);
 #pragma unroll
-        for (int k = 0; k < CH; ++k) cur[k] = (k < NT) ? L0[k] : 0.0;
+        for (int k = 0; k < CH; ++k) cur[k] = (S0 + k < S1) ? Lk[S0 + k] : 0.0;
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int base = c * CH;
+        const int base = S0 + c * CH;
         auto op = [&](int k) {
             const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
             y[r] = fma(cur[k], dev[i], (i == 0) ? 0.0 : y[r]);
@@ -215,15 +219,15 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
             const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
             if (i == j) {
                 if (DERIVED) derived[j] = y[r];
-                chi2 = fma(y[r], y[r], chi2);
+                if (SUMSQ) chi2 = fma(y[r], y[r], chi2);
             }
         };
         // first operand of the chunk: the only wait; then the next chunk's loads go out
         const int r0 = op(0);
         if (c + 1 < NCH) {
-            const cptr L2 = after(Lk + base + CH, y[r0]);
+            Lk = after(Lk, y[r0]);
 #pragma unroll
-            for (int q = 0; q < CH; ++q) nxt[q] = (base + CH + q < NT) ? L2[q] : 0.0;
+            for (int q = 0; q < CH; ++q) nxt[q] = (base + CH + q < S1) ? Lk[base + CH + q] : 0.0;
         }
         if (TAIL && c + 1 == NCH) {
             const TP T2 = after(tail_ptr, y[r0]);
@@ -238,7 +242,7 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
         fin(0);
 #pragma unroll
         for (int k = 1; k < CH; ++k)
-            if (base + k < NT) {
+            if (base + k < S1) {
                 op(k);
                 fin(k);
             }
@@ -286,17 +290,16 @@ __device__ __forceinline__ void propose_fused(double (&dev)[D], double r, lptr v
         const int b = 4 * c;
         double t0 = fma(r, cv[0], x[b]);
         if (c + 1 < NC) {
-            lptr v2 = v + b + 4;
-            cptr e2 = E + 3 * (b + 4);
-            after2(v2, e2, t0);
+            after2(v, E, t0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nv[k] = (b + 4 + k < D) ? v2[k] : 0.0;
+            for (int k = 0; k < 4; ++k) nv[k] = (b + 4 + k < D) ? v[b + 4 + k] : 0.0;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) ne[k] = (3 * (b + 4) + k < 3 * D) ? e2[k] : 0.0;
+            for (int k = 0; k < 12; ++k)
+                ne[k] = (3 * (b + 4) + k < 3 * D) ? E[3 * (b + 4) + k] : 0.0;
         } else {  // last chunk: fetch the first chunk of the whitening stream behind it
-            const cptr L0 = after(Lk, t0);
+            Lk = after(Lk, t0);
 #pragma unroll
-            for (int k = 0; k < CH; ++k) lfirst[k] = (k < NT) ? L0[k] : 0.0;
+            for (int k = 0; k < CH; ++k) lfirst[k] = (k < NT) ? Lk[k] : 0.0;
         }
         dev[b] = ((t0 <= ce[1]) & (t0 >= ce[0])) ? t0 - ce[2] : INFINITY;
 #pragma unroll
@@ -363,11 +366,11 @@ __device__ __forceinline__ double wrap_periodic(double t, double lo, double hi)
 
 // out[i] = fma(r, v[i], x[i]) with v streamed 16 dimensions per chunk (out may alias x);
 // PRELOADED: the first chunk is already in `first` (fetched by the previous phase).
-template <bool PRELOADED>
+template <bool PRELOADED, int N = D>
 __device__ __forceinline__ void axpy_stream(double (&out)[D], double r, lptr v,
                                             const double (&x)[D], const double (&first)[16])
 {
-    constexpr int NC = (D + 15) / 16;
+    constexpr int NC = (N + 15) / 16;
     double cur[16], nxt[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) cur[k] = PRELOADED ? first[k] : ((k < D) ? v[k] : 0.0);
@@ -376,13 +379,13 @@ __device__ __forceinline__ void axpy_stream(double (&out)[D], double r, lptr v,
         const int b = c * 16;
         out[b] = fma(r, cur[0], x[b]);
         if (c + 1 < NC) {
-            const lptr v2 = after(v + b + 16, out[b]);
+            v = after(v, out[b]);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < D) ? v2[k] : 0.0;
+            for (int k = 0; k < 16; ++k) nxt[k] = (b + 16 + k < N) ? v[b + 16 + k] : 0.0;
         }
 #pragma unroll
         for (int k = 1; k < 16; ++k)
-            if (b + k < D) out[b + k] = fma(r, cur[k], x[b + k]);
+            if (b + k < N) out[b + k] = fma(r, cur[k], x[b + k]);
 #pragma unroll
         for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
     }
@@ -568,6 +571,310 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     if (ka->rows) ka->n_rows[w] = nrow;
 }
 
+// ---------------------------------------------------------------- the paired Metropolis kernel
+// The hot variant again, but with TWO waves per 64 walkers so that a SIMD always holds two
+// waves (at W = 65 536 the one-wave-per-walker-set kernel leaves every SIMD with a single wave
+// and nothing hides its scalar-load and LDS latencies).  The rows of the whitening factor are
+// split at kSplit (a whole number of row blocks):
+//   role 0: trial + support test of dimensions [0, kSplit), rows [0, kSplit) of y = L^-1 dev,
+//           the partial chi2 of those rows, the walker's random variates and bookkeeping;
+//   role 1: trial of all dimensions (support test only for [kSplit, D)), rows [kSplit, D).
+// Once per step the two waves meet at a workgroup barrier and exchange, through LDS, role 0's
+// partial chi2 and the next step's variates against role 1's y_j; both then finish
+// chi2 = fma(y_j, y_j, chi2) for j = kSplit .. D-1 -- the SAME ascending chain as the one-wave
+// kernel and the oracle, so the result is bit-identical -- take the same accept decision and
+// commit their own copy of the state.
+constexpr bool kPair = D >= 8;
+// Measured at d = 30 (W = 65 536): splits 16 / 20 / 24 run 3.47 / 3.32 / 3.46 ms per 1200 steps,
+// 12 runs 4.1 ms -- role 0 (which also generates the variates) takes about two thirds of the rows.
+constexpr int pair_split()
+{
+    const int h = kRowBlock * ((2 * D + 6) / 12);  // multiple of the row block nearest 2D/3
+    return h < kRowBlock ? kRowBlock : (h >= D ? D - 1 - (D - 1) % kRowBlock : h);
+}
+#ifdef MCMC_SPLIT   // developer experiments
+constexpr int kSplit = MCMC_SPLIT;
+#else
+constexpr int kSplit = kPair ? pair_split() : D;
+#endif
+constexpr int kNTA = kSplit * (kSplit + 1) / 2;   // operands of rows [0, kSplit)
+constexpr int kDB = D - kSplit;
+constexpr int kXF = kDB + 3;                       // exchanged doubles per walker and step
+
+// `ok` collects the support test as a wave mask on the scalar ALU (one bit per walker):
+// v_cmp writes an SGPR pair, s_and folds it in -- no per-dimension VALU select.
+__device__ __forceinline__ void support_and(unsigned long long& ok, double t, double lo, double hi)
+{
+    ok &= __builtin_amdgcn_ballot_w64(t <= hi) & __builtin_amdgcn_ballot_w64(t >= lo);
+    asm volatile("; support" : "+s"(ok));  // keeps the AND a chain (a tree would hold 2D masks)
+}
+// a if this lane's bit of `mask` is set, else b
+__device__ __forceinline__ double select_by_mask(unsigned long long mask, double a, double b)
+{
+    const unsigned long long ab = (unsigned long long)__double_as_longlong(a);
+    const unsigned long long bb = (unsigned long long)__double_as_longlong(b);
+    unsigned lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"((unsigned)bb), "v"((unsigned)ab), "s"(mask));
+    asm("v_cndmask_b32 %0, %1, %2, %3"
+        : "=v"(hi) : "v"((unsigned)(bb >> 32)), "v"((unsigned)(ab >> 32)), "s"(mask));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int ROLE>
+__device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v, cptr E, cptr MU,
+                                             const double (&x)[D], cptr Lk, double (&lfirst)[CH],
+                                             unsigned long long& ok)
+{
+    constexpr int N = ROLE == 0 ? kSplit : D;
+    constexpr int C0 = ROLE == 0 ? 0 : kSplit / 4;  // first chunk with the support test
+    constexpr int NC = (N + 3) / 4;
+    constexpr int S0 = ROLE == 0 ? 0 : kNTA, S1 = ROLE == 0 ? kNTA : NT;
+    double cv[4], ce[12], nv[4], ne[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cv[k] = (k < N) ? v[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        ce[k] = (C0 == 0) ? ((k < 3 * D) ? E[k] : 0.0) : ((k < 4) ? MU[k] : 0.0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int b = 4 * c;
+        const bool test = c >= C0;
+        double t0 = fma(r, cv[0], x[b]);
+        if (c + 1 < NC) {
+            const bool test2 = c + 1 >= C0;
+            if (test2) after2(v, E, t0);
+            else after2(v, MU, t0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nv[k] = (b + 4 + k < N) ? v[b + 4 + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                ne[k] = test2 ? ((3 * (b + 4) + k < 3 * D) ? E[3 * (b + 4) + k] : 0.0)
+                              : ((k < 4 && b + 4 + k < D) ? MU[b + 4 + k] : 0.0);
+        } else {  // last chunk: fetch the first chunk of this role's whitening stream behind it
+            Lk = after(Lk, t0);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) lfirst[k] = (S0 + k < S1) ? Lk[S0 + k] : 0.0;
+        }
+        if (test) {
+            support_and(ok, t0, ce[0], ce[1]);
+            dev[b] = t0 - ce[2];
+        } else {
+            dev[b] = t0 - ce[0];
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (b + k < N) {
+                const double tk = fma(r, cv[k], x[b + k]);
+                if (test) {
+                    support_and(ok, tk, ce[3 * k], ce[3 * k + 1]);
+                    dev[b + k] = tk - ce[3 * k + 2];
+                } else {
+                    dev[b + k] = tk - ce[k];
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cv[k] = nv[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ce[k] = ne[k];
+    }
+}
+
+// all waves of the workgroup have issued their exchange stores; LDS only (the global->LDS DMA
+// of the next cycle's slab stays in flight across this barrier)
+__device__ __forceinline__ void exchange_barrier()
+{
+#if defined(MCMC_EXP) && (MCMC_EXP & 1)   // timing experiment: no barrier (results are wrong)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+template <int ROLE>
+__device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
+{
+    constexpr int SLAB = v_slab(D);
+    constexpr int NX = ROLE == 0 ? kSplit : D;      // dimensions of the state this role holds
+    const ConstLayout cl{D, 1};
+    const cptr C0 = as_const(a.cblock);
+    const int tid = threadIdx.x;
+    const int wl = tid & 255;                        // walker within the block
+    const int w = blockIdx.x * 256 + wl;
+    const int W = a.W;
+    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
+    const int gpb = 256 / a.group_size;
+    const int gib = __builtin_amdgcn_readfirstlane(wl / a.group_size);
+    const int wpg = a.group_size >> 6;
+    const int part = __builtin_amdgcn_readfirstlane((wl >> 6) % wpg) + wpg * ROLE;
+    // LDS (32-bit addresses throughout): two slabs of proposal directions per group of the
+    // block (current cycle and the next), then the exchange area [parity][kXF][256]
+    const int slab2 = gpb * SLAB;
+    const lds_t sX = smem + 2 * slab2;
+    const double* const Vgrp = a.V + (size_t)group * a.ncyc * SLAB;
+    auto stage_dma = [&](int cycle, lds_t dst) {
+        for (int kb = part; kb < SLAB / 128; kb += 2 * wpg) {
+            const char* g = (const char*)(Vgrp + (size_t)cycle * SLAB) + kb * 1024 + (tid & 63) * 16;
+            const lds_t l = dst + gib * SLAB + kb * 128;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)g,
+                (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    stage_dma(0, smem);
+    if (a.ncyc > 1) stage_dma(1, smem + slab2);
+
+    double x[D];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = a.x[(size_t)i * W + w];
+    double lpost = a.logpost[w];
+    double llik = 0.0, lpri = 0.0;
+    int wt = 0, prej = 0, burn = 0;
+    long long nacc = 0;
+    if (ROLE == 0) {
+        llik = a.loglike[w];
+        lpri = a.logprior[w];
+        wt = a.weight[w]; prej = a.prior_rej[w]; burn = a.burn_left[w];
+        nacc = a.n_accept[w];
+    }
+    const long long nacc0 = nacc;
+    const uint32_t gid = a.walker0 + (uint32_t)w;
+    unsigned long long step = a.step0;
+    int col = (int)(step % (unsigned long long)D);
+    int cyc = 0, cur_buf = 0;
+    StepRng rng;
+    double r = 0.0, Ea = 0.0;
+    if (ROLE == 0) {  // the first step's variates, handed to role 1 through the parity-1 slot
+        rng.begin(a.key0, a.key1, gid, step);
+        rng.run_all();
+        sX[(kXF + 1) * 256 + wl] = rng.r;
+        sX[(kXF + 2) * 256 + wl] = rng.Ea;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ROLE == 1) {
+        r = sX[(kXF + 1) * 256 + wl];
+        Ea = sX[(kXF + 2) * 256 + wl];
+    }
+
+    typedef const StepArgs __attribute__((address_space(4))) * kaptr;
+    const int n_steps = a.n_steps, ncyc = a.ncyc;
+    for (int s = 0; s < n_steps; ++s) {
+        // The scalars of the step (keys, temperature, norm, ...) are re-read from the kernarg
+        // segment every step, behind an asm the loads cannot be hoisted over: as loop
+        // invariants they would be spilled to VGPR lanes and cost a v_readlane per use.
+        unsigned long long kas = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("; step scalars" : "+s"(kas));
+        const kaptr ks = (kaptr)kas;
+        const lds_t X = sX + (s & 1) * (kXF * 256) + wl;
+        if (ROLE == 0) {  // computed during the previous step's whitening stream
+            r = rng.r;
+            Ea = rng.Ea;
+            rng.begin(ks->key0, ks->key1, gid, step + 1);
+        }
+        const lptr v = (lptr)(smem + cur_buf * slab2 + gib * SLAB + col * D);
+        const cptr C = launder(C0);
+        double dev[D], lfirst[CH], vhead[16], yb[D];
+        unsigned long long ok = ~0ull;  // walkers whose trial is inside the prior support
+        propose_pair<ROLE>(dev, r, v, C + cl.elem(), C + cl.mean(0), x, C + cl.linv(0), lfirst, ok);
+        double chi2, r_next = 0.0, Ea_next = 0.0;
+        if (ROLE == 0) {
+            chi2 = tri_stream<false, true, true, true, lptr, 0, kNTA, true>(
+                dev, C + cl.linv(0), dev[kSplit - 1], nullptr, v, vhead, lfirst, rng);
+            chi2 = select_by_mask(ok, chi2, INFINITY);  // outside: chi2 is not finite
+            X[0] = chi2;
+            X[256] = rng.r;
+            X[512] = rng.Ea;
+            exchange_barrier();
+#pragma unroll
+            for (int q = 0; q < kDB; ++q) yb[kSplit + q] = X[(3 + q) * 256];
+        } else {
+            StepRng none;
+            tri_stream<true, true, true, false, lptr, kNTA, NT, false>(
+                dev, C + cl.linv(0), dev[D - 1], yb, v, vhead, lfirst, none);
+            yb[D - 1] = select_by_mask(ok, yb[D - 1], INFINITY);
+#pragma unroll
+            for (int q = 0; q < kDB; ++q) X[(3 + q) * 256] = yb[kSplit + q];
+            exchange_barrier();
+            chi2 = X[0];
+            r_next = X[256];
+            Ea_next = X[512];
+        }
+#if !(defined(MCMC_EXP) && (MCMC_EXP & 2))
+#pragma unroll
+        for (int q = 0; q < kDB; ++q) chi2 = fma(yb[kSplit + q], yb[kSplit + q], chi2);
+#endif
+        const bool inb = chi2 < INFINITY;  // false for +inf and NaN: outside the prior support
+        const double lp = ks->uniform_logp + 0.0;
+        const double ll = -0.5 * (ks->cnorm0 + chi2);
+        const double lt = inb ? lp + ll : -INFINITY;
+        // ---- Metropolis test (mcmc.py:678-683), identical in both roles
+        const bool accept = inb & (lt != -INFINITY) &
+#if defined(MCMC_EXP) && (MCMC_EXP & 4)
+                            ((lt > lpost) | (Ea > (lpost - lt) * ks->temperature));
+#else
+                            ((lt > lpost) | (Ea > (lpost - lt) / ks->temperature));
+#endif
+        const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly (v finite)
+        axpy_stream<true, NX>(x, ra, v, x, vhead);
+        lpost = accept ? lt : lpost;
+        if (ROLE == 0) {  // bookkeeping (mcmc.py:685-748)
+            burn -= (accept & (burn > 0)) ? 1 : 0;
+            llik = accept ? ll : llik;
+            lpri = accept ? lp : lpri;
+            prej = accept ? 0 : (prej + (inb ? 0 : 1));
+            wt = accept ? 1 : wt + 1;
+            nacc += accept ? 1 : 0;
+            if (!accept) {
+                const double max_now = ks->max_tries * (burn > 0 ? 10.0 : 1.0);
+                if ((double)(wt - prej) > max_now) atomicCAS(ks->stuck, 0, 1 + (int)gid);
+            }
+        } else {
+            r = r_next;
+            Ea = Ea_next;
+        }
+        ++step;
+        if (++col == D) {  // next cycle: its slab was DMA'd during this one
+            col = 0;
+            ++cyc;
+            if (s + 1 < n_steps) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (cyc + 1 < ncyc) stage_dma(cyc + 1, smem + cur_buf * slab2);
+                cur_buf ^= 1;
+            }
+        }
+    }
+
+    typedef const StepArgs __attribute__((address_space(4))) * kaptr;
+    unsigned long long kav = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; epilogue" : "+s"(kav));
+    const kaptr ka = (kaptr)kav;
+    double* const ox = ka->x;
+    if (ROLE == 0) {
+#pragma unroll
+        for (int i = 0; i < kSplit; ++i) ox[(size_t)i * W + w] = x[i];
+        ka->logpost[w] = lpost;
+        ka->logprior[w] = lpri;
+        ka->loglike[w] = llik;
+        ka->weight[w] = wt; ka->prior_rej[w] = prej; ka->burn_left[w] = burn;
+        ka->n_accept[w] = nacc;
+        wave_add_accepts(ka->accept_total, nacc - nacc0);
+    } else {
+#pragma unroll
+        for (int i = kSplit; i < D; ++i) ox[(size_t)i * W + w] = x[i];
+    }
+}
+
+__global__ void __launch_bounds__(512) step_pair_kernel(const StepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if constexpr (kPair) {
+        const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+        if (role == 0) pair_steps<0>(a, (lds_t)smem);
+        else pair_steps<1>(a, (lds_t)smem);
+    }
+}
+
 // ---------------------------------------------------------------- Haar basis kernel
 // Two (group, cycle) problems per 64-lane workgroup, one per half-wave (D <= 32 rows each):
 // Box-Muller normals on the basis Philox stream, Householder construction of
@@ -750,6 +1057,20 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
     }
     const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
                          a.rows != nullptr || D == 1;
+    if (kPair && !multi && !general && a.W % 256 == 0 && 256 % a.group_size == 0) {
+        // two waves per 64 walkers: 512-thread workgroups of 256 walkers
+        size_t plds = sizeof(double) * (size_t)(2 * (256 / a.group_size) * v_slab(D) + 2 * kXF * 256);
+        const int nwg = a.W / 256;
+        const int per_cu = (nwg + 255) / 256;      // same even-placement request as below
+        size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;
+        if (per_cu == 1) want = 96 * 1024;         // > half of the LDS: one workgroup per CU
+        if (want > plds) plds = want;
+        hipError_t e = hipFuncSetAttribute((const void*)step_pair_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(step_pair_kernel, dim3(nwg), dim3(512), plds, st, a);
+        return hipGetLastError();
+    }
     const void* fn = multi ? (general ? (const void*)step_kernel<true, true>
                                       : (const void*)step_kernel<true, false>)
                            : (general ? (const void*)step_kernel<false, true>

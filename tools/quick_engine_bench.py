@@ -3,6 +3,8 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cobaya_amd import engine as E
+if os.environ.get("MCMC_HIP_LIB"):  # experiment builds (tools/exp_variants.sh)
+    E.load_library(os.environ["MCMC_HIP_LIB"])
 
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
