@@ -195,8 +195,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "kernel": ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
-                else ("mcmc::step_big_kernel (d=%d)" % d),
+                "kernel": (("mcmc::step_pair_kernel<true> (d=%d)" % d)
+                           if 8 <= d <= 32 and a.walkers % 256 == 0
+                           else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
+                           else ("mcmc::step_big_reg_kernel (d=%d)" % d)),
                 "kernel_ms_per_launch": step_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": ("achieved = algorithmic bytes (16d+24 B per evaluation, state "

@@ -655,8 +655,9 @@ __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v,
 #pragma unroll
             for (int k = 0; k < CH; ++k) lfirst[k] = (S0 + k < S1) ? Lk[S0 + k] : 0.0;
         }
+        unsigned long long m = ~0ull;  // this chunk's tests: folded into `ok` once per chunk
         if (test) {
-            support_and(ok, t0, ce[0], ce[1]);
+            m &= __builtin_amdgcn_ballot_w64(t0 <= ce[1]) & __builtin_amdgcn_ballot_w64(t0 >= ce[0]);
             dev[b] = t0 - ce[2];
         } else {
             dev[b] = t0 - ce[0];
@@ -666,12 +667,17 @@ __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v,
             if (b + k < N) {
                 const double tk = fma(r, cv[k], x[b + k]);
                 if (test) {
-                    support_and(ok, tk, ce[3 * k], ce[3 * k + 1]);
+                    m &= __builtin_amdgcn_ballot_w64(tk <= ce[3 * k + 1]) &
+                         __builtin_amdgcn_ballot_w64(tk >= ce[3 * k]);
                     dev[b + k] = tk - ce[3 * k + 2];
                 } else {
                     dev[b + k] = tk - ce[k];
                 }
             }
+        if (test) {
+            ok &= m;
+            asm volatile("; support" : "+s"(ok));  // a chain over the chunks, not a tree
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) cv[k] = nv[k];
 #pragma unroll
@@ -690,7 +696,8 @@ __device__ __forceinline__ void exchange_barrier()
 #endif
 }
 
-template <int ROLE>
+// UNIT_T: temperature == 1 (x / 1.0 == x exactly, so the division is dropped)
+template <int ROLE, bool UNIT_T>
 __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
 {
     constexpr int SLAB = v_slab(D);
@@ -701,27 +708,36 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
     const int wl = tid & 255;                        // walker within the block
     const int w = blockIdx.x * 256 + wl;
     const int W = a.W;
-    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
-    const int gpb = 256 / a.group_size;
-    const int gib = __builtin_amdgcn_readfirstlane(wl / a.group_size);
-    const int wpg = a.group_size >> 6;
-    const int part = __builtin_amdgcn_readfirstlane((wl >> 6) % wpg) + wpg * ROLE;
+    typedef const StepArgs __attribute__((address_space(4))) * kaptr;
     // LDS (32-bit addresses throughout): two slabs of proposal directions per group of the
-    // block (current cycle and the next), then the exchange area [parity][kXF][256]
-    const int slab2 = gpb * SLAB;
+    // block (current cycle and the next), then the exchange area [parity][kXF][256].
+    // group_size is 64, 128 or 256: divisions are shifts.
+    const int lg = __builtin_ctz((unsigned)a.group_size);
+    const int slab2 = (256 >> lg) * SLAB;                                  // one buffer
+    const int vbase = __builtin_amdgcn_readfirstlane(wl >> lg) * SLAB;     // this group's slab
     const lds_t sX = smem + 2 * slab2;
-    const double* const Vgrp = a.V + (size_t)group * a.ncyc * SLAB;
-    auto stage_dma = [&](int cycle, lds_t dst) {
+    // The slab DMA runs once per cycle: everything it needs is recomputed from the kernarg
+    // segment there, so that nothing of it stays live (in SGPRs) across the step loop.
+    auto stage_dma = [&](kaptr k, int cycle, int buf) {
+        const int lgs = __builtin_ctz((unsigned)k->group_size);
+        const int wpg = 1 << (lgs - 6);
+        const int part = __builtin_amdgcn_readfirstlane((wl >> 6) & (wpg - 1)) + wpg * ROLE;
+        const int group = __builtin_amdgcn_readfirstlane(w >> lgs);
+        const double* const src = k->V + ((size_t)group * k->ncyc + cycle) * SLAB;
+        const lds_t dst = smem + buf * ((256 >> lgs) * SLAB) +
+                          __builtin_amdgcn_readfirstlane(wl >> lgs) * SLAB;
         for (int kb = part; kb < SLAB / 128; kb += 2 * wpg) {
-            const char* g = (const char*)(Vgrp + (size_t)cycle * SLAB) + kb * 1024 + (tid & 63) * 16;
-            const lds_t l = dst + gib * SLAB + kb * 128;
+            const char* g = (const char*)src + kb * 1024 + (tid & 63) * 16;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)g,
-                (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(dst + kb * 128), 16, 0, 0);
         }
     };
-    stage_dma(0, smem);
-    if (a.ncyc > 1) stage_dma(1, smem + slab2);
+    {
+        const kaptr k0 = (kaptr)(unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        stage_dma(k0, 0, 0);
+        if (a.ncyc > 1) stage_dma(k0, 1, 1);
+    }
 
     double x[D];
 #pragma unroll
@@ -738,13 +754,12 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
     }
     const long long nacc0 = nacc;
     const uint32_t gid = a.walker0 + (uint32_t)w;
-    unsigned long long step = a.step0;
-    int col = (int)(step % (unsigned long long)D);
-    int cyc = 0, cur_buf = 0;
+    int col = (int)(a.step0 % (unsigned long long)D);
+    int cyc = 0;
     StepRng rng;
     double r = 0.0, Ea = 0.0;
     if (ROLE == 0) {  // the first step's variates, handed to role 1 through the parity-1 slot
-        rng.begin(a.key0, a.key1, gid, step);
+        rng.begin(a.key0, a.key1, gid, a.step0);
         rng.run_all();
         sX[(kXF + 1) * 256 + wl] = rng.r;
         sX[(kXF + 2) * 256 + wl] = rng.Ea;
@@ -756,8 +771,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
         Ea = sX[(kXF + 2) * 256 + wl];
     }
 
-    typedef const StepArgs __attribute__((address_space(4))) * kaptr;
-    const int n_steps = a.n_steps, ncyc = a.ncyc;
+    const int n_steps = a.n_steps;
     for (int s = 0; s < n_steps; ++s) {
         // The scalars of the step (keys, temperature, norm, ...) are re-read from the kernarg
         // segment every step, behind an asm the loads cannot be hoisted over: as loop
@@ -769,9 +783,9 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
         if (ROLE == 0) {  // computed during the previous step's whitening stream
             r = rng.r;
             Ea = rng.Ea;
-            rng.begin(ks->key0, ks->key1, gid, step + 1);
+            rng.begin(ks->key0, ks->key1, gid, ks->step0 + (unsigned)(s + 1));
         }
-        const lptr v = (lptr)(smem + cur_buf * slab2 + gib * SLAB + col * D);
+        const lptr v = (lptr)(smem + (cyc & 1) * slab2 + vbase + col * D);
         const cptr C = launder(C0);
         double dev[D], lfirst[CH], vhead[16], yb[D];
         unsigned long long ok = ~0ull;  // walkers whose trial is inside the prior support
@@ -809,11 +823,8 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
         const double lt = inb ? lp + ll : -INFINITY;
         // ---- Metropolis test (mcmc.py:678-683), identical in both roles
         const bool accept = inb & (lt != -INFINITY) &
-#if defined(MCMC_EXP) && (MCMC_EXP & 4)
-                            ((lt > lpost) | (Ea > (lpost - lt) * ks->temperature));
-#else
-                            ((lt > lpost) | (Ea > (lpost - lt) / ks->temperature));
-#endif
+                            ((lt > lpost) |
+                             (Ea > (UNIT_T ? lpost - lt : (lpost - lt) / ks->temperature)));
         const double ra = accept ? r : 0.0;  // fma(0, v, x) == x exactly (v finite)
         axpy_stream<true, NX>(x, ra, v, x, vhead);
         lpost = accept ? lt : lpost;
@@ -832,15 +843,14 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
             r = r_next;
             Ea = Ea_next;
         }
-        ++step;
         if (++col == D) {  // next cycle: its slab was DMA'd during this one
             col = 0;
             ++cyc;
             if (s + 1 < n_steps) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (cyc + 1 < ncyc) stage_dma(cyc + 1, smem + cur_buf * slab2);
-                cur_buf ^= 1;
+                // the buffer of the cycle just finished receives the cycle after the next
+                if (cyc + 1 < ks->ncyc) stage_dma(ks, cyc + 1, (cyc + 1) & 1);
             }
         }
     }
@@ -865,13 +875,14 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
     }
 }
 
+template <bool UNIT_T>
 __global__ void __launch_bounds__(512) step_pair_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if constexpr (kPair) {
         const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-        if (role == 0) pair_steps<0>(a, (lds_t)smem);
-        else pair_steps<1>(a, (lds_t)smem);
+        if (role == 0) pair_steps<0, UNIT_T>(a, (lds_t)smem);
+        else pair_steps<1, UNIT_T>(a, (lds_t)smem);
     }
 }
 
@@ -1065,10 +1076,13 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
         size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;
         if (per_cu == 1) want = 96 * 1024;         // > half of the LDS: one workgroup per CU
         if (want > plds) plds = want;
-        hipError_t e = hipFuncSetAttribute((const void*)step_pair_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        const bool unit_t = a.temperature == 1.0;
+        hipError_t e = hipFuncSetAttribute(
+            unit_t ? (const void*)step_pair_kernel<true> : (const void*)step_pair_kernel<false>,
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(step_pair_kernel, dim3(nwg), dim3(512), plds, st, a);
+        if (unit_t) hipLaunchKernelGGL(step_pair_kernel<true>, dim3(nwg), dim3(512), plds, st, a);
+        else hipLaunchKernelGGL(step_pair_kernel<false>, dim3(nwg), dim3(512), plds, st, a);
         return hipGetLastError();
     }
     const void* fn = multi ? (general ? (const void*)step_kernel<true, true>

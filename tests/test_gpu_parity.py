@@ -182,6 +182,16 @@ def test_emitted_rows_and_burn_in_bit_exact():
     assert rows[:, 1].min() >= 1
 
 
+def test_paired_kernel_with_temperature_bit_exact():
+    """Hot variant, two waves per walker set, T != 1 (the division by T stays in)."""
+    eng, prob, st = make_pair(30, 512, 128, T=2.5)
+    for n in (7, 40, 33):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+
+
 def test_walker_offset_shards_reproduce_the_whole():
     """Multi-GPU sharding: walkers [256, 512) run as a shard with
     walker_offset=256 are bit-identical to the same walkers inside a 512-walker ensemble."""
