@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/final (written by tools/gpu_final.sh on the GPU box) into the committed
+evidence under profiles/: r01_bench.json, r01_gpu_tests.log, r01_kernel_stats.txt,
+r01_pmc.txt and traffic.json (the per-launch HBM bytes bench.py copies into roofline.traffic).
+
+    python tools/collect_evidence.py [round-prefix, default r01]
+"""
+import json
+import os
+import shutil
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+DST = os.path.join(ROOT, "profiles")
+CMD = "python bench.py --no-cpu-baseline --steps 20 --warmup 4"
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{rnd}_bench.json"))
+    shutil.copy(os.path.join(SRC, "gpu_tests.log"), os.path.join(DST, f"{rnd}_gpu_tests.log"))
+    with open(os.path.join(SRC, "bench.json")) as f:
+        bench = json.loads(f.read().strip().splitlines()[-1])
+    dom = bench["roofline"]["kernel"].split("(")[0].strip().split("::")[-1].split("<")[0]
+
+    c = sqlite3.connect(os.path.join(SRC, "trace", "t_results.db"))
+    rows = c.execute("select name, count(*), sum(end - start) / 1e3, avg(end - start) / 1e3 "
+                     "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(os.path.join(DST, f"{rnd}_kernel_stats.txt"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- {CMD}   (MI355X)\n")
+        f.write("# name, calls, total_us, avg_us, pct\n")
+        for n, k, t, a in rows:
+            f.write(f"{n}, {k}, {t:.3f}, {a:.3f}, {100 * t / tot:.3f}\n")
+
+    vals = {}
+    lines = []
+    for p in ("pmc_fetch", "pmc_lds", "pmc_sq", "pmc_write"):
+        db = os.path.join(SRC, p, "p_results.db")
+        if not os.path.exists(db):
+            continue
+        c = sqlite3.connect(db)
+        for n, v, k, dur in c.execute(
+                "select counter_name, avg(value), count(*), avg(duration) from counters_collection "
+                "where kernel_name like ? group by counter_name", (f"%{dom}%",)):
+            lines.append(f"{p}, {n}, {v:.6g}, {k}, {dur:.0f}")
+            vals[n] = v
+    wl = bench["config"]
+    with open(os.path.join(DST, f"{rnd}_pmc.txt"), "w") as f:
+        f.write(f"# rocprofv3 --pmc <counters> (one pass per line group) -- {CMD}\n")
+        f.write(f"# per-dispatch averages for {bench['roofline']['kernel']}, "
+                f"{wl['walkers_per_gpu']} walkers, {wl['metropolis_steps_per_launch']} steps "
+                "per launch\n# pass, counter, avg value, dispatches, avg dispatch ns\n")
+        f.write("\n".join(lines) + "\n")
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        traffic = {
+            "d": wl["d"], "walkers": wl["walkers_per_gpu"],
+            "steps_per_launch": wl["metropolis_steps_per_launch"],
+            "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+            "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+            "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; KiB; "
+                    "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, "
+                    "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated"}
+        with open(os.path.join(DST, "traffic.json"), "w") as f:
+            json.dump(traffic, f, indent=1)
+    print(open(os.path.join(DST, f"{rnd}_kernel_stats.txt")).read())
+    print(open(os.path.join(DST, f"{rnd}_pmc.txt")).read())
+
+
+if __name__ == "__main__":
+    main()
