@@ -43,7 +43,14 @@ class _Problem(C.Structure):
         ("scale", c_double_p), ("mls", c_double_p), ("periodic", c_int32_p),
         ("uniform_logp", C.c_double),
         ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
-        ("weight", c_double_p), ("T", c_double_p),
+        ("weight", c_double_p), ("T", c_double_p), ("blocking", C.c_void_p),
+    ]
+
+
+class _Blocking(C.Structure):
+    _fields_ = [
+        ("n_blocks", C.c_int32), ("size", c_int32_p), ("oversample", c_int32_p),
+        ("i_of_j", c_int32_p), ("drag_last_slow", C.c_int32), ("drag_steps", C.c_int32),
     ]
 
 
@@ -80,11 +87,25 @@ def lib():
         L.orc_step_injected.restype = C.c_int
         L.orc_step_injected.argtypes = [C.POINTER(_Problem), C.POINTER(_State), c_double_p,
                                         C.c_double]
+        L.orc_step_injected_delta.restype = C.c_int
+        L.orc_step_injected_delta.argtypes = [C.POINTER(_Problem), C.POINTER(_State),
+                                              c_double_p, C.c_double]
+        L.orc_drag_injected.restype = C.c_int
+        L.orc_drag_injected.argtypes = [C.POINTER(_Problem), C.POINTER(_State), c_double_p,
+                                        c_double_p, c_double_p]
         L.orc_run.restype = C.c_int64
         L.orc_run.argtypes = [C.POINTER(_Problem), C.POINTER(_State), C.c_int, C.c_uint32,
                               C.c_uint64, C.c_int, C.c_int]
         L.orc_moments.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
                                   c_double_p, c_double_p]
+        L.orc_block_slots.restype = C.c_int
+        L.orc_block_slots.argtypes = [C.POINTER(_Problem), C.c_int, c_int32_p]
+        L.orc_block_schedule.restype = C.c_int
+        L.orc_block_schedule.argtypes = [C.POINTER(_Problem), C.c_uint32, C.c_uint32, C.c_int,
+                                         c_int32_p, c_int32_p, c_int32_p]
+        L.orc_basis_blocked.restype = C.c_int
+        L.orc_basis_blocked.argtypes = [C.POINTER(_Problem), C.c_uint32, C.c_uint32, C.c_int,
+                                        c_double_p, c_int32_p]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -134,14 +155,38 @@ def proposal_transform(cov, scale):
     return scale * (np.diag(std) @ np.linalg.cholesky(corr))
 
 
+def blocked_transform(cov, blocks, scale):
+    """T (sorted order) of BlockedProposer.set_covariance (proposal.py:250-260): the
+    covariance is reordered by i_of_j before std / corr / Cholesky."""
+    i_of_j = [i for b in blocks for i in b]
+    cov = np.asarray(cov, dtype=np.float64)
+    return proposal_transform(cov[np.ix_(i_of_j, i_of_j)], scale)
+
+
 class Problem:
     """Owns the arrays behind an `orc_problem`.  All derived constants may be passed in
     (e.g. the ones the HIP engine reports) so that oracle and engine see one problem."""
 
     def __init__(self, d, kinds, a, b, periodic=None, means=None, covs=None, weights=None,
                  normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
-                 max_tries=None, derived=None):
+                 max_tries=None, derived=None, blocks=None, oversampling=None,
+                 drag_last_slow=-1, drag_steps=0):
         self.d = d
+        # blocked proposal: `blocks` = lists of sampler indices, slow -> fast; T must then be
+        # the transform of the covariance in sorted order (blocked_transform below)
+        self.blocking = None
+        if blocks is not None:
+            self.block_size = np.array([len(b) for b in blocks], dtype=np.int32)
+            self.oversample = np.array(oversampling if oversampling is not None
+                                       else [1] * len(blocks), dtype=np.int32)
+            self.i_of_j = np.array([i for b in blocks for i in b], dtype=np.int32)
+            assert sorted(self.i_of_j.tolist()) == list(range(d))
+            bl = _Blocking()
+            bl.n_blocks = len(blocks)
+            bl.size, bl.oversample, bl.i_of_j = (_ip(self.block_size), _ip(self.oversample),
+                                                 _ip(self.i_of_j))
+            bl.drag_last_slow, bl.drag_steps = drag_last_slow, drag_steps
+            self.blocking = bl
         kinds = np.asarray(kinds, dtype=np.int32)
         a = np.asarray(a, dtype=np.float64)
         b = np.asarray(b, dtype=np.float64)
@@ -203,6 +248,8 @@ class Problem:
         p.uniform_logp = self.uniform_logp
         p.mean, p.Linv, p.cnorm = _dp(self.mean), _dp(self.Linv), _dp(self.cnorm)
         p.weight, p.T = _dp(self.weight), _dp(self.T)
+        p.blocking = (C.cast(C.pointer(self.blocking), C.c_void_p) if self.blocking is not None
+                      else None)
         self.c = p
 
     def set_T(self, T):
@@ -222,6 +269,23 @@ class Problem:
         V = np.empty((self.d, self.d))
         lib().orc_basis(C.byref(self.c), group, cycle, _dp(V))
         return V  # V[c] = direction of column c
+
+    def cycle_length(self, which=0):
+        return lib().orc_block_slots(C.byref(self.c), which, None)
+
+    def schedule(self, group, cycle, which=0):
+        L = self.cycle_length(which)
+        blk, bas, col = (np.zeros(max(L, 1), np.int32) for _ in range(3))
+        lib().orc_block_schedule(C.byref(self.c), group, cycle, which, _ip(blk), _ip(bas),
+                                 _ip(col))
+        return blk[:L], bas[:L], col[:L]
+
+    def basis_blocked(self, group, cycle, which=0):
+        L = self.cycle_length(which)
+        V = np.zeros((max(L, 1), self.d))
+        flag = np.zeros(max(L, 1), np.int32)
+        lib().orc_basis_blocked(C.byref(self.c), group, cycle, which, _dp(V), _ip(flag))
+        return V[:L], flag[:L]
 
 
 class State:
@@ -265,6 +329,18 @@ class State:
         vec = np.ascontiguousarray(vec, dtype=np.float64)
         return lib().orc_step_injected(C.byref(self.p.c), C.byref(self.c), _dp(vec),
                                        float(exp_draw))
+
+    def step_injected_delta(self, delta, exp_draw):
+        delta = np.ascontiguousarray(delta, dtype=np.float64)
+        return lib().orc_step_injected_delta(C.byref(self.p.c), C.byref(self.c), _dp(delta),
+                                             float(exp_draw))
+
+    def drag_injected(self, slow, fast, e):
+        slow = np.ascontiguousarray(slow, dtype=np.float64)
+        fast = np.ascontiguousarray(fast, dtype=np.float64)
+        e = np.ascontiguousarray(e, dtype=np.float64)
+        return lib().orc_drag_injected(C.byref(self.p.c), C.byref(self.c), _dp(slow),
+                                       _dp(fast), _dp(e))
 
     def drain(self):
         """rows as (walker, weight, logpost, logprior, loglike, x...) like the engine."""

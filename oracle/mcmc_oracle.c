@@ -55,7 +55,7 @@ void orc_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
     philox4x32_10(k0, k1, c0, c1, c2, c3, out);
 }
 
-enum { STREAM_STEP = 0, STREAM_BASIS = 1 };
+enum { STREAM_STEP = 0, STREAM_BASIS = 1, STREAM_PERM = 2 };
 #define BRANCH_EXP_24 5536481u /* floor(0.33 * 2^24): proposal.py:79 */
 
 /* u = (2k+1) 2^-53, k < 2^52: an odd multiple of 2^-53 in (0,1), exact in binary64 */
@@ -177,9 +177,24 @@ typedef struct {
      * mode, upper part ignored); cnorm[k] = d log 2pi + log|S_k| (0 if unnormalised);
      * weight[k] */
     const double* mean; const double* Linv; const double* cnorm; const double* weight;
-    /* proposal transform T = scale * diag(std) * chol(corr), row-major lower-tri d*d */
+    /* proposal transform T = scale * diag(std) * chol(corr), row-major lower-tri d*d; with
+     * blocks it is built from the covariance in SORTED order (j-indexed, proposal.py:252) */
     const double* T;
+    const struct orc_blocking* blocking; /* NULL: one block holding every parameter */
 } orc_problem;
+
+/* Blocked proposal (proposal.py:96-224): blocks sorted slow -> fast; parameter j of the
+ * sorted order is sampler parameter i_of_j[j]; block b covers n_b consecutive j from
+ * j_start(b).  drag_last_slow >= 0 selects the dragging step (mcmc.py:564-668) with the
+ * blocks up to that index slow and drag_steps interpolation steps. */
+typedef struct orc_blocking {
+    int32_t n_blocks;
+    const int32_t* size;
+    const int32_t* oversample;
+    const int32_t* i_of_j;
+    int32_t drag_last_slow;
+    int32_t drag_steps;
+} orc_blocking;
 
 /* ------------------------------------------------------------------ Haar basis (a3) */
 /* Householder construction of functions.py:45-61 with a fixed operation order.
@@ -252,6 +267,121 @@ void orc_basis(const orc_problem* p, uint32_t group, uint32_t cycle, double* V)
             V[c * d + i] = s;
         }
     free(z); free(H);
+}
+
+/* ------------------------------------------------------------------ blocked schedule */
+/* The three slot sequences of the blocked proposer (proposal.py:187-196):
+ *   which 0: every block b listed oversample[b] * n_b times (block_cycler),
+ *   which 1: the slow blocks, one slot per parameter (block_cycler_slow),
+ *   which 2: the fast blocks, one slot per parameter (block_cycler_fast).
+ * Returns the cycle length L and the unshuffled slot list in blk[]. */
+int orc_block_slots(const orc_problem* p, int which, int32_t* blk)
+{
+    const orc_blocking* B = p->blocking;
+    if (!B) { if (blk) for (int i = 0; i < p->d; ++i) blk[i] = 0; return p->d; }
+    int L = 0;
+    for (int b = 0; b < B->n_blocks; ++b) {
+        int reps;
+        if (which == 0) reps = B->oversample[b] * B->size[b];
+        else if (which == 1) reps = (b <= B->drag_last_slow) ? B->size[b] : 0;
+        else reps = (b > B->drag_last_slow) ? B->size[b] : 0;
+        for (int r = 0; r < reps; ++r) { if (blk) blk[L] = b; ++L; }
+    }
+    return L;
+}
+
+/* Schedule of one (group, cycle): block, basis number and basis column of every slot.
+ * CyclicIndexRandomizer.next (proposal.py:46-55) reshuffles the slot list once per cycle
+ * when it is longer than 2; here a Fisher-Yates shuffle on the Philox stream
+ * (group, STREAM_PERM | which << 8, cycle, i), j = floor(u32 * (i + 1) / 2^32), i descending.
+ * The k-th use of block b in the cycle takes column k % n_b of its basis number k / n_b
+ * (RandDirectionProposer.propose_vec, proposal.py:66-69: a new basis every n_b uses). */
+int orc_block_schedule(const orc_problem* p, uint32_t group, uint32_t cycle, int which,
+                       int32_t* blk, int32_t* basis, int32_t* col)
+{
+    int L = orc_block_slots(p, which, blk);
+    uint32_t k0 = (uint32_t)p->seed, k1 = (uint32_t)(p->seed >> 32);
+    if (p->blocking && L > 2)
+        for (int i = L - 1; i >= 1; --i) {
+            uint32_t w[4];
+            philox4x32_10(k0, k1, group, STREAM_PERM | ((uint32_t)which << 8), cycle,
+                          (uint32_t)i, w);
+            int j = (int)(((uint64_t)w[0] * (uint64_t)(i + 1)) >> 32);
+            int32_t t = blk[i]; blk[i] = blk[j]; blk[j] = t;
+        }
+    int used[64];
+    for (int b = 0; b < 64; ++b) used[b] = 0;
+    for (int s = 0; s < L; ++s) {
+        int b = blk[s];
+        int n = p->blocking ? p->blocking->size[b] : p->d;
+        basis[s] = used[b] / n;
+        col[s] = used[b] % n;
+        ++used[b];
+    }
+    return L;
+}
+
+/* V[s*d + i] for the L slots of one (group, cycle) of sequence `which`:
+ * v_sorted[j] = sum_{k <= min(j - j_b, n_b - 1)} T[j][j_b + k] u[k] for j >= j_b (0 above),
+ * u = column `col` of the block's Haar basis number `basis` (u = 1 for a 1-d block,
+ * proposal.py:85-93), scattered to sampler order through i_of_j (proposal.py:222-224).
+ * The normals of basis q of block b come from the Philox stream
+ * (group, STREAM_BASIS | which << 4 | b << 8, cycle, q << 16 | pair). flag1d[s] = 1 when the
+ * slot's block has one parameter. */
+int orc_basis_blocked(const orc_problem* p, uint32_t group, uint32_t cycle, int which,
+                      double* V, int32_t* flag1d)
+{
+    const orc_blocking* B = p->blocking;
+    int d = p->d;
+    if (!B) { orc_basis(p, group, cycle, V); if (flag1d) for (int i = 0; i < d; ++i) flag1d[i] = (d == 1); return d; }
+    int32_t* blk = (int32_t*)malloc(sizeof(int32_t) * 3 * 4096);
+    int32_t* bas = blk + 4096; int32_t* col = bas + 4096;
+    int L = orc_block_schedule(p, group, cycle, which, blk, bas, col);
+    uint32_t k0 = (uint32_t)p->seed, k1 = (uint32_t)(p->seed >> 32);
+    double* H = (double*)malloc(sizeof(double) * (size_t)d * d);
+    double* z = (double*)malloc(sizeof(double) * (size_t)((d + 2) * (d - 1) / 2 + 2));
+    int jb = 0;
+    for (int b = 0; b < B->n_blocks; jb += B->size[b], ++b) {
+        int n = B->size[b];
+        int have = -1;
+        for (int s = 0; s < L; ++s) {
+            if (blk[s] != b) continue;
+            double* v = V + (size_t)s * d;
+            for (int i = 0; i < d; ++i) v[i] = 0.0;
+            if (flag1d) flag1d[s] = (n == 1);
+            if (n == 1) {
+                for (int j = jb; j < d; ++j) v[B->i_of_j[j]] = p->T[j * d + jb];
+                continue;
+            }
+            if (bas[s] != have) {
+                int nz = (n + 2) * (n - 1) / 2;
+                for (int j = 0; 2 * j < nz; ++j) {
+                    uint32_t w[4];
+                    philox4x32_10(k0, k1, group,
+                                  STREAM_BASIS | ((uint32_t)which << 4) | ((uint32_t)b << 8), cycle,
+                                  ((uint32_t)bas[s] << 16) | (uint32_t)j, w);
+                    uint64_t ka = ((uint64_t)w[0] << 20) | (w[1] >> 12);
+                    uint64_t kb = ((uint64_t)w[2] << 20) | (w[3] >> 12);
+                    double rad = sqrt(-2.0 * orc_dlog(u52(ka)));
+                    double sn, cs;
+                    orc_sincos2pi(kb, &sn, &cs);
+                    z[2 * j] = rad * cs;
+                    if (2 * j + 1 < nz) z[2 * j + 1] = rad * sn;
+                }
+                orc_haar_from_normals(n, z, H);
+                have = bas[s];
+            }
+            for (int j = jb; j < d; ++j) {
+                int kmax = j - jb < n - 1 ? j - jb : n - 1;
+                double acc = 0.0;
+                for (int k = 0; k <= kmax; ++k)
+                    acc = fma(p->T[j * d + jb + k], H[k * n + col[s]], acc);
+                v[B->i_of_j[j]] = acc;
+            }
+        }
+    }
+    free(z); free(H); free(blk);
+    return L;
 }
 
 /* ------------------------------------------------------------------ log-posterior (a6-a10) */
@@ -399,6 +529,98 @@ int orc_step_injected(const orc_problem* p, orc_state* st, const double* vec, do
 }
 
 /* ------------------------------------------------------------------ the ensemble driver */
+/* Random variates of (walker, step, sub): one Philox block on the counter
+ * (walker, STREAM_STEP | sub << 16, step).  r = radial part of the proposal (proposal.py:71-82:
+ * Exp(1) w.p. 0.33 else chi(min(n, 2))), Ea = Exp(1) variate of the accept test
+ * (mcmc.py:683).  oned: the block has one parameter (proposal.py:85-93): chi(1) = sqrt(2E)
+ * |cos| of a Box-Muller pair, random sign, and Ea from a second block (| 0x100).  sub = 0 is
+ * the step itself, 1..n the interpolation steps of a dragging step. */
+static inline void walker_variates(uint32_t k0, uint32_t k1, uint32_t gid, uint64_t step,
+                                   uint32_t sub, int oned, double* r_out, double* Ea_out)
+{
+    uint32_t wd[4];
+    uint32_t c1 = STREAM_STEP | (sub << 16);
+    philox4x32_10(k0, k1, gid, c1, (uint32_t)step, (uint32_t)(step >> 32), wd);
+    uint64_t kr = ((uint64_t)wd[1] << 20) | (wd[2] >> 12);
+    uint64_t ka = ((uint64_t)wd[3] << 20) | ((uint64_t)(wd[2] & 0xFFFu) << 8) | (wd[0] & 0xFFu);
+    double Er = -orc_dlog(u52(kr));
+    if (oned) {
+        double sn, cs;
+        orc_sincos2pi(ka, &sn, &cs);
+        double rr = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er) * fabs(cs);
+        *r_out = (wd[0] & 0x80u) ? rr : -rr;
+        uint32_t w2[4];
+        philox4x32_10(k0, k1, gid, c1 | 0x100u, (uint32_t)step, (uint32_t)(step >> 32), w2);
+        *Ea_out = -orc_dlog(u52(((uint64_t)w2[0] << 20) | (w2[1] >> 12)));
+    } else {
+        *r_out = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er);
+        *Ea_out = -orc_dlog(u52(ka));
+    }
+}
+
+/* mcmc.py:670-683 with the Exp(1) variate supplied */
+static inline int metropolis(double trial, double current, double T, double exp_draw)
+{
+    if (trial == -INFINITY) return 0;
+    if (trial > current) return 1;
+    return exp_draw > (current - trial) / T;
+}
+
+/* One dragging step of walker w (mcmc.py:564-668): vs = slow direction, vf[i] = the fast
+ * directions of the n interpolation steps, variates r[0..n], Ea[0..n] (index 0: the slow
+ * proposal and the final test). */
+static int drag_core(const orc_problem* p, orc_state* st, int w, const double* vs,
+                     const double* const* vf, const double* r, const double* Ea)
+{
+    int d = p->d, n = p->blocking->drag_steps;
+    double cs[128], ce[128], t[128];
+    const double* x = st->x + (size_t)w * d;
+    for (int i = 0; i < d; ++i) { cs[i] = x[i]; ce[i] = fma(r[0], vs[i], x[i]); }
+    if (p->has_periodic)
+        for (int i = 0; i < d; ++i)
+            if (p->periodic[i]) ce[i] = wrap_periodic(ce[i], p->lo[i], p->hi[i]);
+    double cs_lt = st->logpost[w];
+    double ce_lp, ce_ll;
+    int inb = eval_point(p, ce, &ce_lp, &ce_ll, NULL);
+    double ce_lt = inb ? ce_lp + ce_ll : -INFINITY;
+    if (ce_lt == -INFINITY) { st->weight[w] += 1; return 0; }   /* mcmc.py:590-592 */
+    double start_acc = cs_lt, end_acc = ce_lt;
+    for (int i = 1; i <= n; ++i) {
+        double delta[128];
+        for (int k = 0; k < d; ++k) delta[k] = r[i] * vf[i - 1][k];
+        if (p->has_periodic)   /* the reference wraps the DELTA (mcmc.py:606) */
+            for (int k = 0; k < d; ++k)
+                if (p->periodic[k]) delta[k] = wrap_periodic(delta[k], p->lo[k], p->hi[k]);
+        for (int k = 0; k < d; ++k) t[k] = cs[k] + delta[k];
+        double ps_lp, ps_ll;
+        int in_s = eval_point(p, t, &ps_lp, &ps_ll, NULL);
+        double ps_lt = in_s ? ps_lp + ps_ll : -INFINITY;
+        if (ps_lt != -INFINITY) {
+            double te[128];
+            for (int k = 0; k < d; ++k) te[k] = ce[k] + delta[k];
+            double pe_lp, pe_ll;
+            int in_e = eval_point(p, te, &pe_lp, &pe_ll, NULL);
+            double pe_lt = in_e ? pe_lp + pe_ll : -INFINITY;
+            if (pe_lt != -INFINITY) {
+                double frac = (double)i / (double)(1 + n);
+                double pi = (1.0 - frac) * ps_lt + frac * pe_lt;
+                double ci = (1.0 - frac) * cs_lt + frac * ce_lt;
+                if (metropolis(pi, ci, p->temperature, Ea[i])) {
+                    for (int k = 0; k < d; ++k) { cs[k] = t[k]; ce[k] = te[k]; }
+                    cs_lt = ps_lt;
+                    ce_lp = pe_lp; ce_ll = pe_ll; ce_lt = pe_lt;
+                }
+            }
+        }
+        start_acc += cs_lt;
+        end_acc += ce_lt;
+    }
+    double navg = (double)(1 + n);
+    int accept = metropolis(end_acc / navg, start_acc / navg, p->temperature, Ea[0]);
+    commit(p, st, w, ce, 1, ce_lp, ce_ll, ce_lt, accept);
+    return accept;
+}
+
 /* Advance walkers [0, W) (global ids walker0 + w, groups of p->group_size) by n_steps
  * steps starting at global step index step0.  Returns total accepts. */
 int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, uint64_t step0,
@@ -407,6 +629,11 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
     int d = p->d, gs = p->group_size;
     int G = W / gs;
     uint32_t k0 = (uint32_t)p->seed, k1 = (uint32_t)(p->seed >> 32);
+    const orc_blocking* B = p->blocking;
+    const int drag = B && B->drag_last_slow >= 0;
+    const int L0 = orc_block_slots(p, drag ? 1 : 0, NULL);    /* steps per cycle */
+    const int Lf = drag ? orc_block_slots(p, 2, NULL) : 0;
+    const int nd = drag ? B->drag_steps : 0;
     int64_t total = 0;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -414,49 +641,83 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
 #endif
     for (int g = 0; g < G; ++g) {
         uint32_t group = walker0 / (uint32_t)gs + (uint32_t)g;
-        double* V = (double*)malloc(sizeof(double) * (size_t)d * d);
-        uint64_t have_cycle = UINT64_MAX;
+        double* V = (double*)malloc(sizeof(double) * (size_t)L0 * d);
+        int32_t* f1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(L0 + Lf + 1));
+        double* Vf = drag ? (double*)malloc(sizeof(double) * (size_t)Lf * d * 2) : NULL;
+        int32_t* f1f = f1 + L0;
+        uint64_t have_cycle = UINT64_MAX, have_f[2] = {UINT64_MAX, UINT64_MAX};
         for (int s = 0; s < n_steps; ++s) {
             uint64_t step = step0 + (uint64_t)s;
-            uint64_t cycle = step / (uint64_t)d;
-            int col = (int)(step % (uint64_t)d);
-            if (cycle != have_cycle) { orc_basis(p, group, (uint32_t)cycle, V); have_cycle = cycle; }
+            uint64_t cycle = step / (uint64_t)L0;
+            int col = (int)(step % (uint64_t)L0);
+            if (cycle != have_cycle) {
+                orc_basis_blocked(p, group, (uint32_t)cycle, drag ? 1 : 0, V, f1);
+                have_cycle = cycle;
+            }
             const double* v = V + (size_t)col * d;
+            if (!drag) {
+                for (int l = 0; l < gs; ++l) {
+                    int w = g * gs + l;
+                    double r, Ea;
+                    walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, f1[col], &r, &Ea);
+                    total += step_core(p, st, w, v, r, Ea);
+                }
+                continue;
+            }
+            /* dragging: interpolation step i of slow step `step` is fast step step*nd + i-1 */
+            const double* vfp[256];
+            int oned[257];
+            oned[0] = f1[col];
+            for (int i = 1; i <= nd; ++i) {
+                uint64_t f = step * (uint64_t)nd + (uint64_t)(i - 1);
+                uint64_t cf = f / (uint64_t)Lf;
+                int slot = (int)(cf & 1);            /* two cycles of fast directions cached */
+                if (have_f[slot] != cf) {
+                    orc_basis_blocked(p, group, (uint32_t)cf, 2, Vf + (size_t)slot * Lf * d,
+                                      f1f);
+                    have_f[slot] = cf;
+                }
+                vfp[i - 1] = Vf + ((size_t)slot * Lf + (size_t)(f % (uint64_t)Lf)) * d;
+                oned[i] = 0;
+                {   /* 1-d flag of that slot: recomputed from the schedule */
+                    int32_t blk[4096], bas[4096], cl[4096];
+                    orc_block_schedule(p, group, (uint32_t)cf, 2, blk, bas, cl);
+                    oned[i] = B->size[blk[f % (uint64_t)Lf]] == 1;
+                }
+            }
             for (int l = 0; l < gs; ++l) {
                 int w = g * gs + l;
-                uint32_t wd[4];
-                philox4x32_10(k0, k1, walker0 + (uint32_t)w, STREAM_STEP, (uint32_t)step,
-                              (uint32_t)(step >> 32), wd);
-                uint64_t kr = ((uint64_t)wd[1] << 20) | (wd[2] >> 12);
-                uint64_t ka = ((uint64_t)wd[3] << 20) | ((uint64_t)(wd[2] & 0xFFFu) << 8) |
-                              (wd[0] & 0xFFu);
-                double Er = -orc_dlog(u52(kr));
-                double r;
-                if (d == 1) {
-                    /* RandProposer1D (proposal.py:85-93): |N(0,1)| radial part of the
-                     * mixture, random sign; chi(1) = sqrt(2 E) |cos| of a Box-Muller pair */
-                    double sn, cs;
-                    orc_sincos2pi(ka, &sn, &cs);
-                    double rr = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er) * fabs(cs);
-                    r = (wd[0] & 0x80u) ? rr : -rr;
-                } else {
-                    r = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er);
-                }
-                double Ea;
-                if (d == 1) {
-                    uint32_t w2[4];
-                    philox4x32_10(k0, k1, walker0 + (uint32_t)w, STREAM_STEP | 0x100u,
-                                  (uint32_t)step, (uint32_t)(step >> 32), w2);
-                    Ea = -orc_dlog(u52(((uint64_t)w2[0] << 20) | (w2[1] >> 12)));
-                } else {
-                    Ea = -orc_dlog(u52(ka));
-                }
-                total += step_core(p, st, w, v, r, Ea);
+                double r[257], Ea[257];
+                for (int i = 0; i <= nd; ++i)
+                    walker_variates(k0, k1, walker0 + (uint32_t)w, step, (uint32_t)i, oned[i],
+                                    &r[i], &Ea[i]);
+                total += drag_core(p, st, w, v, vfp, r, Ea);
             }
         }
-        free(V);
+        free(V); free(f1); free(Vf);
     }
     return total;
+}
+
+/* Tier-A links for the blocked proposer: walker 0 advances with increments and accept
+ * variates drawn by the reference (oracle/ref_numpy.py BlockedRefChain.draws): one Metropolis
+ * step with the increment `delta` (sampler order), or one dragging step with the slow
+ * increment, the n fast increments and the accept variates e[0] (final test), e[1..n]. */
+int orc_step_injected_delta(const orc_problem* p, orc_state* st, const double* delta,
+                            double exp_draw)
+{
+    return step_core(p, st, 0, delta, 1.0, exp_draw);
+}
+
+int orc_drag_injected(const orc_problem* p, orc_state* st, const double* slow,
+                      const double* fast, const double* e)
+{
+    int n = p->blocking->drag_steps, d = p->d;
+    const double* vf[256];
+    double r[257];
+    for (int i = 0; i <= n; ++i) r[i] = 1.0;
+    for (int i = 0; i < n; ++i) vf[i] = fast + (size_t)i * d;
+    return drag_core(p, st, 0, slow, vf, r, e);
 }
 
 /* ------------------------------------------------------------------ moments (a15) */

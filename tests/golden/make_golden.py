@@ -196,6 +196,7 @@ def run_chain(info, sampler_opts):
     opts = {"measure_speeds": False, "Rminus1_stop": 0.0, "Rminus1_cl_stop": 0.0}
     opts.update(sampler_opts)
     sampler = get_sampler({"mcmc": opts}, model)
+    sampled = list(model.parameterization.sampled_params())
     state0 = rng_state_json(sampler._rng)
     x0 = sampler.current_point.values.copy()
     lp0 = sampler.current_point.logpost
@@ -229,6 +230,15 @@ def run_chain(info, sampler_opts):
         "burn_in": np.array(sampler.burn_in.value),
         "temperature": np.array(float(sampler.temperature)),
         "proposal_scale": np.array(float(sampler.proposal_scale)),
+        # blocking (mcmc.py:320-410); lengths vary, hence flat arrays + sizes
+        "block_sizes": np.array([len(b) for b in sampler.blocks]),
+        "block_params": np.array([sampled.index(p) for b in sampler.blocks for p in b]),
+        "oversampling": np.array(sampler.oversampling_factors, dtype=int),
+        "drag": np.array(bool(sampler.drag)),
+        "drag_interp_steps": np.array(getattr(sampler, "drag_interp_steps", 0) or 0),
+        "drag_last_slow": np.array(sampler.i_last_slow_block if sampler.drag else -1),
+        "cycle_length": np.array(sampler.cycle_length),
+        "output_thin": np.array(sampler.current_point.output_thin),
     }
     return out
 
@@ -269,6 +279,42 @@ def g6_traces():
             out[f"{name}__{k}"] = v
         print(name, "rows", res["data"].shape, "steps", int(res["n_steps_raw"]))
     save("g6_traces", **out)
+
+
+def g10_blocked():
+    """(f)1: parameter blocks, oversampling, thinned output and dragging
+    (proposal.py:96-260, mcmc.py:320-410, 545-668)."""
+    info5 = info_random_gaussian_mixture(
+        ranges=[[0, 1]] * 5, n_modes=1, input_params_prefix="a_", O_std_min=0.02,
+        O_std_max=0.08, mpi_aware=False, random_state=np.random.default_rng(11),
+        add_ref=True)
+    n = list(info5["params"])
+    cases = {
+        "over_thin": {"seed": 21, "max_samples": 300, "learn_proposal": False,
+                      "blocking": [[1, n[:2]], [3, n[2:]]]},
+        "over_nothin": {"seed": 22, "max_samples": 400, "learn_proposal": True,
+                        "oversample_thin": False, "blocking": [[1, n[3:]], [2, n[:3]]]},
+        "blocks_1d": {"seed": 23, "max_samples": 300, "learn_proposal": False,
+                      "oversample_thin": False,
+                      "blocking": [[1, n[:3]], [2, n[3:4]], [4, n[4:]]]},
+        "drag": {"seed": 24, "max_samples": 250, "learn_proposal": False, "drag": True,
+                 "blocking": [[1, n[:2]], [4, n[2:]]]},
+        "drag_learn": {"seed": 25, "max_samples": 300, "learn_proposal": True, "drag": True,
+                       "burn_in": 5, "blocking": [[1, [n[4], n[0]]], [3, [n[1], n[3], n[2]]]]},
+    }
+    out = {}
+    gm = info5["likelihood"]["gaussian_mixture"]
+    out["means"] = np.atleast_2d(np.array(gm["means"], dtype=float))
+    covs = np.array(gm["covs"], dtype=float)
+    out["covs"] = covs if covs.ndim == 3 else covs[None]
+    for name, opts in cases.items():
+        res = run_chain(info5, opts)
+        for k, v in res.items():
+            out[f"{name}__{k}"] = v
+        print(name, "rows", res["data"].shape, "steps", int(res["n_steps_raw"]),
+              "blocks", res["block_sizes"], res["oversampling"], "drag",
+              int(res["drag_interp_steps"]), "thin", int(res["output_thin"]))
+    save("g10_blocked", **out)
 
 
 def g7_multichain():
@@ -376,3 +422,4 @@ if __name__ == "__main__":
     g6_traces()
     g7_multichain()
     g9_initial_covmat()
+    g10_blocked()

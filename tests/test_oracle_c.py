@@ -2,6 +2,7 @@
 known answers for the generator, libm for the fixed-order math, golden vectors G4/G5 for the
 log-posterior, and a step-by-step replay of reference chains with the reference's own random
 draws injected (through oracle/ref_numpy.py, itself pinned to golden G6)."""
+import json
 import math
 
 import numpy as np
@@ -155,6 +156,102 @@ def test_injected_replay_of_reference_chains(golden, name, learn):
                                rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(-2 * rows[:, 4], data[:, cols.index("chi2")], rtol=1e-11,
                                atol=1e-10)
+
+
+def _g10_chain(g, name, learn):
+    key = lambda k: g[f"{name}__{k}"]  # noqa: E731
+    rng = np.random.Generator(np.random.PCG64())
+    rng.bit_generator.state = json.loads(str(key("rng_state")))
+    prior = R.Prior(kinds=[0] * 5, a=[0.0] * 5, b=[1.0] * 5)
+    target = R.GaussianMixtureTarget(g["means"], g["covs"])
+    sizes, flat = key("block_sizes"), key("block_params").tolist()
+    blocks = [flat[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(len(sizes))]
+    chain = R.BlockedRefChain(
+        prior, target, key("cov0"), key("x0"), rng, blocks,
+        oversampling=key("oversampling").tolist(), drag_last_slow=int(key("drag_last_slow")),
+        drag_interp_steps=int(key("drag_interp_steps")), output_thin=1,
+        temperature=float(key("temperature")), proposal_scale=float(key("proposal_scale")),
+        burn_in=int(key("burn_in")), max_tries=float(key("max_tries")), learn_proposal=learn,
+        learn_every=int(key("learn_every")), learn_Rminus1_max=30.0, record_draws=True)
+    for _ in range(int(key("n_steps_raw"))):
+        chain.step()
+    return chain, blocks
+
+
+@pytest.mark.parametrize("name", ["over_nothin", "blocks_1d", "drag"])
+def test_injected_replay_of_blocked_and_dragging_chains(golden, name):
+    """Tier-A link of the C step and dragging cores ((f)1): fed the increments and accept
+    variates the reference drew (as restated by BlockedRefChain, itself pinned to golden
+    G10), orc_step_injected_delta / orc_drag_injected reproduce the reference chain:
+    identical weights, values to a few ulp."""
+    g = golden("g10_blocked")
+    key = lambda k: g[f"{name}__{k}"]  # noqa: E731
+    if name == "over_nothin":  # learning changes the proposal only: draws carry it already
+        chain, blocks = _g10_chain(g, name, True)
+    else:
+        chain, blocks = _g10_chain(g, name, False)
+    n_drag = int(key("drag_interp_steps"))
+    prob = O.Problem(5, [0] * 5, [0.0] * 5, [1.0] * 5, means=g["means"], covs=g["covs"],
+                     max_tries=float(key("max_tries")), blocks=blocks,
+                     oversampling=key("oversampling").tolist(),
+                     drag_last_slow=int(key("drag_last_slow")), drag_steps=n_drag)
+    st = O.State(prob, key("x0")[None, :], burn_in=int(key("burn_in")), row_cap=1000)
+    for rec in chain.draws:
+        if n_drag:
+            fast = np.zeros((n_drag, 5))
+            e = np.full(n_drag + 1, np.nan)
+            if rec["fast"]:
+                fast[:] = np.array(rec["fast"])
+                e[1:] = rec["e"]
+                e[0] = rec["e0"]
+            st.drag_injected(rec["slow"], fast, e)
+        else:
+            st.step_injected_delta(*rec)
+    rows = st.drain()
+    data = key("data")
+    cols = [str(c) for c in key("columns")]
+    assert len(rows) == len(data)
+    assert np.array_equal(rows[:, 1], data[:, cols.index("weight")])
+    np.testing.assert_allclose(rows[:, 5:], data[:, 2:7], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(-rows[:, 2], data[:, cols.index("minuslogpost")], rtol=1e-11,
+                               atol=1e-11)
+    np.testing.assert_allclose(st.x[0], key("final_x"), rtol=1e-12)
+    assert int(st.weight[0]) == int(key("final_weight"))
+
+
+def test_blocked_schedule_and_directions():
+    """Every block appears oversample * n_b times per cycle; the k-th use of a block takes
+    column k % n_b of its basis k / n_b; each basis is orthonormal, so the n_b directions of
+    one basis reproduce T_b T_b^T; directions only move the block and faster parameters."""
+    d = 7
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(d, d))
+    cov = A @ A.T / d + np.eye(d) * 0.1
+    blocks = [[5, 0], [3], [1, 6, 2, 4]]
+    over = [1, 2, 3]
+    T = O.blocked_transform(cov, blocks, 1.0)
+    prob = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, T=T, blocks=blocks, oversampling=over,
+                     seed=9)
+    L = prob.cycle_length()
+    assert L == 2 * 1 + 1 * 2 + 4 * 3
+    i_of_j = np.array([i for b in blocks for i in b])
+    for cycle in (0, 1, 5):
+        blk, bas, col = prob.schedule(3, cycle)
+        assert np.bincount(blk, minlength=3).tolist() == [2, 2, 12]
+        V, flag = prob.basis_blocked(3, cycle)
+        assert flag.tolist() == (blk == 1).astype(int).tolist()
+        for b, (jb, n) in enumerate([(0, 2), (2, 1), (3, 4)]):
+            for q in range(over[b]):
+                sel = [s for s in range(L) if blk[s] == b and bas[s] == q]
+                assert sorted(col[sel].tolist()) == list(range(n))
+                Vs = V[sel][:, i_of_j]            # sorted order
+                assert np.all(Vs[:, :jb] == 0.0)  # slower parameters untouched
+                Tb = T[:, jb:jb + n]
+                np.testing.assert_allclose(Vs.T @ Vs, Tb @ Tb.T, rtol=1e-11, atol=1e-14)
+    b0, _, _ = prob.schedule(3, 0)
+    b1, _, _ = prob.schedule(3, 1)
+    b2, _, _ = prob.schedule(4, 0)
+    assert not np.array_equal(b0, b1) and not np.array_equal(b0, b2)
 
 
 def test_radial_law_of_the_philox_stream():

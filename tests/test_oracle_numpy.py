@@ -126,6 +126,46 @@ def test_g6_chain_traces(golden, name, learn):
         np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-18)
 
 
+@pytest.mark.parametrize("name,learn", [
+    ("over_thin", False), ("over_nothin", True), ("blocks_1d", False), ("drag", False),
+    ("drag_learn", True)])
+def test_g10_blocked_oversampled_dragged_traces(golden, name, learn):
+    """Tier A for (f)1: blocks, oversampling, thinned output and dragging replay the
+    reference's chains with identical weights (proposal.py:96-260, mcmc.py:320-410, 564-668)."""
+    g = golden("g10_blocked")
+    key = lambda k: g[f"{name}__{k}"]  # noqa: E731
+    rng = np.random.Generator(np.random.PCG64())
+    rng.bit_generator.state = json.loads(str(key("rng_state")))
+    prior = R.Prior(kinds=[0] * 5, a=[0.0] * 5, b=[1.0] * 5)
+    target = R.GaussianMixtureTarget(g["means"], g["covs"])
+    sizes, flat = key("block_sizes"), key("block_params").tolist()
+    blocks = [flat[sum(sizes[:i]):sum(sizes[:i + 1])] for i in range(len(sizes))]
+    chain = R.BlockedRefChain(
+        prior, target, key("cov0"), key("x0"), rng, blocks,
+        oversampling=key("oversampling").tolist(), drag_last_slow=int(key("drag_last_slow")),
+        drag_interp_steps=int(key("drag_interp_steps")), output_thin=int(key("output_thin")),
+        temperature=float(key("temperature")), proposal_scale=float(key("proposal_scale")),
+        burn_in=int(key("burn_in")), max_tries=float(key("max_tries")), learn_proposal=learn,
+        learn_every=int(key("learn_every")), learn_Rminus1_max=30.0)
+    assert chain.cycle_length == int(key("cycle_length"))
+    data = key("data")
+    cols = [str(c) for c in key("columns")]
+    while len(chain.rows) < len(data):
+        chain.step()
+    rows = np.array(chain.rows)
+    assert chain.n_steps == int(key("n_steps_raw"))
+    assert np.array_equal(rows[:, 0], data[:, cols.index("weight")])
+    np.testing.assert_allclose(rows[:, 2:7], data[:, 2:7], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(rows[:, 1], data[:, cols.index("minuslogpost")],
+                               rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(chain.x, key("final_x"), rtol=1e-12)
+    assert chain.weight == int(key("final_weight"))
+    ref_learned = key("learned_covs")
+    assert len(chain.learned) == len(ref_learned)
+    for a, b in zip(chain.learned, ref_learned):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-18)
+
+
 def test_g7_multichain_rminus1(golden):
     g = golden("g7_multichain")
     cols = [str(c) for c in g["columns"]]
