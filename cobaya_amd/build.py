@@ -89,6 +89,9 @@ def build(dims=None, jobs=None, verbose=True):
     for dp in big_dps:
         stamp = _digest([big] + hdrs, extra=f"big{dp}|{' '.join(FLAGS)}")
         tasks.append((big, os.path.join(OBJ, f"walker_big{dp}.o"), [f"-DMCMC_DP={dp}"], stamp))
+    blocked = os.path.join(CSRC, "blocked_kernels.hip")
+    tasks.append((blocked, os.path.join(OBJ, "blocked.o"), [],
+                  _digest([blocked] + hdrs, extra=" ".join(FLAGS))))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

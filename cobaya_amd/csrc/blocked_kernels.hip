@@ -1,0 +1,174 @@
+// Proposal directions of the BLOCKED proposer for any d <= 32 (gfx950): parameter blocks
+// sorted slow -> fast, per-block oversampling, and the slow / fast sequences of the dragging
+// step.  One 64-lane workgroup per (group, cycle); dimension-independent (run-time d), since
+// this kernel is a few per cent of a launch.
+//
+// Restates (paths relative to the reference checkout):
+//   cobaya/samplers/mcmc/proposal.py:32-55 (CyclicIndexRandomizer), 58-93 (direction
+//   proposers), 176-224 (BlockedProposer cyclers and get_block_proposal), 226-260 (transforms)
+//   cobaya/functions.py:35-61 (Haar basis)
+// in the ensemble form fixed by oracle/mcmc_oracle.c (orc_block_schedule, orc_basis_blocked):
+// the HIP output must equal the oracle's bit for bit.
+#include "det_math.h"
+#include "kernels.h"
+
+namespace mcmc {
+namespace {
+
+constexpr uint32_t kStreamPerm = 2u;
+constexpr int kMaxSlots = 2048;   // slots per cycle this kernel supports
+constexpr int kMaxN = 32;
+
+__global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArgs a)
+{
+    __shared__ double sT[kMaxN * kMaxN];
+    __shared__ double sH[kMaxN * (kMaxN + 1)];
+    __shared__ double sz[(kMaxN + 2) * (kMaxN - 1) / 2 + 2];
+    __shared__ double sx[kMaxN + 1];
+    __shared__ unsigned sw[kMaxSlots];
+    __shared__ short sblk[kMaxSlots], sbas[kMaxSlots], scol[kMaxSlots];
+    __shared__ int sIofJ[kMaxN], sSize[kMaxN], sOver[kMaxN];
+    const int t = threadIdx.x;
+    const int d = a.d, L = a.L;
+    const int pg = blockIdx.x / a.ncyc, pc = blockIdx.x % a.ncyc;
+    const uint32_t group = a.group0 + (uint32_t)pg;
+    const uint32_t cycle = a.cycle0 + (uint32_t)pc;
+    double* __restrict__ Vout = a.V + ((size_t)pg * a.ncyc + pc) * a.slab;
+    int* __restrict__ Fout = a.vflag ? a.vflag + ((size_t)pg * a.ncyc + pc) * L : nullptr;
+
+    for (int i = t; i < d * d; i += 64) sT[i] = a.T[i];
+    if (t < d) sIofJ[t] = a.i_of_j[t];
+    if (t < a.n_blocks) {
+        sSize[t] = a.block_size[t];
+        sOver[t] = a.oversample[t];
+    }
+    // Philox words of the shuffle, in parallel; the swaps themselves are sequential
+    if (L > 2)
+        for (int i = 1 + t; i < L; i += 64)
+            sw[i] = philox4x32_10(a.key0, a.key1, group, kStreamPerm | ((uint32_t)a.which << 8),
+                                  cycle, (uint32_t)i).w0;
+    __syncthreads();
+    if (t == 0) {
+        int n = 0;
+        for (int b = 0; b < a.n_blocks; ++b) {
+            int reps;
+            if (a.which == 0) reps = sOver[b] * sSize[b];
+            else if (a.which == 1) reps = (b <= a.drag_last_slow) ? sSize[b] : 0;
+            else reps = (b > a.drag_last_slow) ? sSize[b] : 0;
+            for (int r = 0; r < reps; ++r) sblk[n++] = (short)b;
+        }
+        if (L > 2)
+            for (int i = L - 1; i >= 1; --i) {
+                const int j = (int)(((unsigned long long)sw[i] * (unsigned long long)(i + 1)) >> 32);
+                const short tmp = sblk[i];
+                sblk[i] = sblk[j];
+                sblk[j] = tmp;
+            }
+        int used[kMaxN];
+        for (int b = 0; b < a.n_blocks; ++b) used[b] = 0;
+        for (int s = 0; s < L; ++s) {
+            const int b = sblk[s], n_b = sSize[b];
+            sbas[s] = (short)(used[b] / n_b);
+            scol[s] = (short)(used[b] % n_b);
+            ++used[b];
+        }
+    }
+    __syncthreads();
+
+    int jb = 0;
+    for (int b = 0; b < a.n_blocks; jb += sSize[b], ++b) {
+        const int n = sSize[b];
+        int reps;
+        if (a.which == 0) reps = sOver[b] * n;
+        else if (a.which == 1) reps = (b <= a.drag_last_slow) ? n : 0;
+        else reps = (b > a.drag_last_slow) ? n : 0;
+        if (reps == 0) continue;
+        if (n == 1) {  // RandProposer1D: the direction is the block's column of T itself
+            for (int s = 0; s < L; ++s)
+                if (sblk[s] == b) {
+                    if (t < d) Vout[(size_t)s * d + sIofJ[t]] = (t >= jb) ? sT[t * d + jb] : 0.0;
+                    if (Fout && t == 0) Fout[s] = 1;
+                }
+            continue;
+        }
+        const int nz = (n + 2) * (n - 1) / 2;
+        const int ldh = n | 1;
+        for (int q = 0; q < reps / n; ++q) {
+            __syncthreads();
+            // Box-Muller normals on the basis stream of (block, basis number)
+            for (int j = t; 2 * j < nz; j += 64) {
+                const u32x4 w4 = philox4x32_10(
+                    a.key0, a.key1, group,
+                    kStreamBasis | ((uint32_t)a.which << 4) | ((uint32_t)b << 8), cycle,
+                    ((uint32_t)q << 16) | (uint32_t)j);
+                const uint64_t ka = ((uint64_t)w4.w0 << 20) | (w4.w1 >> 12);
+                const uint64_t kb = ((uint64_t)w4.w2 << 20) | (w4.w3 >> 12);
+                const double rad = sqrt(-2.0 * dlog(u52(ka)));
+                double sn, cs;
+                sincos2pi(kb, sn, cs);
+                sz[2 * j] = rad * cs;
+                sz[2 * j + 1] = rad * sn;
+            }
+            if (t < n)
+                for (int k = 0; k < n; ++k) sH[t * ldh + k] = (k == t) ? 1.0 : 0.0;
+            __syncthreads();
+            // Householder construction, the arithmetic and order of orc_haar_from_normals
+            double dprod = 1.0, Dmine = 1.0;
+            int ix = 0;
+            for (int m0 = 0; m0 < n - 1; ++m0) {
+                const int m = n - m0;
+                double norm2 = 0.0;
+                for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
+                const double x0 = sz[ix];
+                const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
+                dprod *= Dn;
+                if (t == m0) Dmine = Dn;
+                const double x0n = x0 + Dn * sqrt(norm2);
+                double tt = norm2 - x0 * x0;
+                tt = tt + x0n * x0n;
+                const double den = sqrt(0.5 * tt);
+                __syncthreads();
+                if (t < m) sx[t] = ((t == 0) ? x0n : sz[ix + t]) / den;
+                __syncthreads();
+                if (t < n) {
+                    double* row = sH + t * ldh + m0;
+                    double tmp = 0.0;
+                    for (int k = 0; k < m; ++k) tmp = fma(row[k], sx[k], tmp);
+                    for (int k = 0; k < m; ++k) row[k] = fma(-tmp, sx[k], row[k]);
+                }
+                ix += m;
+            }
+            if (t == n - 1) Dmine = (((n - 1) & 1) ? -1.0 : 1.0) * dprod;
+            if (t < n)
+                for (int k = 0; k < n; ++k) sH[t * ldh + k] = Dmine * sH[t * ldh + k];
+            __syncthreads();
+            // the columns of this basis, wherever the shuffle put them
+            for (int s = 0; s < L; ++s) {
+                if (sblk[s] != b || sbas[s] != q) continue;
+                const int c = scol[s];
+                if (t < d) {
+                    double acc = 0.0;
+                    if (t >= jb) {
+                        const int kmax = (t - jb < n - 1) ? t - jb : n - 1;
+                        for (int k = 0; k <= kmax; ++k)
+                            acc = fma(sT[t * d + jb + k], sH[k * ldh + c], acc);
+                    }
+                    Vout[(size_t)s * d + sIofJ[t]] = acc;
+                }
+                if (Fout && t == 0) Fout[s] = 0;
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace mcmc
+
+extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs* a, int n_groups,
+                                                    hipStream_t st)
+{
+    if (a->L > mcmc::kMaxSlots || a->d > mcmc::kMaxN || a->n_blocks > mcmc::kMaxN)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mcmc::basis_blocked_kernel, dim3(n_groups * a->ncyc), dim3(64), 0, st, *a);
+    return hipGetLastError();
+}

@@ -62,6 +62,9 @@ const DimKernels* kernels_for_dim(int d)
 
 std::string g_create_error;
 
+// slots per cycle of the blocked proposer's three sequences (oracle: orc_block_slots)
+int block_slots(const mcmc_hip_ctx* h, int which);
+
 // ------------------------------------------------------------------ small dense LA (host)
 // lower Cholesky, row-major; false if not positive definite (np.linalg.cholesky semantics)
 bool cholesky_lower(int n, const double* A, double* L)
@@ -222,6 +225,9 @@ struct DevBuf {
 
 }  // namespace
 
+extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs* a, int n_groups,
+                                                    hipStream_t st);
+
 struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
     const DimKernels* k = nullptr;    // d <= 32: lane-per-walker kernels of that dimension
@@ -239,6 +245,12 @@ struct mcmc_hip_ctx {
     bool any_periodic = false;
     std::vector<double> mean, Linv, cnorm, weight;  // Linv: [K][d*d] row-major
     std::vector<double> cov, T;                     // proposal
+    // parameter blocks (proposal.py:96-196); blocked == false: one block, identity order
+    bool blocked = false;
+    std::vector<int32_t> blk_size, blk_over, i_of_j;
+    int drag_last_slow = -1, drag_steps = 0;
+    DevBuf<int> dblk, vflag, vflag_f;               // dblk: size | oversample | i_of_j
+    DevBuf<double> Vf;                              // dragging: directions of the fast blocks
     std::vector<double> shift;                      // moment shift
     // device
     DevBuf<double> x, logpost, logprior, loglike, cblock, dT, V, rows, gsum, Sg, pooled, dshift;
@@ -272,6 +284,18 @@ int fail(mcmc_hip_ctx* h, int code, const char* fmt, ...)
     if (h) h->err = buf;
     else g_create_error = buf;
     return code;
+}
+
+int block_slots(const mcmc_hip_ctx* h, int which)
+{
+    if (!h->blocked) return h->d;
+    int L = 0;
+    for (size_t b = 0; b < h->blk_size.size(); ++b) {
+        if (which == 0) L += h->blk_over[b] * h->blk_size[b];
+        else if (which == 1) L += ((int)b <= h->drag_last_slow) ? h->blk_size[b] : 0;
+        else L += ((int)b > h->drag_last_slow) ? h->blk_size[b] : 0;
+    }
+    return L;
 }
 
 #define HIP_TRY(h, call)                                                                      \
@@ -546,6 +570,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->dLcol.release(); h->weight_i.release(); h->prej.release();
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
     h->acc_total.release();
+    h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -636,6 +661,77 @@ int mcmc_hip_get_derived_constants(const mcmc_hip_ctx* h, double* uniform_logp, 
     return MCMC_HIP_OK;
 }
 
+int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* block_size,
+                          const int32_t* oversampling, const int32_t* i_of_j,
+                          int32_t drag_last_slow, int32_t drag_steps)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!block_size || !oversampling || !i_of_j) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    const int d = h->d;
+    if (h->kb)
+        return fail(h, MCMC_HIP_ERR_ARG, "parameter blocks are supported for d <= 32 (d=%d)", d);
+    if (n_blocks < 1 || n_blocks > 32)
+        return fail(h, MCMC_HIP_ERR_ARG, "n_blocks must be in 1..32, got %d", n_blocks);
+    int total = 0;
+    bool trivial = n_blocks == 1;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (block_size[b] < 1) return fail(h, MCMC_HIP_ERR_ARG, "empty parameter block %d", b);
+        if (oversampling[b] < 1)   // proposal.py:131-137
+            return fail(h, MCMC_HIP_ERR_ARG, "Oversampling factors must be integer! Got %d.",
+                        oversampling[b]);
+        total += block_size[b];
+        trivial = trivial && oversampling[b] == 1;
+    }
+    std::vector<char> seen(d, 0);
+    if (total == d)
+        for (int j = 0; j < d; ++j) {
+            if (i_of_j[j] < 0 || i_of_j[j] >= d || seen[i_of_j[j]]) { total = -1; break; }
+            seen[i_of_j[j]] = 1;
+            trivial = trivial && i_of_j[j] == j;
+        }
+    if (total != d)   // proposal.py:153-156
+        return fail(h, MCMC_HIP_ERR_ARG, "The blocks do not contain all the parameter indices.");
+    if (drag_last_slow >= 0) {
+        if (drag_last_slow > n_blocks - 2)   // proposal.py:143-150: a fast block must remain
+            return fail(h, MCMC_HIP_ERR_ARG,
+                        "The index given for the last slow block, %d, is not valid: there are "
+                        "only %d blocks.", drag_last_slow, n_blocks);
+        if (drag_steps < 1 || drag_steps > 256)
+            return fail(h, MCMC_HIP_ERR_ARG, "drag_steps must be in 1..256, got %d", drag_steps);
+        if (h->cfg.emit_capacity > 0)
+            return fail(h, MCMC_HIP_ERR_ARG, "dragging does not emit rows (emit_capacity > 0)");
+        trivial = false;
+    } else {
+        drag_last_slow = -1;
+        drag_steps = 0;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->blocked = !trivial;
+    h->blk_size.assign(block_size, block_size + n_blocks);
+    h->blk_over.assign(oversampling, oversampling + n_blocks);
+    h->i_of_j.assign(i_of_j, i_of_j + d);
+    h->drag_last_slow = drag_last_slow;
+    h->drag_steps = drag_steps;
+    for (int w = 0; w < 3; ++w)
+        if (block_slots(h, w) > 2048)
+            return fail(h, MCMC_HIP_ERR_ARG, "a cycle of %d steps exceeds the supported 2048",
+                        block_slots(h, w));
+    std::vector<int> pack;
+    pack.insert(pack.end(), h->blk_size.begin(), h->blk_size.end());
+    pack.insert(pack.end(), h->blk_over.begin(), h->blk_over.end());
+    pack.insert(pack.end(), h->i_of_j.begin(), h->i_of_j.end());
+    HIP_TRY(h, h->dblk.resize(pack.size()));
+    HIP_TRY(h, hipMemcpy(h->dblk.p, pack.data(), sizeof(int) * pack.size(), hipMemcpyHostToDevice));
+    h->have_cov = false;  // the transform depends on the parameter order
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_cycle_length(const mcmc_hip_ctx* h)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    return block_slots(h, h->drag_last_slow >= 0 ? 1 : 0);
+}
+
 int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
 {
     if (!h) return MCMC_HIP_ERR_ARG;
@@ -645,6 +741,15 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
     if (!is_symmetric(d, cov))
         return fail(h, MCMC_HIP_ERR_NOT_PD,
                     "The given covmat is not a positive-definite, symmetric square matrix.");
+    const std::vector<double> cov_in(cov, cov + (size_t)d * d);
+    std::vector<double> sorted_cov;
+    if (h->blocked) {  // proposal.py:250-252: reorder by i_of_j before std / corr / Cholesky
+        sorted_cov.resize((size_t)d * d);
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j)
+                sorted_cov[i * d + j] = cov_in[h->i_of_j[i] * d + h->i_of_j[j]];
+        cov = sorted_cov.data();
+    }
     for (int i = 0; i < d; ++i) {
         if (!(cov[i * d + i] > 0.0) || !std::isfinite(cov[i * d + i]))
             return fail(h, MCMC_HIP_ERR_NOT_PD,
@@ -658,7 +763,7 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
     if (!cholesky_lower(d, corr.data(), L.data()))
         return fail(h, MCMC_HIP_ERR_NOT_PD,
                     "The given covmat is not a positive-definite, symmetric square matrix.");
-    h->cov.assign(cov, cov + (size_t)d * d);
+    h->cov = cov_in;
     h->T.assign((size_t)d * d, 0.0);
     for (int i = 0; i < d; ++i)
         for (int j = 0; j <= i; ++j) h->T[i * d + j] = h->cfg.proposal_scale * (sd[i] * L[i * d + j]);
@@ -841,6 +946,36 @@ int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logp
     return MCMC_HIP_OK;
 }
 
+namespace {
+
+// fills `V` (and `flag` when the sequence has one-parameter blocks) with the directions of
+// cycles [c0, c0 + ncyc) of sequence `which` of the blocked proposer
+int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, int L, size_t slab,
+                  DevBuf<double>& V, DevBuf<int>& flag, bool& any_1d)
+{
+    const int nb = (int)h->blk_size.size();
+    any_1d = false;
+    for (int b = 0; b < nb; ++b) {
+        const bool in_seq = which == 0 || (which == 1) == (b <= h->drag_last_slow);
+        any_1d = any_1d || (in_seq && h->blk_size[b] == 1);
+    }
+    HIP_TRY(h, V.resize((size_t)h->G * ncyc * slab));
+    if (any_1d) HIP_TRY(h, flag.resize((size_t)h->G * ncyc * L));
+    mcmc::BlockedBasisArgs b{};
+    b.T = h->dT.p; b.V = V.p; b.vflag = any_1d ? flag.p : nullptr;
+    b.block_size = h->dblk.p; b.oversample = h->dblk.p + nb; b.i_of_j = h->dblk.p + 2 * nb;
+    b.n_blocks = nb; b.d = h->d; b.which = which; b.drag_last_slow = h->drag_last_slow;
+    b.L = L; b.slab = (int)slab;
+    b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+    b.cycle0 = (uint32_t)c0;
+    b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+    b.ncyc = ncyc;
+    HIP_TRY(h, mcmc_hip_launch_blocked_basis(&b, h->G, h->stream));
+    return MCMC_HIP_OK;
+}
+
+}  // namespace
+
 int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
 {
     if (!h) return MCMC_HIP_ERR_ARG;
@@ -848,14 +983,21 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         return fail(h, MCMC_HIP_ERR_STATE, "set_state and set_proposal_cov must precede step");
     if (n_steps <= 0) return fail(h, MCMC_HIP_ERR_ARG, "n_steps must be > 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    const unsigned long long d = (unsigned long long)h->d;
-    // doubles per (group, cycle) slab of proposal directions
-    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(h->d) : (size_t)mcmc::v_slab(h->d);
+    const bool drag = h->drag_last_slow >= 0;
+    // steps (= direction columns) per cycle, doubles per (group, cycle) slab of directions
+    const int Lc = block_slots(h, drag ? 1 : 0);
+    const unsigned long long d = (unsigned long long)Lc;
+    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(h->d)
+                            : (size_t)mcmc::v_slab_cols(Lc, h->d);
     if (h->kb && (h->K != 1 || h->norm_mask4[0] || h->norm_mask4[1] || h->norm_mask4[2] ||
                   h->norm_mask4[3] || h->any_periodic || h->cfg.emit_capacity > 0))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "for d > 32 this build samples a single Gaussian mode with uniform, "
                     "non-periodic priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
+    if (!h->kb && !drag && 2 * (size_t)(256 / std::min(h->gs, 256)) * dd * sizeof(double) > (96u << 10))
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "a cycle of %d steps needs %zu KiB of LDS per group: use group_size 256 or "
+                    "smaller oversampling factors", Lc, dd * sizeof(double) / 1024);
     // directions buffer: at most ~256 MiB of cycles per launch
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
     int left = n_steps;
@@ -865,17 +1007,23 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         const int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
         const unsigned long long c1 = (h->step + (unsigned long long)n - 1) / d;
         const int ncyc = (int)(c1 - c0 + 1);
-        HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+        bool any_1d = false;
         {
             Timed t(h, 1);
-            mcmc::BasisArgs b{};
-            b.T = h->dT.p; b.V = h->V.p;
-            b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
-            b.cycle0 = (uint32_t)c0;
-            b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
-            b.ncyc = ncyc;
-            if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
-            else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+            if (h->blocked) {
+                const int rc = blocked_basis(h, drag ? 1 : 0, c0, ncyc, Lc, dd, h->V, h->vflag, any_1d);
+                if (rc != MCMC_HIP_OK) return rc;
+            } else {
+                HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+                mcmc::BasisArgs b{};
+                b.T = h->dT.p; b.V = h->V.p;
+                b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+                b.cycle0 = (uint32_t)c0;
+                b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+                b.ncyc = ncyc;
+                if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
+                else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+            }
         }
         {
             Timed t(h, 0);
@@ -894,6 +1042,9 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             a.uniform_logp = h->uniform_logp; a.temperature = h->cfg.temperature;
             a.max_tries = h->cfg.max_tries;
             a.cnorm0 = h->K > 0 ? h->cnorm[0] : 0.0;
+            a.cps = Lc; a.slab = (int)dd;
+            a.vflag = any_1d ? h->vflag.p : nullptr;
+            if (drag) return fail(h, MCMC_HIP_ERR_ARG, "dragging: not built");
             if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->stream));
             else HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;

@@ -28,7 +28,12 @@ __host__ __device__ inline void tri_stream_for_each(int d, F&& f)
 
 // Doubles per (group, cycle) slab of proposal directions V[col][i]: d*d rounded up to whole
 // KiB so that the step kernel can move a slab into LDS with 1 KiB global->LDS DMA pieces.
-__host__ __device__ constexpr int v_slab(int d) { return ((d * d * 8 + 1023) / 1024) * 128; }
+// With parameter blocks a cycle has `ncols` = sum_b oversample_b * n_b columns instead of d.
+__host__ __device__ constexpr int v_slab_cols(int ncols, int d)
+{
+    return ((ncols * d * 8 + 1023) / 1024) * 128;
+}
+__host__ __device__ constexpr int v_slab(int d) { return v_slab_cols(d, d); }
 
 // d > 32 ("big" kernels): columns of V are padded to an even number of doubles (16-byte aligned
 // for the per-step 1 KiB global->LDS DMA), and a slab keeps >= 1 KiB behind its last column.
@@ -90,6 +95,30 @@ struct StepArgs {
     int ncyc;
     double uniform_logp, temperature, max_tries;
     double cnorm0;  // d log 2pi + log|S_0| of mode 0 (kernarg copy for the hot variant)
+    // cycle geometry: columns (= steps) per cycle and doubles per (group, cycle) slab of V;
+    // d and v_slab(d) for one block, sum_b oversample_b n_b with parameter blocks
+    int cps;
+    int slab;
+    // [G][ncyc][cps] 1 where the column belongs to a one-parameter block (its step draws the
+    // RandProposer1D variates, proposal.py:85-93), or null
+    const int* vflag;
+};
+
+// Directions of the blocked proposer (blocked_kernels.hip; any d <= 32).
+struct BlockedBasisArgs {
+    const double* T;        // [d*d] transform of the covariance in SORTED order
+    double* V;              // [G][ncyc][slab]
+    int* vflag;             // [G][ncyc][L] or null
+    const int* block_size;  // [n_blocks]
+    const int* oversample;  // [n_blocks]
+    const int* i_of_j;      // [d]
+    int n_blocks, d;
+    int which;              // 0 all blocks with oversampling; 1 slow; 2 fast (dragging)
+    int drag_last_slow;
+    int L;                  // slots per cycle of this sequence
+    int slab;
+    uint32_t group0, cycle0, key0, key1;
+    int ncyc;
 };
 
 struct BasisArgs {

@@ -400,7 +400,7 @@ template <bool MULTI, bool GENERAL>
 __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int SLAB = v_slab(D);
+    const int SLAB = a.slab, cps = a.cps;
     const ConstLayout cl{D, a.n_modes};
     const cptr C0 = as_const(a.cblock);
     const int tid = threadIdx.x, gs = blockDim.x;
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     int nrow = a.rows ? a.n_rows[w] : 0;
     const uint32_t gid = a.walker0 + (uint32_t)w;
     unsigned long long step = a.step0;
-    int col = (int)(step % (unsigned long long)D);
+    int col = (int)(step % (unsigned long long)cps);
     int cyc = 0;
     StepRng rng;
     if (!MULTI && !GENERAL && D >= 2) {  // hot variant: the first step's variates up front
@@ -466,7 +466,10 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             rng.run_all();
             r = rng.r;
             Ea = rng.Ea;
-            if (D == 1) {
+            // a column of a one-parameter block (wave-uniform flag written with the directions)
+            const bool oned = D == 1 || (GENERAL && a.vflag != nullptr &&
+                                         a.vflag[((size_t)group * a.ncyc + cyc) * cps + col] != 0);
+            if (oned) {
                 double sn, cs;
                 sincos2pi(rng.ka, sn, cs);
                 const double rr = rng.expo ? rng.Er : sqrt(2.0 * rng.Er) * fabs(cs);
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
             if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
         }
         ++step;
-        if (++col == D) {  // next cycle: its slab was DMA'd during this one
+        if (++col == cps) {  // next cycle: its slab was DMA'd during this one
             col = 0;
             ++cyc;
             if (s + 1 < a.n_steps) {
@@ -700,7 +703,7 @@ __device__ __forceinline__ void exchange_barrier()
 template <int ROLE, bool UNIT_T>
 __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
 {
-    constexpr int SLAB = v_slab(D);
+    const int SLAB = a.slab;
     constexpr int NX = ROLE == 0 ? kSplit : D;      // dimensions of the state this role holds
     const ConstLayout cl{D, 1};
     const cptr C0 = as_const(a.cblock);
@@ -719,7 +722,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
     // The slab DMA runs once per cycle: everything it needs is recomputed from the kernarg
     // segment there, so that nothing of it stays live (in SGPRs) across the step loop.
     auto stage_dma = [&](kaptr k, int cycle, int buf) {
-        const int lgs = __builtin_ctz((unsigned)k->group_size);
+        const int lgs = __builtin_ctz((unsigned)k->group_size), SLAB = k->slab;
         const int wpg = 1 << (lgs - 6);
         const int part = __builtin_amdgcn_readfirstlane((wl >> 6) & (wpg - 1)) + wpg * ROLE;
         const int group = __builtin_amdgcn_readfirstlane(w >> lgs);
@@ -754,7 +757,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
     }
     const long long nacc0 = nacc;
     const uint32_t gid = a.walker0 + (uint32_t)w;
-    int col = (int)(a.step0 % (unsigned long long)D);
+    int col = (int)(a.step0 % (unsigned long long)a.cps);
     int cyc = 0;
     StepRng rng;
     double r = 0.0, Ea = 0.0;
@@ -843,7 +846,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
             r = r_next;
             Ea = Ea_next;
         }
-        if (++col == D) {  // next cycle: its slab was DMA'd during this one
+        if (++col == ks->cps) {  // next cycle: its slab was DMA'd during this one
             col = 0;
             ++cyc;
             if (s + 1 < n_steps) {
@@ -1054,7 +1057,7 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
     size_t lds = 0;
     const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
     const dim3 grid(a.W / bs), block(bs);
-    lds = sizeof(double) * (size_t)(2 * (bs / a.group_size) * v_slab(D) + (multi ? a.n_modes * bs : 0));
+    lds = sizeof(double) * (size_t)(2 * (bs / a.group_size) * a.slab + (multi ? a.n_modes * bs : 0));
     // Placement: the waves of this kernel run for the whole launch, and at W = 65 536 there
     // are exactly as many waves as SIMDs.  Requesting (otherwise unused) LDS so that only
     // ceil(#workgroups / 256 CUs) workgroups fit on a CU makes the dispatcher spread them
@@ -1067,10 +1070,10 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
         if (want > lds) lds = want;
     }
     const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
-                         a.rows != nullptr || D == 1;
+                         a.rows != nullptr || D == 1 || a.vflag != nullptr;
     if (kPair && !multi && !general && a.W % 256 == 0 && 256 % a.group_size == 0) {
         // two waves per 64 walkers: 512-thread workgroups of 256 walkers
-        size_t plds = sizeof(double) * (size_t)(2 * (256 / a.group_size) * v_slab(D) + 2 * kXF * 256);
+        size_t plds = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab + 2 * kXF * 256);
         const int nwg = a.W / 256;
         const int per_cu = (nwg + 255) / 256;      // same even-placement request as below
         size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;

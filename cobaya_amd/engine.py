@@ -58,6 +58,9 @@ SYMBOLS = [
      [_H, C.c_int32, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_set_target_gaussian", C.c_int, [_H, c_double_p, c_double_p, C.c_int32]),
     ("mcmc_hip_set_target_one", C.c_int, [_H]),
+    ("mcmc_hip_set_blocking", C.c_int, [_H, C.c_int32, c_int32_p, c_int32_p, c_int32_p,
+                                        C.c_int32, C.c_int32]),
+    ("mcmc_hip_cycle_length", C.c_int, [_H]),
     ("mcmc_hip_set_proposal_cov", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_get_proposal_cov", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_get_proposal_transform", C.c_int, [_H, c_double_p]),
@@ -231,6 +234,22 @@ class Engine:
             _dp(w) if K else None))
         return {"uniform_logp": u.value, "mls": mls, "Linv": Linv[:K], "cnorm": cn[:K],
                 "weight": w[:K]}
+
+    def set_blocking(self, blocks, oversampling=None, drag_last_slow=-1, drag_steps=0):
+        """Parameter blocks (lists of sampler indices, slow -> fast) with their oversampling
+        factors (proposal.py:96-196); drag_last_slow >= 0 selects the dragging step."""
+        sizes = np.array([len(b) for b in blocks], dtype=np.int32)
+        over = np.array(oversampling if oversampling is not None else [1] * len(blocks),
+                        dtype=np.int32)
+        i_of_j = np.array([i for b in blocks for i in b], dtype=np.int32)
+        if len(i_of_j) != self.d or len(over) != len(sizes):
+            raise EngineError(ERR_ARG, "The blocks do not contain all the parameter indices.")
+        self._check(self._lib.mcmc_hip_set_blocking(
+            self._h, len(sizes), _ip(sizes), _ip(over), _ip(i_of_j), int(drag_last_slow),
+            int(drag_steps)))
+
+    def cycle_length(self):
+        return int(self._lib.mcmc_hip_cycle_length(self._h))
 
     def set_proposal_cov(self, cov):
         cov = _f64(cov, (self.d, self.d))

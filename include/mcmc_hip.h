@@ -78,7 +78,22 @@ int mcmc_hip_set_target_gaussian(mcmc_hip_ctx* h, const double* mean, const doub
 /* likelihoods/one/one.py:27-29: loglike = 0 (prior-only sampling) */
 int mcmc_hip_set_target_one(mcmc_hip_ctx* h);
 
-/* BlockedProposer.set_covariance (proposal.py:226-260) for one block of all parameters:
+/* BlockedProposer.__init__ (proposal.py:96-196) + MCMC.set_proposer_blocking (mcmc.py:320-410):
+ * n_blocks parameter blocks sorted slow -> fast, block b holding block_size[b] consecutive
+ * entries of i_of_j[d] (sampler indices in sorted order) and visited oversampling[b] *
+ * block_size[b] times per cycle.  drag_last_slow >= 0 switches mcmc_hip_step to the dragging
+ * step (mcmc.py:564-668) with blocks 0..drag_last_slow slow and drag_steps interpolation
+ * steps; -1 keeps Metropolis steps.  d <= 32 only.  Must precede set_proposal_cov (a previous
+ * covariance is forgotten).  One block with factor 1 and the identity order is the default. */
+int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* block_size,
+                          const int32_t* oversampling, const int32_t* i_of_j,
+                          int32_t drag_last_slow, int32_t drag_steps);
+/* steps per cycle: d for one block, sum_b oversampling_b n_b with blocks, the number of slow
+ * parameters when dragging (mcmc.py:400-407) */
+int mcmc_hip_cycle_length(const mcmc_hip_ctx* h);
+
+/* BlockedProposer.set_covariance (proposal.py:226-260); with blocks the covariance is
+ * reordered by i_of_j first and get_proposal_transform returns T in that sorted order:
  * checks symmetric positive definite, builds T = scale * diag(std) * chol(corr).  `cov`
  * must already carry the temperature factor (mcmc.py:438-440), as in the reference. */
 int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov);

@@ -36,7 +36,7 @@ def random_target(d, K, rng, spread=0.05):
 
 def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, T=1.0,
               burn_in=0, cap=0, weights=None, normalized=True, rng=None, walker_offset=0,
-              max_tries=None):
+              max_tries=None, blocks=None, over=None, drag_last_slow=-1, drag_steps=0):
     rng = rng or np.random.default_rng(100 + d)
     kinds = [0] * d if kinds is None else kinds
     a = [0.0] * d if a is None else a
@@ -54,9 +54,16 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
         else:
             eng.set_target_gaussian_mixture(means, covs, weights)
     pcov = (covs[0] if K else np.diag(np.full(d, 0.01))) * T
+    if blocks is not None:
+        eng.set_blocking(blocks, over, drag_last_slow, drag_steps)
     eng.set_proposal_cov(pcov)
+    if blocks is not None:  # the engine's transform is the oracle's recipe in sorted order
+        np.testing.assert_allclose(eng.get_proposal_transform(),
+                                   O.blocked_transform(pcov, blocks, 2.4), rtol=1e-12, atol=1e-15)
     prob = O.Problem(d, kinds, a, b, periodic=periodic, means=means, covs=covs,
                      weights=weights, normalized=normalized, T=eng.get_proposal_transform(),
+                     blocks=blocks, oversampling=over, drag_last_slow=drag_last_slow,
+                     drag_steps=drag_steps,
                      group_size=gs, seed=seed, temperature=T, max_tries=max_tries,
                      derived=eng.derived_constants())
     m0 = means[0] if K else np.full(d, 0.5)
@@ -180,6 +187,43 @@ def test_emitted_rows_and_burn_in_bit_exact():
     assert eng.counters()["dropped_rows"] == 0
     # weights are multiplicities: per walker they sum to the steps spent at emitted points
     assert rows[:, 1].min() >= 1
+
+
+@pytest.mark.parametrize("d,W,gs,K,blocks,over,steps", [
+    # a one-parameter block (RandProposer1D variates) -> general kernel
+    (7, 256, 64, 1, [[5, 0], [3], [1, 6, 2, 4]], [1, 2, 3], 100),
+    # hot kernels: two waves per walker set (W % 256 == 0) and one wave (W = 192)
+    (30, 512, 256, 1, [list(range(10, 30)), list(range(10))], [1, 3], 130),
+    (12, 192, 64, 1, [[11, 3, 7, 1, 9, 5], [0, 2, 4, 6, 8, 10]], [2, 1], 75),
+    # mixture target, three blocks, permuted order
+    (5, 256, 128, 2, [[4, 1], [0, 3], [2]], [1, 1, 5], 80),
+    # blocks without oversampling still change the proposal (block-wise directions)
+    (8, 256, 64, 1, [[0, 1, 2], [3, 4, 5, 6, 7]], [1, 1], 60)])
+def test_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, over, steps):
+    """(f)1: parameter blocks with oversampling (proposal.py:96-224): the slot shuffle, the
+    per-block Haar bases and the steps equal the oracle's bit for bit."""
+    eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.3, 0.7] if K == 2 else None,
+                              blocks=blocks, over=over)
+    assert eng.cycle_length() == prob.cycle_length() == sum(
+        o * len(b) for o, b in zip(over, blocks))
+    for n in (1, steps // 3, steps - steps // 3 - 1):   # launches start and stop mid-cycle
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+    c = eng.counters()
+    assert c["steps"] == steps and c["accepted"] == int(st.n_accept.sum())
+
+
+def test_blocking_errors_are_loud():
+    eng = E.Engine(4, 64, group_size=64, seed=1)
+    with pytest.raises(E.EngineError, match="do not contain all"):
+        eng.set_blocking([[0, 1], [1, 3]], [1, 2])
+    with pytest.raises(E.EngineError, match="Oversampling factors"):
+        eng.set_blocking([[0, 1], [2, 3]], [1, 0])
+    big = E.Engine(40, 64, group_size=64, seed=1)
+    with pytest.raises(E.EngineError, match="d <= 32"):
+        big.set_blocking([list(range(20)), list(range(20, 40))], [1, 2])
 
 
 def test_paired_kernel_with_temperature_bit_exact():

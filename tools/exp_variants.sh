@@ -12,7 +12,7 @@ FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math 
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   ( hipcc $FL $flags -DMCMC_D=$D -c $CS/walker_kernels.hip -o $CS/_exp/w_$name.o &&
-    hipcc -shared -fPIC --offload-arch=gfx950 $CS/_exp/w_$name.o $CS/_obj/capi.o -o $CS/_exp/lib_$name.so &&
+    hipcc -shared -fPIC --offload-arch=gfx950 $CS/_exp/w_$name.o $CS/_obj/capi.o $CS/_obj/blocked.o -o $CS/_exp/lib_$name.so &&
     echo "built $name" ) &
 done
 wait

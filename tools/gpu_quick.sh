@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for v in prev cur prev cur; do
-echo -n "$v: "; MCMC_HIP_LIB=cobaya_amd/csrc/_exp/lib_$v.so timeout 300 python tools/quick_engine_bench.py 30 65536 256 1200 2>&1 | tail -1
-done
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -12
+timeout 300 python tools/quick_engine_bench.py 30 65536 256 1200 2>&1 | tail -1
