@@ -1000,11 +1000,23 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                     "smaller oversampling factors", Lc, dd * sizeof(double) / 1024);
     // directions buffer: at most ~256 MiB of cycles per launch
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    // dragging: the fast blocks' directions, n_drag columns per step
+    const int Lf = drag ? block_slots(h, 2) : 0;
+    const size_t ddf = drag ? (size_t)mcmc::v_slab_cols(Lf, h->d) : 0;
+    const unsigned long long nd = (unsigned long long)h->drag_steps;
+    const int max_cyc_f =
+        drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * ddf * (size_t)h->G)) : 0;
     int left = n_steps;
     while (left > 0) {
         const unsigned long long c0 = h->step / d;
         const unsigned long long room = (c0 + (unsigned long long)max_cyc) * d - h->step;
-        const int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        if (drag) {  // at most max_cyc_f cycles of fast directions per launch
+            const unsigned long long fc0 = h->step * nd / (unsigned long long)Lf;
+            const unsigned long long fend = (fc0 + (unsigned long long)max_cyc_f) * (unsigned long long)Lf;
+            const unsigned long long room_f = (fend - h->step * nd) / nd;   // whole steps
+            n = (int)std::min<unsigned long long>((unsigned long long)n, std::max<unsigned long long>(1, room_f));
+        }
         const unsigned long long c1 = (h->step + (unsigned long long)n - 1) / d;
         const int ncyc = (int)(c1 - c0 + 1);
         bool any_1d = false;
@@ -1044,8 +1056,23 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             a.cnorm0 = h->K > 0 ? h->cnorm[0] : 0.0;
             a.cps = Lc; a.slab = (int)dd;
             a.vflag = any_1d ? h->vflag.p : nullptr;
-            if (drag) return fail(h, MCMC_HIP_ERR_ARG, "dragging: not built");
-            if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->stream));
+            if (drag) {
+                mcmc::DragArgs g{};
+                g.s = a;
+                const unsigned long long f0 = h->step * nd;
+                const unsigned long long f1 = (h->step + (unsigned long long)n) * nd - 1;
+                g.cyc0 = c0;
+                g.cyc0_f = f0 / (unsigned long long)Lf;
+                g.ncyc_f = (int)(f1 / (unsigned long long)Lf - g.cyc0_f + 1);
+                g.cps_f = Lf; g.slab_f = (int)ddf; g.n_drag = h->drag_steps;
+                bool any_1d_f = false;
+                const int rc = blocked_basis(h, 2, g.cyc0_f, g.ncyc_f, Lf, ddf, h->Vf, h->vflag_f,
+                                             any_1d_f);
+                if (rc != MCMC_HIP_OK) return rc;
+                g.Vf = h->Vf.p;
+                g.vflag_f = any_1d_f ? h->vflag_f.p : nullptr;
+                HIP_TRY(h, h->k->drag(g, h->stream));
+            } else if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->stream));
             else HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;
         }

@@ -141,15 +141,16 @@ struct StepRng {
     bool expo;
     double f, dk, s, Er, Ea, r;
 
+    // sub: 0 = the step itself, 1..n = the interpolation steps of a dragging step
     __device__ __forceinline__ void begin(uint32_t key0, uint32_t key1, uint32_t gid,
-                                          unsigned long long step)
+                                          unsigned long long step, uint32_t sub = 0)
     {
         // the keys go through an empty asm: the nine bumped round keys are then recomputed on
         // the scalar ALU every step instead of being hoisted out of the step loop (where they
         // would sit in 18 SGPRs, i.e. get spilled to VGPR lanes and read back every step)
         asm volatile("; step keys" : "+s"(key0), "+s"(key1));
         k0 = key0; k1 = key1;
-        c0 = gid; c1 = kStreamStep; c2 = (uint32_t)step; c3 = (uint32_t)(step >> 32);
+        c0 = gid; c1 = kStreamStep | (sub << 16); c2 = (uint32_t)step; c3 = (uint32_t)(step >> 32);
     }
     __device__ __forceinline__ void round()
     {

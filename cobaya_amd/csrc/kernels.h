@@ -153,12 +153,24 @@ struct MomentArgs {
     int G;
 };
 
+// The dragging step (mcmc.py:564-668): `s` carries the state, the slow directions (V, cps,
+// slab, ncyc, vflag; cycles counted from cyc0) and everything else of a Metropolis launch.
+struct DragArgs {
+    StepArgs s;
+    const double* Vf;      // [G][ncyc_f][slab_f] directions of the fast blocks
+    const int* vflag_f;    // [G][ncyc_f][cps_f] or null
+    unsigned long long cyc0, cyc0_f;   // first slow / fast cycle held in V / Vf
+    int cps_f, slab_f, ncyc_f;
+    int n_drag;            // interpolation steps per dragging step
+};
+
 // Per-dimension launchers (one translation unit per d, see walker_kernels.hip).
 struct DimKernels {
     hipError_t (*step)(const StepArgs&, int group_size, hipStream_t);
     hipError_t (*basis)(const BasisArgs&, int n_groups, hipStream_t);
     hipError_t (*evaluate)(const EvalArgs&, hipStream_t);
     hipError_t (*moments)(const MomentArgs&, int group_size, hipStream_t);
+    hipError_t (*drag)(const DragArgs&, hipStream_t);
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

@@ -889,6 +889,161 @@ __global__ void __launch_bounds__(512) step_pair_kernel(const StepArgs a)
     }
 }
 
+// ---------------------------------------------------------------- the dragging kernel
+// One dragging step per walker and iteration (mcmc.py:564-668), the arithmetic and order of
+// oracle/mcmc_oracle.c drag_core: a slow proposal to the end point, n_drag interpolation
+// steps that move start and end point together along fast directions under the interpolated
+// posterior, and the final test on the averaged log-posteriors.  Not a hot kernel: general
+// evaluator, directions read from global memory, the start point kept in LDS.
+__device__ __forceinline__ void drag_variates(uint32_t key0, uint32_t key1, uint32_t gid,
+                                              unsigned long long step, uint32_t sub, bool oned,
+                                              double& r, double& Ea)
+{
+    StepRng rng;
+    rng.begin(key0, key1, gid, step, sub);
+    rng.run_all();
+    r = rng.r;
+    Ea = rng.Ea;
+    if (oned) {  // RandProposer1D, proposal.py:85-93
+        double sn, cs;
+        sincos2pi(rng.ka, sn, cs);
+        const double rr = rng.expo ? rng.Er : sqrt(2.0 * rng.Er) * fabs(cs);
+        r = (rng.c0 & 0x80u) ? rr : -rr;
+        const u32x4 q4 = philox4x32_10(key0, key1, gid, kStreamStep | (sub << 16) | 0x100u,
+                                       (uint32_t)step, (uint32_t)(step >> 32));
+        Ea = -dlog(u52(((uint64_t)q4.w0 << 20) | (q4.w1 >> 12)));
+    }
+}
+
+__device__ __forceinline__ bool metropolis(double trial, double current, double T, double Ea)
+{
+    return (trial != -INFINITY) & ((trial > current) | (Ea > (current - trial) / T));
+}
+
+template <bool MULTI>
+__global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const StepArgs& a = da.s;
+    const ConstLayout cl{D, a.n_modes};
+    const cptr C = as_const(a.cblock);
+    const int tid = threadIdx.x;
+    const int w = blockIdx.x * 64 + tid;
+    const int W = a.W;
+    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
+    double* const sC = smem + tid;             // start point: sC[i * 64]
+    double* const sX = smem + D * 64 + tid;    // current point, restored on rejection
+    double* const sA = smem + 2 * D * 64 + tid;  // MULTI: mode log-densities [K][64]
+    double ce[D], t[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) ce[i] = a.x[(size_t)i * W + w];
+    double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
+    int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
+    long long nacc = a.n_accept[w];
+    const long long nacc0 = nacc;
+    const uint32_t gid = a.walker0 + (uint32_t)w;
+    const int n = da.n_drag;
+    auto evaluate = [&](double& lp, double& ll) -> double {
+        bool inb;
+        eval_point<MULTI, false, true>(t, C, cl, a.norm_mask, a.uniform_logp, sA, 64, inb, lp, ll,
+                                       nullptr);
+        return inb ? lp + ll : -INFINITY;
+    };
+    for (int s = 0; s < a.n_steps; ++s) {
+        const unsigned long long step = a.step0 + (unsigned long long)s;
+        const unsigned long long cyc = step / (unsigned long long)a.cps;
+        const int col = (int)(step % (unsigned long long)a.cps);
+        const size_t slot = ((size_t)group * a.ncyc + (size_t)(cyc - da.cyc0)) ;
+        const double* __restrict__ vs = a.V + slot * a.slab + (size_t)col * D;
+        const bool oned0 = a.vflag != nullptr && a.vflag[slot * a.cps + col] != 0;
+        double r0, Ea0;
+        drag_variates(a.key0, a.key1, gid, step, 0, oned0, r0, Ea0);
+        // start point = current point (LDS), end point = slow proposal
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            sC[i * 64] = ce[i];
+            sX[i * 64] = ce[i];
+            t[i] = fma(r0, vs[i], ce[i]);
+        }
+        if (a.periodic_mask) {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+                if ((a.periodic_mask >> i) & 1u)
+                    t[i] = wrap_periodic(t[i], C[cl.lo() + i], C[cl.hi() + i]);
+        }
+        double ce_lp, ce_ll;
+        double ce_lt = evaluate(ce_lp, ce_ll);
+        const bool dead = ce_lt == -INFINITY;   // mcmc.py:590-592
+        // ce <- end point (the current point stays in LDS until the final test)
+#pragma unroll
+        for (int i = 0; i < D; ++i) ce[i] = t[i];
+        double cs_lt = lpost;
+        double start_acc = cs_lt, end_acc = ce_lt;
+        for (int i = 1; i <= n; ++i) {
+            const unsigned long long f = step * (unsigned long long)n + (unsigned long long)(i - 1);
+            const unsigned long long fc = f / (unsigned long long)da.cps_f;
+            const int fcol = (int)(f % (unsigned long long)da.cps_f);
+            const size_t fslot = (size_t)group * da.ncyc_f + (size_t)(fc - da.cyc0_f);
+            const double* __restrict__ vf = da.Vf + fslot * da.slab_f + (size_t)fcol * D;
+            const bool oned = da.vflag_f != nullptr && da.vflag_f[fslot * da.cps_f + fcol] != 0;
+            double ri, Eai;
+            drag_variates(a.key0, a.key1, gid, step, (uint32_t)i, oned, ri, Eai);
+            auto delta = [&](int k) -> double {
+                double dk = ri * vf[k];
+                if ((a.periodic_mask >> k) & 1u)   // the reference wraps the DELTA (mcmc.py:606)
+                    dk = wrap_periodic(dk, C[cl.lo() + k], C[cl.hi() + k]);
+                return dk;
+            };
+#pragma unroll
+            for (int k = 0; k < D; ++k) t[k] = sC[k * 64] + delta(k);
+            double ps_lp, ps_ll;
+            const double ps_lt = evaluate(ps_lp, ps_ll);
+#pragma unroll
+            for (int k = 0; k < D; ++k) t[k] = ce[k] + delta(k);
+            double pe_lp, pe_ll;
+            const double pe_lt = evaluate(pe_lp, pe_ll);
+            const double frac = (double)i / (double)(1 + n);
+            const double pi = (1.0 - frac) * ps_lt + frac * pe_lt;
+            const double ci = (1.0 - frac) * cs_lt + frac * ce_lt;
+            const bool ok = !dead & (ps_lt != -INFINITY) & (pe_lt != -INFINITY) &
+                            metropolis(pi, ci, a.temperature, Eai);
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    sC[k * 64] = sC[k * 64] + delta(k);
+                    ce[k] = t[k];
+                }
+                cs_lt = ps_lt;
+                ce_lp = pe_lp; ce_ll = pe_ll; ce_lt = pe_lt;
+            }
+            start_acc += cs_lt;
+            end_acc += ce_lt;
+        }
+        const double navg = (double)(1 + n);
+        const bool accept = !dead & metropolis(end_acc / navg, start_acc / navg, a.temperature, Ea0);
+        // bookkeeping (mcmc.py:685-748); a dead slow proposal only adds weight
+        if (accept) {
+            if (burn > 0) --burn;
+            lpri = ce_lp; llik = ce_ll; lpost = ce_lt;
+            wt = 1; prej = 0; ++nacc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) ce[i] = sX[i * 64];
+            wt += 1;
+            if (!dead) {   // the end point is always inside the prior support here
+                const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
+                if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) a.x[(size_t)i * W + w] = ce[i];
+    a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
+    a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
+    a.n_accept[w] = nacc;
+    wave_add_accepts(a.accept_total, nacc - nacc0);
+}
+
 // ---------------------------------------------------------------- Haar basis kernel
 // Two (group, cycle) problems per 64-lane workgroup, one per half-wave (D <= 32 rows each):
 // Box-Muller normals on the basis Philox stream, Householder construction of
@@ -1136,7 +1291,18 @@ hipError_t launch_moments(const MomentArgs& a, int group_size, hipStream_t st)
     return hipGetLastError();
 }
 
-const DimKernels kKernels = {launch_step, launch_basis, launch_evaluate, launch_moments};
+hipError_t launch_drag(const DragArgs& a, hipStream_t st)
+{
+    const bool multi = a.s.n_modes > 1;
+    const size_t lds = sizeof(double) * 64 * (size_t)(2 * D + (multi ? a.s.n_modes : 0));
+    const dim3 grid(a.s.W / 64), block(64);
+    if (multi) hipLaunchKernelGGL(drag_kernel<true>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(drag_kernel<false>, grid, block, lds, st, a);
+    return hipGetLastError();
+}
+
+const DimKernels kKernels = {launch_step, launch_basis, launch_evaluate, launch_moments,
+                             launch_drag};
 
 }  // namespace
 }  // namespace mcmc

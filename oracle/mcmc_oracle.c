@@ -643,7 +643,8 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
         uint32_t group = walker0 / (uint32_t)gs + (uint32_t)g;
         double* V = (double*)malloc(sizeof(double) * (size_t)L0 * d);
         int32_t* f1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(L0 + Lf + 1));
-        double* Vf = drag ? (double*)malloc(sizeof(double) * (size_t)Lf * d * 2) : NULL;
+        double* Vf = drag ? (double*)malloc(sizeof(double) * (size_t)Lf * d) : NULL;
+        double* Vstep = drag ? (double*)malloc(sizeof(double) * (size_t)nd * d) : NULL;
         int32_t* f1f = f1 + L0;
         uint64_t have_cycle = UINT64_MAX, have_f[2] = {UINT64_MAX, UINT64_MAX};
         for (int s = 0; s < n_steps; ++s) {
@@ -664,26 +665,22 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 }
                 continue;
             }
-            /* dragging: interpolation step i of slow step `step` is fast step step*nd + i-1 */
+            /* dragging: interpolation step i of slow step `step` is fast step step*nd + i-1;
+             * its direction is copied out of the (one-cycle) cache of fast directions */
             const double* vfp[256];
             int oned[257];
             oned[0] = f1[col];
             for (int i = 1; i <= nd; ++i) {
                 uint64_t f = step * (uint64_t)nd + (uint64_t)(i - 1);
                 uint64_t cf = f / (uint64_t)Lf;
-                int slot = (int)(cf & 1);            /* two cycles of fast directions cached */
-                if (have_f[slot] != cf) {
-                    orc_basis_blocked(p, group, (uint32_t)cf, 2, Vf + (size_t)slot * Lf * d,
-                                      f1f);
-                    have_f[slot] = cf;
+                int fcol = (int)(f % (uint64_t)Lf);
+                if (have_f[0] != cf) {
+                    orc_basis_blocked(p, group, (uint32_t)cf, 2, Vf, f1f);
+                    have_f[0] = cf;
                 }
-                vfp[i - 1] = Vf + ((size_t)slot * Lf + (size_t)(f % (uint64_t)Lf)) * d;
-                oned[i] = 0;
-                {   /* 1-d flag of that slot: recomputed from the schedule */
-                    int32_t blk[4096], bas[4096], cl[4096];
-                    orc_block_schedule(p, group, (uint32_t)cf, 2, blk, bas, cl);
-                    oned[i] = B->size[blk[f % (uint64_t)Lf]] == 1;
-                }
+                memcpy(Vstep + (size_t)(i - 1) * d, Vf + (size_t)fcol * d, sizeof(double) * (size_t)d);
+                vfp[i - 1] = Vstep + (size_t)(i - 1) * d;
+                oned[i] = f1f[fcol];
             }
             for (int l = 0; l < gs; ++l) {
                 int w = g * gs + l;
@@ -694,7 +691,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 total += drag_core(p, st, w, v, vfp, r, Ea);
             }
         }
-        free(V); free(f1); free(Vf);
+        free(V); free(f1); free(Vf); free(Vstep);
     }
     return total;
 }

@@ -215,6 +215,33 @@ def test_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, over, steps):
     assert c["steps"] == steps and c["accepted"] == int(st.n_accept.sum())
 
 
+@pytest.mark.parametrize("d,W,gs,K,blocks,last_slow,n_drag,steps,extra", [
+    (5, 256, 64, 1, [[0, 1], [2, 3, 4]], 0, 6, 40, {}),
+    # one-parameter blocks on both sides, mixture target, two slow blocks
+    (7, 256, 128, 2, [[5], [0, 3], [1], [6, 2, 4]], 1, 3, 45, {}),
+    (30, 256, 256, 1, [list(range(10)), list(range(10, 30))], 0, 4, 25, {}),
+    # normal priors, a periodic parameter, temperature, burn-in
+    (6, 128, 64, 1, [[0, 1, 2], [3, 4, 5]], 0, 5, 40,
+     dict(kinds=[0, 1, 0, 1, 0, 0], a=[0.0, 0.5, 0.0, 0.5, 0.0, 0.0],
+          b=[1.0, 0.2, 1.0, 0.3, 1.0, 1.0], periodic=[0, 0, 1, 0, 0, 1], T=1.7, burn_in=3))])
+def test_dragging_steps_bit_exact(d, W, gs, K, blocks, last_slow, n_drag, steps, extra):
+    """(f)1: the dragging step (mcmc.py:564-668) against the oracle's drag_core, bit for bit:
+    slow and fast direction sequences, interpolation steps, final averaged test, bookkeeping."""
+    eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.4, 0.6] if K == 2 else None,
+                              blocks=blocks, over=[1] * (last_slow + 1) + [2] * (len(blocks) - last_slow - 1),
+                              drag_last_slow=last_slow, drag_steps=n_drag, **extra)
+    n_slow = sum(len(b) for b in blocks[:last_slow + 1])
+    assert eng.cycle_length() == prob.cycle_length(1) == n_slow
+    for n in (1, steps // 3, steps - steps // 3 - 1):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+    c = eng.counters()
+    assert c["steps"] == steps and c["accepted"] == int(st.n_accept.sum())
+    assert c["accepted"] > 0.05 * W * steps
+
+
 def test_blocking_errors_are_loud():
     eng = E.Engine(4, 64, group_size=64, seed=1)
     with pytest.raises(E.EngineError, match="do not contain all"):
