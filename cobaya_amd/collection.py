@@ -20,7 +20,9 @@ class SampleCollection:
         self.temperature = float(temperature)
         self.name = name
         self.minuslogprior_names = ["minuslogprior__0"]
-        self.chi2_names = ["chi2__" + like_name]
+        # one chi2__<name> column per likelihood (collection.py:154-161)
+        like_names = [like_name] if isinstance(like_name, str) else list(like_name)
+        self.chi2_names = ["chi2__" + n for n in like_names]
         self.columns = (["weight", "minuslogpost"] + self.sampled_params + self.derived_params
                         + ["minuslogprior"] + self.minuslogprior_names + ["chi2"]
                         + self.chi2_names)
@@ -28,8 +30,9 @@ class SampleCollection:
         self._data = None
 
     # ------------------------------------------------------------------ filling
-    def add_rows(self, weight, logpost, x, logprior, loglike, derived=None):
-        """Vectorised SampleCollection.add (collection.py:402-427, 519-559)."""
+    def add_rows(self, weight, logpost, x, logprior, loglike, derived=None, loglike_parts=None):
+        """Vectorised SampleCollection.add (collection.py:402-427, 519-559).  loglike_parts
+        [n][n_likelihoods]: the log-likelihood of every component (default: the only one)."""
         weight = np.atleast_1d(np.asarray(weight, dtype=np.float64))
         n = len(weight)
         x = np.asarray(x, dtype=np.float64).reshape(n, len(self.sampled_params))
@@ -40,7 +43,12 @@ class SampleCollection:
             cols += [derived[:, i] for i in range(derived.shape[1])]
         mlp = -np.asarray(logprior, dtype=np.float64)
         chi2 = -2 * np.asarray(loglike, dtype=np.float64)
-        cols += [mlp, mlp, chi2, chi2]
+        cols += [mlp, mlp, chi2]
+        if loglike_parts is None:
+            cols += [chi2] * len(self.chi2_names)
+        else:
+            parts = np.asarray(loglike_parts, dtype=np.float64).reshape(n, len(self.chi2_names))
+            cols += [-2 * parts[:, i] for i in range(parts.shape[1])]
         self._blocks.append(np.column_stack(cols))
         self._data = None
 

@@ -17,10 +17,39 @@ Reference behaviour mirrored here (paths relative to the reference checkout):
 """
 from __future__ import annotations
 
+import itertools
 import numbers
 from dataclasses import dataclass, field
 
 import numpy as np
+
+
+OVERHEAD_TIME = 0.0003  # conventions.py:141
+
+
+def sort_parameter_blocks(blocks, speeds, footprints, oversample_power=0.0):
+    """tools.py:955-1006: ordering of the blocks that minimises the cost of varying every
+    parameter once after the Cholesky mixing; returns (ordering, per-parameter cumulative
+    costs, oversampling factors) in that order."""
+    n_per_block = np.array([len(b) for b in blocks])
+    all_costs = 1 / np.array(speeds, dtype=float)
+    fps = np.array(footprints)
+    tri_lower = np.tri(len(n_per_block))
+
+    def cost_per_param_per_block(ordering):
+        return np.minimum(1, tri_lower.T.dot(fps[ordering])).dot(all_costs)
+
+    if oversample_power >= 1:
+        best, _, _ = sort_parameter_blocks(blocks, speeds, footprints, 1 - 1e-3)
+        orderings = [best]
+    else:
+        orderings = list(itertools.permutations(np.arange(len(n_per_block))))
+    costs = np.array([cost_per_param_per_block(list(o)) for o in orderings])
+    factors = np.array([(c[0] / c) ** oversample_power for c in costs])
+    total = np.array([(n_per_block[list(o)] * factors[i]).dot(costs[i])
+                      for i, o in enumerate(orderings)])
+    i_opt = int(np.argmin(total))
+    return orderings[i_opt], costs[i_opt], np.floor(factors[i_opt]).astype(int)
 
 
 class UnsupportedModel(ValueError):
@@ -97,6 +126,7 @@ class ProblemSpec:
     normalized: bool = True
     has_derived: bool = False
     labels: dict = field(default_factory=dict)
+    components: list = field(default_factory=list)  # one dict per likelihood (_parse_likelihood)
 
     @property
     def d(self):
@@ -210,87 +240,196 @@ class ProblemSpec:
         spec = cls(sampled, derived, np.array(kinds), np.array(a, float), np.array(b, float),
                    np.array(per), refs, props, labels=labels)
         likes = info.get("likelihood") or {}
-        if len(likes) != 1:
-            raise UnsupportedModel("exactly one likelihood (gaussian_mixture, gaussian or "
-                                   f"one) is supported, got {list(likes)}")
-        (lname, linfo), = likes.items()
+        if not likes:
+            raise UnsupportedModel("no likelihood given (use `one` for prior-only sampling)")
+        comps = [cls._parse_likelihood(lname, linfo, sampled, derived, single=len(likes) == 1)
+                 for lname, linfo in likes.items()]
+        spec.components = comps
+        if len(comps) == 1:
+            c = comps[0]
+            spec.like_name, spec.like_kind = c["name"], c["kind"]
+            spec.means, spec.covs, spec.weights = c["means"], c["covs"], c["weights"]
+            spec.normalized, spec.has_derived = c["normalized"], c["has_derived"]
+            return spec
+        # several likelihoods over disjoint parameter sets: the posterior is the product, i.e.
+        # ONE mixture whose modes are all combinations of the components' modes, with
+        # block-diagonal covariances (what the device evaluates); the per-likelihood chi2
+        # columns of the output are recomputed on the host (component_loglikes).
+        claimed = [i for c in comps for i in c["idx"]]
+        if sorted(claimed) != list(range(spec.d)):
+            raise UnsupportedModel(
+                "with several likelihoods every sampled parameter must be the input of "
+                "exactly one of them (distinct `input_params_prefix`es)")
+        for c in comps:
+            if c["kind"] == "one" or not c["normalized"] or c["has_derived"]:
+                raise UnsupportedModel(
+                    f"likelihood '{c['name']}': only normalized gaussian / gaussian_mixture "
+                    "likelihoods without derived parameters can be combined")
+        n_modes = int(np.prod([len(c["means"]) for c in comps]))
+        if n_modes > 16:
+            raise UnsupportedModel(f"the product of the mixtures has {n_modes} modes (max 16)")
+        means, covs, weights = [], [], []
+        for combo in itertools.product(*[range(len(c["means"])) for c in comps]):
+            m, S, w = np.zeros(spec.d), np.zeros((spec.d, spec.d)), 1.0
+            for c, k in zip(comps, combo):
+                m[c["idx"]] = c["means"][k]
+                S[np.ix_(c["idx"], c["idx"])] = c["covs"][k]
+                wk = c["weights"]
+                wk = np.full(len(c["means"]), 1.0 / len(c["means"])) if wk is None else wk / wk.sum()
+                w *= wk[k]
+            means.append(m), covs.append(S), weights.append(w)
+        spec.like_name, spec.like_kind = comps[0]["name"], "gaussian_mixture"
+        spec.means, spec.covs = np.array(means), np.array(covs)
+        spec.weights = np.array(weights) if n_modes > 1 else None
+        return spec
+
+    @staticmethod
+    def _parse_likelihood(lname, linfo, sampled, derived, single):
+        """One entry of the `likelihood` block -> dict(name, kind, idx, means, covs, weights,
+        normalized, has_derived, speed).  Parameter routing by `input_params_prefix`
+        (model.py:1169-1172)."""
         linfo = dict(linfo or {})
         lclass = linfo.pop("class", lname)
         lclass = str(lclass).split(".")[-1].lower().replace("_", "")
-        spec.like_name = lname
-        d = spec.d
+        d_all = len(sampled)
         in_prefix = linfo.pop("input_params_prefix", "") or ""
         out_prefix = linfo.pop("output_params_prefix", "") or ""
-        linfo.pop("speed", None)
+        speed = linfo.pop("speed", -1)
         linfo.pop("stop_at_error", None)
+        comp = {"name": lname, "kind": "one", "idx": [], "means": None, "covs": None,
+                "weights": None, "normalized": True, "has_derived": False,
+                "speed": float(speed if speed is not None else -1)}
         if lclass == "one":
             linfo.pop("noise", None)
-            spec.like_kind = "one"
             if derived:
                 raise UnsupportedModel("derived parameters need a gaussian_mixture with "
                                        "`derived: True`")
-        elif lclass in ("gaussianmixture", "gaussian"):
-            inputs = [p for p in sampled if p.startswith(in_prefix)]  # model.py:1169-1172
-            if inputs != sampled:
-                raise UnsupportedModel(
-                    f"input_params_prefix '{in_prefix}' selects {inputs} but all sampled "
-                    f"parameters {sampled} must feed the likelihood")
-            if lclass == "gaussianmixture":
-                means, covs = linfo.pop("means", None), linfo.pop("covs", None)
-                if means is None or covs is None:
-                    raise UnsupportedModel("You must specify both a mean (or a list of them) "
-                                           "and a covariance matrix, or a list of them.")
-                means = np.atleast_1d(np.array(means, dtype=float))
-                while means.ndim < 2:
-                    means = means[None]
-                covs = np.atleast_1d(np.array(covs, dtype=float))
-                while covs.ndim < 3:
-                    covs = covs[None]
-                weights = linfo.pop("weights", None)
-                spec.has_derived = bool(linfo.pop("derived", False))
-                spec.like_kind = "gaussian_mixture"
-            else:
-                mean, cov = linfo.pop("mean", None), linfo.pop("cov", None)
-                if mean is None or cov is None:
-                    raise UnsupportedModel("You must specify both a mean and a covariance "
-                                           "matrix.")
-                means = np.atleast_1d(np.array(mean, dtype=float))[None]
-                covs = np.atleast_2d(np.array(cov, dtype=float))[None]
-                weights = None
-                spec.normalized = bool(linfo.pop("normalized", True))
-                spec.like_kind = "gaussian"
-            if linfo:
-                raise UnsupportedModel(f"unknown options for likelihood '{lname}': "
-                                       f"{sorted(linfo)}")
-            K = len(means)
-            if covs.shape != (K, means.shape[1], means.shape[1]):
-                raise UnsupportedModel("The dimensionalities guessed from mean(s) and "
-                                       "cov(s) do not match!")
-            if means.shape[1] != d:
-                raise UnsupportedModel(
-                    f"The dimensionality is {means.shape[1]} (guessed from given means and "
-                    f"covmats) but was passed {d} parameters instead.")
-            if weights is not None and not np.isscalar(weights):
-                weights = np.array(weights, dtype=float)
-                if len(weights) != K:
-                    raise UnsupportedModel("There must be as many weights as components.")
-            else:
-                weights = None
-            spec.means, spec.covs, spec.weights = means, covs, weights
-            outs = [p for p in derived if p.startswith(out_prefix)]
-            if spec.has_derived:
-                if len(outs) != d * K or outs != derived:
-                    raise UnsupportedModel(
-                        "The number of derived parameters must be equal to the "
-                        f"dimensionality times the number of modes, i.e. {d} x {K} = "
-                        f"{d * K}, but was given {len(derived)} derived parameters.")
-            elif derived:
-                raise UnsupportedModel("Derived parameters were requested, but 'derived' "
-                                       "option is False.")
-        else:
+            return comp
+        if lclass not in ("gaussianmixture", "gaussian"):
             raise UnsupportedModel(f"likelihood '{lname}' is not one of gaussian_mixture, "
                                    "gaussian, one")
-        return spec
+        inputs = [p for p in sampled if p.startswith(in_prefix)]  # model.py:1169-1172
+        if single and inputs != sampled:
+            raise UnsupportedModel(
+                f"input_params_prefix '{in_prefix}' selects {inputs} but all sampled "
+                f"parameters {sampled} must feed the likelihood")
+        comp["idx"] = [sampled.index(p) for p in inputs]
+        d = len(inputs)
+        if lclass == "gaussianmixture":
+            means, covs = linfo.pop("means", None), linfo.pop("covs", None)
+            if means is None or covs is None:
+                raise UnsupportedModel("You must specify both a mean (or a list of them) "
+                                       "and a covariance matrix, or a list of them.")
+            means = np.atleast_1d(np.array(means, dtype=float))
+            while means.ndim < 2:
+                means = means[None]
+            covs = np.atleast_1d(np.array(covs, dtype=float))
+            while covs.ndim < 3:
+                covs = covs[None]
+            weights = linfo.pop("weights", None)
+            comp["has_derived"] = bool(linfo.pop("derived", False))
+            comp["kind"] = "gaussian_mixture"
+        else:
+            mean, cov = linfo.pop("mean", None), linfo.pop("cov", None)
+            if mean is None or cov is None:
+                raise UnsupportedModel("You must specify both a mean and a covariance "
+                                       "matrix.")
+            means = np.atleast_1d(np.array(mean, dtype=float))[None]
+            covs = np.atleast_2d(np.array(cov, dtype=float))[None]
+            weights = None
+            comp["normalized"] = bool(linfo.pop("normalized", True))
+            comp["kind"] = "gaussian"
+        if linfo:
+            raise UnsupportedModel(f"unknown options for likelihood '{lname}': "
+                                   f"{sorted(linfo)}")
+        K = len(means)
+        if covs.shape != (K, means.shape[1], means.shape[1]):
+            raise UnsupportedModel("The dimensionalities guessed from mean(s) and "
+                                   "cov(s) do not match!")
+        if means.shape[1] != d:
+            raise UnsupportedModel(
+                f"The dimensionality is {means.shape[1]} (guessed from given means and "
+                f"covmats) but was passed {d} parameters instead.")
+        if weights is not None and not np.isscalar(weights):
+            weights = np.array(weights, dtype=float)
+            if len(weights) != K:
+                raise UnsupportedModel("There must be as many weights as components.")
+        else:
+            weights = None
+        comp["means"], comp["covs"], comp["weights"] = means, covs, weights
+        outs = [p for p in derived if p.startswith(out_prefix)]
+        if comp["has_derived"]:
+            if len(outs) != d * K or outs != derived:
+                raise UnsupportedModel(
+                    "The number of derived parameters must be equal to the "
+                    f"dimensionality times the number of modes, i.e. {d} x {K} = "
+                    f"{d * K}, but was given {len(derived)} derived parameters.")
+        elif derived and single:
+            raise UnsupportedModel("Derived parameters were requested, but 'derived' "
+                                   "option is False.")
+        del d_all
+        return comp
+
+    # ----------------------------------------------------------------- several likelihoods
+    def component_loglikes(self, x):
+        """log-likelihood of every likelihood component at the points x[n][d] (host side, for
+        the chi2__<name> output columns; gaussian_mixture.py:138-163)."""
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        out = np.zeros((len(x), len(self.components)))
+        for ic, c in enumerate(self.components):
+            if c["kind"] == "one":
+                continue
+            xs = x[:, c["idx"]]
+            K, n = c["means"].shape
+            w = c["weights"]
+            w = np.full(K, 1.0 / K) if w is None else w / w.sum()
+            a = np.empty((len(x), K))
+            for k in range(K):
+                L = np.linalg.cholesky(c["covs"][k])
+                y = np.linalg.solve(L, (xs - c["means"][k]).T)
+                norm = n * np.log(2 * np.pi) + 2 * np.sum(np.log(np.diag(L)))
+                a[:, k] = -0.5 * ((norm if c["normalized"] else 0.0) + np.sum(y * y, axis=0))
+            amax = a.max(axis=1, keepdims=True)
+            out[:, ic] = np.log(np.sum(w * np.exp(a - amax), axis=1)) + amax[:, 0]
+        return out
+
+    def param_blocking(self, oversample_power=0.0, split_fast_slow=False):
+        """Model.get_param_blocking_for_sampler (model.py:1340-1467) with
+        tools.sort_parameter_blocks (tools.py:955-1006): parameters grouped by the likelihood
+        they feed, blocks ordered by the cost-optimal permutation, oversampling factors
+        floor((cost_0 / cost_b) ** oversample_power).  Returns (blocks of names, factors)."""
+        comps = self.components
+        speeds = np.array([c["speed"] for c in comps], dtype=float)
+        pos = speeds[speeds > 0]
+        min_speed = pos.min() if len(pos) else 1.0
+        speeds = 1.0 / (1.0 / np.maximum(speeds, min_speed) + OVERHEAD_TIME)
+        if len(comps) == 1 or all(not c["idx"] for c in comps[1:]):
+            blocks = [list(self.sampled)]
+            footprints = [tuple([1] + [0] * (len(comps) - 1))]
+        else:
+            blocks = [[self.sampled[i] for i in c["idx"]] for c in comps if c["idx"]]
+            footprints = [tuple(int(j == ic) for j in range(len(comps)))
+                          for ic, c in enumerate(comps) if c["idx"]]
+        if not split_fast_slow:
+            order, costs, factors = sort_parameter_blocks(blocks, speeds, footprints,
+                                                          oversample_power)
+            return [blocks[i] for i in order], [int(f) for f in factors]
+        if len(blocks) == 1:
+            raise UnsupportedModel("Requested fast/slow separation, but all parameters have "
+                                   "the same speed.")
+        order, costs, _ = sort_parameter_blocks(blocks, speeds, footprints, 0.0)
+        blocks_sorted = [blocks[i] for i in order]
+        fp_sorted = np.array(footprints)[list(order)]
+        per_block = costs - np.concatenate([costs[1:], [0]])
+        i_last_slow = int(np.argmax(np.log(per_block[:-1]) - np.log(per_block[1:])))
+        split = [sum(blocks_sorted[:i_last_slow + 1], []), sum(blocks_sorted[i_last_slow + 1:], [])]
+        fp_split = np.clip(np.array([fp_sorted[:i_last_slow + 1].sum(axis=0),
+                                     fp_sorted[i_last_slow + 1:].sum(axis=0)]), 0, 1)
+        _, _, factors = sort_parameter_blocks(split, speeds, fp_split, oversample_power)
+        # (the reference only WARNS when the fast factor is 1, model.py:1437-1444)
+        factors = ([int(factors[0])] * (1 + i_last_slow)
+                   + [int(factors[1])] * (len(blocks) - (1 + i_last_slow)))
+        return blocks_sorted, factors
 
     @classmethod
     def from_cobaya_model(cls, model):

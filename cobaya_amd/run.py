@@ -42,7 +42,6 @@ def run(info_or_yaml, **overrides):
     sampler = MCMCHip(opts or {}, spec, output=info.get("output"), name=name,
                       resume=bool(info.get("resume")))
     updated = copy.deepcopy(info)
-    updated["sampler"] = {name: {k: getattr(sampler, k)
-                                 for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}}
+    updated["sampler"] = {name: sampler.info()}
     sampler.run()
     return updated, sampler

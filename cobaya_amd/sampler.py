@@ -135,21 +135,20 @@ class MCMCHip:
         """mcmc.py:111-271."""
         spec = self.spec
         d = spec.d
-        for key in ("drag", "blocking"):
-            if getattr(self, key):
-                raise LoggedError(log, "`%s` (fast/slow blocking) is not supported by mcmc_hip: "
-                                       "analytic targets form a single parameter block", key)
         if self.temperature is None:
             self.temperature = 1
         if self.temperature < 1:
             log.warning("Sampling temperatures <1 can lead to innacurate inference.")
         self.temperature = float(self.temperature)
-        # 'd' units: one cycle = d steps (single block, oversampling 1; mcmc.py:405-410)
-        self.cycle_length = d
-        self.max_tries = _number_with_units(self.max_tries, "d", d)
-        self.learn_every = int(_number_with_units(self.learn_every, "d", d))
-        self.burn_in = int(_number_with_units(self.burn_in, "d", d))
-        self.steps_per_launch = max(1, int(_number_with_units(self.steps_per_launch, "d", d)))
+        self.set_proposer_blocking()
+        # 'd' units: one cycle of the proposer, thinned (mcmc.py:400-410)
+        unit = max(1, self.cycle_length // self.output_thin)
+        self.max_tries = _number_with_units(self.max_tries, "d", unit)
+        self.learn_every = int(_number_with_units(self.learn_every, "d", unit))
+        self.burn_in = int(_number_with_units(self.burn_in, "d", unit))
+        self.steps_per_launch = max(1, int(_number_with_units(self.steps_per_launch, "d", unit)))
+        if self.drag:  # a dragging step costs 1 + 2 * drag_interp_steps evaluations
+            self.steps_per_launch = max(1, self.steps_per_launch // (1 + self.drag_interp_steps))
         if self.callback_every is None:
             self.callback_every = self.learn_every
         if self.emit not in ("snapshots", "chains"):
@@ -186,10 +185,18 @@ class MCMCHip:
         try:
             self.engine = Engine(d, W, group_size=int(self.group_size), device=int(device),
                                  seed=self.seed, walker_offset=self.rank * W,
-                                 burn_in=self.burn_in, temperature=self.temperature,
+                                 burn_in=self.burn_in * self.output_thin,  # mcmc.py:265
+                                 temperature=self.temperature,
                                  proposal_scale=float(self.proposal_scale),
                                  max_tries=float(self.max_tries), emit_capacity=cap)
             spec.configure(self.engine)
+            if len(self.blocks) > 1 or self.oversampling_factors[0] != 1:
+                self.engine.set_blocking(
+                    [[spec.sampled.index(p) for p in b] for b in self.blocks],
+                    self.oversampling_factors,
+                    self.i_last_slow_block if self.drag else -1,
+                    self.drag_interp_steps if self.drag else 0)
+                assert self.engine.cycle_length() == self.cycle_length
         except EngineError as e:
             raise LoggedError(log, "%s", str(e)) from e
         # initial proposal covariance (sampler.py:485-685), tempered (mcmc.py:438-440)
@@ -229,10 +236,84 @@ class MCMCHip:
         self.engine.set_moment_shift(self._shift)
         self._init_bookkeeping()
 
+    def set_proposer_blocking(self):
+        """mcmc.py:320-410: parameter blocks and oversampling factors (manual `blocking` or
+        from the likelihoods' speeds), the dragging decision, output thinning and the cycle
+        length that the 'd' units refer to."""
+        spec = self.spec
+        if self.blocking:
+            try:  # model.py:1469-1508 check_blocking
+                factors, blocks = zip(*list(self.blocking))
+                blocks = [list(b) for b in blocks]
+                factors = [int(f) for f in factors]
+            except (TypeError, ValueError) as e:
+                raise LoggedError(log, "Manual blocking not understood. Check "
+                                       "documentation.") from e
+            flat = [p for b in blocks for p in b]
+            dup = sorted({p for p in flat if flat.count(p) > 1})
+            if dup:
+                raise LoggedError(log, "Manual blocking: repeated parameters: %r", dup)
+            missing = [p for p in spec.sampled if p not in flat]
+            if missing:
+                raise LoggedError(log, "Manual blocking: missing parameters: %r", missing)
+            unknown = [p for p in flat if p not in spec.sampled]
+            if unknown:
+                raise LoggedError(log, "Manual blocking: unknown parameters: %r", unknown)
+            if list(factors) != sorted(factors):
+                log.warning("Manual blocking: speed-blocking *apparently* non-optimal: "
+                            "oversampling factors must go from small (slow) to large (fast).")
+        else:
+            try:
+                blocks, factors = spec.param_blocking(
+                    oversample_power=float(self.oversample_power or 0),
+                    split_fast_slow=bool(self.drag))
+            except UnsupportedModel as e:
+                raise LoggedError(log, "%s", str(e)) from e
+        self.blocks, self.oversampling_factors = blocks, list(factors)
+        self.drag = bool(self.drag)
+        if self.drag:  # mcmc.py:333-360
+            if len(blocks) == 1:
+                self.drag = False
+                log.warning("Dragging disabled: not possible if there is only one block.")
+            elif max(factors) / min(factors) < 2:
+                self.drag = False
+                log.warning("Dragging disabled: speed ratios < 2.")
+        self.drag_interp_steps = 0
+        if self.drag:
+            n_slow = sum(len(b) for b in blocks[:1 + self.i_last_slow_block])
+            n_fast = spec.d - n_slow
+            self.drag_interp_steps = int(np.round(
+                factors[self.i_last_slow_block + 1] * n_fast / n_slow))
+            if self.drag_interp_steps < 2:
+                self.drag = False
+                log.warning("Dragging disabled: speed ratio and fast-to-slow ratio not large "
+                            "enough.")
+        self.output_thin = 1
+        if self.drag:
+            log.info("Dragging with number of interpolating steps: %d", self.drag_interp_steps)
+            self.cycle_length = sum(len(b) for b in blocks[:1 + self.i_last_slow_block])
+            if self.emit == "chains":
+                raise LoggedError(log, "emit: chains is not available with dragging")
+        else:
+            if any(f > 1 for f in factors):
+                log.info("Oversampling with factors: %r", list(zip(factors, blocks)))
+                if self.oversample_thin:  # mcmc.py:377-389
+                    self.output_thin = int(np.round(
+                        sum(len(b) * o for b, o in zip(blocks, factors)) / spec.d))
+            self.cycle_length = sum(len(b) * o for b, o in zip(blocks, factors))
+
+    @property
+    def i_last_slow_block(self):
+        """mcmc.py:273-279: index of the last slow block of the fast/slow split."""
+        if self.drag:
+            return next(i for i, o in enumerate(self.oversampling_factors) if o != 1) - 1
+        return 0
+
     def _init_bookkeeping(self):
         spec = self.spec
-        self.collection = SampleCollection(spec.sampled, spec.derived, spec.like_name,
+        self.collection = SampleCollection(spec.sampled, spec.derived, self._like_names(),
                                            self.temperature, name=str(1 + self.rank))
+        self._thin_carry = {}    # chains mode with thinned output: added weight per walker
         self._rows = []          # (walker, weight, logpost, logprior, loglike, x...) blocks
         self._n_rows = 0
         self._intervals = []     # per checkpoint: (n_snapshots, group_sum[G,d], pooled_S[d,d])
@@ -454,7 +535,35 @@ class MCMCHip:
         log.info("Resumed from %s at %d steps per walker.", self._state_file(), self.n_steps_raw)
 
     # ------------------------------------------------------------------ storage
+    def _like_names(self):
+        return [c["name"] for c in self.spec.components] or [self.spec.like_name]
+
+    def _thin_rows(self, rows):
+        """OneSamplePoint.add_to_collection (collection.py:1362-1383) for emitted chain rows:
+        a walker's weights accumulate; a row is written when the sum reaches `output_thin`,
+        with weight sum // output_thin, the remainder carried to its next rows."""
+        thin = self.output_thin
+        order = np.argsort(rows[:, 0], kind="stable")
+        rows = rows[order]
+        ids = rows[:, 0].astype(np.int64)
+        w = rows[:, 1].astype(np.int64)
+        cum = np.cumsum(w)
+        first = np.r_[0, np.flatnonzero(np.diff(ids)) + 1]
+        base = np.repeat(cum[first] - w[first], np.diff(np.r_[first, len(ids)]))
+        carry = np.array([self._thin_carry.get(int(i), 0) for i in ids[first]], dtype=np.int64)
+        total = cum - base + np.repeat(carry, np.diff(np.r_[first, len(ids)]))
+        q, q_prev = total // thin, (total - w) // thin
+        last = np.r_[first[1:] - 1, len(ids) - 1]
+        for i, t in zip(ids[last], total[last]):
+            self._thin_carry[int(i)] = int(t % thin)
+        keep = q > q_prev
+        out = rows[keep].copy()
+        out[:, 1] = (q - q_prev)[keep]
+        return out
+
     def _store_rows(self, rows):
+        if len(rows) and self.emit == "chains" and self.output_thin > 1:
+            rows = self._thin_rows(rows)
         if len(rows) and self._n_rows < self.max_rows:
             self._rows.append(rows)
             self._n_rows += len(rows)
@@ -624,14 +733,16 @@ class MCMCHip:
         rows = (np.vstack(self._rows) if self._rows else np.zeros((0, d + 5)))
         if self.emit == "chains" and len(rows):
             rows = rows[np.argsort(rows[:, 0], kind="stable")]  # chain after chain
-        coll = SampleCollection(spec.sampled, spec.derived, spec.like_name, self.temperature,
+        coll = SampleCollection(spec.sampled, spec.derived, self._like_names(), self.temperature,
                                 name=str(1 + self.rank))
         if len(rows):
             derived = None
             if spec.derived:
                 derived = np.vstack([self.engine.evaluate(rows[i:i + 65536, 5:], derived=True)[2]
                                      for i in range(0, len(rows), 65536)])
-            coll.add_rows(rows[:, 1], rows[:, 2], rows[:, 5:], rows[:, 3], rows[:, 4], derived)
+            parts = (spec.component_loglikes(rows[:, 5:]) if len(spec.components) > 1 else None)
+            coll.add_rows(rows[:, 1], rows[:, 2], rows[:, 5:], rows[:, 3], rows[:, 4], derived,
+                          parts)
         self._chain_ids = rows[:, 0].astype(np.int64) if len(rows) else np.zeros(0, np.int64)
         return coll
 
@@ -676,7 +787,10 @@ class MCMCHip:
         return self.engine.get_state()
 
     def info(self):
-        return {k: getattr(self, k) for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}
+        out = {k: getattr(self, k) for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}
+        # mcmc.py:391: the blocking actually used, so that a resumed run repeats it
+        out["blocking"] = [[int(o), list(b)] for o, b in zip(self.oversampling_factors, self.blocks)]
+        return out
 
     # ------------------------------------------------------------------ output
     def _write_output(self):

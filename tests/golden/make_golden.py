@@ -317,6 +317,39 @@ def g10_blocked():
     save("g10_blocked", **out)
 
 
+def blocking_info(speeds):
+    """Three Gaussian likelihoods over disjoint parameters with the given speeds."""
+    return {
+        "likelihood": {
+            "slow": {"class": "gaussian_mixture", "means": [[0.2, 0]],
+                     "covs": [[[0.1, 0.05], [0.05, 0.2]]], "input_params_prefix": "a_",
+                     "speed": speeds[0]},
+            "fast": {"class": "gaussian_mixture", "means": [[0.5, 0.5, 0.5]],
+                     "covs": [(np.eye(3) * 0.01).tolist()], "input_params_prefix": "b_",
+                     "speed": speeds[1]},
+            "mid": {"class": "gaussian_mixture", "means": [[0.5]], "covs": [[[0.01]]],
+                    "input_params_prefix": "c_", "speed": speeds[2]}},
+        "params": {"a_0": {"prior": {"min": -3, "max": 3}}, "b_0": {"prior": {"min": 0, "max": 1}},
+                   "a_1": {"prior": {"min": -3, "max": 3}}, "b_1": {"prior": {"min": 0, "max": 1}},
+                   "c_0": {"prior": {"min": 0, "max": 1}}, "b_2": {"prior": {"min": 0, "max": 1}}}}
+
+
+def g11_param_blocking():
+    """(f)1: Model.get_param_blocking_for_sampler (model.py:1340-1467) decisions."""
+    cases = []
+    for speeds in ([1, 50, 7], [30, 2, 500], [5, 5, 5], [-1, 10, -1]):
+        for power, split in ((0.0, False), (0.4, False), (1.0, False), (0.4, True), (0.7, True)):
+            model = get_model(blocking_info(speeds))
+            blocks, factors = model.get_param_blocking_for_sampler(
+                split_fast_slow=split, oversample_power=power)
+            cases.append({"speeds": speeds, "oversample_power": power, "split": split,
+                          "blocks": [list(b) for b in blocks],
+                          "factors": [int(f) for f in factors]})
+    with open(os.path.join(HERE, "g11_param_blocking.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("wrote g11_param_blocking.json", len(cases), "cases")
+
+
 def g7_multichain():
     """a16 multi-chain branch (mcmc.py:787-793, 856-889, 1021-1023) driven without MPI:
     m samplers in one process, `more_than_one_process` and `mpi.array_gather` patched so
@@ -423,3 +456,4 @@ if __name__ == "__main__":
     g7_multichain()
     g9_initial_covmat()
     g10_blocked()
+    g11_param_blocking()

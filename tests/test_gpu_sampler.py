@@ -120,7 +120,8 @@ def test_fixed3_learns_from_bad_initial_proposal():
 def test_unsupported_inputs_raise():
     info = dict(QUICK)
     info["sampler"] = {"mcmc_hip": {"drag": True, "n_walkers": 64}}
-    with pytest.raises(LoggedError, match="not supported"):
+    # one likelihood = one speed: the reference refuses the split too (model.py:1402-1407)
+    with pytest.raises(LoggedError, match="all parameters have the same speed"):
         run(info)
     info["sampler"] = {"mcmc": {}}
     with pytest.raises(LoggedError, match="only runs"):
@@ -305,4 +306,81 @@ def test_temperature_2_samples_the_tempered_posterior():
     row = coll.data.iloc[-1]
     logpost = -(row["minuslogprior"] + 0.5 * row["chi2"])
     assert row["minuslogpost"] == pytest.approx(-logpost / 2.0, rel=1e-12)
+    sampler.close()
+
+
+def _two_speed_info(sampler_opts):
+    """A slow 2-d Gaussian on a_* and a 50x faster 3-d Gaussian on b_* (the shape of the
+    reference's tests/common_sampler.py:192-260 speed test)."""
+    rng = np.random.default_rng(17)
+    A = rng.normal(size=(3, 3))
+    cov_b = (A @ A.T / 3 + np.eye(3)) * 0.01
+    info = {
+        "likelihood": {
+            "slow": {"class": "gaussian_mixture", "means": [[0.2, 0.0]],
+                     "covs": [[[0.1, 0.05], [0.05, 0.2]]], "input_params_prefix": "a_",
+                     "speed": 1},
+            "fast": {"class": "gaussian_mixture", "means": [[0.5, 0.4, 0.6]], "covs": [cov_b],
+                     "input_params_prefix": "b_", "speed": 50}},
+        "params": {
+            "a_0": {"prior": {"min": -3, "max": 3}, "proposal": 0.3,
+                    "ref": {"dist": "norm", "loc": 0.2, "scale": 0.3}},
+            "b_0": {"prior": {"min": 0, "max": 1}, "proposal": 0.1,
+                    "ref": {"dist": "norm", "loc": 0.5, "scale": 0.1}},
+            "a_1": {"prior": {"min": -3, "max": 3}, "proposal": 0.4,
+                    "ref": {"dist": "norm", "loc": 0.0, "scale": 0.4}},
+            "b_1": {"prior": {"min": 0, "max": 1}, "proposal": 0.1,
+                    "ref": {"dist": "norm", "loc": 0.4, "scale": 0.1}},
+            "b_2": {"prior": {"min": 0, "max": 1}, "proposal": 0.1,
+                    "ref": {"dist": "norm", "loc": 0.6, "scale": 0.1}}},
+        "sampler": {"mcmc_hip": sampler_opts}}
+    tm = np.array([0.2, 0.5, 0.0, 0.4, 0.6])
+    tc = np.zeros((5, 5))
+    tc[np.ix_([0, 2], [0, 2])] = [[0.1, 0.05], [0.05, 0.2]]
+    tc[np.ix_([1, 3, 4], [1, 3, 4])] = cov_b
+    return info, tm, tc
+
+
+def test_oversampled_blocks_from_likelihood_speeds():
+    """(f)1 end to end: two likelihoods of different speed -> two parameter blocks, the fast
+    one oversampled (model.py:1340-1467), thinned chain output (mcmc.py:377-389), one chi2
+    column per likelihood; the posterior is recovered."""
+    info, tm, tc = _two_speed_info({
+        "seed": 5, "n_walkers": 512, "group_size": 64, "emit": "chains", "oversample_power": 0.4,
+        "steps_per_launch": 60, "max_samples": 400000, "Rminus1_stop": 0.0, "burn_in": 10,
+        "learn_proposal": True})
+    updated, sampler = run(info)
+    assert sampler.blocks == [["a_0", "a_1"], ["b_0", "b_1", "b_2"]]
+    assert sampler.oversampling_factors == [1, 4] and not sampler.drag
+    assert sampler.cycle_length == 14 and sampler.output_thin == 3
+    assert updated["sampler"]["mcmc_hip"]["blocking"] == [[1, ["a_0", "a_1"]],
+                                                          [4, ["b_0", "b_1", "b_2"]]]
+    coll = sampler.products()["sample"]
+    df = coll.data
+    assert list(df.columns)[-3:] == ["chi2", "chi2__slow", "chi2__fast"]
+    np.testing.assert_allclose(df["chi2__slow"] + df["chi2__fast"], df["chi2"], rtol=1e-9,
+                               atol=1e-9)
+    w = df["weight"].to_numpy()
+    assert np.all(w == np.round(w)) and w.min() >= 1
+    assert kl_norm(tm, tc, coll.mean(), coll.cov()) < 0.01
+    sampler.close()
+
+
+def test_dragging_from_likelihood_speeds():
+    """(f)1 end to end: `drag: True` splits the blocks into slow and fast (mcmc.py:333-360)
+    and runs the dragging step; the posterior is recovered (the reference's own bar is
+    KL <= 0.07, tests/common_sampler.py:18)."""
+    info, tm, tc = _two_speed_info({
+        "seed": 6, "n_walkers": 1024, "group_size": 64, "drag": True, "oversample_power": 0.4,
+        "steps_per_launch": 70, "max_samples": 1500000, "Rminus1_stop": 0.0,
+        "learn_proposal": True})
+    updated, sampler = run(info)
+    assert sampler.drag and sampler.i_last_slow_block == 0
+    assert sampler.drag_interp_steps == 6          # round(4 * 3 / 2)
+    assert sampler.cycle_length == 2 and sampler.steps_per_launch == 10
+    coll = sampler.products(skip_samples=0.3)["sample"]
+    assert len(coll) >= 10 * 1024
+    assert kl_norm(tm, tc, coll.mean(), coll.cov()) < 0.01
+    c = sampler.engine.counters()
+    assert 0.1 < c["accepted"] / (c["steps"] * 1024) < 0.9
     sampler.close()

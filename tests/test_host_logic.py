@@ -288,3 +288,133 @@ def test_rminus1_of_bounds_statistic():
     assert s._rminus1_of_bounds(np.eye(d)) == 0.0
     s._rows = []
     assert s._rminus1_of_bounds(np.eye(d)) is None
+
+
+# ----------------------------------------------------------------------------- (f)1 blocking
+def _bare_sampler(spec, **opts):
+    """MCMCHip with the options set but no engine: exercises the set-up logic on the CPU."""
+    from cobaya_amd.sampler import HIP_DEFAULTS, MCMC_DEFAULTS
+    s = object.__new__(MCMCHip)
+    for k, v in {**MCMC_DEFAULTS, **HIP_DEFAULTS, **opts}.items():
+        setattr(s, k, v)
+    s.spec = spec
+    return s
+
+
+def _three_likelihood_info(speeds):
+    return {
+        "likelihood": {
+            "slow": {"class": "gaussian_mixture", "means": [[0.2, 0]],
+                     "covs": [[[0.1, 0.05], [0.05, 0.2]]], "input_params_prefix": "a_",
+                     "speed": speeds[0]},
+            "fast": {"class": "gaussian_mixture", "means": [[0.5, 0.5, 0.5]],
+                     "covs": [(np.eye(3) * 0.01).tolist()], "input_params_prefix": "b_",
+                     "speed": speeds[1]},
+            "mid": {"class": "gaussian_mixture", "means": [[0.5]], "covs": [[[0.01]]],
+                    "input_params_prefix": "c_", "speed": speeds[2]}},
+        "params": {"a_0": {"prior": {"min": -3, "max": 3}}, "b_0": {"prior": {"min": 0, "max": 1}},
+                   "a_1": {"prior": {"min": -3, "max": 3}}, "b_1": {"prior": {"min": 0, "max": 1}},
+                   "c_0": {"prior": {"min": 0, "max": 1}}, "b_2": {"prior": {"min": 0, "max": 1}}}}
+
+
+def test_param_blocking_matches_reference_decisions():
+    """G11: blocks, their order and the oversampling factors chosen from the likelihoods'
+    speeds equal Model.get_param_blocking_for_sampler (model.py:1340-1467) in 20 cases."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g11_param_blocking.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 20
+    for c in cases:
+        spec = ProblemSpec.from_info(_three_likelihood_info(c["speeds"]))
+        blocks, factors = spec.param_blocking(c["oversample_power"], c["split"])
+        assert blocks == c["blocks"] and factors == c["factors"], c
+
+
+def test_several_likelihoods_merge_into_one_mixture():
+    info = _three_likelihood_info([1, 50, 7])
+    info["likelihood"]["mid"]["means"] = [[0.3], [0.7]]
+    info["likelihood"]["mid"]["covs"] = [[[0.01]], [[0.02]]]
+    info["likelihood"]["mid"]["weights"] = [1, 3]
+    spec = ProblemSpec.from_info(info)
+    assert spec.sampled == ["a_0", "b_0", "a_1", "b_1", "c_0", "b_2"]
+    assert spec.means.shape == (2, 6) and spec.covs.shape == (2, 6, 6)
+    np.testing.assert_allclose(spec.weights, [0.25, 0.75])
+    np.testing.assert_allclose(spec.means[1], [0.2, 0.5, 0.0, 0.5, 0.7, 0.5])
+    assert spec.covs[0][0, 2] == 0.05 and spec.covs[0][0, 1] == 0.0 and spec.covs[1][4, 4] == 0.02
+    # the product of the components equals the merged mixture
+    from oracle import ref_numpy as R
+    x = np.random.default_rng(0).uniform(0.2, 0.8, size=(5, 6))
+    merged = R.GaussianMixtureTarget(spec.means, spec.covs, spec.weights)
+    np.testing.assert_allclose(spec.component_loglikes(x).sum(axis=1),
+                               [merged.loglike(p) for p in x], rtol=1e-12)
+    bad = _three_likelihood_info([1, 1, 1])
+    bad["likelihood"]["mid"]["input_params_prefix"] = "b_"
+    with pytest.raises(UnsupportedModel):
+        ProblemSpec.from_info(bad)
+
+
+def test_set_proposer_blocking_decisions(golden):
+    """mcmc.py:320-410 on the cases of golden G10: blocks, factors, dragging decision, number
+    of interpolation steps, output thinning and cycle length as the reference set them."""
+    g = golden("g10_blocked")
+    names = [f"a__{i}" for i in range(5)]
+    info = {"likelihood": {"gaussian_mixture": {"means": g["means"], "covs": g["covs"],
+                                                "input_params_prefix": "a_"}},
+            "params": {n: {"prior": {"min": 0, "max": 1}} for n in names}}
+    spec = ProblemSpec.from_info(info)
+    cases = {
+        "over_thin": dict(blocking=[[1, names[:2]], [3, names[2:]]]),
+        "over_nothin": dict(oversample_thin=False, blocking=[[1, names[3:]], [2, names[:3]]]),
+        "blocks_1d": dict(oversample_thin=False,
+                          blocking=[[1, names[:3]], [2, names[3:4]], [4, names[4:]]]),
+        "drag": dict(drag=True, blocking=[[1, names[:2]], [4, names[2:]]]),
+        "drag_learn": dict(drag=True, blocking=[[1, [names[4], names[0]]],
+                                                [3, [names[1], names[3], names[2]]]]),
+    }
+    for name, opts in cases.items():
+        s = _bare_sampler(spec, **opts)
+        s.set_proposer_blocking()
+        key = lambda k: g[f"{name}__{k}"]  # noqa: E731
+        assert [len(b) for b in s.blocks] == key("block_sizes").tolist()
+        assert [spec.sampled.index(p) for b in s.blocks for p in b] == key("block_params").tolist()
+        assert s.oversampling_factors == key("oversampling").tolist()
+        assert s.drag == bool(key("drag"))
+        assert s.drag_interp_steps == int(key("drag_interp_steps"))
+        assert (s.i_last_slow_block if s.drag else -1) == int(key("drag_last_slow"))
+        assert s.cycle_length == int(key("cycle_length"))
+        assert s.output_thin == int(key("output_thin"))
+    # dragging is switched off where the reference does so (mcmc.py:333-360)
+    s = _bare_sampler(spec, drag=True, blocking=[[1, names[:2]], [1, names[2:]]])
+    s.set_proposer_blocking()
+    assert not s.drag
+    with pytest.raises(LoggedError, match="missing parameters"):
+        s = _bare_sampler(spec, blocking=[[1, names[:2]], [2, names[3:]]])
+        s.set_proposer_blocking()
+
+
+def test_thinned_chain_rows_follow_the_reference_rule():
+    """collection.py:1362-1383: rows of a walker accumulate weight until output_thin is
+    reached; remainders carry over between drains."""
+    rng = np.random.default_rng(5)
+    s = _bare_sampler(None, emit="chains")
+    s.output_thin, s._thin_carry = 3, {}
+    rows_all = []
+    expect = {w: [] for w in range(4)}
+    carry = {w: 0 for w in range(4)}
+    for _ in range(6):  # six drains
+        n = 40
+        rows = np.column_stack((rng.integers(0, 4, n), rng.integers(1, 6, n),
+                                rng.normal(size=(n, 4))))
+        rows = rows[np.argsort(rows[:, 0], kind="stable")]
+        for r in rows:
+            w = int(r[0])
+            carry[w] += int(r[1])
+            if carry[w] >= 3:
+                expect[w].append((carry[w] // 3, r[2]))
+                carry[w] %= 3
+        rows_all.append(s._thin_rows(rows))
+    out = np.vstack(rows_all)
+    for w in range(4):
+        got = out[out[:, 0] == w]
+        assert [(int(a), b) for a, b in zip(got[:, 1], got[:, 2])] == expect[w]
