@@ -602,7 +602,9 @@ constexpr int kSplit = kPair ? pair_split() : D;
 #endif
 constexpr int kNTA = kSplit * (kSplit + 1) / 2;   // operands of rows [0, kSplit)
 constexpr int kDB = D - kSplit;
-constexpr int kXF = kDB + 3;                       // exchanged doubles per walker and step
+// exchanged doubles per walker and step: chi2 of role 0, r, Ea, the y_j of role 1; with normal
+// priors also role 1's prior sum
+constexpr int xf_count(bool normp) { return normp ? kDB + 4 : kDB + 3; }
 
 // `ok` collects the support test as a wave mask on the scalar ALU (one bit per walker):
 // v_cmp writes an SGPR pair, s_and folds it in -- no per-dimension VALU select.
@@ -623,11 +625,22 @@ __device__ __forceinline__ double select_by_mask(unsigned long long mask, double
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-template <int ROLE>
+// NORMP: some priors are normal (prior.py:746-761).  Role 1 forms every trial t_i anyway (and
+// carries less of the whitening), so it chains the terms fma(-q/2, q, mls_i),
+// q = (t_i - loc_i) / scale_i, of the normal dimensions in ascending order into s0.
+template <int ROLE, bool NORMP>
 __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v, cptr E, cptr MU,
                                              const double (&x)[D], cptr Lk, double (&lfirst)[CH],
-                                             unsigned long long& ok)
+                                             unsigned long long& ok, uint32_t nmask, cptr Cn,
+                                             double& s0)
 {
+    const ConstLayout cl{D, 1};
+    auto prior_term = [&](int dim, double t) {
+        if (NORMP && ROLE == 1 && ((nmask >> dim) & 1u)) {
+            const double q = (t - Cn[cl.loc() + dim]) / Cn[cl.scale() + dim];
+            s0 = s0 + fma(-0.5 * q, q, Cn[cl.mls() + dim]);
+        }
+    };
     constexpr int N = ROLE == 0 ? kSplit : D;
     constexpr int C0 = ROLE == 0 ? 0 : kSplit / 4;  // first chunk with the support test
     constexpr int NC = (N + 3) / 4;
@@ -665,10 +678,12 @@ __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v,
         } else {
             dev[b] = t0 - ce[0];
         }
+        prior_term(b, t0);
 #pragma unroll
         for (int k = 1; k < 4; ++k)
             if (b + k < N) {
                 const double tk = fma(r, cv[k], x[b + k]);
+                prior_term(b + k, tk);
                 if (test) {
                     m &= __builtin_amdgcn_ballot_w64(tk <= ce[3 * k + 1]) &
                          __builtin_amdgcn_ballot_w64(tk >= ce[3 * k]);
@@ -700,9 +715,10 @@ __device__ __forceinline__ void exchange_barrier()
 }
 
 // UNIT_T: temperature == 1 (x / 1.0 == x exactly, so the division is dropped)
-template <int ROLE, bool UNIT_T>
+template <int ROLE, bool UNIT_T, bool NORMP>
 __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
 {
+    constexpr int kXF = xf_count(NORMP);
     const int SLAB = a.slab;
     constexpr int NX = ROLE == 0 ? kSplit : D;      // dimensions of the state this role holds
     const ConstLayout cl{D, 1};
@@ -792,7 +808,9 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
         const cptr C = launder(C0);
         double dev[D], lfirst[CH], vhead[16], yb[D];
         unsigned long long ok = ~0ull;  // walkers whose trial is inside the prior support
-        propose_pair<ROLE>(dev, r, v, C + cl.elem(), C + cl.mean(0), x, C + cl.linv(0), lfirst, ok);
+        double s0 = 0.0;   // sum of the normal priors' terms (role 1 forms it)
+        propose_pair<ROLE, NORMP>(dev, r, v, C + cl.elem(), C + cl.mean(0), x, C + cl.linv(0),
+                                  lfirst, ok, NORMP ? ks->norm_mask : 0u, C, s0);
         double chi2, r_next = 0.0, Ea_next = 0.0;
         if (ROLE == 0) {
             chi2 = tri_stream<false, true, true, true, lptr, 0, kNTA, true>(
@@ -804,6 +822,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
             exchange_barrier();
 #pragma unroll
             for (int q = 0; q < kDB; ++q) yb[kSplit + q] = X[(3 + q) * 256];
+            if (NORMP) s0 = X[(3 + kDB) * 256];
         } else {
             StepRng none;
             tri_stream<true, true, true, false, lptr, kNTA, NT, false>(
@@ -811,6 +830,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
             yb[D - 1] = select_by_mask(ok, yb[D - 1], INFINITY);
 #pragma unroll
             for (int q = 0; q < kDB; ++q) X[(3 + q) * 256] = yb[kSplit + q];
+            if (NORMP) X[(3 + kDB) * 256] = s0;
             exchange_barrier();
             chi2 = X[0];
             r_next = X[256];
@@ -821,7 +841,7 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
         for (int q = 0; q < kDB; ++q) chi2 = fma(yb[kSplit + q], yb[kSplit + q], chi2);
 #endif
         const bool inb = chi2 < INFINITY;  // false for +inf and NaN: outside the prior support
-        const double lp = ks->uniform_logp + 0.0;
+        const double lp = ks->uniform_logp + s0;
         const double ll = -0.5 * (ks->cnorm0 + chi2);
         const double lt = inb ? lp + ll : -INFINITY;
         // ---- Metropolis test (mcmc.py:678-683), identical in both roles
@@ -878,14 +898,14 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
     }
 }
 
-template <bool UNIT_T>
+template <bool UNIT_T, bool NORMP>
 __global__ void __launch_bounds__(512) step_pair_kernel(const StepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if constexpr (kPair) {
         const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-        if (role == 0) pair_steps<0, UNIT_T>(a, (lds_t)smem);
-        else pair_steps<1, UNIT_T>(a, (lds_t)smem);
+        if (role == 0) pair_steps<0, UNIT_T, NORMP>(a, (lds_t)smem);
+        else pair_steps<1, UNIT_T, NORMP>(a, (lds_t)smem);
     }
 }
 
@@ -1226,21 +1246,26 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
     }
     const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
                          a.rows != nullptr || D == 1 || a.vflag != nullptr;
-    if (kPair && !multi && !general && a.W % 256 == 0 && 256 % a.group_size == 0) {
+    const bool pairable = (a.periodic_mask == 0u && a.n_modes == 1 && a.rows == nullptr &&
+                           a.vflag == nullptr);   // normal priors have their own instantiation
+    if (kPair && pairable && a.W % 256 == 0 && 256 % a.group_size == 0) {
         // two waves per 64 walkers: 512-thread workgroups of 256 walkers
-        size_t plds = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab + 2 * kXF * 256);
+        const bool normp = a.norm_mask != 0u;
+        size_t plds = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab +
+                                                2 * xf_count(normp) * 256);
         const int nwg = a.W / 256;
         const int per_cu = (nwg + 255) / 256;      // same even-placement request as below
         size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;
         if (per_cu == 1) want = 96 * 1024;         // > half of the LDS: one workgroup per CU
         if (want > plds) plds = want;
         const bool unit_t = a.temperature == 1.0;
-        hipError_t e = hipFuncSetAttribute(
-            unit_t ? (const void*)step_pair_kernel<true> : (const void*)step_pair_kernel<false>,
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+        typedef void (*kern_t)(const StepArgs);
+        const kern_t kern = normp ? (unit_t ? step_pair_kernel<true, true> : step_pair_kernel<false, true>)
+                                  : (unit_t ? step_pair_kernel<true, false> : step_pair_kernel<false, false>);
+        hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
         if (e != hipSuccess) return e;
-        if (unit_t) hipLaunchKernelGGL(step_pair_kernel<true>, dim3(nwg), dim3(512), plds, st, a);
-        else hipLaunchKernelGGL(step_pair_kernel<false>, dim3(nwg), dim3(512), plds, st, a);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), plds, st, a);
         return hipGetLastError();
     }
     const void* fn = multi ? (general ? (const void*)step_kernel<true, true>

@@ -404,9 +404,15 @@ def test_config5_shape_d27_bit_exact():
     kinds = [0] * 6 + [1] * 21
     a = [0.0] * 6 + list(rng.uniform(0.45, 0.55, 21))
     b = [1.0] * 6 + list(rng.uniform(0.05, 0.2, 21))
-    eng, prob, st = make_pair(d, 256, 64, kinds=kinds, a=a, b=b, rng=rng)
-    for n in (30, 51):
-        eng.step(n)
-        eng.sync()
-        st.run(n, n_threads=4)
-        compare_state(eng, st)
+    # W = 256: the two-wave kernel with normal priors; W = 192: the general one-wave kernel;
+    # T != 1 and mixed positions of the normal priors as well
+    for W, T, kk in ((256, 1.0, kinds), (192, 1.0, kinds), (512, 1.3, kinds[::-1])):
+        aa = a if kk is kinds else a[::-1]
+        bb = b if kk is kinds else b[::-1]
+        eng, prob, st = make_pair(d, W, 64, kinds=kk, a=aa, b=bb, T=T,
+                                  rng=np.random.default_rng(27))
+        for n in (30, 51):
+            eng.step(n)
+            eng.sync()
+            st.run(n, n_threads=4)
+            compare_state(eng, st)

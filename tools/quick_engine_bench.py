@@ -16,7 +16,11 @@ if d in (30, 100):
 else:
     rng = np.random.default_rng(d); A = rng.normal(size=(d, d)); cov = (A @ A.T / d + np.eye(d)) * 1e-3; mean = np.full(d, 0.5)
 eng = E.Engine(d, W, group_size=gs, seed=1)
-eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
+n_norm = int(os.environ.get("QB_NORM", "0"))  # the last n_norm priors normal (config-5 shape)
+sd = np.sqrt(np.diag(cov))
+kinds = [0] * (d - n_norm) + [1] * n_norm
+eng.set_prior(kinds, [0.0] * (d - n_norm) + list(mean[d - n_norm:] + 0.5 * sd[d - n_norm:]),
+              [1.0] * (d - n_norm) + list(2.0 * sd[d - n_norm:]))
 eng.set_target_gaussian_mixture([mean], [cov])
 eng.set_proposal_cov(cov)
 rng = np.random.default_rng(1)
