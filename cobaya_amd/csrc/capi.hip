@@ -391,6 +391,19 @@ int upload_constants(mcmc_hip_ctx* h)
             for (int i = 0; i <= j; ++i)
                 lcol[(((size_t)(i / 4) * nb + (j / 4)) * 4 + (i % 4)) * 4 + (j % 4)] =
                     h->Linv[(size_t)j * d + i];
+        // then the 16 x 4 tiles (R, kk), kk <= 4R + 3, of the matrix-core kernel, R-major,
+        // each in A-operand lane order: lane l holds L^-1[16R + (l & 15)][4kk + (l >> 4)]
+        {
+            const int RT = (dp + 15) / 16, KT = (dp + 3) / 4;
+            for (int R = 0; R < RT; ++R)
+                for (int kk = 0; kk < std::min(4 * R + 4, KT); ++kk)
+                    for (int l = 0; l < 64; ++l) {
+                        const int j = 16 * R + (l & 15), i = 4 * kk + (l >> 4);
+                        lcol.push_back((j < d && i <= j) ? h->Linv[(size_t)j * d + i] : 0.0);
+                    }
+            if ((int)(lcol.size() - (size_t)dp * dp) != 64 * h->kb->n_tiles)
+                return fail(h, MCMC_HIP_ERR_ARG, "internal: tile count mismatch");
+        }
         HIP_TRY(h, h->dLcol.resize(lcol.size()));
         HIP_TRY(h, hipMemcpyAsync(h->dLcol.p, lcol.data(), sizeof(double) * lcol.size(),
                                   hipMemcpyHostToDevice, h->stream));

@@ -180,6 +180,7 @@ struct BigKernels {
     hipError_t (*basis)(const BasisArgs&, int n_groups, int d, hipStream_t);
     hipError_t (*evaluate)(const EvalArgs&, const double* Lrow, int d, double* scratch, hipStream_t);
     hipError_t (*moments)(const MomentArgs&, int group_size, int d, hipStream_t);
+    int n_tiles;  // 16 x 4 tiles of L^-1 the matrix-core step kernel reads (after Lcol's dp*dp)
 };
 
 }  // namespace mcmc

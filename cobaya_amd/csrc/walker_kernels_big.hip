@@ -16,6 +16,7 @@
 //
 // One translation unit per accumulator count DP (-DMCMC_DP=48|64|80|100|112); the actual d is
 // a run-time argument <= DP (rows/columns beyond d are zero operands: exact no-ops).
+#include <type_traits>
 #include "det_math.h"
 #include "kernels.h"
 
@@ -291,7 +292,9 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
         const double* __restrict__ v = sVr + (slot * gpb + gib) * 128;
         const lptr lv = lsm + (DP * DP + 4 * DP) + (slot * gpb + gib) * 128;
         const lptr lE = lsm + DP * DP;
-        double chi2 = 0.0;
+        // chi2: four interleaved chains over the rows j = c (mod 4) (the specification for
+        // d > 32, see step_mfma_kernel), rows of both passes in ascending order
+        double pc[4] = {0.0, 0.0, 0.0, 0.0};
         {
             constexpr int H = (NB + 1) / 2;
             double y[4 * H];
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
             for (int j = 0; j < 4 * H; ++j) y[j] = 0.0;
             sweep_pass<0, H>(y, x, r, lv, lE, lsm, d);
 #pragma unroll
-            for (int j = 0; j < 4 * H; ++j) chi2 = fma(y[j], y[j], chi2);
+            for (int j = 0; j < 4 * H; ++j) pc[j & 3] = fma(y[j], y[j], pc[j & 3]);
         }
         {
             constexpr int H = (NB + 1) / 2;
@@ -308,8 +311,9 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
             for (int j = 0; j < 4 * (NB - H); ++j) y[j] = 0.0;
             sweep_pass<H, NB>(y, x, r, lv, lE, lsm, d);
 #pragma unroll
-            for (int j = 0; j < 4 * (NB - H); ++j) chi2 = fma(y[j], y[j], chi2);
+            for (int j = 0; j < 4 * (NB - H); ++j) pc[j & 3] = fma(y[j], y[j], pc[j & 3]);
         }
+        const double chi2 = (pc[0] + pc[1]) + (pc[2] + pc[3]);
         const bool inb = chi2 < INFINITY;
         const double lp = a.uniform_logp + 0.0;
         const double ll = -0.5 * (a.cnorm0 + chi2);
@@ -343,6 +347,203 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
     a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
     a.n_accept[w] = nacc;
     wave_add_accepts(a.accept_total, nacc - nacc0);
+}
+
+// ---------------------------------------------------------------- the matrix-core Metropolis kernel
+// y = L^-1 dev for 16 walkers at a time as FP64 MFMAs (v_mfma_f64_16x16x4_f64): the whitening
+// of d > 32 is a triangular GEMM (rows x walkers), and the matrix core delivers its uniform
+// operand -- the L^-1 tile -- to all 16 walkers from 64 lane registers, where the VALU form
+// needs one LDS broadcast per two FMAs.  The instruction accumulates k in ascending order with
+// one rounding per product-sum (verified bit for bit against an fma chain,
+// tools/probes/mfma_f64_order.hip), so y_j is exactly the oracle's chain; tile entries above
+// the diagonal are zero (fma(0, dev, y) == y).
+//
+// Layout.  A wave owns 16 walkers.  Lane l = 16 c + n serves walker n of the wave and the
+// dimensions i = 4 kk + c (kk = 0 .. KT-1): x[kk] is lane-resident, and dev for k-step kk is
+// exactly the MFMA's B operand (B[k = l >> 4][col = l & 15]).  A = the 16 x 4 tile
+// (rows 16 R .., columns 4 kk ..) of L^-1 from LDS in lane order.  D: lane l holds rows
+// 16 R + 4 r + c (r = 0..3) of walker n, i.e. the rows j = c (mod 4): its chi2 chain p_c.
+// chi2 = (p0 + p1) + (p2 + p3) through four cross-lane reads; all four lanes of a walker take
+// the same decision and commit their own quarter of x.  16 waves (256 walkers) per workgroup,
+// one workgroup per CU, so every SIMD holds four waves; the row tiles go in two passes so that
+// x, the accumulators of one pass and the temporaries (nearly) fit the 128 registers that
+// occupancy allows.  Left to the compiler's own schedule on purpose: pinning the LDS loads
+// behind asm anchors (as the VALU kernels do), three passes, or parking the walker scalars in
+// LDS all measured SLOWER (5.1-5.8 ms vs 4.07 ms per 200 steps at d = 100) -- the unpinned
+// schedule pairs adjacent tiles into ds_read2st64_b64.
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int RT = (DP + 15) / 16;     // row tiles
+constexpr int KT = (DP + 3) / 4;       // k-steps
+constexpr int RH = (RT + 1) / 2;       // row tiles of the first pass
+// tile (R, kk) exists for kk <= 4 R + 3; tiles are stored R-major
+constexpr int tiles_of_row(int R) { return (4 * R + 4 < KT) ? 4 * R + 4 : KT; }
+constexpr int tile_offset(int R)
+{
+    int n = 0;
+    for (int q = 0; q < R; ++q) n += tiles_of_row(q);
+    return n;
+}
+constexpr int kTiles = tile_offset(RT);
+
+struct MfmaStepArgs {
+    StepArgs s;
+    const double* Ltiles;  // [kTiles][64] tiles of L^-1 in A-operand lane order
+    int d;
+};
+
+template <int R0, int R1>
+__device__ __forceinline__ void mfma_pass(d4 (&acc)[R1 - R0], const double (&x)[KT], double r,
+                                          const double* __restrict__ sv,
+                                          const double* __restrict__ sE,
+                                          const double* __restrict__ sL, int c, int lane, int d)
+{
+#pragma unroll
+    for (int q = 0; q < R1 - R0; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        if (kk > 4 * (R1 - 1) + 3) continue;
+        const int i = 4 * kk + c;
+        const double ti = fma(r, sv[i], x[kk]);
+        const double lo = sE[3 * i], hi = sE[3 * i + 1], mu = sE[3 * i + 2];
+        double dev = ((ti <= hi) & (ti >= lo)) ? ti - mu : INFINITY;
+        dev = (i < d) ? dev : 0.0;
+#pragma unroll
+        for (int R = R0; R < R1; ++R) {
+            if (kk > 4 * R + 3) continue;
+            const double a = sL[(tile_offset(R) + kk) * 64 + lane];
+            acc[R - R0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, dev, acc[R - R0], 0, 0, 0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) step_mfma_kernel(const MfmaStepArgs b)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const StepArgs& a = b.s;
+    const int d = b.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int c = lane >> 4;
+    const int wl = wv * 16 + (lane & 15);
+    const int w = blockIdx.x * 256 + wl;
+    const int W = a.W;
+    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
+    const int gpb = 256 / a.group_size;
+    const int gib = __builtin_amdgcn_readfirstlane(wl / a.group_size);
+    const bool stager = __builtin_amdgcn_readfirstlane(wl % a.group_size) == 0;
+    const ConstLayout cl{d, 1};
+    double* sL = smem;
+    double* sE = sL + kTiles * 64;
+    double* sVr = sE + 3 * 4 * KT;
+    for (int i = tid; i < kTiles * 64; i += 1024) sL[i] = b.Ltiles[i];
+    for (int i = tid; i < 4 * KT; i += 1024) {
+        const bool in = i < d;
+        sE[3 * i + 0] = in ? a.cblock[cl.lo() + i] : -INFINITY;
+        sE[3 * i + 1] = in ? a.cblock[cl.hi() + i] : INFINITY;
+        sE[3 * i + 2] = in ? a.cblock[cl.mean(0) + i] : 0.0;
+    }
+    const int ldv = v_ld(d);
+    const double* const Vgrp = a.V + (size_t)group * a.ncyc * v_slab_big(d);
+    auto stage_col = [&](int cycle, int column, int slot) {
+        if (stager) {
+            const char* g = (const char*)(Vgrp + (size_t)cycle * v_slab_big(d) + (size_t)column * ldv) +
+                            lane * 16;
+            char* l = (char*)(sVr + (slot * gpb + gib) * 128);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+    unsigned long long step = a.step0;
+    int col = (int)(step % (unsigned long long)d);
+    int cyc = 0;
+    stage_col(0, col, 0);
+    double x[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int i = 4 * kk + c;
+        x[kk] = (i < d) ? a.x[(size_t)i * W + w] : 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int slot = 0;
+    double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
+    int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
+    long long nacc = a.n_accept[w];
+    const long long nacc0 = nacc;
+    const uint32_t gid = a.walker0 + (uint32_t)w;
+
+    for (int s = 0; s < a.n_steps; ++s) {
+        {
+            int ncol = col + 1, ncyc = cyc;
+            if (ncol == d) { ncol = 0; ++ncyc; }
+            if (s + 1 < a.n_steps) stage_col(ncyc, ncol, slot ^ 1);
+        }
+        StepRng rng;
+        rng.begin(a.key0, a.key1, gid, step);
+        rng.run_all();
+        const double r = rng.r, Ea = rng.Ea;
+        const double* __restrict__ v = sVr + (slot * gpb + gib) * 128;
+        double p = 0.0;
+        {
+            d4 acc[RH];
+            mfma_pass<0, RH>(acc, x, r, v, sE, sL, c, lane, d);
+#pragma unroll
+            for (int q = 0; q < RH; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p = fma(acc[q][e], acc[q][e], p);
+        }
+        if (RT > RH) {
+            d4 acc[RT - RH > 0 ? RT - RH : 1];
+            mfma_pass<RH, RT>(acc, x, r, v, sE, sL, c, lane, d);
+#pragma unroll
+            for (int q = 0; q < RT - RH; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p = fma(acc[q][e], acc[q][e], p);
+        }
+        const int n = lane & 15;
+        const double p0 = __shfl(p, n), p1 = __shfl(p, n + 16), p2 = __shfl(p, n + 32),
+                     p3 = __shfl(p, n + 48);
+        const double chi2 = (p0 + p1) + (p2 + p3);
+        const bool inb = chi2 < INFINITY;
+        const double lp = a.uniform_logp + 0.0;
+        const double ll = -0.5 * (a.cnorm0 + chi2);
+        const double lt = inb ? lp + ll : -INFINITY;
+        const bool accept = inb & (lt != -INFINITY) &
+                            ((lt > lpost) | (Ea > (lpost - lt) / a.temperature));
+        burn -= (accept & (burn > 0)) ? 1 : 0;
+        const double ra = accept ? r : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const int i = 4 * kk + c;
+            x[kk] = (i < d) ? fma(ra, v[i], x[kk]) : 0.0;
+        }
+        lpri = accept ? lp : lpri;
+        llik = accept ? ll : llik;
+        lpost = accept ? lt : lpost;
+        prej = accept ? 0 : (prej + (inb ? 0 : 1));
+        wt = accept ? 1 : wt + 1;
+        nacc += accept ? 1 : 0;
+        if (!accept && c == 0) {
+            const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
+            if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
+        }
+        ++step;
+        if (++col == d) { col = 0; ++cyc; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slot ^= 1;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+        const int i = 4 * kk + c;
+        if (i < d) a.x[(size_t)i * W + w] = x[kk];
+    }
+    if (c == 0) {
+        a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
+        a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
+        a.n_accept[w] = nacc;
+    }
+    wave_add_accepts(a.accept_total, (c == 0) ? nacc - nacc0 : 0);
 }
 
 // ---------------------------------------------------------------- batch evaluator (run-time d)
@@ -381,13 +582,14 @@ __global__ void __launch_bounds__(64) evaluate_big_kernel(const BigEvalArgs b)
         for (int k = 0; k < K; ++k) {
             const double* __restrict__ Lk = b.Lrow + (size_t)k * d * d;
             const double* __restrict__ mu = C + cl.mean(k);
-            double chi2 = 0.0;
+            double pc[4] = {0.0, 0.0, 0.0, 0.0};  // d > 32: four interleaved chi2 chains
             for (int j = 0; j < d; ++j) {
                 double y = 0.0;
                 for (int i = 0; i <= j; ++i) y = fma(Lk[j * d + i], t[i] - mu[i], y);
                 if (a.derived) a.derived[((size_t)p * K + k) * d + j] = y;
-                chi2 = fma(y, y, chi2);
+                pc[j & 3] = fma(y, y, pc[j & 3]);
             }
+            const double chi2 = (pc[0] + pc[1]) + (pc[2] + pc[3]);
             const double ak = -0.5 * (C[cl.cnorm() + k] + chi2);
             b.scratch[(size_t)p * K + k] = ak;
             amax = (ak > amax) ? ak : amax;
@@ -452,6 +654,17 @@ __global__ void __launch_bounds__(64) pool_moments_big_kernel(const MomentArgs a
 // ---------------------------------------------------------------- launchers
 hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, hipStream_t st)
 {
+    if (a.W % 256 == 0 && 256 % a.group_size == 0) {
+        // matrix-core kernel: its tiles follow the column-sweep copy of L^-1 in `Lcol`
+        MfmaStepArgs m{a, Lcol + (size_t)DP * DP, d};
+        const size_t lds = sizeof(double) * (size_t)(kTiles * 64 + 12 * KT + 2 * (256 / a.group_size) * 128);
+        const size_t want = lds > (size_t)(96 << 10) ? lds : (size_t)(96 << 10);  // one per CU
+        hipError_t e = hipFuncSetAttribute((const void*)step_mfma_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(step_mfma_kernel, dim3(a.W / 256), dim3(1024), want, st, m);
+        return hipGetLastError();
+    }
     BigStepArgs b{a, Lcol, d};
     const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
     const size_t lds = sizeof(double) * (size_t)(DP * DP + 4 * DP + 2 * (bs / a.group_size) * 128);
@@ -500,7 +713,8 @@ hipError_t launch_moments(const MomentArgs& a, int group_size, int d, hipStream_
     return hipGetLastError();
 }
 
-const BigKernels kKernels = {DP, launch_step, launch_basis, launch_evaluate, launch_moments};
+const BigKernels kKernels = {DP, launch_step, launch_basis, launch_evaluate, launch_moments,
+                             kTiles};
 
 }  // namespace
 }  // namespace mcmc

@@ -417,13 +417,18 @@ static int eval_point(const orc_problem* p, const double* t, double* lp_out, dou
     for (int k = 0; k < K; ++k) {
         const double* Li = p->Linv + (size_t)k * d * d;
         const double* mu = p->mean + (size_t)k * d;
-        double chi2 = 0.0;
+        /* chi2 = sum_j y_j^2: one ascending chain for d <= 32; for d > 32 four interleaved
+         * chains p_c over the rows j = c (mod 4), combined as (p0 + p1) + (p2 + p3) -- the
+         * order in which the matrix-core (MFMA) kernel holds the y_j, four rows per lane */
+        double pc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int j = 0; j < d; ++j) {
             double y = 0.0;
             for (int i = 0; i <= j; ++i) y = fma(Li[j * d + i], t[i] - mu[i], y);
             if (derived) derived[k * d + j] = y;
-            chi2 = fma(y, y, chi2);
+            const int c = d > 32 ? (j & 3) : 0;
+            pc[c] = fma(y, y, pc[c]);
         }
+        const double chi2 = d > 32 ? (pc[0] + pc[1]) + (pc[2] + pc[3]) : pc[0];
         a[k] = -0.5 * (p->cnorm[k] + chi2);
         if (a[k] > amax) amax = a[k];
     }
