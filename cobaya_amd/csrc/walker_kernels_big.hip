@@ -31,17 +31,22 @@ constexpr int DP = MCMC_DP;
 constexpr int NB = DP / 4;
 static_assert(DP % 4 == 0 && DP <= 128, "DP must be a multiple of 4, at most 128");
 
-// ---------------------------------------------------------------- Haar basis (run-time d)
-// Same arithmetic, same order as basis_kernel / orc_haar_from_normals; H lives in LDS (row i
-// owned by thread i), T is read through the scalar path.  blockDim = d rounded up to 64.
+// ---------------------------------------------------------------- Haar basis (run-time d <= DP)
+// Same arithmetic, same order as basis_kernel / orc_haar_from_normals.  Thread t owns row t of
+// H in REGISTERS (DP doubles, every loop unrolled; entries beyond d stay zero and the
+// reflector is zero-padded, so the extra terms are exact no-ops); the normals, the reflector
+// and the per-reflection scalars are in LDS.  H goes to LDS only for the final V = T H, over
+// the space of the normals: 80 KB at d = 100, i.e. two workgroups per CU.
 __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int nz = (d + 2) * (d - 1) / 2;
-    const int ldh = d | 1;
-    double* sz = smem;                  // [nz + 2]
-    double* sx = sz + ((nz + 3) & ~1);  // [d + 1]
-    double* sH = sx + ((d + 2) & ~1);   // [d][ldh]
+    double* sz = smem;                        // [nz + 2] normals
+    double* sx = sz + ((nz + 3) & ~1);        // [DP + 2] reflector (zero-padded)
+    double* sDn = sx + DP + 2;                // [DP] sign D_n
+    double* sPv = sDn + DP;                   // [DP] pivot x0 + D_n sqrt(norm2)
+    double* sDen = sPv + DP;                  // [DP] denominator
+    double* sH = smem;                        // [d][d] overlays everything, final phase only
     const int t = threadIdx.x, nt = blockDim.x;
     const uint32_t group = a.group0 + blockIdx.x;
     const uint32_t cycle = a.cycle0 + blockIdx.y;
@@ -60,46 +65,63 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
         sz[2 * j] = rad * cs;
         sz[2 * j + 1] = rad * sn;
     }
-    if (t < d)
-        for (int k = 0; k < d; ++k) sH[t * ldh + k] = (k == t) ? 1.0 : 0.0;
     __syncthreads();
-    double dprod = 1.0, Dmine = 1.0;
-    int ix = 0;
-    for (int n = 0; n < d - 1; ++n) {
-        const int m = d - n;
+    // The scalars of reflection n (norm, sign, pivot, denominator) depend on the normals only:
+    // thread n forms them for its reflection -- all reflections in parallel, each with the
+    // sequential chain the specification fixes.
+    if (t < d - 1) {
+        const int m = d - t;
+        const int ix = t * d - (t * (t - 1)) / 2;
         double norm2 = 0.0;
 #pragma unroll 8
         for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
         const double x0 = sz[ix];
         const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
-        dprod *= Dn;
-        if (t == n) Dmine = Dn;
         const double x0n = x0 + Dn * sqrt(norm2);
         double tt = norm2 - x0 * x0;
         tt = tt + x0n * x0n;
-        const double den = sqrt(0.5 * tt);
-        __syncthreads();
-        if (t < m) sx[t] = ((t == 0) ? x0n : sz[ix + t]) / den;
-        __syncthreads();
-        if (t < d) {
-            double* row = sH + t * ldh + n;
-            double tmp = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < m; ++k) tmp = fma(row[k], sx[k], tmp);
-#pragma unroll 8
-            for (int k = 0; k < m; ++k) row[k] = fma(-tmp, sx[k], row[k]);
-        }
-        ix += m;
+        sDn[t] = Dn;
+        sPv[t] = x0n;
+        sDen[t] = sqrt(0.5 * tt);
     }
+    __syncthreads();
+    double Dmine = (t < d - 1) ? sDn[t] : 1.0;
+    double dprod = 1.0;   // product of the signs, in order (exact: +-1)
+    for (int n = 0; n < d - 1; ++n) dprod *= sDn[n];
     if (t == d - 1) Dmine = (((d - 1) & 1) ? -1.0 : 1.0) * dprod;
-    if (t < d)
-        for (int k = 0; k < d; ++k) sH[t * ldh + k] = Dmine * sH[t * ldh + k];
+
+    double h[DP];         // row t of H
+#pragma unroll
+    for (int k = 0; k < DP; ++k) h[k] = (k == t) ? 1.0 : 0.0;
+    int ix = 0;
+#pragma unroll
+    for (int n = 0; n < DP - 1; ++n) {
+        if (n < d - 1) {   // uniform
+            const int m = d - n;
+            const double x0n = sPv[n], den = sDen[n];
+            __syncthreads();
+            if (t < DP - n) sx[t] = (t < m) ? ((t == 0) ? x0n : sz[ix + t]) / den : 0.0;
+            __syncthreads();
+            double tmp = 0.0;
+#pragma unroll
+            for (int k = 0; k < DP - n; ++k) tmp = fma(h[n + k], sx[k], tmp);
+#pragma unroll
+            for (int k = 0; k < DP - n; ++k) h[n + k] = fma(-tmp, sx[k], h[n + k]);
+            ix += m;
+        }
+    }
+    __syncthreads();      // the normals are dead: H takes their place in LDS
+    if (t < d) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+            if (k < d) sH[t * d + k] = Dmine * h[k];
+    }
     __syncthreads();
     if (t < d) {  // thread = column c of R; V[c][i] = sum_{k<=i} T[i][k] R[k][c]
         for (int i = 0; i < d; ++i) {
             double s = 0.0;
 #pragma unroll 8
-            for (int k = 0; k <= i; ++k) s = fma(T[i * d + k], sH[k * ldh + t], s);
+            for (int k = 0; k <= i; ++k) s = fma(T[i * d + k], sH[k * d + t], s);
             Vout[(size_t)t * ldv + i] = s;
         }
     }
@@ -680,13 +702,15 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, hipStream_t
 hipError_t launch_basis(const BasisArgs& a, int n_groups, int d, hipStream_t st)
 {
     const int nz = (d + 2) * (d - 1) / 2;
-    const size_t lds = sizeof(double) * (size_t)(((nz + 3) & ~1) + ((d + 2) & ~1) + d * (d | 1));
+    const size_t phase1 = (size_t)(((nz + 3) & ~1) + DP + 2 + 3 * DP);
+    const size_t phase2 = (size_t)d * d;
+    const size_t lds = sizeof(double) * (phase1 > phase2 ? phase1 : phase2);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)basis_big_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(basis_big_kernel, dim3(n_groups, a.ncyc), dim3(d <= 64 ? 64 : 128), lds, st,
+    hipLaunchKernelGGL(basis_big_kernel, dim3(n_groups, a.ncyc), dim3(DP <= 64 ? 64 : 128), lds, st,
                        a, d);
     return hipGetLastError();
 }
