@@ -165,7 +165,10 @@ def main():
     evals = float(a.walkers) * size * spl * a.steps
     out = None
     if rank == 0:
-        step_ms = kt["step_ms"] / max(kt["step_launches"], 1)
+        # one bench step = one engine.step(spl) call; the engine splits it into several kernel
+        # launches when the directions of spl steps exceed its 256 MiB buffer (d = 100)
+        step_ms = kt["step_ms"] / max(a.steps, 1)
+        launches_per_step = kt["step_launches"] / max(a.steps, 1)
         algo_bytes = ALGO_BYTES_PER_EVAL(d) * a.walkers * spl
         achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None
         traffic = None
@@ -177,7 +180,7 @@ def main():
                     t.get("steps_per_launch") == spl:
                 traffic = t.get("hbm_bytes_per_launch")
         out = {
-            "metric": "log-posterior evals/sec (whole node), 30-dim gaussian_mixture",
+            "metric": "log-posterior evals/sec (whole node), %d-dim gaussian_mixture" % d,
             "value": evals / dt, "unit": "evals/s", "n_gpus": size, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -192,14 +195,28 @@ def main():
                 "learn_checkpoints_in_timed_region": sampler.i_learn - n_ckpt0,
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
-            "roofline": {
+            "roofline": ({
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+            } if d <= 32 else {
+                # d > 32: the whitening runs on the matrix cores (v_mfma_f64_16x16x4_f64);
+                # algorithmic flops (d(d+1) + 4d per evaluation) against the dense FP64 peak
+                "bound": "mfma",
+                "achieved": (d * (d + 1) + 4 * d) * a.walkers * spl / (step_ms * 1e-3) / 1e12
+                if step_ms > 0 else None,
+                "peak": 78.6, "unit": "TFLOP/s",
+                "frac": ((d * (d + 1) + 4 * d) * a.walkers * spl / (step_ms * 1e-3) / 1e12 / 78.6)
+                if step_ms > 0 else None,
+                "traffic": traffic,
+                "algorithmic_GBps": achieved,
+            }) | {
                 "kernel": (("mcmc::step_pair_kernel<true> (d=%d)" % d)
                            if 8 <= d <= 32 and a.walkers % 256 == 0
                            else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
+                           else ("mcmc::step_mfma_kernel (d=%d)" % d) if a.walkers % 256 == 0
                            else ("mcmc::step_big_reg_kernel (d=%d)" % d)),
                 "kernel_ms_per_launch": step_ms,
+                "kernel_launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "note": ("achieved = algorithmic bytes (16d+24 B per evaluation, state "
                          "persisted every step, SURVEY 8d) / HIP-event duration of the step "
@@ -211,7 +228,7 @@ def main():
                     "achieved_tflops": (d * (d + 1) + 4 * d) * a.walkers * spl
                     / (step_ms * 1e-3) / 1e12 if step_ms > 0 else None,
                     "peak_tflops": 78.6},
-                "basis_kernel_ms_per_launch": kt["basis_ms"] / max(kt["step_launches"], 1),
+                "basis_kernel_ms_per_launch": kt["basis_ms"] / max(a.steps, 1),
                 "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1)},
         }
         if size == 1 and not a.no_cpu_baseline:

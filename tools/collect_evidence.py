@@ -3,7 +3,8 @@
 evidence under profiles/: r01_bench.json, r01_gpu_tests.log, r01_kernel_stats.txt,
 r01_pmc.txt and traffic.json (the per-launch HBM bytes bench.py copies into roofline.traffic).
 
-    python tools/collect_evidence.py [round-prefix, default r01]
+    python tools/collect_evidence.py [round-prefix, default r01] [source dir under gpurun_out,
+                                      default final; e.g. `r01_d100 d100` after tools/gpu_d100.sh]
 """
 import json
 import os
@@ -14,13 +15,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-CMD = "python bench.py --no-cpu-baseline --steps 20 --warmup 4"
+CMD = "python bench.py --no-cpu-baseline --steps 20 --warmup 4  (d = 100: --dim 100 --steps 10 --warmup 2)"
 
 
 def main():
+    global SRC
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    if len(sys.argv) > 2:
+        SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2])
+    main_run = len(sys.argv) <= 2
     shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{rnd}_bench.json"))
-    shutil.copy(os.path.join(SRC, "gpu_tests.log"), os.path.join(DST, f"{rnd}_gpu_tests.log"))
+    if os.path.exists(os.path.join(SRC, "gpu_tests.log")):
+        shutil.copy(os.path.join(SRC, "gpu_tests.log"), os.path.join(DST, f"{rnd}_gpu_tests.log"))
     with open(os.path.join(SRC, "bench.json")) as f:
         bench = json.loads(f.read().strip().splitlines()[-1])
     dom = bench["roofline"]["kernel"].split("(")[0].strip().split("::")[-1].split("<")[0]
@@ -63,7 +69,7 @@ def main():
             "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; KiB; "
                     "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, "
                     "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated"}
-        with open(os.path.join(DST, "traffic.json"), "w") as f:
+        with open(os.path.join(DST, "traffic.json" if main_run else f"{rnd}_traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     print(open(os.path.join(DST, f"{rnd}_kernel_stats.txt")).read())
     print(open(os.path.join(DST, f"{rnd}_pmc.txt")).read())
