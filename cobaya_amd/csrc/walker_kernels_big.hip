@@ -438,7 +438,19 @@ __device__ __forceinline__ void mfma_pass(d4 (&acc)[R1 - R0], const double (&x)[
     }
 }
 
-__global__ void __launch_bounds__(1024) step_mfma_kernel(const MfmaStepArgs b)
+// kMfmaWaves waves of 16 walkers per workgroup.  16 (256 walkers, one workgroup per CU, 128
+// registers per lane, two passes with 73 spilled registers) measured 4.04 ms per 200 steps at
+// d = 100; 8 (128 walkers, two workgroups per CU, 256 registers: one pass, no spills, no second
+// evaluation of the trial) 4.33 ms -- four waves per SIMD hide more than the spills cost.
+#ifndef MCMC_MFMA_WAVES
+#define MCMC_MFMA_WAVES 16
+#endif
+constexpr int kMfmaWaves = MCMC_MFMA_WAVES;
+constexpr int kMfmaWalkers = 16 * kMfmaWaves;
+constexpr int kMfmaThreads = 64 * kMfmaWaves;
+constexpr int kMfmaFirstPass = kMfmaWaves <= 8 ? RT : RH;
+
+__global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepArgs b)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const StepArgs& a = b.s;
@@ -447,18 +459,18 @@ __global__ void __launch_bounds__(1024) step_mfma_kernel(const MfmaStepArgs b)
     const int lane = tid & 63, wv = tid >> 6;
     const int c = lane >> 4;
     const int wl = wv * 16 + (lane & 15);
-    const int w = blockIdx.x * 256 + wl;
+    const int w = blockIdx.x * kMfmaWalkers + wl;
     const int W = a.W;
     const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
-    const int gpb = 256 / a.group_size;
+    const int gpb = (kMfmaWalkers + a.group_size - 1) / a.group_size;  // groups touching the block
     const int gib = __builtin_amdgcn_readfirstlane(wl / a.group_size);
     const bool stager = __builtin_amdgcn_readfirstlane(wl % a.group_size) == 0;
     const ConstLayout cl{d, 1};
     double* sL = smem;
     double* sE = sL + kTiles * 64;
     double* sVr = sE + 3 * 4 * KT;
-    for (int i = tid; i < kTiles * 64; i += 1024) sL[i] = b.Ltiles[i];
-    for (int i = tid; i < 4 * KT; i += 1024) {
+    for (int i = tid; i < kTiles * 64; i += kMfmaThreads) sL[i] = b.Ltiles[i];
+    for (int i = tid; i < 4 * KT; i += kMfmaThreads) {
         const bool in = i < d;
         sE[3 * i + 0] = in ? a.cblock[cl.lo() + i] : -INFINITY;
         sE[3 * i + 1] = in ? a.cblock[cl.hi() + i] : INFINITY;
@@ -507,18 +519,20 @@ __global__ void __launch_bounds__(1024) step_mfma_kernel(const MfmaStepArgs b)
         const double* __restrict__ v = sVr + (slot * gpb + gib) * 128;
         double p = 0.0;
         {
-            d4 acc[RH];
-            mfma_pass<0, RH>(acc, x, r, v, sE, sL, c, lane, d);
+            constexpr int R1 = kMfmaFirstPass;
+            d4 acc[R1];
+            mfma_pass<0, R1>(acc, x, r, v, sE, sL, c, lane, d);
 #pragma unroll
-            for (int q = 0; q < RH; ++q)
+            for (int q = 0; q < R1; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) p = fma(acc[q][e], acc[q][e], p);
         }
-        if (RT > RH) {
-            d4 acc[RT - RH > 0 ? RT - RH : 1];
-            mfma_pass<RH, RT>(acc, x, r, v, sE, sL, c, lane, d);
+        if (RT > kMfmaFirstPass) {   // (R0 is clamped so that the dead instantiation is valid)
+            constexpr int R0 = RT > kMfmaFirstPass ? kMfmaFirstPass : RT - 1;
+            d4 acc[RT - R0];
+            mfma_pass<R0, RT>(acc, x, r, v, sE, sL, c, lane, d);
 #pragma unroll
-            for (int q = 0; q < RT - RH; ++q)
+            for (int q = 0; q < RT - R0; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) p = fma(acc[q][e], acc[q][e], p);
         }
@@ -676,15 +690,19 @@ __global__ void __launch_bounds__(64) pool_moments_big_kernel(const MomentArgs a
 // ---------------------------------------------------------------- launchers
 hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, hipStream_t st)
 {
-    if (a.W % 256 == 0 && 256 % a.group_size == 0) {
+    if (a.W % kMfmaWalkers == 0 && (kMfmaWalkers % a.group_size == 0 || a.group_size % kMfmaWalkers == 0)) {
         // matrix-core kernel: its tiles follow the column-sweep copy of L^-1 in `Lcol`
         MfmaStepArgs m{a, Lcol + (size_t)DP * DP, d};
-        const size_t lds = sizeof(double) * (size_t)(kTiles * 64 + 12 * KT + 2 * (256 / a.group_size) * 128);
-        const size_t want = lds > (size_t)(96 << 10) ? lds : (size_t)(96 << 10);  // one per CU
+        const int gpb = (kMfmaWalkers + a.group_size - 1) / a.group_size;
+        const size_t lds = sizeof(double) * (size_t)(kTiles * 64 + 12 * KT + 2 * gpb * 128);
+        // placement: 256 walkers per CU at W = 65 536 -- ask for just under 1/n of the LDS so
+        // that exactly n = 256 / walkers-per-workgroup workgroups share a CU
+        const size_t share = ((size_t)(160 << 10) / (size_t)(256 / kMfmaWalkers)) - 2048;
+        const size_t want = lds > share ? lds : share;
         hipError_t e = hipFuncSetAttribute((const void*)step_mfma_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(step_mfma_kernel, dim3(a.W / 256), dim3(1024), want, st, m);
+        hipLaunchKernelGGL(step_mfma_kernel, dim3(a.W / kMfmaWalkers), dim3(kMfmaThreads), want, st, m);
         return hipGetLastError();
     }
     BigStepArgs b{a, Lcol, d};

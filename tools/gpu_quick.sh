@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k big 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 timeout 300 python tools/quick_engine_bench.py 100 65536 128 200 2>&1 | tail -1
-timeout 300 python tools/quick_engine_bench.py 64 65536 256 256 2>&1 | tail -1
