@@ -210,7 +210,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_GBps": achieved,
             }) | {
-                "kernel": (("mcmc::step_pair_kernel<true> (d=%d)" % d)
+                "kernel": (("mcmc::step_pair_kernel<true, false> (d=%d)" % d)
                            if 8 <= d <= 32 and a.walkers % 256 == 0
                            else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
                            else ("mcmc::step_mfma_kernel (d=%d)" % d) if a.walkers % 256 == 0
