@@ -8,6 +8,10 @@
 // HBM once per launch (coalesced, dimension-major).  DESIGN.md section 4 has the reasoning
 // and the measurements behind each of these choices.
 //
+// Kernels: step_kernel<MULTI, GENERAL> (one wave per 64 walkers; every feature),
+// step_pair_kernel<UNIT_T, NORMP> (the hot variant: two waves per 64 walkers), drag_kernel
+// (dragging steps), basis_kernel (Haar directions), evaluate_kernel, moment kernels.
+//
 // Restates (paths relative to the reference checkout):
 //   cobaya/samplers/mcmc/mcmc.py:545-562 (step) 670-683 (accept) 685-748 (bookkeeping)
 //   cobaya/samplers/mcmc/proposal.py:59-82,222-224 ; cobaya/functions.py:35-61 (Haar basis)
@@ -48,7 +52,8 @@ __device__ __forceinline__ cptr launder(cptr p)
 }
 
 // ---------------------------------------------------------------- operand streaming
-// With W = 65 536 walkers there is exactly ONE wave per SIMD, so nothing but the wave's own
+// With one lane per walker, W = 65 536 walkers give exactly ONE wave per SIMD (the paired kernel
+// below splits a walker set over two waves for that reason), so little but the wave's own
 // instruction stream can hide the latency of the scalar loads.  The operand streams are
 // therefore consumed in chunks with an explicit software pipeline:
 //     [use FIRST operand of chunk c]  -> the only s_waitcnt, for chunk c alone
