@@ -85,7 +85,11 @@ def all_reduce_sum(buf: np.ndarray) -> np.ndarray:
 
 def barrier():
     if size() > 1:
-        _td().barrier()
+        td = _td()
+        if td.get_backend() == "nccl":   # name the device: RCCL otherwise guesses (and warns)
+            td.barrier(device_ids=[local_rank()])
+        else:
+            td.barrier()
 
 
 def gather_rows(rows: np.ndarray):

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k(double* out, long long* clk, int iters,
 template <int KIND>
 void run(const char* name, double* out, long long* clk)
 {
-    const int iters = 1000;
+    const int iters = 20000;
     printf("%-34s", name);
     for (int wg : {256, 512, 1024}) {
         k<KIND><<<wg, 256>>>(out, clk, iters, 1.0000001);
