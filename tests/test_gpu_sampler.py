@@ -384,3 +384,41 @@ def test_dragging_from_likelihood_speeds():
     c = sampler.engine.counters()
     assert 0.1 < c["accepted"] / (c["steps"] * 1024) < 0.9
     sampler.close()
+
+
+def test_config2_full_size_run_converges():
+    """BASELINE config 2 through the plugin surface at full size: 30-d single-mode
+    gaussian_mixture, 65 536 walkers, learning on, run to the reference's default stopping
+    rule (R-1 < 0.01 twice, then the bounds criterion); posterior mean and covariance within
+    2 % from the few snapshots such a short run keeps (the 1 % of the north star is checked
+    on 20 snapshots by test_posterior_moments_full_size), far inside the reference's KL <= 0.07."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
+    mean, cov = g["mean_d30"], g["cov_d30"]
+    d = 30
+    names = [f"a__{i}" for i in range(d)]
+    sig = np.sqrt(np.diag(cov))
+    info = {
+        "likelihood": {"gaussian_mixture": {"means": [mean], "covs": [cov],
+                                            "input_params_prefix": "a_"}},
+        "params": {n: {"prior": {"min": 0.0, "max": 1.0},
+                       "ref": {"dist": "norm", "loc": float(mean[i]), "scale": float(sig[i])},
+                       "proposal": float(sig[i])} for i, n in enumerate(names)},
+        "sampler": {"mcmc_hip": {"seed": 11, "n_walkers": 65536, "Rminus1_stop": 0.01,
+                                 "Rminus1_cl_stop": 0.2,
+                                 "max_samples": 2 * 10 ** 10}}}   # bounds the run to seconds
+    updated, sampler = run(info)
+    assert sampler.converged
+    prog = sampler.products()["progress"]
+    assert float(prog["Rminus1"].to_numpy(dtype=float)[-1]) < 0.01
+    coll = sampler.products(skip_samples=0.3)["sample"]
+    m, c = coll.mean(), coll.cov()
+    # one ensemble snapshot alone pins a mean to 0.4 % of sigma (65 536 walkers); the run stops
+    # after a few of them, so the largest of 30 deviations sits around 1 %
+    assert np.max(np.abs(m - mean) / sig) < 0.02, (len(coll), np.max(np.abs(m - mean) / sig))
+    assert np.max(np.abs(c - cov) / np.outer(sig, sig)) < 0.02
+    assert kl_norm(mean, cov, m, c) < 0.01
+    # the learned proposal covariance is the posterior covariance
+    learned = sampler.proposer.get_covariance()
+    assert np.max(np.abs(learned - cov) / np.outer(sig, sig)) < 0.02
+    sampler.close()
