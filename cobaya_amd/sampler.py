@@ -314,6 +314,7 @@ class MCMCHip:
         self.collection = SampleCollection(spec.sampled, spec.derived, self._like_names(),
                                            self.temperature, name=str(1 + self.rank))
         self._thin_carry = {}    # chains mode with thinned output: added weight per walker
+        self._snap_stride, self._snap_count, self._rows_capped = 1, 0, False
         self._rows = []          # (walker, weight, logpost, logprior, loglike, x...) blocks
         self._n_rows = 0
         self._intervals = []     # per checkpoint: (n_snapshots, group_sum[G,d], pooled_S[d,d])
@@ -497,7 +498,8 @@ class MCMCHip:
                      book=np.array([self.n_steps_raw, self.i_learn, self._acc_last,
                                     self._steps_last, self._launches, self._dropped_snapshots,
                                     self._accepted_total, self.seed, self.size,
-                                    int(self.n_walkers), int(self._next_ckpt or 0)],
+                                    int(self.n_walkers), int(self._next_ckpt or 0),
+                                    self._snap_stride, self._snap_count],
                                    dtype=np.int64),
                      fbook=np.array([self._acc_rate, self.Rminus1_last, float(self.converged),
                                      self.learn_proposal_Rminus1_max]),
@@ -523,6 +525,8 @@ class MCMCHip:
         (self.n_steps_raw, self.i_learn, self._acc_last, self._steps_last, self._launches,
          self._dropped_snapshots, self._accepted_total) = (int(v) for v in book[:7])
         self._next_ckpt = int(book[10]) or None
+        if len(book) > 12:
+            self._snap_stride, self._snap_count = int(book[11]), int(book[12])
         if int(book[7]) != int(self.seed):
             log.warning("Resuming with the seed of the checkpoint (%d), not %d", int(book[7]),
                         int(self.seed))
@@ -562,9 +566,27 @@ class MCMCHip:
         return out
 
     def _store_rows(self, rows):
+        """Keeps at most `max_rows` rows per process WITHOUT freezing: the bounds criterion
+        (mcmc.py:918-1002) looks at the later half of the stored samples, so the store must
+        keep following the run.  Snapshots: when full, every other stored snapshot is dropped
+        and from then on only every second (fourth, ...) snapshot is kept -- a uniformly
+        thinned record of the whole run.  Chains: the oldest half of the rows is dropped."""
         if len(rows) and self.emit == "chains" and self.output_thin > 1:
             rows = self._thin_rows(rows)
-        if len(rows) and self._n_rows < self.max_rows:
+        if not len(rows) or self.max_rows <= 0:
+            return
+        if self._n_rows + len(rows) > self.max_rows and len(self._rows) > 1:
+            if self.emit == "snapshots":
+                self._rows = self._rows[1::2]
+                self._snap_stride *= 2
+            else:
+                self._rows = self._rows[len(self._rows) // 2:]
+            self._n_rows = sum(len(r) for r in self._rows)
+            if not self._rows_capped:
+                self._rows_capped = True
+                log.info("max_rows (%d) reached: older stored samples are thinned out as the "
+                         "run goes on.", self.max_rows)
+        if self._n_rows + len(rows) <= self.max_rows or not self._rows:
             self._rows.append(rows)
             self._n_rows += len(rows)
 
@@ -572,7 +594,8 @@ class MCMCHip:
         """Thinned sample emission: the current point of every walker with weight 1 (the
         ensemble analogue of `output_thin`, collection.py:1362-1372)."""
         self._since_snapshot = 0
-        if self._n_rows >= self.max_rows:
+        self._snap_count += 1
+        if self.max_rows <= 0 or self._snap_count % self._snap_stride:
             return
         s = self.engine.get_state()
         W = len(s["x"])

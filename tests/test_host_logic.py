@@ -418,3 +418,30 @@ def test_thinned_chain_rows_follow_the_reference_rule():
     for w in range(4):
         got = out[out[:, 0] == w]
         assert [(int(a), b) for a, b in zip(got[:, 1], got[:, 2])] == expect[w]
+
+
+def test_row_store_keeps_following_the_run():
+    """max_rows must not freeze the stored samples (the bounds criterion reads their later
+    half): full snapshot stores are thinned by two and the stride doubles; chain stores drop
+    their oldest half."""
+    s = _bare_sampler(None, emit="snapshots", max_rows=10 * 8)
+    s._rows, s._n_rows, s._snap_stride, s._snap_count, s._rows_capped = [], 0, 1, 0, False
+    s.output_thin, s.rank = 1, 0
+
+    class FakeEngine:
+        def get_state(self):
+            z = np.zeros(8)
+            return {"x": np.full((8, 2), float(s._snap_count)), "logpost": z, "logprior": z,
+                    "loglike": z}
+
+    s.engine = FakeEngine()
+    for _ in range(200):
+        s._snapshot()
+    stamps = [int(r[0, 5]) for r in s._rows]
+    assert s._n_rows <= 80 and len(stamps) >= 5
+    assert stamps == sorted(stamps) and stamps[-1] > 180 and stamps[0] < 60  # spans the run
+    c = _bare_sampler(None, emit="chains", max_rows=100)
+    c._rows, c._n_rows, c._rows_capped, c.output_thin = [], 0, False, 1
+    for k in range(30):
+        c._store_rows(np.full((10, 7), float(k)))
+    assert c._n_rows <= 100 and int(c._rows[-1][0, 0]) == 29
