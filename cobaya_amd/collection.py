@@ -68,25 +68,101 @@ class SampleCollection:
         return self.data[key]
 
     # ------------------------------------------------------------------ statistics
-    def _xw(self, first, last, derived):
-        df = self.data
-        names = self.sampled_params + (self.derived_params if derived else [])
-        return (df[names][first:last].to_numpy(dtype=np.float64),
-                df["weight"][first:last].to_numpy(dtype=np.float64))
+    @property
+    def is_tempered(self):
+        return self.temperature != 1
 
-    def mean(self, first=None, last=None, derived=False):
-        """collection.py:893-934."""
+    def _detempered_weights(self, with_batch=None):
+        """collection.py:688-731: weights of the unit-temperature posterior, one vector per
+        collection of the batch: w * exp(logp (1 - 1/T)) with logp the untempered
+        log-posterior, normalised by the largest log-posterior of the whole batch."""
+        batch = [self] + list(with_batch or [])
+        temps = [c.temperature for c in batch]
+        if not np.allclose(temps, temps[0]):
+            raise ValueError(f"Temperature inconsistent across the batch: {temps}.")
+        weights = [c.data["weight"].to_numpy(dtype=np.float64) for c in batch]
+        if self.temperature == 1:
+            return weights
+        T = self.temperature
+        tlp = [-c.data["minuslogpost"].to_numpy(dtype=np.float64) for c in batch]
+        mx = np.max(np.concatenate(tlp))
+        max_log_ratio = mx / (1 / T) - mx          # remove_temperature(x, T) = x / (1 / T)
+        return [w * np.exp((lp / (1 / T) - lp) - max_log_ratio) for w, lp in zip(weights, tlp)]
+
+    def _detempered_minuslogpost(self):
+        """collection.py:733-739."""
+        mlp = self.data["minuslogpost"].to_numpy(dtype=np.float64)
+        return mlp if self.temperature == 1 else -((-mlp) / (1 / self.temperature))
+
+    def _set_data(self, arr):
+        self._blocks, self._data = ([arr] if len(arr) else []), None
+
+    def copy(self):
+        """collection.py:850-857."""
+        c = SampleCollection(self.sampled_params, self.derived_params,
+                             [n[len("chi2__"):] for n in self.chi2_names], self.temperature,
+                             self.name)
+        c._set_data(self.data.to_numpy(dtype=np.float64).copy())
+        return c
+
+    def reset_temperature(self, with_batch=None):
+        """collection.py:741-763: `weight` and `minuslogpost` become those of a
+        unit-temperature sample (rows of zero weight dropped); irreversible."""
+        weights_batch = self._detempered_weights(with_batch=with_batch)
+        if self.temperature == 1:
+            return
+        for c, w in zip([self] + list(with_batch or []), weights_batch):
+            arr = c.data.to_numpy(dtype=np.float64).copy()
+            arr[:, c.columns.index("minuslogpost")] = c._detempered_minuslogpost()
+            arr[:, c.columns.index("weight")] = w
+            c.temperature = 1.0
+            c._set_data(arr[arr[:, c.columns.index("weight")] > 0])
+
+    def reweight(self, importance_weights, with_batch=None, check=True):
+        """collection.py:988-1019: multiplies the (detempered) weights in place."""
+        self.reset_temperature(with_batch=with_batch)
+        if not hasattr(importance_weights[0], "__len__"):
+            importance_weights = [importance_weights]
+        batch = [self] + list(with_batch or [])
+        for c, iw in zip(batch, importance_weights):
+            iw = np.asarray(iw, dtype=np.float64)
+            if check and (len(iw) != len(c) or np.any(iw < 0)):
+                raise ValueError("importance weights must be non-negative, one per sample")
+            arr = c.data.to_numpy(dtype=np.float64).copy()
+            arr[:, c.columns.index("weight")] *= iw
+            c._set_data(arr[arr[:, c.columns.index("weight")] > 0])
+
+    def _weights_for_stats(self, first, last, weights, tempered):
+        """collection.py:859-891: (weights, known to be integer)."""
+        if weights is not None:
+            weights = np.asarray(weights, dtype=np.float64)
+            weights = weights / max(weights)
+            return weights, bool(np.allclose(np.round(weights), weights))
+        if self.is_tempered and not tempered:
+            return self._detempered_weights()[0][first:last], False
+        w = self.data["weight"][first:last].to_numpy(dtype=np.float64)
+        return w, bool(np.allclose(np.round(w), w))
+
+    def _x(self, first, last, derived):
+        names = self.sampled_params + (self.derived_params if derived else [])
+        return self.data[names][first:last].to_numpy(dtype=np.float64)
+
+    def mean(self, first=None, last=None, weights=None, derived=False, tempered=False):
+        """collection.py:893-934.  For a tempered sample the default is the mean of the
+        unit-temperature posterior (weights detempered on the fly); `tempered=True` gives the
+        mean of p**(1/T)."""
         if not len(self):
             raise ValueError("Collection is empty. Cannot compute mean.")
-        x, w = self._xw(first, last, derived)
-        return np.average(x.T, weights=w, axis=-1)
+        w, _ = self._weights_for_stats(first, last, weights, tempered)
+        return np.average(self._x(first, last, derived).T, weights=w, axis=-1)
 
-    def cov(self, first=None, last=None, derived=False):
-        """collection.py:936-981 (ddof=0; integer weights as fweights)."""
+    def cov(self, first=None, last=None, weights=None, derived=False, tempered=False):
+        """collection.py:936-981 (ddof=0; integer weights as fweights, else aweights)."""
         if not len(self):
             raise ValueError("Collection is empty. Cannot compute cov.")
-        x, w = self._xw(first, last, derived)
-        if np.allclose(np.round(w), w):
+        w, are_int = self._weights_for_stats(first, last, weights, tempered)
+        x = self._x(first, last, derived)
+        if are_int:
             return np.atleast_2d(np.cov(x.T, ddof=0, fweights=np.round(w).astype(np.int64)))
         return np.atleast_2d(np.cov(x.T, ddof=0, aweights=w))
 

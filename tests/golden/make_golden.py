@@ -350,6 +350,37 @@ def g11_param_blocking():
     print("wrote g11_param_blocking.json", len(cases), "cases")
 
 
+def g12_detempering():
+    """(f)4 collection utilities on a tempered chain (collection.py:688-763, 859-1019):
+    detempered weights / -logpost, mean and covariance with and without tempering,
+    reset_temperature, reweight."""
+    info = copy.deepcopy(FIXED3)
+    model = get_model(info)
+    sampler = get_sampler({"mcmc": {"seed": 31, "max_samples": 400, "temperature": 3,
+                                    "learn_proposal": False, "measure_speeds": False,
+                                    "Rminus1_stop": 0.0, "Rminus1_cl_stop": 0.0}}, model)
+    sampler.run()
+    c = sampler.collection
+    data = c.data.to_numpy(dtype=np.float64)
+    out = {"columns": np.array(list(c.data.columns)), "data": data,
+           "temperature": np.array(float(c.temperature)),
+           "mean_tempered": c.mean(tempered=True), "cov_tempered": c.cov(tempered=True),
+           "mean_detempered": c.mean(), "cov_detempered": c.cov(),
+           "mean_slice": c.mean(first=50, last=300), "cov_slice": c.cov(first=50, last=300)}
+    d1 = c.copy()
+    d1.reset_temperature()
+    out["reset_data"] = d1.data.to_numpy(dtype=np.float64)
+    out["reset_temperature"] = np.array(float(d1.temperature))
+    iw = np.random.default_rng(5).uniform(0, 2, size=len(c))
+    iw[::7] = 0.0  # zero-weight rows are dropped
+    d2 = c.copy()
+    d2.reweight(iw.copy())
+    out["importance_weights"] = iw
+    out["reweight_data"] = d2.data.to_numpy(dtype=np.float64)
+    save("g12_detempering", **out)
+    print("g12 rows", data.shape, "->", out["reset_data"].shape, out["reweight_data"].shape)
+
+
 def g7_multichain():
     """a16 multi-chain branch (mcmc.py:787-793, 856-889, 1021-1023) driven without MPI:
     m samplers in one process, `more_than_one_process` and `mpi.array_gather` patched so
@@ -457,3 +488,4 @@ if __name__ == "__main__":
     g9_initial_covmat()
     g10_blocked()
     g11_param_blocking()
+    g12_detempering()

@@ -301,8 +301,14 @@ def test_temperature_2_samples_the_tempered_posterior():
     np.testing.assert_allclose(sampler.proposer.get_covariance(), 2 * tc, rtol=0.3, atol=1e-5)
     coll = sampler.products()["sample"]
     n0 = len(coll) // 3
-    m, c = coll.mean(first=n0), coll.cov(first=n0)
+    m, c = coll.mean(first=n0, tempered=True), coll.cov(first=n0, tempered=True)
     assert kl_norm(tm, 2 * tc, m, c) < 0.01
+    # detempered statistics (the default of mean/cov, collection.py:859-981) and an explicitly
+    # detempered copy both recover the unit-temperature posterior
+    assert kl_norm(tm, tc, coll.mean(first=n0), coll.cov(first=n0)) < 0.01
+    unit = coll.copy()
+    unit.reset_temperature()
+    assert unit.temperature == 1 and kl_norm(tm, tc, unit.mean(first=n0), unit.cov(first=n0)) < 0.01
     row = coll.data.iloc[-1]
     logpost = -(row["minuslogprior"] + 0.5 * row["chi2"])
     assert row["minuslogpost"] == pytest.approx(-logpost / 2.0, rel=1e-12)

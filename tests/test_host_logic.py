@@ -198,9 +198,10 @@ def test_collection_columns_stats_and_txt(tmp_path):
                                     "minuslogprior", "minuslogprior__0", "chi2",
                                     "chi2__gaussian_mixture"]
     assert len(c) == n and c["minuslogpost"][3] == 1.5 and c["chi2"][0] == 4.0
-    np.testing.assert_allclose(c.mean(), R.weighted_mean(x, w), rtol=1e-14)
-    np.testing.assert_allclose(c.cov(first=10, last=40), R.weighted_cov(x[10:40], w[10:40]),
-                               rtol=1e-13)
+    # (the collection is tempered: the raw integer weights are those of p**(1/T))
+    np.testing.assert_allclose(c.mean(tempered=True), R.weighted_mean(x, w), rtol=1e-14)
+    np.testing.assert_allclose(c.cov(first=10, last=40, tempered=True),
+                               R.weighted_cov(x[10:40], w[10:40]), rtol=1e-13)
     path = tmp_path / "chain.1.txt"
     c.to_txt(path)
     lines = open(path).read().splitlines()
@@ -445,3 +446,35 @@ def test_row_store_keeps_following_the_run():
     for k in range(30):
         c._store_rows(np.full((10, 7), float(k)))
     assert c._n_rows <= 100 and int(c._rows[-1][0, 0]) == 29
+
+
+def test_detempering_and_reweighting_match_the_reference(golden):
+    """G12: a T = 3 reference chain -- tempered and detempered mean/cov, reset_temperature and
+    reweight (collection.py:688-763, 859-1019) reproduce the reference's numbers."""
+    g = golden("g12_detempering")
+    cols = [str(c) for c in g["columns"]]
+    sampled = cols[2:cols.index("minuslogprior")][:3]
+    derived = cols[2 + len(sampled):cols.index("minuslogprior")]
+
+    def make():
+        c = SampleCollection(sampled, derived, "gaussian_mixture", float(g["temperature"]))
+        c._set_data(g["data"].copy())
+        assert c.columns == cols
+        return c
+
+    c = make()
+    np.testing.assert_allclose(c.mean(tempered=True), g["mean_tempered"], rtol=1e-13)
+    np.testing.assert_allclose(c.cov(tempered=True), g["cov_tempered"], rtol=1e-12)
+    np.testing.assert_allclose(c.mean(), g["mean_detempered"], rtol=1e-12)
+    np.testing.assert_allclose(c.cov(), g["cov_detempered"], rtol=1e-11)
+    np.testing.assert_allclose(c.mean(first=50, last=300), g["mean_slice"], rtol=1e-12)
+    np.testing.assert_allclose(c.cov(first=50, last=300), g["cov_slice"], rtol=1e-11)
+    d1 = c.copy()
+    d1.reset_temperature()
+    assert d1.temperature == float(g["reset_temperature"]) == 1.0
+    np.testing.assert_allclose(d1.data.to_numpy(), g["reset_data"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(c.data.to_numpy(), g["data"])          # the copy was independent
+    d2 = make()
+    d2.reweight(g["importance_weights"].copy())
+    np.testing.assert_allclose(d2.data.to_numpy(), g["reweight_data"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(d1.mean(), g["mean_detempered"], rtol=1e-12)
