@@ -12,7 +12,8 @@ reference cobaya v3.6.2 (no numba => scipy special_ortho_group fallback).  The t
 `getdist` is absent here; a 4-name stand-in (tests/golden/_getdist_stub) satisfies the
 import in cobaya/collection.py:18-19 and is never called.
 
-Fixture ids follow SURVEY.md §8c (G1..G9).
+Fixture ids follow SURVEY.md §8c (G1..G9); G10 (blocked / oversampled / dragging chains), G11
+(parameter-blocking decisions) and G12 (detempering, reweighting) were added for §8f.
 """
 import copy
 import json
