@@ -478,3 +478,52 @@ def test_detempering_and_reweighting_match_the_reference(golden):
     d2.reweight(g["importance_weights"].copy())
     np.testing.assert_allclose(d2.data.to_numpy(), g["reweight_data"], rtol=1e-12, atol=1e-300)
     np.testing.assert_allclose(d1.mean(), g["mean_detempered"], rtol=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cobaya"),
+                    reason="the Cobaya reference tree is only mounted in the build container")
+def test_reference_loads_our_chain_file(tmp_path):
+    """(f)2: a chain file written by SampleCollection.to_txt is read back by the REFERENCE's
+    own SampleCollection (collection.py:1290-1333 `_load`): same columns, same values."""
+    import subprocess
+    import sys
+    names = ["a", "b"]
+    c = SampleCollection(names, ["derived_a", "derived_b"], "gaussian_mixture")
+    rng = np.random.default_rng(3)
+    n = 40
+    x = rng.normal(size=(n, 2))
+    lp, ll = -np.full(n, 1.25), -rng.uniform(0.5, 3, n)   # consistent rows: the loader checks
+    c.add_rows(rng.integers(1, 9, size=n), lp + ll, x, lp, ll, x * 2)  # logpost = prior + like
+    prefix = tmp_path / "run"
+    c.to_txt(f"{prefix}.1.txt")
+    np.save(tmp_path / "expect.npy", c.data.to_numpy())
+    code = r'''
+import sys
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, "/root/reference"]
+import logging
+logging.disable(logging.CRITICAL)
+import numpy as np
+from cobaya.model import get_model
+from cobaya.output import get_output
+from cobaya.collection import SampleCollection
+info = {"likelihood": {"gaussian_mixture": {"means": [0.2, 0], "covs": [[0.1, 0.05], [0.05, 0.2]],
+                                            "derived": True}},
+        "params": {"a": {"prior": {"min": -0.5, "max": 3}},
+                   "b": {"prior": {"dist": "norm", "loc": 0, "scale": 1}},
+                   "derived_a": None, "derived_b": None}}
+model = get_model(info)
+out = get_output(prefix=%r, resume=True)
+col = SampleCollection(model, out, name="1", load=True)
+expect = np.load(%r)
+assert list(col.data.columns) == ["weight", "minuslogpost", "a", "b", "derived_a", "derived_b",
+                                  "minuslogprior", "minuslogprior__0", "chi2",
+                                  "chi2__gaussian_mixture"], list(col.data.columns)
+assert len(col) == len(expect)
+np.testing.assert_allclose(col.data.to_numpy(dtype=float), expect, rtol=2e-7)  # %.8g text
+print("LOADED", len(col))
+''' % (os.path.join(ROOT, "tests", "golden", "_getdist_stub"), str(prefix),
+       str(tmp_path / "expect.npy"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         timeout=300)
+    assert "LOADED 40" in out.stdout, out.stdout + out.stderr
