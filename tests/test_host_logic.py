@@ -520,7 +520,7 @@ assert list(col.data.columns) == ["weight", "minuslogpost", "a", "b", "derived_a
                                   "minuslogprior", "minuslogprior__0", "chi2",
                                   "chi2__gaussian_mixture"], list(col.data.columns)
 assert len(col) == len(expect)
-np.testing.assert_allclose(col.data.to_numpy(dtype=float), expect, rtol=2e-7)  # %.8g text
+np.testing.assert_allclose(col.data.to_numpy(dtype=float), expect, rtol=2e-7)  # 8 significant digits in the text
 print("LOADED", len(col))
 ''' % (os.path.join(ROOT, "tests", "golden", "_getdist_stub"), str(prefix),
        str(tmp_path / "expect.npy"))
