@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 120 python -m pytest tests/test_gpu_sampler.py -x -q -k config2 --durations=3 2>&1 | tail -25
+timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
