@@ -13,7 +13,9 @@ reference cobaya v3.6.2 (no numba => scipy special_ortho_group fallback).  The t
 import in cobaya/collection.py:18-19 and is never called.
 
 Fixture ids follow SURVEY.md §8c (G1..G9); G10 (blocked / oversampled / dragging chains), G11
-(parameter-blocking decisions) and G12 (detempering, reweighting) were added for §8f.
+(parameter-blocking decisions) and G12 (detempering, reweighting) were added for §8f; G2 and G8
+share one file (g2_g8_haar_chainstats.npz).  G3 (radial law) is a statistical test of the
+oracle's own stream (tests/test_oracle_c.py), not a stored vector.
 """
 import copy
 import json
@@ -382,6 +384,32 @@ def g12_detempering():
     print("g12 rows", data.shape, "->", out["reset_data"].shape, out["reweight_data"].shape)
 
 
+def g2_g8_haar_and_chain_stats():
+    """G2 (a3): PCG64 state -> SO(n) matrix of functions.random_SO_N (scipy fallback here);
+    G8 (a15): SampleCollection.mean / cov over [first:last] of a stored integer-weight chain."""
+    from cobaya.functions import random_SO_N
+    out = {}
+    for n in (2, 3, 5, 30):
+        rng = np.random.default_rng(1000 + n)
+        out[f"haar_state_{n}"] = np.array(rng_state_json(rng))
+        out[f"haar_{n}"] = random_SO_N(n, random_state=rng)
+        out[f"haar_next_normal_{n}"] = np.array(rng.standard_normal())  # stream position after
+    model = get_model(copy.deepcopy(QUICKSTART))
+    sampler = get_sampler({"mcmc": {"seed": 41, "max_samples": 500, "learn_proposal": False,
+                                    "measure_speeds": False, "Rminus1_stop": 0.0,
+                                    "Rminus1_cl_stop": 0.0}}, model)
+    sampler.run()
+    c = sampler.collection
+    out["chain_columns"] = np.array(list(c.data.columns))
+    out["chain_data"] = c.data.to_numpy(dtype=np.float64)
+    for tag, (first, last) in {"all": (None, None), "mid": (100, 400), "tail": (250, None)}.items():
+        out[f"mean_{tag}"] = c.mean(first=first, last=last)
+        out[f"cov_{tag}"] = c.cov(first=first, last=last)
+        out[f"mean_derived_{tag}"] = c.mean(first=first, last=last, derived=True)
+        out[f"cov_derived_{tag}"] = c.cov(first=first, last=last, derived=True)
+    save("g2_g8_haar_chainstats", **out)
+
+
 def g7_multichain():
     """a16 multi-chain branch (mcmc.py:787-793, 856-889, 1021-1023) driven without MPI:
     m samplers in one process, `more_than_one_process` and `mpi.array_gather` patched so
@@ -490,3 +518,4 @@ if __name__ == "__main__":
     g10_blocked()
     g11_param_blocking()
     g12_detempering()
+    g2_g8_haar_and_chain_stats()

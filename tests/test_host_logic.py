@@ -527,3 +527,20 @@ print("LOADED", len(col))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                          timeout=300)
     assert "LOADED 40" in out.stdout, out.stdout + out.stderr
+
+
+def test_g8_chain_statistics_match_the_reference(golden):
+    """G8 (a15): weighted mean / covariance over [first:last] of a stored integer-weight chain,
+    with and without the derived parameters (collection.py:893-981)."""
+    g = golden("g2_g8_haar_chainstats")
+    cols = [str(c) for c in g["chain_columns"]]
+    c = SampleCollection(["a", "b"], ["derived_a", "derived_b"], "gaussian_mixture")
+    assert c.columns == cols
+    c._set_data(g["chain_data"].copy())
+    for tag, (first, last) in {"all": (None, None), "mid": (100, 400), "tail": (250, None)}.items():
+        np.testing.assert_allclose(c.mean(first=first, last=last), g[f"mean_{tag}"], rtol=1e-14)
+        np.testing.assert_allclose(c.cov(first=first, last=last), g[f"cov_{tag}"], rtol=1e-12)
+        np.testing.assert_allclose(c.mean(first=first, last=last, derived=True),
+                                   g[f"mean_derived_{tag}"], rtol=1e-14)
+        np.testing.assert_allclose(c.cov(first=first, last=last, derived=True),
+                                   g[f"cov_derived_{tag}"], rtol=1e-12)

@@ -212,3 +212,17 @@ def test_haar_so_n_is_special_orthogonal():
         H = R.haar_so_n(n, rng)
         np.testing.assert_allclose(H @ H.T, np.eye(n), atol=1e-13)
         assert np.linalg.det(H) == pytest.approx(1.0, abs=1e-12)
+
+
+def test_g2_haar_matrix_from_the_numpy_stream(golden):
+    """G2 (a3): from the same PCG64 state, haar_so_n returns the reference's random_SO_N matrix
+    and leaves the stream at the same position."""
+    g = golden("g2_g8_haar_chainstats")
+    for n in (2, 3, 5, 30):
+        rng = np.random.Generator(np.random.PCG64())
+        rng.bit_generator.state = json.loads(str(g[f"haar_state_{n}"]))
+        H = R.haar_so_n(n, rng)
+        np.testing.assert_allclose(H, g[f"haar_{n}"], rtol=0, atol=4e-16)
+        assert rng.standard_normal() == float(g[f"haar_next_normal_{n}"])
+        np.testing.assert_allclose(H @ H.T, np.eye(n), atol=1e-14)
+        assert np.linalg.det(H) == pytest.approx(1.0, abs=1e-12)
