@@ -909,9 +909,6 @@ __global__ void __launch_bounds__(512) step_pair_kernel(const StepArgs a)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if constexpr (kPair) {
         const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-#ifdef MCMC_PRIO
-        if (role == 0) __builtin_amdgcn_s_setprio(MCMC_PRIO);   // developer experiment
-#endif
         if (role == 0) pair_steps<0, UNIT_T, NORMP>(a, (lds_t)smem);
         else pair_steps<1, UNIT_T, NORMP>(a, (lds_t)smem);
     }
