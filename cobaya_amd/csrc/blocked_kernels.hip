@@ -25,8 +25,13 @@ __global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArg
     __shared__ double sH[kMaxN * (kMaxN + 1)];
     __shared__ double sz[(kMaxN + 2) * (kMaxN - 1) / 2 + 2];
     __shared__ double sx[kMaxN + 1];
-    __shared__ unsigned sw[kMaxSlots];
-    __shared__ short sblk[kMaxSlots], sbas[kMaxSlots], scol[kMaxSlots];
+    __shared__ double sDn[kMaxN], sPv[kMaxN], sDen[kMaxN];
+    // per-slot arrays sized by the cycle length (dynamic LDS): several workgroups per CU
+    extern __shared__ unsigned dyn_lds[];
+    unsigned* const sw = dyn_lds;                       // [L] shuffle words
+    short* const sblk = (short*)(dyn_lds + a.L);        // [L] block of the slot
+    short* const sbas = sblk + a.L;                     // [L] basis number
+    short* const scol = sbas + a.L;                     // [L] column of the basis
     __shared__ int sIofJ[kMaxN], sSize[kMaxN], sOver[kMaxN];
     const int t = threadIdx.x;
     const int d = a.d, L = a.L;
@@ -109,38 +114,56 @@ __global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArg
                 sz[2 * j] = rad * cs;
                 sz[2 * j + 1] = rad * sn;
             }
-            if (t < n)
-                for (int k = 0; k < n; ++k) sH[t * ldh + k] = (k == t) ? 1.0 : 0.0;
             __syncthreads();
-            // Householder construction, the arithmetic and order of orc_haar_from_normals
-            double dprod = 1.0, Dmine = 1.0;
-            int ix = 0;
-            for (int m0 = 0; m0 < n - 1; ++m0) {
-                const int m = n - m0;
+            // Householder construction, the arithmetic and order of orc_haar_from_normals.
+            // The scalars of reflection m0 (norm, sign, pivot, denominator) depend on the
+            // normals only: thread m0 forms them, all reflections in parallel; row t of H
+            // lives in registers (kMaxN entries, zero beyond n, the reflector zero-padded so
+            // that the extra terms are exact no-ops) and goes to LDS for the column products.
+            if (t < n - 1) {
+                const int m = n - t;
+                const int ix0 = t * n - (t * (t - 1)) / 2;
                 double norm2 = 0.0;
-                for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
-                const double x0 = sz[ix];
+                for (int k = 0; k < m; ++k) norm2 = fma(sz[ix0 + k], sz[ix0 + k], norm2);
+                const double x0 = sz[ix0];
                 const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
-                dprod *= Dn;
-                if (t == m0) Dmine = Dn;
                 const double x0n = x0 + Dn * sqrt(norm2);
                 double tt = norm2 - x0 * x0;
                 tt = tt + x0n * x0n;
-                const double den = sqrt(0.5 * tt);
-                __syncthreads();
-                if (t < m) sx[t] = ((t == 0) ? x0n : sz[ix + t]) / den;
-                __syncthreads();
-                if (t < n) {
-                    double* row = sH + t * ldh + m0;
-                    double tmp = 0.0;
-                    for (int k = 0; k < m; ++k) tmp = fma(row[k], sx[k], tmp);
-                    for (int k = 0; k < m; ++k) row[k] = fma(-tmp, sx[k], row[k]);
-                }
-                ix += m;
+                sDn[t] = Dn;
+                sPv[t] = x0n;
+                sDen[t] = sqrt(0.5 * tt);
             }
+            __syncthreads();
+            double Dmine = (t < n - 1) ? sDn[t] : 1.0;
+            double dprod = 1.0;
+            for (int m0 = 0; m0 < n - 1; ++m0) dprod *= sDn[m0];
             if (t == n - 1) Dmine = (((n - 1) & 1) ? -1.0 : 1.0) * dprod;
-            if (t < n)
-                for (int k = 0; k < n; ++k) sH[t * ldh + k] = Dmine * sH[t * ldh + k];
+            double h[kMaxN];
+#pragma unroll
+            for (int k = 0; k < kMaxN; ++k) h[k] = (k == t) ? 1.0 : 0.0;
+            int ix = 0;
+#pragma unroll
+            for (int m0 = 0; m0 < kMaxN - 1; ++m0) {
+                if (m0 < n - 1) {   // uniform
+                    const int m = n - m0;
+                    const double x0n = sPv[m0], den = sDen[m0];
+                    __syncthreads();
+                    if (t < kMaxN - m0) sx[t] = (t < m) ? ((t == 0) ? x0n : sz[ix + t]) / den : 0.0;
+                    __syncthreads();
+                    double tmp = 0.0;
+#pragma unroll
+                    for (int k = 0; k < kMaxN - m0; ++k) tmp = fma(h[m0 + k], sx[k], tmp);
+#pragma unroll
+                    for (int k = 0; k < kMaxN - m0; ++k) h[m0 + k] = fma(-tmp, sx[k], h[m0 + k]);
+                    ix += m;
+                }
+            }
+            if (t < n) {
+#pragma unroll
+                for (int k = 0; k < kMaxN; ++k)
+                    if (k < n) sH[t * ldh + k] = Dmine * h[k];
+            }
             __syncthreads();
             // the columns of this basis, wherever the shuffle put them
             for (int s = 0; s < L; ++s) {
@@ -169,6 +192,7 @@ extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs
 {
     if (a->L > mcmc::kMaxSlots || a->d > mcmc::kMaxN || a->n_blocks > mcmc::kMaxN)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mcmc::basis_blocked_kernel, dim3(n_groups * a->ncyc), dim3(64), 0, st, *a);
+    const size_t lds = (size_t)a->L * (sizeof(unsigned) + 3 * sizeof(short)) + 16;
+    hipLaunchKernelGGL(mcmc::basis_blocked_kernel, dim3(n_groups * a->ncyc), dim3(64), lds, st, *a);
     return hipGetLastError();
 }

@@ -22,6 +22,14 @@ kinds = [0] * (d - n_norm) + [1] * n_norm
 eng.set_prior(kinds, [0.0] * (d - n_norm) + list(mean[d - n_norm:] + 0.5 * sd[d - n_norm:]),
               [1.0] * (d - n_norm) + list(2.0 * sd[d - n_norm:]))
 eng.set_target_gaussian_mixture([mean], [cov])
+evals_per_step = 1
+if os.environ.get("QB_BLOCKS"):  # "n_slow,oversample_fast[,drag_steps]": two blocks, slow first
+    parts = [int(v) for v in os.environ["QB_BLOCKS"].split(",")]
+    n_slow, over = parts[0], parts[1]
+    drag = parts[2] if len(parts) > 2 else 0
+    eng.set_blocking([list(range(n_slow)), list(range(n_slow, d))], [1, over],
+                     0 if drag else -1, drag)
+    evals_per_step = 1 + 2 * drag
 eng.set_proposal_cov(cov)
 rng = np.random.default_rng(1)
 eng.set_state(np.clip(mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov)), 1e-6, 1 - 1e-6))
@@ -35,7 +43,7 @@ for _ in range(n):
 eng.sync()
 dt = time.perf_counter() - t0
 kt = eng.kernel_times()
-ev = W * spl * n
+ev = W * spl * n * evals_per_step
 print(f"d={d} W={W} gs={gs} spl={spl}: {ev/dt:.3e} evals/s wall; step kernel {kt['step_ms']/n:.3f} ms/launch "
-      f"=> {W*spl/(kt['step_ms']/n*1e-3):.3e} evals/s; basis {kt['basis_ms']/n:.3f} ms; moments {kt['moments_ms']/n:.3f} ms; "
+      f"=> {W*spl*evals_per_step/(kt['step_ms']/n*1e-3):.3e} evals/s; basis {kt['basis_ms']/n:.3f} ms; moments {kt['moments_ms']/n:.3f} ms; "
       f"acc={eng.counters()['accepted']/(W*spl*(n+1)):.3f}")
