@@ -946,19 +946,21 @@ __device__ __forceinline__ bool metropolis(double trial, double current, double 
 }
 
 template <bool MULTI>
-__global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
+__global__ void __launch_bounds__(256) drag_kernel(const DragArgs da)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const StepArgs& a = da.s;
     const ConstLayout cl{D, a.n_modes};
     const cptr C = as_const(a.cblock);
-    const int tid = threadIdx.x;
-    const int w = blockIdx.x * 64 + tid;
+    // blocks are 256 wide when W allows (one wave per SIMD of a CU: single-wave workgroups
+    // get piled onto one SIMD by the dispatcher), else 64
+    const int tid = threadIdx.x, bs = blockDim.x;
+    const int w = blockIdx.x * bs + tid;
     const int W = a.W;
     const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);
-    double* const sC = smem + tid;             // start point: sC[i * 64]
-    double* const sX = smem + D * 64 + tid;    // current point, restored on rejection
-    double* const sA = smem + 2 * D * 64 + tid;  // MULTI: mode log-densities [K][64]
+    double* const sC = smem + tid;             // start point: sC[i * bs]
+    double* const sX = smem + D * bs + tid;    // current point, restored on rejection
+    double* const sA = smem + 2 * D * bs + tid;  // MULTI: mode log-densities [K][bs]
     double ce[D], t[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) ce[i] = a.x[(size_t)i * W + w];
@@ -970,7 +972,7 @@ __global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
     const int n = da.n_drag;
     auto evaluate = [&](double& lp, double& ll) -> double {
         bool inb;
-        eval_point<MULTI, false, true>(t, C, cl, a.norm_mask, a.uniform_logp, sA, 64, inb, lp, ll,
+        eval_point<MULTI, false, true>(t, C, cl, a.norm_mask, a.uniform_logp, sA, bs, inb, lp, ll,
                                        nullptr);
         return inb ? lp + ll : -INFINITY;
     };
@@ -986,8 +988,8 @@ __global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
         // start point = current point (LDS), end point = slow proposal
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            sC[i * 64] = ce[i];
-            sX[i * 64] = ce[i];
+            sC[i * bs] = ce[i];
+            sX[i * bs] = ce[i];
             t[i] = fma(r0, vs[i], ce[i]);
         }
         if (a.periodic_mask) {
@@ -1020,7 +1022,7 @@ __global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
                 return dk;
             };
 #pragma unroll
-            for (int k = 0; k < D; ++k) t[k] = sC[k * 64] + delta(k);
+            for (int k = 0; k < D; ++k) t[k] = sC[k * bs] + delta(k);
             double ps_lp, ps_ll;
             const double ps_lt = evaluate(ps_lp, ps_ll);
 #pragma unroll
@@ -1035,7 +1037,7 @@ __global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
             if (ok) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    sC[k * 64] = sC[k * 64] + delta(k);
+                    sC[k * bs] = sC[k * bs] + delta(k);
                     ce[k] = t[k];
                 }
                 cs_lt = ps_lt;
@@ -1053,7 +1055,7 @@ __global__ void __launch_bounds__(64) drag_kernel(const DragArgs da)
             wt = 1; prej = 0; ++nacc;
         } else {
 #pragma unroll
-            for (int i = 0; i < D; ++i) ce[i] = sX[i * 64];
+            for (int i = 0; i < D; ++i) ce[i] = sX[i * bs];
             wt += 1;
             if (!dead) {   // the end point is always inside the prior support here
                 const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
@@ -1324,8 +1326,14 @@ hipError_t launch_moments(const MomentArgs& a, int group_size, hipStream_t st)
 hipError_t launch_drag(const DragArgs& a, hipStream_t st)
 {
     const bool multi = a.s.n_modes > 1;
-    const size_t lds = sizeof(double) * 64 * (size_t)(2 * D + (multi ? a.s.n_modes : 0));
-    const dim3 grid(a.s.W / 64), block(64);
+    const int bs = (a.s.W % 256 == 0) ? 256 : 64;
+    const size_t lds = sizeof(double) * bs * (size_t)(2 * D + (multi ? a.s.n_modes : 0));
+    const dim3 grid(a.s.W / bs), block(bs);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(multi ? (const void*)drag_kernel<true> : (const void*)drag_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (multi) hipLaunchKernelGGL(drag_kernel<true>, grid, block, lds, st, a);
     else hipLaunchKernelGGL(drag_kernel<false>, grid, block, lds, st, a);
     return hipGetLastError();
