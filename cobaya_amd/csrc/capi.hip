@@ -1007,7 +1007,11 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         return fail(h, MCMC_HIP_ERR_ARG,
                     "for d > 32 this build samples a single Gaussian mode with uniform, "
                     "non-periodic priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
-    if (!h->kb && !drag && 2 * (size_t)(256 / std::min(h->gs, 256)) * dd * sizeof(double) > (96u << 10))
+    // two slabs per group of a workgroup (workgroups are 256, 128 or 64 walkers wide)
+    const int wg = (h->W % 256 == 0) ? 256 : (h->W % 128 == 0) ? 128 : 64;
+    if (!h->kb && !drag &&
+        (2 * (size_t)std::max(1, wg / h->gs) * dd + (h->K > 1 ? (size_t)h->K * wg : 0)) * sizeof(double) >
+            (160u << 10))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "a cycle of %d steps needs %zu KiB of LDS per group: use group_size 256 or "
                     "smaller oversampling factors", Lc, dd * sizeof(double) / 1024);

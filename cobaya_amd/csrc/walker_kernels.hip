@@ -1255,11 +1255,14 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
                          a.rows != nullptr || D == 1 || a.vflag != nullptr;
     const bool pairable = (a.periodic_mask == 0u && a.n_modes == 1 && a.rows == nullptr &&
                            a.vflag == nullptr);   // normal priors have their own instantiation
-    if (kPair && pairable && a.W % 256 == 0 && 256 % a.group_size == 0) {
+    constexpr size_t kLdsMax = 160 * 1024;
+    const size_t pair_need = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab +
+                                                       2 * xf_count(a.norm_mask != 0u) * 256);
+    if (lds > kLdsMax) return hipErrorInvalidValue;   // the cycle's directions do not fit LDS
+    if (kPair && pairable && a.W % 256 == 0 && 256 % a.group_size == 0 && pair_need <= kLdsMax) {
         // two waves per 64 walkers: 512-thread workgroups of 256 walkers
         const bool normp = a.norm_mask != 0u;
-        size_t plds = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab +
-                                                2 * xf_count(normp) * 256);
+        size_t plds = pair_need;
         const int nwg = a.W / 256;
         const int per_cu = (nwg + 255) / 256;      // same even-placement request as below
         size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;

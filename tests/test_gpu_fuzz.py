@@ -1,0 +1,63 @@
+"""GPU parity fuzz (Tier B): randomly drawn problem shapes -- dimension, ensemble and group
+size, number of modes, prior kinds, periodic parameters, temperature, burn-in, parameter
+blocks with oversampling, dragging -- stepped in uneven launches and compared bit for bit
+with the oracle.  The draws are seeded: the cases are the same on every run."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_parity import compare_state, make_pair  # noqa: E402
+
+
+def draw_case(seed):
+    rng = np.random.default_rng(seed)
+    d = int(rng.integers(2, 33))
+    gs = int(rng.choice([64, 128, 256]))
+    W = gs * int(rng.integers(1, 4)) if rng.random() < 0.5 else 256 * int(rng.integers(1, 3))
+    if W % gs:
+        W = gs * max(1, W // gs)
+    K = int(rng.choice([1, 1, 1, 2, 3]))
+    kw = {}
+    if rng.random() < 0.4:   # some normal priors
+        kinds = (rng.random(d) < 0.5).astype(int).tolist()
+        kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.05, 0.3)) if k else 1.0 for k in kinds])
+    if rng.random() < 0.3:   # periodic among the uniform ones
+        kinds = kw.get("kinds", [0] * d)
+        kw["periodic"] = [int(k == 0 and rng.random() < 0.3) for k in kinds]
+    if rng.random() < 0.3:
+        kw["T"] = float(rng.choice([1.5, 2.0, 3.0]))
+    if rng.random() < 0.3:
+        kw["burn_in"] = int(rng.integers(1, 5))
+    if K > 1:
+        w = rng.uniform(0.2, 1.0, K)
+        kw["weights"] = (w / w.sum()).tolist()
+    if rng.random() < 0.5 and d >= 3:   # parameter blocks
+        perm = rng.permutation(d).tolist()
+        nb = int(rng.integers(2, min(4, d) + 1))
+        cuts = sorted(rng.choice(np.arange(1, d), size=nb - 1, replace=False).tolist())
+        blocks = [perm[a:b] for a, b in zip([0] + cuts, cuts + [d])]
+        over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
+        kw.update(blocks=blocks, over=over)
+        if rng.random() < 0.4:
+            kw.update(drag_last_slow=int(rng.integers(0, nb - 1)), drag_steps=int(rng.integers(2, 6)))
+            kw["over"] = [1] * nb
+    steps = [int(v) for v in rng.integers(1, 25, size=3)]
+    return d, W, gs, K, kw, steps
+
+
+# MCMC_FUZZ_CASES=400 widens the hunt (the default keeps the suite short)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_CASES", "40")))))
+def test_random_shapes_bit_exact(seed):
+    d, W, gs, K, kw, steps = draw_case(1000 + seed)
+    eng, prob, st = make_pair(d, W, gs, K=K, **kw)
+    for n in steps:
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+    c = eng.counters()
+    assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
