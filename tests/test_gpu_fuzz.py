@@ -61,3 +61,26 @@ def test_random_shapes_bit_exact(seed):
         compare_state(eng, st)
     c = eng.counters()
     assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_big_dimensions_bit_exact(seed):
+    """d = 33 .. 112: the matrix-core kernel (ensembles that are a multiple of 256) and the
+    column-sweep fallback (other sizes), any group size, launches that stop mid-cycle."""
+    rng = np.random.default_rng(5000 + seed)
+    d = int(rng.integers(33, 113))
+    gs = int(rng.choice([64, 128] if d > 80 else [64, 128, 256]))
+    W = int(rng.choice([256, 512])) if rng.random() < 0.6 else gs * int(rng.integers(1, 4))
+    if W % gs:
+        W = gs * max(1, W // gs)
+    kw = {}
+    if rng.random() < 0.3:
+        kw["T"] = 2.0
+    if rng.random() < 0.3:
+        kw["burn_in"] = 2
+    eng, prob, st = make_pair(d, W, gs, **kw)
+    for n in (int(rng.integers(1, 10)), int(rng.integers(5, d)), int(rng.integers(1, 30))):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
