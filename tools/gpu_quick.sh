@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -k big 2>&1 | tail -3
+for d in 33 40 48 64 80 100 112; do
+timeout 120 python tools/quick_engine_bench.py $d 65536 128 $((2*d)) 2>&1 | tail -1
+done
