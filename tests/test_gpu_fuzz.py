@@ -52,10 +52,16 @@ def draw_case(seed):
 # MCMC_FUZZ_CASES=400 widens the hunt (the default keeps the suite short)
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_CASES", "40")))))
 def test_random_shapes_bit_exact(seed):
+    from cobaya_amd.engine import EngineError
     d, W, gs, K, kw, steps = draw_case(1000 + seed)
     eng, prob, st = make_pair(d, W, gs, K=K, **kw)
     for n in steps:
-        eng.step(n)
+        try:
+            eng.step(n)
+        except EngineError as e:   # a long cycle of a wide problem with small groups
+            if "KiB of LDS per group" in str(e):
+                pytest.skip(str(e))
+            raise
         eng.sync()
         st.run(n, n_threads=4)
         compare_state(eng, st)

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for d in 33 40 48 64 80 100 112; do
-timeout 120 python tools/quick_engine_bench.py $d 65536 128 $((2*d)) 2>&1 | tail -1
-done
+MCMC_FUZZ_CASES=3000 timeout 280 python -m pytest tests/test_gpu_fuzz.py -q -x -k random_shapes 2>&1 | tail -6
