@@ -21,7 +21,8 @@ constexpr int kMaxN = 32;
 
 __global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArgs a)
 {
-    __shared__ double sT[kMaxN * kMaxN];
+    __shared__ double sT[kMaxN * (kMaxN + 1)];   // leading dimension d | 1 (odd: no conflicts)
+    __shared__ short sslot[kMaxN];               // slot of column c of the basis at hand
     __shared__ double sH[kMaxN * (kMaxN + 1)];
     __shared__ double sz[(kMaxN + 2) * (kMaxN - 1) / 2 + 2];
     __shared__ double sx[kMaxN + 1];
@@ -41,7 +42,8 @@ __global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArg
     double* __restrict__ Vout = a.V + ((size_t)pg * a.ncyc + pc) * a.slab;
     int* __restrict__ Fout = a.vflag ? a.vflag + ((size_t)pg * a.ncyc + pc) * L : nullptr;
 
-    for (int i = t; i < d * d; i += 64) sT[i] = a.T[i];
+    const int ldt = d | 1;
+    for (int i = t; i < d * d; i += 64) sT[(i / d) * ldt + i % d] = a.T[i];
     if (t < d) sIofJ[t] = a.i_of_j[t];
     if (t < a.n_blocks) {
         sSize[t] = a.block_size[t];
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArg
         if (n == 1) {  // RandProposer1D: the direction is the block's column of T itself
             for (int s = 0; s < L; ++s)
                 if (sblk[s] == b) {
-                    if (t < d) Vout[(size_t)s * d + sIofJ[t]] = (t >= jb) ? sT[t * d + jb] : 0.0;
+                    if (t < d) Vout[(size_t)s * d + sIofJ[t]] = (t >= jb) ? sT[t * ldt + jb] : 0.0;
                     if (Fout && t == 0) Fout[s] = 1;
                 }
             continue;
@@ -165,20 +167,36 @@ __global__ void __launch_bounds__(64) basis_blocked_kernel(const BlockedBasisArg
                     if (k < n) sH[t * ldh + k] = Dmine * h[k];
             }
             __syncthreads();
-            // the columns of this basis, wherever the shuffle put them
-            for (int s = 0; s < L; ++s) {
-                if (sblk[s] != b || sbas[s] != q) continue;
-                const int c = scol[s];
-                if (t < d) {
-                    double acc = 0.0;
-                    if (t >= jb) {
-                        const int kmax = (t - jb < n - 1) ? t - jb : n - 1;
-                        for (int k = 0; k <= kmax; ++k)
-                            acc = fma(sT[t * d + jb + k], sH[k * ldh + c], acc);
-                    }
-                    Vout[(size_t)s * d + sIofJ[t]] = acc;
+            // The columns of this basis, wherever the shuffle put them: all n * d outputs
+            // (column c, sorted row j) are spread over the 64 lanes, four independent chains
+            // per lane in flight.  Every chain runs over the whole block, k = 0 .. n-1: T is
+            // lower triangular, so the terms beyond the oracle's k <= j - j_b (and the rows
+            // above the block) multiply exact zeros and leave the sum -- or +0.0 -- unchanged.
+            for (int s = t; s < L; s += 64)
+                if (sblk[s] == b && sbas[s] == q) {
+                    sslot[scol[s]] = (short)s;
+                    if (Fout) Fout[s] = 0;
                 }
-                if (Fout && t == 0) Fout[s] = 0;
+            __syncthreads();
+            const int n_out = n * d;
+            for (int o0 = t; o0 < n_out; o0 += 256) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                int cc[4], jj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int o = o0 + 64 * u < n_out ? o0 + 64 * u : o0;
+                    cc[u] = o / d;
+                    jj[u] = o % d;
+                }
+                for (int k = 0; k < n; ++k) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[u] = fma(sT[jj[u] * ldt + jb + k], sH[k * ldh + cc[u]], acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (o0 + 64 * u < n_out)
+                        Vout[(size_t)sslot[cc[u]] * d + sIofJ[jj[u]]] = acc[u];
             }
         }
     }
