@@ -595,21 +595,31 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 constexpr bool kPair = D >= 8;
 // Measured at d = 30 (W = 65 536): splits 16 / 20 / 24 run 3.47 / 3.32 / 3.46 ms per 1200 steps,
 // 12 runs 4.1 ms -- role 0 (which also generates the variates) takes about two thirds of the rows.
-constexpr int pair_split()
+// With normal priors role 1 also forms the prior terms (a division each), and one more row
+// block moves to role 0: at the config-5 shape (d = 27, 21 normal priors) splits 16 / 20 / 24
+// run 4.42 / 4.25 / 4.03 ms per 1080 steps.
+constexpr int pair_split(bool normp)
 {
-    const int h = kRowBlock * ((2 * D + 6) / 12);  // multiple of the row block nearest 2D/3
-    return h < kRowBlock ? kRowBlock : (h >= D ? D - 1 - (D - 1) % kRowBlock : h);
-}
 #ifdef MCMC_SPLIT   // developer experiments
-constexpr int kSplit = MCMC_SPLIT;
+    return MCMC_SPLIT;
 #else
-constexpr int kSplit = kPair ? pair_split() : D;
+    if (!kPair) return D;
+    int h = kRowBlock * ((2 * D + 6) / 12);  // multiple of the row block nearest 2D/3
+    if (normp) h += kRowBlock;
+    const int hmax = D - 1 - (D - 1) % kRowBlock;   // largest whole number of row blocks below D
+    return h < kRowBlock ? kRowBlock : (h > hmax ? hmax : h);
 #endif
-constexpr int kNTA = kSplit * (kSplit + 1) / 2;   // operands of rows [0, kSplit)
-constexpr int kDB = D - kSplit;
-// exchanged doubles per walker and step: chi2 of role 0, r, Ea, the y_j of role 1; with normal
-// priors also role 1's prior sum
-constexpr int xf_count(bool normp) { return normp ? kDB + 4 : kDB + 3; }
+}
+// the split and what follows from it, per instantiation
+template <bool NORMP>
+struct PairGeom {
+    static constexpr int split = pair_split(NORMP);
+    static constexpr int nta = split * (split + 1) / 2;   // operands of rows [0, split)
+    static constexpr int db = D - split;
+    // exchanged doubles per walker and step: chi2 of role 0, r, Ea, the y_j of role 1; with
+    // normal priors also role 1's prior sum
+    static constexpr int xf = db + (NORMP ? 4 : 3);
+};
 
 // `ok` collects the support test as a wave mask on the scalar ALU (one bit per walker):
 // v_cmp writes an SGPR pair, s_and folds it in -- no per-dimension VALU select.
@@ -639,6 +649,7 @@ __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v,
                                              unsigned long long& ok, uint32_t nmask, cptr Cn,
                                              double& s0)
 {
+    constexpr int kSplit = PairGeom<NORMP>::split, kNTA = PairGeom<NORMP>::nta;
     const ConstLayout cl{D, 1};
     auto prior_term = [&](int dim, double t) {
         if (NORMP && ROLE == 1 && ((nmask >> dim) & 1u)) {
@@ -723,7 +734,8 @@ __device__ __forceinline__ void exchange_barrier()
 template <int ROLE, bool UNIT_T, bool NORMP>
 __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
 {
-    constexpr int kXF = xf_count(NORMP);
+    constexpr int kSplit = PairGeom<NORMP>::split, kNTA = PairGeom<NORMP>::nta,
+                  kDB = PairGeom<NORMP>::db, kXF = PairGeom<NORMP>::xf;
     const int SLAB = a.slab;
     constexpr int NX = ROLE == 0 ? kSplit : D;      // dimensions of the state this role holds
     const ConstLayout cl{D, 1};
@@ -1257,7 +1269,7 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
                            a.vflag == nullptr);   // normal priors have their own instantiation
     constexpr size_t kLdsMax = 160 * 1024;
     const size_t pair_need = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab +
-                                                       2 * xf_count(a.norm_mask != 0u) * 256);
+        2 * (a.norm_mask != 0u ? PairGeom<true>::xf : PairGeom<false>::xf) * 256);
     if (lds > kLdsMax) return hipErrorInvalidValue;   // the cycle's directions do not fit LDS
     if (kPair && pairable && a.W % 256 == 0 && 256 % a.group_size == 0 && pair_need <= kLdsMax) {
         // two waves per 64 walkers: 512-thread workgroups of 256 walkers
