@@ -211,7 +211,7 @@ def main():
                 "algorithmic_GBps": achieved,
             }) | {
                 "kernel": (("mcmc::step_pair_kernel<true, false> (d=%d)" % d)
-                           if 8 <= d <= 32 and a.walkers % 256 == 0
+                           if 14 <= d <= 32 and a.walkers % 256 == 0
                            else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
                            else ("mcmc::step_mfma_kernel (d=%d)" % d) if a.walkers % 256 == 0
                            else ("mcmc::step_big_reg_kernel (d=%d)" % d)),

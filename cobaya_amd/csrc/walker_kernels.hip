@@ -592,7 +592,13 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 // chi2 = fma(y_j, y_j, chi2) for j = kSplit .. D-1 -- the SAME ascending chain as the one-wave
 // kernel and the oracle, so the result is bit-identical -- take the same accept decision and
 // commit their own copy of the state.
-constexpr bool kPair = D >= 8;
+// The split pays from d ~ 14: per 40d steps of 65 536 walkers, two waves vs one wave per walker
+// set run 0.387 / 0.385 ms at d = 8, 0.698 / 0.655 at 12, 1.09 / 1.25 at 16, 1.61 / 1.93 at 20,
+// 2.22 / 2.84 at 24.
+#ifndef MCMC_PAIR_MIN
+#define MCMC_PAIR_MIN 14
+#endif
+constexpr bool kPair = D >= MCMC_PAIR_MIN;
 // Measured at d = 30 (W = 65 536): splits 16 / 20 / 24 run 3.47 / 3.32 / 3.46 ms per 1200 steps,
 // 12 runs 4.1 ms -- role 0 (which also generates the variates) takes about two thirds of the rows.
 // With normal priors role 1 also forms the prior terms (a division each), and one more row

@@ -101,9 +101,10 @@ def test_initial_evaluation_bit_exact():
     (30, 512, 64, 1, 95), (2, 256, 64, 1, 41), (3, 256, 128, 1, 50), (30, 512, 256, 1, 61),
     (4, 256, 64, 2, 60), (30, 256, 64, 3, 45), (5, 256, 64, 0, 40), (1, 256, 64, 1, 30),
     (27, 256, 64, 1, 60), (32, 256, 64, 1, 40),
-    # d >= 8 with W % 256 == 0 runs the two-waves-per-walker-set kernel (every row split);
-    # other widths run the one-wave kernel
-    (8, 256, 64, 1, 50), (13, 256, 128, 1, 45), (16, 512, 256, 1, 40), (21, 256, 64, 1, 50),
+    # d >= 14 with W % 256 == 0 runs the two-waves-per-walker-set kernel (every row split);
+    # smaller d and other widths run the one-wave kernel
+    (8, 256, 64, 1, 50), (13, 256, 128, 1, 45), (14, 256, 64, 1, 45), (16, 512, 256, 1, 40),
+    (17, 256, 128, 1, 40), (21, 256, 64, 1, 50),
     (24, 256, 256, 1, 55), (30, 192, 64, 1, 70), (16, 64, 64, 1, 40)])
 def test_steps_bit_exact(d, W, gs, K, steps):
     eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.2, 0.8] if K == 2 else None)
