@@ -21,7 +21,11 @@ sd = np.sqrt(np.diag(cov))
 kinds = [0] * (d - n_norm) + [1] * n_norm
 eng.set_prior(kinds, [0.0] * (d - n_norm) + list(mean[d - n_norm:] + 0.5 * sd[d - n_norm:]),
               [1.0] * (d - n_norm) + list(2.0 * sd[d - n_norm:]))
-eng.set_target_gaussian_mixture([mean], [cov])
+n_modes = int(os.environ.get("QB_MODES", "1"))  # K > 1: shifted copies of the target
+rngm = np.random.default_rng(11)
+means = [mean] + [np.clip(mean + rngm.normal(size=d) * np.sqrt(np.diag(cov)), 0.05, 0.95)
+                  for _ in range(n_modes - 1)]
+eng.set_target_gaussian_mixture(means, [cov] * n_modes)
 evals_per_step = 1
 if os.environ.get("QB_BLOCKS"):  # "n_slow,oversample_fast[,drag_steps]": two blocks, slow first
     parts = [int(v) for v in os.environ["QB_BLOCKS"].split(",")]
