@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for K in 1 2 3; do
-QB_MODES=$K timeout 120 python tools/quick_engine_bench.py 30 65536 256 1200 2>&1 | tail -1 | sed 's/; basis.*//'
-done
+timeout 120 python -m pytest tests/test_gpu_sampler.py -x -q -k manual_blocking --durations=2 2>&1 | tail -8
