@@ -213,7 +213,7 @@ def main():
                 "kernel": (("mcmc::step_pair_kernel<true, false> (d=%d)" % d)
                            if 14 <= d <= 32 and a.walkers % 256 == 0
                            else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
-                           else ("mcmc::step_mfma_kernel (d=%d)" % d) if a.walkers % 256 == 0
+                           else ("mcmc::step_mfma_kernel<false> (d=%d)" % d) if a.walkers % 256 == 0
                            else ("mcmc::step_big_reg_kernel (d=%d)" % d)),
                 "kernel_ms_per_launch": step_ms,
                 "kernel_launches_per_step": launches_per_step,

@@ -1002,11 +1002,15 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     const unsigned long long d = (unsigned long long)Lc;
     const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(h->d)
                             : (size_t)mcmc::v_slab_cols(Lc, h->d);
-    if (h->kb && (h->K != 1 || h->norm_mask4[0] || h->norm_mask4[1] || h->norm_mask4[2] ||
-                  h->norm_mask4[3] || h->any_periodic || h->cfg.emit_capacity > 0))
+    const bool big_norm = h->norm_mask4[0] || h->norm_mask4[1] || h->norm_mask4[2] || h->norm_mask4[3];
+    if (h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "for d > 32 this build samples a single Gaussian mode with uniform, "
-                    "non-periodic priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
+                    "for d > 32 this build samples a single Gaussian mode with non-periodic "
+                    "priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
+    if (h->kb && big_norm && h->W % 256 != 0)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "for d > 32 normal priors need an ensemble that is a multiple of 256 walkers "
+                    "(the matrix-core kernel), got %d", h->W);
     // two slabs per group of a workgroup (workgroups are 256, 128 or 64 walkers wide)
     const int wg = (h->W % 256 == 0) ? 256 : (h->W % 128 == 0) ? 128 : 64;
     if (!h->kb && !drag &&
@@ -1089,7 +1093,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                 g.Vf = h->Vf.p;
                 g.vflag_f = any_1d_f ? h->vflag_f.p : nullptr;
                 HIP_TRY(h, h->k->drag(g, h->stream));
-            } else if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->stream));
+            } else if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->norm_mask4, h->stream));
             else HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;
         }

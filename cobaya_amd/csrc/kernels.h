@@ -176,7 +176,8 @@ struct DimKernels {
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).
 struct BigKernels {
     int dp;  // largest dimension this instantiation serves
-    hipError_t (*step)(const StepArgs&, const double* Lcol, int d, hipStream_t);
+    hipError_t (*step)(const StepArgs&, const double* Lcol, int d, const uint32_t* norm_mask4,
+                       hipStream_t);
     hipError_t (*basis)(const BasisArgs&, int n_groups, int d, hipStream_t);
     hipError_t (*evaluate)(const EvalArgs&, const double* Lrow, int d, double* scratch, hipStream_t);
     hipError_t (*moments)(const MomentArgs&, int group_size, int d, hipStream_t);

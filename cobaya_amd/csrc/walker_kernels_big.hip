@@ -411,6 +411,7 @@ struct MfmaStepArgs {
     StepArgs s;
     const double* Ltiles;  // [kTiles][64] tiles of L^-1 in A-operand lane order
     int d;
+    uint32_t norm_mask4[4];  // one bit per dimension with a normal prior
 };
 
 template <int R0, int R1>
@@ -453,6 +454,9 @@ constexpr int kMfmaWalkers = 16 * kMfmaWaves;
 constexpr int kMfmaThreads = 64 * kMfmaWaves;
 constexpr int kMfmaFirstPass = kMfmaWaves <= 8 ? RT : RH;
 
+// NORMP: some priors are normal (its own instantiation: the uniform-only kernel keeps its
+// registers)
+template <bool NORMP>
 __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepArgs b)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -472,6 +476,15 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
     double* sL = smem;
     double* sE = sL + kTiles * 64;
     double* sVr = sE + 3 * 4 * KT;
+    constexpr bool has_norm = NORMP;
+    double* sN = sVr + 2 * gpb * 128;   // {loc, scale, mls}[4 KT]; scale = +inf marks "uniform"
+    if (has_norm)
+        for (int i = tid; i < 4 * KT; i += kMfmaThreads) {
+            const bool nrm = i < d && ((b.norm_mask4[i >> 5] >> (i & 31)) & 1u);
+            sN[3 * i + 0] = nrm ? a.cblock[cl.loc() + i] : 0.0;
+            sN[3 * i + 1] = nrm ? a.cblock[cl.scale() + i] : INFINITY;
+            sN[3 * i + 2] = nrm ? a.cblock[cl.mls() + i] : 0.0;
+        }
     for (int i = tid; i < kTiles * 64; i += kMfmaThreads) sL[i] = b.Ltiles[i];
     for (int i = tid; i < 4 * KT; i += kMfmaThreads) {
         const bool in = i < d;
@@ -562,7 +575,26 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
                      p3 = __shfl(p, n + 48);
         const double chi2 = (p0 + p1) + (p2 + p3);
         const bool inb = chi2 < INFINITY;
-        const double lp = a.uniform_logp + 0.0;
+        // Normal priors (prior.py:746-761): lane class c chains the terms of its dimensions
+        // i = c (mod 4) in ascending order; the four chains combine like chi2 (specification
+        // for d > 32).  Wave-uniform branch: skipped when every prior is uniform.
+        double psum = 0.0;
+        if (has_norm) {
+            double sc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                const int i = 4 * kk + c;
+                const double scale = sN[3 * i + 1];
+                if (scale < INFINITY) {   // (trial of this dimension recomputed: same fma)
+                    const double q = (fma(r, v[i], x[kk]) - sN[3 * i]) / scale;
+                    sc = sc + fma(-0.5 * q, q, sN[3 * i + 2]);
+                }
+            }
+            const double s0 = __shfl(sc, n), s1 = __shfl(sc, n + 16), s2 = __shfl(sc, n + 32),
+                         s3 = __shfl(sc, n + 48);
+            psum = (s0 + s1) + (s2 + s3);
+        }
+        const double lp = a.uniform_logp + psum;
         const double ll = -0.5 * (a.cnorm0 + chi2);
         const double lt = inb ? lp + ll : -INFINITY;
         const bool accept = inb & (lt != -INFINITY) &
@@ -624,15 +656,15 @@ __global__ void __launch_bounds__(64) evaluate_big_kernel(const BigEvalArgs b)
     const double* __restrict__ C = a.cblock;
     bool in = true;
     for (int i = 0; i < d; ++i) in = in & (t[i] <= C[cl.hi() + i]) & (t[i] >= C[cl.lo() + i]);
-    double s = 0.0;
+    double sc[4] = {0.0, 0.0, 0.0, 0.0};   // d > 32: four interleaved chains (specification)
     if (a.norm_mask4[0] | a.norm_mask4[1] | a.norm_mask4[2] | a.norm_mask4[3]) {
         for (int i = 0; i < d; ++i)
             if ((a.norm_mask4[i >> 5] >> (i & 31)) & 1u) {
                 const double q = (t[i] - C[cl.loc() + i]) / C[cl.scale() + i];
-                s = s + fma(-0.5 * q, q, C[cl.mls() + i]);
+                sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, C[cl.mls() + i]);
             }
     }
-    const double lp = a.uniform_logp + s;
+    const double lp = a.uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
     double ll = 0.0;
     if (K >= 1) {
         double amax = -INFINITY;
@@ -709,23 +741,32 @@ __global__ void __launch_bounds__(64) pool_moments_big_kernel(const MomentArgs a
 }
 
 // ---------------------------------------------------------------- launchers
-hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, hipStream_t st)
+hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, const uint32_t* norm_mask4,
+                       hipStream_t st)
 {
+    const bool has_norm = (norm_mask4[0] | norm_mask4[1] | norm_mask4[2] | norm_mask4[3]) != 0u;
     if (a.W % kMfmaWalkers == 0 && (kMfmaWalkers % a.group_size == 0 || a.group_size % kMfmaWalkers == 0)) {
         // matrix-core kernel: its tiles follow the column-sweep copy of L^-1 in `Lcol`
-        MfmaStepArgs m{a, Lcol + (size_t)DP * DP, d};
+        MfmaStepArgs m{a, Lcol + (size_t)DP * DP, d, {norm_mask4[0], norm_mask4[1], norm_mask4[2], norm_mask4[3]}};
         const int gpb = (kMfmaWalkers + a.group_size - 1) / a.group_size;
-        const size_t lds = sizeof(double) * (size_t)(kTiles * 64 + 12 * KT + 2 * gpb * 128);
+        const size_t lds = sizeof(double) * (size_t)(kTiles * 64 + 24 * KT + 2 * gpb * 128);
         // placement: 256 walkers per CU at W = 65 536 -- ask for just under 1/n of the LDS so
         // that exactly n = 256 / walkers-per-workgroup workgroups share a CU
         const size_t share = ((size_t)(160 << 10) / (size_t)(256 / kMfmaWalkers)) - 2048;
         const size_t want = lds > share ? lds : share;
-        hipError_t e = hipFuncSetAttribute((const void*)step_mfma_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        hipError_t e = hipFuncSetAttribute(
+            has_norm ? (const void*)step_mfma_kernel<true> : (const void*)step_mfma_kernel<false>,
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(step_mfma_kernel, dim3(a.W / kMfmaWalkers), dim3(kMfmaThreads), want, st, m);
+        if (has_norm)
+            hipLaunchKernelGGL(step_mfma_kernel<true>, dim3(a.W / kMfmaWalkers), dim3(kMfmaThreads),
+                               want, st, m);
+        else
+            hipLaunchKernelGGL(step_mfma_kernel<false>, dim3(a.W / kMfmaWalkers), dim3(kMfmaThreads),
+                               want, st, m);
         return hipGetLastError();
     }
+    if (has_norm) return hipErrorInvalidValue;   // the column-sweep fallback has uniform priors only
     BigStepArgs b{a, Lcol, d};
     const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
     const size_t lds = sizeof(double) * (size_t)(DP * DP + 4 * DP + 2 * (bs / a.group_size) * 128);

@@ -403,12 +403,17 @@ static int eval_point(const orc_problem* p, const double* t, double* lp_out, dou
     int inb = 1;
     for (int i = 0; i < d; ++i) inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
     if (!inb) { *lp_out = -INFINITY; *ll_out = -INFINITY; return 0; }
-    double s = 0.0;
+    /* sum of the normal priors' terms: one ascending chain for d <= 32; for d > 32 four
+     * interleaved chains s_c over the dimensions i = c (mod 4), combined (s0 + s1) + (s2 + s3)
+     * -- the matrix-core kernel holds dimension i in lane class i mod 4 (see chi2 below) */
+    double sc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = 0; i < d; ++i)
         if (p->kind[i] == 1) {
             double q = (t[i] - p->loc[i]) / p->scale[i];
-            s = s + fma(-0.5 * q, q, p->mls[i]);
+            const int c = d > 32 ? (i & 3) : 0;
+            sc[c] = sc[c] + fma(-0.5 * q, q, p->mls[i]);
         }
+    const double s = d > 32 ? (sc[0] + sc[1]) + (sc[2] + sc[3]) : sc[0];
     *lp_out = p->uniform_logp + s;
     int K = p->n_modes;
     if (K == 0) { *ll_out = 0.0; return 1; }

@@ -147,6 +147,30 @@ def test_big_dimension_steps_bit_exact(d, W, gs, steps):
     assert_bit_equal(g_S, S, "pooled second moments")
 
 
+@pytest.mark.parametrize("d,W,gs", [(40, 256, 64), (100, 512, 128), (112, 256, 128)])
+def test_big_dimension_normal_priors_bit_exact(d, W, gs):
+    """d > 32 with normal priors on the matrix-core kernel: the prior sum is formed as four
+    interleaved chains (dimension i in lane class i mod 4), like chi2."""
+    rng = np.random.default_rng(900 + d)
+    kinds = (rng.random(d) < 0.6).astype(int).tolist()
+    a = [0.5 if k else 0.0 for k in kinds]
+    b = [float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds]
+    eng, prob, st = make_pair(d, W, gs, kinds=kinds, a=a, b=b, T=1.5 if d == 40 else 1.0)
+    compare_state(eng, st)
+    for n in (3, d + 5, 17):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+    small = E.Engine(40, 64, group_size=64, seed=1)
+    small.set_prior([1] * 40, [0.5] * 40, [0.2] * 40)
+    small.set_target_gaussian_mixture([np.full(40, 0.5)], [np.eye(40) * 0.01])
+    small.set_proposal_cov(np.eye(40) * 0.01)
+    small.set_state(np.full((64, 40), 0.5))
+    with pytest.raises(E.EngineError, match="multiple of 256"):
+        small.step(1)
+
+
 def test_big_dimension_unsupported_features_are_refused():
     d = 40
     eng = E.Engine(d, 64)
@@ -157,7 +181,14 @@ def test_big_dimension_unsupported_features_are_refused():
     assert np.all(np.isfinite(lp + ll))
     eng.set_state(np.full((64, d), 0.5))
     with pytest.raises(E.EngineError, match="d > 32"):
-        eng.step(5)                                # ... the step kernel is not (yet)
+        eng.step(5)        # ... normal priors step only on the matrix-core kernel (W % 256 == 0)
+    mix = E.Engine(d, 256)
+    mix.set_prior([0] * d, [0.0] * d, [1.0] * d)
+    mix.set_target_gaussian_mixture([[0.4] * d, [0.6] * d], [np.eye(d) * 1e-3] * 2)
+    mix.set_proposal_cov(np.eye(d) * 1e-3)
+    mix.set_state(np.full((256, d), 0.5))
+    with pytest.raises(E.EngineError, match="single Gaussian mode"):
+        mix.step(5)        # mixtures at d > 32: evaluator only
     with pytest.raises(E.EngineError):
         E.Engine(113, 64)
 

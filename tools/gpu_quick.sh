@@ -1,5 +1,4 @@
-# Scratch command line of the last quick GPU check (edit freely; run with
-#   gpurun --timeout 600 -- 'bash tools/gpu_quick.sh > gpurun_out/quick.log 2>&1')
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-timeout 120 python tools/quick_engine_bench.py 30 65536 256 1200 2>&1 | tail -1
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -k "big" 2>&1 | tail -6
+timeout 120 python tools/quick_engine_bench.py 100 65536 128 200 2>&1 | tail -1 | sed 's/; basis.*//'
+QB_NORM=70 timeout 120 python tools/quick_engine_bench.py 100 65536 128 200 2>&1 | tail -1 | sed 's/; basis.*//'
