@@ -69,7 +69,7 @@ def test_random_shapes_bit_exact(seed):
     assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(20)))
 def test_random_big_dimensions_bit_exact(seed):
     """d = 33 .. 112: the matrix-core kernel (ensembles that are a multiple of 256) and the
     column-sweep fallback (other sizes), any group size, launches that stop mid-cycle."""
@@ -84,6 +84,10 @@ def test_random_big_dimensions_bit_exact(seed):
         kw["T"] = 2.0
     if rng.random() < 0.3:
         kw["burn_in"] = 2
+    if W % 256 == 0 and rng.random() < 0.5:   # normal priors: matrix-core kernel only
+        kinds = (rng.random(d) < 0.5).astype(int).tolist()
+        kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
     eng, prob, st = make_pair(d, W, gs, **kw)
     for n in (int(rng.integers(1, 10)), int(rng.integers(5, d)), int(rng.integers(1, 30))):
         eng.step(n)
