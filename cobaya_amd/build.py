@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libmcmc_hip.so")
 ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
-BIG_DPS = [48, 64, 80, 100, 112]  # accumulator counts of the d > 32 column-sweep kernels
+BIG_DPS = [48, 64, 80, 100, 112, 128]  # padded sizes of the d > 32 kernels
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
 # operations are written as fma()); see DESIGN.md "Ensemble specification".

@@ -24,6 +24,7 @@ MCMC_DECLARE_DIM(29) MCMC_DECLARE_DIM(30) MCMC_DECLARE_DIM(31) MCMC_DECLARE_DIM(
 
 MCMC_DECLARE_BIG(48) MCMC_DECLARE_BIG(64) MCMC_DECLARE_BIG(80) MCMC_DECLARE_BIG(100)
 MCMC_DECLARE_BIG(112)
+MCMC_DECLARE_BIG(128)
 
 namespace {
 
@@ -31,14 +32,14 @@ using mcmc::BigKernels;
 using mcmc::ConstLayout;
 using mcmc::DimKernels;
 
-constexpr int kMaxDimBig = 112;  // basis_big_kernel keeps H and the normals in 160 KiB of LDS
+constexpr int kMaxDimBig = 128;  // basis_big_kernel keeps H (d*d doubles) in 160 KiB of LDS
 
-// smallest compiled accumulator count that serves dimension d (32 < d <= 112)
+// smallest compiled padded size that serves dimension d (32 < d <= 128)
 const BigKernels* big_for_dim(int d)
 {
     typedef const BigKernels* (*getter)();
     static const getter table[] = {mcmc_hip_big_48, mcmc_hip_big_64, mcmc_hip_big_80,
-                                   mcmc_hip_big_100, mcmc_hip_big_112};
+                                   mcmc_hip_big_100, mcmc_hip_big_112, mcmc_hip_big_128};
     if (d <= mcmc::kMaxDimLane || d > kMaxDimBig) return nullptr;
     for (getter g : table)
         if (g != nullptr && g()->dp >= d) return g();
@@ -1007,6 +1008,10 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         return fail(h, MCMC_HIP_ERR_ARG,
                     "for d > 32 this build samples a single Gaussian mode with non-periodic "
                     "priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
+    if (h->kb && h->d > 112 && h->W % 256 != 0)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "d > 112 needs an ensemble that is a multiple of 256 walkers (the "
+                    "matrix-core kernel), got %d", h->W);
     if (h->kb && big_norm && h->W % 256 != 0)
         return fail(h, MCMC_HIP_ERR_ARG,
                     "for d > 32 normal priors need an ensemble that is a multiple of 256 walkers "

@@ -127,7 +127,10 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
     }
 }
 
-// ---------------------------------------------------------------- the Metropolis kernel
+// ---------------------------------------------------------------- the column-sweep kernel
+// Lane-per-walker fallback for ensembles that are not a multiple of 256 walkers; needs 2 * DP
+// doubles of registers per lane, hence not compiled for DP > 112.
+#if MCMC_DP <= 112
 struct BigStepArgs {
     StepArgs s;
     const double* Lcol;  // [DP/4 column blocks][DP/4 row blocks][4 cols][4 rows] tiles of L^-1
@@ -370,6 +373,8 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
     a.n_accept[w] = nacc;
     wave_add_accepts(a.accept_total, nacc - nacc0);
 }
+
+#endif  // MCMC_DP <= 112
 
 // ---------------------------------------------------------------- the matrix-core Metropolis kernel
 // y = L^-1 dev for 16 walkers at a time as FP64 MFMAs (v_mfma_f64_16x16x4_f64): the whitening
@@ -766,6 +771,9 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, const uint3
                                want, st, m);
         return hipGetLastError();
     }
+#if MCMC_DP > 112
+    return hipErrorInvalidValue;                 // no column-sweep fallback at this size
+#else
     if (has_norm) return hipErrorInvalidValue;   // the column-sweep fallback has uniform priors only
     BigStepArgs b{a, Lcol, d};
     const int bs = (a.W % 256 == 0) ? 256 : (a.W % 128 == 0) ? 128 : 64;
@@ -777,6 +785,7 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, const uint3
     }
     hipLaunchKernelGGL(step_big_reg_kernel, dim3(a.W / bs), dim3(bs), lds, st, b);
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_basis(const BasisArgs& a, int n_groups, int d, hipStream_t st)

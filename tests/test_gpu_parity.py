@@ -121,7 +121,8 @@ def test_steps_bit_exact(d, W, gs, K, steps):
 
 @pytest.mark.parametrize("d,W,gs,steps", [(33, 256, 64, 70), (48, 256, 128, 60),
                                           (64, 512, 64, 70), (100, 256, 64, 130),
-                                          (112, 256, 128, 40)])
+                                          (112, 256, 128, 40), (120, 256, 64, 30),
+                                          (128, 512, 128, 35)])
 def test_big_dimension_steps_bit_exact(d, W, gs, steps):
     """32 < d <= 112 (BASELINE config 4 is d = 100): the column-sweep kernels against the
     oracle, bit for bit, across launches that start and stop mid-cycle."""
@@ -190,7 +191,14 @@ def test_big_dimension_unsupported_features_are_refused():
     with pytest.raises(E.EngineError, match="single Gaussian mode"):
         mix.step(5)        # mixtures at d > 32: evaluator only
     with pytest.raises(E.EngineError):
-        E.Engine(113, 64)
+        E.Engine(129, 64)
+    wide = E.Engine(120, 64)   # d > 112: matrix-core kernel only
+    wide.set_prior([0] * 120, [0.0] * 120, [1.0] * 120)
+    wide.set_target_gaussian_mixture([[0.5] * 120], [np.eye(120) * 1e-3])
+    wide.set_proposal_cov(np.eye(120) * 1e-3)
+    wide.set_state(np.full((64, 120), 0.5))
+    with pytest.raises(E.EngineError, match="multiple of 256"):
+        wide.step(2)
 
 
 def test_general_priors_periodic_temperature_bit_exact():

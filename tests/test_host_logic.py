@@ -28,8 +28,8 @@ def test_capi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in mcmc_hip.h but not exported"
     assert declared == {s[0] for s in E.SYMBOLS}
     assert b"gfx950" in lib.mcmc_hip_version()
-    assert all(lib.mcmc_hip_dim_supported(d) for d in range(1, 113))
-    assert not lib.mcmc_hip_dim_supported(113) and not lib.mcmc_hip_dim_supported(0)
+    assert all(lib.mcmc_hip_dim_supported(d) for d in range(1, 129))
+    assert not lib.mcmc_hip_dim_supported(129) and not lib.mcmc_hip_dim_supported(0)
 
 
 def test_engine_fails_loudly_without_gpu_or_with_bad_config():
