@@ -22,6 +22,7 @@ LIB = os.path.join(CSRC, "libmcmc_hip.so")
 ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
 BIG_DPS = [48, 64, 80, 100, 112, 128]  # padded sizes of the d > 32 kernels
+PAIR_DIMS = list(range(33, 49))  # 32 < d <= 48: walker_kernels.hip's two-wave step kernel alone
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
 # operations are written as fma()); see DESIGN.md "Ensemble specification".
@@ -86,6 +87,9 @@ def build(dims=None, jobs=None, verbose=True):
         tasks.append((wk, os.path.join(OBJ, f"walker_d{d}.o"), [f"-DMCMC_D={d}"], stamp))
     big = os.path.join(CSRC, "walker_kernels_big.hip")
     big_dps = [] if os.environ.get("MCMC_HIP_NO_BIG") else BIG_DPS
+    for d in ([] if os.environ.get("MCMC_HIP_NO_BIG") else PAIR_DIMS):
+        stamp = _digest([wk] + hdrs, extra=f"{d}|{' '.join(FLAGS)}")
+        tasks.append((wk, os.path.join(OBJ, f"walker_d{d}.o"), [f"-DMCMC_D={d}"], stamp))
     for dp in big_dps:
         stamp = _digest([big] + hdrs, extra=f"big{dp}|{' '.join(FLAGS)}")
         tasks.append((big, os.path.join(OBJ, f"walker_big{dp}.o"), [f"-DMCMC_DP={dp}"], stamp))

@@ -26,6 +26,11 @@ MCMC_DECLARE_BIG(48) MCMC_DECLARE_BIG(64) MCMC_DECLARE_BIG(80) MCMC_DECLARE_BIG(
 MCMC_DECLARE_BIG(112)
 MCMC_DECLARE_BIG(128)
 
+MCMC_DECLARE_PAIR(33) MCMC_DECLARE_PAIR(34) MCMC_DECLARE_PAIR(35) MCMC_DECLARE_PAIR(36)
+MCMC_DECLARE_PAIR(37) MCMC_DECLARE_PAIR(38) MCMC_DECLARE_PAIR(39) MCMC_DECLARE_PAIR(40)
+MCMC_DECLARE_PAIR(41) MCMC_DECLARE_PAIR(42) MCMC_DECLARE_PAIR(43) MCMC_DECLARE_PAIR(44)
+MCMC_DECLARE_PAIR(45) MCMC_DECLARE_PAIR(46) MCMC_DECLARE_PAIR(47) MCMC_DECLARE_PAIR(48)
+
 namespace {
 
 using mcmc::BigKernels;
@@ -44,6 +49,22 @@ const BigKernels* big_for_dim(int d)
     for (getter g : table)
         if (g != nullptr && g()->dp >= d) return g();
     return nullptr;
+}
+
+// the two-wave step kernel of a dimension 32 < d <= kMaxDimPair, if compiled
+const mcmc::PairKernels* pair_for_dim(int d)
+{
+    typedef const mcmc::PairKernels* (*getter)();
+    static const getter table[] = {mcmc_hip_pair_33, mcmc_hip_pair_34, mcmc_hip_pair_35,
+                                   mcmc_hip_pair_36, mcmc_hip_pair_37, mcmc_hip_pair_38,
+                                   mcmc_hip_pair_39, mcmc_hip_pair_40, mcmc_hip_pair_41,
+                                   mcmc_hip_pair_42, mcmc_hip_pair_43, mcmc_hip_pair_44,
+                                   mcmc_hip_pair_45, mcmc_hip_pair_46, mcmc_hip_pair_47,
+                                   mcmc_hip_pair_48};
+    static_assert(sizeof(table) / sizeof(table[0]) == mcmc::kMaxDimPair - mcmc::kMaxDimLane, "");
+    if (d <= mcmc::kMaxDimLane || d > mcmc::kMaxDimPair) return nullptr;
+    const getter g = table[d - mcmc::kMaxDimLane - 1];
+    return g != nullptr ? g() : nullptr;
 }
 
 const DimKernels* kernels_for_dim(int d)
@@ -232,7 +253,8 @@ extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs
 struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
     const DimKernels* k = nullptr;    // d <= 32: lane-per-walker kernels of that dimension
-    const BigKernels* kb = nullptr;   // 32 < d <= 112: column-sweep kernels
+    const BigKernels* kb = nullptr;   // 32 < d <= 128: column-sweep / matrix-core kernels
+    const mcmc::PairKernels* kp = nullptr;   // 32 < d <= 48: the two-wave step kernel, if it fits
     hipStream_t stream = nullptr;
     std::string err;
     int d = 0, W = 0, G = 0, gs = 0, K = -1;
@@ -533,6 +555,8 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     h->cfg = *cfg;
     h->k = k;
     h->kb = kb;
+    // MCMC_HIP_NO_PAIR_BIG (developer switch): keep 32 < d <= 48 on the matrix-core kernel
+    h->kp = (kb && !getenv("MCMC_HIP_NO_PAIR_BIG")) ? pair_for_dim(cfg->d) : nullptr;
     h->d = cfg->d;
     h->W = cfg->n_walkers;
     h->gs = cfg->group_size;
@@ -1098,7 +1122,12 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                 g.Vf = h->Vf.p;
                 g.vflag_f = any_1d_f ? h->vflag_f.p : nullptr;
                 HIP_TRY(h, h->k->drag(g, h->stream));
-            } else if (h->kb) HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->norm_mask4, h->stream));
+            } else if (h->kb) {
+                a.norm_mask = h->norm_mask4[0];
+                a.norm_mask_hi = h->norm_mask4[1];
+                if (h->kp && h->kp->fits(a)) HIP_TRY(h, h->kp->step(a, h->stream));
+                else HIP_TRY(h, h->kb->step(a, h->dLcol.p, h->d, h->norm_mask4, h->stream));
+            }
             else HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;
         }

@@ -6,6 +6,7 @@
 namespace mcmc {
 
 constexpr int kMaxDimLane = 32;   // lane-per-walker kernels: d <= 32 (state in VGPRs)
+constexpr int kMaxDimPair = 48;   // ... and the two-wave step kernel alone up to here
 constexpr int kMaxModes = 16;
 
 // Whitening factor L_k^-1 (lower triangular) packed in the order the kernels consume it, so
@@ -102,6 +103,7 @@ struct StepArgs {
     // [G][ncyc][cps] 1 where the column belongs to a one-parameter block (its step draws the
     // RandProposer1D variates, proposal.py:85-93), or null
     const int* vflag;
+    uint32_t norm_mask_hi;   // dimensions 32..63 (the two-wave kernel of 32 < d <= 48)
 };
 
 // Directions of the blocked proposer (blocked_kernels.hip; any d <= 32).
@@ -173,6 +175,14 @@ struct DimKernels {
     hipError_t (*drag)(const DragArgs&, hipStream_t);
 };
 
+// The two-wave step kernel of one dimension 32 < d <= kMaxDimPair (walker_kernels.hip compiled
+// for that d; it reads the d > 32 layout of V).  `fits`: the launch geometry of `a` is one the
+// kernel serves (whole 256-walker workgroups, LDS) -- otherwise the caller uses BigKernels.step.
+struct PairKernels {
+    bool (*fits)(const StepArgs&);
+    hipError_t (*step)(const StepArgs&, hipStream_t);
+};
+
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).
 struct BigKernels {
     int dp;  // largest dimension this instantiation serves
@@ -187,4 +197,5 @@ struct BigKernels {
 }  // namespace mcmc
 
 #define MCMC_DECLARE_BIG(DP) extern "C" const mcmc::BigKernels* mcmc_hip_big_##DP() __attribute__((weak));
+#define MCMC_DECLARE_PAIR(D) extern "C" const mcmc::PairKernels* mcmc_hip_pair_##D() __attribute__((weak));
 #define MCMC_DECLARE_DIM(D) extern "C" const mcmc::DimKernels* mcmc_hip_dim_##D() __attribute__((weak));

@@ -34,6 +34,11 @@ namespace {
 
 constexpr int D = MCMC_D;
 constexpr int NPAIR = D * (D + 1) / 2;
+// 32 < D <= kMaxDimPair: this translation unit only provides the two-wave step kernel (the other
+// kernels of such a dimension are the walker_kernels_big.hip ones, whose layout of V it reads).
+// The sums over dimensions follow the d > 32 specification: four interleaved chains.
+constexpr bool kBigD = D > kMaxDimLane;
+constexpr int LDV = kBigD ? v_ld(D) : D;   // doubles between two columns of V
 
 // Wave-uniform read-only operands (problem constants, proposal directions) are read through
 // the SCALAR data path: pointers in the constant address space make every load an s_load into
@@ -195,11 +200,15 @@ template <bool DERIVED, bool TAIL, bool PRELOADED, bool RNG, typename TP, int S0
           bool SUMSQ = true>
 __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, double& anchor,
                                              double* derived, TP tail_ptr, double (&tail)[16],
-                                             const double (&first)[CH], StepRng& rng)
+                                             const double (&first)[CH], StepRng& rng,
+                                             double* pcs = nullptr)
 {
     constexpr int RB = kRowBlock;
     constexpr int NCH = (S1 - S0 + CH - 1) / CH;
-    double chi2 = 0.0;
+    static_assert(RB == 4, "the d > 32 chains are the rows j mod 4");
+    // chi2 chains: one (d <= 32) or four over the rows j = c (mod 4) (d > 32; the caller
+    // combines pcs[0..3])
+    double pc[4] = {0.0, 0.0, 0.0, 0.0};
     double y[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) y[r] = 0.0;
@@ -224,7 +233,7 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
             const int j = kTriMap.j[base + k], i = kTriMap.i[base + k], r = j % RB;
             if (i == j) {
                 if (DERIVED) derived[j] = y[r];
-                if (SUMSQ) chi2 = fma(y[r], y[r], chi2);
+                if (SUMSQ) pc[kBigD ? r : 0] = fma(y[r], y[r], pc[kBigD ? r : 0]);
             }
         };
         // first operand of the chunk: the only wait; then the next chunk's loads go out
@@ -253,11 +262,16 @@ __device__ __forceinline__ double tri_stream(const double (&dev)[D], cptr Lk, do
             }
         // chunk fence: every accumulator passes through an empty asm, so no FMA of this chunk
         // can be delayed past it (its SGPR operands die here) and none of the next can start
-        asm volatile("; chunk end" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(chi2));
+        asm volatile("; chunk end" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(pc[0]));
+        if (kBigD && SUMSQ) asm volatile("; chunk end" : "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]));
 #pragma unroll
         for (int k = 0; k < CH; ++k) cur[k] = nxt[k];
     }
-    return chi2;
+    if (kBigD && SUMSQ) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pcs[c] = pc[c];
+    }
+    return pc[0];
 }
 
 // One mode: triangular whitening y = L^-1 (t - mu), chi2 = |y|^2, as fma chains in ascending
@@ -396,6 +410,7 @@ __device__ __forceinline__ void axpy_stream(double (&out)[D], double r, lptr v,
     }
 }
 
+#if MCMC_D <= 32
 // ---------------------------------------------------------------- the Metropolis kernel
 // FAST (= !MULTI && !GENERAL) is the hot variant: exactly one mode, uniform priors only,
 // nothing periodic, no row emission; no control flow inside a step, the trial is not kept in
@@ -579,6 +594,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     if (ka->rows) ka->n_rows[w] = nrow;
 }
 
+#endif  // MCMC_D <= 32
 // ---------------------------------------------------------------- the paired Metropolis kernel
 // The hot variant again, but with TWO waves per 64 walkers so that a SIMD always holds two
 // waves (at W = 65 536 the one-wave-per-walker-set kernel leaves every SIMD with a single wave
@@ -611,6 +627,12 @@ constexpr int pair_split(bool normp)
 #else
     if (!kPair) return D;
     int h = kRowBlock * ((2 * D + 6) / 12);  // multiple of the row block nearest 2D/3
+    // 32 < d <= 48, measured (10^10 evals/s at W = 65 536; the matrix-core kernel runs 1.15 at
+    // every one of these d): d = 33: split 24 / 28 give 2.01 / 1.85; d = 36: 24 / 28 / 32 give
+    // 1.85 / 1.76 / 1.78; d = 40: 24 / 28 / 32 / 36 give 1.60 / 1.63 / 1.68 / 1.51; d = 44:
+    // 28 / 32 / 36 give 1.46 / 1.52 / 1.48; d = 48: 28 / 32 / 36 / 40 give 1.31 / 1.31 / 1.38 / 1.26
+    // (d = 38 with split 24 dips to 1.56)
+    if (kBigD) h = D < 37 ? 24 : (D < 47 ? 32 : 36);
     if (normp) h += kRowBlock;
     const int hmax = D - 1 - (D - 1) % kRowBlock;   // largest whole number of row blocks below D
     return h < kRowBlock ? kRowBlock : (h > hmax ? hmax : h);
@@ -624,7 +646,8 @@ struct PairGeom {
     static constexpr int db = D - split;
     // exchanged doubles per walker and step: chi2 of role 0, r, Ea, the y_j of role 1; with
     // normal priors also role 1's prior sum
-    static constexpr int xf = db + (NORMP ? 4 : 3);
+    // (d > 32: the three other chi2 chains of role 0 at the end)
+    static constexpr int xf = db + (NORMP ? 4 : 3) + (kBigD ? 3 : 0);
 };
 
 // `ok` collects the support test as a wave mask on the scalar ALU (one bit per walker):
@@ -652,15 +675,16 @@ __device__ __forceinline__ double select_by_mask(unsigned long long mask, double
 template <int ROLE, bool NORMP>
 __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v, cptr E, cptr MU,
                                              const double (&x)[D], cptr Lk, double (&lfirst)[CH],
-                                             unsigned long long& ok, uint32_t nmask, cptr Cn,
-                                             double& s0)
+                                             unsigned long long& ok, unsigned long long nmask,
+                                             cptr Cn, double (&sc)[4])
 {
     constexpr int kSplit = PairGeom<NORMP>::split, kNTA = PairGeom<NORMP>::nta;
     const ConstLayout cl{D, 1};
     auto prior_term = [&](int dim, double t) {
-        if (NORMP && ROLE == 1 && ((nmask >> dim) & 1u)) {
+        if (NORMP && ROLE == 1 && ((nmask >> dim) & 1ull)) {
             const double q = (t - Cn[cl.loc() + dim]) / Cn[cl.scale() + dim];
-            s0 = s0 + fma(-0.5 * q, q, Cn[cl.mls() + dim]);
+            const int c = kBigD ? (dim & 3) : 0;   // d > 32: chains over i mod 4
+            sc[c] = sc[c] + fma(-0.5 * q, q, Cn[cl.mls() + dim]);
         }
     };
     constexpr int N = ROLE == 0 ? kSplit : D;
@@ -827,21 +851,30 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
             Ea = rng.Ea;
             rng.begin(ks->key0, ks->key1, gid, ks->step0 + (unsigned)(s + 1));
         }
-        const lptr v = (lptr)(smem + (cyc & 1) * slab2 + vbase + col * D);
+        const lptr v = (lptr)(smem + (cyc & 1) * slab2 + vbase + col * LDV);
         const cptr C = launder(C0);
         double dev[D], lfirst[CH], vhead[16], yb[D];
         unsigned long long ok = ~0ull;  // walkers whose trial is inside the prior support
-        double s0 = 0.0;   // sum of the normal priors' terms (role 1 forms it)
+        double sc[4] = {0.0, 0.0, 0.0, 0.0};   // normal priors' terms (role 1 forms them)
+        unsigned long long nmask = 0ull;
+        if (NORMP) nmask = ks->norm_mask | (kBigD ? (unsigned long long)ks->norm_mask_hi << 32 : 0ull);
         propose_pair<ROLE, NORMP>(dev, r, v, C + cl.elem(), C + cl.mean(0), x, C + cl.linv(0),
-                                  lfirst, ok, NORMP ? ks->norm_mask : 0u, C, s0);
+                                  lfirst, ok, nmask, C, sc);
+        double s0 = kBigD ? (sc[0] + sc[1]) + (sc[2] + sc[3]) : sc[0];
+        constexpr int kXP = 3 + kDB + (NORMP ? 1 : 0);   // slots of chi2 chains 1..3 (d > 32)
+        double pc[4] = {0.0, 0.0, 0.0, 0.0};
         double chi2, r_next = 0.0, Ea_next = 0.0;
         if (ROLE == 0) {
             chi2 = tri_stream<false, true, true, true, lptr, 0, kNTA, true>(
-                dev, C + cl.linv(0), dev[kSplit - 1], nullptr, v, vhead, lfirst, rng);
+                dev, C + cl.linv(0), dev[kSplit - 1], nullptr, v, vhead, lfirst, rng, pc);
             chi2 = select_by_mask(ok, chi2, INFINITY);  // outside: chi2 is not finite
             X[0] = chi2;
             X[256] = rng.r;
             X[512] = rng.Ea;
+            if (kBigD) {
+#pragma unroll
+                for (int c = 1; c < 4; ++c) X[(kXP + c - 1) * 256] = pc[c];
+            }
             exchange_barrier();
 #pragma unroll
             for (int q = 0; q < kDB; ++q) yb[kSplit + q] = X[(3 + q) * 256];
@@ -858,10 +891,22 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
             chi2 = X[0];
             r_next = X[256];
             Ea_next = X[512];
+            if (kBigD) {
+#pragma unroll
+                for (int c = 1; c < 4; ++c) pc[c] = X[(kXP + c - 1) * 256];
+            }
         }
 #if !(defined(MCMC_EXP) && (MCMC_EXP & 2))
+        if (kBigD) {  // kSplit is a whole number of row blocks: row kSplit + q is chain q mod 4
+            pc[0] = chi2;
 #pragma unroll
-        for (int q = 0; q < kDB; ++q) chi2 = fma(yb[kSplit + q], yb[kSplit + q], chi2);
+            for (int q = 0; q < kDB; ++q)
+                pc[q & 3] = fma(yb[kSplit + q], yb[kSplit + q], pc[q & 3]);
+            chi2 = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < kDB; ++q) chi2 = fma(yb[kSplit + q], yb[kSplit + q], chi2);
+        }
 #endif
         const bool inb = chi2 < INFINITY;  // false for +inf and NaN: outside the prior support
         const double lp = ks->uniform_logp + s0;
@@ -932,6 +977,7 @@ __global__ void __launch_bounds__(512) step_pair_kernel(const StepArgs a)
     }
 }
 
+#if MCMC_D <= 32
 // ---------------------------------------------------------------- the dragging kernel
 // One dragging step per walker and iteration (mcmc.py:564-668), the arithmetic and order of
 // oracle/mcmc_oracle.c drag_core: a slow proposal to the end point, n_drag interpolation
@@ -1250,7 +1296,44 @@ __global__ void __launch_bounds__(64) pool_moments_kernel(const MomentArgs a)
     a.pooled[p] = acc;
 }
 
+#endif  // MCMC_D <= 32
 // ---------------------------------------------------------------- launchers
+constexpr size_t kLdsMax = 160 * 1024;
+size_t pair_lds(const StepArgs& a)
+{
+    return sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab +
+        2 * ((a.norm_mask | a.norm_mask_hi) != 0u ? PairGeom<true>::xf : PairGeom<false>::xf) * 256);
+}
+// the two-wave kernel serves: one mode, non-periodic priors (normal ones have their own
+// instantiation), no emitted rows, no one-parameter blocks, whole 256-walker workgroups
+bool pair_fits(const StepArgs& a)
+{
+    return kPair && a.periodic_mask == 0u && a.n_modes == 1 && a.rows == nullptr &&
+           a.vflag == nullptr && a.W % 256 == 0 && 256 % a.group_size == 0 &&
+           pair_lds(a) <= kLdsMax;
+}
+hipError_t launch_pair(const StepArgs& a, hipStream_t st)
+{
+    // two waves per 64 walkers: 512-thread workgroups of 256 walkers
+    const bool normp = (a.norm_mask | a.norm_mask_hi) != 0u;
+    size_t plds = pair_lds(a);
+    const int nwg = a.W / 256;
+    const int per_cu = (nwg + 255) / 256;      // even placement, see launch_step
+    size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;
+    if (per_cu == 1) want = 96 * 1024;         // > half of the LDS: one workgroup per CU
+    if (want > plds) plds = want;
+    const bool unit_t = a.temperature == 1.0;
+    typedef void (*kern_t)(const StepArgs);
+    const kern_t kern = normp ? (unit_t ? step_pair_kernel<true, true> : step_pair_kernel<false, true>)
+                              : (unit_t ? step_pair_kernel<true, false> : step_pair_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), plds, st, a);
+    return hipGetLastError();
+}
+
+#if MCMC_D <= 32
 hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
 {
     const bool multi = a.n_modes > 1;
@@ -1271,31 +1354,8 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
     }
     const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
                          a.rows != nullptr || D == 1 || a.vflag != nullptr;
-    const bool pairable = (a.periodic_mask == 0u && a.n_modes == 1 && a.rows == nullptr &&
-                           a.vflag == nullptr);   // normal priors have their own instantiation
-    constexpr size_t kLdsMax = 160 * 1024;
-    const size_t pair_need = sizeof(double) * (size_t)(2 * (256 / a.group_size) * a.slab +
-        2 * (a.norm_mask != 0u ? PairGeom<true>::xf : PairGeom<false>::xf) * 256);
     if (lds > kLdsMax) return hipErrorInvalidValue;   // the cycle's directions do not fit LDS
-    if (kPair && pairable && a.W % 256 == 0 && 256 % a.group_size == 0 && pair_need <= kLdsMax) {
-        // two waves per 64 walkers: 512-thread workgroups of 256 walkers
-        const bool normp = a.norm_mask != 0u;
-        size_t plds = pair_need;
-        const int nwg = a.W / 256;
-        const int per_cu = (nwg + 255) / 256;      // same even-placement request as below
-        size_t want = ((size_t)(160 * 1024) / (size_t)per_cu / 1024) * 1024;
-        if (per_cu == 1) want = 96 * 1024;         // > half of the LDS: one workgroup per CU
-        if (want > plds) plds = want;
-        const bool unit_t = a.temperature == 1.0;
-        typedef void (*kern_t)(const StepArgs);
-        const kern_t kern = normp ? (unit_t ? step_pair_kernel<true, true> : step_pair_kernel<false, true>)
-                                  : (unit_t ? step_pair_kernel<true, false> : step_pair_kernel<false, false>);
-        hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), plds, st, a);
-        return hipGetLastError();
-    }
+    if (pair_fits(a)) return launch_pair(a, st);
     const void* fn = multi ? (general ? (const void*)step_kernel<true, true>
                                       : (const void*)step_kernel<true, false>)
                            : (general ? (const void*)step_kernel<false, true>
@@ -1362,10 +1422,18 @@ hipError_t launch_drag(const DragArgs& a, hipStream_t st)
 
 const DimKernels kKernels = {launch_step, launch_basis, launch_evaluate, launch_moments,
                              launch_drag};
+#else
+const PairKernels kPairKernels = {pair_fits, launch_pair};
+#endif
 
 }  // namespace
 }  // namespace mcmc
 
 #define MCMC_CAT2(a, b) a##b
 #define MCMC_CAT(a, b) MCMC_CAT2(a, b)
+#if MCMC_D <= 32
 extern "C" const mcmc::DimKernels* MCMC_CAT(mcmc_hip_dim_, MCMC_D)() { return &mcmc::kKernels; }
+#else
+static_assert(MCMC_D <= mcmc::kMaxDimPair, "two-wave kernel: d <= kMaxDimPair");
+extern "C" const mcmc::PairKernels* MCMC_CAT(mcmc_hip_pair_, MCMC_D)() { return &mcmc::kPairKernels; }
+#endif

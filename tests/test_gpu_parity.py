@@ -2,6 +2,8 @@
 (oracle/mcmc_oracle.c) on the same seeded inputs -- BIT-EXACT for the walker state, the
 log-posterior values, integer weights, accept counts and emitted rows; and against the golden
 vectors generated from the reference (G4/G5) for the batch evaluator."""
+import os
+
 import numpy as np
 import pytest
 
@@ -170,6 +172,44 @@ def test_big_dimension_normal_priors_bit_exact(d, W, gs):
     small.set_state(np.full((64, 40), 0.5))
     with pytest.raises(E.EngineError, match="multiple of 256"):
         small.step(1)
+
+
+@pytest.mark.parametrize("d,W,gs,normal", [(33, 256, 128, False), (34, 512, 256, True),
+                                            (35, 256, 64, False), (36, 512, 128, True),
+                                            (37, 256, 256, False), (38, 256, 128, True),
+                                            (39, 512, 256, False), (40, 512, 128, True),
+                                            (40, 256, 256, False), (43, 256, 256, True),
+                                            (44, 512, 128, False), (47, 512, 256, False),
+                                            (48, 256, 256, True), (48, 512, 256, False)])
+def test_two_wave_kernel_above_32_dimensions_bit_exact(d, W, gs, normal):
+    """32 < d <= 48 on whole 256-walker workgroups: the two-wave step kernel (compiled per
+    dimension) with the d > 32 sums -- four interleaved chi2 chains handed from one wave to the
+    other, four chains of normal-prior terms -- on the d > 32 layout of V.  The same launches on
+    the matrix-core kernel (MCMC_HIP_NO_PAIR_BIG) give the same bits."""
+    rng = np.random.default_rng(3300 + d)
+    kw = {}
+    if normal:
+        kinds = (rng.random(d) < 0.5).astype(int).tolist()
+        kinds[d - 1] = 1                       # a normal prior beyond bit 31 of the mask
+        kw = dict(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
+    eng, prob, st = make_pair(d, W, gs, rng=np.random.default_rng(d), T=1.0 if d % 2 else 1.7, **kw)
+    compare_state(eng, st)
+    for n in (1, d + 3, 2 * d - 1, 9):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+    assert eng.counters()["accepted"] == int(st.n_accept.sum())
+    os.environ["MCMC_HIP_NO_PAIR_BIG"] = "1"
+    try:
+        eng2, prob2, st2 = make_pair(d, W, gs, rng=np.random.default_rng(d),
+                                     T=1.0 if d % 2 else 1.7, **kw)
+        eng2.step(3 * d + 12)
+        eng2.sync()
+    finally:
+        del os.environ["MCMC_HIP_NO_PAIR_BIG"]
+    compare_state(eng2, st)
 
 
 def test_big_dimension_unsupported_features_are_refused():
