@@ -22,9 +22,9 @@ MCMC_DECLARE_DIM(21) MCMC_DECLARE_DIM(22) MCMC_DECLARE_DIM(23) MCMC_DECLARE_DIM(
 MCMC_DECLARE_DIM(25) MCMC_DECLARE_DIM(26) MCMC_DECLARE_DIM(27) MCMC_DECLARE_DIM(28)
 MCMC_DECLARE_DIM(29) MCMC_DECLARE_DIM(30) MCMC_DECLARE_DIM(31) MCMC_DECLARE_DIM(32)
 
-MCMC_DECLARE_BIG(48) MCMC_DECLARE_BIG(64) MCMC_DECLARE_BIG(80) MCMC_DECLARE_BIG(100)
-MCMC_DECLARE_BIG(112)
-MCMC_DECLARE_BIG(128)
+MCMC_DECLARE_BIG(48) MCMC_DECLARE_BIG(56) MCMC_DECLARE_BIG(64) MCMC_DECLARE_BIG(72)
+MCMC_DECLARE_BIG(80) MCMC_DECLARE_BIG(88) MCMC_DECLARE_BIG(96) MCMC_DECLARE_BIG(100)
+MCMC_DECLARE_BIG(112) MCMC_DECLARE_BIG(120) MCMC_DECLARE_BIG(128)
 
 MCMC_DECLARE_PAIR(33) MCMC_DECLARE_PAIR(34) MCMC_DECLARE_PAIR(35) MCMC_DECLARE_PAIR(36)
 MCMC_DECLARE_PAIR(37) MCMC_DECLARE_PAIR(38) MCMC_DECLARE_PAIR(39) MCMC_DECLARE_PAIR(40)
@@ -43,8 +43,10 @@ constexpr int kMaxDimBig = 128;  // basis_big_kernel keeps H (d*d doubles) in 16
 const BigKernels* big_for_dim(int d)
 {
     typedef const BigKernels* (*getter)();
-    static const getter table[] = {mcmc_hip_big_48, mcmc_hip_big_64, mcmc_hip_big_80,
-                                   mcmc_hip_big_100, mcmc_hip_big_112, mcmc_hip_big_128};
+    static const getter table[] = {mcmc_hip_big_48,  mcmc_hip_big_56,  mcmc_hip_big_64,
+                                   mcmc_hip_big_72,  mcmc_hip_big_80,  mcmc_hip_big_88,
+                                   mcmc_hip_big_96,  mcmc_hip_big_100, mcmc_hip_big_112,
+                                   mcmc_hip_big_120, mcmc_hip_big_128};
     if (d <= mcmc::kMaxDimLane || d > kMaxDimBig) return nullptr;
     for (getter g : table)
         if (g != nullptr && g()->dp >= d) return g();
@@ -414,15 +416,17 @@ int upload_constants(mcmc_hip_ctx* h)
             for (int i = 0; i <= j; ++i)
                 lcol[(((size_t)(i / 4) * nb + (j / 4)) * 4 + (i % 4)) * 4 + (j % 4)] =
                     h->Linv[(size_t)j * d + i];
-        // then the 16 x 4 tiles (R, kk), kk <= 4R + 3, of the matrix-core kernel, R-major,
-        // each in A-operand lane order: lane l holds L^-1[16R + (l & 15)][4kk + (l >> 4)]
+        // then the 16 x 4 tiles (R, kk), kk <= 4R + 3 - shift/4, of the matrix-core kernel,
+        // R-major, each in A-operand lane order: lane l holds
+        // L^-1[16R - shift + (l & 15)][4kk + (l >> 4)]
         {
-            const int RT = (dp + 15) / 16, KT = (dp + 3) / 4;
+            const int sh = h->kb->row_shift;   // the partial row tile comes first
+            const int RT = (dp + sh + 15) / 16, KT = (dp + 3) / 4;
             for (int R = 0; R < RT; ++R)
-                for (int kk = 0; kk < std::min(4 * R + 4, KT); ++kk)
+                for (int kk = 0; kk < std::min(4 * R + 4 - sh / 4, KT); ++kk)
                     for (int l = 0; l < 64; ++l) {
-                        const int j = 16 * R + (l & 15), i = 4 * kk + (l >> 4);
-                        lcol.push_back((j < d && i <= j) ? h->Linv[(size_t)j * d + i] : 0.0);
+                        const int j = 16 * R - sh + (l & 15), i = 4 * kk + (l >> 4);
+                        lcol.push_back((j >= 0 && j < d && i <= j) ? h->Linv[(size_t)j * d + i] : 0.0);
                     }
             if ((int)(lcol.size() - (size_t)dp * dp) != 64 * h->kb->n_tiles)
                 return fail(h, MCMC_HIP_ERR_ARG, "internal: tile count mismatch");
@@ -517,10 +521,6 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         return fail(nullptr, MCMC_HIP_ERR_ARG,
                     "no kernels compiled for d=%d (this build covers d = 1..32 lane-per-walker "
                     "and 33..%d column-sweep, as selected at build time)", cfg->d, kMaxDimBig);
-    if (kb && (size_t)cfg->group_size * (size_t)(cfg->d | 1) * sizeof(double) > 160 * 1024)
-        return fail(nullptr, MCMC_HIP_ERR_ARG,
-                    "group_size %d is too large for d=%d (moment tile exceeds LDS): use %d",
-                    cfg->group_size, cfg->d, cfg->d > 80 ? 128 : 256);
     if (cfg->group_size != 64 && cfg->group_size != 128 && cfg->group_size != 256)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "group_size must be 64, 128 or 256, got %d",
                     cfg->group_size);

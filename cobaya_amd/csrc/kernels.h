@@ -192,6 +192,7 @@ struct BigKernels {
     hipError_t (*evaluate)(const EvalArgs&, const double* Lrow, int d, double* scratch, hipStream_t);
     hipError_t (*moments)(const MomentArgs&, int group_size, int d, hipStream_t);
     int n_tiles;  // 16 x 4 tiles of L^-1 the matrix-core step kernel reads (after Lcol's dp*dp)
+    int row_shift;  // row tile R of those holds the rows 16 R - row_shift .. + 15 (a multiple of 4)
 };
 
 }  // namespace mcmc

@@ -96,6 +96,9 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
     int ix = 0;
 #pragma unroll
     for (int n = 0; n < DP - 1; ++n) {
+#if defined(MCMC_BASIS_EXP) && (MCMC_BASIS_EXP & 2)   // timing experiment: no reflections
+        break;
+#endif
         if (n < d - 1) {   // uniform
             const int m = d - n;
             const double x0n = sPv[n], den = sDen[n];
@@ -118,6 +121,10 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
     }
     __syncthreads();
     if (t < d) {  // thread = column c of R; V[c][i] = sum_{k<=i} T[i][k] R[k][c]
+#if defined(MCMC_BASIS_EXP) && (MCMC_BASIS_EXP & 1)   // timing experiment: no product
+        for (int i = 0; i < d; ++i) Vout[(size_t)t * ldv + i] = sH[i * d + t];
+        return;
+#endif
         for (int i = 0; i < d; ++i) {
             double s = 0.0;
 #pragma unroll 8
@@ -388,8 +395,8 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
 // Layout.  A wave owns 16 walkers.  Lane l = 16 c + n serves walker n of the wave and the
 // dimensions i = 4 kk + c (kk = 0 .. KT-1): x[kk] is lane-resident, and dev for k-step kk is
 // exactly the MFMA's B operand (B[k = l >> 4][col = l & 15]).  A = the 16 x 4 tile
-// (rows 16 R .., columns 4 kk ..) of L^-1 from LDS in lane order.  D: lane l holds rows
-// 16 R + 4 r + c (r = 0..3) of walker n, i.e. the rows j = c (mod 4): its chi2 chain p_c.
+// (rows 16 R - kRowShift .., columns 4 kk ..) of L^-1 from LDS in lane order.  D: lane l holds
+// rows 16 R - kRowShift + 4 r + c (r = 0..3) of walker n, i.e. rows j = c (mod 4): its chain p_c.
 // chi2 = (p0 + p1) + (p2 + p3) through four cross-lane reads; all four lanes of a walker take
 // the same decision and commit their own quarter of x.  16 waves (256 walkers) per workgroup,
 // one workgroup per CU, so every SIMD holds four waves; the row tiles go in two passes so that
@@ -399,11 +406,17 @@ __global__ void __launch_bounds__(256) step_big_reg_kernel(const BigStepArgs b)
 // LDS all measured SLOWER (5.1-5.8 ms vs 4.07 ms per 200 steps at d = 100) -- the unpinned
 // schedule pairs adjacent tiles into ds_read2st64_b64.
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int RT = (DP + 15) / 16;     // row tiles
+// Row tile R holds the rows 16 R - kRowShift .. + 15: when DP is not a multiple of 16 the PARTIAL
+// row tile is the FIRST one (rows < 0 are zero padding), where it costs 4 - kRowShift/4 tiles,
+// instead of the last one, where it would cost KT (DP = 100: 91 tiles instead of 109).  The
+// shift is a multiple of 4, so lane class c still holds the rows j = c (mod 4).
+constexpr int kRowShift = (16 - (DP + 3) / 4 * 4 % 16) % 16;
+constexpr int RT = (DP + kRowShift + 15) / 16;     // row tiles
 constexpr int KT = (DP + 3) / 4;       // k-steps
 constexpr int RH = (RT + 1) / 2;       // row tiles of the first pass
-// tile (R, kk) exists for kk <= 4 R + 3; tiles are stored R-major
-constexpr int tiles_of_row(int R) { return (4 * R + 4 < KT) ? 4 * R + 4 : KT; }
+// tile (R, kk) exists for kk <= kk_max(R) (its last row is 16 R - kRowShift + 15); R-major
+constexpr int kk_max(int R) { return 4 * R + 3 - kRowShift / 4; }
+constexpr int tiles_of_row(int R) { return (kk_max(R) + 1 < KT) ? kk_max(R) + 1 : KT; }
 constexpr int tile_offset(int R)
 {
     int n = 0;
@@ -429,7 +442,7 @@ __device__ __forceinline__ void mfma_pass(d4 (&acc)[R1 - R0], const double (&x)[
     for (int q = 0; q < R1 - R0; ++q) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
-        if (kk > 4 * (R1 - 1) + 3) continue;
+        if (kk > kk_max(R1 - 1)) continue;
         const int i = 4 * kk + c;
         const double ti = fma(r, sv[i], x[kk]);
         const double lo = sE[3 * i], hi = sE[3 * i + 1], mu = sE[3 * i + 2];
@@ -437,7 +450,7 @@ __device__ __forceinline__ void mfma_pass(d4 (&acc)[R1 - R0], const double (&x)[
         dev = (i < d) ? dev : 0.0;
 #pragma unroll
         for (int R = R0; R < R1; ++R) {
-            if (kk > 4 * R + 3) continue;
+            if (kk > kk_max(R)) continue;
             const double a = sL[(tile_offset(R) + kk) * 64 + lane];
             acc[R - R0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, dev, acc[R - R0], 0, 0, 0);
         }
@@ -702,28 +715,44 @@ __global__ void __launch_bounds__(64) evaluate_big_kernel(const BigEvalArgs b)
 }
 
 // ---------------------------------------------------------------- moments (run-time d)
-__global__ void __launch_bounds__(256) group_moments_big_kernel(const MomentArgs a, int d)
+// The group's walkers pass through LDS in slices of `slice` walkers (the whole group when its
+// tile fits 160 KiB): every sum is ONE chain over the walkers in ascending order, carried from
+// slice to slice (the pair sums through Sg, which this block owns), so the result does not
+// depend on the slicing.
+__global__ void __launch_bounds__(256) group_moments_big_kernel(const MomentArgs a, int d, int slice)
 {
-    extern __shared__ __attribute__((aligned(16))) double sX[];  // [gs][d|1]
+    extern __shared__ __attribute__((aligned(16))) double sX[];  // [slice][d|1]
     const int ldx = d | 1;
     const int npair = d * (d + 1) / 2;
     const int tid = threadIdx.x, gs = blockDim.x, g = blockIdx.x;
-    const int w = g * gs + tid;
-    for (int i = 0; i < d; ++i) sX[tid * ldx + i] = a.x[(size_t)i * a.W + w] - a.shift[i];
-    __syncthreads();
-    for (int i = tid; i < d; i += gs) {
-        double s = 0.0;
-        for (int l = 0; l < gs; ++l) s = s + sX[l * ldx + i];
-        a.group_sum[(size_t)g * d + i] += s;
-    }
-    for (int p = tid; p < npair; p += gs) {
-        int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-        while ((i + 1) * (i + 2) / 2 <= p) ++i;
-        while (i * (i + 1) / 2 > p) --i;
-        const int j = p - i * (i + 1) / 2;
-        double s = 0.0;
-        for (int l = 0; l < gs; ++l) s = fma(sX[l * ldx + i], sX[l * ldx + j], s);
-        a.Sg[(size_t)g * npair + p] = s;
+    double gpart[2] = {0.0, 0.0};   // this thread's group sums, carried over the slices
+    for (int l0 = 0; l0 < gs; l0 += slice) {
+        if (l0) __syncthreads();
+        // slice x d values, walker-fastest across the threads (coalesced)
+        for (int e = tid; e < slice * d; e += gs) {
+            const int l = e % slice, i = e / slice;
+            sX[l * ldx + i] = a.x[(size_t)i * a.W + (size_t)g * gs + l0 + l] - a.shift[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // d <= 128, gs >= 64: at most two sums per thread
+            const int i = tid + q * gs;
+            if (i < d) {
+                double s = gpart[q];
+                for (int l = 0; l < slice; ++l) s = s + sX[l * ldx + i];
+                gpart[q] = s;
+                if (l0 + slice >= gs) a.group_sum[(size_t)g * d + i] += s;
+            }
+        }
+        for (int p = tid; p < npair; p += gs) {
+            int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= p) ++i;
+            while (i * (i + 1) / 2 > p) --i;
+            const int j = p - i * (i + 1) / 2;
+            double s = l0 ? a.Sg[(size_t)g * npair + p] : 0.0;
+            for (int l = 0; l < slice; ++l) s = fma(sX[l * ldx + i], sX[l * ldx + j], s);
+            a.Sg[(size_t)g * npair + p] = s;
+        }
     }
 }
 
@@ -814,20 +843,22 @@ hipError_t launch_evaluate(const EvalArgs& a, const double* Lrow, int d, double*
 
 hipError_t launch_moments(const MomentArgs& a, int group_size, int d, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (size_t)group_size * (d | 1);
+    int slice = group_size;   // walkers per pass through LDS
+    while (sizeof(double) * (size_t)slice * (d | 1) > 160 * 1024) slice /= 2;
+    const size_t lds = sizeof(double) * (size_t)slice * (d | 1);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)group_moments_big_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(group_moments_big_kernel, dim3(a.G), dim3(group_size), lds, st, a, d);
+    hipLaunchKernelGGL(group_moments_big_kernel, dim3(a.G), dim3(group_size), lds, st, a, d, slice);
     const int npair = d * (d + 1) / 2;
     hipLaunchKernelGGL(pool_moments_big_kernel, dim3((npair + 63) / 64), dim3(64), 0, st, a, d);
     return hipGetLastError();
 }
 
 const BigKernels kKernels = {DP, launch_step, launch_basis, launch_evaluate, launch_moments,
-                             kTiles};
+                             kTiles, kRowShift};
 
 }  // namespace
 }  // namespace mcmc

@@ -167,11 +167,10 @@ class MCMCHip:
         self._rng = np.random.default_rng(ss)
         W = int(self.n_walkers)
         if self.group_size is None:
-            # large ensembles: wide groups (fewer Haar bases to generate, still >> d chains);
-            # for d > 32 the group's moment tile must fit the 160 KiB of LDS
+            # large ensembles: wide groups (fewer Haar bases to generate, still >> d chains)
             self.group_size = 64
             for gs in (256, 128):
-                if W >= 16384 and W % gs == 0 and (d <= 32 or gs * (d | 1) * 8 <= 160 * 1024):
+                if W >= 16384 and W % gs == 0:
                     self.group_size = gs
                     break
         device = self.device if self.device is not None else dist.default_device()

@@ -122,9 +122,13 @@ def test_steps_bit_exact(d, W, gs, K, steps):
 
 
 @pytest.mark.parametrize("d,W,gs,steps", [(33, 256, 64, 70), (48, 256, 128, 60),
+                                          (50, 256, 64, 60), (56, 512, 128, 60),
+                                          (70, 256, 64, 75), (88, 256, 128, 50),
+                                          (93, 256, 64, 40), (96, 512, 64, 40),
                                           (64, 512, 64, 70), (100, 256, 64, 130),
                                           (112, 256, 128, 40), (120, 256, 64, 30),
-                                          (128, 512, 128, 35)])
+                                          (128, 512, 128, 35), (100, 512, 256, 30),
+                                          (128, 256, 256, 20)])
 def test_big_dimension_steps_bit_exact(d, W, gs, steps):
     """32 < d <= 112 (BASELINE config 4 is d = 100): the column-sweep kernels against the
     oracle, bit for bit, across launches that start and stop mid-cycle."""
