@@ -573,7 +573,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     acc(h->loglike.resize(W)); acc(h->weight_i.resize(W)); acc(h->prej.resize(W));
     acc(h->burn.resize(W)); acc(h->nacc.resize(W)); acc(h->stuck.resize(1));
     acc(h->acc_total.resize(1));
-    acc(h->dT.resize(d * d)); acc(h->gsum.resize(G * d)); acc(h->Sg.resize(G * np));
+    acc(h->dT.resize(d * d + 16)); /* +16: wide scalar loads at the end of T */ acc(h->gsum.resize(G * d)); acc(h->Sg.resize(G * np));
     acc(h->pooled.resize(np)); acc(h->dshift.resize(d));
     if (cfg->emit_capacity > 0) {
         acc(h->rows.resize(W * (size_t)cfg->emit_capacity * (d + 4)));

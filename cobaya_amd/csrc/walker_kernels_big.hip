@@ -32,22 +32,43 @@ constexpr int NB = DP / 4;
 static_assert(DP % 4 == 0 && DP <= 128, "DP must be a multiple of 4, at most 128");
 
 // ---------------------------------------------------------------- Haar basis (run-time d <= DP)
-// Same arithmetic, same order as basis_kernel / orc_haar_from_normals.  Thread t owns row t of
-// H in REGISTERS (DP doubles, every loop unrolled; entries beyond d stay zero and the
-// reflector is zero-padded, so the extra terms are exact no-ops); the normals, the reflector
-// and the per-reflection scalars are in LDS.  H goes to LDS only for the final V = T H, over
-// the space of the normals: 80 KB at d = 100, i.e. two workgroups per CU.
-__global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d)
+// Same construction as basis_kernel / orc_haar_from_normals, in the d > 32 order of the
+// specification: the projection of a row on a reflector is formed as FOUR chains over the columns
+// j = c (mod 4), combined (t0 + t1) + (t2 + t3) -- so that FOUR lanes serve one row of H, lane
+// class c holding its columns j = c (mod 4) in DP/4 registers.
+//   A  the (d+2)(d-1)/2 normals (Philox + Box-Muller), all threads;
+//   B  thread n: norm, sign, pivot and denominator of reflection n (sequential chain, all
+//      reflections in parallel); then every reflector normalised and stored zero-padded to the
+//      DP layout (reflection n at n DP - n(n-1)/2, indexed by the absolute column);
+//   C  the d-1 reflections: no barrier -- a row needs only its own four lanes (DPP) and the
+//      reflectors, which are read-only by now;
+//   D  R = D H to LDS (over the space of the normals), then V = T R: a wave takes 4 rows i of T
+//      (wave-uniform, scalar loads) x 64 columns c (lanes) at a time, four independent chains
+//      over k in the specified ascending order.
+constexpr int kBasisRows = (DP + 15) / 16 * 16;   // whole waves: 16 rows x 4 classes
+constexpr int kBasisThreads = 4 * kBasisRows;
+constexpr int kBasisQ = DP / 4;
+__host__ __device__ constexpr int refl_offset(int n, int dim) { return n * dim - n * (n - 1) / 2; }
+
+__device__ __forceinline__ double quad_bcast(double v, int cc)
+{
+    const int lane = __lane_id();
+    return __shfl(v, (lane & ~3) | cc);
+}
+
+__global__ void __launch_bounds__(kBasisThreads) basis_big_kernel(const BasisArgs a, int d)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int nz = (d + 2) * (d - 1) / 2;
+    constexpr int nzp = refl_offset(DP - 1, DP) + 1;   // padded reflectors: sum_{n<DP-1} (DP-n) (+1)
     double* sz = smem;                        // [nz + 2] normals
-    double* sx = sz + ((nz + 3) & ~1);        // [DP + 2] reflector (zero-padded)
-    double* sDn = sx + DP + 2;                // [DP] sign D_n
+    double* sxp = sz + ((nz + 3) & ~1);       // [nzp] normalised reflectors, DP layout
+    double* sDn = sxp + ((nzp + 1) & ~1);     // [DP] sign D_n
     double* sPv = sDn + DP;                   // [DP] pivot x0 + D_n sqrt(norm2)
     double* sDen = sPv + DP;                  // [DP] denominator
     double* sH = smem;                        // [d][d] overlays everything, final phase only
-    const int t = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = kBasisThreads;
+    const int t = tid >> 2, c = tid & 3;
     const uint32_t group = a.group0 + blockIdx.x;
     const uint32_t cycle = a.cycle0 + blockIdx.y;
     const int ldv = v_ld(d);
@@ -55,7 +76,8 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
     typedef const double __attribute__((address_space(4))) * cptr;
     const cptr T = (cptr)(unsigned long long)a.T;
 
-    for (int j = t; 2 * j < nz; j += nt) {
+    // ---- A
+    for (int j = tid; 2 * j < nz; j += nt) {
         const u32x4 w4 = philox4x32_10(a.key0, a.key1, group, kStreamBasis, cycle, (uint32_t)j);
         const uint64_t ka = ((uint64_t)w4.w0 << 20) | (w4.w1 >> 12);
         const uint64_t kb = ((uint64_t)w4.w2 << 20) | (w4.w3 >> 12);
@@ -66,12 +88,10 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
         sz[2 * j + 1] = rad * sn;
     }
     __syncthreads();
-    // The scalars of reflection n (norm, sign, pivot, denominator) depend on the normals only:
-    // thread n forms them for its reflection -- all reflections in parallel, each with the
-    // sequential chain the specification fixes.
-    if (t < d - 1) {
-        const int m = d - t;
-        const int ix = t * d - (t * (t - 1)) / 2;
+    // ---- B
+    if (tid < d - 1) {
+        const int n = tid, m = d - n;
+        const int ix = refl_offset(n, d);
         double norm2 = 0.0;
 #pragma unroll 8
         for (int k = 0; k < m; ++k) norm2 = fma(sz[ix + k], sz[ix + k], norm2);
@@ -80,56 +100,94 @@ __global__ void __launch_bounds__(128) basis_big_kernel(const BasisArgs a, int d
         const double x0n = x0 + Dn * sqrt(norm2);
         double tt = norm2 - x0 * x0;
         tt = tt + x0n * x0n;
-        sDn[t] = Dn;
-        sPv[t] = x0n;
-        sDen[t] = sqrt(0.5 * tt);
+        sDn[n] = Dn;
+        sPv[n] = x0n;
+        sDen[n] = sqrt(0.5 * tt);
     }
     __syncthreads();
-    double Dmine = (t < d - 1) ? sDn[t] : 1.0;
-    double dprod = 1.0;   // product of the signs, in order (exact: +-1)
-    for (int n = 0; n < d - 1; ++n) dprod *= sDn[n];
-    if (t == d - 1) Dmine = (((d - 1) & 1) ? -1.0 : 1.0) * dprod;
-
-    double h[DP];         // row t of H
-#pragma unroll
-    for (int k = 0; k < DP; ++k) h[k] = (k == t) ? 1.0 : 0.0;
-    int ix = 0;
-#pragma unroll
-    for (int n = 0; n < DP - 1; ++n) {
-#if defined(MCMC_BASIS_EXP) && (MCMC_BASIS_EXP & 2)   // timing experiment: no reflections
-        break;
-#endif
-        if (n < d - 1) {   // uniform
+    {   // wave w normalises the reflectors n = w, w + #waves, ...; lanes over the columns
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int n = wv; n < DP - 1; n += nt / 64) {
+            const bool live = n < d - 1;
             const int m = d - n;
-            const double x0n = sPv[n], den = sDen[n];
-            __syncthreads();
-            if (t < DP - n) sx[t] = (t < m) ? ((t == 0) ? x0n : sz[ix + t]) / den : 0.0;
-            __syncthreads();
-            double tmp = 0.0;
-#pragma unroll
-            for (int k = 0; k < DP - n; ++k) tmp = fma(h[n + k], sx[k], tmp);
-#pragma unroll
-            for (int k = 0; k < DP - n; ++k) h[n + k] = fma(-tmp, sx[k], h[n + k]);
-            ix += m;
+            const double pv = live ? sPv[n] : 0.0, den = live ? sDen[n] : 1.0;
+            const int ix = live ? refl_offset(n, d) : 0;
+            for (int k = lane; k < DP - n; k += 64)
+                sxp[refl_offset(n, DP) + k] =
+                    (live && k < m) ? ((k == 0) ? pv : sz[ix + k]) / den : 0.0;
         }
     }
-    __syncthreads();      // the normals are dead: H takes their place in LDS
-    if (t < d) {
-#pragma unroll
-        for (int k = 0; k < DP; ++k)
-            if (k < d) sH[t * d + k] = Dmine * h[k];
+    double Dmine = 1.0;   // sign of row t: D_t, the last one closes det = +1
+    {
+        double dprod = 1.0;   // product of the signs, in order (exact: +-1)
+        for (int n = 0; n < d - 1; ++n) dprod *= sDn[n];
+        if (t < d - 1) Dmine = sDn[t];
+        else if (t == d - 1) Dmine = (((d - 1) & 1) ? -1.0 : 1.0) * dprod;
     }
     __syncthreads();
-    if (t < d) {  // thread = column c of R; V[c][i] = sum_{k<=i} T[i][k] R[k][c]
-#if defined(MCMC_BASIS_EXP) && (MCMC_BASIS_EXP & 1)   // timing experiment: no product
-        for (int i = 0; i < d; ++i) Vout[(size_t)t * ldv + i] = sH[i * d + t];
-        return;
-#endif
-        for (int i = 0; i < d; ++i) {
-            double s = 0.0;
+    // ---- C
+    double h[kBasisQ];    // h[q] = H[t][4 q + c]
+#pragma unroll
+    for (int q = 0; q < kBasisQ; ++q) h[q] = (4 * q + c == t) ? 1.0 : 0.0;
+#pragma unroll
+    for (int n = 0; n < DP - 1; ++n) {
+        if (n < d - 1) {   // uniform (the padded reflectors beyond are zero anyway)
+            const double* __restrict__ xr = sxp + (refl_offset(n, DP) - n);   // xr[j], j >= n
+            const int q0 = n / 4;
+            double xv[kBasisQ];
+            double tmp = 0.0;
+#pragma unroll
+            for (int q = q0; q < kBasisQ; ++q) {
+                const int j = 4 * q + c;
+                // the first group of four straddles column n: the columns below it are not part
+                // of the reflector (a zero term is an exact no-op)
+                xv[q] = (q == q0 && (n & 3) && j < n) ? 0.0 : xr[j];
+                tmp = fma(h[q], xv[q], tmp);
+            }
+            const double t0 = quad_bcast(tmp, 0), t1 = quad_bcast(tmp, 1), t2 = quad_bcast(tmp, 2),
+                         t3 = quad_bcast(tmp, 3);
+            const double tot = (t0 + t1) + (t2 + t3);
+#pragma unroll
+            for (int q = q0; q < kBasisQ; ++q) h[q] = fma(-tot, xv[q], h[q]);
+        }
+    }
+    __syncthreads();      // normals and reflectors are dead: R takes their place in LDS
+    // ---- D
+    if (t < d) {
+#pragma unroll
+        for (int q = 0; q < kBasisQ; ++q)
+            if (4 * q + c < d) sH[t * d + 4 * q + c] = Dmine * h[q];
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int nrb = (d + 3) / 4, nct = (d + 63) / 64;
+        for (int it = wv; it < nrb * nct; it += nt / 64) {
+            const int rb = it / nct, ct = it - rb * nct;
+            const int i0 = 4 * rb;
+            const int col = 64 * ct + lane;
+            const int cc = col < d ? col : d - 1;
+            // rows i0 .. i0+3 (clamped: a duplicate row is computed and not stored)
+            const int r1 = i0 + 1 < d ? i0 + 1 : d - 1, r2 = i0 + 2 < d ? i0 + 2 : d - 1,
+                      r3 = i0 + 3 < d ? i0 + 3 : d - 1;
+            const cptr T0 = T + i0 * d, T1 = T + r1 * d, T2 = T + r2 * d, T3 = T + r3 * d;
+            const int K = (i0 + 4 < d) ? i0 + 4 : d;   // T is lower triangular: zeros above
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 8
-            for (int k = 0; k <= i; ++k) s = fma(T[i * d + k], sH[k * d + t], s);
-            Vout[(size_t)t * ldv + i] = s;
+            for (int k = 0; k < K; ++k) {
+                const double hk = sH[k * d + cc];
+                s0 = fma(T0[k], hk, s0);
+                s1 = fma(T1[k], hk, s1);
+                s2 = fma(T2[k], hk, s2);
+                s3 = fma(T3[k], hk, s3);
+            }
+            if (col < d) {
+                double* o = Vout + (size_t)col * ldv + i0;
+                o[0] = s0;
+                if (i0 + 1 < d) o[1] = s1;
+                if (i0 + 2 < d) o[2] = s2;
+                if (i0 + 3 < d) o[3] = s3;
+            }
         }
     }
 }
@@ -820,7 +878,8 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, const uint3
 hipError_t launch_basis(const BasisArgs& a, int n_groups, int d, hipStream_t st)
 {
     const int nz = (d + 2) * (d - 1) / 2;
-    const size_t phase1 = (size_t)(((nz + 3) & ~1) + DP + 2 + 3 * DP);
+    constexpr int nzp = refl_offset(DP - 1, DP) + 1;
+    const size_t phase1 = (size_t)(((nz + 3) & ~1) + ((nzp + 1) & ~1) + 3 * DP);
     const size_t phase2 = (size_t)d * d;
     const size_t lds = sizeof(double) * (phase1 > phase2 ? phase1 : phase2);
     if (lds > 64 * 1024) {
@@ -828,8 +887,7 @@ hipError_t launch_basis(const BasisArgs& a, int n_groups, int d, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(basis_big_kernel, dim3(n_groups, a.ncyc), dim3(DP <= 64 ? 64 : 128), lds, st,
-                       a, d);
+    hipLaunchKernelGGL(basis_big_kernel, dim3(n_groups, a.ncyc), dim3(kBasisThreads), lds, st, a, d);
     return hipGetLastError();
 }
 

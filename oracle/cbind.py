@@ -71,8 +71,9 @@ def lib():
     if _lib is None:
         name = "libmcmc_oracle_fma.so" if _cpu_has_fma() else "libmcmc_oracle.so"
         path = os.path.join(BUILD, name)
-        if not os.path.exists(path):
-            build()
+        src = os.path.join(HERE, "mcmc_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build()   # never test against a library older than its source
         L = C.CDLL(path)
         L.orc_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
         L.orc_dlog.restype = C.c_double

@@ -221,8 +221,15 @@ void orc_haar_from_normals(int d, const double* z, double* H)
         double den = sqrt(0.5 * t);
         for (int k = 0; k < m; ++k) x[k] = x[k] / den;
         for (int i = 0; i < d; ++i) {
-            double tmp = 0.0;
-            for (int k = 0; k < m; ++k) tmp = fma(H[i * d + n + k], x[k], tmp);
+            /* projection of row i on the reflector: one ascending chain for d <= 32; for d > 32
+             * four interleaved chains over the columns j = c (mod 4), combined
+             * (t0 + t1) + (t2 + t3) -- four lanes of the d > 32 basis kernel serve one row */
+            double tc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < m; ++k) {
+                const int c = d > 32 ? ((n + k) & 3) : 0;
+                tc[c] = fma(H[i * d + n + k], x[k], tc[c]);
+            }
+            const double tmp = d > 32 ? (tc[0] + tc[1]) + (tc[2] + tc[3]) : tc[0];
             for (int k = 0; k < m; ++k) H[i * d + n + k] = fma(-tmp, x[k], H[i * d + n + k]);
         }
     }

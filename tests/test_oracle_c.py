@@ -55,7 +55,7 @@ def test_haar_matches_numpy_restatement():
             return self.z.copy()
 
     rng = np.random.default_rng(1)
-    for d in (2, 3, 7, 30):
+    for d in (2, 3, 7, 30, 33, 100):   # d > 32: four interleaved chains per projection
         z = rng.standard_normal((d + 2) * (d - 1) // 2)
         H = O.haar_from_normals(d, z)
         Href = R.haar_so_n(d, FixedNormals(z))
