@@ -490,7 +490,12 @@ struct MfmaStepArgs {
     uint32_t norm_mask4[4];  // one bit per dimension with a normal prior
 };
 
-template <int R0, int R1>
+// SEL: mask the trial deviation of the padded dimensions with a select.  The padded part of V is
+// zero (zero_tail below), so the select is redundant -- but whether dropping it helps is decided
+// by the register allocation it leads to, measured per instantiation (ms per 8 d steps, with /
+// without): d = 80: 7.35 / 7.20, 100: 14.65 / 14.04, 112: 19.7 / 21.4, 120: 25.2 / 26.2; normal
+// priors at d = 100: 2.5 % slower without.
+template <int R0, int R1, bool SEL>
 __device__ __forceinline__ void mfma_pass(d4 (&acc)[R1 - R0], const double (&x)[KT], double r,
                                           const double* __restrict__ sv,
                                           const double* __restrict__ sE,
@@ -504,8 +509,9 @@ __device__ __forceinline__ void mfma_pass(d4 (&acc)[R1 - R0], const double (&x)[
         const int i = 4 * kk + c;
         const double ti = fma(r, sv[i], x[kk]);
         const double lo = sE[3 * i], hi = sE[3 * i + 1], mu = sE[3 * i + 2];
+        // (a padded dimension i >= d has v = x = mu = 0 and infinite bounds: dev = 0)
         double dev = ((ti <= hi) & (ti >= lo)) ? ti - mu : INFINITY;
-        dev = (i < d) ? dev : 0.0;
+        if (SEL) dev = (i < d) ? dev : 0.0;
 #pragma unroll
         for (int R = R0; R < R1; ++R) {
             if (kk > kk_max(R)) continue;
@@ -553,6 +559,7 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
     double* sE = sL + kTiles * 64;
     double* sVr = sE + 3 * 4 * KT;
     constexpr bool has_norm = NORMP;
+    constexpr bool kSel = NORMP || DP > 100;   // see mfma_pass
     double* sN = sVr + 2 * gpb * 128;   // {loc, scale, mls}[4 KT]; scale = +inf marks "uniform"
     if (has_norm)
         for (int i = tid; i < 4 * KT; i += kMfmaThreads) {
@@ -579,6 +586,13 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
         }
     };
+    // The DMA brings 128 doubles: beyond the d of the column lies the next column.  The padded
+    // dimensions d .. 4 KT - 1 are zeroed by the staging wave once its DMA has landed, so that
+    // the `i < d` select on the trial deviation can be dropped (mfma_pass<.., SEL>).
+    auto zero_tail = [&](int slot) {
+        if (stager)
+            for (int k = d + lane; k < 4 * KT; k += 64) sVr[(slot * gpb + gib) * 128 + k] = 0.0;
+    };
     unsigned long long step = a.step0;
     int col = (int)(step % (unsigned long long)d);
     int cyc = 0;
@@ -590,6 +604,7 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
         x[kk] = (i < d) ? a.x[(size_t)i * W + w] : 0.0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    zero_tail(0);
     __syncthreads();
     int slot = 0;
     double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
@@ -631,7 +646,7 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
         {
             constexpr int R1 = kMfmaFirstPass;
             d4 acc[R1];
-            mfma_pass<0, R1>(acc, x, r, v, sE, sL, c, lane, d);
+            mfma_pass<0, R1, kSel>(acc, x, r, v, sE, sL, c, lane, d);
 #pragma unroll
             for (int q = 0; q < R1; ++q)
 #pragma unroll
@@ -640,7 +655,7 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
         if (RT > kMfmaFirstPass) {   // (R0 is clamped so that the dead instantiation is valid)
             constexpr int R0 = RT > kMfmaFirstPass ? kMfmaFirstPass : RT - 1;
             d4 acc[RT - R0];
-            mfma_pass<R0, RT>(acc, x, r, v, sE, sL, c, lane, d);
+            mfma_pass<R0, RT, kSel>(acc, x, r, v, sE, sL, c, lane, d);
 #pragma unroll
             for (int q = 0; q < RT - R0; ++q)
 #pragma unroll
@@ -680,6 +695,8 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
             const int i = 4 * kk + c;
+            // (guarded on purpose: the unconditional form lets the compiler hoist the 25 LDS
+            // loads and spill 30 more registers -- 16.6 against 14.1 ms per 800 steps at d = 100)
             x[kk] = (i < d) ? fma(ra, v[i], x[kk]) : 0.0;
         }
         lpri = accept ? lp : lpri;
@@ -695,6 +712,7 @@ __global__ void __launch_bounds__(kMfmaThreads) step_mfma_kernel(const MfmaStepA
         ++step;
         if (++col == d) { col = 0; ++cyc; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        zero_tail(slot ^ 1);
         __syncthreads();
         slot ^= 1;
     }
