@@ -471,7 +471,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int kRowShift = (16 - (DP + 3) / 4 * 4 % 16) % 16;
 constexpr int RT = (DP + kRowShift + 15) / 16;     // row tiles
 constexpr int KT = (DP + 3) / 4;       // k-steps
-constexpr int RH = (RT + 1) / 2;       // row tiles of the first pass
+constexpr int RH = (RT + 1) / 2;       // row tiles of the first pass (RT / 2 -- fewer repeated trial
+                                       // deviations -- measured 14.95 against 14.0 ms at d = 100)
 // tile (R, kk) exists for kk <= kk_max(R) (its last row is 16 R - kRowShift + 15); R-major
 constexpr int kk_max(int R) { return 4 * R + 3 - kRowShift / 4; }
 constexpr int tiles_of_row(int R) { return (kk_max(R) + 1 < KT) ? kk_max(R) + 1 : KT; }
