@@ -196,7 +196,7 @@ def test_config4_d100_posterior():
                                      "covmat": cov, "covmat_params": names, "Rminus1_stop": 0.0,
                                      "max_samples": 2.2e7, "snapshot_every": 800}}}
     updated, sampler = run(info)
-    assert sampler.group_size == 128
+    assert sampler.group_size == 256   # (the moments pass the group through LDS in slices)
     coll = sampler.products()["sample"]
     n0 = len(coll) // 2
     m, c = coll.mean(first=n0), coll.cov(first=n0)
