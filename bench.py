@@ -198,8 +198,8 @@ def main():
             "roofline": ({
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-            } if d <= 48 else {
-                # d > 48: the whitening runs on the matrix cores (v_mfma_f64_16x16x4_f64);
+            } if d <= 56 else {
+                # d > 56: the whitening runs on the matrix cores (v_mfma_f64_16x16x4_f64);
                 # algorithmic flops (d(d+1) + 4d per evaluation) against the dense FP64 peak
                 "bound": "mfma",
                 "achieved": (d * (d + 1) + 4 * d) * a.walkers * spl / (step_ms * 1e-3) / 1e12
@@ -211,7 +211,7 @@ def main():
                 "algorithmic_GBps": achieved,
             }) | {
                 "kernel": (("mcmc::step_pair_kernel<true, false> (d=%d)" % d)
-                           if 14 <= d <= 48 and a.walkers % 256 == 0
+                           if 14 <= d <= 56 and a.walkers % 256 == 0
                            else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
                            else ("mcmc::step_mfma_kernel<false> (d=%d)" % d) if a.walkers % 256 == 0
                            else ("mcmc::step_big_reg_kernel (d=%d)" % d)),

@@ -22,7 +22,7 @@ LIB = os.path.join(CSRC, "libmcmc_hip.so")
 ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
 BIG_DPS = [48, 56, 64, 72, 80, 88, 96, 100, 112, 120, 128]  # padded sizes of the d > 32 kernels
-PAIR_DIMS = list(range(33, 49))  # 32 < d <= 48: walker_kernels.hip's two-wave step kernel alone
+PAIR_DIMS = list(range(33, 57))  # 32 < d <= 48: walker_kernels.hip's two-wave step kernel alone
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
 # operations are written as fma()); see DESIGN.md "Ensemble specification".

@@ -30,6 +30,8 @@ MCMC_DECLARE_PAIR(33) MCMC_DECLARE_PAIR(34) MCMC_DECLARE_PAIR(35) MCMC_DECLARE_P
 MCMC_DECLARE_PAIR(37) MCMC_DECLARE_PAIR(38) MCMC_DECLARE_PAIR(39) MCMC_DECLARE_PAIR(40)
 MCMC_DECLARE_PAIR(41) MCMC_DECLARE_PAIR(42) MCMC_DECLARE_PAIR(43) MCMC_DECLARE_PAIR(44)
 MCMC_DECLARE_PAIR(45) MCMC_DECLARE_PAIR(46) MCMC_DECLARE_PAIR(47) MCMC_DECLARE_PAIR(48)
+MCMC_DECLARE_PAIR(49) MCMC_DECLARE_PAIR(50) MCMC_DECLARE_PAIR(51) MCMC_DECLARE_PAIR(52)
+MCMC_DECLARE_PAIR(53) MCMC_DECLARE_PAIR(54) MCMC_DECLARE_PAIR(55) MCMC_DECLARE_PAIR(56)
 
 namespace {
 
@@ -62,7 +64,9 @@ const mcmc::PairKernels* pair_for_dim(int d)
                                    mcmc_hip_pair_39, mcmc_hip_pair_40, mcmc_hip_pair_41,
                                    mcmc_hip_pair_42, mcmc_hip_pair_43, mcmc_hip_pair_44,
                                    mcmc_hip_pair_45, mcmc_hip_pair_46, mcmc_hip_pair_47,
-                                   mcmc_hip_pair_48};
+                                   mcmc_hip_pair_48, mcmc_hip_pair_49, mcmc_hip_pair_50,
+                                   mcmc_hip_pair_51, mcmc_hip_pair_52, mcmc_hip_pair_53,
+                                   mcmc_hip_pair_54, mcmc_hip_pair_55, mcmc_hip_pair_56};
     static_assert(sizeof(table) / sizeof(table[0]) == mcmc::kMaxDimPair - mcmc::kMaxDimLane, "");
     if (d <= mcmc::kMaxDimLane || d > mcmc::kMaxDimPair) return nullptr;
     const getter g = table[d - mcmc::kMaxDimLane - 1];
@@ -256,7 +260,7 @@ struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
     const DimKernels* k = nullptr;    // d <= 32: lane-per-walker kernels of that dimension
     const BigKernels* kb = nullptr;   // 32 < d <= 128: column-sweep / matrix-core kernels
-    const mcmc::PairKernels* kp = nullptr;   // 32 < d <= 48: the two-wave step kernel, if it fits
+    const mcmc::PairKernels* kp = nullptr;   // 32 < d <= 56: the two-wave step kernel, if it fits
     hipStream_t stream = nullptr;
     std::string err;
     int d = 0, W = 0, G = 0, gs = 0, K = -1;
@@ -555,7 +559,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     h->cfg = *cfg;
     h->k = k;
     h->kb = kb;
-    // MCMC_HIP_NO_PAIR_BIG (developer switch): keep 32 < d <= 48 on the matrix-core kernel
+    // MCMC_HIP_NO_PAIR_BIG (developer switch): keep 32 < d <= 56 on the matrix-core kernel
     h->kp = (kb && !getenv("MCMC_HIP_NO_PAIR_BIG")) ? pair_for_dim(cfg->d) : nullptr;
     h->d = cfg->d;
     h->W = cfg->n_walkers;

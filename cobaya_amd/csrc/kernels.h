@@ -6,7 +6,7 @@
 namespace mcmc {
 
 constexpr int kMaxDimLane = 32;   // lane-per-walker kernels: d <= 32 (state in VGPRs)
-constexpr int kMaxDimPair = 48;   // ... and the two-wave step kernel alone up to here
+constexpr int kMaxDimPair = 56;   // ... and the two-wave step kernel alone up to here
 constexpr int kMaxModes = 16;
 
 // Whitening factor L_k^-1 (lower triangular) packed in the order the kernels consume it, so
@@ -103,7 +103,7 @@ struct StepArgs {
     // [G][ncyc][cps] 1 where the column belongs to a one-parameter block (its step draws the
     // RandProposer1D variates, proposal.py:85-93), or null
     const int* vflag;
-    uint32_t norm_mask_hi;   // dimensions 32..63 (the two-wave kernel of 32 < d <= 48)
+    uint32_t norm_mask_hi;   // dimensions 32..63 (the two-wave kernel of 32 < d <= 56)
 };
 
 // Directions of the blocked proposer (blocked_kernels.hip; any d <= 32).

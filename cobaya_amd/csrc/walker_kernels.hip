@@ -632,7 +632,10 @@ constexpr int pair_split(bool normp)
     // 1.85 / 1.76 / 1.78; d = 40: 24 / 28 / 32 / 36 give 1.60 / 1.63 / 1.68 / 1.51; d = 44:
     // 28 / 32 / 36 give 1.46 / 1.52 / 1.48; d = 48: 28 / 32 / 36 / 40 give 1.31 / 1.31 / 1.38 / 1.26
     // (d = 38 with split 24 dips to 1.56)
-    if (kBigD) h = D < 37 ? 24 : (D < 47 ? 32 : 36);
+    // d = 50: 32 / 36 / 40 give 1.16 / 1.18 / 1.20; d = 52: 32 / 36 / 40 give 0.89 / 1.00 / 1.15;
+    // d = 54: 40 / 44 give 1.02 / 1.07; d = 56: 40 / 44 / 48 give 0.85 / 0.97 / 0.84 (matrix
+    // cores, padded to 56: 0.93) -- past d = 48 role 1 runs out of registers first
+    if (kBigD) h = D < 37 ? 24 : (D < 47 ? 32 : (D < 49 ? 36 : (D < 53 ? 40 : 44)));
     if (normp) h += kRowBlock;
     const int hmax = D - 1 - (D - 1) % kRowBlock;   // largest whole number of row blocks below D
     return h < kRowBlock ? kRowBlock : (h > hmax ? hmax : h);
@@ -1308,6 +1311,8 @@ size_t pair_lds(const StepArgs& a)
 // instantiation), no emitted rows, no one-parameter blocks, whole 256-walker workgroups
 bool pair_fits(const StepArgs& a)
 {
+    // (with normal priors the matrix-core kernel is ahead again from d = 55: 7.3 against 7.0)
+    if (D >= 55 && (a.norm_mask | a.norm_mask_hi) != 0u) return false;
     return kPair && a.periodic_mask == 0u && a.n_modes == 1 && a.rows == nullptr &&
            a.vflag == nullptr && a.W % 256 == 0 && 256 % a.group_size == 0 &&
            pair_lds(a) <= kLdsMax;

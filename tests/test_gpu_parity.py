@@ -184,9 +184,13 @@ def test_big_dimension_normal_priors_bit_exact(d, W, gs):
                                             (39, 512, 256, False), (40, 512, 128, True),
                                             (40, 256, 256, False), (43, 256, 256, True),
                                             (44, 512, 128, False), (47, 512, 256, False),
-                                            (48, 256, 256, True), (48, 512, 256, False)])
+                                            (48, 256, 256, True), (48, 512, 256, False),
+                                            (49, 256, 256, False), (50, 512, 256, True),
+                                            (52, 256, 256, False), (53, 512, 256, True),
+                                            (55, 256, 256, False), (56, 512, 256, True),
+                                            (56, 256, 256, False)])
 def test_two_wave_kernel_above_32_dimensions_bit_exact(d, W, gs, normal):
-    """32 < d <= 48 on whole 256-walker workgroups: the two-wave step kernel (compiled per
+    """32 < d <= 56 on whole 256-walker workgroups: the two-wave step kernel (compiled per
     dimension) with the d > 32 sums -- four interleaved chi2 chains handed from one wave to the
     other, four chains of normal-prior terms -- on the d > 32 layout of V.  The same launches on
     the matrix-core kernel (MCMC_HIP_NO_PAIR_BIG) give the same bits."""

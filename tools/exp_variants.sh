@@ -9,7 +9,7 @@ D=$1; shift
 CS=cobaya_amd/csrc; mkdir -p $CS/_exp
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -pragma-unroll-threshold=1000000"
 [ -f $CS/_obj/capi.o ] || python -m cobaya_amd.build
-BIG=""; [ "$D" -gt 32 ] && BIG=$CS/_obj/walker_big48.o   # 32 < d <= 48: the other kernels
+BIG=""; [ "$D" -gt 32 ] && BIG=$CS/_obj/walker_big48.o; [ "$D" -gt 48 ] && BIG=$CS/_obj/walker_big56.o   # 32 < d <= 56: the other kernels
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   ( hipcc $FL $flags -DMCMC_D=$D -c $CS/walker_kernels.hip -o $CS/_exp/w_$name.o &&
