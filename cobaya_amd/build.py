@@ -96,6 +96,9 @@ def build(dims=None, jobs=None, verbose=True):
     blocked = os.path.join(CSRC, "blocked_kernels.hip")
     tasks.append((blocked, os.path.join(OBJ, "blocked.o"), [],
                   _digest([blocked] + hdrs, extra=" ".join(FLAGS))))
+    general = os.path.join(CSRC, "general_kernels.hip")
+    tasks.append((general, os.path.join(OBJ, "general.o"), [],
+                  _digest([general] + hdrs, extra=" ".join(FLAGS))))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

@@ -253,6 +253,7 @@ struct DevBuf {
 
 }  // namespace
 
+extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* b, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs* a, int n_groups,
                                                     hipStream_t st);
 
@@ -1032,18 +1033,15 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(h->d)
                             : (size_t)mcmc::v_slab_cols(Lc, h->d);
     const bool big_norm = h->norm_mask4[0] || h->norm_mask4[1] || h->norm_mask4[2] || h->norm_mask4[3];
-    if (h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0))
+    // d > 32: what the matrix-core / two-wave / column-sweep kernels leave out (mixtures, `one`,
+    // periodic parameters, emitted rows; odd ensemble sizes with normal priors or d > 112) runs
+    // on the general kernel
+    const bool general_big =
+        h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0 ||
+                  (h->W % 256 != 0 && (big_norm || h->d > 112)));
+    if (general_big && sizeof(double) * 64 * (size_t)(2 * h->d + std::max(1, h->K)) > (160u << 10))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "for d > 32 this build samples a single Gaussian mode with non-periodic "
-                    "priors and no emitted rows (d=%d, modes=%d)", h->d, h->K);
-    if (h->kb && h->d > 112 && h->W % 256 != 0)
-        return fail(h, MCMC_HIP_ERR_ARG,
-                    "d > 112 needs an ensemble that is a multiple of 256 walkers (the "
-                    "matrix-core kernel), got %d", h->W);
-    if (h->kb && big_norm && h->W % 256 != 0)
-        return fail(h, MCMC_HIP_ERR_ARG,
-                    "for d > 32 normal priors need an ensemble that is a multiple of 256 walkers "
-                    "(the matrix-core kernel), got %d", h->W);
+                    "d=%d with %d modes does not fit the general d > 32 kernel (LDS)", h->d, h->K);
     // two slabs per group of a workgroup (workgroups are 256, 128 or 64 walkers wide)
     const int wg = (h->W % 256 == 0) ? 256 : (h->W % 128 == 0) ? 128 : 64;
     if (!h->kb && !drag &&
@@ -1126,6 +1124,15 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                 g.Vf = h->Vf.p;
                 g.vflag_f = any_1d_f ? h->vflag_f.p : nullptr;
                 HIP_TRY(h, h->k->drag(g, h->stream));
+            } else if (general_big) {
+                mcmc::GeneralStepArgs g{};
+                g.s = a;
+                g.Lrow = h->dLrow.p;
+                g.d = h->d;
+                for (int q = 0; q < 4; ++q) g.norm_mask4[q] = h->norm_mask4[q];
+                for (int i = 0; i < h->d; ++i)
+                    if (h->periodic[i]) g.periodic_mask4[i >> 5] |= 1u << (i & 31);
+                HIP_TRY(h, mcmc_hip_launch_general_step(&g, h->stream));
             } else if (h->kb) {
                 a.norm_mask = h->norm_mask4[0];
                 a.norm_mask_hi = h->norm_mask4[1];

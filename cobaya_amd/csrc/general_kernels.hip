@@ -1,0 +1,156 @@
+// The GENERAL Metropolis step for 32 < d <= 128 (gfx950): everything the specialised d > 32
+// kernels leave out -- Gaussian mixtures (and `one`), periodic parameters, emitted rows with
+// burn-in, normal priors and ensembles that are not whole 256-walker workgroups.  Not a hot
+// kernel: one lane per walker with state and trial in LDS (dimension-major, conflict-free), the
+// problem constants read from global memory at wave-uniform addresses; run-time d, compiled once.
+//
+// Restates the same reference lines as walker_kernels.hip (mcmc.py:545-562, 670-748;
+// prior.py:658-676, 733-763; gaussian_mixture.py:138-163) in the d > 32 order of the
+// specification (DESIGN.md "Ensemble specification", oracle/mcmc_oracle.c eval_point): sums over
+// dimensions / rows as four interleaved chains combined (s0 + s1) + (s2 + s3).
+#include "det_math.h"
+#include "kernels.h"
+
+namespace mcmc {
+namespace {
+
+__device__ __forceinline__ double wrap_periodic(double t, double lo, double hi)
+{
+    const double w = hi - lo;
+    const double y = (t - lo) / w;
+    const double m = y - floor(y);
+    return m * w + lo;
+}
+
+__global__ void __launch_bounds__(64) step_general_kernel(const GeneralStepArgs b)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const StepArgs& a = b.s;
+    const int d = b.d, K = a.n_modes;
+    const ConstLayout cl{d, K};
+    const int tid = threadIdx.x;
+    const int w = blockIdx.x * 64 + tid;
+    const int W = a.W;
+    double* const sx = smem + tid;            // x[i] at sx[64 i]
+    double* const st = smem + 64 * d + tid;   // trial
+    double* const sa = smem + 128 * d + tid;  // mode log-pdfs a_k at sa[64 k]
+    const double* __restrict__ C = a.cblock;
+    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);   // group_size >= 64
+    const int ldv = v_ld(d);
+    const double* const Vgrp = a.V + (size_t)group * a.ncyc * (size_t)a.slab;
+
+    for (int i = 0; i < d; ++i) sx[64 * i] = a.x[(size_t)i * W + w];
+    double lpost = a.logpost[w], lpri = a.logprior[w], llik = a.loglike[w];
+    int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
+    long long nacc = a.n_accept[w];
+    const long long nacc0 = nacc;
+    int nrow = a.rows ? a.n_rows[w] : 0;
+    const uint32_t gid = a.walker0 + (uint32_t)w;
+    unsigned long long step = a.step0;
+    int col = (int)(step % (unsigned long long)d);
+    int cyc = 0;
+
+    for (int s = 0; s < a.n_steps; ++s) {
+        StepRng rng;
+        rng.begin(a.key0, a.key1, gid, step);
+        rng.run_all();
+        const double r = rng.r, Ea = rng.Ea;
+        const double* __restrict__ v = Vgrp + (size_t)cyc * a.slab + (size_t)col * ldv;
+        // ---- trial, periodic wrap, prior support and normal priors (prior.py:658-676, 733-763)
+        bool inb = true;
+        double sc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < d; ++i) {
+            double t = fma(r, v[i], sx[64 * i]);
+            const double lo = C[cl.lo() + i], hi = C[cl.hi() + i];
+            if ((b.periodic_mask4[i >> 5] >> (i & 31)) & 1u) t = wrap_periodic(t, lo, hi);
+            st[64 * i] = t;
+            inb = inb & (t <= hi) & (t >= lo);
+            if ((b.norm_mask4[i >> 5] >> (i & 31)) & 1u) {
+                const double q = (t - C[cl.loc() + i]) / C[cl.scale() + i];
+                sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, C[cl.mls() + i]);
+            }
+        }
+        const double lp = a.uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
+        // ---- likelihood (gaussian_mixture.py:138-163); lanes outside the support skip it
+        double ll = 0.0;
+        if (inb && K >= 1) {
+            double amax = -INFINITY;
+            for (int k = 0; k < K; ++k) {
+                const double* __restrict__ Lk = b.Lrow + (size_t)k * d * d;
+                const double* __restrict__ mu = C + cl.mean(k);
+                double pc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int j = 0; j < d; ++j) {
+                    double y = 0.0;
+                    for (int i = 0; i <= j; ++i) y = fma(Lk[j * d + i], st[64 * i] - mu[i], y);
+                    pc[j & 3] = fma(y, y, pc[j & 3]);
+                }
+                const double chi2 = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+                const double ak = -0.5 * (C[cl.cnorm() + k] + chi2);
+                sa[64 * k] = ak;
+                amax = (ak > amax) ? ak : amax;
+            }
+            if (K == 1) {
+                ll = sa[0];
+            } else {
+                double S = 0.0;
+                for (int k = 0; k < K; ++k) S = fma(C[cl.weight() + k], dexp(sa[64 * k] - amax), S);
+                ll = dlog(S) + amax;
+            }
+        }
+        const double lt = inb ? lp + ll : -INFINITY;
+        // ---- Metropolis test (mcmc.py:678-683) and bookkeeping (mcmc.py:685-748)
+        const bool accept = inb & (lt != -INFINITY) &
+                            ((lt > lpost) | (Ea > (lpost - lt) / a.temperature));
+        if (accept) {
+            if (burn <= 0) {
+                if (a.rows) {
+                    if (nrow < a.row_cap) {
+                        double* row = a.rows + ((size_t)w * a.row_cap + nrow) * (d + 4);
+                        row[0] = (double)wt; row[1] = lpost; row[2] = lpri; row[3] = llik;
+                        for (int i = 0; i < d; ++i) row[4 + i] = sx[64 * i];
+                    }
+                    ++nrow;  // rows beyond the capacity are counted as dropped
+                }
+            } else {
+                --burn;
+            }
+            for (int i = 0; i < d; ++i) sx[64 * i] = st[64 * i];
+        }
+        lpri = accept ? lp : lpri;
+        llik = accept ? ll : llik;
+        lpost = accept ? lt : lpost;
+        prej = accept ? 0 : (prej + (inb ? 0 : 1));
+        wt = accept ? 1 : wt + 1;
+        nacc += accept ? 1 : 0;
+        if (!accept) {
+            const double max_now = a.max_tries * (burn > 0 ? 10.0 : 1.0);
+            if ((double)(wt - prej) > max_now) atomicCAS(a.stuck, 0, 1 + (int)gid);
+        }
+        ++step;
+        if (++col == d) { col = 0; ++cyc; }
+    }
+
+    for (int i = 0; i < d; ++i) a.x[(size_t)i * W + w] = sx[64 * i];
+    a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
+    a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
+    a.n_accept[w] = nacc;
+    wave_add_accepts(a.accept_total, nacc - nacc0);
+    if (a.rows) a.n_rows[w] = nrow;
+}
+
+}  // namespace
+}  // namespace mcmc
+
+extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* b, hipStream_t st)
+{
+    using namespace mcmc;
+    const size_t lds = sizeof(double) * 64 * (size_t)(2 * b->d + (b->s.n_modes > 0 ? b->s.n_modes : 1));
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)step_general_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(step_general_kernel, dim3(b->s.W / 64), dim3(64), lds, st, *b);
+    return hipGetLastError();
+}

@@ -183,6 +183,16 @@ struct PairKernels {
     hipError_t (*step)(const StepArgs&, hipStream_t);
 };
 
+// The general step of 32 < d <= 128 (general_kernels.hip): mixtures, `one`, periodic parameters,
+// emitted rows, and ensembles the specialised kernels do not take.
+struct GeneralStepArgs {
+    StepArgs s;
+    const double* Lrow;           // [K][d][d] row-major L^-1
+    int d;
+    uint32_t norm_mask4[4];       // one bit per dimension with a normal prior
+    uint32_t periodic_mask4[4];   // ... with a periodic parameter
+};
+
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).
 struct BigKernels {
     int dp;  // largest dimension this instantiation serves

@@ -71,13 +71,14 @@ def test_random_shapes_bit_exact(seed):
 
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_BIG_CASES", "20")))))
 def test_random_big_dimensions_bit_exact(seed):
-    """d = 33 .. 128: the matrix-core kernel (ensembles that are a multiple of 256) and the
-    column-sweep fallback (other sizes), any group size, launches that stop mid-cycle."""
+    """d = 33 .. 128: the two-wave kernel (d <= 56), the matrix-core kernel (ensembles that are
+    a multiple of 256), the column-sweep fallback (other sizes) and the general kernel
+    (mixtures, `one`, periodic parameters, odd ensembles with normal priors or d > 112); any
+    group size, launches that stop mid-cycle."""
     rng = np.random.default_rng(5000 + seed)
     d = int(rng.integers(33, 129))
     gs = int(rng.choice([64, 128, 256]))
-    W = (int(rng.choice([256, 512])) if rng.random() < 0.6 or d > 112
-         else gs * int(rng.integers(1, 4)))
+    W = (int(rng.choice([256, 512])) if rng.random() < 0.6 else gs * int(rng.integers(1, 4)))
     if W % gs:
         W = gs * max(1, W // gs)
     kw = {}
@@ -85,10 +86,15 @@ def test_random_big_dimensions_bit_exact(seed):
         kw["T"] = 2.0
     if rng.random() < 0.3:
         kw["burn_in"] = 2
-    if W % 256 == 0 and rng.random() < 0.5:   # normal priors: matrix-core kernel only
+    kinds = [0] * d
+    if rng.random() < 0.5:
         kinds = (rng.random(d) < 0.5).astype(int).tolist()
         kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
                   b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
+    if rng.random() < 0.2:
+        kw["periodic"] = [int(not k and rng.random() < 0.1) for k in kinds]
+    if rng.random() < 0.25:
+        kw["K"] = int(rng.choice([0, 2, 3]))
     eng, prob, st = make_pair(d, W, gs, **kw)
     for n in (int(rng.integers(1, 10)), int(rng.integers(5, d)), int(rng.integers(1, 30))):
         eng.step(n)

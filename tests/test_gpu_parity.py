@@ -169,13 +169,6 @@ def test_big_dimension_normal_priors_bit_exact(d, W, gs):
         eng.sync()
         st.run(n, n_threads=4)
         compare_state(eng, st)
-    small = E.Engine(40, 64, group_size=64, seed=1)
-    small.set_prior([1] * 40, [0.5] * 40, [0.2] * 40)
-    small.set_target_gaussian_mixture([np.full(40, 0.5)], [np.eye(40) * 0.01])
-    small.set_proposal_cov(np.eye(40) * 0.01)
-    small.set_state(np.full((64, 40), 0.5))
-    with pytest.raises(E.EngineError, match="multiple of 256"):
-        small.step(1)
 
 
 @pytest.mark.parametrize("d,W,gs,normal", [(33, 256, 128, False), (34, 512, 256, True),
@@ -220,33 +213,52 @@ def test_two_wave_kernel_above_32_dimensions_bit_exact(d, W, gs, normal):
     compare_state(eng2, st)
 
 
-def test_big_dimension_unsupported_features_are_refused():
-    d = 40
-    eng = E.Engine(d, 64)
-    eng.set_prior([1] + [0] * (d - 1), [0.5] + [0.0] * (d - 1), [0.1] + [1.0] * (d - 1))
-    eng.set_target_gaussian_mixture([[0.5] * d], [np.eye(d) * 1e-3])
-    eng.set_proposal_cov(np.eye(d) * 1e-3)
-    lp, ll = eng.evaluate(np.full((3, d), 0.5))  # the evaluator is general ...
-    assert np.all(np.isfinite(lp + ll))
-    eng.set_state(np.full((64, d), 0.5))
-    with pytest.raises(E.EngineError, match="d > 32"):
-        eng.step(5)        # ... normal priors step only on the matrix-core kernel (W % 256 == 0)
-    mix = E.Engine(d, 256)
-    mix.set_prior([0] * d, [0.0] * d, [1.0] * d)
-    mix.set_target_gaussian_mixture([[0.4] * d, [0.6] * d], [np.eye(d) * 1e-3] * 2)
-    mix.set_proposal_cov(np.eye(d) * 1e-3)
-    mix.set_state(np.full((256, d), 0.5))
-    with pytest.raises(E.EngineError, match="single Gaussian mode"):
-        mix.step(5)        # mixtures at d > 32: evaluator only
+@pytest.mark.parametrize("d,W,gs,K,case", [
+    (40, 256, 64, 2, "mixture"), (64, 128, 64, 3, "mixture"), (36, 128, 128, 0, "one"),
+    (50, 128, 64, 1, "periodic+normal"), (100, 256, 128, 1, "periodic"),
+    (40, 64, 64, 1, "normal, odd ensemble"), (120, 128, 64, 1, "d > 112, odd ensemble"),
+    (48, 256, 256, 2, "mixture+periodic+normal+T")])
+def test_big_dimension_general_kernel_bit_exact(d, W, gs, K, case):
+    """d > 32 outside the specialised kernels -- mixtures, `one`, periodic parameters, normal
+    priors or d > 112 on ensembles that are not whole 256-walker workgroups -- runs on the
+    general kernel (general_kernels.hip), bit for bit like the oracle."""
+    rng = np.random.default_rng(7000 + d)
+    kw = {}
+    if "normal" in case:
+        kinds = (rng.random(d) < 0.4).astype(int).tolist()
+        kinds[d - 1] = 1
+        kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
+    if "periodic" in case:
+        per = [0] * d
+        for i in (1, 33, d - 2):
+            if not kw.get("kinds", [0] * d)[i]:
+                per[i] = 1
+        kw["periodic"] = per
+    if "+T" in case:
+        kw["T"] = 1.8
+    eng, prob, st = make_pair(d, W, gs, K=K, rng=np.random.default_rng(d), burn_in=2, **kw)
+    compare_state(eng, st)
+    for n in (1, d + 2, 17):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+    assert eng.counters()["accepted"] == int(st.n_accept.sum())
+
+
+def test_big_dimension_emitted_rows_bit_exact():
+    eng, prob, st = make_pair(40, 128, 64, burn_in=1, cap=48)
+    for n in (30, 45):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        rows, ref = eng.drain_samples(), st.drain()
+        assert rows.shape == ref.shape and len(rows) > 128
+        assert_bit_equal(rows, ref, "rows")
+    assert eng.counters()["dropped_rows"] == 0
     with pytest.raises(E.EngineError):
         E.Engine(129, 64)
-    wide = E.Engine(120, 64)   # d > 112: matrix-core kernel only
-    wide.set_prior([0] * 120, [0.0] * 120, [1.0] * 120)
-    wide.set_target_gaussian_mixture([[0.5] * 120], [np.eye(120) * 1e-3])
-    wide.set_proposal_cov(np.eye(120) * 1e-3)
-    wide.set_state(np.full((64, 120), 0.5))
-    with pytest.raises(E.EngineError, match="multiple of 256"):
-        wide.step(2)
 
 
 def test_general_priors_periodic_temperature_bit_exact():

@@ -13,7 +13,7 @@ BIG=""; [ "$D" -gt 32 ] && BIG=$CS/_obj/walker_big48.o; [ "$D" -gt 48 ] && BIG=$
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
   ( hipcc $FL $flags -DMCMC_D=$D -c $CS/walker_kernels.hip -o $CS/_exp/w_$name.o &&
-    hipcc -shared -fPIC --offload-arch=gfx950 $CS/_exp/w_$name.o $BIG $CS/_obj/capi.o $CS/_obj/blocked.o -o $CS/_exp/lib_$name.so &&
+    hipcc -shared -fPIC --offload-arch=gfx950 $CS/_exp/w_$name.o $BIG $CS/_obj/capi.o $CS/_obj/blocked.o $CS/_obj/general.o -o $CS/_exp/lib_$name.so &&
     echo "built $name" ) &
 done
 wait

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/final/gpu_tests.log
-cat gpurun_out/final/gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -k "big_dimension or two_wave" 2>&1 | tail -8
+MCMC_FUZZ_CASES=5 MCMC_FUZZ_BIG_CASES=200 timeout 600 python -m pytest tests/test_gpu_fuzz.py -x -q 2>&1 | tail -8
