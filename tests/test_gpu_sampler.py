@@ -457,3 +457,33 @@ def test_config2_with_manual_blocking_recovers_the_posterior():
     assert np.max(np.abs(c - cov) / np.outer(sig, sig)) < 0.02
     assert kl_norm(mean, cov, m, c) < 0.01
     sampler.close()
+
+
+def test_two_mode_mixture_at_d40_chains_mode():
+    """d > 32 beyond the specialised kernels, through `run(info)`: a two-mode gaussian_mixture
+    with a periodic parameter and emitted chains (the general kernel).  The modes are close
+    enough for the walkers to cross; mean and covariance follow the mixture's."""
+    d = 40
+    rng = np.random.default_rng(40)
+    mu1 = np.full(d, 0.496) + 0.002 * rng.standard_normal(d)   # 1.7 sigma apart in all
+    mu2 = np.full(d, 0.504) + 0.002 * rng.standard_normal(d)
+    sig = 0.03
+    cov = np.eye(d) * sig ** 2
+    names = [f"a__{i}" for i in range(d)]
+    params = {n: {"prior": {"min": 0.0, "max": 1.0},
+                  "ref": {"dist": "norm", "loc": 0.5, "scale": 0.03}} for n in names}
+    params[names[3]]["periodic"] = True
+    info = {"likelihood": {"gaussian_mixture": {"means": [mu1, mu2], "covs": [cov, cov],
+                                                "weights": [0.5, 0.5],
+                                                "input_params_prefix": "a_"}},
+            "params": params,
+            "sampler": {"mcmc_hip": {"seed": 11, "n_walkers": 1024, "group_size": 64,
+                                     "steps_per_launch": 80, "emit": "chains", "burn_in": 50,
+                                     "max_samples": 250000, "Rminus1_stop": 0.0}}}
+    updated, sampler = run(info)
+    coll = sampler.products()["sample"]
+    m, c = coll.mean(), coll.cov()
+    mean = 0.5 * (mu1 + mu2)
+    truth = cov + 0.25 * np.outer(mu1 - mu2, mu1 - mu2)
+    assert np.max(np.abs(m - mean)) < 0.2 * sig
+    assert np.max(np.abs(np.sqrt(np.diag(c)) / np.sqrt(np.diag(truth)) - 1)) < 0.1
