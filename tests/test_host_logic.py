@@ -30,6 +30,20 @@ def test_capi_exports_every_declared_symbol():
     assert b"gfx950" in lib.mcmc_hip_version()
     assert all(lib.mcmc_hip_dim_supported(d) for d in range(1, 129))
     assert not lib.mcmc_hip_dim_supported(129) and not lib.mcmc_hip_dim_supported(0)
+    # every kernel translation unit the build lists is linked in (the C ABI finds them through
+    # weak per-dimension getters: a missing object would silently drop a fast path)
+    from cobaya_amd import build as B
+    for d in B.ALL_DIMS:
+        assert hasattr(lib, f"mcmc_hip_dim_{d}")
+    for d in B.PAIR_DIMS:
+        assert hasattr(lib, f"mcmc_hip_pair_{d}")
+    for dp in B.BIG_DPS:
+        assert hasattr(lib, f"mcmc_hip_big_{dp}")
+    assert hasattr(lib, "mcmc_hip_launch_general_step") and hasattr(lib, "mcmc_hip_launch_blocked_basis")
+    with open(os.path.join(ROOT, "cobaya_amd", "csrc", "capi.hip")) as f:
+        capi = f.read()
+    assert {int(x) for x in re.findall(r"MCMC_DECLARE_PAIR\((\d+)\)", capi)} == set(B.PAIR_DIMS)
+    assert {int(x) for x in re.findall(r"MCMC_DECLARE_BIG\((\d+)\)", capi)} == set(B.BIG_DPS)
 
 
 def test_engine_fails_loudly_without_gpu_or_with_bad_config():
