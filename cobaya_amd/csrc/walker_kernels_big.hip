@@ -1,21 +1,22 @@
-// Walker kernels for 32 < d <= MCMC_DP (gfx950).
+// Walker kernels for 32 < d <= MCMC_DP (gfx950); one translation unit per padded size DP, the
+// actual d is a run-time argument <= DP (rows / columns beyond d are zero operands: exact no-ops).
 //
-// Still one lane per walker and n_steps fused per launch, but 2*d doubles of state no longer
-// fit the 256 architectural VGPRs: the whitened accumulators y_j take them (in two passes over
-// half of the rows each, so that the other half of the VGPRs can hold L^-1 tiles in flight),
-// and the parameter vector x lives in the accumulation half of the unified register file.
-// The sweep goes column block by column block: t_i = fma(r, v_i, x_i), prior support, dev_i
-// for four columns, then every 4x4 tile of L^-1 below them (16 FMAs per tile; tiles staged in
-// LDS once per launch, zero above the diagonal, read as wave-uniform broadcasts two tiles
-// ahead).  Each y_j accumulates i = 0..j in ascending order from +0 -- the same fma chain as
-// the oracle and the small-d kernels, so parity stays bit-exact.  The proposal direction of
-// the NEXT step arrives in LDS by a 1 KiB global->LDS DMA while the current step runs.
-//
-// Scope of this variant: one Gaussian mode, uniform priors, nothing periodic, no emitted rows
-// (BASELINE config 4).  Everything else at d > 32 is refused by the host with a clear error.
-//
-// One translation unit per accumulator count DP (-DMCMC_DP=48|64|80|100|112); the actual d is
-// a run-time argument <= DP (rows/columns beyond d are zero operands: exact no-ops).
+//   basis_big_kernel      Haar directions V = T R per (group, cycle): four lanes per row of H,
+//                         barrier-free reflections, row-blocked product
+//   step_mfma_kernel<N>   the step for ensembles of whole 256-walker workgroups: y = L^-1 dev on
+//                         the matrix cores (v_mfma_f64_16x16x4_f64), 16 walkers per wave; N = with
+//                         normal priors.  One Gaussian mode, non-periodic priors, no emitted rows.
+//   step_big_reg_kernel   (DP <= 112) lane-per-walker fallback for other ensemble sizes, uniform
+//                         priors: a column sweep over 4x4 tiles of L^-1 broadcast from LDS, the
+//                         accumulators y_j in VGPRs and x in the accumulation half of the
+//                         register file; each y_j is the same ascending fma chain
+//   evaluate_big_kernel   batch log-prior / log-likelihood (general: mixtures, normal priors)
+//   group_moments_big_kernel, pool_moments_big_kernel   streaming sufficient statistics; the
+//                         group passes through LDS in slices, so any group size serves any d
+// Every sum follows the d > 32 order of the specification (four interleaved chains), so the
+// results equal the oracle's bit for bit.  What these kernels leave out (mixtures, periodic
+// parameters, emitted rows, ...) runs on general_kernels.hip; for 32 < d <= 56 the step of whole
+// 256-walker workgroups is served by walker_kernels.hip's two-wave kernel instead.
 #include <type_traits>
 #include "det_math.h"
 #include "kernels.h"
