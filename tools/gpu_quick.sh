@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/final/gpu_tests.log
-cat gpurun_out/final/gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 300 python bench.py --no-cpu-baseline --steps 30 --warmup 4 2>/dev/null | tail -1 | cut -c1-200
+export TMPDIR=/tmp
+OUT=gpurun_out/d40; rm -rf $OUT; mkdir -p $OUT
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --dim 40 --no-cpu-baseline --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/trace.log
+tail -1 $OUT/bench.json | cut -c1-300
+ls $OUT/trace
