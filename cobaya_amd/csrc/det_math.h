@@ -204,6 +204,14 @@ struct StepRng {
         else if (k == 14) Ea = -log_b();
         else if (k == 15) r = sqrt(2.0 * Er);
         else if (k == 16) r = expo ? Er : r;
+        // the walker's PRIVATE sign (bit 7 of w0; set = positive, as for one-parameter blocks):
+        // the basis column is shared by the group, and x + r v with r > 0 is a symmetric
+        // proposal only on average over v and -v.  With its own sign every walker's kernel is
+        // symmetric for every fixed basis, so the walkers of a group are independent chains
+        // given the bases ("Why a shared basis")
+        else if (k == 17)
+            r = __longlong_as_double(__double_as_longlong(r) ^
+                                     ((long long)((c0 & 0x80u) ^ 0x80u) << 56));
     }
     __device__ __forceinline__ void run_all()
     {

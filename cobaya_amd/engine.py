@@ -41,7 +41,7 @@ class Config(C.Structure):
         ("d", C.c_int32), ("n_walkers", C.c_int32), ("group_size", C.c_int32),
         ("device", C.c_int32), ("seed", C.c_uint64), ("walker_offset", C.c_uint32),
         ("burn_in", C.c_int32), ("temperature", C.c_double), ("proposal_scale", C.c_double),
-        ("max_tries", C.c_double), ("emit_capacity", C.c_int32), ("reserved", C.c_int32),
+        ("max_tries", C.c_double), ("emit_capacity", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -152,7 +152,7 @@ class Engine:
 
     def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
                  burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
-                 emit_capacity=0):
+                 emit_capacity=0, shared_basis=True):
         self._lib = load_library()
         self._h = _H()
         self.d, self.W, self.group_size = int(d), int(n_walkers), int(group_size)
@@ -164,7 +164,7 @@ class Engine:
                      burn_in=int(burn_in), temperature=float(temperature),
                      proposal_scale=float(proposal_scale),
                      max_tries=float(max_tries if max_tries is not None else 40 * d),
-                     emit_capacity=int(emit_capacity), reserved=0)
+                     emit_capacity=int(emit_capacity), flags=0 if shared_basis else 1)
         self.cfg = cfg
         rc = self._lib.mcmc_hip_create(C.byref(cfg), C.byref(self._h))
         if rc:

@@ -28,28 +28,28 @@ OVERHEAD_TIME = 0.0003  # conventions.py:141
 
 
 def sort_parameter_blocks(blocks, speeds, footprints, oversample_power=0.0):
-    """tools.py:955-1006: ordering of the blocks that minimises the cost of varying every
-    parameter once after the Cholesky mixing; returns (ordering, per-parameter cumulative
-    costs, oversampling factors) in that order."""
-    n_per_block = np.array([len(b) for b in blocks])
-    all_costs = 1 / np.array(speeds, dtype=float)
-    fps = np.array(footprints)
-    tri_lower = np.tri(len(n_per_block))
+    """Block ordering of tools.py:955-1006 (`sort_parameter_blocks`), from its cost model.
 
-    def cost_per_param_per_block(ordering):
-        return np.minimum(1, tri_lower.T.dot(fps[ordering])).dot(all_costs)
-
-    if oversample_power >= 1:
-        best, _, _ = sort_parameter_blocks(blocks, speeds, footprints, 1 - 1e-3)
-        orderings = [best]
-    else:
-        orderings = list(itertools.permutations(np.arange(len(n_per_block))))
-    costs = np.array([cost_per_param_per_block(list(o)) for o in orderings])
-    factors = np.array([(c[0] / c) ** oversample_power for c in costs])
-    total = np.array([(n_per_block[list(o)] * factors[i]).dot(costs[i])
-                      for i, o in enumerate(orderings)])
-    i_opt = int(np.argmin(total))
-    return orderings[i_opt], costs[i_opt], np.floor(factors[i_opt]).astype(int)
+    After the Cholesky mixing, moving a parameter of the block at position i also moves every
+    later (faster) block, so it costs one evaluation of each likelihood that any block at
+    position >= i feeds: cost_i = sum_l [1/speed_l] * [some block at position >= i has l in
+    its footprint].  A block is oversampled by (cost_0 / cost_i) ** oversample_power and an
+    ordering is charged sum_i n_i * factor_i * cost_i.  All m! orderings are scored in one
+    array pass (lexicographic order, first minimum wins -- the reference's tie-break, pinned
+    by golden G11); for oversample_power >= 1 the ordering is the one that is optimal just
+    below 1 (tools.py:996-998).  Returns (ordering, cost per position, integer factors)."""
+    sizes = np.array([len(b) for b in blocks], dtype=float)
+    like_cost = 1.0 / np.asarray(speeds, dtype=float)
+    foot = np.asarray(footprints, dtype=float)
+    perms = np.array(list(itertools.permutations(range(len(blocks)))), dtype=int)
+    # likelihoods touched from position i onwards: reversed running sum of the footprints
+    touched = np.cumsum(foot[perms][:, ::-1, :], axis=1)[:, ::-1, :]
+    cost = np.minimum(touched, 1.0) @ like_cost                       # [m!, m]
+    rank_power = oversample_power if oversample_power < 1 else 1 - 1e-3
+    charge = np.sum(sizes[perms] * (cost[:, :1] / cost) ** rank_power * cost, axis=1)
+    best = int(np.argmin(charge))
+    factors = np.floor((cost[best, 0] / cost[best]) ** oversample_power).astype(int)
+    return tuple(int(i) for i in perms[best]), cost[best], factors
 
 
 class UnsupportedModel(ValueError):
@@ -186,16 +186,12 @@ class ProblemSpec:
 
     # ----------------------------------------------------------------- construction
     @classmethod
-    def from_info(cls, info):
-        params = info.get("params") or {}
-        if info.get("prior"):
-            raise UnsupportedModel("external priors (`prior:` block) are arbitrary Python "
-                                   "and cannot run on the device")
-        if info.get("theory"):
-            raise UnsupportedModel("theory codes are out of scope for mcmc_hip")
+    def _from_params(cls, params):
+        """The `params` block -> a spec without likelihoods (parameterization.py: sampled =
+        has `prior`; derived = neither prior nor value)."""
         sampled, derived, fixed = [], [], {}
         kinds, a, b, per, refs, props, labels = [], [], [], [], [], [], {}
-        for name, p in params.items():
+        for name, p in (params or {}).items():
             if isinstance(p, numbers.Real):
                 fixed[name] = float(p)
                 continue
@@ -237,13 +233,28 @@ class ProblemSpec:
                                    "the analytic likelihoods handled here")
         if not sampled:
             raise UnsupportedModel("No parameters being varied for sampler")
-        spec = cls(sampled, derived, np.array(kinds), np.array(a, float), np.array(b, float),
+        return cls(sampled, derived, np.array(kinds), np.array(a, float), np.array(b, float),
                    np.array(per), refs, props, labels=labels)
+
+    @classmethod
+    def from_info(cls, info):
+        if info.get("prior"):
+            raise UnsupportedModel("external priors (`prior:` block) are arbitrary Python "
+                                   "and cannot run on the device")
+        if info.get("theory"):
+            raise UnsupportedModel("theory codes are out of scope for mcmc_hip")
+        spec = cls._from_params(info.get("params"))
+        sampled, derived = spec.sampled, spec.derived
         likes = info.get("likelihood") or {}
         if not likes:
             raise UnsupportedModel("no likelihood given (use `one` for prior-only sampling)")
         comps = [cls._parse_likelihood(lname, linfo, sampled, derived, single=len(likes) == 1)
                  for lname, linfo in likes.items()]
+        return spec._with_components(comps)
+
+    def _with_components(self, comps):
+        """Attach the parsed likelihoods: one is taken as it is, several are merged."""
+        spec, cls = self, type(self)
         spec.components = comps
         if len(comps) == 1:
             c = comps[0]
@@ -283,65 +294,86 @@ class ProblemSpec:
         spec.weights = np.array(weights) if n_modes > 1 else None
         return spec
 
-    @staticmethod
-    def _parse_likelihood(lname, linfo, sampled, derived, single):
-        """One entry of the `likelihood` block -> dict(name, kind, idx, means, covs, weights,
-        normalized, has_derived, speed).  Parameter routing by `input_params_prefix`
+    # keys Cobaya itself adds to a likelihood block when it updates the input
+    # (input.py update_info, model.py:1320-1328, component.py get_versions): accepted so that
+    # an `*.updated.yaml` -- or `model.info()` -- can be fed back in
+    _FRAMEWORK_KEYS = ("delay", "type", "version", "stop_at_error", "python_path", "params")
+
+    @classmethod
+    def _parse_likelihood(cls, lname, linfo, sampled, derived, single):
+        """One entry of the `likelihood` block -> component dict (see `_component`).
+        Parameter routing: an explicit `input_params` / `output_params` list
+        (model.py:1155-1167), else `input_params_prefix` / `output_params_prefix`
         (model.py:1169-1172)."""
         linfo = dict(linfo or {})
         lclass = linfo.pop("class", lname)
         lclass = str(lclass).split(".")[-1].lower().replace("_", "")
-        d_all = len(sampled)
         in_prefix = linfo.pop("input_params_prefix", "") or ""
         out_prefix = linfo.pop("output_params_prefix", "") or ""
+        inputs, outputs = linfo.pop("input_params", None), linfo.pop("output_params", None)
         speed = linfo.pop("speed", -1)
-        linfo.pop("stop_at_error", None)
-        comp = {"name": lname, "kind": "one", "idx": [], "means": None, "covs": None,
-                "weights": None, "normalized": True, "has_derived": False,
-                "speed": float(speed if speed is not None else -1)}
+        for k in cls._FRAMEWORK_KEYS:
+            linfo.pop(k, None)
         if lclass == "one":
             linfo.pop("noise", None)
+            return cls._component(lname, "one", [], [], sampled, derived, single, speed=speed)
+        if lclass not in ("gaussianmixture", "gaussian"):
+            raise UnsupportedModel(f"likelihood '{lname}' is not one of gaussian_mixture, "
+                                   "gaussian, one")
+        if not isinstance(inputs, (list, tuple)):
+            inputs = [p for p in sampled if p.startswith(in_prefix)]  # model.py:1169-1172
+        if not isinstance(outputs, (list, tuple)):
+            outputs = [p for p in derived if p.startswith(out_prefix)]
+        if lclass == "gaussianmixture":
+            kw = dict(means=linfo.pop("means", None), covs=linfo.pop("covs", None),
+                      weights=linfo.pop("weights", None),
+                      has_derived=bool(linfo.pop("derived", False)))
+            kind = "gaussian_mixture"
+        else:
+            kw = dict(means=linfo.pop("mean", None), covs=linfo.pop("cov", None),
+                      normalized=bool(linfo.pop("normalized", True)))
+            kind = "gaussian"
+        if linfo:
+            raise UnsupportedModel(f"unknown options for likelihood '{lname}': "
+                                   f"{sorted(linfo)}")
+        return cls._component(lname, kind, list(inputs), list(outputs), sampled, derived,
+                              single, speed=speed, **kw)
+
+    @staticmethod
+    def _component(lname, kind, inputs, outputs, sampled, derived, single, means=None,
+                   covs=None, weights=None, normalized=True, has_derived=False, speed=-1):
+        """Validated description of one likelihood: dict(name, kind, idx, means[K][n],
+        covs[K][n][n], weights[K] | None, normalized, has_derived, speed), with the checks of
+        gaussian_mixture.py:45-136 / gaussian.py:30-94."""
+        comp = {"name": lname, "kind": kind, "idx": [], "means": None, "covs": None,
+                "weights": None, "normalized": bool(normalized), "has_derived": False,
+                "speed": float(speed if speed is not None else -1)}
+        if kind == "one":
             if derived:
                 raise UnsupportedModel("derived parameters need a gaussian_mixture with "
                                        "`derived: True`")
             return comp
-        if lclass not in ("gaussianmixture", "gaussian"):
-            raise UnsupportedModel(f"likelihood '{lname}' is not one of gaussian_mixture, "
-                                   "gaussian, one")
-        inputs = [p for p in sampled if p.startswith(in_prefix)]  # model.py:1169-1172
-        if single and inputs != sampled:
+        foreign = [p for p in inputs if p not in sampled]
+        if foreign:
+            raise UnsupportedModel(f"likelihood '{lname}': input parameters {foreign} are not "
+                                   "sampled parameters")
+        if single and list(inputs) != list(sampled):
             raise UnsupportedModel(
-                f"input_params_prefix '{in_prefix}' selects {inputs} but all sampled "
-                f"parameters {sampled} must feed the likelihood")
+                f"likelihood '{lname}' takes {list(inputs)} but all sampled "
+                f"parameters {list(sampled)} must feed the likelihood")
         comp["idx"] = [sampled.index(p) for p in inputs]
         d = len(inputs)
-        if lclass == "gaussianmixture":
-            means, covs = linfo.pop("means", None), linfo.pop("covs", None)
-            if means is None or covs is None:
-                raise UnsupportedModel("You must specify both a mean (or a list of them) "
-                                       "and a covariance matrix, or a list of them.")
-            means = np.atleast_1d(np.array(means, dtype=float))
-            while means.ndim < 2:
-                means = means[None]
-            covs = np.atleast_1d(np.array(covs, dtype=float))
-            while covs.ndim < 3:
-                covs = covs[None]
-            weights = linfo.pop("weights", None)
-            comp["has_derived"] = bool(linfo.pop("derived", False))
-            comp["kind"] = "gaussian_mixture"
-        else:
-            mean, cov = linfo.pop("mean", None), linfo.pop("cov", None)
-            if mean is None or cov is None:
-                raise UnsupportedModel("You must specify both a mean and a covariance "
-                                       "matrix.")
-            means = np.atleast_1d(np.array(mean, dtype=float))[None]
-            covs = np.atleast_2d(np.array(cov, dtype=float))[None]
-            weights = None
-            comp["normalized"] = bool(linfo.pop("normalized", True))
-            comp["kind"] = "gaussian"
-        if linfo:
-            raise UnsupportedModel(f"unknown options for likelihood '{lname}': "
-                                   f"{sorted(linfo)}")
+        if means is None or covs is None:
+            raise UnsupportedModel(
+                "You must specify both a mean (or a list of them) and a covariance matrix, "
+                "or a list of them." if kind == "gaussian_mixture" else
+                "You must specify both a mean and a covariance matrix.")
+        means = np.atleast_1d(np.array(means, dtype=float))
+        while means.ndim < 2:
+            means = means[None]
+        covs = np.atleast_1d(np.array(covs, dtype=float))
+        while covs.ndim < 3:
+            covs = covs[None]
         K = len(means)
         if covs.shape != (K, means.shape[1], means.shape[1]):
             raise UnsupportedModel("The dimensionalities guessed from mean(s) and "
@@ -355,11 +387,11 @@ class ProblemSpec:
             if len(weights) != K:
                 raise UnsupportedModel("There must be as many weights as components.")
         else:
-            weights = None
+            weights = None  # equal weights (gaussian_mixture.py:131-132)
         comp["means"], comp["covs"], comp["weights"] = means, covs, weights
-        outs = [p for p in derived if p.startswith(out_prefix)]
+        comp["has_derived"] = bool(has_derived)
         if comp["has_derived"]:
-            if len(outs) != d * K or outs != derived:
+            if len(outputs) != d * K or list(outputs) != list(derived):
                 raise UnsupportedModel(
                     "The number of derived parameters must be equal to the "
                     f"dimensionality times the number of modes, i.e. {d} x {K} = "
@@ -367,7 +399,6 @@ class ProblemSpec:
         elif derived and single:
             raise UnsupportedModel("Derived parameters were requested, but 'derived' "
                                    "option is False.")
-        del d_all
         return comp
 
     # ----------------------------------------------------------------- several likelihoods
@@ -433,10 +464,56 @@ class ProblemSpec:
 
     @classmethod
     def from_cobaya_model(cls, model):
-        """Introspect a real cobaya.model.Model (attributes of SURVEY.md 8b)."""
+        """Introspect a live `cobaya.model.Model` (the attributes SURVEY.md 8b lists): the
+        parameter block of `model.info()` (prior / ref / proposal / periodic of every sampled
+        parameter, cross-checked against `model.parameterization` and `model.prior`), and the
+        INITIALISED likelihood objects `model.likelihood[name]` -- their routed
+        `input_params` / `output_params` (model.py:1115-1335) and the arrays they were built
+        with (`means`, `covs`, `weights`: gaussian_mixture.py:53-136; `mean`, `cov`,
+        `normalized`: gaussian.py:30-94)."""
         info = model.info()
-        return cls.from_info({"params": info["params"], "likelihood": info["likelihood"],
-                              "prior": info.get("prior"), "theory": info.get("theory")})
+        if info.get("prior") or len(list(model.prior)) > 1:
+            raise UnsupportedModel("external priors (`prior:` block) are arbitrary Python "
+                                   "and cannot run on the device")
+        if len(getattr(model, "theory", None) or {}):
+            raise UnsupportedModel("theory codes are out of scope for mcmc_hip")
+        spec = cls._from_params(info["params"])
+        live = list(model.parameterization.sampled_params())
+        if live != spec.sampled:
+            raise UnsupportedModel(f"sampled parameters of the model {live} differ from the "
+                                   f"ones read from its info {spec.sampled}")
+        lo, hi = np.asarray(model.prior.bounds(confidence_for_unbounded=1.0)).T
+        mine = spec.bounds()
+        if not (np.array_equal(lo, mine[0]) and np.array_equal(hi, mine[1])):
+            raise UnsupportedModel("prior bounds of the model and of its info disagree")
+        comps = []
+        likes = dict(model.likelihood.items())
+        for lname, like in likes.items():
+            mro = [c.__name__ for c in type(like).__mro__]
+            speed = getattr(like, "speed", -1)
+            ins, outs = list(like.input_params), list(like.output_params)
+            if "GaussianMixture" in mro:
+                w = getattr(like, "weights", None)
+                comps.append(cls._component(
+                    lname, "gaussian_mixture", ins, outs, spec.sampled, spec.derived,
+                    len(likes) == 1, means=like.means, covs=like.covs,
+                    weights=None if np.isscalar(w) else w, has_derived=bool(like.derived),
+                    speed=speed))
+            elif "Gaussian" in mro:
+                comps.append(cls._component(
+                    lname, "gaussian", ins, outs, spec.sampled, spec.derived, len(likes) == 1,
+                    means=like.mean, covs=like.cov,
+                    normalized=bool(getattr(like, "normalized", True)), speed=speed))
+            elif "one" in mro or "One" in mro:
+                comps.append(cls._component(lname, "one", [], [], spec.sampled, spec.derived,
+                                            len(likes) == 1, speed=speed))
+            else:
+                raise UnsupportedModel(
+                    f"likelihood '{lname}' ({type(like).__name__}) is not one of "
+                    "gaussian_mixture, gaussian, one")
+        if not comps:
+            raise UnsupportedModel("no likelihood given (use `one` for prior-only sampling)")
+        return spec._with_components(comps)
 
     # ----------------------------------------------------------------- engine hookup
     def configure(self, engine):

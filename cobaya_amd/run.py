@@ -1,6 +1,7 @@
 """`run(info) -> (updated_info, sampler)` for the inputs the mcmc_hip path covers: the shape
-of cobaya.run.run (cobaya/run.py:30-183) without the parts that are out of scope (output
-driver, resume logic, post-processing, other samplers).  When Cobaya itself is installed,
+of cobaya.run.run (cobaya/run.py:30-183) without the parts that are out of scope (post-processing,
+other samplers, the `.input/.updated.yaml` dumps); `output`, `resume` and `force` behave as in
+the reference.  When Cobaya itself is installed,
 use `cobaya.run.run` with `sampler: {mcmc_hip: ...}` instead -- the class registers through
 the top-level `mcmc_hip` module."""
 from __future__ import annotations
@@ -40,7 +41,7 @@ def run(info_or_yaml, **overrides):
     except UnsupportedModel as e:
         raise LoggedError(log, "mcmc_hip cannot sample this model: %s", str(e)) from e
     sampler = MCMCHip(opts or {}, spec, output=info.get("output"), name=name,
-                      resume=bool(info.get("resume")))
+                      resume=bool(info.get("resume")), force=bool(info.get("force")))
     updated = copy.deepcopy(info)
     updated["sampler"] = {name: sampler.info()}
     sampler.run()

@@ -73,6 +73,9 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
+    "shared_basis": True,     # True: the walkers of a group share one Haar basis per cycle;
+                              # False: every walker draws its own (proposal.py:59-69 to the
+                              # letter: the reference-faithful control, much slower)
 }
 
 
@@ -88,57 +91,85 @@ def _number_with_units(value, unit, scale):
     return value
 
 
-class MCMCHip:
-    """Adaptive Metropolis MCMC on a walker ensemble (HIP engine)."""
+class EnsembleMCMC:
+    """The engine-backed sampler logic, host-agnostic.  Two hosts give it a constructor:
+
+      * `MCMCHip` below (standalone: no Cobaya needed), and
+      * `mcmc_hip.MCMCHip(EnsembleMCMC, cobaya.samplers.mcmc.MCMC)` (Cobaya-hosted:
+        `cobaya.sampler.Sampler.__init__`, sampler.py:257-322, sets the options, the model and
+        the `Output` object and then calls `initialize()`).
+
+    What a host must provide: `self.log`, every option of MCMC_DEFAULTS + HIP_DEFAULTS as an
+    attribute, the read-only attributes `model` / `output`, `get_name()`, and -- optionally --
+    `self.spec` (else it is read from the live model in `initialize`)."""
 
     file_base_name = "mcmc_hip"
     sampler_type = "mcmc"
     supports_periodic_params = True
     fallback_covmat_scale = 4.0  # sampler.py:474
+    _LoggedError = LoggedError   # the hosted class raises cobaya.log.LoggedError instead
+    _engine_factory = staticmethod(Engine)  # the seam to libmcmc_hip.so (tests swap it)
 
-    # ------------------------------------------------------------------ construction
-    def __init__(self, info_sampler=None, model=None, output=None, packages_path=None,
-                 name=None, resume=False):
-        info_sampler = dict(info_sampler or {})
-        known = {**MCMC_DEFAULTS, **HIP_DEFAULTS}
-        unknown = set(info_sampler) - set(known)
-        if unknown:  # input.py:403-435: unknown options are rejected
-            raise LoggedError(log, "mcmc_hip does not recognise the option(s) %s. Valid "
-                                   "options: %s", sorted(unknown), sorted(known))
-        for k, v in known.items():
-            setattr(self, k, copy.deepcopy(info_sampler.get(k, v)))
-        self._name = name or "mcmc_hip"
-        self.output = output
-        self._resume = bool(resume)
-        self.packages_path = packages_path
-        if isinstance(model, ProblemSpec):
-            self.spec = model
-            self.model = None
-        elif model is not None:  # a real cobaya.model.Model
-            self.model = model
-            try:
-                self.spec = ProblemSpec.from_cobaya_model(model)
-            except UnsupportedModel as e:
-                raise LoggedError(log, "mcmc_hip cannot sample this model: %s", str(e)) from e
-        else:
-            raise LoggedError(log, "mcmc_hip needs a model")
-        self.converged = False
-        self.Rminus1_last = np.inf
-        self.engine = None
-        self.initialize()
+    # ------------------------------------------------------------------ host seams
+    def _fail(self, msg, *args, cause=None):
+        """Log, then raise the host's LoggedError (log.py:22-46)."""
+        err = self._LoggedError(self.log, msg, *args)
+        if cause is not None:
+            raise err from cause
+        raise err
 
-    def get_name(self):
-        return self._name
+    def _out_parts(self):
+        """(folder, file prefix) of the output, or None: from a `cobaya.output.Output`
+        (output.py:199-200 `split_prefix`; OutputDummy is falsy) or from a plain string."""
+        out = self.output
+        if not out:
+            return None
+        if hasattr(out, "folder") and hasattr(out, "prefix"):
+            return out.folder, out.prefix
+        text = str(out)
+        folder, prefix = os.path.split(text)   # 'chains/' -> ('chains', '')
+        return folder or ".", prefix
+
+    def _out_file(self, ext):
+        """`[folder]/[prefix]<ext>`, e.g. ext = '.checkpoint' (sampler.py:324-338)."""
+        folder, prefix = self._out_parts()
+        return os.path.join(folder, prefix + ext)
+
+    def _chain_file(self, suffix="txt"):
+        """`[folder]/[prefix].<rank+1>.<suffix>` (output.py:298-322 prepare_collection)."""
+        folder, prefix = self._out_parts()
+        return os.path.join(folder, (prefix + "." if prefix else "")
+                            + f"{1 + self.rank}.{suffix}")
+
+    def _is_resuming(self):
+        out = self.output
+        if hasattr(out, "is_resuming"):
+            return bool(out.is_resuming())
+        return bool(getattr(self, "_resume", False))
+
+    def _export_collection(self, coll):
+        """What `products()['sample']` hands out; the hosted class converts to Cobaya's own
+        `SampleCollection`."""
+        return coll
 
     # ------------------------------------------------------------------ MCMC.initialize
     def initialize(self):
         """mcmc.py:111-271."""
+        if getattr(self, "spec", None) is None:
+            try:  # the attributes of the live model SURVEY.md 8b lists
+                self.spec = ProblemSpec.from_cobaya_model(self.model)
+            except UnsupportedModel as e:
+                self._fail("mcmc_hip cannot sample this model: %s", str(e), cause=e)
+        self.engine = None
+        self.converged = bool(getattr(self, "converged", False))
+        if getattr(self, "Rminus1_last", None) is None:
+            self.Rminus1_last = np.inf
         spec = self.spec
         d = spec.d
         if self.temperature is None:
             self.temperature = 1
         if self.temperature < 1:
-            log.warning("Sampling temperatures <1 can lead to innacurate inference.")
+            self.log.warning("Sampling temperatures <1 can lead to innacurate inference.")
         self.temperature = float(self.temperature)
         self.set_proposer_blocking()
         # 'd' units: one cycle of the proposer, thinned (mcmc.py:400-410)
@@ -152,7 +183,7 @@ class MCMCHip:
         if self.callback_every is None:
             self.callback_every = self.learn_every
         if self.emit not in ("snapshots", "chains"):
-            raise LoggedError(log, "emit must be 'snapshots' or 'chains', got %r", self.emit)
+            self._fail("emit must be 'snapshots' or 'chains', got %r", self.emit)
         dist.init_from_env()
         self.rank, self.size = dist.rank(), dist.size()
         # seed: one key for the whole job; walkers are keyed by their global id
@@ -162,7 +193,7 @@ class MCMCHip:
                 seed[:] = 0
             self.seed = int(dist.all_reduce_sum(seed)[0])
         else:
-            log.warning("This run has been SEEDED with seed %s", self.seed)
+            self.log.warning("This run has been SEEDED with seed %s", self.seed)
         ss = np.random.SeedSequence(self.seed).spawn(self.size)[self.rank]  # sampler.py:378-384
         self._rng = np.random.default_rng(ss)
         W = int(self.n_walkers)
@@ -173,6 +204,12 @@ class MCMCHip:
                 if W >= 16384 and W % gs == 0:
                     self.group_size = gs
                     break
+        if W % int(self.group_size) or (W // int(self.group_size)) * self.size < 2:
+            # R-1 needs at least two chains (= walker groups) over all processes
+            # (mcmc.py:856-889; the reference splits a single chain instead, 796-813)
+            self._fail("n_walkers (%d) must be a multiple of group_size (%d) and give at least "
+                       "two groups over all processes: a group is one chain of the R-1 test",
+                       W, int(self.group_size))
         device = self.device if self.device is not None else dist.default_device()
         cap = 0
         if self.emit == "chains":
@@ -182,12 +219,13 @@ class MCMCHip:
                                                    (1 << 30) // row_bytes)))
             cap = self.steps_per_launch
         try:
-            self.engine = Engine(d, W, group_size=int(self.group_size), device=int(device),
+            self.engine = self._engine_factory(d, W, group_size=int(self.group_size), device=int(device),
                                  seed=self.seed, walker_offset=self.rank * W,
                                  burn_in=self.burn_in * self.output_thin,  # mcmc.py:265
                                  temperature=self.temperature,
                                  proposal_scale=float(self.proposal_scale),
-                                 max_tries=float(self.max_tries), emit_capacity=cap)
+                                 max_tries=float(self.max_tries), emit_capacity=cap,
+                                 shared_basis=bool(self.shared_basis))
             spec.configure(self.engine)
             if len(self.blocks) > 1 or self.oversampling_factors[0] != 1:
                 self.engine.set_blocking(
@@ -197,11 +235,11 @@ class MCMCHip:
                     self.drag_interp_steps if self.drag else 0)
                 assert self.engine.cycle_length() == self.cycle_length
         except EngineError as e:
-            raise LoggedError(log, "%s", str(e)) from e
+            self._fail("%s", str(e), cause=e)
         # initial proposal covariance (sampler.py:485-685), tempered (mcmc.py:438-440)
         self._initial_covmat, where_nan = self.initial_proposal_covmat()
         if np.any(where_nan) and self.learn_proposal:
-            log.info("Covariance matrix %s. We will start learning the covariance of the "
+            self.log.info("Covariance matrix %s. We will start learning the covariance of the "
                      "proposal earlier: R-1 = %g (would be %g if all params loaded).",
                      "not present" if np.all(where_nan) else "not complete",
                      self.learn_proposal_Rminus1_max_early, self.learn_proposal_Rminus1_max)
@@ -209,15 +247,15 @@ class MCMCHip:
         try:
             self.engine.set_proposal_cov(self._initial_covmat * self.temperature)
         except NotPositiveDefinite as e:
-            raise LoggedError(log, "%s", str(e)) from e
+            self._fail("%s", str(e), cause=e)
         self.output_every = _number_with_units(self.output_every, "s", 1)
         self._last_state_dump = 0.0
-        if self._resume and self.output and os.path.exists(self._state_file()):
+        if self._is_resuming() and self.output and os.path.exists(self._state_file()):
             self._init_bookkeeping()
             self._load_checkpoint()
             return
         # initial points (model.py:707-754 get_valid_point, one per walker)
-        log.info("Getting initial points... (%d walkers)", W)
+        self.log.info("Getting initial points... (%d walkers)", W)
         x0 = spec.sample_reference(W, self._rng)
         for _ in range(int(min(self.max_tries, 1000))):
             lp, ll = self.engine.evaluate(x0)
@@ -226,7 +264,7 @@ class MCMCHip:
                 break
             x0[bad] = spec.sample_reference(int(bad.sum()), self._rng)
         else:
-            raise LoggedError(log, "Could not find random point giving finite posterior after "
+            self._fail("Could not find random point giving finite posterior after "
                                    "%g tries", self.max_tries)
         self.engine.set_state(x0)
         shift = np.concatenate((x0.sum(0), [W]))
@@ -246,20 +284,20 @@ class MCMCHip:
                 blocks = [list(b) for b in blocks]
                 factors = [int(f) for f in factors]
             except (TypeError, ValueError) as e:
-                raise LoggedError(log, "Manual blocking not understood. Check "
-                                       "documentation.") from e
+                self._fail("Manual blocking not understood. Check "
+                                       "documentation.", cause=e)
             flat = [p for b in blocks for p in b]
             dup = sorted({p for p in flat if flat.count(p) > 1})
             if dup:
-                raise LoggedError(log, "Manual blocking: repeated parameters: %r", dup)
+                self._fail("Manual blocking: repeated parameters: %r", dup)
             missing = [p for p in spec.sampled if p not in flat]
             if missing:
-                raise LoggedError(log, "Manual blocking: missing parameters: %r", missing)
+                self._fail("Manual blocking: missing parameters: %r", missing)
             unknown = [p for p in flat if p not in spec.sampled]
             if unknown:
-                raise LoggedError(log, "Manual blocking: unknown parameters: %r", unknown)
+                self._fail("Manual blocking: unknown parameters: %r", unknown)
             if list(factors) != sorted(factors):
-                log.warning("Manual blocking: speed-blocking *apparently* non-optimal: "
+                self.log.warning("Manual blocking: speed-blocking *apparently* non-optimal: "
                             "oversampling factors must go from small (slow) to large (fast).")
         else:
             try:
@@ -267,16 +305,16 @@ class MCMCHip:
                     oversample_power=float(self.oversample_power or 0),
                     split_fast_slow=bool(self.drag))
             except UnsupportedModel as e:
-                raise LoggedError(log, "%s", str(e)) from e
+                self._fail("%s", str(e), cause=e)
         self.blocks, self.oversampling_factors = blocks, list(factors)
         self.drag = bool(self.drag)
         if self.drag:  # mcmc.py:333-360
             if len(blocks) == 1:
                 self.drag = False
-                log.warning("Dragging disabled: not possible if there is only one block.")
+                self.log.warning("Dragging disabled: not possible if there is only one block.")
             elif max(factors) / min(factors) < 2:
                 self.drag = False
-                log.warning("Dragging disabled: speed ratios < 2.")
+                self.log.warning("Dragging disabled: speed ratios < 2.")
         self.drag_interp_steps = 0
         if self.drag:
             n_slow = sum(len(b) for b in blocks[:1 + self.i_last_slow_block])
@@ -285,17 +323,17 @@ class MCMCHip:
                 factors[self.i_last_slow_block + 1] * n_fast / n_slow))
             if self.drag_interp_steps < 2:
                 self.drag = False
-                log.warning("Dragging disabled: speed ratio and fast-to-slow ratio not large "
+                self.log.warning("Dragging disabled: speed ratio and fast-to-slow ratio not large "
                             "enough.")
         self.output_thin = 1
         if self.drag:
-            log.info("Dragging with number of interpolating steps: %d", self.drag_interp_steps)
+            self.log.info("Dragging with number of interpolating steps: %d", self.drag_interp_steps)
             self.cycle_length = sum(len(b) for b in blocks[:1 + self.i_last_slow_block])
             if self.emit == "chains":
-                raise LoggedError(log, "emit: chains is not available with dragging")
+                self._fail("emit: chains is not available with dragging")
         else:
             if any(f > 1 for f in factors):
-                log.info("Oversampling with factors: %r", list(zip(factors, blocks)))
+                self.log.info("Oversampling with factors: %r", list(zip(factors, blocks)))
                 if self.oversample_thin:  # mcmc.py:377-389
                     self.output_thin = int(np.round(
                         sum(len(b) * o for b, o in zip(blocks, factors)) / spec.d))
@@ -310,12 +348,16 @@ class MCMCHip:
 
     def _init_bookkeeping(self):
         spec = self.spec
-        self.collection = SampleCollection(spec.sampled, spec.derived, self._like_names(),
-                                           self.temperature, name=str(1 + self.rank))
+        self.collection = self._export_collection(
+            SampleCollection(spec.sampled, spec.derived, self._like_names(),
+                             self.temperature, name=str(1 + self.rank)))
         self._thin_carry = {}    # chains mode with thinned output: added weight per walker
         self._snap_stride, self._snap_count, self._rows_capped = 1, 0, False
         self._rows = []          # (walker, weight, logpost, logprior, loglike, x...) blocks
         self._n_rows = 0
+        self._pending = []       # stored blocks not yet appended to the chain file
+        self._txt_rows = 0       # data rows of this process' chain file
+        self._carried = None     # table rows of earlier legs, read back at resume
         self._intervals = []     # per checkpoint: (n_snapshots, group_sum[G,d], pooled_S[d,d])
         self._dropped_snapshots = 0
         self._progress_rows = {}  # i_learn -> row dict (DataFrame built on demand: `progress`)
@@ -340,40 +382,40 @@ class MCMCHip:
         covmat, covmat_params = self.covmat, self.covmat_params
         if isinstance(covmat, str):
             if covmat.lower() == "auto":
-                raise LoggedError(log, "covmat: auto (cosmology database) is not available in "
+                self._fail("covmat: auto (cosmology database) is not available in "
                                        "mcmc_hip")
             try:
                 with open(covmat, encoding="utf-8-sig") as f:
                     header = f.readline()
                 loaded = np.atleast_2d(np.loadtxt(covmat))
             except OSError as e:
-                raise LoggedError(log, "Can't open covmat file '%s'.", covmat) from e
+                self._fail("Can't open covmat file '%s'.", covmat, cause=e)
             if header[0] != "#":
-                raise LoggedError(log, "The first line of the covmat file '%s' must be one "
+                self._fail("The first line of the covmat file '%s' must be one "
                                        "list of parameter names separated by spaces and "
                                        "staring with '#'", covmat)
             covmat_params = header.strip("#").strip().split()
             covmat = loaded
         if covmat is not None:
             if not covmat_params:
-                raise LoggedError(log, "If a covariance matrix is passed as a numpy array, you "
+                self._fail("If a covariance matrix is passed as a numpy array, you "
                                        "also need to pass the parameters it corresponds to via "
                                        "'covmat_params: [name1, name2, ...]'.")
             covmat = np.atleast_2d(np.array(covmat, dtype=float))
             covmat_params = list(covmat_params)
             if len(covmat_params) != len(set(covmat_params)):
-                raise LoggedError(log, "Parameter(s) appear more than once in `covmat_params`")
+                self._fail("Parameter(s) appear more than once in `covmat_params`")
             if covmat.shape != (len(covmat_params),) * 2:
-                raise LoggedError(log, "The number of parameters in `covmat_params` and the "
+                self._fail("The number of parameters in `covmat_params` and the "
                                        "dimensions of the matrix do not agree: %d vs %r",
                                   len(covmat_params), covmat.shape)
             if not np.allclose(covmat.T, covmat):
-                raise LoggedError(log, "The covariance matrix passed is not a symmetric square "
+                self._fail("The covariance matrix passed is not a symmetric square "
                                        "matrix.")
             idx_l = [j for j, p in enumerate(covmat_params) if p in names]
             idx_s = [names.index(covmat_params[j]) for j in idx_l]
             if not idx_s:
-                raise LoggedError(log, "A proposal covariance matrix has been loaded, but none "
+                self._fail("A proposal covariance matrix has been loaded, but none "
                                        "of its parameters are actually sampled here.")
             cov[np.ix_(idx_s, idx_s)] = covmat[np.ix_(idx_l, idx_l)]
         where_nan = np.isnan(cov.diagonal())
@@ -410,9 +452,19 @@ class MCMCHip:
 
     def run(self):
         """mcmc.py:451-528."""
-        log.info("Sampling!%s", (" (NB: no accepted step will be saved until %d burn-in "
-                                 "samples have been obtained)" % self.burn_in)
-                 if self.burn_in else "")
+        if self.converged:
+            # a resumed run whose checkpoint says "converged" under unchanged stop criteria
+            # (sampler.py:339-351, mcmc.py:1080-1088): nothing to do, nothing is rewritten
+            self.log.info("The run was already converged: nothing to do (change Rminus1_stop, "
+                          "Rminus1_cl_stop, Rminus1_cl_level or max_samples to continue).")
+            return
+        if self._accepted_total >= self.max_samples:
+            self.log.info("The maximum number of accepted steps (%s) was already reached: "
+                          "nothing to do.", self.max_samples)
+            return
+        self.log.info("Sampling!%s", (" (NB: no accepted step will be saved until %d burn-in "
+                                      "samples have been obtained)" % self.burn_in)
+                      if self.burn_in else "")
         if self._next_ckpt is None:
             self._next_ckpt = self._checkpoint_steps()
         snap_every = (int(self.snapshot_every) if self.snapshot_every
@@ -435,62 +487,73 @@ class MCMCHip:
                     if self.emit == "snapshots" and not snap_every:
                         self._snapshot()
                     if self.callback_function:
-                        self.callback_function(self)
+                        self._callback()(self)
                     self._next_ckpt = self.n_steps_raw + self._checkpoint_steps()
                     if self.output:
                         self.write_checkpoint()
             self.engine.sync()
             self._update_counters()
         except ChainStuck as e:
-            raise LoggedError(log, "%s Make sure the reference point is sensible and initial "
-                                   "covmat. (see `max_tries`)", str(e)) from e
+            self._fail("%s Make sure the reference point is sensible and initial "
+                       "covmat. (see `max_tries`)", str(e), cause=e)
         if self._accepted_total >= self.max_samples:
-            log.info("Reached maximum number of accepted steps allowed (%s). Stopping.",
-                     self.max_samples)
-        log.info("Sampling complete after %d accepted steps.", self._accepted_total)
+            self.log.info("Reached maximum number of accepted steps allowed (%s). Stopping.",
+                          self.max_samples)
+        self.log.info("Sampling complete after %d accepted steps.", self._accepted_total)
         if self.output:
-            self._write_output()
             self.write_checkpoint(force_state=True)
+
+    def _callback(self):
+        """mcmc.py:160-163: a callable, or a string resolved like Cobaya's external functions
+        (a lambda / `import_module('m').f` expression)."""
+        fn = self.callback_function
+        if callable(fn):
+            return fn
+        import importlib
+        return eval(fn, {"np": np, "import_module": importlib.import_module})  # noqa: S307
 
     # ------------------------------------------------------------------ checkpoint / resume
     def _state_file(self):
-        return f"{self.output}.{1 + self.rank}.state.npz"
+        return self._chain_file("state.npz")
+
+    # the options whose change re-opens a converged run (mcmc.py:1080-1088)
+    CONVERGE_OPTIONS = ("Rminus1_stop", "Rminus1_cl_stop", "Rminus1_cl_level", "max_samples")
 
     def write_checkpoint(self, force_state=False):
         """mcmc.py:1045-1078: `prefix.checkpoint` (yaml), `prefix.covmat`, `prefix.progress` on
-        the root; plus, per process and at most every `output_every` seconds, the complete
-        ensemble state `prefix.<rank+1>.state.npz` (walkers, counters, Philox step counter,
-        moment window) from which `resume` continues bit-identically -- the reference can
-        only restart from its last stored row and does not save its RNG state
-        (sampler.py:373)."""
+        the root; plus, per process and at most every `output_every` seconds (mcmc.py:473-481,
+        697-699), the rows stored since the last dump appended to `prefix.<rank+1>.txt` and
+        then the complete ensemble state `prefix.<rank+1>.state.npz` (walkers, counters,
+        Philox step counter, moment window, number of rows in the text file) from which
+        `resume` continues bit-identically -- the reference can only restart from its last
+        stored row and does not save its RNG state (sampler.py:373)."""
         import time
 
         import yaml
-        prefix = str(self.output)
-        folder = os.path.dirname(prefix)
-        if folder:
-            os.makedirs(folder, exist_ok=True)
+        if not self.output:
+            return
+        os.makedirs(self._out_parts()[0], exist_ok=True)
         if self.rank == 0:
-            np.savetxt(prefix + ".covmat",
+            np.savetxt(self._out_file(".covmat"),
                        self.engine.get_proposal_cov() / self.temperature,  # mcmc.py:1049-1051
                        header=" ".join(self.spec.sampled))
             ck = {"sampler": {self.get_name(): {
                 "converged": bool(self.converged), "Rminus1_last": float(self.Rminus1_last),
-                "burn_in": 0, "mpi_size": int(self.size), "n_walkers": int(self.n_walkers),
-                "group_size": int(self.group_size), "seed": int(self.seed),
-                "n_steps_raw": int(self.n_steps_raw)}}}
-            with open(prefix + ".checkpoint", "w", encoding="utf-8") as f:
+                "burn_in": 0, "mpi_size": int(self.size)}}}
+            with open(self._out_file(".checkpoint"), "w", encoding="utf-8") as f:
                 yaml.safe_dump(ck, f)
-            with open(prefix + ".progress", "w", encoding="utf-8") as f:
+            with open(self._out_file(".progress"), "w", encoding="utf-8") as f:
                 f.write("# " + " ".join(f"{c:>15}" for c in self.progress.columns) + "\n")
                 if len(self.progress):
                     f.write(self.progress.to_string(header=False, index=False) + "\n")
         now = time.time()
         if force_state or now - self._last_state_dump >= float(self.output_every):
             self._last_state_dump = now
+            self._flush_rows()
             st = self.engine.get_full_state()
             ivs = self._intervals
-            np.savez(self._state_file(), **st,
+            tmp = self._state_file() + ".tmp.npz"
+            np.savez(tmp, **st,
                      proposal_cov=self.engine.get_proposal_cov(), shift=self._shift,
                      iv_n=np.array([iv[0] for iv in ivs], dtype=np.int64),
                      iv_gs=np.array([iv[1] for iv in ivs]), iv_S=np.array([iv[2] for iv in ivs]),
@@ -498,22 +561,25 @@ class MCMCHip:
                                     self._steps_last, self._launches, self._dropped_snapshots,
                                     self._accepted_total, self.seed, self.size,
                                     int(self.n_walkers), int(self._next_ckpt or 0),
-                                    self._snap_stride, self._snap_count],
+                                    self._snap_stride, self._snap_count, self._txt_rows],
                                    dtype=np.int64),
                      fbook=np.array([self._acc_rate, self.Rminus1_last, float(self.converged),
-                                     self.learn_proposal_Rminus1_max]),
+                                     self.learn_proposal_Rminus1_max]
+                                    + [float(getattr(self, k)) for k in self.CONVERGE_OPTIONS]),
                      progress=self.progress.to_numpy(dtype=object).astype(str))
+            os.replace(tmp, self._state_file())   # never leave a half-written state behind
 
     def _load_checkpoint(self):
         """Resume (sampler.py:291-310, mcmc.py:131-139, 189-214): same number of processes and
         walkers required; seed, proposal covariance, walkers, counters and the R-1 window come
-        back from the state file."""
+        back from the state file, the rows of the earlier legs from the chain file (cut back
+        to the number of rows the state file vouches for)."""
         z = np.load(self._state_file(), allow_pickle=False)
         book, fbook = z["book"], z["fbook"]
         if int(book[8]) != self.size or int(book[9]) != int(self.n_walkers):
-            raise LoggedError(log, "Cannot resume a run with a different number of chains: was "
-                                   "%d processes x %d walkers and now is %d x %d.",
-                              int(book[8]), int(book[9]), self.size, int(self.n_walkers))
+            self._fail("Cannot resume a run with a different number of chains: was "
+                       "%d processes x %d walkers and now is %d x %d.",
+                       int(book[8]), int(book[9]), self.size, int(self.n_walkers))
         self.engine.set_proposal_cov(z["proposal_cov"])
         self.engine.set_full_state({k: z[k] for k in ("x", "logpost", "logprior", "loglike",
                                                       "weight", "prior_rej", "burn_left",
@@ -526,16 +592,47 @@ class MCMCHip:
         self._next_ckpt = int(book[10]) or None
         if len(book) > 12:
             self._snap_stride, self._snap_count = int(book[11]), int(book[12])
+        txt_rows = int(book[13]) if len(book) > 13 else 0
         if int(book[7]) != int(self.seed):
-            log.warning("Resuming with the seed of the checkpoint (%d), not %d", int(book[7]),
-                        int(self.seed))
+            self.log.warning("Resuming with the seed of the checkpoint (%d), not %d",
+                             int(book[7]), int(self.seed))
+            self.seed = int(book[7])
         self._acc_rate, self.Rminus1_last = float(fbook[0]), float(fbook[1])
-        self.converged = bool(fbook[2])
+        was_converged = bool(fbook[2])
         self.learn_proposal_Rminus1_max = float(fbook[3])
+        old_stop = [float(v) for v in fbook[4:4 + len(self.CONVERGE_OPTIONS)]]
+        new_stop = [float(getattr(self, k)) for k in self.CONVERGE_OPTIONS]
+        self.converged = was_converged and old_stop == new_stop
+        if was_converged and not self.converged:
+            self.log.info("The convergence criteria changed since the checkpoint: the run is "
+                          "continued.")
         for i, prow in enumerate(z["progress"], start=1):
             self._progress_rows[i] = {c: (v if c == "timestamp" else float(v))
                                       for c, v in zip(self.PROGRESS_COLUMNS, prow)}
-        log.info("Resumed from %s at %d steps per walker.", self._state_file(), self.n_steps_raw)
+        self._load_chain_file(txt_rows)
+        self.log.info("Resumed from %s at %d steps per walker (%d stored rows).",
+                      self._state_file(), self.n_steps_raw, self._txt_rows)
+
+    def _load_chain_file(self, n_rows):
+        """The first `n_rows` rows of this process' chain file become the head of the
+        collection; anything after them (written after the last state dump) is cut off."""
+        path = self._chain_file()
+        self._txt_rows, self._carried = 0, None
+        if not n_rows or not os.path.exists(path):
+            if os.path.exists(path):
+                os.remove(path)
+            return
+        with open(path, encoding="utf-8") as f:
+            lines = f.readlines()
+        header, data = lines[:1], lines[1:]
+        if len(data) < n_rows:
+            self._fail("The chain file %s holds %d rows but the checkpoint expects %d: "
+                       "cannot resume.", path, len(data), n_rows)
+        if len(data) > n_rows:
+            with open(path, "w", encoding="utf-8") as f:
+                f.writelines(header + data[:n_rows])
+        self._carried = np.loadtxt(path, ndmin=2)
+        self._txt_rows = n_rows
 
     # ------------------------------------------------------------------ storage
     def _like_names(self):
@@ -583,11 +680,13 @@ class MCMCHip:
             self._n_rows = sum(len(r) for r in self._rows)
             if not self._rows_capped:
                 self._rows_capped = True
-                log.info("max_rows (%d) reached: older stored samples are thinned out as the "
+                self.log.info("max_rows (%d) reached: older stored samples are thinned out as the "
                          "run goes on.", self.max_rows)
         if self._n_rows + len(rows) <= self.max_rows or not self._rows:
             self._rows.append(rows)
             self._n_rows += len(rows)
+            if self.output:   # the chain file receives every stored row, also those that the
+                self._pending.append(rows)  # in-memory store thins out later
 
     def _snapshot(self):
         """Thinned sample emission: the current point of every walker with weight 1 (the
@@ -658,46 +757,53 @@ class MCMCHip:
                "acceptance_rate": float(acceptance_rate), "Rminus1": np.nan,
                "Rminus1_cl": np.nan}
         self._progress_rows[self.i_learn] = row
-        log.info("Learn + convergence test @ %d samples accepted.", self._accepted_total)
-        log.info(" - Acceptance rate: %.3f", acceptance_rate)
+        self.log.info("Learn + convergence test @ %d samples accepted.", self._accepted_total)
+        self.log.info(" - Acceptance rate: %.3f", acceptance_rate)
         try:
             Rminus1, mean_of_covs = gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm)
         except NotPositiveDefinite:
-            log.warning("Negative covariance eigenvectors. This may mean that the covariance of "
+            self.log.warning("Negative covariance eigenvectors. This may mean that the covariance of "
                         "the samples does not contain enough information at this point. "
                         "Skipping learning a new covmat for now.")
             return
+        # A chain of the statistic is a GROUP of `gsz` walkers: the variance of its mean is
+        # 1/gsz of a single walker's.  Expressed per walker (x gsz), R-1 keeps the reference's
+        # meaning -- roughly one over the number of independent samples EACH chain has drawn
+        # -- so `Rminus1_stop`, `learn_proposal_Rminus1_max` ... mean what they mean in
+        # mcmc.yaml, and a transient shared by all groups (they start from one ref pdf)
+        # cannot pass for convergence just because group means average it out.
+        Rminus1 = float(Rminus1) * gsz
         row["Rminus1"] = float(Rminus1)
-        log.info(" - Convergence of means: R-1 = %f after %d accepted steps", Rminus1,
-                 self._accepted_total)
+        self.log.info(" - Convergence of means: R-1 = %f after %d accepted steps", Rminus1,
+                      self._accepted_total)
         # means criterion twice in a row (mcmc.py:908), then the bounds criterion (918-1002)
         if max(Rminus1, self.Rminus1_last) < self.Rminus1_stop:
             Rcl = self._rminus1_of_bounds(mean_of_covs)
             if Rcl is None:
-                log.info("Computation of the bounds was not possible (no stored samples): "
+                self.log.info("Computation of the bounds was not possible (no stored samples): "
                          "convergence judged on the means only.")
                 self.converged = True
             else:
                 row["Rminus1_cl"] = float(Rcl)
-                log.info(" - Convergence of bounds: R-1 = %f after %d accepted steps", Rcl,
+                self.log.info(" - Convergence of bounds: R-1 = %f after %d accepted steps", Rcl,
                          self._accepted_total)
                 self.converged = Rcl < self.Rminus1_cl_stop
             if self.converged:
-                log.info("The run has converged!")
+                self.log.info("The run has converged!")
         self.Rminus1_last = Rminus1
         if self.learn_proposal and not self.converged:
             if Rminus1 > self.learn_proposal_Rminus1_max:
-                log.info("Convergence less than requested for updates: waiting until the next "
+                self.log.info("Convergence less than requested for updates: waiting until the next "
                          "convergence check.")
             elif Rminus1 < self.learn_proposal_Rminus1_min:
-                log.info("Convergence better than `learn_proposal_Rminus1_min`: covmat will "
+                self.log.info("Convergence better than `learn_proposal_Rminus1_min`: covmat will "
                          "not be updated.")
             else:
                 try:
                     eng.set_proposal_cov(mean_of_covs)  # is already tempered (mcmc.py:1023)
-                    log.info(" - Updated covariance matrix of proposal pdf.")
+                    self.log.info(" - Updated covariance matrix of proposal pdf.")
                 except NotPositiveDefinite:
-                    log.debug("Updating covariance matrix failed unexpectedly. waiting until "
+                    self.log.debug("Updating covariance matrix failed unexpectedly. waiting until "
                               "next covmat learning attempt.")
 
     def _rminus1_of_bounds(self, mean_of_covs, min_per_chain=40):
@@ -746,13 +852,17 @@ class MCMCHip:
         var_lo = np.maximum(stats[1 + 2 * d:1 + 3 * d] / m - mean_lo ** 2, 0.0)  # np.std: ddof 0
         var_hi = np.maximum(stats[1 + 3 * d:] / m - mean_hi ** 2, 0.0)
         sig = np.sqrt(np.diag(mean_of_covs))
+        # NOT rescaled per walker (unlike R-1 of the means, which certifies the mixing): this
+        # one is a precision test of the stored sample's tails, and the unit whose bounds must
+        # agree is the group -- the stored sample cannot hold hundreds of snapshots of 65 536
+        # walkers just to resolve single-walker tails
         return float(max(np.max(np.sqrt(var_lo) / sig), np.max(np.sqrt(var_hi) / sig)))
 
     # ------------------------------------------------------------------ products
-    def _build_collection(self):
+    def _table_collection(self, rows):
+        """(walker, weight, logpost, logprior, loglike, x...) rows -> SampleCollection with
+        the derived parameters (device) and the per-likelihood chi2 columns (host) filled."""
         spec = self.spec
-        d = spec.d
-        rows = (np.vstack(self._rows) if self._rows else np.zeros((0, d + 5)))
         if self.emit == "chains" and len(rows):
             rows = rows[np.argsort(rows[:, 0], kind="stable")]  # chain after chain
         coll = SampleCollection(spec.sampled, spec.derived, self._like_names(), self.temperature,
@@ -765,24 +875,47 @@ class MCMCHip:
             parts = (spec.component_loglikes(rows[:, 5:]) if len(spec.components) > 1 else None)
             coll.add_rows(rows[:, 1], rows[:, 2], rows[:, 5:], rows[:, 3], rows[:, 4], derived,
                           parts)
-        self._chain_ids = rows[:, 0].astype(np.int64) if len(rows) else np.zeros(0, np.int64)
+        coll.chain_ids = rows[:, 0].astype(np.int64) if len(rows) else np.zeros(0, np.int64)
+        return coll
+
+    def _build_collection(self):
+        """All rows this process holds: those of earlier legs (read back from the chain file
+        at resume) followed by the ones stored in memory."""
+        d = self.spec.d
+        coll = self._table_collection(np.vstack(self._rows) if self._rows
+                                      else np.zeros((0, d + 5)))
+        self._chain_ids = coll.chain_ids
+        if self._carried is not None and len(self._carried):
+            coll._blocks.insert(0, self._carried)
+            coll._data = None
+            self._chain_ids = np.concatenate((np.full(len(self._carried), -1, np.int64),
+                                              coll.chain_ids))
         return coll
 
     def samples(self, combined=False, skip_samples=0, to_getdist=False):
-        """mcmc.py:1092-1148 (no GetDist export here)."""
-        if to_getdist:
-            raise LoggedError(log, "GetDist export is not available in mcmc_hip; write the "
-                                   "chain with `output` and load it with GetDist instead")
+        """mcmc.py:1092-1148.  `to_getdist` needs the Cobaya-hosted class (it goes through
+        `cobaya.collection.SampleCollection.to_getdist`)."""
+        if self.temperature != 1 and not to_getdist:
+            self.log.warning("The MCMC chain(s) are stored with temperature != 1. Keep that in "
+                             "mind when operating on them, or detemper (in-place) with "
+                             "products()['sample'].reset_temperature()'.")
         coll = self._build_collection()
         if skip_samples:
             n0 = int(skip_samples * len(coll)) if skip_samples < 1 else int(skip_samples)
             arr = coll.data.to_numpy()[n0:]
             coll._blocks, coll._data = [arr], None
-        if combined and self.size > 1:
+        if (combined or to_getdist) and self.size > 1:
             blocks = dist.gather_rows(coll.data.to_numpy())
             if self.rank == 0:
                 coll._blocks, coll._data = [np.vstack(blocks)], None
-        return coll
+        out = self._export_collection(coll)
+        if to_getdist:
+            if not hasattr(out, "to_getdist"):
+                self._fail("GetDist export needs Cobaya and GetDist (use `sampler: mcmc_hip` "
+                           "inside cobaya.run); or write the chain with `output` and load it "
+                           "with GetDist")
+            return out.to_getdist()
+        return out
 
     def products(self, combined=False, skip_samples=0, to_getdist=False):
         """mcmc.py:1150-1184: {"sample": SampleCollection, "progress": DataFrame}."""
@@ -809,27 +942,123 @@ class MCMCHip:
         return self.engine.get_state()
 
     def info(self):
-        out = {k: getattr(self, k) for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}
-        # mcmc.py:391: the blocking actually used, so that a resumed run repeats it
-        out["blocking"] = [[int(o), list(b)] for o, b in zip(self.oversampling_factors, self.blocks)]
+        """sampler.py:324-330: the options the sampler was set up with, plus what is only
+        known after initialisation (mcmc.py:391: the blocking actually used, so that a
+        resumed run repeats it)."""
+        if hasattr(self, "_updated_info"):      # Cobaya-hosted: Sampler.info()
+            out = copy.deepcopy({k: v for k, v in self._updated_info.items()
+                                 if not callable(v)})
+            out.update({k: v for k, v in self._updated_info.items() if callable(v)})
+        else:
+            out = {k: getattr(self, k) for k in {**MCMC_DEFAULTS, **HIP_DEFAULTS}}
+        if hasattr(self, "blocks"):
+            out["blocking"] = [[int(o), list(b)]
+                               for o, b in zip(self.oversampling_factors, self.blocks)]
         return out
 
     # ------------------------------------------------------------------ output (SURVEY 8f-2)
-    def _write_output(self):
-        prefix = str(self.output)
-        folder = os.path.dirname(prefix)
-        if folder:
-            os.makedirs(folder, exist_ok=True)
-        coll = self._build_collection()
-        path = f"{prefix}.{1 + self.rank}.txt"
-        if self._resume and os.path.exists(path) and len(coll):
-            with open(path, "a", encoding="utf-8") as out:  # rows of the resumed leg
+    def _flush_rows(self):
+        """collection.py:1268-1315 `out_update`: append the rows stored since the last flush
+        to `prefix.<rank+1>.txt` (header first when the file is new).  An existing file is
+        only ever appended to; a fresh run starts by removing a stale one."""
+        if not self.output:
+            return
+        path = self._chain_file()
+        if self._txt_rows == 0 and os.path.exists(path):
+            os.remove(path)
+        blocks, self._pending = self._pending, []
+        if not blocks:
+            if self._txt_rows == 0:
+                self._table_collection(np.zeros((0, self.spec.d + 5))).to_txt(path)
+            return
+        coll = self._table_collection(np.vstack(blocks))
+        if self._txt_rows == 0:
+            coll.to_txt(path)
+        else:
+            with open(path, "a", encoding="utf-8") as out:
                 np.savetxt(out, coll.data.to_numpy(dtype=np.float64),
                            fmt=[f"%{max(15, len(c))}.8g" for c in coll.columns])
-        else:
-            coll.to_txt(path)
+        self._txt_rows += len(coll)
 
     def close(self):
         if self.engine is not None:
             self.engine.close()
             self.engine = None
+
+
+class MCMCHip(EnsembleMCMC):
+    """Standalone host (no Cobaya needed): the constructor of `Sampler.__init__`
+    (sampler.py:257-264) plus `resume` / `force`, which Cobaya keeps in its `Output` object
+    (output.py:447-495, sampler.py:417-458 `check_force_resume`)."""
+
+    log = log
+    _output = _model = spec = None
+    _resume = False
+    _name = "mcmc_hip"
+
+    def __init__(self, info_sampler=None, model=None, output=None, packages_path=None,
+                 name=None, resume=False, force=False):
+        info_sampler = dict(info_sampler or {})
+        known = {**MCMC_DEFAULTS, **HIP_DEFAULTS}
+        unknown = set(info_sampler) - set(known)
+        if unknown:  # input.py:403-435: unknown options are rejected
+            self._fail("mcmc_hip does not recognise the option(s) %s. Valid options: %s",
+                       sorted(unknown), sorted(known))
+        for k, v in known.items():
+            setattr(self, k, copy.deepcopy(info_sampler.get(k, v)))
+        self._name = name or "mcmc_hip"
+        self._output = output or None
+        self._resume = bool(resume)
+        self.packages_path = packages_path
+        if resume and force and output:
+            self._fail("Make 'resume: True' or 'force: True', not both at the same time: "
+                       "can't simultaneously overwrite a chain and resume from it.")
+        if isinstance(model, ProblemSpec):
+            self.spec, self._model = model, None
+        elif model is not None:  # a live cobaya.model.Model: read in initialize()
+            self.spec, self._model = None, model
+        else:
+            self._fail("mcmc_hip needs a model")
+        self.converged = False
+        self.Rminus1_last = np.inf
+        self._check_force_resume(bool(force))
+        self.initialize()
+
+    @property
+    def model(self):
+        return self._model
+
+    @property
+    def output(self):
+        return self._output
+
+    def get_name(self):
+        return self._name
+
+    def _old_files(self):
+        """Files of an earlier run with this prefix (mcmc.py:1186-1198 output_files_regexps,
+        plus the per-process ensemble state)."""
+        folder, prefix = self._out_parts()
+        if not os.path.isdir(folder):
+            return [], []
+        head = re.escape(prefix) + (r"[\._]" if prefix else "")
+        chain = re.compile(head + r"\d+\.txt$")
+        rest = re.compile(head + r"(checkpoint|progress|covmat|\d+\.state\.npz)$")
+        names = sorted(os.listdir(folder))
+        return ([os.path.join(folder, n) for n in names if chain.match(n)],
+                [os.path.join(folder, n) for n in names if rest.match(n)])
+
+    def _check_force_resume(self, force):
+        """sampler.py:417-458: old chains are an error unless `force` (delete them) or
+        `resume` (continue them); `resume` without old chains starts anew."""
+        if not self._output:
+            return
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+        chains, rest = self._old_files()
+        if force or (self._resume and not chains):
+            for f in chains + rest:
+                os.remove(f)
+        elif chains and not self._resume:
+            self._fail("Delete the previous output manually, automatically ('-f', '--force', "
+                       "'force: True') or request resuming ('-r', '--resume', 'resume: True')")

@@ -5,28 +5,39 @@ the component on `sys.path` and takes the class returned by its module-level
 `get_cobaya_class()` (component.py:677-678) or the class whose name matches case-insensitively
 with underscores dropped (component.py:798-807: `mcmc_hip` <-> `MCMCHip`).
 
-With Cobaya importable, the class below derives from `cobaya.samplers.mcmc.MCMC`, so it
-inherits every default of mcmc.yaml through `HasDefaults.get_defaults` (component.py:321-326)
-and only declares the new options as typed class attributes (unknown keys are rejected,
-input.py:403-435).  Without Cobaya it is the standalone `cobaya_amd.MCMCHip`.
+With Cobaya importable, the class below is `EnsembleMCMC` (all of the engine-backed logic,
+`cobaya_amd/sampler.py`) in front of `cobaya.samplers.mcmc.MCMC` in the MRO: Cobaya's own
+`Sampler.__init__` (sampler.py:257-322) sets the options, the model and the `Output` object,
+loads the checkpoint info when resuming and calls `initialize()`; every life-cycle method
+(`initialize`, `run`, `products`, `samples`, `write_checkpoint`, `info`, ...) then resolves to
+the ensemble implementation, while the class-level plumbing -- defaults of mcmc.yaml through
+`HasDefaults.get_defaults` (component.py:321-326), `check_force_resume` (sampler.py:417-458),
+`_at_resume_prefer_new/old`, `get_version`, `_get_desc` -- stays Cobaya's.  Unknown option
+keys are rejected by Cobaya (input.py:403-435), hence the typed class attributes for the new
+options.  Without Cobaya the module exports the standalone `cobaya_amd.MCMCHip`.
 """
-from cobaya_amd.sampler import HIP_DEFAULTS
+import re
+
+from cobaya_amd.sampler import HIP_DEFAULTS, EnsembleMCMC
 from cobaya_amd.sampler import MCMCHip as _Standalone
 
-try:  # pragma: no cover - exercised only where Cobaya is installed
+try:
     from cobaya.samplers.mcmc import MCMC as _CobayaMCMC
-except Exception:  # Cobaya absent (e.g. on the GPU box of this build): standalone class
+except ImportError:  # Cobaya absent (e.g. on the GPU box of this build): standalone class
     _CobayaMCMC = None
 
 if _CobayaMCMC is None:
     MCMCHip = _Standalone
 else:
-    class MCMCHip(_CobayaMCMC):  # type: ignore[misc, valid-type]
-        """Cobaya-hosted variant: Cobaya's `Sampler.__init__` (sampler.py:257-322) sets the
-        options as attributes, seeds `_rng`, and calls `initialize()`; everything from there on
-        is the engine-backed implementation."""
+    import pandas as _pd
+    from cobaya.collection import SampleCollection as _CobayaCollection
+    from cobaya.log import LoggedError as _CobayaLoggedError
+
+    class MCMCHip(EnsembleMCMC, _CobayaMCMC):  # type: ignore[misc, valid-type]
+        """`sampler: mcmc_hip` inside a real Cobaya."""
 
         file_base_name = "mcmc_hip"
+        _LoggedError = _CobayaLoggedError
         n_walkers: int = HIP_DEFAULTS["n_walkers"]
         group_size: int | None = HIP_DEFAULTS["group_size"]
         device: int | None = HIP_DEFAULTS["device"]
@@ -35,30 +46,32 @@ else:
         emit: str = HIP_DEFAULTS["emit"]
         snapshot_every: int | None = HIP_DEFAULTS["snapshot_every"]
         max_rows: int = HIP_DEFAULTS["max_rows"]
+        shared_basis: bool = HIP_DEFAULTS["shared_basis"]
 
-        def initialize(self):
-            from cobaya_amd.model import ProblemSpec, UnsupportedModel
-            from cobaya.log import LoggedError
-            try:
-                self.spec = ProblemSpec.from_cobaya_model(self.model)
-            except UnsupportedModel as e:
-                raise LoggedError(self.log, "mcmc_hip cannot sample this model: %s", str(e))
-            self._name = self.get_name()
-            self.converged = False
-            self.Rminus1_last = float("inf")
-            self.engine = None
-            _Standalone.initialize(self)
+        def _export_collection(self, coll):
+            """Our table -> `cobaya.collection.SampleCollection` (same columns,
+            collection.py:154-161), so that `products()["sample"]` offers the whole reference
+            API (`mean`, `cov`, `to_getdist`, slicing, ...).  It is detached from the output
+            driver: the chain file is written by `_flush_rows`."""
+            out = _CobayaCollection(self.model, None, name=str(1 + self.rank),
+                                    temperature=self.temperature, sample_type="mcmc")
+            if list(out.columns) != list(coll.columns):
+                self._fail("column contract broken: Cobaya expects %r, mcmc_hip has %r",
+                           list(out.columns), list(coll.columns))
+            if not len(coll):
+                return out
+            data = _pd.DataFrame(coll.data.to_numpy(dtype=float), columns=out.columns)
+            return out._copy(data=data)
 
-        _resume = False
-
-    # engine-backed implementation: every method/property of the standalone class that the
-    # Cobaya base does not have to keep (life-cycle hooks above excepted) is shared verbatim
-    for _name, _attr in vars(_Standalone).items():
-        if _name.startswith("__") or _name in ("initialize", "file_base_name", "info",
-                                                "get_name"):
-            continue
-        setattr(MCMCHip, _name, _attr)
-    del _name, _attr
+        @classmethod
+        def output_files_regexps(cls, output, info=None, minimal=False):
+            """mcmc.py:1186-1198 plus the per-process ensemble state files, so that `force`
+            cleans them and a stale state never survives a fresh start."""
+            regexps = _CobayaMCMC.output_files_regexps(output, info=info, minimal=minimal)
+            if not minimal:
+                regexps.append((re.compile(output.prefix_regexp_str + r"\d+\.state\.npz$"),
+                                None))
+            return regexps
 
 
 def get_cobaya_class():

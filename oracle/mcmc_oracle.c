@@ -570,7 +570,14 @@ static inline void walker_variates(uint32_t k0, uint32_t k1, uint32_t gid, uint6
         philox4x32_10(k0, k1, gid, c1 | 0x100u, (uint32_t)step, (uint32_t)(step >> 32), w2);
         *Ea_out = -orc_dlog(u52(((uint64_t)w2[0] << 20) | (w2[1] >> 12)));
     } else {
-        *r_out = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er);
+        /* every walker takes its OWN sign (bit 7 of w0, as for one-parameter blocks): the
+         * basis column v is shared by the walkers of a group, and for a FIXED v the move
+         * x + r v with r > 0 is not a symmetric proposal -- only its average over v and -v
+         * is.  With the private sign each walker's kernel is symmetric, hence pi-invariant,
+         * for every fixed basis, so the walkers of a group are independent chains given the
+         * bases (without it they drift together: a group was worth ~4 walkers, see DESIGN) */
+        double rr = ((wd[0] >> 8) < BRANCH_EXP_24) ? Er : sqrt(2.0 * Er);
+        *r_out = (wd[0] & 0x80u) ? rr : -rr;
         *Ea_out = -orc_dlog(u52(ka));
     }
 }

@@ -1,0 +1,187 @@
+"""TEST DOUBLE for `cobaya_amd.engine.Engine`: the same Python interface served by the CPU
+oracle (oracle/cbind.py) instead of libmcmc_hip.so.
+
+It exists so that the HOST side of the product -- `EnsembleMCMC` under the standalone class
+and under a real Cobaya (`cobaya.run.run` with `sampler: mcmc_hip`) -- can be exercised end to
+end in the CPU-only build container: initialize -> run -> checkpoints -> products -> resume.
+It is test infrastructure: nothing under cobaya_amd/ or mcmc_hip/ imports it, and the product
+has no CPU fallback (the real `Engine` raises without a gfx950 device).  Because the oracle is
+the bit-exact specification of the kernels, a run on this double is the run the GPU would do.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from cobaya_amd.engine import (ERR_ARG, ERR_NOT_PD, ERR_STUCK, ChainStuck, EngineError,
+                               NotPositiveDefinite)
+from oracle import cbind as O
+
+
+class OracleEngine:
+    n_threads = 4
+
+    def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
+                 burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
+                 emit_capacity=0, shared_basis=True):
+        if n_walkers % group_size:
+            raise EngineError(ERR_ARG, "n_walkers must be a multiple of group_size")
+        if not shared_basis:
+            raise EngineError(ERR_ARG, "the oracle double only does shared bases")
+        self.d, self.W, self.group_size = int(d), int(n_walkers), int(group_size)
+        self.G = self.W // self.group_size
+        self.K = None
+        self.walker_offset = int(walker_offset)
+        self.seed, self.burn_in = int(seed), int(burn_in)
+        self.temperature, self.scale = float(temperature), float(proposal_scale)
+        self.max_tries = float(max_tries if max_tries is not None else 40 * d)
+        self.cap = int(emit_capacity)
+        self._prior = self._target = self._blocking = None
+        self._cov = None
+        self._problem = self._state = None
+        self._shift = np.zeros(d)
+        self._n_snap, self._gsum, self._S = 0, np.zeros((self.G, d)), np.zeros((d, d))
+        self._steps = 0
+        self.closed = False
+
+    # -- problem ------------------------------------------------------------------------
+    def set_prior(self, kinds, a, b, periodic=None):
+        self._prior = (np.array(kinds, np.int32), np.array(a, float), np.array(b, float),
+                       None if periodic is None else np.array(periodic, np.int32))
+        self._problem = None
+
+    def set_target_gaussian_mixture(self, means, covs, weights=None):
+        means = np.atleast_2d(np.array(means, float))
+        self.K = len(means)
+        self._target = dict(means=means, covs=np.array(covs, float).reshape(self.K, self.d, self.d),
+                            weights=None if weights is None else np.array(weights, float),
+                            normalized=True)
+        self._problem = None
+
+    def set_target_gaussian(self, mean, cov, normalized=True):
+        self.K = 1
+        self._target = dict(means=np.array(mean, float)[None], covs=np.array(cov, float)[None],
+                            weights=None, normalized=bool(normalized))
+        self._problem = None
+
+    def set_target_one(self):
+        self.K = 0
+        self._target = dict(means=None, covs=None, weights=None, normalized=True)
+        self._problem = None
+
+    def set_blocking(self, blocks, oversampling=None, drag_last_slow=-1, drag_steps=0):
+        blocks = [list(map(int, b)) for b in blocks]
+        if sorted(i for b in blocks for i in b) != list(range(self.d)):
+            raise EngineError(ERR_ARG, "The blocks do not contain all the parameter indices.")
+        self._blocking = dict(blocks=blocks,
+                              oversampling=list(oversampling or [1] * len(blocks)),
+                              drag_last_slow=int(drag_last_slow), drag_steps=int(drag_steps))
+        self._problem = None
+
+    def _prob(self):
+        if self._problem is None:
+            kinds, a, b, per = self._prior
+            bl = self._blocking or {}
+            self._problem = O.Problem(
+                self.d, kinds, a, b, per, **self._target, group_size=self.group_size,
+                seed=self.seed, temperature=self.temperature, max_tries=self.max_tries,
+                **bl)
+            if self._cov is not None:
+                self._problem.set_T(self._transform(self._cov))
+            if self._state is not None:      # re-point the state at the new problem
+                self._state.p = self._problem
+        return self._problem
+
+    def cycle_length(self):
+        p = self._prob()
+        if self._blocking and self._blocking["drag_last_slow"] >= 0:
+            return p.cycle_length(1)
+        return p.cycle_length(0) if self._blocking else self.d
+
+    def _transform(self, cov):
+        if self._blocking:
+            return O.blocked_transform(cov, self._blocking["blocks"], self.scale)
+        return O.proposal_transform(cov, self.scale)
+
+    def set_proposal_cov(self, cov):
+        cov = np.array(cov, float).reshape(self.d, self.d)
+        # proposal.py:243-246: symmetric and positive definite, else LinAlgError
+        if not np.allclose(cov.T, cov) or not np.all(np.linalg.eigvalsh(cov) > 0):
+            raise NotPositiveDefinite(ERR_NOT_PD, "The given covmat is not a positive-definite, "
+                                                  "symmetric square matrix.")
+        self._cov = cov.copy()
+        if self._problem is not None:
+            self._problem.set_T(self._transform(cov))
+
+    def get_proposal_cov(self):
+        return self._cov.copy()
+
+    # -- evaluation / state -------------------------------------------------------------
+    def evaluate(self, x, derived=False):
+        return self._prob().evaluate(x, derived=derived)
+
+    def set_state(self, x):
+        x = np.array(x, float).reshape(self.W, self.d)
+        self._state = O.State(self._prob(), x, burn_in=self.burn_in, row_cap=self.cap)
+        self._state.step = self._steps
+
+    def get_state(self):
+        s = self._state
+        return {"x": s.x.copy(), "logpost": s.logpost.copy(), "logprior": s.logprior.copy(),
+                "loglike": s.loglike.copy(), "weight": s.weight.copy()}
+
+    def get_full_state(self):
+        s = self._state
+        out = self.get_state()
+        out.update(prior_rej=s.prior_rej.copy(), burn_left=s.burn_left.copy(),
+                   n_accept=s.n_accept.copy(), step=np.uint64(s.step))
+        return out
+
+    def set_full_state(self, st):
+        self.set_state(st["x"])
+        s = self._state
+        for k in ("logpost", "logprior", "loglike", "weight", "prior_rej", "burn_left",
+                  "n_accept"):
+            getattr(s, k)[...] = st[k]
+        s.step = self._steps = int(st["step"])
+
+    # -- sampling -----------------------------------------------------------------------
+    def step(self, n_steps):
+        self._prob()
+        self._state.run(int(n_steps), walker0=self.walker_offset, n_threads=self.n_threads)
+        self._steps = self._state.step
+        if int(self._state.stuck[0]):
+            raise ChainStuck(ERR_STUCK, "The chain has been stuck for %g attempts, stopping "
+                                        "sampling." % self.max_tries)
+
+    def sync(self):
+        pass
+
+    def counters(self):
+        s = self._state
+        return {"steps": int(s.step), "accepted": int(s.n_accept.sum()),
+                "stuck": int(s.stuck[0]), "dropped_rows": 0}
+
+    def drain_samples(self):
+        rows = self._state.drain()
+        if len(rows):
+            rows[:, 0] += self.walker_offset
+        return rows
+
+    # -- moments ------------------------------------------------------------------------
+    def set_moment_shift(self, shift):
+        self._shift = np.array(shift, float)
+
+    def accumulate_moments(self):
+        O.moments(self._state.x, self.group_size, self._shift, self._gsum, self._S)
+        self._n_snap += 1
+
+    def read_moments(self, reset=False):
+        out = (self._n_snap, self._gsum.copy(), self._S.copy())
+        if reset:
+            self._n_snap = 0
+            self._gsum[...] = 0
+            self._S[...] = 0
+        return out
+
+    def close(self):
+        self.closed = True

@@ -44,6 +44,7 @@ def test_checkpoint_allreduce_world_size_2(tmp_path):
     covs = np.array([np.cov(c.T, ddof=0) for c in flat])
     Ns = np.full(m, flat.shape[1], dtype=float)
     Rref, Wref = R.rminus1_of_means(Ns, means, covs)
+    Rref *= w.GS   # the sampler quotes R-1 per walker: a chain of the statistic is a group
     for r in res:
         assert abs(r["Rminus1"] - Rref) <= 1e-9 * Rref
         np.testing.assert_allclose(r["new_cov"], Wref, rtol=1e-10)

@@ -1,0 +1,149 @@
+"""The standalone sampler (`cobaya_amd.MCMCHip`, `cobaya_amd.run`) end to end on the CPU, with
+the ctypes seam served by the oracle-backed double (tests/oracle_engine.py): the host logic
+that `-m gpu` tests exercise on the device -- life cycle, checkpoint files, resume, the R-1
+semantics -- runs here at small sizes.  (The product itself has no CPU path.)"""
+import os
+
+import numpy as np
+import pytest
+
+from cobaya_amd.model import ProblemSpec
+from cobaya_amd.sampler import LoggedError, MCMCHip
+from tests.oracle_engine import OracleEngine
+from tests.test_host_logic import QUICK
+
+
+class OnOracle(MCMCHip):
+    _engine_factory = staticmethod(OracleEngine)
+
+
+def make(prefix, max_samples, resume=False, force=False, **opts):
+    o = {"seed": 21, "n_walkers": 128, "group_size": 64, "steps_per_launch": 40,
+         "max_samples": max_samples, "Rminus1_stop": 0.0, "learn_every": "20d",
+         "snapshot_every": 40}
+    o.update(opts)
+    return OnOracle(o, ProblemSpec.from_info(QUICK), output=prefix, resume=resume, force=force)
+
+
+def lines(path):
+    with open(path) as f:
+        return f.read().splitlines()
+
+
+def test_resume_keeps_rows_and_continues_bit_identically(tmp_path):
+    p = str(tmp_path / "b")
+    one = make(str(tmp_path / "a"), 40000)
+    one.run()
+    b1 = make(p, 20000)
+    b1.run()
+    head = lines(p + ".1.txt")
+    for ext in (".checkpoint", ".covmat", ".progress", ".1.state.npz", ".1.txt"):
+        assert os.path.exists(p + ext), ext
+    b2 = make(p, 40000, resume=True)
+    assert b2.n_steps_raw == b1.n_steps_raw and len(b2.progress) == len(b1.progress)
+    b2.run()
+    full = lines(p + ".1.txt")
+    assert full[:len(head)] == head and len(full) > len(head)
+    assert full == lines(str(tmp_path / "a") + ".1.txt")
+    ref, got = one.engine.get_full_state(), b2.engine.get_full_state()
+    for k in ("x", "logpost", "weight", "n_accept", "burn_left", "prior_rej"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert int(got["step"]) == int(ref["step"])
+    np.testing.assert_allclose(b2.progress["Rminus1"].to_numpy(float),
+                               one.progress["Rminus1"].to_numpy(float), rtol=1e-12)
+    assert len(b2.products()["sample"]) == len(full) - 1
+    with pytest.raises(LoggedError, match="different number of chains"):
+        make(p, 40000, resume=True, n_walkers=256)
+
+
+def test_resuming_a_finished_run_leaves_the_chain_file_alone(tmp_path):
+    """`_load_checkpoint` restored a finished run, the loop was skipped and
+    the chain file was rewritten header-only."""
+    p = str(tmp_path / "c")
+    a = make(p, 15000)
+    a.run()
+    before = lines(p + ".1.txt")
+    stamp = os.path.getmtime(p + ".1.txt")
+    assert len(before) > 100
+    b = make(p, 15000, resume=True)
+    b.run()
+    assert lines(p + ".1.txt") == before and os.path.getmtime(p + ".1.txt") == stamp
+    assert len(b.products()["sample"]) == len(before) - 1
+    # a converged checkpoint is honoured unless the stop criteria change (mcmc.py:1080-1088)
+    c = make(str(tmp_path / "d"), 1e9, Rminus1_stop=0.3, Rminus1_cl_stop=1.0)
+    c.run()
+    assert c.converged
+    n = lines(str(tmp_path / "d") + ".1.txt")
+    again = make(str(tmp_path / "d"), 1e9, resume=True, Rminus1_stop=0.3, Rminus1_cl_stop=1.0)
+    assert again.converged
+    again.run()
+    assert lines(str(tmp_path / "d") + ".1.txt") == n and again.n_steps_raw == c.n_steps_raw
+    tighter = make(str(tmp_path / "d"), 1e9, resume=True, Rminus1_stop=0.1, Rminus1_cl_stop=1.0)
+    assert not tighter.converged
+    tighter.run()
+    assert tighter.converged and tighter.n_steps_raw > c.n_steps_raw
+    assert lines(str(tmp_path / "d") + ".1.txt")[:len(n)] == n
+
+
+def test_old_output_needs_force_or_resume(tmp_path):
+    p = str(tmp_path / "e")
+    make(p, 5000).run()
+    with pytest.raises(LoggedError, match="force"):
+        make(p, 5000)
+    with pytest.raises(LoggedError, match="not both"):
+        make(p, 5000, resume=True, force=True)
+    s = make(p, 5000, force=True)
+    assert s.n_steps_raw == 0 and not os.path.exists(p + ".1.state.npz")
+    s.run()
+    assert os.path.exists(p + ".1.state.npz")
+
+
+def test_rows_reach_the_chain_file_during_the_run(tmp_path):
+    """mcmc.py:473-481, 697-699: the chain file follows the run every `output_every`, it is
+    not written only at the end (a killed run keeps its rows)."""
+    p = str(tmp_path / "f")
+    seen = []
+    s = make(p, 30000, output_every="0s",
+             callback_function=lambda smp: seen.append(
+                 len(lines(p + ".1.txt")) if os.path.exists(p + ".1.txt") else 0))
+    s.run()
+    assert len(seen) >= 3 and seen[1] > 1 and seen[-1] > seen[1]
+    assert sorted(seen) == seen
+
+
+def test_rminus1_is_quoted_per_walker_and_a_shared_transient_does_not_pass(tmp_path):
+    """all groups start from ONE narrow ref pdf several sigma off the mode
+    and relax together, so their means agree long before anything has mixed.  Per walker (x
+    group_size) the statistic stays large until every walker has drawn ~1/Rminus1_stop
+    independent samples; by then the transient is long gone from the later half of the run."""
+    tm, tc = np.array([0.2, 0.0]), np.array([[0.1, 0.05], [0.05, 0.2]])
+    info = {"likelihood": {"gaussian_mixture": {"means": [tm], "covs": [tc]}},
+            "params": {"a": {"prior": {"min": -5, "max": 5},
+                             "ref": {"dist": "norm", "loc": 2.2, "scale": 0.01},
+                             "proposal": 0.02},
+                       "b": {"prior": {"min": -5, "max": 5},
+                             "ref": {"dist": "norm", "loc": -2.5, "scale": 0.01},
+                             "proposal": 0.02}}}
+    s = OnOracle({"seed": 4, "n_walkers": 512, "group_size": 64, "steps_per_launch": "10d",
+                  "learn_every": "10d", "max_samples": 3e6, "snapshot_every": 20},
+                 ProblemSpec.from_info(info))
+    s.run()
+    prog = s.progress
+    r = prog["Rminus1"].to_numpy(float)
+    assert s.converged and len(prog) >= 6
+    # the early checkpoints (walkers still travelling, proposal far too small) are NOT
+    # mistaken for convergence; per group the same numbers would be 64x smaller
+    assert np.nanmin(r[:3]) > 0.05 and np.nanmin(r[:3]) / 64 < 0.01
+    assert r[-1] < 0.01 and r[-2] < 0.01
+    coll = s.products(skip_samples=0.5)["sample"]
+    m, c = coll.mean(), coll.cov()
+    assert np.all(np.abs(m - tm) < 0.05 * np.sqrt(np.diag(tc)) + 0.02)
+    np.testing.assert_allclose(c, tc, rtol=0.1, atol=0.004)
+    np.testing.assert_allclose(s.proposer.get_covariance(), tc, rtol=0.2, atol=0.01)
+
+
+def test_a_single_group_is_refused():
+    with pytest.raises(LoggedError, match="at least two groups"):
+        OnOracle({"n_walkers": 64, "group_size": 64}, ProblemSpec.from_info(QUICK))
+    with pytest.raises(LoggedError, match="multiple of group_size"):
+        OnOracle({"n_walkers": 200, "group_size": 64}, ProblemSpec.from_info(QUICK))
