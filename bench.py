@@ -34,8 +34,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_EVAL = lambda d: 16 * d + 24  # noqa: E731  SURVEY 8d: x r/w + logpost r/w + weight r/w
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s (spec)
+def algo_bytes_per_eval(d):
+    """x read + written (16 d), logpost r/w (16), weight r/w (8), state persisted
+    every step."""
+    return 16 * d + 24
+
+
+def algo_flops_per_eval(d):
+    """Arithmetic of ONE log-posterior evaluation as the reference performs it: the triangular
+    whitening y = L^-1 (t - mu) (d (d + 1) flops) + proposal axpy, deviation, chi2 and commit
+    (4 d)."""
+    return d * (d + 1) + 4 * d
+
+
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: dense FP64, vector = matrix
 
 
 def parse():
@@ -50,6 +63,11 @@ def parse():
                          "the benchmark size)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
                     help="default 40*d (the sampler's default)")
+    ap.add_argument("--emit", choices=("snapshots", "chains"), default="snapshots",
+                    help="chains: every accepted row is stored with its weight (the reference's "
+                         "own semantics, mcmc.py:691-707) and drained to the host every launch")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra, separately labelled measurements (emit: chains)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -67,7 +85,7 @@ def target(d):
     return np.full(d, 0.5), c
 
 
-def make_info(d, mean, cov, walkers, group_size, spl):
+def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots"):
     names = [f"a__{i}" for i in range(d)]
     sig = np.sqrt(np.diag(cov))
     return {
@@ -80,7 +98,10 @@ def make_info(d, mean, cov, walkers, group_size, spl):
             "seed": 1, "n_walkers": walkers, "group_size": group_size,
             "steps_per_launch": spl, "covmat": cov, "covmat_params": names,
             "Rminus1_stop": 0.0,  # never declare convergence inside the benchmark
-            "learn_proposal": True, "emit": "snapshots", "max_rows": 0}},
+            # snapshots: nothing is stored in the timed region (max_rows 0); chains: every
+            # accepted row crosses PCIe and lands in host memory, as the reference stores it
+            "learn_proposal": True, "emit": emit,
+            "max_rows": 0 if emit == "snapshots" else 1 << 22}},
     }
 
 
@@ -108,11 +129,87 @@ def cpu_baseline(d, mean, cov, group_size, seconds):
                       f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c)"}
 
 
-def main():
-    a = parse()
+def measured_traffic(d, walkers, spl, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/traffic.json, written by tools/collect_evidence.py from `rocprofv3 --pmc
+    FETCH_SIZE` / `WRITE_SIZE` runs of this same command).  bench.py cannot read hardware
+    counters itself; the entry names the files and the commit it was measured at."""
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tj):
+        return None, None
+    with open(tj) as f:
+        table = json.load(f)
+    for key, t in table.items():
+        if (t.get("d"), t.get("walkers"), t.get("steps_per_launch")) == (d, walkers, spl) and \
+                t.get("kernel", kernel).split("(")[0].strip() == kernel.split("(")[0].strip():
+            return t.get("hbm_bytes_per_launch"), {
+                "file": "profiles/traffic.json#" + key, "pmc": t.get("pmc_file"),
+                "measured_at_commit": t.get("commit"),
+                "note": "PMC passes of an earlier run of this command, not of this run"}
+    return None, None
+
+
+def run_timed(a, d, mean, cov, emit, steps, warmup):
+    """W untimed + K timed bench steps of one sampler; returns the raw measurements."""
     from cobaya_amd import dist
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
+    size = dist.size()
+    spl_req = a.steps_per_launch or 40 * d
+    info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit)
+    sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
+    eng = sampler.engine
+    spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
+    rows_kept = [0]
+
+    def one_step():
+        eng.step(spl)
+        eng.accumulate_moments()
+        sampler.n_steps_raw += spl
+        if emit == "chains":              # D2H of every accepted row + host-side store
+            rows = eng.drain_samples()
+            rows_kept[0] += len(rows)
+            sampler._store_rows(rows)
+        if sampler.n_steps_raw >= sampler._next_ckpt:
+            sampler.check_convergence_and_learn_proposal()
+            sampler.i_learn += 1
+            sampler._next_ckpt = sampler.n_steps_raw + sampler._checkpoint_steps()
+
+    sampler._next_ckpt = sampler._checkpoint_steps()
+    for _ in range(warmup):
+        one_step()
+    eng.sync()
+    dist.all_reduce_sum(np.zeros(4))  # the collective path is initialised before timing
+    eng.enable_timing(True)
+    eng.kernel_times(reset=True)
+    n_ckpt0, rows_kept[0] = sampler.i_learn, 0
+    dist.barrier()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    eng.sync()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    if size > 1:   # MAX over ranks
+        import torch
+        import torch.distributed as td
+        t = torch.tensor([dt], dtype=torch.float64)
+        if td.get_backend() == "nccl":
+            t = t.cuda(dist.local_rank())
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.cpu()[0])
+    kt = eng.kernel_times()
+    res = {"dt": dt, "spl": spl, "kt": kt, "kernel": eng.last_step_kernel(),
+           "group_size": int(sampler.group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
+           "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
+    sampler.close()
+    return res
+
+
+def main():
+    a = parse()
+    from cobaya_amd import dist
 
     dist.init_from_env()
     rank, size = dist.rank(), dist.size()
@@ -120,68 +217,40 @@ def main():
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={size}; launch with "
               "torch.distributed.run for N > 1", file=sys.stderr)
     d = a.dim
-    spl = a.steps_per_launch or 40 * d
     mean, cov = target(d)
-    info = make_info(d, mean, cov, a.walkers, a.group_size, spl)
-    sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
-    eng = sampler.engine
-
-    def one_step():
-        eng.step(spl)
-        eng.accumulate_moments()
-        sampler.n_steps_raw += spl
-        if sampler.n_steps_raw >= sampler._next_ckpt:
-            sampler.check_convergence_and_learn_proposal()
-            sampler.i_learn += 1
-            sampler._next_ckpt = sampler.n_steps_raw + sampler._checkpoint_steps()
-
-    sampler._next_ckpt = sampler._checkpoint_steps()
-    for _ in range(a.warmup):
-        one_step()
-    eng.sync()
-    dist.all_reduce_sum(np.zeros(4))  # the collective path is initialised before timing
-    eng.enable_timing(True)
-    eng.kernel_times(reset=True)
-    n_ckpt0 = sampler.i_learn
-    dist.barrier()
-    eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    eng.sync()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    buf = np.array([dt])
-    if size > 1:
-        import torch
-        import torch.distributed as td
-        t = torch.tensor([dt], dtype=torch.float64)
-        if td.get_backend() == "nccl":
-            t = t.cuda(dist.local_rank())
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        buf[0] = float(t.cpu()[0])
-    dt = float(buf[0])
-    kt = eng.kernel_times()
-    evals = float(a.walkers) * size * spl * a.steps
+    m = run_timed(a, d, mean, cov, a.emit, a.steps, a.warmup)
+    collective = dist.describe()
+    variants = []
+    if a.emit == "snapshots" and size == 1 and not a.no_variants and (d, a.walkers) == (30, 65536):
+        # the reference stores EVERY accepted row (mcmc.py:691-707, collection.py:402-427);
+        # same workload with those semantics: rows cross PCIe and are kept on the host
+        v = run_timed(a, d, mean, cov, "chains", 40, 4)
+        variants.append({
+            "variant": "emit: chains (every accepted row drained to the host, PCIe-inclusive)",
+            "value": v["evals"] / v["dt"], "unit": "evals/s",
+            "ms_per_step": 1e3 * v["dt"] / 40, "steps": 40, "warmup": 4,
+            "metropolis_steps_per_launch": v["spl"], "kernel": v["kernel"],
+            "kernel_ms_per_launch": v["kt"]["step_ms"] / 40,
+            "accepted_rows_per_s": v["rows"] / v["dt"],
+            "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"]})
     out = None
     if rank == 0:
+        spl, kt, dt = m["spl"], m["kt"], m["dt"]
         # one bench step = one engine.step(spl) call; the engine splits it into several kernel
         # launches when the directions of spl steps exceed its 256 MiB buffer (d = 100)
-        step_ms = kt["step_ms"] / max(a.steps, 1)
         launches_per_step = kt["step_launches"] / max(a.steps, 1)
-        algo_bytes = ALGO_BYTES_PER_EVAL(d) * a.walkers * spl
-        achieved = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            with open(tj) as f:
-                t = json.load(f)
-            if t.get("d") == d and t.get("walkers") == a.walkers and \
-                    t.get("steps_per_launch") == spl:
-                traffic = t.get("hbm_bytes_per_launch")
+        step_ms = kt["step_ms"] / max(kt["step_launches"], 1)      # per KERNEL launch
+        evals_per_launch = a.walkers * spl / max(launches_per_step, 1)
+        flops = algo_flops_per_eval(d) * evals_per_launch
+        algo_bytes = algo_bytes_per_eval(d) * evals_per_launch
+        tflops = flops / (step_ms * 1e-3) / 1e12 if step_ms > 0 else None
+        algo_gbs = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None
+        kernel = m["kernel"]
+        on_matrix_cores = "mfma" in kernel
+        traffic, traffic_source = measured_traffic(d, a.walkers, spl, kernel)
         out = {
             "metric": "log-posterior evals/sec (whole node), %d-dim gaussian_mixture" % d,
-            "value": evals / dt, "unit": "evals/s", "n_gpus": size, "steps": a.steps,
+            "value": m["evals"] / dt, "unit": "evals/s", "n_gpus": size, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
@@ -189,55 +258,47 @@ def main():
                              "65536 walkers per MI355X" if (d, a.walkers) == (30, 65536)
                              else f"{d}-dim single-mode gaussian_mixture, {a.walkers} walkers "
                                   "per GPU (non-default)"),
-                "d": d, "walkers_per_gpu": a.walkers, "group_size": int(sampler.group_size),
+                "d": d, "walkers_per_gpu": a.walkers, "group_size": m["group_size"],
+                "emit": a.emit,
                 "metropolis_steps_per_launch": spl,
                 "evals_per_step": a.walkers * size * spl,
-                "learn_checkpoints_in_timed_region": sampler.i_learn - n_ckpt0,
+                "learn_checkpoints_in_timed_region": m["n_ckpt"],
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
-            "roofline": ({
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-            } if d <= 56 else {
-                # d > 56: the whitening runs on the matrix cores (v_mfma_f64_16x16x4_f64);
-                # algorithmic flops (d(d+1) + 4d per evaluation) against the dense FP64 peak
-                "bound": "mfma",
-                "achieved": (d * (d + 1) + 4 * d) * a.walkers * spl / (step_ms * 1e-3) / 1e12
-                if step_ms > 0 else None,
-                "peak": 78.6, "unit": "TFLOP/s",
-                "frac": ((d * (d + 1) + 4 * d) * a.walkers * spl / (step_ms * 1e-3) / 1e12 / 78.6)
-                if step_ms > 0 else None,
-                "traffic": traffic,
-                "algorithmic_GBps": achieved,
-            }) | {
-                "kernel": (("mcmc::step_pair_kernel<true, false> (d=%d)" % d)
-                           if 14 <= d <= 56 and a.walkers % 256 == 0
-                           else ("mcmc::step_kernel<false,false> (d=%d)" % d) if d <= 32
-                           else ("mcmc::step_mfma_kernel<false> (d=%d)" % d) if a.walkers % 256 == 0
-                           else ("mcmc::step_big_reg_kernel (d=%d)" % d)),
+            "collective": collective,
+            "roofline": {
+                # The fused launch keeps the walker state in registers for `spl` steps, so the
+                # roof that binds is FP64 arithmetic -- vector FMA for d <= 56, the matrix cores
+                # above -- not HBM.  achieved = algorithmic flops of the evaluations of one
+                # launch / HIP-event duration of the step kernel.
+                "bound": "mfma" if on_matrix_cores else "fp64_valu",
+                "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_PEAK_TFLOPS if tflops else None,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": kernel,
                 "kernel_ms_per_launch": step_ms,
                 "kernel_launches_per_step": launches_per_step,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "note": ("achieved = algorithmic bytes (16d+24 B per evaluation, state "
-                         "persisted every step, SURVEY 8d) / HIP-event duration of the step "
-                         "kernel; the kernel fuses %d steps per launch and keeps the state in "
-                         "VGPRs, so real HBM traffic is far below the algorithmic figure "
-                         "(see `traffic`) and the kernel is FP64-VALU bound: DESIGN.md" % spl),
-                "fp64_valu": {
-                    "flops_per_eval": d * (d + 1) + 4 * d,
-                    "achieved_tflops": (d * (d + 1) + 4 * d) * a.walkers * spl
-                    / (step_ms * 1e-3) / 1e12 if step_ms > 0 else None,
-                    "peak_tflops": 78.6},
+                "flops_per_eval": algo_flops_per_eval(d),
+                "algorithmic_flops_per_launch": flops,
+                # SURVEY 8d's HBM figure, kept for reference: what the state would move if it
+                # were persisted every step.  It is NOT a bandwidth the kernel achieves (x_peak
+                # may exceed 1): compare `traffic`, the bytes that really cross HBM.
+                "algorithmic_hbm": {
+                    "bytes_per_eval": algo_bytes_per_eval(d), "bytes_per_launch": algo_bytes,
+                    "GBps": algo_gbs, "x_peak": algo_gbs / HBM_PEAK_GBS if algo_gbs else None,
+                    "measured_fraction_of_algorithmic": (traffic / algo_bytes) if traffic else None},
                 "basis_kernel_ms_per_launch": kt["basis_ms"] / max(a.steps, 1),
-                "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1)},
+                "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1),
+                "host_and_checkpoint_ms_per_step": 1e3 * dt / a.steps - (
+                    kt["step_ms"] + kt["basis_ms"] + kt["moments_ms"]) / max(a.steps, 1),
+                "evals_per_kernel_launch": evals_per_launch},
+            "variants": variants,
         }
         if size == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, mean, cov, int(sampler.group_size),
-                                               a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(d, mean, cov, m["group_size"], a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    sampler.close()
     return out
 
 

@@ -300,9 +300,12 @@ struct mcmc_hip_ctx {
     std::vector<hipEvent_t> pool;
     double ms[3] = {0, 0, 0};
     int64_t n_step_launches = 0;
+    std::string last_step_kernel;     // what the last step launcher said it launched
 };
 
 namespace {
+
+thread_local const char* g_noted_kernel = nullptr;
 
 int fail(mcmc_hip_ctx* h, int code, const char* fmt, ...)
 {
@@ -537,6 +540,8 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "walker_offset must be a multiple of group_size");
     if (!(cfg->temperature > 0) || !(cfg->proposal_scale > 0))
         return fail(nullptr, MCMC_HIP_ERR_ARG, "temperature and proposal_scale must be > 0");
+    if (cfg->flags != 0)
+        return fail(nullptr, MCMC_HIP_ERR_ARG, "unknown flags 0x%x", (unsigned)cfg->flags);
     if (cfg->emit_capacity < 0 || cfg->burn_in < 0)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "emit_capacity and burn_in must be >= 0");
     int ndev = 0;
@@ -1141,6 +1146,10 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             }
             else HIP_TRY(h, h->k->step(a, h->gs, h->stream));
             h->n_step_launches += 1;
+            if (g_noted_kernel) {
+                h->last_step_kernel = std::string(g_noted_kernel) + " (d=" + std::to_string(h->d) + ")";
+                g_noted_kernel = nullptr;
+            }
         }
         h->step += (unsigned long long)n;
         left -= n;
@@ -1322,6 +1331,13 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
     if (!std::isfinite(r)) return MCMC_HIP_ERR_NOT_PD;
     *Rminus1 = r;  // mcmc.py:889
     return MCMC_HIP_OK;
+}
+
+void mcmc_hip_note_step_kernel(const char* name) { g_noted_kernel = name; }
+
+const char* mcmc_hip_last_step_kernel(const mcmc_hip_ctx* h)
+{
+    return h ? h->last_step_kernel.c_str() : "";
 }
 
 int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on)

@@ -151,6 +151,7 @@ extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    mcmc_hip_note_step_kernel("mcmc::step_general_kernel");
     hipLaunchKernelGGL(step_general_kernel, dim3(b->s.W / 64), dim3(64), lds, st, *b);
     return hipGetLastError();
 }

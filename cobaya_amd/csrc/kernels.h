@@ -207,6 +207,11 @@ struct BigKernels {
 
 }  // namespace mcmc
 
+// Every step launcher names the kernel it is about to launch (a string literal); mcmc_hip_step
+// keeps the last one for mcmc_hip_last_step_kernel, so that reports quote the kernel that ran
+// instead of guessing it from the problem shape.
+extern "C" void mcmc_hip_note_step_kernel(const char* name);
+
 #define MCMC_DECLARE_BIG(DP) extern "C" const mcmc::BigKernels* mcmc_hip_big_##DP() __attribute__((weak));
 #define MCMC_DECLARE_PAIR(D) extern "C" const mcmc::PairKernels* mcmc_hip_pair_##D() __attribute__((weak));
 #define MCMC_DECLARE_DIM(D) extern "C" const mcmc::DimKernels* mcmc_hip_dim_##D() __attribute__((weak));

@@ -622,9 +622,6 @@ constexpr bool kPair = D >= MCMC_PAIR_MIN;
 // run 4.42 / 4.25 / 4.03 ms per 1080 steps.
 constexpr int pair_split(bool normp)
 {
-#ifdef MCMC_SPLIT   // developer experiments
-    return MCMC_SPLIT;
-#else
     if (!kPair) return D;
     int h = kRowBlock * ((2 * D + 6) / 12);  // multiple of the row block nearest 2D/3
     // 32 < d <= 48, measured (10^10 evals/s at W = 65 536; the matrix-core kernel runs 1.15 at
@@ -639,7 +636,6 @@ constexpr int pair_split(bool normp)
     if (normp) h += kRowBlock;
     const int hmax = D - 1 - (D - 1) % kRowBlock;   // largest whole number of row blocks below D
     return h < kRowBlock ? kRowBlock : (h > hmax ? hmax : h);
-#endif
 }
 // the split and what follows from it, per instantiation
 template <bool NORMP>
@@ -756,11 +752,7 @@ __device__ __forceinline__ void propose_pair(double (&dev)[D], double r, lptr v,
 // of the next cycle's slab stays in flight across this barrier)
 __device__ __forceinline__ void exchange_barrier()
 {
-#if defined(MCMC_EXP) && (MCMC_EXP & 1)   // timing experiment: no barrier (results are wrong)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 // UNIT_T: temperature == 1 (x / 1.0 == x exactly, so the division is dropped)
@@ -899,7 +891,6 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
                 for (int c = 1; c < 4; ++c) pc[c] = X[(kXP + c - 1) * 256];
             }
         }
-#if !(defined(MCMC_EXP) && (MCMC_EXP & 2))
         if (kBigD) {  // kSplit is a whole number of row blocks: row kSplit + q is chain q mod 4
             pc[0] = chi2;
 #pragma unroll
@@ -910,7 +901,6 @@ __device__ __forceinline__ void pair_steps(const StepArgs& a, lds_t smem)
 #pragma unroll
             for (int q = 0; q < kDB; ++q) chi2 = fma(yb[kSplit + q], yb[kSplit + q], chi2);
         }
-#endif
         const bool inb = chi2 < INFINITY;  // false for +inf and NaN: outside the prior support
         const double lp = ks->uniform_logp + s0;
         const double ll = -0.5 * (ks->cnorm0 + chi2);
@@ -1334,6 +1324,10 @@ hipError_t launch_pair(const StepArgs& a, hipStream_t st)
     hipError_t e = hipFuncSetAttribute((const void*)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
     if (e != hipSuccess) return e;
+    mcmc_hip_note_step_kernel(normp ? (unit_t ? "mcmc::step_pair_kernel<true, true>"
+                                              : "mcmc::step_pair_kernel<false, true>")
+                                    : (unit_t ? "mcmc::step_pair_kernel<true, false>"
+                                              : "mcmc::step_pair_kernel<false, false>"));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), plds, st, a);
     return hipGetLastError();
 }
@@ -1369,6 +1363,10 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    mcmc_hip_note_step_kernel(multi ? (general ? "mcmc::step_kernel<true, true>"
+                                               : "mcmc::step_kernel<true, false>")
+                                    : (general ? "mcmc::step_kernel<false, true>"
+                                               : "mcmc::step_kernel<false, false>"));
     if (multi) {
         if (general) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, lds, st, a);
         else hipLaunchKernelGGL((step_kernel<true, false>), grid, block, lds, st, a);
@@ -1420,6 +1418,7 @@ hipError_t launch_drag(const DragArgs& a, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    mcmc_hip_note_step_kernel(multi ? "mcmc::drag_kernel<true>" : "mcmc::drag_kernel<false>");
     if (multi) hipLaunchKernelGGL(drag_kernel<true>, grid, block, lds, st, a);
     else hipLaunchKernelGGL(drag_kernel<false>, grid, block, lds, st, a);
     return hipGetLastError();

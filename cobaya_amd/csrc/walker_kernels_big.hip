@@ -870,6 +870,8 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, const uint3
             has_norm ? (const void*)step_mfma_kernel<true> : (const void*)step_mfma_kernel<false>,
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         if (e != hipSuccess) return e;
+        mcmc_hip_note_step_kernel(has_norm ? "mcmc::step_mfma_kernel<true>"
+                                           : "mcmc::step_mfma_kernel<false>");
         if (has_norm)
             hipLaunchKernelGGL(step_mfma_kernel<true>, dim3(a.W / kMfmaWalkers), dim3(kMfmaThreads),
                                want, st, m);
@@ -890,6 +892,7 @@ hipError_t launch_step(const StepArgs& a, const double* Lcol, int d, const uint3
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    mcmc_hip_note_step_kernel("mcmc::step_big_reg_kernel");
     hipLaunchKernelGGL(step_big_reg_kernel, dim3(a.W / bs), dim3(bs), lds, st, b);
     return hipGetLastError();
 #endif

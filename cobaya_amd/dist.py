@@ -67,8 +67,10 @@ def init_from_env(backend=None):
 
 def all_reduce_sum(buf: np.ndarray) -> np.ndarray:
     """In-place sum over ranks of a float64 host buffer; through the GPU (RCCL) when the
-    group's backend is nccl, on the CPU for gloo.  Identity for one process."""
-    if size() == 1:
+    group's backend is nccl, on the CPU for gloo.  Without a process group: the identity.
+    A group of ONE rank still goes through its backend (so that a single-GPU test executes
+    the very RCCL path an 8-GPU job takes)."""
+    if not is_initialized():
         return buf
     import torch
     td = _td()
@@ -81,6 +83,16 @@ def all_reduce_sum(buf: np.ndarray) -> np.ndarray:
         td.all_reduce(t, op=td.ReduceOp.SUM)
     buf[...] = t.numpy().reshape(buf.shape)
     return buf
+
+
+def describe():
+    """What the collective layer really is in this process, measured rather than assumed:
+    backend, world size and the number of ranks an all-reduce of ones actually summed."""
+    if not is_initialized():
+        return {"backend": None, "world_size": 1, "nranks_seen": 1}
+    seen = all_reduce_sum(np.ones(1))
+    return {"backend": str(_td().get_backend()), "world_size": size(),
+            "nranks_seen": int(round(float(seen[0])))}
 
 
 def barrier():

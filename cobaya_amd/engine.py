@@ -87,6 +87,7 @@ SYMBOLS = [
     ("mcmc_hip_gelman_rubin", C.c_int, [C.c_int32, C.c_double, C.c_double, c_double_p,
                                         c_double_p, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_enable_timing", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_last_step_kernel", C.c_char_p, [_H]),
     ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
 ]
 
@@ -356,6 +357,10 @@ class Engine:
     # -- timing
     def enable_timing(self, on=True):
         self._check(self._lib.mcmc_hip_enable_timing(self._h, int(bool(on))))
+
+    def last_step_kernel(self):
+        """Name of the step kernel the last `step` launched, as its launcher reports it."""
+        return self._lib.mcmc_hip_last_step_kernel(self._h).decode()
 
     def kernel_times(self, reset=False):
         ms = np.zeros(3)

@@ -671,6 +671,10 @@ class EnsembleMCMC:
             rows = self._thin_rows(rows)
         if not len(rows) or self.max_rows <= 0:
             return
+        if self.emit == "chains":
+            # within a launch: chain after chain; launches follow each other in time -- the
+            # order of the collection and of the chain file alike
+            rows = rows[np.argsort(rows[:, 0], kind="stable")]
         if self._n_rows + len(rows) > self.max_rows and len(self._rows) > 1:
             if self.emit == "snapshots":
                 self._rows = self._rows[1::2]
@@ -863,8 +867,6 @@ class EnsembleMCMC:
         """(walker, weight, logpost, logprior, loglike, x...) rows -> SampleCollection with
         the derived parameters (device) and the per-likelihood chi2 columns (host) filled."""
         spec = self.spec
-        if self.emit == "chains" and len(rows):
-            rows = rows[np.argsort(rows[:, 0], kind="stable")]  # chain after chain
         coll = SampleCollection(spec.sampled, spec.derived, self._like_names(), self.temperature,
                                 name=str(1 + self.rank))
         if len(rows):

@@ -39,7 +39,7 @@ enum {
 /* Options fixed at creation.  Mirrors the attributes cobaya/samplers/mcmc/mcmc.py:111-271
  * (MCMC.initialize) reads from mcmc.yaml, plus the ensemble geometry. */
 typedef struct mcmc_hip_config {
-    int32_t d;               /* number of sampled parameters (1..32 in this build) */
+    int32_t d;               /* number of sampled parameters, 1..128 (mcmc_hip_dim_supported) */
     int32_t n_walkers;       /* walkers on this device; multiple of group_size */
     int32_t group_size;      /* walkers sharing one Haar basis: 64, 128 or 256 */
     int32_t device;          /* HIP device ordinal */
@@ -50,8 +50,12 @@ typedef struct mcmc_hip_config {
     double proposal_scale;   /* mcmc.yaml:17 (proposal.py:223) */
     double max_tries;        /* mcmc.yaml:9, already multiplied by d (mcmc.py:717-743) */
     int32_t emit_capacity;   /* accepted rows kept per walker between drains; 0 = none */
-    int32_t reserved;
+    int32_t flags;           /* MCMC_HIP_FLAG_* (0: the default ensemble) */
 } mcmc_hip_config;
+
+/* every walker draws its OWN Haar basis per cycle (proposal.py:59-69 to the letter) instead
+ * of sharing the group's: the reference-faithful control, much slower */
+#define MCMC_HIP_FLAG_OWN_BASIS 1
 
 const char* mcmc_hip_version(void);
 /* message of the last error on this handle (or of the last failed create if h == NULL) */
@@ -177,6 +181,10 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
  * call with reset != 0, and the number of step-kernel launches: the live measurement
  * bench.py's roofline block uses.  Timing is enabled by mcmc_hip_enable_timing(h, 1). */
 int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
+/* name of the step kernel the last mcmc_hip_step launched, e.g.
+ * "mcmc::step_pair_kernel<true, false> (d=30)" -- reported by the launcher itself, so that
+ * profiles and bench lines quote the kernel that ran ("" before the first step) */
+const char* mcmc_hip_last_step_kernel(const mcmc_hip_ctx* h);
 int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset);
 
 #ifdef __cplusplus

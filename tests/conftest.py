@@ -27,3 +27,14 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
     return load
+
+
+def pytest_sessionstart(session):
+    """Developer aid: MCMC_TEST_ON_ORACLE=1 serves the sampler's ctypes seam with the
+    oracle-backed double (tests/oracle_engine.py), so that the small `-m gpu` sampler tests can
+    be debugged in the CPU-only container (the oracle is the kernels' bit-exact specification).
+    Never set by the driver: on the GPU box the real engine runs."""
+    if os.environ.get("MCMC_TEST_ON_ORACLE"):
+        from cobaya_amd.sampler import EnsembleMCMC
+        from tests.oracle_engine import OracleEngine
+        EnsembleMCMC._engine_factory = staticmethod(OracleEngine)

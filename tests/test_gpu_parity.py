@@ -38,7 +38,12 @@ def random_target(d, K, rng, spread=0.05):
 
 def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, T=1.0,
               burn_in=0, cap=0, weights=None, normalized=True, rng=None, walker_offset=0,
-              max_tries=None, blocks=None, over=None, drag_last_slow=-1, drag_steps=0):
+              max_tries=None, blocks=None, over=None, drag_last_slow=-1, drag_steps=0,
+              own_constants=False):
+    """own_constants=False hands the oracle the constants the engine derived on the host (T,
+    L^-1, log-normalisations), so that the comparison isolates the KERNELS, bit for bit;
+    own_constants=True lets the oracle derive them itself with the numpy recipe (the
+    reference's arithmetic) -- see test_steps_with_the_oracles_own_constants."""
     rng = rng or np.random.default_rng(100 + d)
     kinds = [0] * d if kinds is None else kinds
     a = [0.0] * d if a is None else a
@@ -62,12 +67,17 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
     if blocks is not None:  # the engine's transform is the oracle's recipe in sorted order
         np.testing.assert_allclose(eng.get_proposal_transform(),
                                    O.blocked_transform(pcov, blocks, 2.4), rtol=1e-12, atol=1e-15)
+    if own_constants:
+        T_orc = (O.blocked_transform(pcov, blocks, 2.4) if blocks is not None
+                 else O.proposal_transform(pcov, 2.4))
+    else:
+        T_orc = eng.get_proposal_transform()
     prob = O.Problem(d, kinds, a, b, periodic=periodic, means=means, covs=covs,
-                     weights=weights, normalized=normalized, T=eng.get_proposal_transform(),
+                     weights=weights, normalized=normalized, T=T_orc,
                      blocks=blocks, oversampling=over, drag_last_slow=drag_last_slow,
                      drag_steps=drag_steps,
                      group_size=gs, seed=seed, temperature=T, max_tries=max_tries,
-                     derived=eng.derived_constants())
+                     derived=None if own_constants else eng.derived_constants())
     m0 = means[0] if K else np.full(d, 0.5)
     s0 = np.sqrt(np.diag(covs[0])) if K else np.full(d, 0.1)
     x0 = np.clip(m0 + rng.normal(size=(W, d)) * s0, 1e-3, 1 - 1e-3)
@@ -516,3 +526,134 @@ def test_config5_shape_d27_bit_exact():
             eng.sync()
             st.run(n, n_threads=4)
             compare_state(eng, st)
+
+
+# ------------------------------------------------------------------ host-derived constants
+# The bit-exact tests above give the oracle the constants the engine derived on the host, so
+# they compare kernels, not the host algebra.  The three tests below pin that algebra on its
+# own: against the REFERENCE's golden G1, against the numpy recipe, and end to end.
+def _g1_blocks(g, name):
+    flat, lens = g[name + "_blocks"], g[name + "_blocklens"]
+    blocks, k = [], 0
+    for n in lens:
+        blocks.append([int(i) for i in flat[k:k + n]])
+        k += n
+    return blocks
+
+
+@pytest.mark.parametrize("name", ["d2", "d3", "d30", "d100", "d5_2blocks", "d5_3blocks"])
+def test_proposal_transform_matches_reference_golden_g1(golden, name):
+    """a1: mcmc_hip_set_proposal_cov -> mcmc_hip_get_proposal_transform against the transforms
+    `BlockedProposer.set_covariance` produced in the reference (proposal.py:226-260,
+    tools.py:761-788; tests/golden/make_golden.py g1_transforms), one-block and blocked form.
+    The engine keeps ONE d x d factor in sorted order; the reference's per-block matrix is its
+    slice T[j_b:, j_b:j_b+n_b]."""
+    g = golden("g1_transforms")
+    cov, blocks = g[name + "_cov"], _g1_blocks(g, name)
+    d = len(cov)
+    eng = E.Engine(d, 256, group_size=64, proposal_scale=1.0)
+    eng.set_prior([0] * d, [-100.0] * d, [100.0] * d)
+    eng.set_target_one()
+    if len(blocks) > 1:
+        eng.set_blocking(blocks, [1] * len(blocks))
+    eng.set_proposal_cov(cov)
+    T = eng.get_proposal_transform()
+    assert np.array_equal(np.triu(T, 1), np.zeros_like(T))
+    j = 0
+    for b, blk in enumerate(blocks):
+        ref = g[f"{name}_transform{b}"]
+        np.testing.assert_allclose(T[j:, j:j + len(blk)], ref, rtol=1e-14,
+                                   atol=1e-15 * np.abs(ref).max())
+        j += len(blk)
+    np.testing.assert_array_equal(eng.get_proposal_cov(), cov)
+    eng.close()
+
+
+@pytest.mark.parametrize("d", [30, 100])
+def test_derived_constants_match_the_numpy_recipe(golden, d):
+    """L^-1, the log-normalisation, -log(scale) - log(2 pi)/2 and the uniform log-volume that
+    the host side of the library derives, against numpy (the reference's own tools:
+    functions.py:81-89 inverse_cholesky, tools.py:720-729 _fast_norm_logpdf, prior.py:514-533),
+    on the BASELINE targets.  Scalars to 4 ulp; the triangular inverse entrywise to a few
+    ulp of its row scale (two different but backward-stable algorithms)."""
+    t = golden("targets")
+    mean, cov = t[f"mean_d{d}"], t[f"cov_d{d}"]
+    rng = np.random.default_rng(d)
+    kinds = (rng.random(d) < 0.4).astype(int)
+    a = np.where(kinds == 1, 0.5, -0.25)
+    b = np.where(kinds == 1, rng.uniform(0.05, 3.0, d), 1.5)
+    eng = E.Engine(d, 256, group_size=64)
+    eng.set_prior(kinds, a, b)
+    eng.set_target_gaussian_mixture([mean, mean + 0.01], [cov, 2.0 * cov], [0.25, 0.75])
+    dc = eng.derived_constants()
+    ulp = np.finfo(float).eps
+    uni = kinds == 0
+    # (a sum of n logs: sequential in the library, pairwise in numpy -- n/2 ulp apart at most)
+    assert abs(dc["uniform_logp"] + np.sum(np.log(b[uni] - a[uni]))) <= (4 + uni.sum() / 2) * ulp * abs(
+        dc["uniform_logp"])
+    mls = -np.log(b[kinds == 1]) - np.log(2 * np.pi) / 2
+    np.testing.assert_allclose(dc["mls"][kinds == 1], mls, rtol=4 * ulp, atol=4 * ulp)
+    for k, c in enumerate((cov, 2.0 * cov)):
+        L = np.linalg.cholesky(c)
+        Linv = np.linalg.inv(L)
+        scale = np.abs(Linv).max(axis=1, keepdims=True)
+        assert np.max(np.abs(dc["Linv"][k] - Linv) / scale) < 64 * d * ulp
+        assert np.array_equal(np.triu(dc["Linv"][k], 1), np.zeros((d, d)))
+        cn = d * np.log(2 * np.pi) + 2 * np.sum(np.log(np.diag(L)))
+        assert abs(dc["cnorm"][k] - cn) <= 4 * ulp * abs(cn)
+    np.testing.assert_allclose(dc["weight"], [0.25, 0.75], rtol=2 * ulp)
+    eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,K,steps,kw", [
+    (8, 256, 64, 1, 40, {}),                                    # one-wave kernel
+    (30, 512, 256, 1, 60, {}),                                  # two-wave kernel (config 2)
+    (4, 256, 64, 2, 40, {"weights": [0.2, 0.8]}),               # mixture
+    (40, 256, 256, 1, 50, {}),                                  # two-wave kernel, d > 32
+    (100, 256, 64, 1, 40, {}),                                  # matrix-core kernel (config 4)
+    (40, 256, 64, 2, 30, {"weights": [0.5, 0.5]}),              # general kernel
+    (9, 256, 64, 1, 40, {"blocks": [[0, 1, 2, 3], [4, 5, 6, 7, 8]], "over": [1, 3]}),
+])
+def test_steps_with_the_oracles_own_constants(d, W, gs, K, steps, kw):
+    """One case per kernel family with NOTHING handed over: the oracle derives T, L^-1 and the
+    normalisations itself with numpy (the reference's arithmetic), the engine with its host
+    C++.  The constants differ by rounding (see the two tests above), so the trajectories agree
+    to rounding as long as no accept decision sits within rounding of its threshold -- at
+    these sizes none does: the integer state (weights, accept counts) must be IDENTICAL and the
+    positions equal to 1e-11 of the prior width."""
+    eng, prob, st = make_pair(d, W, gs, K=K, own_constants=True, **kw)
+    eng.step(steps)
+    eng.sync()
+    st.run(steps, n_threads=8)
+    s = eng.get_state()
+    assert np.array_equal(s["weight"], st.weight)
+    assert eng.counters()["accepted"] == int(st.n_accept.sum())
+    np.testing.assert_allclose(s["x"], st.x, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(s["logpost"], st.logpost, rtol=1e-10, atol=1e-9)
+    eng.close()
+
+
+def test_walkers_of_a_group_are_independent_chains():
+    """The walkers of a group share the Haar basis of every cycle but draw their own sign,
+    radial distance and accept variate: given the bases each walker's kernel is symmetric and
+    pi-invariant, so at stationarity the walkers are independent and the variance of the
+    ensemble mean is sigma^2 / W.  (With a shared sign -- the round-1 specification -- the
+    walkers of a group drifted together and this ratio was ~ group_size / 4.)"""
+    t = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
+    mean, cov = t["mean_d30"], t["cov_d30"]
+    d, W, gs = 30, 8192, 256
+    eng = E.Engine(d, W, group_size=gs, seed=5)
+    eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
+    eng.set_target_gaussian_mixture([mean], [cov])
+    eng.set_proposal_cov(cov)
+    rng = np.random.default_rng(1)
+    x0 = np.clip(rng.multivariate_normal(mean, cov, size=W), 1e-9, 1 - 1e-9)
+    eng.set_state(x0)
+    eng.step(20 * d)
+    ms = []
+    for _ in range(300):
+        eng.step(3 * d)
+        ms.append(eng.get_state()["x"].mean(0))
+    ratio = np.var(ms, axis=0) / (np.diag(cov) / W)
+    assert 0.8 < ratio.mean() < 1.25 and ratio.max() < 1.8, ratio
+    eng.close()

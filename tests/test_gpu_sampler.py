@@ -91,8 +91,8 @@ def test_fixed3_learns_from_bad_initial_proposal():
                    "_0": None, "_1": None, "_2": None},
         "sampler": {"mcmc_hip": {"seed": 11, "n_walkers": 1024, "group_size": 64,
                                  "steps_per_launch": "20d", "max_tries": ".inf",
-                                 "burn_in": "100d", "Rminus1_stop": 0.005,
-                                 "max_samples": 5e6}},
+                                 "burn_in": "100d", "Rminus1_stop": 0.02,
+                                 "max_samples": 1e8}},
     }
     updated, sampler = run(info)
     assert sampler.converged
@@ -487,3 +487,33 @@ def test_two_mode_mixture_at_d40_chains_mode():
     truth = cov + 0.25 * np.outer(mu1 - mu2, mu1 - mu2)
     assert np.max(np.abs(m - mean)) < 0.2 * sig
     assert np.max(np.abs(np.sqrt(np.diag(c)) / np.sqrt(np.diag(truth)) - 1)) < 0.1
+
+
+def test_rccl_path_with_one_rank():
+    """the RCCL path executes.  A process group with backend `nccl`, world size
+    1, on cuda:0: every checkpoint's all-reduce goes H2D -> ncclAllReduce -> D2H
+    (cobaya_amd/dist.py), and the whole run -- R-1 table, learned proposal, final ensemble --
+    equals the run without a process group, bit for bit."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    res = {}
+    for mode in ("nccl", "none"):
+        out = subprocess.run([sys.executable, os.path.join(here, "_rccl_worker.py"), mode,
+                              str(port)], capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+        res[mode] = json.loads(lines[-1][7:])
+    assert res["nccl"]["collective"] == {"backend": "nccl", "world_size": 1, "nranks_seen": 1}
+    assert res["none"]["collective"]["backend"] is None
+    assert res["nccl"]["allreduce_identity"]
+    assert len(res["nccl"]["progress"]) >= 3
+    assert res["nccl"]["progress"] == res["none"]["progress"]
+    assert res["nccl"]["proposal_cov"] == res["none"]["proposal_cov"]
+    assert res["nccl"]["x_sum"] == res["none"]["x_sum"]

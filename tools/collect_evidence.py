@@ -23,7 +23,6 @@ def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     if len(sys.argv) > 2:
         SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2])
-    main_run = len(sys.argv) <= 2
     shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{rnd}_bench.json"))
     if os.path.exists(os.path.join(SRC, "gpu_tests.log")):
         shutil.copy(os.path.join(SRC, "gpu_tests.log"), os.path.join(DST, f"{rnd}_gpu_tests.log"))
@@ -69,8 +68,19 @@ def main():
             "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; KiB; "
                     "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, "
                     "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated"}
-        with open(os.path.join(DST, "traffic.json" if main_run else f"{rnd}_traffic.json"), "w") as f:
-            json.dump(traffic, f, indent=1)
+        import subprocess
+        traffic.update(kernel=bench["roofline"]["kernel"].split("(")[0].strip(),
+                       pmc_file=f"profiles/{rnd}_pmc.txt",
+                       commit=subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT,
+                                             capture_output=True, text=True).stdout.strip())
+        tj = os.path.join(DST, "traffic.json")   # keyed table; bench.py looks its workload up
+        table = {}
+        if os.path.exists(tj):
+            with open(tj) as f:
+                table = json.load(f)
+        table[f"{rnd}_d{wl['d']}_w{wl['walkers_per_gpu']}_spl{wl['metropolis_steps_per_launch']}"] = traffic
+        with open(tj, "w") as f:
+            json.dump(table, f, indent=1)
     print(open(os.path.join(DST, f"{rnd}_kernel_stats.txt")).read())
     print(open(os.path.join(DST, f"{rnd}_pmc.txt")).read())
 
