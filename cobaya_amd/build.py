@@ -22,6 +22,7 @@ LIB = os.path.join(CSRC, "libmcmc_hip.so")
 ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
 BIG_DPS = [48, 56, 64, 72, 80, 88, 96, 100, 112, 120, 128]  # padded sizes of the d > 32 kernels
+INC_DQ_RANGES = [(1, 8), (9, 16), (17, 24), (25, 32)]  # incremental_kernels.hip: ceil(d / 4)
 PAIR_DIMS = list(range(33, 57))  # 32 < d <= 48: walker_kernels.hip's two-wave step kernel alone
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
@@ -99,6 +100,11 @@ def build(dims=None, jobs=None, verbose=True):
     general = os.path.join(CSRC, "general_kernels.hip")
     tasks.append((general, os.path.join(OBJ, "general.o"), [],
                   _digest([general] + hdrs, extra=" ".join(FLAGS))))
+    inc = os.path.join(CSRC, "incremental_kernels.hip")
+    for lo_, hi_ in INC_DQ_RANGES:
+        tasks.append((inc, os.path.join(OBJ, f"incremental_{lo_}.o"),
+                      [f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
+                      _digest([inc] + hdrs, extra=f"inc{lo_}-{hi_}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

@@ -257,6 +257,17 @@ extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* 
 extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs* a, int n_groups,
                                                     hipStream_t st);
 
+// incremental_kernels.hip: one translation unit per range of dq = ceil(d / 4)
+extern "C" hipError_t mcmc_hip_launch_inc_step_1(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_step_9(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_step_17(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_step_25(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, const double* mean,
+                                                   const double* Lrow, int d, int W, hipStream_t st)
+    __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* a, int n_groups,
+                                                        hipStream_t st) __attribute__((weak));
+
 struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
     const DimKernels* k = nullptr;    // d <= 32: lane-per-walker kernels of that dimension
@@ -285,6 +296,11 @@ struct mcmc_hip_ctx {
     // device
     DevBuf<double> x, logpost, logprior, loglike, cblock, dT, V, rows, gsum, Sg, pooled, dshift;
     DevBuf<double> ex, elp, ell, eder, escratch, dLrow, dLcol;
+    // incremental evaluation (MCMC_HIP_FLAG_INCREMENTAL): carried y, per-step (v, u) pairs,
+    // padded prior constants, row-major L^-1 and the mean of the one mode
+    bool incremental = false;
+    bool y_valid = false;
+    DevBuf<double> y, VU, inc_prior, inc_Lrow, inc_mean;
     DevBuf<int> weight_i, prej, burn, stuck, nrows;
     DevBuf<long long> nacc;
     DevBuf<unsigned long long> acc_total;
@@ -443,6 +459,28 @@ int upload_constants(mcmc_hip_ctx* h)
         HIP_TRY(h, hipMemcpyAsync(h->dLcol.p, lcol.data(), sizeof(double) * lcol.size(),
                                   hipMemcpyHostToDevice, h->stream));
     }
+    if (h->incremental && K == 1) {
+        const int dq = (d + 3) / 4, dpad = 4 * dq;
+        std::vector<double> pr((size_t)5 * dpad, 0.0);
+        for (int i = 0; i < dpad; ++i) {
+            pr[i] = i < d ? h->lo[i] : -INFINITY;
+            pr[dpad + i] = i < d ? h->hi[i] : INFINITY;
+            pr[2 * dpad + i] = i < d ? h->loc[i] : 0.0;
+            // scale = +inf marks "no normal prior here" (kind 0 and the padding)
+            pr[3 * dpad + i] = (i < d && h->kind[i] == 1) ? h->scale[i] : INFINITY;
+            pr[4 * dpad + i] = i < d ? h->mls[i] : 0.0;
+        }
+        HIP_TRY(h, h->inc_prior.resize(pr.size()));
+        HIP_TRY(h, hipMemcpyAsync(h->inc_prior.p, pr.data(), sizeof(double) * pr.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, h->inc_Lrow.resize((size_t)d * d));
+        HIP_TRY(h, hipMemcpyAsync(h->inc_Lrow.p, h->Linv.data(), sizeof(double) * d * d,
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, h->inc_mean.resize((size_t)d));
+        HIP_TRY(h, hipMemcpyAsync(h->inc_mean.p, h->mean.data(), sizeof(double) * d,
+                                  hipMemcpyHostToDevice, h->stream));
+        h->y_valid = false;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MCMC_HIP_OK;
 }
@@ -540,8 +578,14 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "walker_offset must be a multiple of group_size");
     if (!(cfg->temperature > 0) || !(cfg->proposal_scale > 0))
         return fail(nullptr, MCMC_HIP_ERR_ARG, "temperature and proposal_scale must be > 0");
-    if (cfg->flags != 0)
+    if (cfg->flags & ~MCMC_HIP_FLAG_INCREMENTAL)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "unknown flags 0x%x", (unsigned)cfg->flags);
+    if ((cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) &&
+        (cfg->d < 2 || cfg->group_size % 64 != 0 || cfg->emit_capacity > 0 ||
+         !mcmc_hip_launch_whiten_state))
+        return fail(nullptr, MCMC_HIP_ERR_ARG,
+                    "incremental evaluation needs d >= 2, a group_size that is a multiple of 64 "
+                    "and emit_capacity 0 (snapshots)");
     if (cfg->emit_capacity < 0 || cfg->burn_in < 0)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "emit_capacity and burn_in must be >= 0");
     int ndev = 0;
@@ -572,6 +616,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     h->gs = cfg->group_size;
     h->G = h->W / h->gs;
     h->shift.assign(h->d, 0.0);
+    h->incremental = (cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) != 0;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, MCMC_HIP_ERR_DEVICE, "hipStreamCreate failed");
@@ -589,6 +634,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         acc(h->rows.resize(W * (size_t)cfg->emit_capacity * (d + 4)));
         acc(h->nrows.resize(W));
     }
+    if (h->incremental) acc(h->y.resize(W * d));
     if (r == hipSuccess) r = hipMemsetAsync(h->gsum.p, 0, sizeof(double) * G * d, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->dshift.p, 0, sizeof(double) * d, h->stream);
@@ -619,6 +665,8 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
     h->acc_total.release();
     h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
+    h->y.release(); h->VU.release(); h->inc_prior.release(); h->inc_Lrow.release();
+    h->inc_mean.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -910,6 +958,7 @@ int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad)
     HIP_TRY(h, hipStreamSynchronize(s));
     h->step = 0;
     h->have_state = true;
+    h->y_valid = false;   // incremental mode: y = L^-1 (x - mu) is formed before the next step
     return MCMC_HIP_OK;
 }
 
@@ -991,6 +1040,7 @@ int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logp
     }
     h->step = step;
     h->have_state = true;
+    h->y_valid = false;   // incremental mode: mcmc_hip_set_whitened must follow (bit-exact resume)
     return MCMC_HIP_OK;
 }
 
@@ -1022,6 +1072,90 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
     return MCMC_HIP_OK;
 }
 
+
+// mcmc_hip_step in incremental mode (MCMC_HIP_FLAG_INCREMENTAL; incremental_kernels.hip).
+// Launches are cut at the multiples of refresh_every = 40 d steps, where y = L^-1 (x - mu) is
+// recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
+int step_incremental(mcmc_hip_ctx* h, int n_steps)
+{
+    const int d = h->d, dq = (d + 3) / 4;
+    if (h->K != 1 || h->any_periodic || h->blocked || h->drag_last_slow >= 0)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "incremental evaluation serves one Gaussian mode with non-periodic priors "
+                    "and a single parameter block; use evaluation: full for this model");
+    auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
+                : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
+    if (!launch || !mcmc_hip_launch_whiten_directions)
+        return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
+    const unsigned long long R = 40ull * (unsigned long long)d, dd_steps = (unsigned long long)d;
+    const size_t colb = 8 * (size_t)dq;   // doubles per (group, step) column of (v, u) pairs
+    const int max_steps_vu =
+        (int)std::max<size_t>(4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)h->G));
+    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(d) : (size_t)mcmc::v_slab(d);
+    const int ld = h->kb ? mcmc::v_ld(d) : d;
+    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    int left = n_steps;
+    while (left > 0) {
+        if (!h->y_valid || h->step % R == 0) {
+            HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
+                                                    d, h->W, h->stream));
+            h->y_valid = true;
+        }
+        const unsigned long long c0 = h->step / dd_steps;
+        unsigned long long room = R - h->step % R;
+        room = std::min<unsigned long long>(room, (c0 + (unsigned long long)max_cyc) * dd_steps - h->step);
+        room = std::min<unsigned long long>(room, (unsigned long long)max_steps_vu);
+        const int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        const unsigned long long c1 = (h->step + (unsigned long long)n - 1) / dd_steps;
+        const int ncyc = (int)(c1 - c0 + 1);
+        {
+            Timed t(h, 1);
+            HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+            mcmc::BasisArgs b{};
+            b.T = h->dT.p; b.V = h->V.p;
+            b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+            b.cycle0 = (uint32_t)c0;
+            b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+            b.ncyc = ncyc;
+            if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
+            else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+            HIP_TRY(h, h->VU.resize((size_t)h->G * n * colb));
+            mcmc::IncDirArgs w{};
+            w.V = h->V.p; w.Lrow = h->inc_Lrow.p; w.VU = h->VU.p;
+            w.step0 = h->step; w.cycle0 = c0; w.n_steps = n; w.ncyc = ncyc;
+            w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq;
+            HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
+        }
+        {
+            Timed t(h, 0);
+            mcmc::IncStepArgs a{};
+            a.s.x = h->x.p; a.s.logpost = h->logpost.p; a.s.logprior = h->logprior.p;
+            a.s.loglike = h->loglike.p; a.s.weight = h->weight_i.p; a.s.prior_rej = h->prej.p;
+            a.s.burn_left = h->burn.p; a.s.n_accept = h->nacc.p; a.s.stuck = h->stuck.p;
+            a.s.accept_total = h->acc_total.p;
+            a.s.W = h->W; a.s.n_modes = 1; a.s.group_size = h->gs;
+            a.s.walker0 = h->cfg.walker_offset;
+            a.s.key0 = (uint32_t)h->cfg.seed; a.s.key1 = (uint32_t)(h->cfg.seed >> 32);
+            a.s.step0 = h->step; a.s.n_steps = n;
+            a.s.uniform_logp = h->uniform_logp; a.s.temperature = h->cfg.temperature;
+            a.s.max_tries = h->cfg.max_tries;
+            a.s.cnorm0 = h->cnorm[0];
+            a.y = h->y.p; a.VU = h->VU.p; a.prior = h->inc_prior.p;
+            a.d = d; a.dq = dq;
+            a.has_norm = (h->norm_mask4[0] | h->norm_mask4[1] | h->norm_mask4[2] | h->norm_mask4[3]) != 0u;
+            HIP_TRY(h, launch(&a, h->stream));
+            h->n_step_launches += 1;
+            if (g_noted_kernel) {
+                h->last_step_kernel = std::string(g_noted_kernel) + " (d=" + std::to_string(d) + ")";
+                g_noted_kernel = nullptr;
+            }
+        }
+        h->step += (unsigned long long)n;
+        left -= n;
+    }
+    return MCMC_HIP_OK;
+}
+
 }  // namespace
 
 int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
@@ -1031,6 +1165,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         return fail(h, MCMC_HIP_ERR_STATE, "set_state and set_proposal_cov must precede step");
     if (n_steps <= 0) return fail(h, MCMC_HIP_ERR_ARG, "n_steps must be > 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->incremental) return step_incremental(h, n_steps);
     const bool drag = h->drag_last_slow >= 0;
     // steps (= direction columns) per cycle, doubles per (group, cycle) slab of directions
     const int Lc = block_slots(h, drag ? 1 : 0);
@@ -1330,6 +1465,42 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
     for (size_t i = 0; i < n; ++i) r = std::max(r, std::fabs(ev[i]));
     if (!std::isfinite(r)) return MCMC_HIP_ERR_NOT_PD;
     *Rminus1 = r;  // mcmc.py:889
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->incremental || !y) return fail(h, MCMC_HIP_ERR_ARG, "not in incremental mode, or null");
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (!h->y_valid) {
+        HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p, h->d,
+                                                h->W, h->stream));
+        h->y_valid = true;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t W = h->W, d = h->d;
+    std::vector<double> yt(W * d);
+    HIP_TRY(h, hipMemcpy(yt.data(), h->y.p, sizeof(double) * W * d, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < W; ++w)
+        for (size_t i = 0; i < d; ++i) y[w * d + i] = yt[i * W + w];
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->incremental || !y) return fail(h, MCMC_HIP_ERR_ARG, "not in incremental mode, or null");
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "set_full_state must precede set_whitened");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t W = h->W, d = h->d;
+    std::vector<double> yt(W * d);
+    for (size_t w = 0; w < W; ++w)
+        for (size_t i = 0; i < d; ++i) yt[i * W + w] = y[w * d + i];
+    HIP_TRY(h, hipMemcpy(h->y.p, yt.data(), sizeof(double) * W * d, hipMemcpyHostToDevice));
+    h->y_valid = true;
     return MCMC_HIP_OK;
 }
 

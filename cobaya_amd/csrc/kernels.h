@@ -193,6 +193,25 @@ struct GeneralStepArgs {
     uint32_t periodic_mask4[4];   // ... with a periodic parameter
 };
 
+// Incremental evaluation (incremental_kernels.hip): one Gaussian mode, non-periodic priors,
+// one block; 2 <= d <= 128 with dq = ceil(d / 4) dimensions per lane, four lanes per walker.
+struct IncStepArgs {
+    StepArgs s;            // state, keys, step0, n_steps, uniform_logp, temperature, cnorm0, ...
+    double* y;             // [d][W] whitened residual L^-1 (x - mu) of the current points
+    const double* VU;      // [G][n_steps][dq][4][2]: (v_i, u_i) of every step, zero beyond d
+    const double* prior;   // [5][4 dq]: lo, hi, loc, scale, mls; beyond d: -inf, +inf, 0, inf, 0
+    int d, dq;
+    int has_norm;          // some prior is normal
+};
+
+struct IncDirArgs {
+    const double* V;       // the basis kernels' buffer [G][ncyc][slab], column stride ld
+    const double* Lrow;    // [d][d] row-major L^-1
+    double* VU;            // [G][n_steps][dq][4][2]
+    unsigned long long step0, cycle0;   // first step of the launch, first cycle held in V
+    int n_steps, ncyc, slab, ld, d, dq;
+};
+
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).
 struct BigKernels {
     int dp;  // largest dimension this instantiation serves

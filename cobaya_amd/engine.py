@@ -88,6 +88,8 @@ SYMBOLS = [
                                         c_double_p, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_enable_timing", C.c_int, [_H, C.c_int32]),
     ("mcmc_hip_last_step_kernel", C.c_char_p, [_H]),
+    ("mcmc_hip_get_whitened", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_set_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
 ]
 
@@ -153,8 +155,9 @@ class Engine:
 
     def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
                  burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
-                 emit_capacity=0, shared_basis=True):
+                 emit_capacity=0, shared_basis=True, incremental=False):
         self._lib = load_library()
+        self.incremental = bool(incremental)
         self._h = _H()
         self.d, self.W, self.group_size = int(d), int(n_walkers), int(group_size)
         self.G = self.W // self.group_size if self.group_size else 0
@@ -165,7 +168,7 @@ class Engine:
                      burn_in=int(burn_in), temperature=float(temperature),
                      proposal_scale=float(proposal_scale),
                      max_tries=float(max_tries if max_tries is not None else 40 * d),
-                     emit_capacity=int(emit_capacity), flags=0 if shared_basis else 1)
+                     emit_capacity=int(emit_capacity), flags=(0 if shared_basis else 1) | (2 if incremental else 0))
         self.cfg = cfg
         rc = self._lib.mcmc_hip_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -302,6 +305,9 @@ class Engine:
             _dp(out["loglike"]), _ip(out["weight"]), _ip(out["prior_rej"]),
             _ip(out["burn_left"]), out["n_accept"].ctypes.data_as(c_int64_p), C.byref(step)))
         out["step"] = np.uint64(step.value)
+        if self.incremental:   # the carried whitened residual is part of the state
+            out["y"] = np.empty((W, self.d))
+            self._check(self._lib.mcmc_hip_get_whitened(self._h, _dp(out["y"])))
         return out
 
     def set_full_state(self, st):
@@ -315,6 +321,9 @@ class Engine:
             self._h, _dp(x), _dp(f["logpost"]), _dp(f["logprior"]), _dp(f["loglike"]),
             _ip(i["weight"]), _ip(i["prior_rej"]), _ip(i["burn_left"]),
             na.ctypes.data_as(c_int64_p), int(st["step"])))
+        if self.incremental and "y" in st:
+            y = _f64(st["y"], (W, self.d))
+            self._check(self._lib.mcmc_hip_set_whitened(self._h, _dp(y)))
 
     # -- sampling
     def step(self, n_steps):

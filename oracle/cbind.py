@@ -44,6 +44,7 @@ class _Problem(C.Structure):
         ("uniform_logp", C.c_double),
         ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
         ("weight", c_double_p), ("T", c_double_p), ("blocking", C.c_void_p),
+        ("incremental", C.c_int32), ("refresh_every", C.c_int32),
     ]
 
 
@@ -60,6 +61,7 @@ class _State(C.Structure):
         ("logpost", c_double_p), ("weight", c_int32_p), ("prior_rej", c_int32_p),
         ("burn_left", c_int32_p), ("n_accept", c_int64_p), ("stuck", c_int32_p),
         ("rows", c_double_p), ("n_rows", c_int32_p), ("row_cap", C.c_int32),
+        ("y", c_double_p),
     ]
 
 
@@ -107,6 +109,8 @@ def lib():
         L.orc_basis_blocked.restype = C.c_int
         L.orc_basis_blocked.argtypes = [C.POINTER(_Problem), C.c_uint32, C.c_uint32, C.c_int,
                                         c_double_p, c_int32_p]
+        L.orc_whiten.argtypes = [C.POINTER(_Problem), c_double_p, c_double_p]
+        L.orc_whiten_directions.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -171,8 +175,12 @@ class Problem:
     def __init__(self, d, kinds, a, b, periodic=None, means=None, covs=None, weights=None,
                  normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
                  max_tries=None, derived=None, blocks=None, oversampling=None,
-                 drag_last_slow=-1, drag_steps=0):
+                 drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None):
         self.d = d
+        # incremental evaluation (one Gaussian mode, non-periodic, one block): the whitened
+        # residual is carried and refreshed every `refresh_every` (default 40 d) steps
+        self.incremental = bool(incremental)
+        self.refresh_every = int(refresh_every or 40 * d)
         # blocked proposal: `blocks` = lists of sampler indices, slow -> fast; T must then be
         # the transform of the covariance in sorted order (blocked_transform below)
         self.blocking = None
@@ -251,6 +259,7 @@ class Problem:
         p.weight, p.T = _dp(self.weight), _dp(self.T)
         p.blocking = (C.cast(C.pointer(self.blocking), C.c_void_p) if self.blocking is not None
                       else None)
+        p.incremental, p.refresh_every = int(self.incremental), self.refresh_every
         self.c = p
 
     def set_T(self, T):
@@ -265,6 +274,20 @@ class Problem:
         lib().orc_evaluate(C.byref(self.c), n, _dp(x), _dp(lp), _dp(ll),
                            _dp(der) if derived else None)
         return (lp, ll, der) if derived else (lp, ll)
+
+    def whiten(self, x):
+        """y = L^-1 (x - mu) per point, in the oracle's chain order."""
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        y = np.empty_like(x)
+        for i in range(len(x)):
+            lib().orc_whiten(C.byref(self.c), _dp(x[i]), _dp(y[i]))
+        return y
+
+    def whiten_directions(self, V):
+        V = np.ascontiguousarray(V, dtype=np.float64)
+        U = np.empty_like(V)
+        lib().orc_whiten_directions(C.byref(self.c), len(V), _dp(V), _dp(U))
+        return U
 
     def basis(self, group, cycle):
         V = np.empty((self.d, self.d))
@@ -309,6 +332,7 @@ class State:
         self.rows = np.zeros((self.W, max(row_cap, 1), d + 4)) if row_cap else None
         self.n_rows = np.zeros(self.W, np.int32)
         self.step = 0
+        self.y = problem.whiten(self.x) if problem.incremental else np.zeros((1, 1))
         s = _State()
         s.x, s.logprior, s.loglike = _dp(self.x), _dp(self.logprior), _dp(self.loglike)
         s.logpost, s.weight, s.prior_rej = _dp(self.logpost), _ip(self.weight), _ip(self.prior_rej)
@@ -318,6 +342,7 @@ class State:
         s.rows = _dp(self.rows) if row_cap else None
         s.n_rows = _ip(self.n_rows)
         s.row_cap = row_cap
+        s.y = _dp(self.y)
         self.c = s
 
     def run(self, n_steps, walker0=0, n_threads=1):

@@ -181,6 +181,12 @@ typedef struct {
      * blocks it is built from the covariance in SORTED order (j-indexed, proposal.py:252) */
     const double* T;
     const struct orc_blocking* blocking; /* NULL: one block holding every parameter */
+    /* evaluation mode (DESIGN.md "Incremental evaluation"): 0 = every trial is evaluated from
+     * scratch (eval_point); 1 = the whitened residual y = L^-1 (x - mu) of every walker is
+     * CARRIED and moved along the whitened direction, y' = y + r L^-1 v -- O(d) per step for
+     * the same log-posterior -- and recomputed from x every `refresh_every` steps */
+    int32_t incremental;
+    int32_t refresh_every;
 } orc_problem;
 
 /* Blocked proposal (proposal.py:96-224): blocks sorted slow -> fast; parameter j of the
@@ -474,6 +480,7 @@ typedef struct {
     /* optional emission of accepted rows (mcmc.py:691-707): rows[W][cap][d+4] =
      * (weight, logpost, logprior, loglike, x...), n_rows[W] */
     double* rows; int32_t* n_rows; int32_t row_cap;
+    double* y;         /* [W][d] incremental mode: L^-1 (x - mu) of the current point, carried */
 } orc_state;
 
 /* the Metropolis bookkeeping shared by the Philox and the injected drivers */
@@ -527,6 +534,72 @@ static inline int step_core(const orc_problem* p, orc_state* st, int w, const do
     if (!inb || lt == -INFINITY) accept = 0;
     else if (lt > st->logpost[w]) accept = 1;
     else accept = exp_draw > (st->logpost[w] - lt) / p->temperature;
+    commit(p, st, w, t, inb, lp, ll, lt, accept);
+    return accept;
+}
+
+/* ---- incremental evaluation (one Gaussian mode, non-periodic priors, one block) ----------
+ * y_j = sum_{i<=j} Linv[j][i] (x_i - mu_i), ascending fma chain from +0.0 (== `derived` of
+ * eval_point): what a walker carries, recomputed at every step s with s % refresh_every == 0 */
+void orc_whiten(const orc_problem* p, const double* x, double* y)
+{
+    int d = p->d;
+    for (int j = 0; j < d; ++j) {
+        double a = 0.0;
+        for (int i = 0; i <= j; ++i) a = fma(p->Linv[j * d + i], x[i] - p->mean[i], a);
+        y[j] = a;
+    }
+}
+
+/* U[c*d + j] = sum_{i<=j} Linv[j][i] V[c*d + i]: the whitened proposal directions of a cycle */
+void orc_whiten_directions(const orc_problem* p, int ncol, const double* V, double* U)
+{
+    int d = p->d;
+    for (int c = 0; c < ncol; ++c)
+        for (int j = 0; j < d; ++j) {
+            double a = 0.0;
+            for (int i = 0; i <= j; ++i) a = fma(p->Linv[j * d + i], V[c * d + i], a);
+            U[c * d + j] = a;
+        }
+}
+
+/* One step in incremental mode.  Trial t = x + r v and its whitened residual yt = y + r u;
+ * prior terms and chi2 are summed as FOUR interleaved chains over the dimensions i = c (mod 4)
+ * (the kernel keeps dimension i in lane i mod 4 of the walker's quad), combined
+ * (s0 + s1) + (s2 + s3) -- for every d in this mode. */
+static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, const double* v,
+                                const double* u, double r, double exp_draw)
+{
+    int d = p->d;
+    double t[128], yt[128];
+    const double* x = st->x + (size_t)w * d;
+    double* y = st->y + (size_t)w * d;
+    int inb = 1;
+    for (int i = 0; i < d; ++i) {
+        t[i] = fma(r, v[i], x[i]);
+        inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
+    }
+    double lp = -INFINITY, ll = -INFINITY, lt = -INFINITY;
+    if (inb) {
+        double sc[4] = {0.0, 0.0, 0.0, 0.0}, pc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < d; ++i) {
+            if (p->kind[i] == 1) {
+                double q = (t[i] - p->loc[i]) / p->scale[i];
+                sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, p->mls[i]);
+            }
+            yt[i] = fma(r, u[i], y[i]);
+            pc[i & 3] = fma(yt[i], yt[i], pc[i & 3]);
+        }
+        lp = p->uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
+        ll = -0.5 * (p->cnorm[0] + ((pc[0] + pc[1]) + (pc[2] + pc[3])));
+        lt = lp + ll;
+    }
+    int accept;
+    if (!inb || lt == -INFINITY) accept = 0;
+    else if (lt > st->logpost[w]) accept = 1;
+    else accept = exp_draw > (st->logpost[w] - lt) / p->temperature;
+    if (accept)
+        for (int i = 0; i < d; ++i) y[i] = yt[i];
     commit(p, st, w, t, inb, lp, ll, lt, accept);
     return accept;
 }
@@ -671,6 +744,8 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
         double* Vstep = drag ? (double*)malloc(sizeof(double) * (size_t)nd * d) : NULL;
         int32_t* f1f = f1 + L0;
         uint64_t have_cycle = UINT64_MAX, have_f[2] = {UINT64_MAX, UINT64_MAX};
+        uint64_t have_u = UINT64_MAX;
+        double* U = NULL;
         for (int s = 0; s < n_steps; ++s) {
             uint64_t step = step0 + (uint64_t)s;
             uint64_t cycle = step / (uint64_t)L0;
@@ -680,6 +755,22 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 have_cycle = cycle;
             }
             const double* v = V + (size_t)col * d;
+            if (p->incremental) {
+                if (cycle != have_u) {
+                    if (!U) U = (double*)malloc(sizeof(double) * (size_t)L0 * d);
+                    orc_whiten_directions(p, L0, V, U);
+                    have_u = cycle;
+                }
+                for (int l = 0; l < gs; ++l) {
+                    int w = g * gs + l;
+                    double r, Ea;
+                    if (step % (uint64_t)p->refresh_every == 0)
+                        orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * d);
+                    walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
+                    total += step_core_inc(p, st, w, v, U + (size_t)col * d, r, Ea);
+                }
+                continue;
+            }
             if (!drag) {
                 for (int l = 0; l < gs; ++l) {
                     int w = g * gs + l;
@@ -715,7 +806,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 total += drag_core(p, st, w, v, vfp, r, Ea);
             }
         }
-        free(V); free(f1); free(Vf); free(Vstep);
+        free(V); free(f1); free(Vf); free(Vstep); free(U);
     }
     return total;
 }

@@ -39,7 +39,7 @@ def random_target(d, K, rng, spread=0.05):
 def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, T=1.0,
               burn_in=0, cap=0, weights=None, normalized=True, rng=None, walker_offset=0,
               max_tries=None, blocks=None, over=None, drag_last_slow=-1, drag_steps=0,
-              own_constants=False):
+              own_constants=False, incremental=False):
     """own_constants=False hands the oracle the constants the engine derived on the host (T,
     L^-1, log-normalisations), so that the comparison isolates the KERNELS, bit for bit;
     own_constants=True lets the oracle derive them itself with the numpy recipe (the
@@ -49,7 +49,8 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
     a = [0.0] * d if a is None else a
     b = [1.0] * d if b is None else b
     eng = E.Engine(d, W, group_size=gs, seed=seed, temperature=T, burn_in=burn_in,
-                   emit_capacity=cap, walker_offset=walker_offset, max_tries=max_tries)
+                   emit_capacity=cap, walker_offset=walker_offset, max_tries=max_tries,
+                   incremental=incremental)
     eng.set_prior(kinds, a, b, periodic)
     if K == 0:
         eng.set_target_one()
@@ -77,7 +78,8 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
                      blocks=blocks, oversampling=over, drag_last_slow=drag_last_slow,
                      drag_steps=drag_steps,
                      group_size=gs, seed=seed, temperature=T, max_tries=max_tries,
-                     derived=None if own_constants else eng.derived_constants())
+                     derived=None if own_constants else eng.derived_constants(),
+                     incremental=incremental)
     m0 = means[0] if K else np.full(d, 0.5)
     s0 = np.sqrt(np.diag(covs[0])) if K else np.full(d, 0.1)
     x0 = np.clip(m0 + rng.normal(size=(W, d)) * s0, 1e-3, 1 - 1e-3)
@@ -657,3 +659,73 @@ def test_walkers_of_a_group_are_independent_chains():
     ratio = np.var(ms, axis=0) / (np.diag(cov) / W)
     assert 0.8 < ratio.mean() < 1.25 and ratio.max() < 1.8, ratio
     eng.close()
+
+
+# ------------------------------------------------------------------ incremental evaluation
+@pytest.mark.parametrize("d,W,gs,normal,T", [
+    (2, 256, 64, False, 1.0), (3, 128, 64, True, 1.0), (5, 256, 128, False, 2.0),
+    (8, 256, 64, False, 1.0), (13, 192, 64, True, 1.0), (30, 512, 256, False, 1.0),
+    (27, 256, 64, True, 1.0), (32, 256, 64, False, 1.0), (33, 256, 64, False, 1.0),
+    (48, 256, 128, True, 1.5), (64, 256, 64, False, 1.0), (100, 256, 64, False, 1.0),
+    (100, 512, 256, True, 1.0), (112, 128, 64, False, 1.0), (128, 256, 128, False, 1.0)])
+def test_incremental_steps_bit_exact(d, W, gs, normal, T):
+    """MCMC_HIP_FLAG_INCREMENTAL (incremental_kernels.hip) against the oracle's incremental mode
+    (oracle/mcmc_oracle.c: step_core_inc, orc_whiten, orc_whiten_directions): positions, the
+    carried whitened residual, log-posterior values, weights and accept counts BIT FOR BIT,
+    over launches that end mid-cycle, off the four-step variate blocks, and across the refresh
+    at 40 d steps."""
+    kw = {}
+    if normal:
+        rng = np.random.default_rng(7000 + d)
+        kinds = (rng.random(d) < 0.5).astype(int).tolist()
+        kinds[d - 1] = 1
+        kw = dict(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
+    eng, prob, st = make_pair(d, W, gs, T=T, incremental=True,
+                              rng=np.random.default_rng(6000 + d), **kw)
+    compare_state(eng, st)
+    R = 40 * d
+    for n in (1, 2, 7, d + 3, R - (d + 13) - 1, 5, 2 * d + 1):   # crosses step R after launch 5
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residual")
+    assert st.step > R
+    c = eng.counters()
+    assert c["steps"] == st.step and c["accepted"] == int(st.n_accept.sum())
+    assert 0.03 < c["accepted"] / (W * st.step) < 0.9
+    assert "step_inc_kernel" in eng.last_step_kernel()
+    eng.close()
+
+
+def test_incremental_mode_refuses_what_it_does_not_cover():
+    with pytest.raises(E.EngineError, match="incremental"):
+        E.Engine(1, 256, group_size=64, incremental=True)
+    with pytest.raises(E.EngineError, match="incremental"):
+        E.Engine(4, 256, group_size=64, incremental=True, emit_capacity=8)
+    eng = E.Engine(4, 256, group_size=64, incremental=True)
+    eng.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
+    m, c = random_target(4, 2, np.random.default_rng(0))
+    eng.set_target_gaussian_mixture(m, c)
+    eng.set_proposal_cov(c[0])
+    eng.set_state(np.full((256, 4), 0.5))
+    with pytest.raises(E.EngineError, match="one Gaussian mode"):
+        eng.step(3)
+    eng.close()
+
+
+def test_incremental_resume_carries_the_whitened_residual():
+    """get_full_state / set_full_state include y: a fresh engine continues bit-identically."""
+    eng, prob, st = make_pair(30, 256, 64, incremental=True)
+    eng.step(137)
+    full = eng.get_full_state()
+    eng.step(211)
+    ref = eng.get_full_state()
+    eng2, _, _ = make_pair(30, 256, 64, incremental=True)
+    eng2.set_full_state(full)
+    eng2.step(211)
+    got = eng2.get_full_state()
+    for k in ("x", "y", "logpost", "weight", "n_accept"):
+        assert_bit_equal(np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64), k)
+    eng.close(), eng2.close()

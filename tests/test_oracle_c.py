@@ -311,3 +311,73 @@ def test_moments_fixed_order_matches_numpy():
     np.testing.assert_allclose(S, xc.T @ xc, rtol=1e-13)
     gs2, S2 = O.moments(x, 64, shift=shift, group_sum=gs.copy(), pooled=S.copy())
     np.testing.assert_allclose(S2, 2 * S, rtol=1e-15)
+
+
+# ------------------------------------------------------------------ incremental evaluation
+def _inc_pair(d, W, gs, seed, golden, normal=False):
+    from oracle import cbind as O
+    t = golden("targets")
+    if f"mean_d{d}" in t.files:
+        mean, cov = t[f"mean_d{d}"], t[f"cov_d{d}"]
+    else:
+        rng = np.random.default_rng(d)
+        A = rng.normal(size=(d, d))
+        cov = (A @ A.T / d + np.eye(d)) * 0.002
+        mean = np.full(d, 0.5)
+    kinds = [0] * d
+    a, b = [0.0] * d, [1.0] * d
+    if normal:
+        for i in range(0, d, 3):
+            kinds[i], a[i], b[i] = 1, 0.5, 0.3
+    T = O.proposal_transform(cov, 2.4)
+    mk = lambda inc: O.Problem(d, kinds, a, b, means=mean, covs=cov, T=T, group_size=gs,
+                               seed=seed, incremental=inc)
+    rng = np.random.default_rng(seed)
+    x0 = np.clip(rng.multivariate_normal(mean, cov, size=W), 1e-6, 1 - 1e-6)
+    return mk(False), mk(True), x0, mean, cov
+
+
+@pytest.mark.parametrize("d,normal", [(2, False), (7, True), (30, False), (45, True)])
+def test_incremental_evaluation_is_the_same_posterior(golden, d, normal):
+    """Incremental mode carries y = L^-1 (x - mu) and moves it along the whitened direction.
+    Its log-posterior of the CURRENT point must be the from-scratch one of the same x
+    (eval_point: what golden G5 pins to the reference) to rounding at every step -- drift is
+    bounded by the refresh every 40 d steps -- and y must stay L^-1 (x - mu)."""
+    from oracle import cbind as O
+    full, inc, x0, mean, cov = _inc_pair(d, 128, 64, 11, golden, normal)
+    st = O.State(inc, x0)
+    worst = 0.0
+    for _ in range(12):
+        st.run(17 * d + 3, n_threads=4)      # launches end anywhere, refreshes fall inside
+        lp, ll = full.evaluate(st.x)
+        np.testing.assert_allclose(st.logprior, lp, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(st.loglike, ll, rtol=2e-13, atol=1e-11)
+        np.testing.assert_allclose(st.logpost, lp + ll, rtol=2e-13, atol=1e-11)
+        y = full.whiten(st.x)
+        worst = max(worst, np.max(np.abs(st.y - y)))
+        np.testing.assert_allclose(st.y, y, rtol=0, atol=1e-11)
+    assert st.step == 12 * (17 * d + 3) and 0.05 < st.n_accept.sum() / (128 * st.step) < 0.7
+    assert worst > 0.0   # it IS a different arithmetic (else this test would be vacuous)
+
+
+def test_incremental_and_full_evaluation_walk_the_same_chains(golden):
+    """Same seed, same proposal stream: the two modes differ by rounding in the trial
+    log-posterior only, so over a short run every accept decision coincides and the states
+    agree to rounding; statistically they are the same sampler."""
+    from oracle import cbind as O
+    full, inc, x0, mean, cov = _inc_pair(30, 256, 64, 3, golden)
+    a, b = O.State(full, x0), O.State(inc, x0)
+    a.run(400, n_threads=4)
+    b.run(400, n_threads=4)
+    assert np.array_equal(a.weight, b.weight) and np.array_equal(a.n_accept, b.n_accept)
+    np.testing.assert_allclose(a.x, b.x, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a.logpost, b.logpost, rtol=1e-12, atol=1e-10)
+
+
+def test_whitened_directions_are_linv_times_v(golden):
+    from oracle import cbind as O
+    full, inc, x0, mean, cov = _inc_pair(30, 64, 64, 5, golden)
+    V = inc.basis(3, 7)
+    U = inc.whiten_directions(V)
+    Linv = np.linalg.inv(np.linalg.cholesky(cov))
+    np.testing.assert_allclose(U, V @ Linv.T, rtol=1e-11, atol=1e-12 * np.abs(U).max())
