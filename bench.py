@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--emit", choices=("snapshots", "chains"), default="snapshots",
                     help="chains: every accepted row is stored with its weight (the reference's "
                          "own semantics, mcmc.py:691-707) and drained to the host every launch")
+    ap.add_argument("--evaluation", choices=("auto", "full", "incremental"), default="auto",
+                    help="auto (the sampler's default): incremental evaluation where it applies")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra, separately labelled measurements (emit: chains)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,7 +87,7 @@ def target(d):
     return np.full(d, 0.5), c
 
 
-def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots"):
+def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots", evaluation="auto"):
     names = [f"a__{i}" for i in range(d)]
     sig = np.sqrt(np.diag(cov))
     return {
@@ -100,7 +102,7 @@ def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots"):
             "Rminus1_stop": 0.0,  # never declare convergence inside the benchmark
             # snapshots: nothing is stored in the timed region (max_rows 0); chains: every
             # accepted row crosses PCIe and lands in host memory, as the reference stores it
-            "learn_proposal": True, "emit": emit,
+            "learn_proposal": True, "emit": emit, "evaluation": evaluation,
             "max_rows": 0 if emit == "snapshots" else 1 << 22}},
     }
 
@@ -129,6 +131,15 @@ def cpu_baseline(d, mean, cov, group_size, seconds):
                       f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c)"}
 
 
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 1024 SIMDs, one per 4 clocks, 2.4 GHz
+
+
+def algo_flops_incremental(d):
+    """FP64 arithmetic one INCREMENTAL evaluation executes: trial x, trial y, chi2, and the
+    commits of x and y -- five fused multiply-adds per dimension."""
+    return 10 * d
+
+
 def measured_traffic(d, walkers, spl, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/traffic.json, written by tools/collect_evidence.py from `rocprofv3 --pmc
@@ -143,20 +154,22 @@ def measured_traffic(d, walkers, spl, kernel):
         if (t.get("d"), t.get("walkers"), t.get("steps_per_launch")) == (d, walkers, spl) and \
                 t.get("kernel", kernel).split("(")[0].strip() == kernel.split("(")[0].strip():
             return t.get("hbm_bytes_per_launch"), {
+                "sq_insts_valu_per_launch": t.get("sq_insts_valu"),
                 "file": "profiles/traffic.json#" + key, "pmc": t.get("pmc_file"),
                 "measured_at_commit": t.get("commit"),
                 "note": "PMC passes of an earlier run of this command, not of this run"}
     return None, None
 
 
-def run_timed(a, d, mean, cov, emit, steps, warmup):
+def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
     """W untimed + K timed bench steps of one sampler; returns the raw measurements."""
     from cobaya_amd import dist
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
     size = dist.size()
     spl_req = a.steps_per_launch or 40 * d
-    info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit)
+    info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit,
+                     evaluation or a.evaluation)
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -201,6 +214,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup):
         dt = float(t.cpu()[0])
     kt = eng.kernel_times()
     res = {"dt": dt, "spl": spl, "kt": kt, "kernel": eng.last_step_kernel(),
+           "evaluation": "incremental" if sampler.incremental else "full",
            "group_size": int(sampler.group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
     sampler.close()
@@ -221,6 +235,21 @@ def main():
     m = run_timed(a, d, mean, cov, a.emit, a.steps, a.warmup)
     collective = dist.describe()
     variants = []
+    if size == 1 and not a.no_variants and m["evaluation"] == "incremental":
+        # the same workload with every trial evaluated from scratch (O(d^2) per step): the
+        # round-1 path, kept as `evaluation: full`
+        v = run_timed(a, d, mean, cov, a.emit, max(a.steps // 2, 10), 4, evaluation="full")
+        n_v = max(a.steps // 2, 10)
+        v_ms = v["kt"]["step_ms"] / max(v["kt"]["step_launches"], 1)
+        v_launches = v["kt"]["step_launches"] / n_v
+        variants.append({
+            "variant": "evaluation: full (every trial evaluated from scratch)",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 4, "kernel": v["kernel"], "kernel_ms_per_launch": v_ms,
+            "fp64_tflops": algo_flops_per_eval(d) * a.walkers * v["spl"] / max(v_launches, 1)
+            / (v_ms * 1e-3) / 1e12,
+            "fp64_frac_of_peak": algo_flops_per_eval(d) * a.walkers * v["spl"] / max(v_launches, 1)
+            / (v_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS})
     if a.emit == "snapshots" and size == 1 and not a.no_variants and (d, a.walkers) == (30, 65536):
         # the reference stores EVERY accepted row (mcmc.py:691-707, collection.py:402-427);
         # same workload with those semantics: rows cross PCIe and are kept on the host
@@ -248,6 +277,49 @@ def main():
         kernel = m["kernel"]
         on_matrix_cores = "mfma" in kernel
         traffic, traffic_source = measured_traffic(d, a.walkers, spl, kernel)
+        common = {
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
+            "kernel_ms_per_launch": step_ms, "kernel_launches_per_step": launches_per_step,
+            "evals_per_kernel_launch": evals_per_launch,
+            # SURVEY 8d's HBM figure, kept for reference: what the state would move if it were
+            # persisted every step.  It is NOT a bandwidth the kernel achieves (x_peak may
+            # exceed 1): compare `traffic`, the bytes that really cross HBM.
+            "algorithmic_hbm": {
+                "bytes_per_eval": algo_bytes_per_eval(d), "bytes_per_launch": algo_bytes,
+                "GBps": algo_gbs, "x_peak": algo_gbs / HBM_PEAK_GBS if algo_gbs else None,
+                "measured_fraction_of_algorithmic": (traffic / algo_bytes) if traffic else None},
+            "basis_kernel_ms_per_launch": kt["basis_ms"] / max(a.steps, 1),
+            "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1),
+            "host_and_checkpoint_ms_per_step": 1e3 * dt / a.steps - (
+                kt["step_ms"] + kt["basis_ms"] + kt["moments_ms"]) / max(a.steps, 1)}
+        if m["evaluation"] == "incremental":
+            # O(d) per step: most of the instructions are not FP64 multiply-adds (two compares
+            # per dimension for the prior support, Philox, two logarithms, a square root), so
+            # the roof that binds is the VALU ISSUE rate -- one wave-instruction per SIMD every
+            # four clocks.  achieved = SQ_INSTS_VALU of one launch (PMC pass of this command,
+            # see traffic_source) / HIP-event duration of the kernel in THIS run.
+            insts = (traffic_source or {}).get("sq_insts_valu_per_launch")
+            ach = insts / (step_ms * 1e-3) if insts and step_ms > 0 else None
+            tf = algo_flops_incremental(d) * evals_per_launch / (step_ms * 1e-3) / 1e12
+            roofline = {
+                "bound": "valu_issue", "achieved": ach / 1e9 if ach else None,
+                "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
+                "frac": ach / VALU_ISSUE_PEAK if ach else None,
+                "fp64": {"flops_per_eval_executed": algo_flops_incremental(d),
+                         "achieved_tflops": tf, "frac_of_peak": tf / FP64_PEAK_TFLOPS,
+                         "flops_per_eval_from_scratch": algo_flops_per_eval(d),
+                         "equivalent_from_scratch_tflops": tflops},
+                **common}
+        else:
+            # The fused launch keeps the walker state in registers for `spl` steps, so the roof
+            # that binds is FP64 arithmetic -- vector FMA for d <= 56, the matrix cores above --
+            # not HBM.  achieved = algorithmic flops of one launch / HIP-event kernel duration.
+            roofline = {
+                "bound": "mfma" if on_matrix_cores else "fp64_valu",
+                "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_PEAK_TFLOPS if tflops else None,
+                "flops_per_eval": algo_flops_per_eval(d),
+                "algorithmic_flops_per_launch": flops, **common}
         out = {
             "metric": "log-posterior evals/sec (whole node), %d-dim gaussian_mixture" % d,
             "value": m["evals"] / dt, "unit": "evals/s", "n_gpus": size, "steps": a.steps,
@@ -259,39 +331,14 @@ def main():
                              else f"{d}-dim single-mode gaussian_mixture, {a.walkers} walkers "
                                   "per GPU (non-default)"),
                 "d": d, "walkers_per_gpu": a.walkers, "group_size": m["group_size"],
-                "emit": a.emit,
+                "emit": a.emit, "evaluation": m["evaluation"],
                 "metropolis_steps_per_launch": spl,
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": m["n_ckpt"],
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
             "collective": collective,
-            "roofline": {
-                # The fused launch keeps the walker state in registers for `spl` steps, so the
-                # roof that binds is FP64 arithmetic -- vector FMA for d <= 56, the matrix cores
-                # above -- not HBM.  achieved = algorithmic flops of the evaluations of one
-                # launch / HIP-event duration of the step kernel.
-                "bound": "mfma" if on_matrix_cores else "fp64_valu",
-                "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / FP64_PEAK_TFLOPS if tflops else None,
-                "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": kernel,
-                "kernel_ms_per_launch": step_ms,
-                "kernel_launches_per_step": launches_per_step,
-                "flops_per_eval": algo_flops_per_eval(d),
-                "algorithmic_flops_per_launch": flops,
-                # SURVEY 8d's HBM figure, kept for reference: what the state would move if it
-                # were persisted every step.  It is NOT a bandwidth the kernel achieves (x_peak
-                # may exceed 1): compare `traffic`, the bytes that really cross HBM.
-                "algorithmic_hbm": {
-                    "bytes_per_eval": algo_bytes_per_eval(d), "bytes_per_launch": algo_bytes,
-                    "GBps": algo_gbs, "x_peak": algo_gbs / HBM_PEAK_GBS if algo_gbs else None,
-                    "measured_fraction_of_algorithmic": (traffic / algo_bytes) if traffic else None},
-                "basis_kernel_ms_per_launch": kt["basis_ms"] / max(a.steps, 1),
-                "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1),
-                "host_and_checkpoint_ms_per_step": 1e3 * dt / a.steps - (
-                    kt["step_ms"] + kt["basis_ms"] + kt["moments_ms"]) / max(a.steps, 1),
-                "evals_per_kernel_launch": evals_per_launch},
+            "roofline": roofline,
             "variants": variants,
         }
         if size == 1 and not a.no_cpu_baseline:

@@ -1143,6 +1143,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.y = h->y.p; a.VU = h->VU.p; a.prior = h->inc_prior.p;
             a.d = d; a.dq = dq;
             a.has_norm = (h->norm_mask4[0] | h->norm_mask4[1] | h->norm_mask4[2] | h->norm_mask4[3]) != 0u;
+            a.box = !a.has_norm;
+            for (int i = 1; i < d && a.box; ++i)
+                a.box = h->lo[i] == h->lo[0] && h->hi[i] == h->hi[0];
+            a.box_lo = h->lo[0]; a.box_hi = h->hi[0];
             HIP_TRY(h, launch(&a, h->stream));
             h->n_step_launches += 1;
             if (g_noted_kernel) {

@@ -54,57 +54,93 @@ __host__ __device__ constexpr int inc_chunk(int dq)
 
 // ---------------------------------------------------------------- the step kernel
 // 256 threads = 64 walkers of ONE group (group_size is a multiple of 64).
-template <int DQ, bool NORMP, bool UNIT_T>
-__global__ void __launch_bounds__(256) step_inc_kernel(const IncStepArgs a)
+//   MODE 0 "box":    every prior uniform on the SAME interval [lo, hi] (kernel arguments; the
+//                    padded dimensions sit at its midpoint) -- BASELINE configs 2-4
+//   MODE 1 general bounds: per-dimension [lo_i, hi_i] in registers (DQ <= 12) or LDS
+//   MODE 2 ... and normal priors
+// Registers: x and y only (+ the bounds for MODE > 0, DQ <= 12); the (v_i, u_i) pairs of a step
+// are read from LDS twice (trial, commit) -- ds_read_b128 costs 4 LDS cycles per wave, far below
+// what the step's VALU work takes.  The columns of the launch reach LDS by global->LDS DMA,
+// one chunk ahead (double-buffered; one s_waitcnt + workgroup barrier per chunk).
+// waves per SIMD the register allocation is held to (from a scan of the allocator's output for
+// every DQ and MODE: the largest occupancy that does not spill)
+__host__ __device__ constexpr int inc_min_waves(int dq, int mode)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 sVU[];
+    if (mode == 0) return dq <= 8 ? 4 : dq <= 13 ? 3 : dq <= 25 ? 2 : 1;
+    if (mode == 1) return dq <= 4 ? 4 : dq <= 8 ? 3 : dq <= 25 ? 2 : 1;
+    return dq <= 4 ? 4 : dq <= 7 ? 3 : dq <= 15 ? 2 : 1;
+}
+
+template <int DQ, int MODE, bool UNIT_T>
+__global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(const IncStepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 smem2[];
     constexpr int COLB = 4 * DQ;                 // (v, u) pairs per column
     constexpr int C = inc_chunk(DQ);
-    constexpr int PF = (C * COLB + 255) / 256;   // pairs a thread prefetches per chunk
-    constexpr bool kKeepVU = DQ <= 12;           // keep the step's pairs for the commit
+    constexpr int CHUNK = C * COLB;              // pairs per chunk
+    constexpr bool kBoundsInRegs = MODE > 0 && DQ <= 12;
+    constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;
+    constexpr bool NORMP = MODE == 2;
     const StepArgs& s = a.s;
-    const int tid = threadIdx.x, c = tid & 3;
+    const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
     const int w = blockIdx.x * 64 + (tid >> 2);
-    const int g = w / s.group_size;
+    const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
     const int ncols = s.n_steps;
     const double2* __restrict__ gVU = (const double2*)a.VU + (size_t)g * ncols * COLB;
-    const int dpad = 4 * DQ;
+    constexpr int dpad = 4 * DQ;
+    double2* const sVU = smem2;                          // [2][CHUNK]
+    double2* const sLH = smem2 + 2 * CHUNK;              // [dpad] (lo, hi), kBoundsInLds only
 
-    double x[DQ], y[DQ], lo[DQ], hi[DQ];
+    // chunk k of the launch -> buffer k & 1, by DMA: every wave moves every fourth KiB
+    auto stage = [&](int k) {
+        const int first = k * C;
+        if (first >= ncols) return;
+        const int cols = ncols - first < C ? ncols - first : C;
+        const int bytes = cols * COLB * 16;
+        const char* src = (const char*)(gVU + (size_t)first * COLB);
+        char* dst = (char*)(sVU + (k & 1) * CHUNK);
+        for (int kb = wave; kb * 1024 < bytes; kb += 4) {
+            if (kb * 1024 + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+
+    const double blo = a.box_lo, bhi = a.box_hi;
+    double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
         const bool in = i < d;
-        x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;
+        // (MODE 0: a padded dimension rests at the middle of the box, inside for every step)
+        x[kk] = in ? s.x[(size_t)i * W + w] : (MODE == 0 ? 0.5 * (blo + bhi) : 0.0);
         y[kk] = in ? a.y[(size_t)i * W + w] : 0.0;
-        lo[kk] = a.prior[i];               // padded: -inf / +inf beyond d
-        hi[kk] = a.prior[dpad + i];
+        if (kBoundsInRegs) {
+            lo[kk] = a.prior[i];               // padded: -inf / +inf beyond d
+            hi[kk] = a.prior[dpad + i];
+        }
     }
+    if (kBoundsInLds)
+        for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     long long nacc = s.n_accept[w];
     const long long nacc0 = nacc;
     const uint32_t gid = s.walker0 + (uint32_t)w;
+    // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
+    const double mt10 = s.max_tries * 10.0;
+    const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
+    const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
 
-    {   // first chunk straight into buffer 0
-        const int cnt = (ncols < C ? ncols : C) * COLB;
-        for (int e = tid; e < cnt; e += 256) sVU[e] = gVU[e];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int base = 0; base < ncols; base += C) {
-        const int buf = (base / C) & 1;
-        const double2* __restrict__ cur = sVU + buf * (C * COLB);
-        // the next chunk travels to registers while this one is consumed
-        double2 pf[PF];
-        int nextcnt = ncols - base - C;
-        nextcnt = (nextcnt < 0 ? 0 : (nextcnt > C ? C : nextcnt)) * COLB;
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int e = tid + 256 * p;
-            if (e < nextcnt) pf[p] = gVU[(size_t)(base + C) * COLB + e];
-        }
+    for (int base = 0, k = 0; base < ncols; base += C, ++k) {
+        const double2* __restrict__ cur = sVU + (k & 1) * CHUNK;
+        stage(k + 1);     // travels while this chunk is consumed
         const int cols = ncols - base < C ? ncols - base : C;
         for (int s4 = 0; s4 < cols; s4 += 4) {
             // lane class c draws the variates of step base + s4 + c
@@ -112,31 +148,40 @@ __global__ void __launch_bounds__(256) step_inc_kernel(const IncStepArgs a)
             rng.begin(s.key0, s.key1, gid, s.step0 + (unsigned long long)(base + s4 + c));
             rng.run_all();
             const double r4 = rng.r, E4 = rng.Ea;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (s4 + k < cols) {
-                    const double r = k == 0 ? quad_perm<0x00>(r4) : k == 1 ? quad_perm<0x55>(r4)
-                                   : k == 2 ? quad_perm<0xAA>(r4) : quad_perm<0xFF>(r4);
-                    const double Ea = k == 0 ? quad_perm<0x00>(E4) : k == 1 ? quad_perm<0x55>(E4)
-                                    : k == 2 ? quad_perm<0xAA>(E4) : quad_perm<0xFF>(E4);
-                    const double2* __restrict__ col = cur + (s4 + k) * COLB + c;
-                    double2 vu[kKeepVU ? DQ : 1];
+            // (not unrolled: an unrolled body lets the scheduler hoist the LDS reads of all four
+            // steps and costs the registers that decide the occupancy)
+            const int nq = cols - s4 < 4 ? cols - s4 : 4;
+#pragma unroll 1
+            for (int q = 0; q < nq; ++q) {
+                {
+                    double r, Ea;
+                    switch (q) {   // wave-uniform
+                    case 0: r = quad_perm<0x00>(r4); Ea = quad_perm<0x00>(E4); break;
+                    case 1: r = quad_perm<0x55>(r4); Ea = quad_perm<0x55>(E4); break;
+                    case 2: r = quad_perm<0xAA>(r4); Ea = quad_perm<0xAA>(E4); break;
+                    default: r = quad_perm<0xFF>(r4); Ea = quad_perm<0xFF>(E4); break;
+                    }
+                    const double2* __restrict__ col = cur + (s4 + q) * COLB + c;
                     double pc = 0.0, sc = 0.0;
                     bool inb = true;
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
                         const double2 p = col[4 * kk];
-                        if (kKeepVU) vu[kk] = p;
                         const double t = fma(r, p.x, x[kk]);
-                        inb = inb & (t <= hi[kk]) & (t >= lo[kk]);
+                        if (MODE == 0) inb = inb & (t <= bhi) & (t >= blo);
+                        else if (kBoundsInRegs) inb = inb & (t <= hi[kk]) & (t >= lo[kk]);
+                        else {
+                            const double2 lh = sLH[4 * kk + c];
+                            inb = inb & (t <= lh.y) & (t >= lh.x);
+                        }
                         const double yt = fma(r, p.y, y[kk]);
                         pc = fma(yt, yt, pc);
                         if (NORMP) {
                             const int i = 4 * kk + c;
                             const double scale = a.prior[3 * dpad + i];
                             if (scale < INFINITY) {
-                                const double q = (t - a.prior[2 * dpad + i]) / scale;
-                                sc = sc + fma(-0.5 * q, q, a.prior[4 * dpad + i]);
+                                const double qq = (t - a.prior[2 * dpad + i]) / scale;
+                                sc = sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
                             }
                         }
                     }
@@ -148,11 +193,20 @@ __global__ void __launch_bounds__(256) step_inc_kernel(const IncStepArgs a)
                     const double lt = inside ? lp + ll : -INFINITY;
                     const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
                     const bool accept = inside & (lt != -INFINITY) & ((lt > lpost) | (Ea > delta));
+                    const int lim = burn > 0 ? lim10 : lim1;
                     burn -= (accept & (burn > 0)) ? 1 : 0;
                     const double ra = accept ? r : 0.0;
+                    // (the pairs are read AGAIN from LDS: the pointer passes through an empty
+                    // asm so that the compiler cannot keep the first reads alive in 4 DQ registers)
+                    const double2* col2 = col;
+                    asm volatile("" : "+v"(col2));
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
-                        const double2 p = kKeepVU ? vu[kk] : col[4 * kk];
+                        // (four pairs at a time: the pointer of the next four depends, through
+                        // an empty asm, on the last result of these four -- else all DQ reads
+                        // are issued up front into 4 DQ registers)
+                        if (kk % 4 == 0 && kk) asm volatile("" : "+v"(col2) : "v"(y[kk - 1]));
+                        const double2 p = col2[4 * kk];
                         x[kk] = fma(ra, p.x, x[kk]);
                         y[kk] = fma(ra, p.y, y[kk]);
                     }
@@ -162,19 +216,11 @@ __global__ void __launch_bounds__(256) step_inc_kernel(const IncStepArgs a)
                     prej = accept ? 0 : (prej + (inside ? 0 : 1));
                     wt = accept ? 1 : wt + 1;
                     nacc += accept ? 1 : 0;
-                    if (!accept && c == 0) {
-                        const double max_now = s.max_tries * (burn > 0 ? 10.0 : 1.0);
-                        if ((double)(wt - prej) > max_now) atomicCAS(s.stuck, 0, 1 + (int)gid);
-                    }
+                    if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
                 }
             }
         }
-        double2* __restrict__ nxt = sVU + (buf ^ 1) * (C * COLB);
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int e = tid + 256 * p;
-            if (e < nextcnt) nxt[e] = pf[p];
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed
         __syncthreads();
     }
 #pragma unroll
@@ -238,7 +284,35 @@ __global__ void __launch_bounds__(64) whiten_directions_kernel(const IncDirArgs 
     }
     if (!live) return;
     double2* __restrict__ out = (double2*)a.VU + ((size_t)g * a.n_steps + sr) * (4 * a.dq);
-    for (int j = 0; j < d; ++j) {
+    // four rows at a time: four independent chains share every v_i read from LDS (each chain
+    // is still one ascending fma chain from +0.0 -- the order of orc_whiten_directions)
+    int j = 0;
+    for (; j + 4 <= d; j += 4) {
+        const double* __restrict__ r0 = a.Lrow + (size_t)j * d;
+        const double* __restrict__ r1 = r0 + d;
+        const double* __restrict__ r2 = r1 + d;
+        const double* __restrict__ r3 = r2 + d;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int i = 0; i <= j; ++i) {
+            const double v = sv[i * 64 + l];
+            a0 = fma(r0[i], v, a0);
+            a1 = fma(r1[i], v, a1);
+            a2 = fma(r2[i], v, a2);
+            a3 = fma(r3[i], v, a3);
+        }
+        const double v1 = sv[(j + 1) * 64 + l], v2 = sv[(j + 2) * 64 + l], v3 = sv[(j + 3) * 64 + l];
+        a1 = fma(r1[j + 1], v1, a1);
+        a2 = fma(r2[j + 1], v1, a2);
+        a3 = fma(r3[j + 1], v1, a3);
+        a2 = fma(r2[j + 2], v2, a2);
+        a3 = fma(r3[j + 2], v2, a3);
+        a3 = fma(r3[j + 3], v3, a3);
+        out[j] = make_double2(sv[j * 64 + l], a0);
+        out[j + 1] = make_double2(v1, a1);
+        out[j + 2] = make_double2(v2, a2);
+        out[j + 3] = make_double2(v3, a3);
+    }
+    for (; j < d; ++j) {
         const double* __restrict__ row = a.Lrow + (size_t)j * d;
         double acc = 0.0;
         for (int i = 0; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
@@ -251,18 +325,29 @@ template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
     constexpr int C = inc_chunk(DQ);
-    const size_t lds = sizeof(double2) * 2 * C * 4 * DQ;
+    const int mode = a.has_norm ? 2 : (a.box ? 0 : 1);
+    const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);
-    const kern_t kern = a.has_norm ? (unit_t ? step_inc_kernel<DQ, true, true> : step_inc_kernel<DQ, true, false>)
-                                   : (unit_t ? step_inc_kernel<DQ, false, true> : step_inc_kernel<DQ, false, false>);
-    static const std::string names[4] = {
-        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", false, false>",
-        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", false, true>",
-        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", true, false>",
-        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", true, true>"};
-    mcmc_hip_note_step_kernel(names[(a.has_norm ? 2 : 0) + (unit_t ? 1 : 0)].c_str());
-    hipLaunchKernelGGL(kern, dim3(a.s.W / 64), dim3(256), lds, st, a);
+    static const kern_t kerns[6] = {
+        step_inc_kernel<DQ, 0, false>, step_inc_kernel<DQ, 0, true>,
+        step_inc_kernel<DQ, 1, false>, step_inc_kernel<DQ, 1, true>,
+        step_inc_kernel<DQ, 2, false>, step_inc_kernel<DQ, 2, true>};
+    static const std::string names[6] = {
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, false>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, true>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, false>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, true>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true>"};
+    const int v = 2 * mode + (unit_t ? 1 : 0);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    mcmc_hip_note_step_kernel(names[v].c_str());
+    hipLaunchKernelGGL(kerns[v], dim3(a.s.W / 64), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

@@ -202,6 +202,8 @@ struct IncStepArgs {
     const double* prior;   // [5][4 dq]: lo, hi, loc, scale, mls; beyond d: -inf, +inf, 0, inf, 0
     int d, dq;
     int has_norm;          // some prior is normal
+    int box;               // every prior is uniform on the same interval [box_lo, box_hi]
+    double box_lo, box_hi;
 };
 
 struct IncDirArgs {

@@ -73,6 +73,11 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
+    "evaluation": "auto",     # "full": every trial is evaluated from scratch (O(d^2));
+                              # "incremental": the whitened residual L^-1 (x - mu) is carried
+                              # and moved along the whitened shared direction (O(d), same
+                              # posterior; one Gaussian mode, non-periodic, one block,
+                              # snapshots); "auto": incremental where it applies
     "shared_basis": True,     # True: the walkers of a group share one Haar basis per cycle;
                               # False: every walker draws its own (proposal.py:59-69 to the
                               # letter: the reference-faithful control, much slower)
@@ -218,6 +223,18 @@ class EnsembleMCMC:
             self.steps_per_launch = int(max(1, min(self.steps_per_launch,
                                                    (1 << 30) // row_bytes)))
             cap = self.steps_per_launch
+        if self.evaluation not in ("auto", "full", "incremental"):
+            self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
+                       self.evaluation)
+        can_inc = (spec.n_modes == 1 and not np.any(spec.periodic) and len(self.blocks) == 1
+                   and self.oversampling_factors[0] == 1 and not self.drag
+                   and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
+                   and bool(self.shared_basis))
+        if self.evaluation == "incremental" and not can_inc:
+            self._fail("evaluation: incremental serves one Gaussian mode with non-periodic "
+                       "priors, a single parameter block, emit: snapshots, d >= 2 and a "
+                       "group_size that is a multiple of 64; use 'full' (or 'auto')")
+        self.incremental = can_inc and self.evaluation != "full"
         try:
             self.engine = self._engine_factory(d, W, group_size=int(self.group_size), device=int(device),
                                  seed=self.seed, walker_offset=self.rank * W,
@@ -225,7 +242,8 @@ class EnsembleMCMC:
                                  temperature=self.temperature,
                                  proposal_scale=float(self.proposal_scale),
                                  max_tries=float(self.max_tries), emit_capacity=cap,
-                                 shared_basis=bool(self.shared_basis))
+                                 shared_basis=bool(self.shared_basis),
+                                 incremental=self.incremental)
             spec.configure(self.engine)
             if len(self.blocks) > 1 or self.oversampling_factors[0] != 1:
                 self.engine.set_blocking(
@@ -583,7 +601,7 @@ class EnsembleMCMC:
         self.engine.set_proposal_cov(z["proposal_cov"])
         self.engine.set_full_state({k: z[k] for k in ("x", "logpost", "logprior", "loglike",
                                                       "weight", "prior_rej", "burn_left",
-                                                      "n_accept", "step")})
+                                                      "n_accept", "step", "y") if k in z})
         self._shift = z["shift"]
         self.engine.set_moment_shift(self._shift)
         self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]

@@ -47,6 +47,7 @@ else:
         snapshot_every: int | None = HIP_DEFAULTS["snapshot_every"]
         max_rows: int = HIP_DEFAULTS["max_rows"]
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]
+        evaluation: str = HIP_DEFAULTS["evaluation"]
 
         def _export_collection(self, coll):
             """Our table -> `cobaya.collection.SampleCollection` (same columns,

@@ -22,7 +22,7 @@ class OracleEngine:
 
     def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
                  burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
-                 emit_capacity=0, shared_basis=True):
+                 emit_capacity=0, shared_basis=True, incremental=False):
         if n_walkers % group_size:
             raise EngineError(ERR_ARG, "n_walkers must be a multiple of group_size")
         if not shared_basis:
@@ -35,6 +35,10 @@ class OracleEngine:
         self.temperature, self.scale = float(temperature), float(proposal_scale)
         self.max_tries = float(max_tries if max_tries is not None else 40 * d)
         self.cap = int(emit_capacity)
+        self.incremental = bool(incremental)
+        if self.incremental and (d < 2 or group_size % 64 or emit_capacity):
+            raise EngineError(ERR_ARG, "incremental evaluation needs d >= 2, group_size % 64 == "
+                                       "0 and emit_capacity 0")
         self._prior = self._target = self._blocking = None
         self._cov = None
         self._problem = self._state = None
@@ -84,7 +88,7 @@ class OracleEngine:
             self._problem = O.Problem(
                 self.d, kinds, a, b, per, **self._target, group_size=self.group_size,
                 seed=self.seed, temperature=self.temperature, max_tries=self.max_tries,
-                **bl)
+                incremental=self.incremental, **bl)
             if self._cov is not None:
                 self._problem.set_T(self._transform(self._cov))
             if self._state is not None:      # re-point the state at the new problem
@@ -134,6 +138,8 @@ class OracleEngine:
         out = self.get_state()
         out.update(prior_rej=s.prior_rej.copy(), burn_left=s.burn_left.copy(),
                    n_accept=s.n_accept.copy(), step=np.uint64(s.step))
+        if self.incremental:
+            out["y"] = s.y.copy()
         return out
 
     def set_full_state(self, st):
@@ -143,9 +149,15 @@ class OracleEngine:
                   "n_accept"):
             getattr(s, k)[...] = st[k]
         s.step = self._steps = int(st["step"])
+        if self.incremental and "y" in st:
+            s.y[...] = st["y"]
 
     # -- sampling -----------------------------------------------------------------------
     def step(self, n_steps):
+        if self.incremental and (self.K != 1 or self._blocking or
+                                 (self._prior[3] is not None and self._prior[3].any())):
+            raise EngineError(ERR_ARG, "incremental evaluation serves one Gaussian mode with "
+                                       "non-periodic priors and a single parameter block")
         self._prob()
         self._state.run(int(n_steps), walker0=self.walker_offset, n_threads=self.n_threads)
         self._steps = self._state.step
