@@ -254,6 +254,9 @@ struct DevBuf {
 }  // namespace
 
 extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* b, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pack_rows(const double* rows, const int* n_rows,
+                                                const long long* offset, double* out, int W,
+                                                int cap, int d, uint32_t walker0, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_blocked_basis(const mcmc::BlockedBasisArgs* a, int n_groups,
                                                     hipStream_t st);
 
@@ -301,6 +304,17 @@ struct mcmc_hip_ctx {
     bool incremental = false;
     bool y_valid = false;
     DevBuf<double> y, VU, inc_prior, inc_Lrow, inc_mean;
+    // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
+    // stream-ordered proposal refresh: pinned host staging
+    double* pin_mom = nullptr;                      // [G*d + d(d+1)/2 + 2]
+    double* pin_T = nullptr;                        // ring of 4 transforms [4][d*d]
+    int pin_T_slot = 0;
+    hipEvent_t mom_event = nullptr;
+    bool mom_pending = false;
+    int64_t mom_n = 0;
+    unsigned long long mom_step = 0;
+    DevBuf<double> pack_out;                        // drain_samples: packed rows
+    DevBuf<long long> pack_off;
     DevBuf<int> weight_i, prej, burn, stuck, nrows;
     DevBuf<long long> nacc;
     DevBuf<unsigned long long> acc_total;
@@ -635,6 +649,9 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         acc(h->nrows.resize(W));
     }
     if (h->incremental) acc(h->y.resize(W * d));
+    acc(hipHostMalloc((void**)&h->pin_mom, sizeof(double) * (G * d + np + 2), hipHostMallocDefault));
+    acc(hipHostMalloc((void**)&h->pin_T, sizeof(double) * 4 * d * d, hipHostMallocDefault));
+    acc(hipEventCreateWithFlags(&h->mom_event, hipEventDisableTiming));
     if (r == hipSuccess) r = hipMemsetAsync(h->gsum.p, 0, sizeof(double) * G * d, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->dshift.p, 0, sizeof(double) * d, h->stream);
@@ -665,6 +682,10 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
     h->acc_total.release();
     h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
+    if (h->pin_mom) (void)hipHostFree(h->pin_mom);
+    if (h->pin_T) (void)hipHostFree(h->pin_T);
+    if (h->mom_event) (void)hipEventDestroy(h->mom_event);
+    h->pack_out.release(); h->pack_off.release();
     h->y.release(); h->VU.release(); h->inc_prior.release(); h->inc_Lrow.release();
     h->inc_mean.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -863,10 +884,16 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
     h->T.assign((size_t)d * d, 0.0);
     for (int i = 0; i < d; ++i)
         for (int j = 0; j <= i; ++j) h->T[i * d + j] = h->cfg.proposal_scale * (sd[i] * L[i * d + j]);
-    HIP_TRY(h, hipStreamSynchronize(h->stream));  // queued steps keep the old transform
-    HIP_TRY(h, hipMemcpyAsync(h->dT.p, h->T.data(), sizeof(double) * d * d, hipMemcpyHostToDevice,
+    // Stream-ordered, no host synchronisation: launches already queued keep the old transform
+    // (their basis kernels precede this copy in the stream), later ones see the new one.  The
+    // source is a pinned ring slot that stays untouched for the next three refreshes.
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    double* slot = h->pin_T + (size_t)h->pin_T_slot * d * d;
+    h->pin_T_slot = (h->pin_T_slot + 1) & 3;
+    if (h->pin_T_slot == 0) HIP_TRY(h, hipStreamSynchronize(h->stream));   // ring wrapped
+    std::copy(h->T.begin(), h->T.end(), slot);
+    HIP_TRY(h, hipMemcpyAsync(h->dT.p, slot, sizeof(double) * d * d, hipMemcpyHostToDevice,
                               h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->have_cov = true;
     return MCMC_HIP_OK;
 }
@@ -1342,7 +1369,7 @@ int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int6
     if (h->cfg.emit_capacity <= 0) return MCMC_HIP_OK;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const size_t W = h->W, d = h->d, cap = h->cfg.emit_capacity, rl = d + 4;
+    const size_t W = h->W, d = h->d, cap = h->cfg.emit_capacity;
     std::vector<int> nr(W);
     HIP_TRY(h, hipMemcpy(nr.data(), h->nrows.p, sizeof(int) * W, hipMemcpyDeviceToHost));
     int64_t total = 0;
@@ -1352,18 +1379,22 @@ int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int6
     if (cap_rows < total)
         return fail(h, MCMC_HIP_ERR_ARG, "drain buffer holds %lld rows, %lld are pending",
                     (long long)cap_rows, (long long)total);
-    std::vector<double> buf(W * cap * rl);
-    HIP_TRY(h, hipMemcpy(buf.data(), h->rows.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
-    size_t o = 0;
-    for (size_t w = 0; w < W; ++w) {
-        const int n = std::min<int>(nr[w], (int)cap);
-        for (int r = 0; r < n; ++r) {
-            const double* src = buf.data() + (w * cap + r) * rl;
-            double* dst = rows + o * (d + 5);
-            dst[0] = (double)(h->cfg.walker_offset + w);
-            std::copy(src, src + rl, dst + 1);
-            ++o;
-        }
+    // pack on the device, then move only the rows that exist (they are ~ acceptance x steps
+    // of the buffer) straight into the caller's array
+    std::vector<long long> off(W);
+    long long run = 0;
+    for (size_t w = 0; w < W; ++w) { off[w] = run; run += std::min<int>(nr[w], (int)cap); }
+    if (total > 0) {
+        HIP_TRY(h, h->pack_off.resize(W));
+        HIP_TRY(h, h->pack_out.resize(W * cap * (d + 5)));   // worst case once: no regrowth
+        HIP_TRY(h, hipMemcpyAsync(h->pack_off.p, off.data(), sizeof(long long) * W,
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, mcmc_hip_launch_pack_rows(h->rows.p, h->nrows.p, h->pack_off.p, h->pack_out.p,
+                                             (int)W, (int)cap, (int)d, h->cfg.walker_offset,
+                                             h->stream));
+        HIP_TRY(h, hipMemcpyAsync(rows, h->pack_out.p, sizeof(double) * (size_t)total * (d + 5),
+                                  hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
     return MCMC_HIP_OK;
@@ -1419,6 +1450,71 @@ int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_s
         HIP_TRY(h, hipMemset(h->gsum.p, 0, sizeof(double) * G * d));
         HIP_TRY(h, hipMemset(h->pooled.p, 0, sizeof(double) * np));
         h->n_snapshots = 0;
+    }
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_moments(mcmc_hip_ctx* h, int64_t n_snapshots, const double* group_sum,
+                         const double* pooled_S)
+{
+    if (!h || !group_sum || !pooled_S || n_snapshots < 0) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t d = h->d, G = h->G, np = d * (d + 1) / 2;
+    std::vector<double> p(np);
+    for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j <= i; ++j) p[i * (i + 1) / 2 + j] = pooled_S[i * d + j];
+    HIP_TRY(h, hipMemcpy(h->gsum.p, group_sum, sizeof(double) * G * d, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->pooled.p, p.data(), sizeof(double) * np, hipMemcpyHostToDevice));
+    h->n_snapshots = n_snapshots;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_request_moments(mcmc_hip_ctx* h)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    if (h->mom_pending) return fail(h, MCMC_HIP_ERR_STATE, "a moment request is already pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t d = h->d, G = h->G, np = d * (d + 1) / 2;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->pin_mom, h->gsum.p, sizeof(double) * G * d, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_mom + G * d, h->pooled.p, sizeof(double) * np,
+                              hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_mom + G * d + np, h->acc_total.p, sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemsetAsync(h->gsum.p, 0, sizeof(double) * G * d, s));
+    HIP_TRY(h, hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, s));
+    HIP_TRY(h, hipEventRecord(h->mom_event, s));
+    h->mom_n = h->n_snapshots;
+    h->mom_step = h->step;
+    h->n_snapshots = 0;
+    h->mom_pending = true;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
+                           double* pooled_S, int64_t counters[2])
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->mom_pending) return fail(h, MCMC_HIP_ERR_STATE, "no moment request is pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(h->mom_event));
+    h->mom_pending = false;
+    const size_t d = h->d, G = h->G, np = d * (d + 1) / 2;
+    if (n_snapshots) *n_snapshots = h->mom_n;
+    if (group_sum) std::copy(h->pin_mom, h->pin_mom + G * d, group_sum);
+    if (pooled_S) {
+        const double* p = h->pin_mom + G * d;
+        for (size_t i = 0; i < d; ++i)
+            for (size_t j = 0; j <= i; ++j)
+                pooled_S[i * d + j] = pooled_S[j * d + i] = p[i * (i + 1) / 2 + j];
+    }
+    if (counters) {
+        unsigned long long tot;
+        std::memcpy(&tot, h->pin_mom + G * d + np, sizeof tot);
+        counters[0] = (int64_t)h->mom_step;
+        counters[1] = (int64_t)tot;
     }
     return MCMC_HIP_OK;
 }

@@ -141,6 +141,40 @@ __global__ void __launch_bounds__(64) step_general_kernel(const GeneralStepArgs 
 }  // namespace
 }  // namespace mcmc
 
+// ---------------------------------------------------------------- packing of emitted rows
+// rows[W][cap][d+4] (what the step kernels fill) -> out[offset[w] + r][d+5] =
+// (global walker id, weight, logpost, logprior, loglike, x...): only the rows that exist cross
+// PCIe, already in the layout mcmc_hip_drain_samples hands out.  One wave per walker.
+namespace mcmc {
+namespace {
+__global__ void __launch_bounds__(64) pack_rows_kernel(const double* __restrict__ rows,
+                                                      const int* __restrict__ n_rows,
+                                                      const long long* __restrict__ offset,
+                                                      double* __restrict__ out, int cap, int d,
+                                                      uint32_t walker0)
+{
+    const int w = blockIdx.x, l = threadIdx.x;
+    const int n = n_rows[w] < cap ? n_rows[w] : cap;
+    const int rl = d + 4;
+    const double* __restrict__ src = rows + (size_t)w * cap * rl;
+    double* __restrict__ dst = out + (size_t)offset[w] * (d + 5);
+    for (int e = l; e < n * (d + 5); e += 64) {
+        const int r = e / (d + 5), c = e - r * (d + 5);
+        dst[e] = c == 0 ? (double)(walker0 + (uint32_t)w) : src[(size_t)r * rl + c - 1];
+    }
+}
+}  // namespace
+}  // namespace mcmc
+
+extern "C" hipError_t mcmc_hip_launch_pack_rows(const double* rows, const int* n_rows,
+                                                const long long* offset, double* out, int W,
+                                                int cap, int d, uint32_t walker0, hipStream_t st)
+{
+    hipLaunchKernelGGL(mcmc::pack_rows_kernel, dim3(W), dim3(64), 0, st, rows, n_rows, offset, out,
+                       cap, d, walker0);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* b, hipStream_t st)
 {
     using namespace mcmc;

@@ -84,6 +84,9 @@ SYMBOLS = [
     ("mcmc_hip_set_moment_shift", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_accumulate_moments", C.c_int, [_H]),
     ("mcmc_hip_read_moments", C.c_int, [_H, c_int64_p, c_double_p, c_double_p, C.c_int32]),
+    ("mcmc_hip_set_moments", C.c_int, [_H, C.c_int64, c_double_p, c_double_p]),
+    ("mcmc_hip_request_moments", C.c_int, [_H]),
+    ("mcmc_hip_fetch_moments", C.c_int, [_H, c_int64_p, c_double_p, c_double_p, c_int64_p]),
     ("mcmc_hip_gelman_rubin", C.c_int, [C.c_int32, C.c_double, C.c_double, c_double_p,
                                         c_double_p, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_enable_timing", C.c_int, [_H, C.c_int32]),
@@ -362,6 +365,26 @@ class Engine:
         self._check(self._lib.mcmc_hip_read_moments(self._h, C.byref(n), _dp(gs), _dp(S),
                                                     int(bool(reset))))
         return n.value, gs, S
+
+    def set_moments(self, n_snapshots, group_sum, pooled_S):
+        gs, S = _f64(group_sum, (self.G, self.d)), _f64(pooled_S, (self.d, self.d))
+        self._check(self._lib.mcmc_hip_set_moments(self._h, int(n_snapshots), _dp(gs), _dp(S)))
+
+    def request_moments(self):
+        """Queue the read-out (and reset) of the moment accumulators and of the accept counter
+        behind the work already in the stream; returns at once."""
+        self._check(self._lib.mcmc_hip_request_moments(self._h))
+
+    def fetch_moments(self):
+        """(n_snapshots, group_sum[G][d], pooled_S[d][d], {"steps", "accepted"}) of the
+        pending request; waits only for its copies, not for launches queued after it."""
+        n = C.c_int64()
+        gs = np.empty((self.G, self.d))
+        S = np.empty((self.d, self.d))
+        c = np.zeros(2, np.int64)
+        self._check(self._lib.mcmc_hip_fetch_moments(self._h, C.byref(n), _dp(gs), _dp(S),
+                                                     c.ctypes.data_as(c_int64_p)))
+        return n.value, gs, S, {"steps": int(c[0]), "accepted": int(c[1])}
 
     # -- timing
     def enable_timing(self, on=True):

@@ -388,6 +388,7 @@ class EnsembleMCMC:
         self._launches = 0
         self._since_snapshot = 0
         self._next_ckpt = None   # steps per walker at which the next learn checkpoint is due
+        self._ckpt_pending = False  # moments requested, checkpoint not processed yet
 
     # ------------------------------------------------------------------ a17
     def initial_proposal_covmat(self):
@@ -485,30 +486,12 @@ class EnsembleMCMC:
                       if self.burn_in else "")
         if self._next_ckpt is None:
             self._next_ckpt = self._checkpoint_steps()
-        snap_every = (int(self.snapshot_every) if self.snapshot_every
-                      else None)
         try:
+            self._request_checkpoint_if_due()   # (a resumed run: the request the dump preceded)
             while self._accepted_total < self.max_samples and not self.converged:
-                self.engine.step(self.steps_per_launch)
-                self.n_steps_raw += self.steps_per_launch
-                self._launches += 1
-                self._since_snapshot += self.steps_per_launch
-                if self._launches % max(1, int(self.moments_every)) == 0:
-                    self.engine.accumulate_moments()
-                if self.emit == "chains":
-                    self._store_rows(self.engine.drain_samples())
-                elif snap_every and self._since_snapshot >= snap_every:
-                    self._snapshot()
-                if self.n_steps_raw >= self._next_ckpt:
-                    self.check_convergence_and_learn_proposal()
-                    self.i_learn += 1
-                    if self.emit == "snapshots" and not snap_every:
-                        self._snapshot()
-                    if self.callback_function:
-                        self._callback()(self)
-                    self._next_ckpt = self.n_steps_raw + self._checkpoint_steps()
-                    if self.output:
-                        self.write_checkpoint()
+                self.advance()
+            if self._ckpt_pending:
+                self._finish_checkpoint()
             self.engine.sync()
             self._update_counters()
         except ChainStuck as e:
@@ -520,6 +503,52 @@ class EnsembleMCMC:
         self.log.info("Sampling complete after %d accepted steps.", self._accepted_total)
         if self.output:
             self.write_checkpoint(force_state=True)
+
+    def advance(self):
+        """One pass of the hot loop (the body of mcmc.py:451-528 for every walker): a fused
+        launch of `steps_per_launch` Metropolis steps, the moment snapshot, sample emission,
+        and the learn/convergence checkpoint -- which is taken OFF the critical path: when a
+        checkpoint falls due, the read-out of the sufficient statistics is only QUEUED behind
+        the launch (`request_moments`); the next launch is queued right after it, and while
+        that one runs the host fetches the statistics, all-reduces them, forms R-1 and uploads
+        the refreshed proposal in stream order.  The new proposal therefore takes effect one
+        launch after the checkpoint (deterministically, also across a resume)."""
+        eng, spl = self.engine, self.steps_per_launch
+        eng.step(spl)
+        self.n_steps_raw += spl
+        self._launches += 1
+        self._since_snapshot += spl
+        if self._launches % max(1, int(self.moments_every)) == 0:
+            eng.accumulate_moments()
+        snap_every = int(self.snapshot_every) if self.snapshot_every else None
+        if self.emit == "chains":
+            self._store_rows(eng.drain_samples())
+        elif snap_every and self._since_snapshot >= snap_every:
+            self._snapshot()
+        if self._ckpt_pending:
+            self._finish_checkpoint()
+        self._request_checkpoint_if_due()
+
+    def _request_checkpoint_if_due(self):
+        if self._ckpt_pending or self._next_ckpt is None or self.n_steps_raw < self._next_ckpt:
+            return
+        if hasattr(self.engine, "request_moments"):
+            self.engine.request_moments()
+        self._ckpt_pending = True
+        self._next_ckpt = self.n_steps_raw + self._checkpoint_steps()
+
+    def _finish_checkpoint(self):
+        self._ckpt_pending = False
+        moments = (self.engine.fetch_moments() if hasattr(self.engine, "fetch_moments")
+                   else None)
+        self.check_convergence_and_learn_proposal(moments)
+        self.i_learn += 1
+        if self.emit == "snapshots" and not self.snapshot_every:
+            self._snapshot()
+        if self.callback_function:
+            self._callback()(self)
+        if self.output:
+            self.write_checkpoint()
 
     def _callback(self):
         """mcmc.py:160-163: a callable, or a string resolved like Cobaya's external functions
@@ -569,6 +598,8 @@ class EnsembleMCMC:
             self._last_state_dump = now
             self._flush_rows()
             st = self.engine.get_full_state()
+            acc_n, acc_gs, acc_S = self.engine.read_moments(reset=False)
+            st.update(acc_n=np.int64(acc_n), acc_gs=acc_gs, acc_S=acc_S)
             ivs = self._intervals
             tmp = self._state_file() + ".tmp.npz"
             np.savez(tmp, **st,
@@ -604,6 +635,8 @@ class EnsembleMCMC:
                                                       "n_accept", "step", "y") if k in z})
         self._shift = z["shift"]
         self.engine.set_moment_shift(self._shift)
+        if "acc_n" in z:   # snapshots accumulated on the device since the last read-out
+            self.engine.set_moments(int(z["acc_n"]), z["acc_gs"], z["acc_S"])
         self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]
         (self.n_steps_raw, self.i_learn, self._acc_last, self._steps_last, self._launches,
          self._dropped_snapshots, self._accepted_total) = (int(v) for v in book[:7])
@@ -692,7 +725,8 @@ class EnsembleMCMC:
         if self.emit == "chains":
             # within a launch: chain after chain; launches follow each other in time -- the
             # order of the collection and of the chain file alike
-            rows = rows[np.argsort(rows[:, 0], kind="stable")]
+            if np.any(rows[1:, 0] < rows[:-1, 0]):   # (the engine already drains in this order)
+                rows = rows[np.argsort(rows[:, 0], kind="stable")]
         if self._n_rows + len(rows) > self.max_rows and len(self._rows) > 1:
             if self.emit == "snapshots":
                 self._rows = self._rows[1::2]
@@ -746,12 +780,17 @@ class EnsembleMCMC:
         self._intervals = ivs = ivs[k:]
         return (sum(iv[0] for iv in ivs), sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs))
 
-    def check_convergence_and_learn_proposal(self):
-        """mcmc.py:773-1032 on pooled sufficient statistics; one all-reduce."""
+    def check_convergence_and_learn_proposal(self, moments=None):
+        """mcmc.py:773-1032 on pooled sufficient statistics; one all-reduce.
+        `moments`: what `engine.fetch_moments()` returned for the checkpoint (None: read them
+        out now, synchronously)."""
         d, eng = self.spec.d, self.engine
-        n_snap, gs, S = eng.read_moments(reset=True)  # synchronises the stream
-        eng.sync()
-        c = eng.counters()
+        if moments is None:
+            n_snap, gs, S = eng.read_moments(reset=True)  # synchronises the stream
+            eng.sync()
+            c = eng.counters()
+        else:
+            n_snap, gs, S, c = moments
         if n_snap:
             self._intervals.append((n_snap, gs, S))
         if not self._intervals:

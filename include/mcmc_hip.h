@@ -172,6 +172,19 @@ int mcmc_hip_accumulate_moments(mcmc_hip_ctx* h);
  * walkers of x; pooled_S[d*d] = sum over everything of x x^T.  reset != 0 clears them. */
 int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
                           double* pooled_S, int32_t reset);
+/* restores accumulators read with reset == 0 (resume: the snapshots taken since the last
+ * read-out are part of the state) */
+int mcmc_hip_set_moments(mcmc_hip_ctx* h, int64_t n_snapshots, const double* group_sum,
+                         const double* pooled_S);
+/* The same read-out without stalling the host (the learn/convergence checkpoint off the
+ * critical path): `request` queues the device->host copies of the accumulators and of the
+ * accept counter behind the work already in the stream, resets the accumulators in stream
+ * order and returns at once; `fetch` waits for those copies only -- launches queued AFTER the
+ * request keep running meanwhile.  counters[2] = (steps per walker, accepted steps of all
+ * walkers) at the time of the request.  One request may be pending at a time. */
+int mcmc_hip_request_moments(mcmc_hip_ctx* h);
+int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
+                           double* pooled_S, int64_t counters[2]);
 
 /* The R-1 arithmetic of MCMC.check_convergence_and_learn_proposal (mcmc.py:856-889) on
  * reduced sufficient statistics (what the RCCL all-reduce of SURVEY 8e carries):

@@ -195,5 +195,19 @@ class OracleEngine:
             self._S[...] = 0
         return out
 
+    def set_moments(self, n_snapshots, group_sum, pooled_S):
+        self._n_snap = int(n_snapshots)
+        self._gsum[...] = group_sum
+        self._S[...] = pooled_S
+
+    def request_moments(self):
+        n, gs, S = self.read_moments(reset=True)
+        c = self.counters()
+        self._requested = (n, gs, S, {"steps": c["steps"], "accepted": c["accepted"]})
+
+    def fetch_moments(self):
+        out, self._requested = self._requested, None
+        return out
+
     def close(self):
         self.closed = True
