@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/final (written by tools/gpu_final.sh on the GPU box) into the committed
-evidence under profiles/: r01_bench.json, r01_gpu_tests.log, r01_kernel_stats.txt,
-r01_pmc.txt and traffic.json (the per-launch HBM bytes bench.py copies into roofline.traffic).
+evidence under profiles/: <rnd>_bench.json, <rnd>_gpu_tests.log, <rnd>_kernel_stats.txt,
+<rnd>_pmc.txt and an entry of traffic.json (per-launch HBM bytes and VALU instructions of the
+dominant kernel, which bench.py quotes in its roofline block).
 
     python tools/collect_evidence.py [round-prefix, default r01] [source dir under gpurun_out,
                                       default final; e.g. `r01_d100 d100` after tools/gpu_d100.sh]
@@ -15,14 +16,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-CMD = "python bench.py --no-cpu-baseline --steps 20 --warmup 4  (d = 100: --dim 100 --steps 10 --warmup 2)"
+CMD = "python bench.py --no-cpu-baseline --no-variants --steps 20 --warmup 4"
 
 
 def main():
     global SRC
+    global CMD
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     if len(sys.argv) > 2:
         SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2])
+    if os.path.exists(os.path.join(SRC, "cmd.txt")):
+        with open(os.path.join(SRC, "cmd.txt")) as f:
+            CMD = f.read().strip()
     shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{rnd}_bench.json"))
     if os.path.exists(os.path.join(SRC, "gpu_tests.log")):
         shutil.copy(os.path.join(SRC, "gpu_tests.log"), os.path.join(DST, f"{rnd}_gpu_tests.log"))
@@ -65,6 +70,7 @@ def main():
             "steps_per_launch": wl["metropolis_steps_per_launch"],
             "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
             "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+            "sq_insts_valu": vals.get("SQ_INSTS_VALU"),
             "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; KiB; "
                     "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, "
                     "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated"}

@@ -1,15 +1,30 @@
-# Round-end evidence run: GPU tests, smoke, the bench line, rocprofv3 kernel-trace stats and
-# separate PMC passes of the SAME bench command.  Outputs under gpurun_out/final/.
+# Round evidence run: GPU tests, smoke, the bench line, then rocprofv3 kernel-trace stats and
+# separate PMC passes of the SAME bench command (headline config, both evaluation modes, and
+# d = 100).  Outputs under gpurun_out/final{,_full,_d100}/; tools/collect_evidence.py turns them
+# into profiles/.   usage: bash tools/gpu_final.sh [quick]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-CMD="python bench.py --no-cpu-baseline --steps 20 --warmup 4"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SMEM -d $OUT/pmc_sq -o p -- $CMD > /dev/null 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p -- $CMD > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > /dev/null 2>&1
-ls $OUT
+prof() {  # prof <outdir> <bench args...>
+  OUT=$1; shift
+  rm -rf $OUT; mkdir -p $OUT
+  CMD="python bench.py --no-cpu-baseline --no-variants --steps 20 --warmup 4 $*"
+  echo "$CMD" > $OUT/cmd.txt
+  timeout 600 $CMD > $OUT/bench.json 2> $OUT/bench.err
+  rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SMEM -d $OUT/pmc_sq -o p -- $CMD > /dev/null 2>&1
+  rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p -- $CMD > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $CMD > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $CMD > /dev/null 2>&1
+}
+mkdir -p gpurun_out/final
+if [ "$1" != "quick" ]; then
+  timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/final_gpu_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1
+  timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
+fi
+prof gpurun_out/final
+prof gpurun_out/final_full --evaluation full
+prof gpurun_out/final_d100 --dim 100 --steps 10 --warmup 2
+[ -f gpurun_out/final_gpu_tests.log ] && cp gpurun_out/final_gpu_tests.log gpurun_out/final/gpu_tests.log
+[ -f gpurun_out/final_bench.json ] && cp gpurun_out/final_bench.json gpurun_out/final/bench_full_line.json
+ls gpurun_out/final gpurun_out/final_full gpurun_out/final_d100
