@@ -303,6 +303,7 @@ struct mcmc_hip_ctx {
     // padded prior constants, row-major L^-1 and the mean of the one mode
     bool incremental = false;
     bool y_valid = false;
+    bool own_basis = false;     // MCMC_HIP_FLAG_OWN_BASIS (d > 1): a Haar basis per walker
     DevBuf<double> y, VU, inc_prior, inc_Lrow, inc_mean;
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
     // stream-ordered proposal refresh: pinned host staging
@@ -440,6 +441,11 @@ int upload_constants(mcmc_hip_ctx* h)
     HIP_TRY(h, hipMemcpyAsync(h->cblock.p, c.data(), sizeof(double) * c.size(),
                               hipMemcpyHostToDevice, h->stream));
     std::vector<double> lcol;
+    if (h->own_basis && !h->kb && K > 0) {   // the general step kernel reads row-major L^-1
+        HIP_TRY(h, h->dLrow.resize(h->Linv.size()));
+        HIP_TRY(h, hipMemcpyAsync(h->dLrow.p, h->Linv.data(), sizeof(double) * h->Linv.size(),
+                                  hipMemcpyHostToDevice, h->stream));
+    }
     if (h->kb && K > 0) {
         // row-major L^-1 per mode (evaluator) and the column-major, zero-padded [dp][dp]
         // copy of mode 0 that the column-sweep step kernel stages in LDS
@@ -592,8 +598,12 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "walker_offset must be a multiple of group_size");
     if (!(cfg->temperature > 0) || !(cfg->proposal_scale > 0))
         return fail(nullptr, MCMC_HIP_ERR_ARG, "temperature and proposal_scale must be > 0");
-    if (cfg->flags & ~MCMC_HIP_FLAG_INCREMENTAL)
+    if (cfg->flags & ~(MCMC_HIP_FLAG_INCREMENTAL | MCMC_HIP_FLAG_OWN_BASIS))
         return fail(nullptr, MCMC_HIP_ERR_ARG, "unknown flags 0x%x", (unsigned)cfg->flags);
+    if ((cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) && (cfg->flags & MCMC_HIP_FLAG_OWN_BASIS))
+        return fail(nullptr, MCMC_HIP_ERR_ARG,
+                    "incremental evaluation needs the shared basis (the whitened direction is "
+                    "shared with it)");
     if ((cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) &&
         (cfg->d < 2 || cfg->group_size % 64 != 0 || cfg->emit_capacity > 0 ||
          !mcmc_hip_launch_whiten_state))
@@ -631,6 +641,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     h->G = h->W / h->gs;
     h->shift.assign(h->d, 0.0);
     h->incremental = (cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) != 0;
+    h->own_basis = (cfg->flags & MCMC_HIP_FLAG_OWN_BASIS) != 0 && cfg->d > 1;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(nullptr, MCMC_HIP_ERR_DEVICE, "hipStreamCreate failed");
@@ -1207,22 +1218,30 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     // d > 32: what the matrix-core / two-wave / column-sweep kernels leave out (mixtures, `one`,
     // periodic parameters, emitted rows; odd ensemble sizes with normal priors or d > 112) runs
     // on the general kernel
+    if (h->own_basis && (h->blocked || drag))
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "shared_basis: False serves a single parameter block without dragging");
     const bool general_big =
-        h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0 ||
-                  (h->W % 256 != 0 && (big_norm || h->d > 112)));
+        h->own_basis ||
+        (h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0 ||
+                   (h->W % 256 != 0 && (big_norm || h->d > 112))));
+    // basis "groups": the walker groups, or every walker on its own
+    const int n_basis = h->own_basis ? h->W : h->G;
+    const uint32_t basis0 = h->own_basis ? h->cfg.walker_offset
+                                         : h->cfg.walker_offset / (uint32_t)h->gs;
     if (general_big && sizeof(double) * 64 * (size_t)(2 * h->d + std::max(1, h->K)) > (160u << 10))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "d=%d with %d modes does not fit the general d > 32 kernel (LDS)", h->d, h->K);
     // two slabs per group of a workgroup (workgroups are 256, 128 or 64 walkers wide)
     const int wg = (h->W % 256 == 0) ? 256 : (h->W % 128 == 0) ? 128 : 64;
-    if (!h->kb && !drag &&
+    if (!h->kb && !drag && !h->own_basis &&
         (2 * (size_t)std::max(1, wg / h->gs) * dd + (h->K > 1 ? (size_t)h->K * wg : 0)) * sizeof(double) >
             (160u << 10))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "a cycle of %d steps needs %zu KiB of LDS per group: use group_size 256 or "
                     "smaller oversampling factors", Lc, dd * sizeof(double) / 1024);
     // directions buffer: at most ~256 MiB of cycles per launch
-    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)n_basis));
     // dragging: the fast blocks' directions, n_drag columns per step
     const int Lf = drag ? block_slots(h, 2) : 0;
     const size_t ddf = drag ? (size_t)mcmc::v_slab_cols(Lf, h->d) : 0;
@@ -1249,15 +1268,15 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                 const int rc = blocked_basis(h, drag ? 1 : 0, c0, ncyc, Lc, dd, h->V, h->vflag, any_1d);
                 if (rc != MCMC_HIP_OK) return rc;
             } else {
-                HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+                HIP_TRY(h, h->V.resize((size_t)n_basis * ncyc * dd));
                 mcmc::BasisArgs b{};
                 b.T = h->dT.p; b.V = h->V.p;
-                b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+                b.group0 = basis0;
                 b.cycle0 = (uint32_t)c0;
                 b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
                 b.ncyc = ncyc;
-                if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
-                else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+                if (h->kb) HIP_TRY(h, h->kb->basis(b, n_basis, h->d, h->stream));
+                else HIP_TRY(h, h->k->basis(b, n_basis, h->stream));
             }
         }
         {
@@ -1300,6 +1319,8 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                 g.s = a;
                 g.Lrow = h->dLrow.p;
                 g.d = h->d;
+                g.ld = h->kb ? mcmc::v_ld(h->d) : h->d;
+                g.own_basis = h->own_basis ? 1 : 0;
                 for (int q = 0; q < 4; ++q) g.norm_mask4[q] = h->norm_mask4[q];
                 for (int i = 0; i < h->d; ++i)
                     if (h->periodic[i]) g.periodic_mask4[i >> 5] |= 1u << (i & 31);

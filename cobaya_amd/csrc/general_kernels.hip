@@ -1,13 +1,18 @@
-// The GENERAL Metropolis step for 32 < d <= 128 (gfx950): everything the specialised d > 32
-// kernels leave out -- Gaussian mixtures (and `one`), periodic parameters, emitted rows with
-// burn-in, normal priors and ensembles that are not whole 256-walker workgroups.  Not a hot
-// kernel: one lane per walker with state and trial in LDS (dimension-major, conflict-free), the
-// problem constants read from global memory at wave-uniform addresses; run-time d, compiled once.
+// The GENERAL Metropolis step (gfx950), run-time d, compiled once.  It serves
+//   * 32 < d <= 128: everything the specialised d > 32 kernels leave out -- Gaussian mixtures
+//     (and `one`), periodic parameters, emitted rows with burn-in, normal priors and ensembles
+//     that are not whole 256-walker workgroups;
+//   * 2 <= d <= 128 with MCMC_HIP_FLAG_OWN_BASIS (`shared_basis: False`): every walker reads the
+//     columns of its OWN Haar basis (proposal.py:59-69 to the letter) -- the reference-faithful
+//     control of the shared-basis design, not a fast path.
+// Not a hot kernel: one lane per walker with state and trial in LDS (dimension-major,
+// conflict-free), the problem constants read from global memory at wave-uniform addresses.
 //
 // Restates the same reference lines as walker_kernels.hip (mcmc.py:545-562, 670-748;
 // prior.py:658-676, 733-763; gaussian_mixture.py:138-163) in the d > 32 order of the
 // specification (DESIGN.md "Ensemble specification", oracle/mcmc_oracle.c eval_point): sums over
-// dimensions / rows as four interleaved chains combined (s0 + s1) + (s2 + s3).
+// dimensions / rows as four interleaved chains combined (s0 + s1) + (s2 + s3) -- and for d <= 32
+// (own-basis mode only) in the d <= 32 order: one ascending chain.
 #include "det_math.h"
 #include "kernels.h"
 
@@ -35,8 +40,10 @@ __global__ void __launch_bounds__(64) step_general_kernel(const GeneralStepArgs 
     double* const st = smem + 64 * d + tid;   // trial
     double* const sa = smem + 128 * d + tid;  // mode log-pdfs a_k at sa[64 k]
     const double* __restrict__ C = a.cblock;
-    const int group = __builtin_amdgcn_readfirstlane(w / a.group_size);   // group_size >= 64
-    const int ldv = v_ld(d);
+    // shared basis: the group of the wave (group_size >= 64); own basis: one "group" per walker
+    const int group = b.own_basis ? w : __builtin_amdgcn_readfirstlane(w / a.group_size);
+    const int ldv = b.ld;
+    const int cm = d > 32 ? 3 : 0;   // chain of dimension / row i: i & cm
     const double* const Vgrp = a.V + (size_t)group * a.ncyc * (size_t)a.slab;
 
     for (int i = 0; i < d; ++i) sx[64 * i] = a.x[(size_t)i * W + w];
@@ -67,10 +74,10 @@ __global__ void __launch_bounds__(64) step_general_kernel(const GeneralStepArgs 
             inb = inb & (t <= hi) & (t >= lo);
             if ((b.norm_mask4[i >> 5] >> (i & 31)) & 1u) {
                 const double q = (t - C[cl.loc() + i]) / C[cl.scale() + i];
-                sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, C[cl.mls() + i]);
+                sc[i & cm] = sc[i & cm] + fma(-0.5 * q, q, C[cl.mls() + i]);
             }
         }
-        const double lp = a.uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
+        const double lp = a.uniform_logp + (d > 32 ? (sc[0] + sc[1]) + (sc[2] + sc[3]) : sc[0]);
         // ---- likelihood (gaussian_mixture.py:138-163); lanes outside the support skip it
         double ll = 0.0;
         if (inb && K >= 1) {
@@ -82,9 +89,9 @@ __global__ void __launch_bounds__(64) step_general_kernel(const GeneralStepArgs 
                 for (int j = 0; j < d; ++j) {
                     double y = 0.0;
                     for (int i = 0; i <= j; ++i) y = fma(Lk[j * d + i], st[64 * i] - mu[i], y);
-                    pc[j & 3] = fma(y, y, pc[j & 3]);
+                    pc[j & cm] = fma(y, y, pc[j & cm]);
                 }
-                const double chi2 = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+                const double chi2 = d > 32 ? (pc[0] + pc[1]) + (pc[2] + pc[3]) : pc[0];
                 const double ak = -0.5 * (C[cl.cnorm() + k] + chi2);
                 sa[64 * k] = ak;
                 amax = (ak > amax) ? ak : amax;

@@ -191,6 +191,8 @@ struct GeneralStepArgs {
     int d;
     uint32_t norm_mask4[4];       // one bit per dimension with a normal prior
     uint32_t periodic_mask4[4];   // ... with a periodic parameter
+    int ld;                       // column stride of V: d (d <= 32 layout) or v_ld(d)
+    int own_basis;                // every walker has its own (group, cycle) slabs of V
 };
 
 // Incremental evaluation (incremental_kernels.hip): one Gaussian mode, non-periodic priors,

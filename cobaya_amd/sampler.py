@@ -230,6 +230,9 @@ class EnsembleMCMC:
                    and self.oversampling_factors[0] == 1 and not self.drag
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
+        if not self.shared_basis and (len(self.blocks) > 1 or self.oversampling_factors[0] != 1):
+            self._fail("shared_basis: False serves a single parameter block without "
+                       "oversampling or dragging")
         if self.evaluation == "incremental" and not can_inc:
             self._fail("evaluation: incremental serves one Gaussian mode with non-periodic "
                        "priors, a single parameter block, emit: snapshots, d >= 2 and a "

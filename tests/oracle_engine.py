@@ -25,8 +25,10 @@ class OracleEngine:
                  emit_capacity=0, shared_basis=True, incremental=False):
         if n_walkers % group_size:
             raise EngineError(ERR_ARG, "n_walkers must be a multiple of group_size")
-        if not shared_basis:
-            raise EngineError(ERR_ARG, "the oracle double only does shared bases")
+        # shared_basis False: every walker is its own basis "group" (the R-1 groups stay)
+        self.own_basis = (not shared_basis) and d > 1
+        if self.own_basis and incremental:
+            raise EngineError(ERR_ARG, "incremental evaluation needs the shared basis")
         self.d, self.W, self.group_size = int(d), int(n_walkers), int(group_size)
         self.G = self.W // self.group_size
         self.K = None
@@ -86,7 +88,8 @@ class OracleEngine:
             kinds, a, b, per = self._prior
             bl = self._blocking or {}
             self._problem = O.Problem(
-                self.d, kinds, a, b, per, **self._target, group_size=self.group_size,
+                self.d, kinds, a, b, per, **self._target,
+                group_size=1 if self.own_basis else self.group_size,
                 seed=self.seed, temperature=self.temperature, max_tries=self.max_tries,
                 incremental=self.incremental, **bl)
             if self._cov is not None:
@@ -154,6 +157,9 @@ class OracleEngine:
 
     # -- sampling -----------------------------------------------------------------------
     def step(self, n_steps):
+        if self.own_basis and self._blocking:
+            raise EngineError(ERR_ARG, "shared_basis: False serves a single parameter block "
+                                       "without dragging")
         if self.incremental and (self.K != 1 or self._blocking or
                                  (self._prior[3] is not None and self._prior[3].any())):
             raise EngineError(ERR_ARG, "incremental evaluation serves one Gaussian mode with "

@@ -39,7 +39,7 @@ def random_target(d, K, rng, spread=0.05):
 def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, T=1.0,
               burn_in=0, cap=0, weights=None, normalized=True, rng=None, walker_offset=0,
               max_tries=None, blocks=None, over=None, drag_last_slow=-1, drag_steps=0,
-              own_constants=False, incremental=False):
+              own_constants=False, incremental=False, shared_basis=True):
     """own_constants=False hands the oracle the constants the engine derived on the host (T,
     L^-1, log-normalisations), so that the comparison isolates the KERNELS, bit for bit;
     own_constants=True lets the oracle derive them itself with the numpy recipe (the
@@ -50,7 +50,7 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
     b = [1.0] * d if b is None else b
     eng = E.Engine(d, W, group_size=gs, seed=seed, temperature=T, burn_in=burn_in,
                    emit_capacity=cap, walker_offset=walker_offset, max_tries=max_tries,
-                   incremental=incremental)
+                   incremental=incremental, shared_basis=shared_basis)
     eng.set_prior(kinds, a, b, periodic)
     if K == 0:
         eng.set_target_one()
@@ -77,7 +77,8 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
                      weights=weights, normalized=normalized, T=T_orc,
                      blocks=blocks, oversampling=over, drag_last_slow=drag_last_slow,
                      drag_steps=drag_steps,
-                     group_size=gs, seed=seed, temperature=T, max_tries=max_tries,
+                     group_size=gs if (shared_basis or d == 1) else 1, seed=seed,
+                     temperature=T, max_tries=max_tries,
                      derived=None if own_constants else eng.derived_constants(),
                      incremental=incremental)
     m0 = means[0] if K else np.full(d, 0.5)
@@ -729,3 +730,46 @@ def test_incremental_resume_carries_the_whitened_residual():
     for k in ("x", "y", "logpost", "weight", "n_accept"):
         assert_bit_equal(np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64), k)
     eng.close(), eng2.close()
+
+
+# ------------------------------------------------------------------ a Haar basis per walker
+@pytest.mark.parametrize("d,W,gs,K,extra", [
+    (2, 128, 64, 1, {}), (3, 128, 64, 2, {"weights": [0.3, 0.7]}), (8, 192, 64, 1, {}),
+    (30, 128, 64, 1, {}), (30, 256, 256, 1, {"T": 2.0}), (5, 128, 64, 0, {}),
+    (40, 128, 64, 1, {}), (100, 64, 64, 1, {})])
+def test_own_basis_steps_bit_exact(d, W, gs, K, extra):
+    """`shared_basis: False` (MCMC_HIP_FLAG_OWN_BASIS): every walker draws its own Haar basis per
+    cycle, as every chain of the reference does (proposal.py:59-69).  Against the oracle run
+    with one-walker groups -- the basis stream of "group" = global walker id."""
+    eng, prob, st = make_pair(d, W, gs, K=K, shared_basis=False, **extra)
+    compare_state(eng, st)
+    for n in (1, d + 2, 2 * d + 1):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+    assert eng.counters()["accepted"] == int(st.n_accept.sum())
+    assert "step_general_kernel" in eng.last_step_kernel()
+    # the R-1 groups are still the walker groups
+    shift = st.x.mean(0)
+    eng.set_moment_shift(shift)
+    eng.accumulate_moments()
+    gsum, S = O.moments(st.x, gs, shift=shift)
+    n, g_gs, g_S = eng.read_moments()
+    assert_bit_equal(g_gs, gsum, "group sums")
+    eng.close()
+
+
+def test_own_basis_periodic_rows_and_offsets_bit_exact():
+    d, W, gs = 6, 128, 64
+    per = [0, 1, 0, 0, 1, 0]
+    eng, prob, st = make_pair(d, W, gs, periodic=per, shared_basis=False, cap=40, burn_in=3,
+                              walker_offset=4096)
+    for n in (9, 20):
+        eng.step(n)
+        st.run(n, walker0=4096, n_threads=4)
+        compare_state(eng, st)
+    rows_e, rows_o = eng.drain_samples(), st.drain()
+    rows_o[:, 0] += 4096
+    assert_bit_equal(rows_e, rows_o, "emitted rows")
+    eng.close()

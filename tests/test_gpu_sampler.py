@@ -517,3 +517,43 @@ def test_rccl_path_with_one_rank():
     assert res["nccl"]["progress"] == res["none"]["progress"]
     assert res["nccl"]["proposal_cov"] == res["none"]["proposal_cov"]
     assert res["nccl"]["x_sum"] == res["none"]["x_sum"]
+
+
+def test_shared_and_own_basis_sample_the_same_posterior():
+    """SURVEY 7 "hard parts" / App. D `shared_basis`: the design choice -- the walkers of a
+    group share one Haar basis per cycle (plus a private sign) -- against the
+    reference-faithful control `shared_basis: False`, where every walker draws its own basis
+    like every chain of the reference (proposal.py:59-69).  Same target (BASELINE config 2),
+    same budget: posterior mean and covariance agree with the truth and with each other, the
+    acceptance rates agree, and R-1 has the same size."""
+    t = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden",
+                                           "targets.npz"))
+    mean, cov = t["mean_d30"], t["cov_d30"]
+    sig = np.sqrt(np.diag(cov))
+    names = [f"p{i}" for i in range(30)]
+    out = {}
+    for shared in (True, False):
+        info = {"likelihood": {"gaussian_mixture": {"means": [mean], "covs": [cov]}},
+                "params": {n: {"prior": {"min": 0, "max": 1},
+                               "ref": {"dist": "norm", "loc": float(mean[i]),
+                                       "scale": float(sig[i])}} for i, n in enumerate(names)},
+                "sampler": {"mcmc_hip": {"seed": 5, "n_walkers": 4096, "group_size": 64,
+                                         "shared_basis": shared, "steps_per_launch": "4d",
+                                         "covmat": cov, "covmat_params": names,
+                                         "learn_proposal": False, "Rminus1_stop": 0.0,
+                                         "max_samples": 1.5e6, "snapshot_every": 120}}}
+        updated, s = run(info)
+        assert s.engine.last_step_kernel().startswith(
+            "mcmc::step_inc_kernel" if shared else "mcmc::step_general_kernel")
+        coll = s.products(skip_samples=0.3)["sample"]
+        out[shared] = (coll.mean(), coll.cov(), float(s.progress["acceptance_rate"].iloc[-1]),
+                       float(s.progress["Rminus1"].iloc[-1]), len(coll))
+        s.close()
+    for shared in (True, False):
+        m, c, acc, r, n = out[shared]
+        assert n >= 20 * 4096
+        assert np.max(np.abs(m - mean) / sig) < 0.03
+        assert np.max(np.abs(c - cov) / np.outer(sig, sig)) < 0.05
+    assert abs(out[True][2] - out[False][2]) < 0.01
+    assert 0.5 < out[True][3] / out[False][3] < 2.0
+    assert np.max(np.abs(out[True][0] - out[False][0]) / sig) < 0.04

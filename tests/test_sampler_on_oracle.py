@@ -147,3 +147,27 @@ def test_a_single_group_is_refused():
         OnOracle({"n_walkers": 64, "group_size": 64}, ProblemSpec.from_info(QUICK))
     with pytest.raises(LoggedError, match="multiple of group_size"):
         OnOracle({"n_walkers": 200, "group_size": 64}, ProblemSpec.from_info(QUICK))
+
+
+def test_own_basis_option_and_incremental_option_reach_the_engine():
+    """`shared_basis: False` and `evaluation` are plumbed to the engine; the combinations that
+    make no sense are refused with the reference's kind of error."""
+    spec = ProblemSpec.from_info(QUICK)
+    s = OnOracle({"n_walkers": 128, "group_size": 64, "shared_basis": False, "seed": 1,
+                  "max_samples": 3000, "Rminus1_stop": 0.0}, spec)
+    assert s.engine.own_basis and not s.incremental
+    s.run()
+    assert s.n() >= 3000
+    s2 = OnOracle({"n_walkers": 128, "group_size": 64, "seed": 1, "max_samples": 3000,
+                   "Rminus1_stop": 0.0}, spec)
+    assert s2.incremental and s2.engine.incremental      # auto: one mode, snapshots
+    s3 = OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "full", "seed": 1}, spec)
+    assert not s3.incremental
+    with pytest.raises(LoggedError, match="incremental"):
+        OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "incremental",
+                  "emit": "chains"}, spec)
+    with pytest.raises(LoggedError, match="incremental"):
+        OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "incremental",
+                  "shared_basis": False}, spec)
+    with pytest.raises(LoggedError, match="evaluation must be"):
+        OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "sometimes"}, spec)
