@@ -486,9 +486,10 @@ int upload_constants(mcmc_hip_ctx* h)
             pr[i] = i < d ? h->lo[i] : -INFINITY;
             pr[dpad + i] = i < d ? h->hi[i] : INFINITY;
             pr[2 * dpad + i] = i < d ? h->loc[i] : 0.0;
-            // scale = +inf marks "no normal prior here" (kind 0 and the padding)
-            pr[3 * dpad + i] = (i < d && h->kind[i] == 1) ? h->scale[i] : INFINITY;
-            pr[4 * dpad + i] = i < d ? h->mls[i] : 0.0;
+            // 1/scale = 0 and mls = 0: "no normal prior here" (kind 0 and the padding)
+            const bool nrm = i < d && h->kind[i] == 1;
+            pr[3 * dpad + i] = nrm ? 1.0 / h->scale[i] : 0.0;
+            pr[4 * dpad + i] = nrm ? h->mls[i] : 0.0;
         }
         HIP_TRY(h, h->inc_prior.resize(pr.size()));
         HIP_TRY(h, hipMemcpyAsync(h->inc_prior.p, pr.data(), sizeof(double) * pr.size(),

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     constexpr bool kBoundsInRegs = MODE > 0 && DQ <= 12;
     constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;
     constexpr bool NORMP = MODE == 2;
+    constexpr bool kNormInRegs = NORMP && DQ <= 8;
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
@@ -111,6 +112,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 
     const double blo = a.box_lo, bhi = a.box_hi;
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
+    // normal priors, branch-free: a dimension without one has 1/scale = 0 and mls = 0, so its
+    // term is fma(-0, 0, 0) = +0 and leaves the chain untouched
+    double nloc[kNormInRegs ? DQ : 1], ninv[kNormInRegs ? DQ : 1], nmls[kNormInRegs ? DQ : 1];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
@@ -121,6 +125,11 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         if (kBoundsInRegs) {
             lo[kk] = a.prior[i];               // padded: -inf / +inf beyond d
             hi[kk] = a.prior[dpad + i];
+        }
+        if (kNormInRegs) {
+            nloc[kk] = a.prior[2 * dpad + i];
+            ninv[kk] = a.prior[3 * dpad + i];
+            nmls[kk] = a.prior[4 * dpad + i];
         }
     }
     if (kBoundsInLds)
@@ -178,11 +187,11 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         pc = fma(yt, yt, pc);
                         if (NORMP) {
                             const int i = 4 * kk + c;
-                            const double scale = a.prior[3 * dpad + i];
-                            if (scale < INFINITY) {
-                                const double qq = (t - a.prior[2 * dpad + i]) / scale;
-                                sc = sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
-                            }
+                            const double loc = kNormInRegs ? nloc[kk] : a.prior[2 * dpad + i];
+                            const double inv = kNormInRegs ? ninv[kk] : a.prior[3 * dpad + i];
+                            const double mls = kNormInRegs ? nmls[kk] : a.prior[4 * dpad + i];
+                            const double qq = (t - loc) * inv;
+                            sc = sc + fma(-0.5 * qq, qq, mls);
                         }
                     }
                     // a walker outside the prior support anywhere gets chi2 = +inf

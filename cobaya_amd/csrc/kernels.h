@@ -201,7 +201,8 @@ struct IncStepArgs {
     StepArgs s;            // state, keys, step0, n_steps, uniform_logp, temperature, cnorm0, ...
     double* y;             // [d][W] whitened residual L^-1 (x - mu) of the current points
     const double* VU;      // [G][n_steps][dq][4][2]: (v_i, u_i) of every step, zero beyond d
-    const double* prior;   // [5][4 dq]: lo, hi, loc, scale, mls; beyond d: -inf, +inf, 0, inf, 0
+    const double* prior;   // [5][4 dq]: lo, hi, loc, 1/scale, mls; a dimension without a normal
+                           // prior has 1/scale = 0 and mls = 0; beyond d: -inf, +inf, 0, 0, 0
     int d, dq;
     int has_norm;          // some prior is normal
     int box;               // every prior is uniform on the same interval [box_lo, box_hi]

@@ -584,7 +584,9 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
         double sc[4] = {0.0, 0.0, 0.0, 0.0}, pc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = 0; i < d; ++i) {
             if (p->kind[i] == 1) {
-                double q = (t[i] - p->loc[i]) / p->scale[i];
+                /* (multiplication by the reciprocal of the scale, formed once: 1 ulp from the
+                 * division of eval_point, a fifth of its instructions) */
+                double q = (t[i] - p->loc[i]) * (1.0 / p->scale[i]);
                 sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, p->mls[i]);
             }
             yt[i] = fma(r, u[i], y[i]);
