@@ -266,8 +266,8 @@ extern "C" hipError_t mcmc_hip_launch_inc_step_9(const mcmc::IncStepArgs*, hipSt
 extern "C" hipError_t mcmc_hip_launch_inc_step_17(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_inc_step_25(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, const double* mean,
-                                                   const double* Lrow, int d, int W, hipStream_t st)
-    __attribute__((weak));
+                                                   const double* Lrow, int d, int W, int K,
+                                                   hipStream_t st) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* a, int n_groups,
                                                         hipStream_t st) __attribute__((weak));
 
@@ -479,8 +479,9 @@ int upload_constants(mcmc_hip_ctx* h)
         HIP_TRY(h, hipMemcpyAsync(h->dLcol.p, lcol.data(), sizeof(double) * lcol.size(),
                                   hipMemcpyHostToDevice, h->stream));
     }
-    if (h->incremental && K == 1) {
+    if (h->incremental && K >= 1 && K <= 4) {
         const int dq = (d + 3) / 4, dpad = 4 * dq;
+        HIP_TRY(h, h->y.resize((size_t)K * d * h->W));
         std::vector<double> pr((size_t)5 * dpad, 0.0);
         for (int i = 0; i < dpad; ++i) {
             pr[i] = i < d ? h->lo[i] : -INFINITY;
@@ -494,11 +495,11 @@ int upload_constants(mcmc_hip_ctx* h)
         HIP_TRY(h, h->inc_prior.resize(pr.size()));
         HIP_TRY(h, hipMemcpyAsync(h->inc_prior.p, pr.data(), sizeof(double) * pr.size(),
                                   hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, h->inc_Lrow.resize((size_t)d * d));
-        HIP_TRY(h, hipMemcpyAsync(h->inc_Lrow.p, h->Linv.data(), sizeof(double) * d * d,
+        HIP_TRY(h, h->inc_Lrow.resize((size_t)K * d * d));
+        HIP_TRY(h, hipMemcpyAsync(h->inc_Lrow.p, h->Linv.data(), sizeof(double) * K * d * d,
                                   hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, h->inc_mean.resize((size_t)d));
-        HIP_TRY(h, hipMemcpyAsync(h->inc_mean.p, h->mean.data(), sizeof(double) * d,
+        HIP_TRY(h, h->inc_mean.resize((size_t)K * d));
+        HIP_TRY(h, hipMemcpyAsync(h->inc_mean.p, h->mean.data(), sizeof(double) * K * d,
                                   hipMemcpyHostToDevice, h->stream));
         h->y_valid = false;
     }
@@ -660,7 +661,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         acc(h->rows.resize(W * (size_t)cfg->emit_capacity * (d + 4)));
         acc(h->nrows.resize(W));
     }
-    if (h->incremental) acc(h->y.resize(W * d));
+    // (y is sized when the target is known: [K][d][W])
     acc(hipHostMalloc((void**)&h->pin_mom, sizeof(double) * (G * d + np + 2), hipHostMallocDefault));
     acc(hipHostMalloc((void**)&h->pin_T, sizeof(double) * 4 * d * d, hipHostMallocDefault));
     acc(hipEventCreateWithFlags(&h->mom_event, hipEventDisableTiming));
@@ -1118,16 +1119,20 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
 int step_incremental(mcmc_hip_ctx* h, int n_steps)
 {
     const int d = h->d, dq = (d + 3) / 4;
-    if (h->K != 1 || h->any_periodic || h->blocked || h->drag_last_slow >= 0)
+    const int K = h->K;
+    if (K < 1 || K > 4 || (K > 1 && dq > 16) || h->any_periodic || h->blocked ||
+        h->drag_last_slow >= 0)
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation serves one Gaussian mode with non-periodic priors "
-                    "and a single parameter block; use evaluation: full for this model");
+                    "incremental evaluation serves one Gaussian mode (or a mixture of up to four "
+                    "at d <= 64) with non-periodic priors and a single parameter block; use "
+                    "evaluation: full for this model");
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                 : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
     if (!launch || !mcmc_hip_launch_whiten_directions)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
     const unsigned long long R = 40ull * (unsigned long long)d, dd_steps = (unsigned long long)d;
-    const size_t colb = 8 * (size_t)dq;   // doubles per (group, step) column of (v, u) pairs
+    // doubles per (group, step) column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
+    const size_t colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
     const int max_steps_vu =
         (int)std::max<size_t>(4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)h->G));
     const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(d) : (size_t)mcmc::v_slab(d);
@@ -1137,7 +1142,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     while (left > 0) {
         if (!h->y_valid || h->step % R == 0) {
             HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
-                                                    d, h->W, h->stream));
+                                                    d, h->W, K, h->stream));
             h->y_valid = true;
         }
         const unsigned long long c0 = h->step / dd_steps;
@@ -1162,7 +1167,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             mcmc::IncDirArgs w{};
             w.V = h->V.p; w.Lrow = h->inc_Lrow.p; w.VU = h->VU.p;
             w.step0 = h->step; w.cycle0 = c0; w.n_steps = n; w.ncyc = ncyc;
-            w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq;
+            w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq; w.n_modes = K;
             HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
         }
         {
@@ -1172,7 +1177,12 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.s.loglike = h->loglike.p; a.s.weight = h->weight_i.p; a.s.prior_rej = h->prej.p;
             a.s.burn_left = h->burn.p; a.s.n_accept = h->nacc.p; a.s.stuck = h->stuck.p;
             a.s.accept_total = h->acc_total.p;
-            a.s.W = h->W; a.s.n_modes = 1; a.s.group_size = h->gs;
+            a.s.W = h->W; a.s.n_modes = K; a.s.group_size = h->gs;
+            a.s.cblock = h->cblock.p;
+            {
+                const ConstLayout cl{d, K};
+                a.n_modes = K; a.cnorm_off = cl.cnorm(); a.weight_off = cl.weight();
+            }
             a.s.walker0 = h->cfg.walker_offset;
             a.s.key0 = (uint32_t)h->cfg.seed; a.s.key1 = (uint32_t)(h->cfg.seed >> 32);
             a.s.step0 = h->step; a.s.n_steps = n;
@@ -1598,11 +1608,11 @@ int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (!h->y_valid) {
         HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p, h->d,
-                                                h->W, h->stream));
+                                                h->W, h->K, h->stream));
         h->y_valid = true;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const size_t W = h->W, d = h->d;
+    const size_t W = h->W, d = (size_t)h->d * (size_t)h->K;   // device: [K d][W]
     std::vector<double> yt(W * d);
     HIP_TRY(h, hipMemcpy(yt.data(), h->y.p, sizeof(double) * W * d, hipMemcpyDeviceToHost));
     for (size_t w = 0; w < W; ++w)
@@ -1617,7 +1627,7 @@ int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y)
     if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "set_full_state must precede set_whitened");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const size_t W = h->W, d = h->d;
+    const size_t W = h->W, d = (size_t)h->d * (size_t)h->K;
     std::vector<double> yt(W * d);
     for (size_t w = 0; w < W; ++w)
         for (size_t i = 0; i < d; ++i) yt[i * W + w] = y[w * d + i];

@@ -256,18 +256,20 @@ __global__ void __launch_bounds__(64) whiten_state_kernel(const double* __restri
                                                           double* __restrict__ y,
                                                           const double* __restrict__ mean,
                                                           const double* __restrict__ Lrow, int d,
-                                                          int W)
+                                                          int W, int K)
 {
     extern __shared__ __attribute__((aligned(16))) double sdev[];
     const int l = threadIdx.x, w = blockIdx.x * 64 + l;
-    if (w < W)
-        for (int i = 0; i < d; ++i) sdev[i * 64 + l] = x[(size_t)i * W + w] - mean[i];
-    if (w >= W) return;
-    for (int j = 0; j < d; ++j) {
-        const double* __restrict__ row = Lrow + (size_t)j * d;
-        double acc = 0.0;
-        for (int i = 0; i <= j; ++i) acc = fma(row[i], sdev[i * 64 + l], acc);
-        y[(size_t)j * W + w] = acc;
+    for (int k = 0; k < K; ++k) {   // y is [K][d][W]
+        if (w < W)
+            for (int i = 0; i < d; ++i) sdev[i * 64 + l] = x[(size_t)i * W + w] - mean[k * d + i];
+        if (w < W)
+            for (int j = 0; j < d; ++j) {
+                const double* __restrict__ row = Lrow + ((size_t)k * d + j) * d;
+                double acc = 0.0;
+                for (int i = 0; i <= j; ++i) acc = fma(row[i], sdev[i * 64 + l], acc);
+                y[((size_t)k * d + j) * W + w] = acc;
+            }
     }
 }
 
@@ -330,6 +332,231 @@ __global__ void __launch_bounds__(64) whiten_directions_kernel(const IncDirArgs 
     for (int j = d; j < 4 * a.dq; ++j) out[j] = make_double2(0.0, 0.0);
 }
 
+// Mixtures: the same per mode, written as PLANES -- VU[g][step][0] = v, [1 + k] = u_k = L_k^-1 v,
+// each 4 dq doubles (zero beyond d).
+__global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sv[];   // [d][64]
+    const int l = threadIdx.x;
+    const int sr = blockIdx.x * 64 + l;
+    const int g = blockIdx.y;
+    const int d = a.d, K = a.n_modes, dpad = 4 * a.dq;
+    const bool live = sr < a.n_steps;
+    if (live) {
+        const unsigned long long step = a.step0 + (unsigned long long)sr;
+        const int cyc = (int)(step / (unsigned long long)d - a.cycle0);
+        const int col = (int)(step % (unsigned long long)d);
+        const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
+        for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
+    }
+    if (!live) return;
+    double* __restrict__ out = a.VU + ((size_t)g * a.n_steps + sr) * (size_t)((1 + K) * dpad);
+    for (int j = 0; j < dpad; ++j) out[j] = j < d ? sv[j * 64 + l] : 0.0;
+    for (int k = 0; k < K; ++k) {
+        double* __restrict__ uk = out + (size_t)(1 + k) * dpad;
+        for (int j = 0; j < d; ++j) {
+            const double* __restrict__ row = a.Lrow + ((size_t)k * d + j) * d;
+            double acc = 0.0;
+            for (int i = 0; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
+            uk[j] = acc;
+        }
+        for (int j = d; j < dpad; ++j) uk[j] = 0.0;
+    }
+}
+
+#if MCMC_DQ_LO <= 16
+// ---------------------------------------------------------------- the step kernel, mixtures
+// KM = 2..4 modes, DQ <= 16 (d <= 64): one carried residual y_k per mode, the direction planes
+// (v, u_1 .. u_KM) of a step read with ds_read_b64, chi2_k per mode through the quad, then the
+// log-sum-exp of eval_point (gaussian_mixture.py:158-163) -- evaluated by every lane of the quad.
+__host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
+{
+    int c = (2048 / ((1 + km) * 4 * dq)) & ~3;
+    return c < 4 ? 4 : (c > 64 ? 64 : c);
+}
+
+template <int DQ, int KM, bool UNIT_T>
+__global__ void __launch_bounds__(256, (DQ * (KM + 3) <= 28 ? 3 : 2))
+step_inc_mix_kernel(const IncStepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int dpad = 4 * DQ;
+    constexpr int COL = (1 + KM) * dpad;          // doubles per column
+    constexpr int C = inc_chunk_mix(DQ, KM);
+    constexpr int CHUNK = C * COL;
+    const StepArgs& s = a.s;
+    const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
+    const int W = s.W, d = a.d;
+    const int w = blockIdx.x * 64 + (tid >> 2);
+    const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
+    const int ncols = s.n_steps;
+    const double* __restrict__ gVU = a.VU + (size_t)g * ncols * COL;
+    auto stage = [&](int k) {
+        const int first = k * C;
+        if (first >= ncols) return;
+        const int cols = ncols - first < C ? ncols - first : C;
+        const int bytes = cols * COL * 8;
+        const char* src = (const char*)(gVU + (size_t)first * COL);
+        char* dst = (char*)(smem + (k & 1) * CHUNK);
+        for (int kb = wave; kb * 1024 < bytes; kb += 4) {
+            if (kb * 1024 + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+    double x[DQ], y[KM][DQ], lo[DQ], hi[DQ];
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        const bool in = i < d;
+        x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) y[k][kk] = in ? a.y[((size_t)k * d + i) * W + w] : 0.0;
+        lo[kk] = a.prior[i];
+        hi[kk] = a.prior[dpad + i];
+    }
+    double cn[KM], wk[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) { cn[k] = s.cblock[a.cnorm_off + k]; wk[k] = s.cblock[a.weight_off + k]; }
+    double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
+    long long nacc = s.n_accept[w];
+    const long long nacc0 = nacc;
+    const uint32_t gid = s.walker0 + (uint32_t)w;
+    const double mt10 = s.max_tries * 10.0;
+    const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
+    const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
+        const double* __restrict__ cur = smem + (kc & 1) * CHUNK;
+        stage(kc + 1);
+        const int cols = ncols - base < C ? ncols - base : C;
+        for (int s4 = 0; s4 < cols; s4 += 4) {
+            StepRng rng;
+            rng.begin(s.key0, s.key1, gid, s.step0 + (unsigned long long)(base + s4 + c));
+            rng.run_all();
+            const double r4 = rng.r, E4 = rng.Ea;
+            const int nq = cols - s4 < 4 ? cols - s4 : 4;
+#pragma unroll 1
+            for (int q = 0; q < nq; ++q) {
+                double r, Ea;
+                switch (q) {   // wave-uniform
+                case 0: r = quad_perm<0x00>(r4); Ea = quad_perm<0x00>(E4); break;
+                case 1: r = quad_perm<0x55>(r4); Ea = quad_perm<0x55>(E4); break;
+                case 2: r = quad_perm<0xAA>(r4); Ea = quad_perm<0xAA>(E4); break;
+                default: r = quad_perm<0xFF>(r4); Ea = quad_perm<0xFF>(E4); break;
+                }
+                const double* __restrict__ col = cur + (s4 + q) * COL + c;
+                bool inb = true;
+                double sc = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) {
+                    const double t = fma(r, col[4 * kk], x[kk]);
+                    inb = inb & (t <= hi[kk]) & (t >= lo[kk]);
+                    if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
+                        const int i = 4 * kk + c;
+                        const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
+                        sc = sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
+                    }
+                }
+                double ak[KM], amax = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    const double* __restrict__ uk = col + (1 + k) * dpad;
+                    double pc = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) {
+                        const double yt = fma(r, uk[4 * kk], y[k][kk]);
+                        pc = fma(yt, yt, pc);
+                    }
+                    const double chi2 = quad_sum(k == 0 ? (inb ? pc : INFINITY) : pc);
+                    ak[k] = -0.5 * (cn[k] + chi2);
+                    amax = ak[k] > amax ? ak[k] : amax;
+                }
+                const bool inside = ak[0] > -INFINITY;   // chi2_0 = +inf outside the support
+                const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
+                double S = 0.0;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) S = fma(wk[k], dexp(ak[k] - amax), S);
+                const double ll = dlog(S) + amax;
+                const double lt = inside ? lp + ll : -INFINITY;
+                const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
+                const bool accept = inside & (lt != -INFINITY) & ((lt > lpost) | (Ea > delta));
+                const int lim = burn > 0 ? lim10 : lim1;
+                burn -= (accept & (burn > 0)) ? 1 : 0;
+                const double ra = accept ? r : 0.0;
+                const double* col2 = col;
+                asm volatile("" : "+v"(col2));
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) {
+                    x[kk] = fma(ra, col2[4 * kk], x[kk]);
+#pragma unroll
+                    for (int k = 0; k < KM; ++k)
+                        y[k][kk] = fma(ra, col2[(1 + k) * dpad + 4 * kk], y[k][kk]);
+                }
+                lpri = accept ? lp : lpri;
+                llik = accept ? ll : llik;
+                lpost = accept ? lt : lpost;
+                prej = accept ? 0 : (prej + (inside ? 0 : 1));
+                wt = accept ? 1 : wt + 1;
+                nacc += accept ? 1 : 0;
+                if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        if (i < d) {
+            s.x[(size_t)i * W + w] = x[kk];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) a.y[((size_t)k * d + i) * W + w] = y[k][kk];
+        }
+    }
+    if (c == 0) {
+        s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
+        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
+        s.n_accept[w] = nacc;
+    }
+    wave_add_accepts(s.accept_total, (c == 0) ? nacc - nacc0 : 0);
+}
+
+template <int DQ, int KM>
+hipError_t launch_inc_mix(const IncStepArgs& a, hipStream_t st)
+{
+    constexpr int C = inc_chunk_mix(DQ, KM);
+    const size_t lds = sizeof(double) * 2 * C * (1 + KM) * 4 * DQ;
+    const bool unit_t = a.s.temperature == 1.0;
+    static const std::string names[2] = {
+        "mcmc::step_inc_mix_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ", false>",
+        "mcmc::step_inc_mix_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ", true>"};
+    mcmc_hip_note_step_kernel(names[unit_t ? 1 : 0].c_str());
+    if (unit_t) hipLaunchKernelGGL((step_inc_mix_kernel<DQ, KM, true>), dim3(a.s.W / 64), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((step_inc_mix_kernel<DQ, KM, false>), dim3(a.s.W / 64), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int DQ>
+hipError_t dispatch_inc_mix(const IncStepArgs& a, hipStream_t st)
+{
+    if constexpr (DQ > MCMC_DQ_HI) {
+        return hipErrorInvalidValue;
+    } else {
+        if (a.dq == DQ)
+            return a.n_modes == 2 ? launch_inc_mix<DQ, 2>(a, st)
+                 : a.n_modes == 3 ? launch_inc_mix<DQ, 3>(a, st)
+                 : a.n_modes == 4 ? launch_inc_mix<DQ, 4>(a, st) : hipErrorInvalidValue;
+        return dispatch_inc_mix<DQ + 1>(a, st);
+    }
+}
+#endif  // MCMC_DQ_LO <= 16
+
 template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
@@ -381,12 +608,18 @@ extern "C" hipError_t MCMC_CAT(mcmc_hip_launch_inc_step_, MCMC_DQ_LO)(const mcmc
                                                                     hipStream_t st)
 {
     if (a->dq < MCMC_DQ_LO || a->dq > MCMC_DQ_HI) return hipErrorInvalidValue;
+#if MCMC_DQ_LO <= 16
+    if (a->n_modes > 1) return mcmc::dispatch_inc_mix<MCMC_DQ_LO>(*a, st);
+#else
+    if (a->n_modes > 1) return hipErrorInvalidValue;
+#endif
     return mcmc::dispatch_inc<MCMC_DQ_LO>(*a, st);
 }
 
 #if MCMC_DQ_LO == 1
 extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, const double* mean,
-                                                   const double* Lrow, int d, int W, hipStream_t st)
+                                                   const double* Lrow, int d, int W, int K,
+                                                   hipStream_t st)
 {
     const size_t lds = sizeof(double) * 64 * (size_t)d;
     if (lds > 48 * 1024) {
@@ -395,7 +628,7 @@ extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, c
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(mcmc::whiten_state_kernel, dim3((W + 63) / 64), dim3(64), lds, st, x, y,
-                       mean, Lrow, d, W);
+                       mean, Lrow, d, W, K);
     return hipGetLastError();
 }
 
@@ -407,6 +640,16 @@ extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* 
         hipError_t e = hipFuncSetAttribute((const void*)mcmc::whiten_directions_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+    }
+    if (a->n_modes > 1) {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)mcmc::whiten_directions_mix_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(mcmc::whiten_directions_mix_kernel,
+                           dim3((a->n_steps + 63) / 64, n_groups), dim3(64), lds, st, *a);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(mcmc::whiten_directions_kernel, dim3((a->n_steps + 63) / 64, n_groups),
                        dim3(64), lds, st, *a);

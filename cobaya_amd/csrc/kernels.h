@@ -207,14 +207,18 @@ struct IncStepArgs {
     int has_norm;          // some prior is normal
     int box;               // every prior is uniform on the same interval [box_lo, box_hi]
     double box_lo, box_hi;
+    // mixtures (2..4 modes, dq <= 16): y is [K][d][W], VU holds PLANES [G][n_steps][1 + K][4 dq]
+    // (v, u_1 .. u_K), and cnorm[k] / weight[k] sit at these offsets of s.cblock
+    int n_modes, cnorm_off, weight_off;
 };
 
 struct IncDirArgs {
     const double* V;       // the basis kernels' buffer [G][ncyc][slab], column stride ld
     const double* Lrow;    // [d][d] row-major L^-1
-    double* VU;            // [G][n_steps][dq][4][2]
+    double* VU;            // [G][n_steps][dq][4][2]; mixtures: [G][n_steps][1 + K][4 dq]
     unsigned long long step0, cycle0;   // first step of the launch, first cycle held in V
     int n_steps, ncyc, slab, ld, d, dq;
+    int n_modes;           // Lrow is [K][d][d]
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

@@ -309,7 +309,7 @@ class Engine:
             _ip(out["burn_left"]), out["n_accept"].ctypes.data_as(c_int64_p), C.byref(step)))
         out["step"] = np.uint64(step.value)
         if self.incremental:   # the carried whitened residual is part of the state
-            out["y"] = np.empty((W, self.d))
+            out["y"] = np.empty((W, max(self.K or 1, 1) * self.d))
             self._check(self._lib.mcmc_hip_get_whitened(self._h, _dp(out["y"])))
         return out
 
@@ -325,7 +325,7 @@ class Engine:
             _ip(i["weight"]), _ip(i["prior_rej"]), _ip(i["burn_left"]),
             na.ctypes.data_as(c_int64_p), int(st["step"])))
         if self.incremental and "y" in st:
-            y = _f64(st["y"], (W, self.d))
+            y = _f64(st["y"], (W, max(self.K or 1, 1) * self.d))
             self._check(self._lib.mcmc_hip_set_whitened(self._h, _dp(y)))
 
     # -- sampling

@@ -226,7 +226,8 @@ class EnsembleMCMC:
         if self.evaluation not in ("auto", "full", "incremental"):
             self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
                        self.evaluation)
-        can_inc = (spec.n_modes == 1 and not np.any(spec.periodic) and len(self.blocks) == 1
+        can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64))
+                   and not np.any(spec.periodic) and len(self.blocks) == 1
                    and self.oversampling_factors[0] == 1 and not self.drag
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
@@ -234,9 +235,10 @@ class EnsembleMCMC:
             self._fail("shared_basis: False serves a single parameter block without "
                        "oversampling or dragging")
         if self.evaluation == "incremental" and not can_inc:
-            self._fail("evaluation: incremental serves one Gaussian mode with non-periodic "
-                       "priors, a single parameter block, emit: snapshots, d >= 2 and a "
-                       "group_size that is a multiple of 64; use 'full' (or 'auto')")
+            self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
+                       "four at d <= 64) with non-periodic priors, a single parameter block, "
+                       "emit: snapshots, d >= 2 and a group_size that is a multiple of 64; use "
+                       "'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         try:
             self.engine = self._engine_factory(d, W, group_size=int(self.group_size), device=int(device),

@@ -56,7 +56,8 @@ typedef struct mcmc_hip_config {
 /* every walker draws its OWN Haar basis per cycle (proposal.py:59-69 to the letter) instead
  * of sharing the group's: the reference-faithful control, much slower */
 #define MCMC_HIP_FLAG_OWN_BASIS 1
-/* incremental evaluation (one Gaussian mode, non-periodic priors, one block, snapshots): every
+/* incremental evaluation (one Gaussian mode -- or a mixture of up to four at d <= 64 --,
+ * non-periodic priors, one block, snapshots): every
  * walker carries y = L^-1 (x - mu) and a trial moves it along the whitened shared direction,
  * y' = y + r L^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in O(d) per step;
  * y is recomputed from x every 40 d steps.  Specified in oracle/mcmc_oracle.c. */
@@ -199,7 +200,7 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
  * call with reset != 0, and the number of step-kernel launches: the live measurement
  * bench.py's roofline block uses.  Timing is enabled by mcmc_hip_enable_timing(h, 1). */
 int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
-/* incremental mode: the carried y[n_walkers][d] -- part of the state a bit-identical resume
+/* incremental mode: the carried y[n_walkers][n_modes * d] -- part of the state a bit-identical resume
  * needs (call mcmc_hip_set_whitened after mcmc_hip_set_full_state) */
 int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y);
 int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);

@@ -276,18 +276,19 @@ class Problem:
         return (lp, ll, der) if derived else (lp, ll)
 
     def whiten(self, x):
-        """y = L^-1 (x - mu) per point, in the oracle's chain order."""
+        """y[n][K*d] = L_k^-1 (x - mu_k) per point and mode, in the oracle's chain order."""
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
-        y = np.empty_like(x)
+        y = np.empty((len(x), max(self.K, 1) * self.d))
         for i in range(len(x)):
             lib().orc_whiten(C.byref(self.c), _dp(x[i]), _dp(y[i]))
         return y
 
     def whiten_directions(self, V):
+        """U[K][ncol][d] (squeezed for one mode)."""
         V = np.ascontiguousarray(V, dtype=np.float64)
-        U = np.empty_like(V)
+        U = np.empty((max(self.K, 1),) + V.shape)
         lib().orc_whiten_directions(C.byref(self.c), len(V), _dp(V), _dp(U))
-        return U
+        return U[0] if self.K <= 1 else U
 
     def basis(self, group, cycle):
         V = np.empty((self.d, self.d))

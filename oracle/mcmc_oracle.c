@@ -480,7 +480,7 @@ typedef struct {
     /* optional emission of accepted rows (mcmc.py:691-707): rows[W][cap][d+4] =
      * (weight, logpost, logprior, loglike, x...), n_rows[W] */
     double* rows; int32_t* n_rows; int32_t row_cap;
-    double* y;         /* [W][d] incremental mode: L^-1 (x - mu) of the current point, carried */
+    double* y;         /* [W][K][d] incremental mode: L_k^-1 (x - mu_k) of the current point */
 } orc_state;
 
 /* the Metropolis bookkeeping shared by the Philox and the injected drivers */
@@ -538,42 +538,52 @@ static inline int step_core(const orc_problem* p, orc_state* st, int w, const do
     return accept;
 }
 
-/* ---- incremental evaluation (one Gaussian mode, non-periodic priors, one block) ----------
- * y_j = sum_{i<=j} Linv[j][i] (x_i - mu_i), ascending fma chain from +0.0 (== `derived` of
- * eval_point): what a walker carries, recomputed at every step s with s % refresh_every == 0 */
+/* ---- incremental evaluation (Gaussian modes, non-periodic priors, one block) -------------
+ * y[k*d + j] = sum_{i<=j} Linv_k[j][i] (x_i - mu_k,i), ascending fma chain from +0.0 (==
+ * `derived` of eval_point): what a walker carries per mode, recomputed at every step s with
+ * s % refresh_every == 0 */
 void orc_whiten(const orc_problem* p, const double* x, double* y)
 {
-    int d = p->d;
-    for (int j = 0; j < d; ++j) {
-        double a = 0.0;
-        for (int i = 0; i <= j; ++i) a = fma(p->Linv[j * d + i], x[i] - p->mean[i], a);
-        y[j] = a;
+    int d = p->d, K = p->n_modes;
+    for (int k = 0; k < K; ++k) {
+        const double* Li = p->Linv + (size_t)k * d * d;
+        const double* mu = p->mean + (size_t)k * d;
+        for (int j = 0; j < d; ++j) {
+            double a = 0.0;
+            for (int i = 0; i <= j; ++i) a = fma(Li[j * d + i], x[i] - mu[i], a);
+            y[k * d + j] = a;
+        }
     }
 }
 
-/* U[c*d + j] = sum_{i<=j} Linv[j][i] V[c*d + i]: the whitened proposal directions of a cycle */
+/* U[(k*ncol + c)*d + j] = sum_{i<=j} Linv_k[j][i] V[c*d + i]: the whitened proposal directions
+ * of a cycle, per mode */
 void orc_whiten_directions(const orc_problem* p, int ncol, const double* V, double* U)
 {
-    int d = p->d;
-    for (int c = 0; c < ncol; ++c)
-        for (int j = 0; j < d; ++j) {
-            double a = 0.0;
-            for (int i = 0; i <= j; ++i) a = fma(p->Linv[j * d + i], V[c * d + i], a);
-            U[c * d + j] = a;
-        }
+    int d = p->d, K = p->n_modes;
+    for (int k = 0; k < K; ++k) {
+        const double* Li = p->Linv + (size_t)k * d * d;
+        for (int c = 0; c < ncol; ++c)
+            for (int j = 0; j < d; ++j) {
+                double a = 0.0;
+                for (int i = 0; i <= j; ++i) a = fma(Li[j * d + i], V[c * d + i], a);
+                U[((size_t)k * ncol + c) * d + j] = a;
+            }
+    }
 }
 
-/* One step in incremental mode.  Trial t = x + r v and its whitened residual yt = y + r u;
- * prior terms and chi2 are summed as FOUR interleaved chains over the dimensions i = c (mod 4)
- * (the kernel keeps dimension i in lane i mod 4 of the walker's quad), combined
- * (s0 + s1) + (s2 + s3) -- for every d in this mode. */
+/* One step in incremental mode.  Trial t = x + r v and, per mode, its whitened residual
+ * yt_k = y_k + r u_k; prior terms and every chi2_k are summed as FOUR interleaved chains over the
+ * dimensions i = c (mod 4) (the kernel keeps dimension i in lane i mod 4 of the walker's quad),
+ * combined (s0 + s1) + (s2 + s3) -- for every d in this mode.  u: [K] pointers to the mode's
+ * whitened direction of this step.  K > 1: log-sum-exp as in eval_point. */
 static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, const double* v,
-                                const double* u, double r, double exp_draw)
+                                const double* const* u, double r, double exp_draw)
 {
-    int d = p->d;
-    double t[128], yt[128];
+    int d = p->d, K = p->n_modes;
+    double t[128], yt[16 * 128];
     const double* x = st->x + (size_t)w * d;
-    double* y = st->y + (size_t)w * d;
+    double* y = st->y + (size_t)w * K * d;
     int inb = 1;
     for (int i = 0; i < d; ++i) {
         t[i] = fma(r, v[i], x[i]);
@@ -581,19 +591,31 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
     }
     double lp = -INFINITY, ll = -INFINITY, lt = -INFINITY;
     if (inb) {
-        double sc[4] = {0.0, 0.0, 0.0, 0.0}, pc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < d; ++i) {
+        double sc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < d; ++i)
             if (p->kind[i] == 1) {
                 /* (multiplication by the reciprocal of the scale, formed once: 1 ulp from the
                  * division of eval_point, a fifth of its instructions) */
                 double q = (t[i] - p->loc[i]) * (1.0 / p->scale[i]);
                 sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, p->mls[i]);
             }
-            yt[i] = fma(r, u[i], y[i]);
-            pc[i & 3] = fma(yt[i], yt[i], pc[i & 3]);
-        }
         lp = p->uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
-        ll = -0.5 * (p->cnorm[0] + ((pc[0] + pc[1]) + (pc[2] + pc[3])));
+        double a[16], amax = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            double pc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < d; ++i) {
+                yt[k * d + i] = fma(r, u[k][i], y[k * d + i]);
+                pc[i & 3] = fma(yt[k * d + i], yt[k * d + i], pc[i & 3]);
+            }
+            a[k] = -0.5 * (p->cnorm[k] + ((pc[0] + pc[1]) + (pc[2] + pc[3])));
+            if (a[k] > amax) amax = a[k];
+        }
+        if (K == 1) ll = a[0];
+        else {
+            double S = 0.0;
+            for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp(a[k] - amax), S);
+            ll = orc_dlog(S) + amax;
+        }
         lt = lp + ll;
     }
     int accept;
@@ -601,7 +623,7 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
     else if (lt > st->logpost[w]) accept = 1;
     else accept = exp_draw > (st->logpost[w] - lt) / p->temperature;
     if (accept)
-        for (int i = 0; i < d; ++i) y[i] = yt[i];
+        for (int i = 0; i < K * d; ++i) y[i] = yt[i];
     commit(p, st, w, t, inb, lp, ll, lt, accept);
     return accept;
 }
@@ -758,18 +780,21 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
             }
             const double* v = V + (size_t)col * d;
             if (p->incremental) {
+                const int K = p->n_modes;
                 if (cycle != have_u) {
-                    if (!U) U = (double*)malloc(sizeof(double) * (size_t)L0 * d);
+                    if (!U) U = (double*)malloc(sizeof(double) * (size_t)K * L0 * d);
                     orc_whiten_directions(p, L0, V, U);
                     have_u = cycle;
                 }
+                const double* uk[16];
+                for (int k = 0; k < K; ++k) uk[k] = U + ((size_t)k * L0 + col) * d;
                 for (int l = 0; l < gs; ++l) {
                     int w = g * gs + l;
                     double r, Ea;
                     if (step % (uint64_t)p->refresh_every == 0)
-                        orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * d);
+                        orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * K * d);
                     walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
-                    total += step_core_inc(p, st, w, v, U + (size_t)col * d, r, Ea);
+                    total += step_core_inc(p, st, w, v, uk, r, Ea);
                 }
                 continue;
             }

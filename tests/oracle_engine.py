@@ -160,7 +160,8 @@ class OracleEngine:
         if self.own_basis and self._blocking:
             raise EngineError(ERR_ARG, "shared_basis: False serves a single parameter block "
                                        "without dragging")
-        if self.incremental and (self.K != 1 or self._blocking or
+        if self.incremental and (not 1 <= self.K <= 4 or (self.K > 1 and self.d > 64)
+                                 or self._blocking or
                                  (self._prior[3] is not None and self._prior[3].any())):
             raise EngineError(ERR_ARG, "incremental evaluation serves one Gaussian mode with "
                                        "non-periodic priors and a single parameter block")

@@ -707,7 +707,7 @@ def test_incremental_mode_refuses_what_it_does_not_cover():
         E.Engine(4, 256, group_size=64, incremental=True, emit_capacity=8)
     eng = E.Engine(4, 256, group_size=64, incremental=True)
     eng.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
-    m, c = random_target(4, 2, np.random.default_rng(0))
+    m, c = random_target(4, 5, np.random.default_rng(0))     # five modes: more than it serves
     eng.set_target_gaussian_mixture(m, c)
     eng.set_proposal_cov(c[0])
     eng.set_state(np.full((256, 4), 0.5))
@@ -772,4 +772,33 @@ def test_own_basis_periodic_rows_and_offsets_bit_exact():
     rows_e, rows_o = eng.drain_samples(), st.drain()
     rows_o[:, 0] += 4096
     assert_bit_equal(rows_e, rows_o, "emitted rows")
+    eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,K,normal,T", [
+    (4, 256, 64, 2, False, 1.0), (30, 256, 64, 2, False, 1.0), (30, 256, 256, 3, False, 1.0),
+    (9, 128, 64, 4, True, 1.0), (64, 128, 64, 2, False, 2.0), (27, 256, 128, 2, True, 1.0)])
+def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
+    """Mixtures of 2..4 modes in incremental mode (step_inc_mix_kernel): a carried residual and
+    a whitened direction per mode, the log-sum-exp of eval_point -- bit for bit against the
+    oracle, across the refresh at 40 d steps."""
+    kw = {}
+    if normal:
+        rng = np.random.default_rng(7100 + d)
+        kinds = (rng.random(d) < 0.5).astype(int).tolist()
+        kw = dict(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
+    w = np.random.default_rng(d).uniform(0.5, 1.5, K)
+    eng, prob, st = make_pair(d, W, gs, K=K, T=T, incremental=True, weights=(w / w.sum()).tolist(),
+                              rng=np.random.default_rng(6100 + d), **kw)
+    compare_state(eng, st)
+    R = 40 * d
+    for n in (1, 6, d + 3, R - (d + 10) - 2, 9, d + 1):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
+    assert st.step > R and "step_inc_mix_kernel" in eng.last_step_kernel()
+    assert eng.counters()["accepted"] == int(st.n_accept.sum())
     eng.close()

@@ -381,3 +381,36 @@ def test_whitened_directions_are_linv_times_v(golden):
     U = inc.whiten_directions(V)
     Linv = np.linalg.inv(np.linalg.cholesky(cov))
     np.testing.assert_allclose(U, V @ Linv.T, rtol=1e-11, atol=1e-12 * np.abs(U).max())
+
+
+@pytest.mark.parametrize("d,K", [(4, 3), (30, 2), (9, 4)])
+def test_incremental_mixture_is_the_same_posterior(d, K):
+    """K > 1 in incremental mode: one carried residual y_k and one whitened direction u_k per
+    mode, log-sum-exp as in eval_point (gaussian_mixture.py:158-163)."""
+    from oracle import cbind as O
+    rng = np.random.default_rng(40 + d)
+    means = rng.uniform(0.4, 0.6, size=(K, d))
+    covs = []
+    for _ in range(K):
+        A = rng.normal(size=(d, d))
+        covs.append((A @ A.T / d + np.eye(d)) * 0.003)
+    covs = np.array(covs)
+    w = rng.uniform(0.5, 1.5, K)
+    w /= w.sum()
+    T = O.proposal_transform(covs[0], 2.4)
+    mk = lambda inc: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=means, covs=covs,
+                               weights=w, T=T, group_size=64, seed=9, incremental=inc)
+    full, inc = mk(False), mk(True)
+    x0 = np.clip(means[0] + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
+    a, b = O.State(full, x0), O.State(inc, x0)
+    assert b.y.shape == (128, K * d)
+    for _ in range(6):
+        b.run(23 * d + 1, n_threads=4)
+        lp, ll = full.evaluate(b.x)
+        np.testing.assert_allclose(b.loglike, ll, rtol=2e-13, atol=1e-11)
+        np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
+    a.run(300, n_threads=4)
+    c = O.State(inc, x0)
+    c.run(300, n_threads=4)
+    assert np.array_equal(a.weight, c.weight) and np.array_equal(a.n_accept, c.n_accept)
+    np.testing.assert_allclose(a.x, c.x, rtol=0, atol=1e-12)
