@@ -1120,22 +1120,26 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
 {
     const int d = h->d, dq = (d + 3) / 4;
     const int K = h->K;
-    if (K < 1 || K > 4 || (K > 1 && dq > 16) || h->any_periodic || h->blocked ||
-        h->drag_last_slow >= 0)
+    bool one_param_block = false;
+    for (int n : h->blk_size) one_param_block = one_param_block || n == 1;
+    if (K < 1 || K > 4 || (K > 1 && dq > 16) || h->any_periodic || h->drag_last_slow >= 0 ||
+        (h->blocked && (one_param_block || h->kb)))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "incremental evaluation serves one Gaussian mode (or a mixture of up to four "
-                    "at d <= 64) with non-periodic priors and a single parameter block; use "
-                    "evaluation: full for this model");
+                    "at d <= 64) with non-periodic priors, without dragging, and parameter blocks "
+                    "of at least two parameters (d <= 32); use evaluation: full for this model");
+    // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks
+    const int Lc = block_slots(h, 0);
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                 : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
     if (!launch || !mcmc_hip_launch_whiten_directions)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
-    const unsigned long long R = 40ull * (unsigned long long)d, dd_steps = (unsigned long long)d;
+    const unsigned long long R = 40ull * (unsigned long long)Lc, dd_steps = (unsigned long long)Lc;
     // doubles per (group, step) column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
     const size_t colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
     const int max_steps_vu =
         (int)std::max<size_t>(4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)h->G));
-    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(d) : (size_t)mcmc::v_slab(d);
+    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(d) : (size_t)mcmc::v_slab_cols(Lc, d);
     const int ld = h->kb ? mcmc::v_ld(d) : d;
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
     int left = n_steps;
@@ -1154,20 +1158,26 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         const int ncyc = (int)(c1 - c0 + 1);
         {
             Timed t(h, 1);
-            HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
-            mcmc::BasisArgs b{};
-            b.T = h->dT.p; b.V = h->V.p;
-            b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
-            b.cycle0 = (uint32_t)c0;
-            b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
-            b.ncyc = ncyc;
-            if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
-            else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+            if (h->blocked) {
+                bool any_1d = false;
+                const int rc = blocked_basis(h, 0, c0, ncyc, Lc, dd, h->V, h->vflag, any_1d);
+                if (rc != MCMC_HIP_OK) return rc;
+            } else {
+                HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+                mcmc::BasisArgs b{};
+                b.T = h->dT.p; b.V = h->V.p;
+                b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+                b.cycle0 = (uint32_t)c0;
+                b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+                b.ncyc = ncyc;
+                if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
+                else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+            }
             HIP_TRY(h, h->VU.resize((size_t)h->G * n * colb));
             mcmc::IncDirArgs w{};
             w.V = h->V.p; w.Lrow = h->inc_Lrow.p; w.VU = h->VU.p;
             w.step0 = h->step; w.cycle0 = c0; w.n_steps = n; w.ncyc = ncyc;
-            w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq; w.n_modes = K;
+            w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq; w.n_modes = K; w.cps = Lc;
             HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
         }
         {

@@ -288,8 +288,8 @@ __global__ void __launch_bounds__(64) whiten_directions_kernel(const IncDirArgs 
     const bool live = sr < a.n_steps;
     if (live) {
         const unsigned long long step = a.step0 + (unsigned long long)sr;
-        const int cyc = (int)(step / (unsigned long long)d - a.cycle0);
-        const int col = (int)(step % (unsigned long long)d);
+        const int cyc = (int)(step / (unsigned long long)a.cps - a.cycle0);
+        const int col = (int)(step % (unsigned long long)a.cps);
         const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
         for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
     }
@@ -344,8 +344,8 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
     const bool live = sr < a.n_steps;
     if (live) {
         const unsigned long long step = a.step0 + (unsigned long long)sr;
-        const int cyc = (int)(step / (unsigned long long)d - a.cycle0);
-        const int col = (int)(step % (unsigned long long)d);
+        const int cyc = (int)(step / (unsigned long long)a.cps - a.cycle0);
+        const int col = (int)(step % (unsigned long long)a.cps);
         const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
         for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
     }

@@ -219,6 +219,7 @@ struct IncDirArgs {
     unsigned long long step0, cycle0;   // first step of the launch, first cycle held in V
     int n_steps, ncyc, slab, ld, d, dq;
     int n_modes;           // Lrow is [K][d][d]
+    int cps;               // columns (= steps) per cycle: d, or sum_b oversample_b n_b with blocks
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

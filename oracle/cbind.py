@@ -180,7 +180,7 @@ class Problem:
         # incremental evaluation (one Gaussian mode, non-periodic, one block): the whitened
         # residual is carried and refreshed every `refresh_every` (default 40 d) steps
         self.incremental = bool(incremental)
-        self.refresh_every = int(refresh_every or 40 * d)
+        self._refresh_every = refresh_every   # default: 40 cycle lengths (40 d for one block)
         # blocked proposal: `blocks` = lists of sampler indices, slow -> fast; T must then be
         # the transform of the covariance in sorted order (blocked_transform below)
         self.blocking = None
@@ -259,6 +259,12 @@ class Problem:
         p.weight, p.T = _dp(self.weight), _dp(self.T)
         p.blocking = (C.cast(C.pointer(self.blocking), C.c_void_p) if self.blocking is not None
                       else None)
+        p.blocking = (C.cast(C.pointer(self.blocking), C.c_void_p) if self.blocking is not None
+                      else None)
+        self.c = p    # (orc_block_slots below reads the blocking through it)
+        self.refresh_every = int(self._refresh_every or
+                                 40 * (lib().orc_block_slots(C.byref(p), 0, None)
+                                       if self.blocking is not None else self.d))
         p.incremental, p.refresh_every = int(self.incremental), self.refresh_every
         self.c = p
 

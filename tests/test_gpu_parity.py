@@ -802,3 +802,36 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     assert st.step > R and "step_inc_mix_kernel" in eng.last_step_kernel()
     assert eng.counters()["accepted"] == int(st.n_accept.sum())
     eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,K,blocks,over", [
+    (9, 256, 64, 1, [[0, 1, 2, 3], [4, 5, 6, 7, 8]], [1, 3]),
+    (30, 256, 256, 1, [list(range(10)), list(range(10, 30))], [1, 2]),
+    (8, 128, 64, 2, [[6, 1, 3], [0, 2], [4, 5, 7]], [1, 2, 4]),
+    (32, 256, 128, 1, [list(range(0, 32, 2)), list(range(1, 32, 2))], [2, 5])])
+def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, over):
+    """Parameter blocks with oversampling (proposal.py:96-260) in incremental mode: a cycle has
+    L = sum_b oversample_b n_b columns, each with its whitened image; the refresh falls every
+    40 L steps.  (One-parameter blocks and dragging stay with `evaluation: full`.)"""
+    kw = {"weights": [0.3, 0.7]} if K == 2 else {}
+    eng, prob, st = make_pair(d, W, gs, K=K, blocks=blocks, over=over, incremental=True, **kw)
+    L = eng.cycle_length()
+    assert L == sum(o * len(b) for o, b in zip(over, blocks)) and prob.refresh_every == 40 * L
+    compare_state(eng, st)
+    for n in (1, L + 3, 40 * L - (L + 4) - 3, 7, 2 * L):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
+    assert st.step > 40 * L and "step_inc" in eng.last_step_kernel()
+    eng2 = E.Engine(4, 256, group_size=64, incremental=True)
+    eng2.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
+    m, c = random_target(4, 1, np.random.default_rng(0))
+    eng2.set_target_gaussian_mixture(m, c)
+    eng2.set_blocking([[0], [1, 2, 3]], [1, 2])
+    eng2.set_proposal_cov(c[0])
+    eng2.set_state(np.full((256, 4), 0.5))
+    with pytest.raises(E.EngineError, match="at least two parameters"):
+        eng2.step(3)
+    eng.close(), eng2.close()

@@ -414,3 +414,28 @@ def test_incremental_mixture_is_the_same_posterior(d, K):
     c.run(300, n_threads=4)
     assert np.array_equal(a.weight, c.weight) and np.array_equal(a.n_accept, c.n_accept)
     np.testing.assert_allclose(a.x, c.x, rtol=0, atol=1e-12)
+
+
+def test_incremental_with_blocks_is_the_same_posterior():
+    """Blocks and oversampling in incremental mode: same accept decisions as the from-scratch
+    evaluation of the same blocked proposal stream."""
+    from oracle import cbind as O
+    d = 9
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.003
+    mean = np.full(d, 0.5)
+    blocks, over = [[0, 1, 2, 3], [4, 5, 6, 7, 8]], [1, 3]
+    T = O.blocked_transform(cov, blocks, 2.4)
+    mk = lambda inc: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov, T=T,
+                               group_size=64, seed=2, blocks=blocks, oversampling=over,
+                               incremental=inc)
+    full, inc = mk(False), mk(True)
+    assert inc.refresh_every == 40 * 19
+    x0 = np.clip(mean + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
+    a, b = O.State(full, x0), O.State(inc, x0)
+    a.run(900, n_threads=4)
+    b.run(900, n_threads=4)
+    assert np.array_equal(a.weight, b.weight) and np.array_equal(a.n_accept, b.n_accept)
+    np.testing.assert_allclose(a.x, b.x, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
