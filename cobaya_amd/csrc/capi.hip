@@ -798,8 +798,10 @@ int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* bloc
     if (!h) return MCMC_HIP_ERR_ARG;
     if (!block_size || !oversampling || !i_of_j) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
     const int d = h->d;
-    if (h->kb)
-        return fail(h, MCMC_HIP_ERR_ARG, "parameter blocks are supported for d <= 32 (d=%d)", d);
+    if (h->kb && (!h->incremental || drag_last_slow >= 0))
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "parameter blocks at d > 32 need incremental evaluation; dragging is "
+                    "supported for d <= 32 (d=%d)", d);
     if (n_blocks < 1 || n_blocks > 32)
         return fail(h, MCMC_HIP_ERR_ARG, "n_blocks must be in 1..32, got %d", n_blocks);
     int total = 0;
@@ -1104,6 +1106,8 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
     b.block_size = h->dblk.p; b.oversample = h->dblk.p + nb; b.i_of_j = h->dblk.p + 2 * nb;
     b.n_blocks = nb; b.d = h->d; b.which = which; b.drag_last_slow = h->drag_last_slow;
     b.L = L; b.slab = (int)slab;
+    b.ld = h->d;
+    b.nmax = *std::max_element(h->blk_size.begin(), h->blk_size.end());
     b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
     b.cycle0 = (uint32_t)c0;
     b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
@@ -1123,11 +1127,11 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     bool one_param_block = false;
     for (int n : h->blk_size) one_param_block = one_param_block || n == 1;
     if (K < 1 || K > 4 || (K > 1 && dq > 16) || h->any_periodic || h->drag_last_slow >= 0 ||
-        (h->blocked && (one_param_block || h->kb)))
+        (h->blocked && one_param_block))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "incremental evaluation serves one Gaussian mode (or a mixture of up to four "
                     "at d <= 64) with non-periodic priors, without dragging, and parameter blocks "
-                    "of at least two parameters (d <= 32); use evaluation: full for this model");
+                    "of at least two parameters; use evaluation: full for this model");
     // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks
     const int Lc = block_slots(h, 0);
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
@@ -1139,8 +1143,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     const size_t colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
     const int max_steps_vu =
         (int)std::max<size_t>(4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)h->G));
-    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(d) : (size_t)mcmc::v_slab_cols(Lc, d);
-    const int ld = h->kb ? mcmc::v_ld(d) : d;
+    // (blocked directions are written with column stride d at every d)
+    const size_t dd = (h->kb && !h->blocked) ? (size_t)mcmc::v_slab_big(d)
+                                             : (size_t)mcmc::v_slab_cols(Lc, d);
+    const int ld = (h->kb && !h->blocked) ? mcmc::v_ld(d) : d;
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
     int left = n_steps;
     while (left > 0) {

@@ -121,6 +121,8 @@ struct BlockedBasisArgs {
     int slab;
     uint32_t group0, cycle0, key0, key1;
     int ncyc;
+    int ld;                 // column stride of V (d <= 32: d)
+    int nmax;               // largest block (the d > 32 kernel sizes its LDS by it)
 };
 
 struct BasisArgs {

@@ -229,7 +229,7 @@ class EnsembleMCMC:
         can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64))
                    and not np.any(spec.periodic) and not self.drag
                    and ((len(self.blocks) == 1 and self.oversampling_factors[0] == 1)
-                        or (d <= 32 and min(len(b) for b in self.blocks) >= 2))
+                        or min(len(b) for b in self.blocks) >= 2)
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
         if not self.shared_basis and (len(self.blocks) > 1 or self.oversampling_factors[0] != 1):
@@ -238,7 +238,7 @@ class EnsembleMCMC:
         if self.evaluation == "incremental" and not can_inc:
             self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
                        "four at d <= 64) with non-periodic priors, no dragging, parameter blocks "
-                       "of at least two parameters (d <= 32), emit: snapshots, d >= 2 and a "
+                       "of at least two parameters, emit: snapshots, d >= 2 and a "
                        "group_size that is a multiple of 64; use 'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         try:

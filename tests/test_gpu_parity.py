@@ -808,7 +808,15 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (9, 256, 64, 1, [[0, 1, 2, 3], [4, 5, 6, 7, 8]], [1, 3]),
     (30, 256, 256, 1, [list(range(10)), list(range(10, 30))], [1, 2]),
     (8, 128, 64, 2, [[6, 1, 3], [0, 2], [4, 5, 7]], [1, 2, 4]),
-    (32, 256, 128, 1, [list(range(0, 32, 2)), list(range(1, 32, 2))], [2, 5])])
+    (32, 256, 128, 1, [list(range(0, 32, 2)), list(range(1, 32, 2))], [2, 5]),
+    # d > 32: the general blocked-direction kernel (blocks of <= 32 parameters project with one
+    # chain, larger ones with four)
+    (40, 128, 64, 1, [list(range(20)), list(range(20, 40))], [1, 2]),
+    (33, 128, 64, 1, [[32, 0, 5], list(range(1, 5)) + list(range(6, 20)), list(range(20, 32))],
+     [1, 2, 3]),
+    (100, 128, 64, 1, [list(range(0, 100, 5)) + list(range(1, 100, 5)),
+                       [i for i in range(100) if i % 5 >= 2]], [1, 2]),
+    (48, 128, 64, 2, [list(range(40)), list(range(40, 48))], [1, 4])])
 def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, over):
     """Parameter blocks with oversampling (proposal.py:96-260) in incremental mode: a cycle has
     L = sum_b oversample_b n_b columns, each with its whitened image; the refresh falls every
