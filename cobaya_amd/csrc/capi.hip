@@ -798,10 +798,10 @@ int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* bloc
     if (!h) return MCMC_HIP_ERR_ARG;
     if (!block_size || !oversampling || !i_of_j) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
     const int d = h->d;
-    if (h->kb && (!h->incremental || drag_last_slow >= 0))
+    if (h->kb && !h->incremental)
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "parameter blocks at d > 32 need incremental evaluation; dragging is "
-                    "supported for d <= 32 (d=%d)", d);
+                    "parameter blocks and dragging at d > 32 need incremental evaluation (with "
+                    "evaluation: full they are supported for d <= 32; d=%d)", d);
     if (n_blocks < 1 || n_blocks > 32)
         return fail(h, MCMC_HIP_ERR_ARG, "n_blocks must be in 1..32, got %d", n_blocks);
     int total = 0;
@@ -1124,30 +1124,40 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
 {
     const int d = h->d, dq = (d + 3) / 4;
     const int K = h->K;
+    const bool drag = h->drag_last_slow >= 0;
+    const int nd = drag ? h->drag_steps : 0;
     bool one_param_block = false;
     for (int n : h->blk_size) one_param_block = one_param_block || n == 1;
-    if (K < 1 || K > 4 || (K > 1 && dq > 16) || h->any_periodic || h->drag_last_slow >= 0 ||
-        (h->blocked && one_param_block))
+    // dragging: a step's 1 + n_drag columns must fit the LDS twice over
+    const int chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + nd));
+    const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)chunk_steps * (1 + nd) * 4 * dq;
+    if (K < 1 || K > 4 || (K > 1 && (dq > 16 || drag)) || h->any_periodic ||
+        (h->blocked && one_param_block) || (drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation serves one Gaussian mode (or a mixture of up to four "
-                    "at d <= 64) with non-periodic priors, without dragging, and parameter blocks "
-                    "of at least two parameters; use evaluation: full for this model");
-    // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks
-    const int Lc = block_slots(h, 0);
+                    "incremental evaluation serves one Gaussian mode (or, without dragging, a "
+                    "mixture of up to four at d <= 64) with non-periodic priors and parameter "
+                    "blocks of at least two parameters; use evaluation: full for this model");
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                 : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
     if (!launch || !mcmc_hip_launch_whiten_directions)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
+    // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks, the slow
+    // blocks' parameters when dragging (+ the fast sequence of the interpolation steps)
+    const int Lc = block_slots(h, drag ? 1 : 0);
+    const int Lf = drag ? block_slots(h, 2) : 0;
     const unsigned long long R = 40ull * (unsigned long long)Lc, dd_steps = (unsigned long long)Lc;
-    // doubles per (group, step) column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
+    // doubles per column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
     const size_t colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
-    const int max_steps_vu =
-        (int)std::max<size_t>(4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)h->G));
+    const int max_steps_vu = (int)std::max<size_t>(
+        4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)(1 + nd) * (size_t)h->G));
     // (blocked directions are written with column stride d at every d)
     const size_t dd = (h->kb && !h->blocked) ? (size_t)mcmc::v_slab_big(d)
                                              : (size_t)mcmc::v_slab_cols(Lc, d);
+    const size_t ddf = drag ? (size_t)mcmc::v_slab_cols(Lf, d) : 0;
     const int ld = (h->kb && !h->blocked) ? mcmc::v_ld(d) : d;
     const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    const int max_cyc_f =
+        drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * ddf * (size_t)h->G)) : 0;
     int left = n_steps;
     while (left > 0) {
         if (!h->y_valid || h->step % R == 0) {
@@ -1159,15 +1169,30 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         unsigned long long room = R - h->step % R;
         room = std::min<unsigned long long>(room, (c0 + (unsigned long long)max_cyc) * dd_steps - h->step);
         room = std::min<unsigned long long>(room, (unsigned long long)max_steps_vu);
-        const int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        unsigned long long cyc0_f = 0;
+        int ncyc_f = 0;
+        if (drag) {   // at most max_cyc_f cycles of fast directions per launch
+            const unsigned long long und = (unsigned long long)nd, uLf = (unsigned long long)Lf;
+            cyc0_f = h->step * und / uLf;
+            const unsigned long long fend = (cyc0_f + (unsigned long long)max_cyc_f) * uLf;
+            const unsigned long long room_f = (fend - h->step * und) / und;   // whole steps
+            n = (int)std::min<unsigned long long>((unsigned long long)n, std::max<unsigned long long>(1, room_f));
+            const unsigned long long f1 = (h->step + (unsigned long long)n) * und - 1;
+            ncyc_f = (int)(f1 / uLf - cyc0_f + 1);
+        }
         const unsigned long long c1 = (h->step + (unsigned long long)n - 1) / dd_steps;
         const int ncyc = (int)(c1 - c0 + 1);
         {
             Timed t(h, 1);
             if (h->blocked) {
                 bool any_1d = false;
-                const int rc = blocked_basis(h, 0, c0, ncyc, Lc, dd, h->V, h->vflag, any_1d);
+                int rc = blocked_basis(h, drag ? 1 : 0, c0, ncyc, Lc, dd, h->V, h->vflag, any_1d);
                 if (rc != MCMC_HIP_OK) return rc;
+                if (drag) {
+                    rc = blocked_basis(h, 2, cyc0_f, ncyc_f, Lf, ddf, h->Vf, h->vflag_f, any_1d);
+                    if (rc != MCMC_HIP_OK) return rc;
+                }
             } else {
                 HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
                 mcmc::BasisArgs b{};
@@ -1179,12 +1204,21 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                 if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
                 else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
             }
-            HIP_TRY(h, h->VU.resize((size_t)h->G * n * colb));
+            HIP_TRY(h, h->VU.resize((size_t)h->G * n * (1 + nd) * colb));
             mcmc::IncDirArgs w{};
             w.V = h->V.p; w.Lrow = h->inc_Lrow.p; w.VU = h->VU.p;
             w.step0 = h->step; w.cycle0 = c0; w.n_steps = n; w.ncyc = ncyc;
             w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq; w.n_modes = K; w.cps = Lc;
+            w.out_total = n * (1 + nd);
+            if (drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
             HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
+            if (drag) {   // the fast directions of the n * n_drag interpolation steps
+                w.V = h->Vf.p;
+                w.step0 = h->step * (unsigned long long)nd; w.cycle0 = cyc0_f;
+                w.n_steps = n * nd; w.ncyc = ncyc_f; w.slab = (int)ddf; w.cps = Lf;
+                w.out_div = nd; w.out_cols = 1 + nd; w.out_slot0 = 1;
+                HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
+            }
         }
         {
             Timed t(h, 0);
@@ -1212,6 +1246,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             for (int i = 1; i < d && a.box; ++i)
                 a.box = h->lo[i] == h->lo[0] && h->hi[i] == h->hi[0];
             a.box_lo = h->lo[0]; a.box_hi = h->hi[0];
+            a.n_drag = nd; a.chunk_steps = chunk_steps;
             HIP_TRY(h, launch(&a, h->stream));
             h->n_step_launches += 1;
             if (g_noted_kernel) {

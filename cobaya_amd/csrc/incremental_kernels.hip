@@ -248,6 +248,231 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     wave_add_accepts(s.accept_total, (c == 0) ? nacc - nacc0 : 0);
 }
 
+// ---------------------------------------------------------------- the dragging step
+// mcmc.py:564-668 in incremental mode (oracle: drag_core_inc): a dragging step is 1 + n_drag
+// consecutive columns of VU -- the slow direction, then the fast directions of its interpolation
+// steps -- and 1 + 2 n_drag evaluations, every one of them O(d): the start and the end point
+// carry their whitened residuals (ys, ye), a move by r v moves them by fma(r, u, .).  The variates
+// (r_i, E_i) of the sub-steps i = 0 .. n_drag are drawn four at a time, one per lane class.
+template <int DQ, int MODE, bool UNIT_T>
+__global__ void __launch_bounds__(256, (MODE == 0 ? (DQ <= 5 ? 3 : DQ <= 16 ? 2 : 1)
+                                                  : (DQ <= 3 ? 3 : DQ <= 11 ? 2 : 1)))
+drag_inc_kernel(const IncStepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 smem2[];
+    constexpr int COLB = 4 * DQ;
+    constexpr bool kBoundsInRegs = MODE > 0;     // (bounds in registers at every DQ here)
+    constexpr bool NORMP = MODE == 2;
+    constexpr int dpad = 4 * DQ;
+    const StepArgs& s = a.s;
+    const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
+    const int W = s.W, d = a.d, nd = a.n_drag, cps = 1 + nd;
+    const int w = blockIdx.x * 64 + (tid >> 2);
+    const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
+    const int nsteps = s.n_steps;
+    const int Sc = a.chunk_steps;                // dragging steps per LDS chunk
+    const int CHUNK = Sc * cps * COLB;           // pairs per chunk
+    const double2* __restrict__ gVU = (const double2*)a.VU + (size_t)g * nsteps * cps * COLB;
+    double2* const sVU = smem2;
+    auto stage = [&](int k) {
+        const int first = k * Sc;
+        if (first >= nsteps) return;
+        const int n = nsteps - first < Sc ? nsteps - first : Sc;
+        const int bytes = n * cps * COLB * 16;
+        const char* src = (const char*)(gVU + (size_t)first * cps * COLB);
+        char* dst = (char*)(sVU + (k & 1) * CHUNK);
+        for (int kb = wave; kb * 1024 < bytes; kb += 4) {
+            if (kb * 1024 + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+    const double blo = a.box_lo, bhi = a.box_hi;
+    // x0 / y0: the walker's point; cs / ys and ce / ye: start and end point of the dragging step
+    double x0[DQ], y0[DQ], cs[DQ], ce[DQ], ys[DQ], ye[DQ];
+    double lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        const bool in = i < d;
+        x0[kk] = in ? s.x[(size_t)i * W + w] : (MODE == 0 ? 0.5 * (blo + bhi) : 0.0);
+        y0[kk] = in ? a.y[(size_t)i * W + w] : 0.0;
+        if (kBoundsInRegs) {
+            lo[kk] = a.prior[i];
+            hi[kk] = a.prior[dpad + i];
+        }
+    }
+    double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
+    long long nacc = s.n_accept[w];
+    const long long nacc0 = nacc;
+    const uint32_t gid = s.walker0 + (uint32_t)w;
+    const double mt10 = s.max_tries * 10.0;
+    const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
+    const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
+    const double navg = (double)cps;
+
+    // log-posterior of the point t (already formed) with residual yt: lp, ll, lt (-inf outside)
+    auto finish = [&](bool inb, double pc, double sc, double& lp, double& ll) -> double {
+        const double chi2 = quad_sum(inb ? pc : INFINITY);
+        lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
+        ll = -0.5 * (s.cnorm0 + chi2);
+        return chi2 < INFINITY ? lp + ll : -INFINITY;
+    };
+    auto inside = [&](double t, int kk) -> bool {
+        if (MODE == 0) return (t <= bhi) & (t >= blo);
+        return (t <= hi[kk]) & (t >= lo[kk]);
+    };
+    auto prior_term = [&](double t, int kk, double sc) -> double {
+        if (!NORMP) return sc;
+        const int i = 4 * kk + c;
+        const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
+        return sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
+    };
+    auto metropolis = [&](double trial, double current, double Ea) -> bool {
+        const double delta = UNIT_T ? (current - trial) : (current - trial) / s.temperature;
+        return (trial != -INFINITY) & ((trial > current) | (Ea > delta));
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int base = 0, kc = 0; base < nsteps; base += Sc, ++kc) {
+        const double2* __restrict__ cur = sVU + (kc & 1) * CHUNK;
+        stage(kc + 1);
+        const int nhere = nsteps - base < Sc ? nsteps - base : Sc;
+#pragma unroll 1
+        for (int sl = 0; sl < nhere; ++sl) {
+            const unsigned long long step = s.step0 + (unsigned long long)(base + sl);
+            const double2* __restrict__ col0 = cur + (size_t)sl * cps * COLB + c;
+            double cs_lt = lpost, ce_lt = -INFINITY, ce_lp = 0.0, ce_ll = 0.0;
+            double start_acc = 0.0, end_acc = 0.0, Ea0 = 0.0;
+            bool dead = false;
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) { cs[kk] = x0[kk]; ys[kk] = y0[kk]; }
+#pragma unroll 1
+            for (int i4 = 0; i4 < cps; i4 += 4) {
+                // lane class c draws the variates of sub-step i4 + c
+                StepRng rng;
+                rng.begin(s.key0, s.key1, gid, step, (uint32_t)(i4 + c));
+                rng.run_all();
+                const double r4 = rng.r, E4 = rng.Ea;
+                const int nq = cps - i4 < 4 ? cps - i4 : 4;
+#pragma unroll 1
+                for (int q = 0; q < nq; ++q) {
+                    double r, Ea;
+                    switch (q) {   // wave-uniform
+                    case 0: r = quad_perm<0x00>(r4); Ea = quad_perm<0x00>(E4); break;
+                    case 1: r = quad_perm<0x55>(r4); Ea = quad_perm<0x55>(E4); break;
+                    case 2: r = quad_perm<0xAA>(r4); Ea = quad_perm<0xAA>(E4); break;
+                    default: r = quad_perm<0xFF>(r4); Ea = quad_perm<0xFF>(E4); break;
+                    }
+                    const int i = i4 + q;
+                    const double2* __restrict__ col = col0 + (size_t)i * COLB;
+                    if (i == 0) {
+                        // the slow proposal: end = x + r0 v_slow (fused, as drag_core)
+                        Ea0 = Ea;
+                        bool inb = true;
+                        double pc = 0.0, sc = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) {
+                            const double2 p = col[4 * kk];
+                            ce[kk] = fma(r, p.x, cs[kk]);
+                            ye[kk] = fma(r, p.y, ys[kk]);
+                            inb = inb & inside(ce[kk], kk);
+                            sc = prior_term(ce[kk], kk, sc);
+                            pc = fma(ye[kk], ye[kk], pc);
+                        }
+                        ce_lt = finish(inb, pc, sc, ce_lp, ce_ll);
+                        dead = ce_lt == -INFINITY;      // mcmc.py:590-592: only the weight grows
+                        start_acc = cs_lt;
+                        end_acc = ce_lt;
+                    } else {
+                        // interpolation step i: both points move by delta = r v_fast (a product,
+                        // then a sum -- not fused, as drag_core)
+                        bool in_s = true, in_e = true;
+                        double pcs = 0.0, pce = 0.0, scs = 0.0, sce = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) {
+                            const double2 p = col[4 * kk];
+                            const double delta = r * p.x;
+                            const double t = cs[kk] + delta, te = ce[kk] + delta;
+                            const double yst = fma(r, p.y, ys[kk]), yet = fma(r, p.y, ye[kk]);
+                            in_s = in_s & inside(t, kk);
+                            in_e = in_e & inside(te, kk);
+                            scs = prior_term(t, kk, scs);
+                            sce = prior_term(te, kk, sce);
+                            pcs = fma(yst, yst, pcs);
+                            pce = fma(yet, yet, pce);
+                        }
+                        double ps_lp, ps_ll, pe_lp, pe_ll;
+                        const double ps_lt = finish(in_s, pcs, scs, ps_lp, ps_ll);
+                        const double pe_lt = finish(in_e, pce, sce, pe_lp, pe_ll);
+                        const double frac = (double)i / navg;
+                        const double pi = (1.0 - frac) * ps_lt + frac * pe_lt;
+                        const double ci = (1.0 - frac) * cs_lt + frac * ce_lt;
+                        const bool acc = (ps_lt != -INFINITY) & (pe_lt != -INFINITY) &
+                                         metropolis(pi, ci, Ea);
+                        const double ra = acc ? r : 0.0;
+                        const double2* col2 = col;
+                        asm volatile("" : "+v"(col2));
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) {
+                            const double2 p = col2[4 * kk];
+                            const double delta = ra * p.x;     // +-0 when not accepted
+                            cs[kk] = cs[kk] + delta;
+                            ce[kk] = ce[kk] + delta;
+                            ys[kk] = fma(ra, p.y, ys[kk]);
+                            ye[kk] = fma(ra, p.y, ye[kk]);
+                        }
+                        cs_lt = acc ? ps_lt : cs_lt;
+                        ce_lp = acc ? pe_lp : ce_lp;
+                        ce_ll = acc ? pe_ll : ce_ll;
+                        ce_lt = acc ? pe_lt : ce_lt;
+                        start_acc += cs_lt;
+                        end_acc += ce_lt;
+                    }
+                }
+            }
+            const bool accept = !dead & metropolis(end_acc / navg, start_acc / navg, Ea0);
+            const int lim = burn > 0 ? lim10 : lim1;
+            burn -= (accept & (burn > 0)) ? 1 : 0;
+            lpri = accept ? ce_lp : lpri;
+            llik = accept ? ce_ll : llik;
+            lpost = accept ? ce_lt : lpost;
+            prej = accept ? 0 : prej;
+            wt = accept ? 1 : wt + 1;
+            nacc += accept ? 1 : 0;
+            if (!accept & !dead & (wt - prej > lim) && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
+            // the walker's point: the dragged end point on accept (cs / ys were dragged along and
+            // are re-seeded from it at the next step)
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) {
+                x0[kk] = accept ? ce[kk] : x0[kk];
+                y0[kk] = accept ? ye[kk] : y0[kk];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        if (i < d) {
+            s.x[(size_t)i * W + w] = x0[kk];
+            a.y[(size_t)i * W + w] = y0[kk];
+        }
+    }
+    if (c == 0) {
+        s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
+        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
+        s.n_accept[w] = nacc;
+    }
+    wave_add_accepts(s.accept_total, (c == 0) ? nacc - nacc0 : 0);
+}
+
 // ---------------------------------------------------------------- y = L^-1 (x - mu)
 // One thread per walker, 64 walkers per workgroup; the deviations of the workgroup sit in LDS
 // ([i][lane]) and the rows of L^-1 are read at wave-uniform addresses (scalar loads).  One
@@ -294,7 +519,11 @@ __global__ void __launch_bounds__(64) whiten_directions_kernel(const IncDirArgs 
         for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
     }
     if (!live) return;
-    double2* __restrict__ out = (double2*)a.VU + ((size_t)g * a.n_steps + sr) * (4 * a.dq);
+    // output column: sr for a plain launch; a dragging launch interleaves the slow column of a
+    // step (slot 0) with the n_drag fast columns of its interpolation steps (slots 1 ..)
+    const size_t ocol = a.out_div ? (size_t)(sr / a.out_div) * a.out_cols + a.out_slot0 + sr % a.out_div
+                                  : (size_t)sr;
+    double2* __restrict__ out = (double2*)a.VU + ((size_t)g * a.out_total + ocol) * (4 * a.dq);
     // four rows at a time: four independent chains share every v_i read from LDS (each chain
     // is still one ascending fma chain from +0.0 -- the order of orc_whiten_directions)
     int j = 0;
@@ -588,12 +817,42 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 }
 
 template <int DQ>
+hipError_t launch_drag_dq(const IncStepArgs& a, hipStream_t st)
+{
+    const int mode = a.has_norm ? 2 : (a.box ? 0 : 1);
+    const size_t lds = sizeof(double2) * 2 * (size_t)a.chunk_steps * (1 + a.n_drag) * 4 * DQ;
+    const bool unit_t = a.s.temperature == 1.0;
+    typedef void (*kern_t)(const IncStepArgs);
+    static const kern_t kerns[6] = {
+        drag_inc_kernel<DQ, 0, false>, drag_inc_kernel<DQ, 0, true>,
+        drag_inc_kernel<DQ, 1, false>, drag_inc_kernel<DQ, 1, true>,
+        drag_inc_kernel<DQ, 2, false>, drag_inc_kernel<DQ, 2, true>};
+    static const std::string names[6] = {
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 0, false>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 0, true>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 1, false>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 1, true>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, false>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, true>"};
+    const int v = 2 * mode + (unit_t ? 1 : 0);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    mcmc_hip_note_step_kernel(names[v].c_str());
+    hipLaunchKernelGGL(kerns[v], dim3(a.s.W / 64), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int DQ>
 hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
 {
     if constexpr (DQ > MCMC_DQ_HI) {
         return hipErrorInvalidValue;
     } else {
-        if (a.dq == DQ) return launch_inc_dq<DQ>(a, st);
+        if (a.dq == DQ) return a.n_drag > 0 ? launch_drag_dq<DQ>(a, st) : launch_inc_dq<DQ>(a, st);
         return dispatch_inc<DQ + 1>(a, st);
     }
 }

@@ -212,6 +212,9 @@ struct IncStepArgs {
     // mixtures (2..4 modes, dq <= 16): y is [K][d][W], VU holds PLANES [G][n_steps][1 + K][4 dq]
     // (v, u_1 .. u_K), and cnorm[k] / weight[k] sit at these offsets of s.cblock
     int n_modes, cnorm_off, weight_off;
+    // dragging (drag_inc_kernel): interpolation steps per dragging step (0: plain steps); VU then
+    // holds 1 + n_drag columns per step; chunk_steps dragging steps per LDS chunk
+    int n_drag, chunk_steps;
 };
 
 struct IncDirArgs {
@@ -222,6 +225,9 @@ struct IncDirArgs {
     int n_steps, ncyc, slab, ld, d, dq;
     int n_modes;           // Lrow is [K][d][d]
     int cps;               // columns (= steps) per cycle: d, or sum_b oversample_b n_b with blocks
+    // where column sr goes: out_div == 0: column sr of out_total; else column
+    // (sr / out_div) * out_cols + out_slot0 + sr % out_div (dragging: slow / fast interleaved)
+    int out_div, out_cols, out_slot0, out_total;
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

@@ -226,8 +226,9 @@ class EnsembleMCMC:
         if self.evaluation not in ("auto", "full", "incremental"):
             self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
                        self.evaluation)
-        can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64))
-                   and not np.any(spec.periodic) and not self.drag
+        can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64 and not self.drag))
+                   and not np.any(spec.periodic)
+                   and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
                    and ((len(self.blocks) == 1 and self.oversampling_factors[0] == 1)
                         or min(len(b) for b in self.blocks) >= 2)
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
@@ -237,7 +238,7 @@ class EnsembleMCMC:
                        "oversampling or dragging")
         if self.evaluation == "incremental" and not can_inc:
             self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
-                       "four at d <= 64) with non-periodic priors, no dragging, parameter blocks "
+                       "four at d <= 64 without dragging) with non-periodic priors, parameter blocks "
                        "of at least two parameters, emit: snapshots, d >= 2 and a "
                        "group_size that is a multiple of 64; use 'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"

@@ -263,7 +263,8 @@ class Problem:
                       else None)
         self.c = p    # (orc_block_slots below reads the blocking through it)
         self.refresh_every = int(self._refresh_every or
-                                 40 * (lib().orc_block_slots(C.byref(p), 0, None)
+                                 40 * (lib().orc_block_slots(
+                                     C.byref(p), 1 if self.blocking.drag_last_slow >= 0 else 0, None)
                                        if self.blocking is not None else self.d))
         p.incremental, p.refresh_every = int(self.incremental), self.refresh_every
         self.c = p

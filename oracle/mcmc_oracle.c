@@ -744,6 +744,81 @@ static int drag_core(const orc_problem* p, orc_state* st, int w, const double* v
 
 /* Advance walkers [0, W) (global ids walker0 + w, groups of p->group_size) by n_steps
  * steps starting at global step index step0.  Returns total accepts. */
+/* log-posterior of a point given its whitened residual (incremental mode, one Gaussian mode):
+ * prior support and normal terms from t, chi2 from yt, both as four interleaved chains */
+static inline double eval_inc(const orc_problem* p, const double* t, const double* yt, double* lp_out,
+                              double* ll_out)
+{
+    int d = p->d, inb = 1;
+    for (int i = 0; i < d; ++i) inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
+    if (!inb) { *lp_out = -INFINITY; *ll_out = -INFINITY; return -INFINITY; }
+    double sc[4] = {0.0, 0.0, 0.0, 0.0}, pc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < d; ++i) {
+        if (p->kind[i] == 1) {
+            double q = (t[i] - p->loc[i]) * (1.0 / p->scale[i]);
+            sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, p->mls[i]);
+        }
+        pc[i & 3] = fma(yt[i], yt[i], pc[i & 3]);
+    }
+    *lp_out = p->uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
+    *ll_out = -0.5 * (p->cnorm[0] + ((pc[0] + pc[1]) + (pc[2] + pc[3])));
+    return *lp_out + *ll_out;
+}
+
+/* One dragging step in incremental mode (one Gaussian mode, non-periodic): drag_core with the
+ * whitened residuals of the start and end points carried along -- us / uf = L^-1 of the slow /
+ * fast directions (U[0], U[1..n]).  A point moved by delta = r v has its residual moved by
+ * fma(r, u, y). */
+static int drag_core_inc(const orc_problem* p, orc_state* st, int w, const double* vs,
+                         const double* const* vf, const double* U, const double* r,
+                         const double* Ea)
+{
+    int d = p->d, n = p->blocking->drag_steps;
+    double cs[128], ce[128], ys[128], ye[128], t[128], te[128], yst[128], yet[128];
+    const double* x = st->x + (size_t)w * d;
+    double* y = st->y + (size_t)w * d;
+    for (int i = 0; i < d; ++i) {
+        cs[i] = x[i]; ce[i] = fma(r[0], vs[i], x[i]);
+        ys[i] = y[i]; ye[i] = fma(r[0], U[i], y[i]);
+    }
+    double cs_lt = st->logpost[w];
+    double ce_lp, ce_ll;
+    double ce_lt = eval_inc(p, ce, ye, &ce_lp, &ce_ll);
+    if (ce_lt == -INFINITY) { st->weight[w] += 1; return 0; }   /* mcmc.py:590-592 */
+    double start_acc = cs_lt, end_acc = ce_lt;
+    for (int i = 1; i <= n; ++i) {
+        const double* uf = U + (size_t)i * d;
+        for (int k = 0; k < d; ++k) {
+            double delta = r[i] * vf[i - 1][k];
+            t[k] = cs[k] + delta;
+            te[k] = ce[k] + delta;
+            yst[k] = fma(r[i], uf[k], ys[k]);
+            yet[k] = fma(r[i], uf[k], ye[k]);
+        }
+        double ps_lp, ps_ll, pe_lp, pe_ll;
+        double ps_lt = eval_inc(p, t, yst, &ps_lp, &ps_ll);
+        double pe_lt = eval_inc(p, te, yet, &pe_lp, &pe_ll);
+        if (ps_lt != -INFINITY && pe_lt != -INFINITY) {
+            double frac = (double)i / (double)(1 + n);
+            double pi = (1.0 - frac) * ps_lt + frac * pe_lt;
+            double ci = (1.0 - frac) * cs_lt + frac * ce_lt;
+            if (metropolis(pi, ci, p->temperature, Ea[i])) {
+                for (int k = 0; k < d; ++k) { cs[k] = t[k]; ce[k] = te[k]; ys[k] = yst[k]; ye[k] = yet[k]; }
+                cs_lt = ps_lt;
+                ce_lp = pe_lp; ce_ll = pe_ll; ce_lt = pe_lt;
+            }
+        }
+        start_acc += cs_lt;
+        end_acc += ce_lt;
+    }
+    double navg = (double)(1 + n);
+    int accept = metropolis(end_acc / navg, start_acc / navg, p->temperature, Ea[0]);
+    if (accept)
+        for (int k = 0; k < d; ++k) y[k] = ye[k];
+    commit(p, st, w, ce, 1, ce_lp, ce_ll, ce_lt, accept);
+    return accept;
+}
+
 int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, uint64_t step0,
                 int n_steps, int n_threads)
 {
@@ -779,7 +854,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 have_cycle = cycle;
             }
             const double* v = V + (size_t)col * d;
-            if (p->incremental) {
+            if (p->incremental && !drag) {
                 const int K = p->n_modes;
                 if (cycle != have_u) {
                     if (!U) U = (double*)malloc(sizeof(double) * (size_t)K * L0 * d);
@@ -824,13 +899,24 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 vfp[i - 1] = Vstep + (size_t)(i - 1) * d;
                 oned[i] = f1f[fcol];
             }
+            if (p->incremental) {   /* one Gaussian mode: whitened images of the directions */
+                if (!U) U = (double*)malloc(sizeof(double) * (size_t)(1 + nd) * d);
+                orc_whiten_directions(p, 1, v, U);
+                for (int i = 1; i <= nd; ++i) orc_whiten_directions(p, 1, vfp[i - 1], U + (size_t)i * d);
+            }
             for (int l = 0; l < gs; ++l) {
                 int w = g * gs + l;
                 double r[257], Ea[257];
                 for (int i = 0; i <= nd; ++i)
                     walker_variates(k0, k1, walker0 + (uint32_t)w, step, (uint32_t)i, oned[i],
                                     &r[i], &Ea[i]);
-                total += drag_core(p, st, w, v, vfp, r, Ea);
+                if (p->incremental) {
+                    if (step % (uint64_t)p->refresh_every == 0)
+                        orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * d);
+                    total += drag_core_inc(p, st, w, v, vfp, U, r, Ea);
+                } else {
+                    total += drag_core(p, st, w, v, vfp, r, Ea);
+                }
             }
         }
         free(V); free(f1); free(Vf); free(Vstep); free(U);

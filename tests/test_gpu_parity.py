@@ -843,3 +843,35 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
     with pytest.raises(E.EngineError, match="at least two parameters"):
         eng2.step(3)
     eng.close(), eng2.close()
+
+
+@pytest.mark.parametrize("d,W,gs,blocks,last_slow,n_drag,extra", [
+    (5, 256, 64, [[0, 1], [2, 3, 4]], 0, 6, {}),
+    (30, 256, 256, [list(range(10)), list(range(10, 30))], 0, 4, {}),
+    (9, 128, 64, [[0, 1, 2], [3, 4], [5, 6, 7, 8]], 1, 9, {"T": 1.7, "burn_in": 3}),
+    # the config-5 shape: 6 slow + 21 fast parameters, normal priors on the fast ones
+    (27, 256, 128, [list(range(6)), list(range(6, 27))], 0, 7,
+     dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.25] * 21)),
+    # d > 32: the general blocked-direction kernel feeds the slow and the fast sequence
+    (40, 128, 64, [list(range(12)), list(range(12, 40))], 0, 5, {}),
+    (100, 128, 64, [list(range(30)), list(range(30, 100))], 0, 3, {})])
+def test_incremental_dragging_steps_bit_exact(d, W, gs, blocks, last_slow, n_drag, extra):
+    """The dragging step (mcmc.py:564-668) in incremental mode (drag_inc_kernel against the
+    oracle's drag_core_inc): every one of its 1 + 2 n evaluations is O(d), the whitened
+    residuals of the start and end points are dragged along; at every d <= 128."""
+    eng, prob, st = make_pair(d, W, gs, blocks=blocks,
+                              over=[1] * (last_slow + 1) + [2] * (len(blocks) - last_slow - 1),
+                              drag_last_slow=last_slow, drag_steps=n_drag, incremental=True, **extra)
+    n_slow = sum(len(b) for b in blocks[:last_slow + 1])
+    assert eng.cycle_length() == n_slow and prob.refresh_every == 40 * n_slow
+    compare_state(eng, st)
+    for n in (1, n_slow + 2, 40 * n_slow - (n_slow + 3) - 2, 6, n_slow):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residual")
+    assert st.step > 40 * n_slow and "drag_inc_kernel" in eng.last_step_kernel()
+    c = eng.counters()
+    assert c["accepted"] == int(st.n_accept.sum()) and c["accepted"] > 0.03 * W * st.step
+    eng.close()

@@ -439,3 +439,36 @@ def test_incremental_with_blocks_is_the_same_posterior():
     assert np.array_equal(a.weight, b.weight) and np.array_equal(a.n_accept, b.n_accept)
     np.testing.assert_allclose(a.x, b.x, rtol=0, atol=1e-12)
     np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
+
+
+def test_incremental_dragging_is_the_same_sampler():
+    """Dragging (mcmc.py:564-668) in incremental mode: the whitened residuals of the start and
+    end points are carried through the interpolation steps -- same accept decisions as
+    drag_core evaluating every point from scratch, y stays L^-1 (x - mu)."""
+    from oracle import cbind as O
+    d = 9
+    rng = np.random.default_rng(8)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.003
+    mean = np.full(d, 0.5)
+    blocks, over = [[0, 1, 2], [3, 4, 5, 6, 7, 8]], [1, 3]
+    kinds = [0] * d
+    kinds[4] = 1
+    a_, b_ = [0.0] * d, [1.0] * d
+    a_[4], b_[4] = 0.5, 0.2
+    T = O.blocked_transform(cov, blocks, 2.4)
+    mk = lambda inc: O.Problem(d, kinds, a_, b_, means=mean, covs=cov, T=T, group_size=64, seed=4,
+                               blocks=blocks, oversampling=over, drag_last_slow=0, drag_steps=5,
+                               incremental=inc)
+    full, inc = mk(False), mk(True)
+    assert inc.refresh_every == 40 * 3
+    x0 = np.clip(mean + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
+    a, b = O.State(full, x0), O.State(inc, x0)
+    for n in (50, 131, 200):
+        a.run(n, n_threads=4)
+        b.run(n, n_threads=4)
+        assert np.array_equal(a.weight, b.weight) and np.array_equal(a.n_accept, b.n_accept)
+        np.testing.assert_allclose(a.x, b.x, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(a.logpost, b.logpost, rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
+    assert 0.05 < a.n_accept.sum() / (128 * 381) < 0.9
