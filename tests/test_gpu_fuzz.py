@@ -101,3 +101,68 @@ def test_random_big_dimensions_bit_exact(seed):
         eng.sync()
         st.run(n, n_threads=4)
         compare_state(eng, st)
+
+
+def draw_incremental_case(seed):
+    """A random problem incremental evaluation serves: d = 2..128, 1..4 modes (d <= 64 above one
+    mode), uniform / normal priors, temperature, burn-in, blocks of >= 2 parameters with
+    oversampling, or dragging (one mode)."""
+    rng = np.random.default_rng(seed)
+    d = int(rng.choice([int(rng.integers(2, 33)), int(rng.integers(33, 65)), int(rng.integers(65, 129))],
+                       p=[0.6, 0.25, 0.15]))
+    gs = int(rng.choice([64, 128, 256]))
+    W = gs * int(rng.integers(1, 4))
+    K = int(rng.choice([1, 1, 2, 3, 4])) if d <= 64 else 1
+    kw = {}
+    if rng.random() < 0.4:
+        kinds = (rng.random(d) < 0.5).astype(int).tolist()
+        kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.05, 0.3)) if k else 1.0 for k in kinds])
+    elif rng.random() < 0.3:   # uniform priors on different intervals (MODE 1)
+        kw.update(a=[float(v) for v in rng.uniform(-0.5, 0.0, d)],
+                  b=[float(v) for v in rng.uniform(1.0, 1.5, d)])
+    if rng.random() < 0.3:
+        kw["T"] = float(rng.choice([1.5, 2.0]))
+    if rng.random() < 0.3:
+        kw["burn_in"] = int(rng.integers(1, 4))
+    if K > 1:
+        w = rng.uniform(0.2, 1.0, K)
+        kw["weights"] = (w / w.sum()).tolist()
+    L = d
+    if rng.random() < 0.5 and d >= 4:
+        perm = rng.permutation(d).tolist()
+        nb = int(rng.integers(2, min(4, d // 2) + 1))
+        cuts = sorted(rng.choice(np.arange(2, d - 1, 2), size=nb - 1, replace=False).tolist())
+        blocks = [perm[a:b] for a, b in zip([0] + cuts, cuts + [d])]
+        if min(len(b) for b in blocks) >= 2:
+            over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
+            kw.update(blocks=blocks, over=over)
+            L = sum(o * len(b) for o, b in zip(over, blocks))
+            if K == 1 and rng.random() < 0.5:
+                last = int(rng.integers(0, nb - 1))
+                kw.update(drag_last_slow=last, drag_steps=int(rng.integers(2, 6)), over=[1] * nb)
+                L = sum(len(b) for b in blocks[:last + 1])
+    steps = [int(rng.integers(1, 12)), int(rng.integers(1, L + 5)), 40 * L - int(rng.integers(0, 20)),
+             int(rng.integers(1, 30))]
+    return d, W, gs, K, kw, steps
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_INC_CASES", "40")))))
+def test_random_incremental_shapes_bit_exact(seed):
+    """Incremental evaluation on randomly drawn shapes (plain, mixture, blocked, dragging kernels;
+    every MODE; launches that end anywhere and cross the refresh at 40 cycle lengths): state,
+    carried residuals, log-posterior, weights and counts bit for bit against the oracle."""
+    from tests.test_gpu_parity import assert_bit_equal
+    d, W, gs, K, kw, steps = draw_incremental_case(9000 + seed)
+    eng, prob, st = make_pair(d, W, gs, K=K, incremental=True, rng=np.random.default_rng(seed), **kw)
+    compare_state(eng, st)
+    for n in steps:
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
+    c = eng.counters()
+    assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
+    assert "inc" in eng.last_step_kernel()
+    eng.close()
