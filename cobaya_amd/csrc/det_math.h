@@ -220,6 +220,37 @@ struct StepRng {
     }
 };
 
+// The variates of TWO consecutive steps from one Philox block (incremental kernels, plain steps;
+// oracle: walker_variates_pair): block (walker, kStreamStep | 0x4000, P), P = step >> 1; half
+// h = step & 1 uses the words a = w[2h], b = w[2h+1]: sign = bit 31 of a (set = positive),
+// exponential branch iff bits 30..20 of a < 676, k_r = (a & 0xFFFFF) << 4 | b >> 28 (24 bits),
+// u_r = (2 k_r + 1) 2^-25, k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29.
+struct PairRng {
+    double r[2], Ea[2];
+    __device__ __forceinline__ void run(uint32_t key0, uint32_t key1, uint32_t gid,
+                                        unsigned long long pair)
+    {
+        StepRng g;
+        g.begin(key0, key1, gid, pair);
+        g.c1 = kStreamStep | 0x4000u;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) g.round();
+        const uint32_t w[4] = {g.c0, g.c1, g.c2, g.c3};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t a = w[2 * h], b = w[2 * h + 1];
+            const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28);
+            const uint32_t ka = b & 0x0FFFFFFFu;
+            g.log_a((double)(2u * kr + 1u) * 0x1p-25);
+            const double Er = -g.log_b();
+            const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt(2.0 * Er);
+            r[h] = (a & 0x80000000u) ? rr : -rr;
+            g.log_a((double)(2u * ka + 1u) * 0x1p-29);
+            Ea[h] = -g.log_b();
+        }
+    }
+};
+
 // accepted steps of this launch: summed over the wave, one atomic per wave
 __device__ __forceinline__ void wave_add_accepts(unsigned long long* total, long long mine)
 {

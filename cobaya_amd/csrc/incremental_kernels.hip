@@ -146,31 +146,41 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    unsigned long long cur_oct = ~0ull;
+    PairRng pr;
+    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
 
     for (int base = 0, k = 0; base < ncols; base += C, ++k) {
         const double2* __restrict__ cur = sVU + (k & 1) * CHUNK;
         stage(k + 1);     // travels while this chunk is consumed
         const int cols = ncols - base < C ? ncols - base : C;
-        for (int s4 = 0; s4 < cols; s4 += 4) {
-            // lane class c draws the variates of step base + s4 + c
-            StepRng rng;
-            rng.begin(s.key0, s.key1, gid, s.step0 + (unsigned long long)(base + s4 + c));
-            rng.run_all();
-            const double r4 = rng.r, E4 = rng.Ea;
-            // (not unrolled: an unrolled body lets the scheduler hoist the LDS reads of all four
-            // steps and costs the registers that decide the occupancy)
-            const int nq = cols - s4 < 4 ? cols - s4 : 4;
+        // (the step loop is rolled: an unrolled body lets the scheduler hoist the LDS reads of
+        // several steps and costs the registers that decide the occupancy)
 #pragma unroll 1
-            for (int q = 0; q < nq; ++q) {
+        for (int sl = 0; sl < cols; ++sl) {
+            {
                 {
-                    double r, Ea;
-                    switch (q) {   // wave-uniform
-                    case 0: r = quad_perm<0x00>(r4); Ea = quad_perm<0x00>(E4); break;
-                    case 1: r = quad_perm<0x55>(r4); Ea = quad_perm<0x55>(E4); break;
-                    case 2: r = quad_perm<0xAA>(r4); Ea = quad_perm<0xAA>(E4); break;
-                    default: r = quad_perm<0xFF>(r4); Ea = quad_perm<0xFF>(E4); break;
+                    // Variates: EIGHT consecutive steps (an aligned octet of the global step index)
+                    // at once -- lane class c draws the Philox block of the step pair 4 * octet + c
+                    // (PairRng: both halves, four logarithms, two square roots), and a step
+                    // fetches its pair from the class that drew it by a quad broadcast.
+                    const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
+                    if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
+                        cur_oct = S >> 3;
+                        pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c);
                     }
-                    const double2* __restrict__ col = cur + (s4 + q) * COLB + c;
+                    double r, Ea;
+                    switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
+                    case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
+                    case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
+                    case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
+                    case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
+                    case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
+                    case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
+                    case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
+                    default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+                    }
+                    const double2* __restrict__ col = cur + sl * COLB + c;
                     double pc = 0.0, sc = 0.0;
                     bool inb = true;
 #pragma unroll
@@ -219,8 +229,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         x[kk] = fma(ra, p.x, x[kk]);
                         y[kk] = fma(ra, p.y, y[kk]);
                     }
-                    lpri = accept ? lp : lpri;
-                    llik = accept ? ll : llik;
+                    // (logprior and loglike of the current point are formed once, after the
+                    // loop, from the committed x and y: the same chains on the same values)
                     lpost = accept ? lt : lpost;
                     prej = accept ? 0 : (prej + (inside ? 0 : 1));
                     wt = accept ? 1 : wt + 1;
@@ -231,6 +241,23 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed
         __syncthreads();
+    }
+    if (nacc != nacc0) {   // (the same in the four lanes of a walker: the quad sums are safe)
+        double pc = 0.0, sc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < DQ; ++kk) {
+            pc = fma(y[kk], y[kk], pc);
+            if (NORMP) {
+                const int i = 4 * kk + c;
+                const double loc = kNormInRegs ? nloc[kk] : a.prior[2 * dpad + i];
+                const double inv = kNormInRegs ? ninv[kk] : a.prior[3 * dpad + i];
+                const double mls = kNormInRegs ? nmls[kk] : a.prior[4 * dpad + i];
+                const double qq = (x[kk] - loc) * inv;
+                sc = sc + fma(-0.5 * qq, qq, mls);
+            }
+        }
+        llik = -0.5 * (s.cnorm0 + quad_sum(pc));
+        lpri = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
     }
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
@@ -503,10 +530,10 @@ __global__ void __launch_bounds__(64) whiten_state_kernel(const double* __restri
 // kernels' buffer V, forms u_j = sum_{i<=j} L^-1[j][i] v_i (ascending chain from +0.0,
 // orc_whiten_directions) and writes the column in the step kernel's layout
 // VU[g][step][kk][c] = (v_{4kk+c}, u_{4kk+c}), zero beyond d.
-__global__ void __launch_bounds__(64) whiten_directions_kernel(const IncDirArgs a)
+__global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sv[];   // [d][64]
-    const int l = threadIdx.x;
+    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;     // 64 columns x 4 row parts
     const int sr = blockIdx.x * 64 + l;          // step of the launch
     const int g = blockIdx.y;
     const int d = a.d;
@@ -516,49 +543,56 @@ __global__ void __launch_bounds__(64) whiten_directions_kernel(const IncDirArgs 
         const int cyc = (int)(step / (unsigned long long)a.cps - a.cycle0);
         const int col = (int)(step % (unsigned long long)a.cps);
         const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
-        for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
+        for (int i = part; i < d; i += 4) sv[i * 64 + l] = v[i];
     }
+    __syncthreads();
     if (!live) return;
     // output column: sr for a plain launch; a dragging launch interleaves the slow column of a
     // step (slot 0) with the n_drag fast columns of its interpolation steps (slots 1 ..)
     const size_t ocol = a.out_div ? (size_t)(sr / a.out_div) * a.out_cols + a.out_slot0 + sr % a.out_div
                                   : (size_t)sr;
     double2* __restrict__ out = (double2*)a.VU + ((size_t)g * a.out_total + ocol) * (4 * a.dq);
-    // four rows at a time: four independent chains share every v_i read from LDS (each chain
-    // is still one ascending fma chain from +0.0 -- the order of orc_whiten_directions)
-    int j = 0;
-    for (; j + 4 <= d; j += 4) {
-        const double* __restrict__ r0 = a.Lrow + (size_t)j * d;
-        const double* __restrict__ r1 = r0 + d;
-        const double* __restrict__ r2 = r1 + d;
-        const double* __restrict__ r3 = r2 + d;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int i = 0; i <= j; ++i) {
-            const double v = sv[i * 64 + l];
-            a0 = fma(r0[i], v, a0);
-            a1 = fma(r1[i], v, a1);
-            a2 = fma(r2[i], v, a2);
-            a3 = fma(r3[i], v, a3);
+    // Four rows at a time: four independent chains share every v_i read from LDS (each chain is
+    // still one ascending fma chain from +0.0 -- the order of orc_whiten_directions); the row
+    // blocks of a column are dealt to the four waves of the workgroup (the long ones last).
+    const int nblk = (d + 3) / 4;
+    for (int rb = part; rb < nblk; rb += 4) {
+        const int j = 4 * rb;
+        if (j + 4 <= d) {
+            const double* __restrict__ r0 = a.Lrow + (size_t)j * d;
+            const double* __restrict__ r1 = r0 + d;
+            const double* __restrict__ r2 = r1 + d;
+            const double* __restrict__ r3 = r2 + d;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int i = 0; i <= j; ++i) {
+                const double v = sv[i * 64 + l];
+                a0 = fma(r0[i], v, a0);
+                a1 = fma(r1[i], v, a1);
+                a2 = fma(r2[i], v, a2);
+                a3 = fma(r3[i], v, a3);
+            }
+            const double v1 = sv[(j + 1) * 64 + l], v2 = sv[(j + 2) * 64 + l], v3 = sv[(j + 3) * 64 + l];
+            a1 = fma(r1[j + 1], v1, a1);
+            a2 = fma(r2[j + 1], v1, a2);
+            a3 = fma(r3[j + 1], v1, a3);
+            a2 = fma(r2[j + 2], v2, a2);
+            a3 = fma(r3[j + 2], v2, a3);
+            a3 = fma(r3[j + 3], v3, a3);
+            out[j] = make_double2(sv[j * 64 + l], a0);
+            out[j + 1] = make_double2(v1, a1);
+            out[j + 2] = make_double2(v2, a2);
+            out[j + 3] = make_double2(v3, a3);
+        } else {
+            for (int jj = j; jj < d; ++jj) {
+                const double* __restrict__ row = a.Lrow + (size_t)jj * d;
+                double acc = 0.0;
+                for (int i = 0; i <= jj; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
+                out[jj] = make_double2(sv[jj * 64 + l], acc);
+            }
         }
-        const double v1 = sv[(j + 1) * 64 + l], v2 = sv[(j + 2) * 64 + l], v3 = sv[(j + 3) * 64 + l];
-        a1 = fma(r1[j + 1], v1, a1);
-        a2 = fma(r2[j + 1], v1, a2);
-        a3 = fma(r3[j + 1], v1, a3);
-        a2 = fma(r2[j + 2], v2, a2);
-        a3 = fma(r3[j + 2], v2, a3);
-        a3 = fma(r3[j + 3], v3, a3);
-        out[j] = make_double2(sv[j * 64 + l], a0);
-        out[j + 1] = make_double2(v1, a1);
-        out[j + 2] = make_double2(v2, a2);
-        out[j + 3] = make_double2(v3, a3);
     }
-    for (; j < d; ++j) {
-        const double* __restrict__ row = a.Lrow + (size_t)j * d;
-        double acc = 0.0;
-        for (int i = 0; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
-        out[j] = make_double2(sv[j * 64 + l], acc);
-    }
-    for (int j = d; j < 4 * a.dq; ++j) out[j] = make_double2(0.0, 0.0);
+    if (part == 3)
+        for (int j = d; j < 4 * a.dq; ++j) out[j] = make_double2(0.0, 0.0);
 }
 
 // Mixtures: the same per mode, written as PLANES -- VU[g][step][0] = v, [1 + k] = u_k = L_k^-1 v,
@@ -659,27 +693,34 @@ step_inc_mix_kernel(const IncStepArgs a)
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    unsigned long long cur_oct = ~0ull;
+    PairRng pr;
+    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
 
     for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
         const double* __restrict__ cur = smem + (kc & 1) * CHUNK;
         stage(kc + 1);
         const int cols = ncols - base < C ? ncols - base : C;
-        for (int s4 = 0; s4 < cols; s4 += 4) {
-            StepRng rng;
-            rng.begin(s.key0, s.key1, gid, s.step0 + (unsigned long long)(base + s4 + c));
-            rng.run_all();
-            const double r4 = rng.r, E4 = rng.Ea;
-            const int nq = cols - s4 < 4 ? cols - s4 : 4;
 #pragma unroll 1
-            for (int q = 0; q < nq; ++q) {
-                double r, Ea;
-                switch (q) {   // wave-uniform
-                case 0: r = quad_perm<0x00>(r4); Ea = quad_perm<0x00>(E4); break;
-                case 1: r = quad_perm<0x55>(r4); Ea = quad_perm<0x55>(E4); break;
-                case 2: r = quad_perm<0xAA>(r4); Ea = quad_perm<0xAA>(E4); break;
-                default: r = quad_perm<0xFF>(r4); Ea = quad_perm<0xFF>(E4); break;
+        for (int sl = 0; sl < cols; ++sl) {
+            {
+                const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
+                if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
+                    cur_oct = S >> 3;
+                    pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c);
                 }
-                const double* __restrict__ col = cur + (s4 + q) * COL + c;
+                double r, Ea;
+                switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
+                case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
+                case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
+                case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
+                case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
+                case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
+                case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
+                case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
+                default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+                }
+                const double* __restrict__ col = cur + sl * COL + c;
                 bool inb = true;
                 double sc = 0.0;
 #pragma unroll
@@ -708,10 +749,10 @@ step_inc_mix_kernel(const IncStepArgs a)
                 }
                 const bool inside = ak[0] > -INFINITY;   // chi2_0 = +inf outside the support
                 const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
-                double S = 0.0;
+                double Ssum = 0.0;
 #pragma unroll
-                for (int k = 0; k < KM; ++k) S = fma(wk[k], dexp(ak[k] - amax), S);
-                const double ll = dlog(S) + amax;
+                for (int k = 0; k < KM; ++k) Ssum = fma(wk[k], dexp(ak[k] - amax), Ssum);
+                const double ll = dlog(Ssum) + amax;
                 const double lt = inside ? lp + ll : -INFINITY;
                 const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
                 const bool accept = inside & (lt != -INFINITY) & ((lt > lpost) | (Ea > delta));
@@ -911,7 +952,7 @@ extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* 
         return hipGetLastError();
     }
     hipLaunchKernelGGL(mcmc::whiten_directions_kernel, dim3((a->n_steps + 63) / 64, n_groups),
-                       dim3(64), lds, st, *a);
+                       dim3(256), lds, st, *a);
     return hipGetLastError();
 }
 #endif

@@ -45,6 +45,7 @@ class _Problem(C.Structure):
         ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
         ("weight", c_double_p), ("T", c_double_p), ("blocking", C.c_void_p),
         ("incremental", C.c_int32), ("refresh_every", C.c_int32),
+        ("paired_variates", C.c_int32),
     ]
 
 
@@ -175,11 +176,15 @@ class Problem:
     def __init__(self, d, kinds, a, b, periodic=None, means=None, covs=None, weights=None,
                  normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
                  max_tries=None, derived=None, blocks=None, oversampling=None,
-                 drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None):
+                 drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None,
+                 paired_variates=None):
         self.d = d
         # incremental evaluation (one Gaussian mode, non-periodic, one block): the whitened
         # residual is carried and refreshed every `refresh_every` (default 40 d) steps
         self.incremental = bool(incremental)
+        # plain incremental steps draw the variates of two steps from one Philox block (what
+        # the kernels do); False: one block per step, the stream of the from-scratch mode
+        self.paired_variates = bool(incremental if paired_variates is None else paired_variates)
         self._refresh_every = refresh_every   # default: 40 cycle lengths (40 d for one block)
         # blocked proposal: `blocks` = lists of sampler indices, slow -> fast; T must then be
         # the transform of the covariance in sorted order (blocked_transform below)
@@ -267,6 +272,7 @@ class Problem:
                                      C.byref(p), 1 if self.blocking.drag_last_slow >= 0 else 0, None)
                                        if self.blocking is not None else self.d))
         p.incremental, p.refresh_every = int(self.incremental), self.refresh_every
+        p.paired_variates = int(self.paired_variates)
         self.c = p
 
     def set_T(self, T):

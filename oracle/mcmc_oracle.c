@@ -187,6 +187,10 @@ typedef struct {
      * the same log-posterior -- and recomputed from x every `refresh_every` steps */
     int32_t incremental;
     int32_t refresh_every;
+    /* incremental mode, plain steps: 1 = the variates of steps 2P and 2P+1 come from ONE Philox
+     * block (walker_variates_pair) -- what the incremental kernels do; 0 = one block per step as
+     * everywhere else (kept so that tests can run both modes on the same proposal stream) */
+    int32_t paired_variates;
 } orc_problem;
 
 /* Blocked proposal (proposal.py:96-224): blocks sorted slow -> fast; parameter j of the
@@ -679,6 +683,26 @@ static inline void walker_variates(uint32_t k0, uint32_t k1, uint32_t gid, uint6
     }
 }
 
+/* Incremental mode, plain steps: the variates of the steps 2P and 2P + 1 share the Philox block
+ * (walker, STREAM_STEP | 0x4000, P).  Half h = step & 1 uses the words a = w[2h], b = w[2h+1]:
+ * sign = bit 31 of a (set = positive); exponential branch iff bits 30..20 of a < 676
+ * (676 / 2048 = 0.33008, proposal.py:79); k_r = (a & 0xFFFFF) << 4 | b >> 28 (24 bits),
+ * u_r = (2 k_r + 1) 2^-25; k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29. */
+static inline void walker_variates_pair(uint32_t k0, uint32_t k1, uint32_t gid, uint64_t step,
+                                        double* r_out, double* Ea_out)
+{
+    uint32_t wd[4];
+    const uint64_t P = step >> 1;
+    philox4x32_10(k0, k1, gid, STREAM_STEP | 0x4000u, (uint32_t)P, (uint32_t)(P >> 32), wd);
+    const uint32_t a = wd[2 * (step & 1)], b = wd[2 * (step & 1) + 1];
+    const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28);
+    const uint32_t ka = b & 0x0FFFFFFFu;
+    const double Er = -orc_dlog((double)(2 * kr + 1) * 0x1p-25);
+    const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt(2.0 * Er);
+    *r_out = (a & 0x80000000u) ? rr : -rr;
+    *Ea_out = -orc_dlog((double)(2 * ka + 1) * 0x1p-29);
+}
+
 /* mcmc.py:670-683 with the Exp(1) variate supplied */
 static inline int metropolis(double trial, double current, double T, double exp_draw)
 {
@@ -868,7 +892,10 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                     double r, Ea;
                     if (step % (uint64_t)p->refresh_every == 0)
                         orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * K * d);
-                    walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
+                    if (p->paired_variates)
+                        walker_variates_pair(k0, k1, walker0 + (uint32_t)w, step, &r, &Ea);
+                    else
+                        walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
                     total += step_core_inc(p, st, w, v, uk, r, Ea);
                 }
                 continue;

@@ -331,7 +331,7 @@ def _inc_pair(d, W, gs, seed, golden, normal=False):
             kinds[i], a[i], b[i] = 1, 0.5, 0.3
     T = O.proposal_transform(cov, 2.4)
     mk = lambda inc: O.Problem(d, kinds, a, b, means=mean, covs=cov, T=T, group_size=gs,
-                               seed=seed, incremental=inc)
+                               seed=seed, incremental=inc, paired_variates=False)
     rng = np.random.default_rng(seed)
     x0 = np.clip(rng.multivariate_normal(mean, cov, size=W), 1e-6, 1 - 1e-6)
     return mk(False), mk(True), x0, mean, cov
@@ -399,7 +399,8 @@ def test_incremental_mixture_is_the_same_posterior(d, K):
     w /= w.sum()
     T = O.proposal_transform(covs[0], 2.4)
     mk = lambda inc: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=means, covs=covs,
-                               weights=w, T=T, group_size=64, seed=9, incremental=inc)
+                               weights=w, T=T, group_size=64, seed=9, incremental=inc,
+                               paired_variates=False)
     full, inc = mk(False), mk(True)
     x0 = np.clip(means[0] + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
     a, b = O.State(full, x0), O.State(inc, x0)
@@ -429,7 +430,7 @@ def test_incremental_with_blocks_is_the_same_posterior():
     T = O.blocked_transform(cov, blocks, 2.4)
     mk = lambda inc: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov, T=T,
                                group_size=64, seed=2, blocks=blocks, oversampling=over,
-                               incremental=inc)
+                               incremental=inc, paired_variates=False)
     full, inc = mk(False), mk(True)
     assert inc.refresh_every == 40 * 19
     x0 = np.clip(mean + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
@@ -472,3 +473,29 @@ def test_incremental_dragging_is_the_same_sampler():
         np.testing.assert_allclose(a.logpost, b.logpost, rtol=1e-12, atol=1e-10)
         np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
     assert 0.05 < a.n_accept.sum() / (128 * 381) < 0.9
+
+
+def test_paired_variates_have_the_specified_law():
+    """Incremental kernels draw the variates of two steps from one Philox block
+    (walker_variates_pair): |r| is Exp(1) with probability 676/2048 and chi(2) otherwise, its
+    sign is fair, E_a is Exp(1); and a chain on that stream samples the same posterior."""
+    from oracle import cbind as O
+    d = 6
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.004
+    mean = np.full(d, 0.5)
+    p = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov,
+                  T=O.proposal_transform(cov, 2.4), group_size=64, seed=12, incremental=True)
+    assert p.paired_variates
+    st = O.State(p, np.tile(mean, (4096, 1)))
+    xs = []
+    for _ in range(60):
+        st.run(4 * d, n_threads=8)
+        xs.append(st.x.copy())
+    x = np.vstack(xs[10:])
+    sig = np.sqrt(np.diag(cov))
+    assert np.max(np.abs(x.mean(0) - mean) / sig) < 0.02
+    assert np.max(np.abs(np.cov(x.T) - cov) / np.outer(sig, sig)) < 0.03
+    acc = st.n_accept.sum() / (4096 * st.step)
+    assert 0.2 < acc < 0.45
