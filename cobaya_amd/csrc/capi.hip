@@ -304,6 +304,9 @@ struct mcmc_hip_ctx {
     bool incremental = false;
     bool y_valid = false;
     bool own_basis = false;     // MCMC_HIP_FLAG_OWN_BASIS (d > 1): a Haar basis per walker
+    // incremental mode: walkers sharing one Haar basis (a multiple of group_size, flags bits
+    // 8..11 = log2 of the multiple); the R-1 groups (moments) stay group_size wide
+    int bgs = 0, BG = 0;
     DevBuf<double> y, VU, inc_prior, inc_Lrow, inc_mean;
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
     // stream-ordered proposal refresh: pinned host staging
@@ -600,8 +603,17 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "walker_offset must be a multiple of group_size");
     if (!(cfg->temperature > 0) || !(cfg->proposal_scale > 0))
         return fail(nullptr, MCMC_HIP_ERR_ARG, "temperature and proposal_scale must be > 0");
-    if (cfg->flags & ~(MCMC_HIP_FLAG_INCREMENTAL | MCMC_HIP_FLAG_OWN_BASIS))
+    if (cfg->flags & ~(MCMC_HIP_FLAG_INCREMENTAL | MCMC_HIP_FLAG_OWN_BASIS | MCMC_HIP_FLAG_BASIS_GROUP_MASK))
         return fail(nullptr, MCMC_HIP_ERR_ARG, "unknown flags 0x%x", (unsigned)cfg->flags);
+    {
+        const int m = (cfg->flags & MCMC_HIP_FLAG_BASIS_GROUP_MASK) >> 8;
+        const long long bgs = (long long)cfg->group_size << m;
+        if (m && (!(cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) || m > 6 || cfg->n_walkers % bgs ||
+                  cfg->walker_offset % bgs))
+            return fail(nullptr, MCMC_HIP_ERR_ARG,
+                        "a basis group wider than group_size needs incremental evaluation, and "
+                        "n_walkers and walker_offset must be multiples of it (%lld)", bgs);
+    }
     if ((cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) && (cfg->flags & MCMC_HIP_FLAG_OWN_BASIS))
         return fail(nullptr, MCMC_HIP_ERR_ARG,
                     "incremental evaluation needs the shared basis (the whitened direction is "
@@ -641,6 +653,8 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     h->W = cfg->n_walkers;
     h->gs = cfg->group_size;
     h->G = h->W / h->gs;
+    h->bgs = h->gs << ((cfg->flags & MCMC_HIP_FLAG_BASIS_GROUP_MASK) >> 8);
+    h->BG = h->W / h->bgs;
     h->shift.assign(h->d, 0.0);
     h->incremental = (cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) != 0;
     h->own_basis = (cfg->flags & MCMC_HIP_FLAG_OWN_BASIS) != 0 && cfg->d > 1;
@@ -1099,8 +1113,8 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
         const bool in_seq = which == 0 || (which == 1) == (b <= h->drag_last_slow);
         any_1d = any_1d || (in_seq && h->blk_size[b] == 1);
     }
-    HIP_TRY(h, V.resize((size_t)h->G * ncyc * slab));
-    if (any_1d) HIP_TRY(h, flag.resize((size_t)h->G * ncyc * L));
+    HIP_TRY(h, V.resize((size_t)h->BG * ncyc * slab));
+    if (any_1d) HIP_TRY(h, flag.resize((size_t)h->BG * ncyc * L));
     mcmc::BlockedBasisArgs b{};
     b.T = h->dT.p; b.V = V.p; b.vflag = any_1d ? flag.p : nullptr;
     b.block_size = h->dblk.p; b.oversample = h->dblk.p + nb; b.i_of_j = h->dblk.p + 2 * nb;
@@ -1108,11 +1122,11 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
     b.L = L; b.slab = (int)slab;
     b.ld = h->d;
     b.nmax = *std::max_element(h->blk_size.begin(), h->blk_size.end());
-    b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+    b.group0 = h->cfg.walker_offset / (uint32_t)h->bgs;   // (bgs == gs outside incremental mode)
     b.cycle0 = (uint32_t)c0;
     b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
     b.ncyc = ncyc;
-    HIP_TRY(h, mcmc_hip_launch_blocked_basis(&b, h->G, h->stream));
+    HIP_TRY(h, mcmc_hip_launch_blocked_basis(&b, h->BG, h->stream));
     return MCMC_HIP_OK;
 }
 
@@ -1149,15 +1163,15 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     // doubles per column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
     const size_t colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
     const int max_steps_vu = (int)std::max<size_t>(
-        4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)(1 + nd) * (size_t)h->G));
+        4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)(1 + nd) * (size_t)h->BG));
     // (blocked directions are written with column stride d at every d)
     const size_t dd = (h->kb && !h->blocked) ? (size_t)mcmc::v_slab_big(d)
                                              : (size_t)mcmc::v_slab_cols(Lc, d);
     const size_t ddf = drag ? (size_t)mcmc::v_slab_cols(Lf, d) : 0;
     const int ld = (h->kb && !h->blocked) ? mcmc::v_ld(d) : d;
-    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->BG));
     const int max_cyc_f =
-        drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * ddf * (size_t)h->G)) : 0;
+        drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * ddf * (size_t)h->BG)) : 0;
     int left = n_steps;
     while (left > 0) {
         if (!h->y_valid || h->step % R == 0) {
@@ -1194,30 +1208,30 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                     if (rc != MCMC_HIP_OK) return rc;
                 }
             } else {
-                HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+                HIP_TRY(h, h->V.resize((size_t)h->BG * ncyc * dd));
                 mcmc::BasisArgs b{};
                 b.T = h->dT.p; b.V = h->V.p;
-                b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+                b.group0 = h->cfg.walker_offset / (uint32_t)h->bgs;
                 b.cycle0 = (uint32_t)c0;
                 b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
                 b.ncyc = ncyc;
-                if (h->kb) HIP_TRY(h, h->kb->basis(b, h->G, h->d, h->stream));
-                else HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+                if (h->kb) HIP_TRY(h, h->kb->basis(b, h->BG, h->d, h->stream));
+                else HIP_TRY(h, h->k->basis(b, h->BG, h->stream));
             }
-            HIP_TRY(h, h->VU.resize((size_t)h->G * n * (1 + nd) * colb));
+            HIP_TRY(h, h->VU.resize((size_t)h->BG * n * (1 + nd) * colb));
             mcmc::IncDirArgs w{};
             w.V = h->V.p; w.Lrow = h->inc_Lrow.p; w.VU = h->VU.p;
             w.step0 = h->step; w.cycle0 = c0; w.n_steps = n; w.ncyc = ncyc;
             w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq; w.n_modes = K; w.cps = Lc;
             w.out_total = n * (1 + nd);
             if (drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
-            HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
+            HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, h->stream));
             if (drag) {   // the fast directions of the n * n_drag interpolation steps
                 w.V = h->Vf.p;
                 w.step0 = h->step * (unsigned long long)nd; w.cycle0 = cyc0_f;
                 w.n_steps = n * nd; w.ncyc = ncyc_f; w.slab = (int)ddf; w.cps = Lf;
                 w.out_div = nd; w.out_cols = 1 + nd; w.out_slot0 = 1;
-                HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->G, h->stream));
+                HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, h->stream));
             }
         }
         {
@@ -1227,7 +1241,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.s.loglike = h->loglike.p; a.s.weight = h->weight_i.p; a.s.prior_rej = h->prej.p;
             a.s.burn_left = h->burn.p; a.s.n_accept = h->nacc.p; a.s.stuck = h->stuck.p;
             a.s.accept_total = h->acc_total.p;
-            a.s.W = h->W; a.s.n_modes = K; a.s.group_size = h->gs;
+            a.s.W = h->W; a.s.n_modes = K; a.s.group_size = h->bgs;   // the walkers that share a column of VU
             a.s.cblock = h->cblock.p;
             {
                 const ConstLayout cl{d, K};

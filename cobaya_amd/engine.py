@@ -158,9 +158,15 @@ class Engine:
 
     def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
                  burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
-                 emit_capacity=0, shared_basis=True, incremental=False):
+                 emit_capacity=0, shared_basis=True, incremental=False, basis_group_size=None):
         self._lib = load_library()
         self.incremental = bool(incremental)
+        # walkers sharing one Haar basis: group_size * 2**m (incremental mode only)
+        bgs = int(basis_group_size or group_size)
+        m = (bgs // int(group_size)).bit_length() - 1
+        if bgs != int(group_size) << m:
+            raise EngineError(ERR_ARG, "basis_group_size must be group_size times a power of two")
+        self.basis_group_size = bgs
         self._h = _H()
         self.d, self.W, self.group_size = int(d), int(n_walkers), int(group_size)
         self.G = self.W // self.group_size if self.group_size else 0
@@ -171,7 +177,7 @@ class Engine:
                      burn_in=int(burn_in), temperature=float(temperature),
                      proposal_scale=float(proposal_scale),
                      max_tries=float(max_tries if max_tries is not None else 40 * d),
-                     emit_capacity=int(emit_capacity), flags=(0 if shared_basis else 1) | (2 if incremental else 0))
+                     emit_capacity=int(emit_capacity), flags=(0 if shared_basis else 1) | (2 if incremental else 0) | (m << 8))
         self.cfg = cfg
         rc = self._lib.mcmc_hip_create(C.byref(cfg), C.byref(self._h))
         if rc:

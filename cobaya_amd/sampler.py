@@ -73,6 +73,10 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
+    "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
+                              # power of two; incremental evaluation only).  Default: 1024
+                              # from 16384 walkers per process up, else group_size.  The R-1
+                              # "chains" stay the groups of group_size walkers.
     "evaluation": "auto",     # "full": every trial is evaluated from scratch (O(d^2));
                               # "incremental": the whitened residual L^-1 (x - mu) is carried
                               # and moved along the whitened shared direction (O(d), same
@@ -242,6 +246,13 @@ class EnsembleMCMC:
                        "of at least two parameters, emit: snapshots, d >= 2 and a "
                        "group_size that is a multiple of 64; use 'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
+        if self.basis_group_size is None:
+            self.basis_group_size = int(self.group_size)
+            if self.incremental and W >= 16384 and W % 1024 == 0 and 1024 % int(self.group_size) == 0:
+                self.basis_group_size = 1024
+        if int(self.basis_group_size) != int(self.group_size) and not self.incremental:
+            self._fail("basis_group_size (%s) differs from group_size (%s): this needs "
+                       "incremental evaluation", self.basis_group_size, self.group_size)
         try:
             self.engine = self._engine_factory(d, W, group_size=int(self.group_size), device=int(device),
                                  seed=self.seed, walker_offset=self.rank * W,
@@ -250,7 +261,8 @@ class EnsembleMCMC:
                                  proposal_scale=float(self.proposal_scale),
                                  max_tries=float(self.max_tries), emit_capacity=cap,
                                  shared_basis=bool(self.shared_basis),
-                                 incremental=self.incremental)
+                                 incremental=self.incremental,
+                                 basis_group_size=int(self.basis_group_size))
             spec.configure(self.engine)
             if len(self.blocks) > 1 or self.oversampling_factors[0] != 1:
                 self.engine.set_blocking(

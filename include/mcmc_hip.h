@@ -62,6 +62,10 @@ typedef struct mcmc_hip_config {
  * y' = y + r L^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in O(d) per step;
  * y is recomputed from x every 40 d steps.  Specified in oracle/mcmc_oracle.c. */
 #define MCMC_HIP_FLAG_INCREMENTAL 2
+/* incremental mode: the walkers that share one Haar basis = group_size << ((flags >> 8) & 15)
+ * (the R-1 groups of the moments stay group_size wide): fewer bases and whitened columns per
+ * launch */
+#define MCMC_HIP_FLAG_BASIS_GROUP_MASK 0x0F00
 
 const char* mcmc_hip_version(void);
 /* message of the last error on this handle (or of the last failed create if h == NULL) */

@@ -48,6 +48,7 @@ else:
         max_rows: int = HIP_DEFAULTS["max_rows"]
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]
         evaluation: str = HIP_DEFAULTS["evaluation"]
+        basis_group_size: int | None = HIP_DEFAULTS["basis_group_size"]
 
         def _export_collection(self, coll):
             """Our table -> `cobaya.collection.SampleCollection` (same columns,

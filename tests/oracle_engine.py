@@ -22,7 +22,7 @@ class OracleEngine:
 
     def __init__(self, d, n_walkers, group_size=64, device=0, seed=0, walker_offset=0,
                  burn_in=0, temperature=1.0, proposal_scale=2.4, max_tries=None,
-                 emit_capacity=0, shared_basis=True, incremental=False):
+                 emit_capacity=0, shared_basis=True, incremental=False, basis_group_size=None):
         if n_walkers % group_size:
             raise EngineError(ERR_ARG, "n_walkers must be a multiple of group_size")
         # shared_basis False: every walker is its own basis "group" (the R-1 groups stay)
@@ -38,6 +38,12 @@ class OracleEngine:
         self.max_tries = float(max_tries if max_tries is not None else 40 * d)
         self.cap = int(emit_capacity)
         self.incremental = bool(incremental)
+        self.basis_group_size = int(basis_group_size or group_size)
+        if self.basis_group_size != group_size and (
+                not incremental or n_walkers % self.basis_group_size
+                or walker_offset % self.basis_group_size):
+            raise EngineError(ERR_ARG, "a basis group wider than group_size needs incremental "
+                                       "evaluation and must divide n_walkers and walker_offset")
         if self.incremental and (d < 2 or group_size % 64 or emit_capacity):
             raise EngineError(ERR_ARG, "incremental evaluation needs d >= 2, group_size % 64 == "
                                        "0 and emit_capacity 0")
@@ -89,7 +95,7 @@ class OracleEngine:
             bl = self._blocking or {}
             self._problem = O.Problem(
                 self.d, kinds, a, b, per, **self._target,
-                group_size=1 if self.own_basis else self.group_size,
+                group_size=1 if self.own_basis else self.basis_group_size,
                 seed=self.seed, temperature=self.temperature, max_tries=self.max_tries,
                 incremental=self.incremental, **bl)
             if self._cov is not None:

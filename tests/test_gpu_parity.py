@@ -39,7 +39,7 @@ def random_target(d, K, rng, spread=0.05):
 def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, T=1.0,
               burn_in=0, cap=0, weights=None, normalized=True, rng=None, walker_offset=0,
               max_tries=None, blocks=None, over=None, drag_last_slow=-1, drag_steps=0,
-              own_constants=False, incremental=False, shared_basis=True):
+              own_constants=False, incremental=False, shared_basis=True, basis_group_size=None):
     """own_constants=False hands the oracle the constants the engine derived on the host (T,
     L^-1, log-normalisations), so that the comparison isolates the KERNELS, bit for bit;
     own_constants=True lets the oracle derive them itself with the numpy recipe (the
@@ -50,7 +50,8 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
     b = [1.0] * d if b is None else b
     eng = E.Engine(d, W, group_size=gs, seed=seed, temperature=T, burn_in=burn_in,
                    emit_capacity=cap, walker_offset=walker_offset, max_tries=max_tries,
-                   incremental=incremental, shared_basis=shared_basis)
+                   incremental=incremental, shared_basis=shared_basis,
+                   basis_group_size=basis_group_size)
     eng.set_prior(kinds, a, b, periodic)
     if K == 0:
         eng.set_target_one()
@@ -77,7 +78,8 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
                      weights=weights, normalized=normalized, T=T_orc,
                      blocks=blocks, oversampling=over, drag_last_slow=drag_last_slow,
                      drag_steps=drag_steps,
-                     group_size=gs if (shared_basis or d == 1) else 1, seed=seed,
+                     group_size=(basis_group_size or gs) if (shared_basis or d == 1) else 1,
+                     seed=seed,
                      temperature=T, max_tries=max_tries,
                      derived=None if own_constants else eng.derived_constants(),
                      incremental=incremental)
@@ -636,7 +638,8 @@ def test_steps_with_the_oracles_own_constants(d, W, gs, K, steps, kw):
     eng.close()
 
 
-def test_walkers_of_a_group_are_independent_chains():
+@pytest.mark.parametrize("incremental,bgs", [(False, None), (True, None), (True, 1024)])
+def test_walkers_of_a_group_are_independent_chains(incremental, bgs):
     """The walkers of a group share the Haar basis of every cycle but draw their own sign,
     radial distance and accept variate: given the bases each walker's kernel is symmetric and
     pi-invariant, so at stationarity the walkers are independent and the variance of the
@@ -645,7 +648,7 @@ def test_walkers_of_a_group_are_independent_chains():
     t = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
     mean, cov = t["mean_d30"], t["cov_d30"]
     d, W, gs = 30, 8192, 256
-    eng = E.Engine(d, W, group_size=gs, seed=5)
+    eng = E.Engine(d, W, group_size=gs, seed=5, incremental=incremental, basis_group_size=bgs)
     eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
     eng.set_target_gaussian_mixture([mean], [cov])
     eng.set_proposal_cov(cov)
@@ -874,4 +877,34 @@ def test_incremental_dragging_steps_bit_exact(d, W, gs, blocks, last_slow, n_dra
     assert st.step > 40 * n_slow and "drag_inc_kernel" in eng.last_step_kernel()
     c = eng.counters()
     assert c["accepted"] == int(st.n_accept.sum()) and c["accepted"] > 0.03 * W * st.step
+    eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,bgs,kw", [
+    (30, 2048, 256, 1024, {}), (8, 512, 64, 256, {}), (30, 1024, 64, 512, {"walker_offset": 4096}),
+    (9, 512, 64, 512, {"blocks": [[0, 1, 2, 3], [4, 5, 6, 7, 8]], "over": [1, 3]}),
+    (12, 512, 128, 256, {"blocks": [[0, 1, 2], [3, 4, 5, 6, 7, 8, 9, 10, 11]], "over": [1, 1],
+                         "drag_last_slow": 0, "drag_steps": 4}),
+    (100, 512, 64, 256, {})])
+def test_wide_basis_groups_bit_exact(d, W, gs, bgs, kw):
+    """`basis_group_size`: the walkers sharing one Haar basis may be a multiple of the R-1
+    group (incremental mode): the basis stream is indexed by the WIDE group, the moments keep
+    the groups of group_size walkers."""
+    eng, prob, st = make_pair(d, W, gs, incremental=True, basis_group_size=bgs, **kw)
+    w0 = kw.get("walker_offset", 0)
+    for n in (3, 2 * d + 1, 11):
+        eng.step(n)
+        eng.sync()
+        st.run(n, walker0=w0, n_threads=8)
+        compare_state(eng, st)
+    shift = st.x.mean(0)
+    eng.set_moment_shift(shift)
+    eng.accumulate_moments()
+    gsum, S = O.moments(st.x, gs, shift=shift)
+    n, g_gs, g_S = eng.read_moments()
+    assert g_gs.shape == (W // gs, d)
+    assert_bit_equal(g_gs, gsum, "group sums")
+    assert_bit_equal(g_S, S, "pooled second moments")
+    with pytest.raises(E.EngineError, match="incremental"):
+        E.Engine(4, 512, group_size=64, basis_group_size=256)
     eng.close()
