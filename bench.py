@@ -107,14 +107,15 @@ def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots", evaluati
     }
 
 
-def cpu_baseline(d, mean, cov, group_size, seconds):
-    """The CPU oracle (oracle/mcmc_oracle.c, the bit-exact port of the ensemble algorithm)
-    timed on this host's cores on a bounded sample of the same workload."""
+def cpu_baseline(d, mean, cov, group_size, seconds, incremental):
+    """The CPU oracle (oracle/mcmc_oracle.c, the bit-exact port of the ensemble algorithm, in
+    the same evaluation mode as the GPU run) timed on this host's cores on a bounded sample of
+    the same workload."""
     from oracle import cbind as O
     threads = O.max_threads()
     T = O.proposal_transform(cov, 2.4)
     prob = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov, T=T,
-                     group_size=group_size, seed=1)
+                     group_size=group_size, seed=1, incremental=incremental)
     rng = np.random.default_rng(1)
     W = group_size * max(threads, 1) * 4
     x0 = np.clip(mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov)), 1e-6, 1 - 1e-6)
@@ -128,6 +129,7 @@ def cpu_baseline(d, mean, cov, group_size, seconds):
         steps += chunk
     return {"value": W * steps / dt, "unit": "evals/s", "cores": threads, "kind": "port",
             "sample": f"{W} walkers x {steps} steps of the same d={d} workload, "
+                      f"{'incremental' if incremental else 'full'} evaluation, "
                       f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c)"}
 
 
@@ -344,7 +346,8 @@ def main():
             "variants": variants,
         }
         if size == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(d, mean, cov, m["group_size"], a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(d, mean, cov, m["group_size"], a.cpu_seconds,
+                                               m["evaluation"] == "incremental")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

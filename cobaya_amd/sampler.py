@@ -456,15 +456,17 @@ class EnsembleMCMC:
                 self._fail("A proposal covariance matrix has been loaded, but none "
                                        "of its parameters are actually sampled here.")
             cov[np.ix_(idx_s, idx_s)] = covmat[np.ix_(idx_l, idx_l)]
-        where_nan = np.isnan(cov.diagonal())
-        if np.any(where_nan):
-            prop = np.array([(p or np.nan) ** 2 if p is not None else np.nan
-                             for p in spec.proposal], dtype=float)
-            cov[where_nan, where_nan] = prop[where_nan]
-        where_nan2 = np.isnan(cov.diagonal())
-        if np.any(where_nan2):
-            cov[where_nan2, where_nan2] = (spec.reference_variances()[where_nan2]
-                                           / self.fallback_covmat_scale)
+        # variances the matrix did not provide, in order of preference: `proposal` width
+        # squared, then the ref pdf's variance (prior's where there is none) over
+        # `fallback_covmat_scale`; the first mask is what "incomplete covmat" means
+        from_props = np.array([np.nan if not p else float(p) ** 2 for p in spec.proposal])
+        from_ref = spec.reference_variances() / self.fallback_covmat_scale
+        missing = np.isnan(cov.diagonal())
+        where_nan = missing.copy()
+        for source in (from_props, from_ref):
+            idx = np.flatnonzero(missing)
+            cov[idx, idx] = source[idx]
+            missing = np.isnan(cov.diagonal())
         return cov, where_nan
 
     PROGRESS_COLUMNS = ["N", "timestamp", "acceptance_rate", "Rminus1", "Rminus1_cl"]
