@@ -155,6 +155,42 @@ def two_speeds(tmp):
                                             rtol=1e-9, atol=1e-9))}
 
 
+def two_speeds_drag(tmp):
+    """The same two-speed model with `drag: True` (tests/test_mcmc.py:129-143 of the reference):
+    the slow block is proposed, the fast one dragged along -- through Cobaya's live model, on
+    the incremental dragging path."""
+    from cobaya.run import run
+    fake_seam()
+    rng = np.random.default_rng(17)
+    A = rng.normal(size=(3, 3))
+    cov_b = (A @ A.T / 3 + np.eye(3)) * 0.01
+    info = {
+        "likelihood": {
+            "slow": {"class": "gaussian_mixture", "means": [[0.2, 0.0]],
+                     "covs": [[[0.1, 0.05], [0.05, 0.2]]], "input_params_prefix": "a_",
+                     "speed": 1},
+            "fast": {"class": "gaussian_mixture", "means": [[0.5, 0.4, 0.6]], "covs": [cov_b],
+                     "input_params_prefix": "b_", "speed": 50}},
+        "params": {**{f"a_{i}": {"prior": {"min": -3, "max": 3}, "ref": 0.1, "proposal": 0.3}
+                      for i in range(2)},
+                   **{f"b_{i}": {"prior": {"min": 0, "max": 1}, "ref": 0.5, "proposal": 0.1}
+                      for i in range(3)}},
+        "sampler": {"mcmc_hip": {"seed": 6, "n_walkers": 256, "group_size": 64, "drag": True,
+                                 "oversample_power": 0.5, "steps_per_launch": "10d",
+                                 "measure_speeds": False, "Rminus1_stop": 0.0,
+                                 "max_samples": 60000, "snapshot_every": 10}}}
+    updated, sampler = run(info)
+    coll = sampler.products(skip_samples=0.3)["sample"]
+    tm = np.array([0.2, 0.0, 0.5, 0.4, 0.6])
+    tc = np.zeros((5, 5))
+    tc[:2, :2] = [[0.1, 0.05], [0.05, 0.2]]
+    tc[2:, 2:] = cov_b
+    return {"drag": bool(sampler.drag), "interp": int(sampler.drag_interp_steps),
+            "incremental": bool(sampler.incremental), "cycle_length": int(sampler.cycle_length),
+            "blocking": updated["sampler"]["mcmc_hip"]["blocking"],
+            "kl": kl_norm(tm, tc, coll.mean(), coll.cov()), "n_rows": len(coll)}
+
+
 def resume(tmp):
     """Three legs on one prefix through cobaya.run: stop at max_samples; `resume: True` with a
     larger budget continues (rows of the first leg stay, new ones are appended); `resume:

@@ -69,6 +69,14 @@ def test_speed_blocking_from_the_live_model(tmp_path):
     assert r["kl"] < 0.03
 
 
+def test_dragging_from_the_live_model(tmp_path):
+    r = scenario("two_speeds_drag", tmp_path)
+    assert r["drag"] and r["interp"] >= 2 and r["incremental"]
+    assert r["cycle_length"] == 2                  # the slow block's parameters (mcmc.py:400-404)
+    assert [b for _, b in r["blocking"]] == [["a_0", "a_1"], ["b_0", "b_1", "b_2"]]
+    assert r["kl"] < 0.03 and r["n_rows"] > 5000
+
+
 def test_resume_and_force_through_cobaya_output(tmp_path):
     """resuming must never lose the stored rows -- neither of a run that was
     stopped, nor of one that has nothing left to do."""
