@@ -155,6 +155,59 @@ def two_speeds(tmp):
                                             rtol=1e-9, atol=1e-9))}
 
 
+def reference_test_mcmc(tmp):
+    """The reference's own tests/test_mcmc.py::test_mcmc, with `mcmc` replaced by `mcmc_hip`:
+    the SAME input -- `fixed_info` imported from the reference's tests/common_sampler.py, the
+    deliberately bad 3 x 3 initial covmat, `max_tries 3000`, `burn_in 100 d`,
+    `learn_proposal_Rminus1_max 30`, temperature 1 and 2, the check_gaussian callback -- and
+    the same verdict: KL(truth || sample) <= KL_tolerance (0.07) on the later half of the
+    sample (body_of_sampler_test, common_sampler.py:78-161; GetDist is absent here, so the
+    sample moments come from Cobaya's own SampleCollection.mean / cov, detempered)."""
+    sys.path.append("/root/reference")       # the reference's `tests` package (its fixtures)
+    import importlib
+    ref_cs = importlib.import_module("tests.common_sampler")
+    from cobaya.run import run
+    from cobaya.tools import KL_norm
+    fake_seam()
+    out = {}
+    for temperature in (1, 2):
+        cov = np.array([[0.01853538, -0.02990048, 0.00046138],
+                        [-0.02990048, 0.14312571, -0.00441829],
+                        [0.00046138, -0.00441829, 0.00019141]])
+        seen = []
+
+        def check_gaussian(sampler_instance):
+            seen.append(float(KL_norm(
+                S1=sampler_instance.model.likelihood["gaussian_mixture"].covs[0],
+                S2=sampler_instance.proposer.get_covariance())))
+
+        info = dict(ref_cs.fixed_info)
+        dimension = 3
+        info["sampler"] = {"mcmc_hip": {
+            "max_tries": 3000, "burn_in": 100 * dimension, "covmat": cov,
+            "covmat_params": list(info["params"])[:dimension],
+            "learn_proposal_Rminus1_max": 30, "temperature": temperature,
+            "callback_function": check_gaussian, "callback_every": 100,
+            "seed": int(np.random.default_rng(1).integers(0, 2 ** 31)),
+            # the ensemble: 512 walkers in 8 R-1 groups
+            "n_walkers": 512, "group_size": 64, "steps_per_launch": "20d", "snapshot_every": 60}}
+        info["debug"] = False
+        info["output"] = os.path.join(tmp, f"out_chain_T{temperature}")
+        updated, sampler = run(info)
+        products = sampler.products(combined=True, skip_samples=0.5)
+        sample = products["sample"]
+        gm = info["likelihood"]["gaussian_mixture"]
+        kl = float(KL_norm(m1=gm["means"][0], S1=gm["covs"][0], m2=sample.mean(),
+                           S2=sample.cov()))     # (mean / cov detemper on the fly)
+        out[f"T{temperature}"] = {
+            "kl": kl, "tolerance": float(ref_cs.KL_tolerance), "converged": bool(sampler.converged),
+            "n_rows": len(sample), "callbacks": len(seen),
+            "kl_proposer_first": seen[0] if seen else None,
+            "kl_proposer_last": seen[-1] if seen else None,
+            "temperature_of_sample": float(sample.temperature)}
+    return out
+
+
 def two_speeds_drag(tmp):
     """The same two-speed model with `drag: True` (tests/test_mcmc.py:129-143 of the reference):
     the slow block is proposed, the fast one dragged along -- through Cobaya's live model, on

@@ -61,6 +61,20 @@ def test_fixed3_learns_and_converges_under_cobaya_run(tmp_path):
     assert r["derived_cols"] == ["_0", "_1", "_2"]
 
 
+def test_the_references_own_test_mcmc_with_mcmc_hip(tmp_path):
+    """tests/test_mcmc.py::test_mcmc of the reference (temperature 1 and 2) with the sampler
+    name swapped: same input, same pass criterion."""
+    r = scenario("reference_test_mcmc", tmp_path)
+    for key, T in (("T1", 1.0), ("T2", 2.0)):
+        t = r[key]
+        assert t["tolerance"] == 0.07 and t["kl"] <= t["tolerance"], t
+        assert t["converged"] and t["n_rows"] > 1000 and t["callbacks"] >= 2
+        assert t["temperature_of_sample"] == T
+        # the deliberately bad proposal has been re-learnt (mcmc.py:1009-1023); at T = 2 the
+        # proposal covariance is twice the target's, KL(S || 2 S) = 0.29 in three dimensions
+        assert t["kl_proposer_last"] < (0.01 if T == 1 else 0.35) and t["kl_proposer_first"] > 1
+
+
 def test_speed_blocking_from_the_live_model(tmp_path):
     r = scenario("two_speeds", tmp_path)
     assert r["blocking"] == [[1, ["a_0", "a_1"]], [7, ["b_0", "b_1", "b_2"]]]
