@@ -307,7 +307,26 @@ struct mcmc_hip_ctx {
     // incremental mode: walkers sharing one Haar basis (a multiple of group_size, flags bits
     // 8..11 = log2 of the multiple); the R-1 groups (moments) stay group_size wide
     int bgs = 0, BG = 0;
-    DevBuf<double> y, VU, inc_prior, inc_Lrow, inc_mean;
+    DevBuf<double> y, inc_prior, inc_Lrow, inc_mean;
+    // The directions of a launch -- Haar columns V (Vf: the fast blocks' when dragging) and their
+    // whitened pairs VU -- do not depend on the walkers' state, so the set of the NEXT launch is
+    // computed on a second stream while the step kernel of this one runs (two sets, used in
+    // turn).  A set computed ahead is used only if the launch that comes is the one predicted
+    // (same first step, same length) and nothing the directions depend on has been set since
+    // (dir_epoch); otherwise it is recomputed on the main stream.
+    struct DirSet {
+        DevBuf<double> V, Vf, VU;
+        DevBuf<int> vflag, vflag_f;
+        hipEvent_t ready = nullptr;          // recorded on the stream that filled the set
+        bool ahead = false;                  // filled ahead of its launch (on stream2)
+        unsigned long long step0 = ~0ull, epoch = 0;
+        int n = 0;
+    } dirs[2];
+    int dir_cur = 0;
+    unsigned long long dir_epoch = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t mark = nullptr;               // main stream: "the step kernel is next"
+    bool prefetch = true;
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
     // stream-ordered proposal refresh: pinned host staging
     double* pin_mom = nullptr;                      // [G*d + d(d+1)/2 + 2]
@@ -388,18 +407,20 @@ struct Timed {
     mcmc_hip_ctx* h;
     int kind;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(mcmc_hip_ctx* h_, int kind_) : h(h_), kind(kind_)
+    hipStream_t st;
+    Timed(mcmc_hip_ctx* h_, int kind_, hipStream_t st_ = nullptr)
+        : h(h_), kind(kind_), st(st_ ? st_ : h_->stream)
     {
         if (h->timing) {
             a = get_event(h);
             b = get_event(h);
-            (void)hipEventRecord(a, h->stream);
+            (void)hipEventRecord(a, st);
         }
     }
     ~Timed()
     {
         if (h->timing) {
-            (void)hipEventRecord(b, h->stream);
+            (void)hipEventRecord(b, st);
             h->pending.push_back({a, b, kind});
         }
     }
@@ -559,6 +580,7 @@ int set_target_common(mcmc_hip_ctx* h, int K, const double* means, const double*
     }
     h->K = K;
     h->have_target = true;
+    ++h->dir_epoch;
     h->have_state = false;
     int rc = lds_check(h);
     if (rc) return rc;
@@ -679,6 +701,13 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     acc(hipHostMalloc((void**)&h->pin_mom, sizeof(double) * (G * d + np + 2), hipHostMallocDefault));
     acc(hipHostMalloc((void**)&h->pin_T, sizeof(double) * 4 * d * d, hipHostMallocDefault));
     acc(hipEventCreateWithFlags(&h->mom_event, hipEventDisableTiming));
+    if (h->incremental) {
+        acc(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        acc(hipEventCreateWithFlags(&h->mark, hipEventDisableTiming));
+        for (auto& D : h->dirs) acc(hipEventCreateWithFlags(&D.ready, hipEventDisableTiming));
+        // MCMC_HIP_NO_PREFETCH (developer switch): directions on the main stream, in line
+        h->prefetch = !getenv("MCMC_HIP_NO_PREFETCH");
+    }
     if (r == hipSuccess) r = hipMemsetAsync(h->gsum.p, 0, sizeof(double) * G * d, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, h->stream);
     if (r == hipSuccess) r = hipMemsetAsync(h->dshift.p, 0, sizeof(double) * d, h->stream);
@@ -699,8 +728,15 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     resolve_timing(h);
     for (auto e : h->pool) (void)hipEventDestroy(e);
+    for (auto& D : h->dirs) {
+        D.V.release(); D.Vf.release(); D.VU.release(); D.vflag.release(); D.vflag_f.release();
+        if (D.ready) (void)hipEventDestroy(D.ready);
+    }
+    if (h->mark) (void)hipEventDestroy(h->mark);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     h->x.release(); h->logpost.release(); h->logprior.release(); h->loglike.release();
     h->cblock.release(); h->dT.release(); h->V.release(); h->rows.release(); h->gsum.release();
     h->Sg.release(); h->pooled.release(); h->dshift.release(); h->ex.release(); h->elp.release();
@@ -713,7 +749,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->mom_event) (void)hipEventDestroy(h->mom_event);
     h->pack_out.release(); h->pack_off.release();
-    h->y.release(); h->VU.release(); h->inc_prior.release(); h->inc_Lrow.release();
+    h->y.release(); h->inc_prior.release(); h->inc_Lrow.release();
     h->inc_mean.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -763,6 +799,7 @@ int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, co
     }
     h->uniform_logp = -ulp;  // prior.py:528-533
     h->have_prior = true;
+    ++h->dir_epoch;
     h->have_state = false;
     return upload_constants(h);
 }
@@ -789,6 +826,7 @@ int mcmc_hip_set_target_one(mcmc_hip_ctx* h)
     h->K = 0;
     h->mean.clear(); h->Linv.clear(); h->cnorm.clear(); h->weight.clear();
     h->have_target = true;
+    ++h->dir_epoch;
     h->have_state = false;
     return upload_constants(h);
 }
@@ -853,6 +891,7 @@ int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* bloc
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->blocked = !trivial;
+    ++h->dir_epoch;
     h->blk_size.assign(block_size, block_size + n_blocks);
     h->blk_over.assign(oversampling, oversampling + n_blocks);
     h->i_of_j.assign(i_of_j, i_of_j + d);
@@ -924,6 +963,7 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
     HIP_TRY(h, hipMemcpyAsync(h->dT.p, slot, sizeof(double) * d * d, hipMemcpyHostToDevice,
                               h->stream));
     h->have_cov = true;
+    ++h->dir_epoch;
     return MCMC_HIP_OK;
 }
 
@@ -1105,8 +1145,9 @@ namespace {
 // fills `V` (and `flag` when the sequence has one-parameter blocks) with the directions of
 // cycles [c0, c0 + ncyc) of sequence `which` of the blocked proposer
 int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, int L, size_t slab,
-                  DevBuf<double>& V, DevBuf<int>& flag, bool& any_1d)
+                  DevBuf<double>& V, DevBuf<int>& flag, bool& any_1d, hipStream_t st = nullptr)
 {
+    if (!st) st = h->stream;
     const int nb = (int)h->blk_size.size();
     any_1d = false;
     for (int b = 0; b < nb; ++b) {
@@ -1126,27 +1167,109 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
     b.cycle0 = (uint32_t)c0;
     b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
     b.ncyc = ncyc;
-    HIP_TRY(h, mcmc_hip_launch_blocked_basis(&b, h->BG, h->stream));
+    HIP_TRY(h, mcmc_hip_launch_blocked_basis(&b, h->BG, st));
     return MCMC_HIP_OK;
 }
 
 
 // mcmc_hip_step in incremental mode (MCMC_HIP_FLAG_INCREMENTAL; incremental_kernels.hip).
-// Launches are cut at the multiples of refresh_every = 40 d steps, where y = L^-1 (x - mu) is
-// recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
+// Launches are cut at the multiples of refresh_every = 40 cycle lengths, where y = L^-1 (x - mu)
+// is recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
+struct IncPlan {   // what the cutting of launches depends on besides the step counter
+    int d, dq, K, nd, chunk_steps, Lc, Lf, ld, max_cyc, max_cyc_f, max_steps_vu;
+    size_t colb, dd, ddf;
+    unsigned long long R;
+    bool drag;
+};
+struct IncSeg {    // one launch: steps [step0, step0 + n)
+    unsigned long long step0, c0, cyc0_f;
+    int n, ncyc, ncyc_f;
+};
+
+IncSeg plan_segment(const IncPlan& P, unsigned long long step, int left)
+{
+    IncSeg s{};
+    const unsigned long long Lc = (unsigned long long)P.Lc;
+    s.step0 = step;
+    s.c0 = step / Lc;
+    unsigned long long room = P.R - step % P.R;
+    room = std::min<unsigned long long>(room, (s.c0 + (unsigned long long)P.max_cyc) * Lc - step);
+    room = std::min<unsigned long long>(room, (unsigned long long)P.max_steps_vu);
+    int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+    if (P.drag) {   // at most max_cyc_f cycles of fast directions per launch
+        const unsigned long long und = (unsigned long long)P.nd, uLf = (unsigned long long)P.Lf;
+        s.cyc0_f = step * und / uLf;
+        const unsigned long long fend = (s.cyc0_f + (unsigned long long)P.max_cyc_f) * uLf;
+        const unsigned long long room_f = (fend - step * und) / und;   // whole steps
+        n = (int)std::min<unsigned long long>((unsigned long long)n, std::max<unsigned long long>(1, room_f));
+        const unsigned long long f1 = (step + (unsigned long long)n) * und - 1;
+        s.ncyc_f = (int)(f1 / uLf - s.cyc0_f + 1);
+    }
+    s.n = n;
+    s.ncyc = (int)((step + (unsigned long long)n - 1) / Lc - s.c0 + 1);
+    return s;
+}
+
+// fills the set D with the directions of launch `s`, on stream `st`
+int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip_ctx::DirSet& D,
+                    hipStream_t st)
+{
+    Timed t(h, 1, st);
+    const int nd = P.nd;
+    if (h->blocked) {
+        bool any_1d = false;
+        int rc = blocked_basis(h, P.drag ? 1 : 0, s.c0, s.ncyc, P.Lc, P.dd, D.V, D.vflag, any_1d, st);
+        if (rc != MCMC_HIP_OK) return rc;
+        if (P.drag) {
+            rc = blocked_basis(h, 2, s.cyc0_f, s.ncyc_f, P.Lf, P.ddf, D.Vf, D.vflag_f, any_1d, st);
+            if (rc != MCMC_HIP_OK) return rc;
+        }
+    } else {
+        HIP_TRY(h, D.V.resize((size_t)h->BG * s.ncyc * P.dd));
+        mcmc::BasisArgs b{};
+        b.T = h->dT.p; b.V = D.V.p;
+        b.group0 = h->cfg.walker_offset / (uint32_t)h->bgs;
+        b.cycle0 = (uint32_t)s.c0;
+        b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+        b.ncyc = s.ncyc;
+        if (h->kb) HIP_TRY(h, h->kb->basis(b, h->BG, h->d, st));
+        else HIP_TRY(h, h->k->basis(b, h->BG, st));
+    }
+    HIP_TRY(h, D.VU.resize((size_t)h->BG * s.n * (1 + nd) * P.colb));
+    mcmc::IncDirArgs w{};
+    w.V = D.V.p; w.Lrow = h->inc_Lrow.p; w.VU = D.VU.p;
+    w.step0 = s.step0; w.cycle0 = s.c0; w.n_steps = s.n; w.ncyc = s.ncyc;
+    w.slab = (int)P.dd; w.ld = P.ld; w.d = P.d; w.dq = P.dq; w.n_modes = P.K; w.cps = P.Lc;
+    w.out_total = s.n * (1 + nd);
+    if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
+    HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
+    if (P.drag) {   // the fast directions of the n * n_drag interpolation steps
+        w.V = D.Vf.p;
+        w.step0 = s.step0 * (unsigned long long)nd; w.cycle0 = s.cyc0_f;
+        w.n_steps = s.n * nd; w.ncyc = s.ncyc_f; w.slab = (int)P.ddf; w.cps = P.Lf;
+        w.out_div = nd; w.out_cols = 1 + nd; w.out_slot0 = 1;
+        HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
+    }
+    D.step0 = s.step0; D.n = s.n; D.epoch = h->dir_epoch;
+    HIP_TRY(h, hipEventRecord(D.ready, st));
+    return MCMC_HIP_OK;
+}
+
 int step_incremental(mcmc_hip_ctx* h, int n_steps)
 {
     const int d = h->d, dq = (d + 3) / 4;
     const int K = h->K;
-    const bool drag = h->drag_last_slow >= 0;
-    const int nd = drag ? h->drag_steps : 0;
+    IncPlan P{};
+    P.d = d; P.dq = dq; P.K = K;
+    P.drag = h->drag_last_slow >= 0;
+    const int nd = P.nd = P.drag ? h->drag_steps : 0;
     bool one_param_block = false;
     for (int n : h->blk_size) one_param_block = one_param_block || n == 1;
     // dragging: a step's 1 + n_drag columns must fit the LDS twice over
-    const int chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + nd));
-    const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)chunk_steps * (1 + nd) * 4 * dq;
-    if (K < 1 || K > 4 || (K > 1 && (dq > 16 || drag)) || h->any_periodic ||
-        (h->blocked && one_param_block) || (drag && drag_lds > (128u << 10)))
+    P.chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + nd));
+    const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)P.chunk_steps * (1 + nd) * 4 * dq;
+    if (K < 1 || K > 4 || (K > 1 && (dq > 16 || P.drag)) || h->any_periodic ||
+        (h->blocked && one_param_block) || (P.drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "incremental evaluation serves one Gaussian mode (or, without dragging, a "
                     "mixture of up to four at d <= 64) with non-periodic priors and parameter "
@@ -1157,82 +1280,52 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
     // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks, the slow
     // blocks' parameters when dragging (+ the fast sequence of the interpolation steps)
-    const int Lc = block_slots(h, drag ? 1 : 0);
-    const int Lf = drag ? block_slots(h, 2) : 0;
-    const unsigned long long R = 40ull * (unsigned long long)Lc, dd_steps = (unsigned long long)Lc;
+    P.Lc = block_slots(h, P.drag ? 1 : 0);
+    P.Lf = P.drag ? block_slots(h, 2) : 0;
+    P.R = 40ull * (unsigned long long)P.Lc;
     // doubles per column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
-    const size_t colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
-    const int max_steps_vu = (int)std::max<size_t>(
-        4, ((size_t)512 << 20) / (sizeof(double) * colb * (size_t)(1 + nd) * (size_t)h->BG));
+    P.colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
+    P.max_steps_vu = (int)std::max<size_t>(
+        4, ((size_t)512 << 20) / (sizeof(double) * P.colb * (size_t)(1 + nd) * (size_t)h->BG));
     // (blocked directions are written with column stride d at every d)
-    const size_t dd = (h->kb && !h->blocked) ? (size_t)mcmc::v_slab_big(d)
-                                             : (size_t)mcmc::v_slab_cols(Lc, d);
-    const size_t ddf = drag ? (size_t)mcmc::v_slab_cols(Lf, d) : 0;
-    const int ld = (h->kb && !h->blocked) ? mcmc::v_ld(d) : d;
-    const int max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * dd * (size_t)h->BG));
-    const int max_cyc_f =
-        drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * ddf * (size_t)h->BG)) : 0;
+    P.dd = (h->kb && !h->blocked) ? (size_t)mcmc::v_slab_big(d) : (size_t)mcmc::v_slab_cols(P.Lc, d);
+    P.ddf = P.drag ? (size_t)mcmc::v_slab_cols(P.Lf, d) : 0;
+    P.ld = (h->kb && !h->blocked) ? mcmc::v_ld(d) : d;
+    P.max_cyc = (int)std::max<size_t>(1, (256u << 20) / (sizeof(double) * P.dd * (size_t)h->BG));
+    P.max_cyc_f =
+        P.drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * P.ddf * (size_t)h->BG)) : 0;
     int left = n_steps;
     while (left > 0) {
-        if (!h->y_valid || h->step % R == 0) {
+        if (!h->y_valid || h->step % P.R == 0) {
             HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
                                                     d, h->W, K, h->stream));
             h->y_valid = true;
         }
-        const unsigned long long c0 = h->step / dd_steps;
-        unsigned long long room = R - h->step % R;
-        room = std::min<unsigned long long>(room, (c0 + (unsigned long long)max_cyc) * dd_steps - h->step);
-        room = std::min<unsigned long long>(room, (unsigned long long)max_steps_vu);
-        int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
-        unsigned long long cyc0_f = 0;
-        int ncyc_f = 0;
-        if (drag) {   // at most max_cyc_f cycles of fast directions per launch
-            const unsigned long long und = (unsigned long long)nd, uLf = (unsigned long long)Lf;
-            cyc0_f = h->step * und / uLf;
-            const unsigned long long fend = (cyc0_f + (unsigned long long)max_cyc_f) * uLf;
-            const unsigned long long room_f = (fend - h->step * und) / und;   // whole steps
-            n = (int)std::min<unsigned long long>((unsigned long long)n, std::max<unsigned long long>(1, room_f));
-            const unsigned long long f1 = (h->step + (unsigned long long)n) * und - 1;
-            ncyc_f = (int)(f1 / uLf - cyc0_f + 1);
+        const IncSeg seg = plan_segment(P, h->step, left);
+        const int n = seg.n;
+        auto& D = h->dirs[h->dir_cur];
+        const bool hit = D.ahead && D.step0 == seg.step0 && D.n == n && D.epoch == h->dir_epoch;
+        // (a set filled ahead on stream2 -- hit or not -- must have been written before it is
+        // read or overwritten here)
+        if (D.ahead) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
+        D.ahead = false;
+        if (!hit) {
+            const int rc = make_directions(h, P, seg, D, h->stream);
+            if (rc != MCMC_HIP_OK) return rc;
         }
-        const unsigned long long c1 = (h->step + (unsigned long long)n - 1) / dd_steps;
-        const int ncyc = (int)(c1 - c0 + 1);
-        {
-            Timed t(h, 1);
-            if (h->blocked) {
-                bool any_1d = false;
-                int rc = blocked_basis(h, drag ? 1 : 0, c0, ncyc, Lc, dd, h->V, h->vflag, any_1d);
-                if (rc != MCMC_HIP_OK) return rc;
-                if (drag) {
-                    rc = blocked_basis(h, 2, cyc0_f, ncyc_f, Lf, ddf, h->Vf, h->vflag_f, any_1d);
-                    if (rc != MCMC_HIP_OK) return rc;
-                }
-            } else {
-                HIP_TRY(h, h->V.resize((size_t)h->BG * ncyc * dd));
-                mcmc::BasisArgs b{};
-                b.T = h->dT.p; b.V = h->V.p;
-                b.group0 = h->cfg.walker_offset / (uint32_t)h->bgs;
-                b.cycle0 = (uint32_t)c0;
-                b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
-                b.ncyc = ncyc;
-                if (h->kb) HIP_TRY(h, h->kb->basis(b, h->BG, h->d, h->stream));
-                else HIP_TRY(h, h->k->basis(b, h->BG, h->stream));
-            }
-            HIP_TRY(h, h->VU.resize((size_t)h->BG * n * (1 + nd) * colb));
-            mcmc::IncDirArgs w{};
-            w.V = h->V.p; w.Lrow = h->inc_Lrow.p; w.VU = h->VU.p;
-            w.step0 = h->step; w.cycle0 = c0; w.n_steps = n; w.ncyc = ncyc;
-            w.slab = (int)dd; w.ld = ld; w.d = d; w.dq = dq; w.n_modes = K; w.cps = Lc;
-            w.out_total = n * (1 + nd);
-            if (drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
-            HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, h->stream));
-            if (drag) {   // the fast directions of the n * n_drag interpolation steps
-                w.V = h->Vf.p;
-                w.step0 = h->step * (unsigned long long)nd; w.cycle0 = cyc0_f;
-                w.n_steps = n * nd; w.ncyc = ncyc_f; w.slab = (int)ddf; w.cps = Lf;
-                w.out_div = nd; w.out_cols = 1 + nd; w.out_slot0 = 1;
-                HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, h->stream));
-            }
+        if (h->prefetch) {
+            // the launch expected next: the rest of this call, or a call like this one.  Its
+            // directions start once the main stream has reached this point (the proposal
+            // transform and the other set's last reader are behind it) and run beside the step
+            // kernel.
+            auto& N = h->dirs[h->dir_cur ^ 1];
+            const IncSeg nxt = plan_segment(P, h->step + (unsigned long long)n,
+                                            left > n ? left - n : n_steps);
+            HIP_TRY(h, hipEventRecord(h->mark, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
+            const int rc = make_directions(h, P, nxt, N, h->stream2);
+            if (rc != MCMC_HIP_OK) return rc;
+            N.ahead = true;
         }
         {
             Timed t(h, 0);
@@ -1253,14 +1346,14 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.s.uniform_logp = h->uniform_logp; a.s.temperature = h->cfg.temperature;
             a.s.max_tries = h->cfg.max_tries;
             a.s.cnorm0 = h->cnorm[0];
-            a.y = h->y.p; a.VU = h->VU.p; a.prior = h->inc_prior.p;
+            a.y = h->y.p; a.VU = D.VU.p; a.prior = h->inc_prior.p;
             a.d = d; a.dq = dq;
             a.has_norm = (h->norm_mask4[0] | h->norm_mask4[1] | h->norm_mask4[2] | h->norm_mask4[3]) != 0u;
             a.box = !a.has_norm;
             for (int i = 1; i < d && a.box; ++i)
                 a.box = h->lo[i] == h->lo[0] && h->hi[i] == h->hi[0];
             a.box_lo = h->lo[0]; a.box_hi = h->hi[0];
-            a.n_drag = nd; a.chunk_steps = chunk_steps;
+            a.n_drag = nd; a.chunk_steps = P.chunk_steps;
             HIP_TRY(h, launch(&a, h->stream));
             h->n_step_launches += 1;
             if (g_noted_kernel) {
@@ -1268,6 +1361,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                 g_noted_kernel = nullptr;
             }
         }
+        h->dir_cur ^= 1;
         h->step += (unsigned long long)n;
         left -= n;
     }
@@ -1425,6 +1519,7 @@ int mcmc_hip_sync(mcmc_hip_ctx* h)
     if (!h) return MCMC_HIP_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));   // directions computed ahead
     resolve_timing(h);
     int stuck = 0;
     HIP_TRY(h, hipMemcpy(&stuck, h->stuck.p, sizeof(int), hipMemcpyDeviceToHost));

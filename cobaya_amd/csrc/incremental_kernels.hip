@@ -45,6 +45,33 @@ __device__ __forceinline__ double quad_sum(double p)
     return q + quad_perm<0x4E>(q);             // [2,3,0,1]
 }
 
+// A pointer into LDS that the optimiser has to take as new (so that it re-reads what it read
+// before instead of keeping it in registers) and that stays an LDS pointer: the 32-bit LDS offset
+// goes through the empty asm, not the generic pointer -- a laundered generic pointer makes every
+// read a flat_load_dwordx4 (64-bit address, both memory counters).
+typedef double __attribute__((ext_vector_type(2))) pair_t;   // (v_i, u_i): .x, .y
+typedef const pair_t __attribute__((address_space(3))) * lds_pairs;
+typedef const double __attribute__((address_space(3))) * lds_doubles;
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
+__device__ __forceinline__ lds_pairs relaunder(const double2* p)
+{
+    unsigned off = lds_offset(p);
+    asm volatile("" : "+v"(off));
+    return (lds_pairs)(unsigned long long)off;
+}
+__device__ __forceinline__ lds_pairs relaunder_after(lds_pairs p, double anchor)
+{
+    unsigned off = (unsigned)(unsigned long long)p;
+    asm volatile("" : "+v"(off) : "v"(anchor));
+    return (lds_pairs)(unsigned long long)off;
+}
+__device__ __forceinline__ lds_doubles relaunder(const double* p)
+{
+    unsigned off = lds_offset(p);
+    asm volatile("" : "+v"(off));
+    return (lds_doubles)(unsigned long long)off;
+}
+
 // columns of one LDS chunk: a multiple of 4 (the variates come in fours), <= 16 KiB of pairs
 __host__ __device__ constexpr int inc_chunk(int dq)
 {
@@ -217,15 +244,14 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const double ra = accept ? r : 0.0;
                     // (the pairs are read AGAIN from LDS: the pointer passes through an empty
                     // asm so that the compiler cannot keep the first reads alive in 4 DQ registers)
-                    const double2* col2 = col;
-                    asm volatile("" : "+v"(col2));
+                    lds_pairs col2 = relaunder(col);
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
                         // (four pairs at a time: the pointer of the next four depends, through
                         // an empty asm, on the last result of these four -- else all DQ reads
                         // are issued up front into 4 DQ registers)
-                        if (kk % 4 == 0 && kk) asm volatile("" : "+v"(col2) : "v"(y[kk - 1]));
-                        const double2 p = col2[4 * kk];
+                        if (kk % 4 == 0 && kk) col2 = relaunder_after(col2, y[kk - 1]);
+                        const pair_t p = col2[4 * kk];
                         x[kk] = fma(ra, p.x, x[kk]);
                         y[kk] = fma(ra, p.y, y[kk]);
                     }
@@ -443,11 +469,10 @@ drag_inc_kernel(const IncStepArgs a)
                         const bool acc = (ps_lt != -INFINITY) & (pe_lt != -INFINITY) &
                                          metropolis(pi, ci, Ea);
                         const double ra = acc ? r : 0.0;
-                        const double2* col2 = col;
-                        asm volatile("" : "+v"(col2));
+                        const lds_pairs col2 = relaunder(col);
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
-                            const double2 p = col2[4 * kk];
+                            const pair_t p = col2[4 * kk];
                             const double delta = ra * p.x;     // +-0 when not accepted
                             cs[kk] = cs[kk] + delta;
                             ce[kk] = ce[kk] + delta;
@@ -503,7 +528,9 @@ drag_inc_kernel(const IncStepArgs a)
 // ---------------------------------------------------------------- y = L^-1 (x - mu)
 // One thread per walker, 64 walkers per workgroup; the deviations of the workgroup sit in LDS
 // ([i][lane]) and the rows of L^-1 are read at wave-uniform addresses (scalar loads).  One
-// ascending fma chain per row from +0.0 (orc_whiten).  Runs once per `refresh_every` steps.
+// ascending fma chain per row from +0.0 (orc_whiten); four rows advance together on every
+// deviation read, which gives the lane four independent chains.  Runs once per `refresh_every`
+// steps.
 __global__ void __launch_bounds__(64) whiten_state_kernel(const double* __restrict__ x,
                                                           double* __restrict__ y,
                                                           const double* __restrict__ mean,
@@ -512,16 +539,40 @@ __global__ void __launch_bounds__(64) whiten_state_kernel(const double* __restri
 {
     extern __shared__ __attribute__((aligned(16))) double sdev[];
     const int l = threadIdx.x, w = blockIdx.x * 64 + l;
+    if (w >= W) return;    // (no barrier below: a lane reads only what it wrote)
     for (int k = 0; k < K; ++k) {   // y is [K][d][W]
-        if (w < W)
-            for (int i = 0; i < d; ++i) sdev[i * 64 + l] = x[(size_t)i * W + w] - mean[k * d + i];
-        if (w < W)
-            for (int j = 0; j < d; ++j) {
-                const double* __restrict__ row = Lrow + ((size_t)k * d + j) * d;
-                double acc = 0.0;
-                for (int i = 0; i <= j; ++i) acc = fma(row[i], sdev[i * 64 + l], acc);
-                y[((size_t)k * d + j) * W + w] = acc;
+        for (int i = 0; i < d; ++i) sdev[i * 64 + l] = x[(size_t)i * W + w] - mean[k * d + i];
+        int j0 = 0;
+        for (; j0 + 4 <= d; j0 += 4) {
+            const double* __restrict__ r0 = Lrow + ((size_t)k * d + j0) * d;
+            const double* __restrict__ r1 = r0 + d;
+            const double* __restrict__ r2 = r1 + d;
+            const double* __restrict__ r3 = r2 + d;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int i = 0; i <= j0; ++i) {
+                const double dv = sdev[i * 64 + l];
+                a0 = fma(r0[i], dv, a0);
+                a1 = fma(r1[i], dv, a1);
+                a2 = fma(r2[i], dv, a2);
+                a3 = fma(r3[i], dv, a3);
             }
+            const double d1 = sdev[(j0 + 1) * 64 + l], d2 = sdev[(j0 + 2) * 64 + l],
+                         d3 = sdev[(j0 + 3) * 64 + l];
+            a1 = fma(r1[j0 + 1], d1, a1);
+            a2 = fma(r2[j0 + 1], d1, a2);
+            a3 = fma(r3[j0 + 1], d1, a3);
+            a2 = fma(r2[j0 + 2], d2, a2);
+            a3 = fma(r3[j0 + 2], d2, a3);
+            a3 = fma(r3[j0 + 3], d3, a3);
+            double* __restrict__ out = y + ((size_t)k * d + j0) * W + w;
+            out[0] = a0; out[(size_t)W] = a1; out[2 * (size_t)W] = a2; out[3 * (size_t)W] = a3;
+        }
+        for (int j = j0; j < d; ++j) {
+            const double* __restrict__ row = Lrow + ((size_t)k * d + j) * d;
+            double acc = 0.0;
+            for (int i = 0; i <= j; ++i) acc = fma(row[i], sdev[i * 64 + l], acc);
+            y[((size_t)k * d + j) * W + w] = acc;
+        }
     }
 }
 
@@ -759,8 +810,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                 const int lim = burn > 0 ? lim10 : lim1;
                 burn -= (accept & (burn > 0)) ? 1 : 0;
                 const double ra = accept ? r : 0.0;
-                const double* col2 = col;
-                asm volatile("" : "+v"(col2));
+                const lds_doubles col2 = relaunder(col);
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {
                     x[kk] = fma(ra, col2[4 * kk], x[kk]);
