@@ -8,6 +8,7 @@
 // normative text; tests/test_gpu_parity.py checks these bit for bit against the CPU oracle.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "short_log_table.h"
 #include <stdint.h>
 
 namespace mcmc {
@@ -220,15 +221,66 @@ struct StepRng {
     }
 };
 
+// -log(n 2^-b) for an ODD integer n < 2^29: the logarithm of the paired variates, whose arguments
+// are short (25 / 29 significant bits), so that a table step is exact (oracle:
+// orc_neg_log_short; table: short_log_table.h).  n = m 2^e, m in [1/2, 1); j = top seven
+// fraction bits of m; f = fma(m, RC_j, -1) exactly, |f| <= 2^-8; log1p(f) by its Taylor polynomial
+// to f^6; result = (b - e) ln 2 + log RC_j - log1p(f).  18 instructions and one LDS read, against
+// the 45 (a division among them) of dlog.  The table sits in LDS: short_log_load fills it.
+typedef double __attribute__((ext_vector_type(2))) dpair_t;
+typedef const dpair_t __attribute__((address_space(3))) * short_log_tab;
+static __device__ const double kShortLog[SHORT_LOG_TABLE_SIZE][2] = SHORT_LOG_TABLE;
+
+__device__ __forceinline__ short_log_tab short_log_load(dpair_t* lds_table)
+{
+    for (int i = threadIdx.x; i < SHORT_LOG_TABLE_SIZE; i += blockDim.x) {
+        dpair_t t;
+        t.x = kShortLog[i][0];
+        t.y = kShortLog[i][1];
+        lds_table[i] = t;
+    }
+    return (short_log_tab)(unsigned long long)(unsigned)(unsigned long long)lds_table;
+}
+
+__device__ __forceinline__ double neg_log_short(uint32_t n, int b, short_log_tab tab)
+{
+    constexpr double LN2 = 6.93147180559945286227e-01, C2 = -0.5, C3 = 3.33333333333333314830e-01,
+                     C4 = -0.25, C5 = 2.00000000000000011102e-01, C6 = -1.66666666666666657415e-01;
+    const double xd = (double)n;
+    const double m = __builtin_amdgcn_frexp_mant(xd);
+    const int e = __builtin_amdgcn_frexp_exp(xd);
+    const unsigned j = ((unsigned)__double2hiint(m) >> 13) & 0x7Fu;
+    const dpair_t t = tab[j];
+    const double f = fma(m, t.x, -1.0);
+    const double p = f * fma(f, fma(f, fma(f, fma(f, fma(f, C6, C5), C4), C3), C2), 1.0);
+    return fma((double)(b - e), LN2, t.y) - p;
+}
+
 // The variates of TWO consecutive steps from one Philox block (incremental kernels, plain steps;
 // oracle: walker_variates_pair): block (walker, kStreamStep | 0x4000, P), P = step >> 1; half
 // h = step & 1 uses the words a = w[2h], b = w[2h+1]: sign = bit 31 of a (set = positive),
 // exponential branch iff bits 30..20 of a < 676, k_r = (a & 0xFFFFF) << 4 | b >> 28 (24 bits),
-// u_r = (2 k_r + 1) 2^-25, k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29.
+// u_r = (2 k_r + 1) 2^-25, k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29; the two
+// logarithms are short-argument ones (neg_log_short above).
+// sqrt of a double in [2^-100, 2^100]: the correctly rounded result (what sqrt() returns) without
+// the range scaling and the zero / infinity fix-up of the general expansion -- the hardware
+// reciprocal-square-root estimate, one Goldschmidt step and two residual corrections.
+__device__ __forceinline__ double sqrt_midrange(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, a), h, g);
+    g = fma(fma(-g, g, a), h, g);
+    return g;
+}
+
 struct PairRng {
     double r[2], Ea[2];
     __device__ __forceinline__ void run(uint32_t key0, uint32_t key1, uint32_t gid,
-                                        unsigned long long pair)
+                                        unsigned long long pair, short_log_tab tab)
     {
         StepRng g;
         g.begin(key0, key1, gid, pair);
@@ -241,12 +293,11 @@ struct PairRng {
             const uint32_t a = w[2 * h], b = w[2 * h + 1];
             const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28);
             const uint32_t ka = b & 0x0FFFFFFFu;
-            g.log_a((double)(2u * kr + 1u) * 0x1p-25);
-            const double Er = -g.log_b();
-            const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt(2.0 * Er);
+            const double Er = neg_log_short(2u * kr + 1u, 25, tab);
+            // (2 E_r lies in [2^-24, 35])
+            const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt_midrange(2.0 * Er);
             r[h] = (a & 0x80000000u) ? rr : -rr;
-            g.log_a((double)(2u * ka + 1u) * 0x1p-29);
-            Ea[h] = -g.log_b();
+            Ea[h] = neg_log_short(2u * ka + 1u, 29, tab);
         }
     }
 };

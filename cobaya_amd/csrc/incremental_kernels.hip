@@ -45,6 +45,17 @@ __device__ __forceinline__ double quad_sum(double p)
     return q + quad_perm<0x4E>(q);             // [2,3,0,1]
 }
 
+// the wave's lane mask of a condition (a v_cmp writes it to a scalar register pair)
+__device__ __forceinline__ unsigned long long lanes(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+// lane mask -> true in the four lanes of a quad iff the mask holds all four of its lanes
+__device__ __forceinline__ bool quad_all(unsigned long long m)
+{
+    m &= m >> 1;
+    m &= m >> 2;
+    m &= 0x1111111111111111ull;
+    return __builtin_amdgcn_inverse_ballot_w64(m * 15ull);
+}
+
 // A pointer into LDS that the optimiser has to take as new (so that it re-reads what it read
 // before instead of keeping it in registers) and that stays an LDS pointer: the 32-bit LDS offset
 // goes through the empty asm, not the generic pointer -- a laundered generic pointer makes every
@@ -163,14 +174,16 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
-    long long nacc = s.n_accept[w];
-    const long long nacc0 = nacc;
+    const long long nacc0 = s.n_accept[w];
+    int nacc = 0;     // accepted steps of this launch (< 2^31)
     const uint32_t gid = s.walker0 + (uint32_t)w;
     // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
 
+    __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
+    const short_log_tab slog = short_log_load(short_log_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned long long cur_oct = ~0ull;
@@ -194,7 +207,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                     if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
                         cur_oct = S >> 3;
-                        pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c);
+                        pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                     }
                     double r, Ea;
                     switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
@@ -209,16 +222,18 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     }
                     const double2* __restrict__ col = cur + sl * COLB + c;
                     double pc = 0.0, sc = 0.0;
-                    bool inb = true;
+                    // (the support test is kept as the wave's lane mask: every comparison lands
+                    // in a scalar register pair and the ANDs run on the scalar unit)
+                    unsigned long long inb = ~0ull;
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
                         const double2 p = col[4 * kk];
                         const double t = fma(r, p.x, x[kk]);
-                        if (MODE == 0) inb = inb & (t <= bhi) & (t >= blo);
-                        else if (kBoundsInRegs) inb = inb & (t <= hi[kk]) & (t >= lo[kk]);
+                        if (MODE == 0) inb &= lanes(t <= bhi) & lanes(t >= blo);
+                        else if (kBoundsInRegs) inb &= lanes(t <= hi[kk]) & lanes(t >= lo[kk]);
                         else {
                             const double2 lh = sLH[4 * kk + c];
-                            inb = inb & (t <= lh.y) & (t >= lh.x);
+                            inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
                         }
                         const double yt = fma(r, p.y, y[kk]);
                         pc = fma(yt, yt, pc);
@@ -231,14 +246,18 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             sc = sc + fma(-0.5 * qq, qq, mls);
                         }
                     }
-                    // a walker outside the prior support anywhere gets chi2 = +inf
-                    const double chi2 = quad_sum(inb ? pc : INFINITY);
-                    const bool inside = chi2 < INFINITY;
+                    // inside the prior support = all four lanes of the walker are: the AND over
+                    // the quad is taken on the wave's lane mask (scalar unit, no vector work)
+                    const bool inside = quad_all(inb);
+                    const double chi2 = quad_sum(pc);
                     const double lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
                     const double ll = -0.5 * (s.cnorm0 + chi2);
-                    const double lt = inside ? lp + ll : -INFINITY;
+                    // (outside the support lt is not used; a chi2 that overflowed gives
+                    // lt = -inf, which fails both comparisons like the specification's
+                    // explicit lt != -inf)
+                    const double lt = lp + ll;
                     const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
-                    const bool accept = inside & (lt != -INFINITY) & ((lt > lpost) | (Ea > delta));
+                    const bool accept = inside & ((lt > lpost) | (Ea > delta));
                     const int lim = burn > 0 ? lim10 : lim1;
                     burn -= (accept & (burn > 0)) ? 1 : 0;
                     const double ra = accept ? r : 0.0;
@@ -268,7 +287,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed
         __syncthreads();
     }
-    if (nacc != nacc0) {   // (the same in the four lanes of a walker: the quad sums are safe)
+    if (nacc != 0) {   // (the same in the four lanes of a walker: the quad sums are safe)
         double pc = 0.0, sc = 0.0;
 #pragma unroll
         for (int kk = 0; kk < DQ; ++kk) {
@@ -296,9 +315,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     if (c == 0) {
         s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
-        s.n_accept[w] = nacc;
+        s.n_accept[w] = nacc0 + nacc;
     }
-    wave_add_accepts(s.accept_total, (c == 0) ? nacc - nacc0 : 0);
+    wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
 
 // ---------------------------------------------------------------- the dragging step
@@ -742,6 +761,8 @@ step_inc_mix_kernel(const IncStepArgs a)
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
+    __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
+    const short_log_tab slog = short_log_load(short_log_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned long long cur_oct = ~0ull;
@@ -758,7 +779,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                 const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                 if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                     cur_oct = S >> 3;
-                    pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c);
+                    pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                 }
                 double r, Ea;
                 switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
@@ -897,7 +918,7 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false>",
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true>"};
     const int v = 2 * mode + (unit_t ? 1 : 0);
-    if (lds > 48 * 1024) {
+    if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -927,7 +948,7 @@ hipError_t launch_drag_dq(const IncStepArgs& a, hipStream_t st)
         "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, true>"};
     const int v = 2 * mode + (unit_t ? 1 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (lds > 48 * 1024) {
+    if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -972,7 +993,7 @@ extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, c
                                                    hipStream_t st)
 {
     const size_t lds = sizeof(double) * 64 * (size_t)d;
-    if (lds > 48 * 1024) {
+    if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mcmc::whiten_state_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -986,13 +1007,13 @@ extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* 
                                                         hipStream_t st)
 {
     const size_t lds = sizeof(double) * 64 * (size_t)a->d;
-    if (lds > 48 * 1024) {
+    if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)mcmc::whiten_directions_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     if (a->n_modes > 1) {
-        if (lds > 48 * 1024) {
+        if (lds > 40 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)mcmc::whiten_directions_mix_kernel,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;

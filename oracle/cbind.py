@@ -83,6 +83,9 @@ def lib():
         L.orc_dlog.argtypes = [C.c_double]
         L.orc_dexp.restype = C.c_double
         L.orc_dexp.argtypes = [C.c_double]
+        L.orc_neg_log_short.restype = C.c_double
+        L.orc_neg_log_short.argtypes = [C.c_uint32, C.c_int32]
+        L.orc_pair_variates.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, c_double_p, c_double_p]
         L.orc_sincos2pi.argtypes = [C.c_uint64, c_double_p, c_double_p]
         L.orc_haar_from_normals.argtypes = [C.c_int, c_double_p, c_double_p]
         L.orc_basis.argtypes = [C.POINTER(_Problem), C.c_uint32, C.c_uint32, c_double_p]
@@ -137,6 +140,18 @@ def dlog(x):
 
 def dexp(x):
     return lib().orc_dexp(float(x))
+
+
+def neg_log_short(n, b):
+    """-log(n 2^-b), n odd < 2^29: the logarithm of the paired variates."""
+    return lib().orc_neg_log_short(int(n), int(b))
+
+
+def pair_variates(seed, gid, step):
+    """(r, E_a) of walker `gid` at `step` on the paired stream (walker_variates_pair)."""
+    r, e = C.c_double(), C.c_double()
+    lib().orc_pair_variates(int(seed), int(gid), int(step), C.byref(r), C.byref(e))
+    return r.value, e.value
 
 
 def sincos2pi(k):

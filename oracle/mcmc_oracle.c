@@ -93,6 +93,27 @@ double orc_dlog(double x)
     return dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
 
+/* -log(n 2^-b) for an ODD integer n < 2^29 (b <= 29): the logarithm of the paired variates
+ * (walker_variates_pair), whose arguments are short -- 25 or 29 significant bits -- so that a
+ * table step is exact.  n = m 2^e, m in [1/2, 1); j = top seven fraction bits of m;
+ * f = fma(m, RC_j, -1) is EXACT (29 + 24 bits) with |f| <= 2^-8; log1p(f) by its Taylor
+ * polynomial to f^6 (next term < 2^-58); result = (b - e) ln 2 + log(RC_j) - log1p(f).
+ * Table: oracle/short_log_table.h (tools/make_short_log_table.py).  Absolute error < 3e-16. */
+#include "short_log_table.h"
+static const double short_log_table[SHORT_LOG_TABLE_SIZE][2] = SHORT_LOG_TABLE;
+double orc_neg_log_short(uint32_t n, int32_t b)
+{
+    static const double LN2 = 6.93147180559945286227e-01, C2 = -0.5,
+        C3 = 3.33333333333333314830e-01, C4 = -0.25, C5 = 2.00000000000000011102e-01,
+        C6 = -1.66666666666666657415e-01;
+    int e;
+    const double m = frexp((double)n, &e);
+    const unsigned j = (unsigned)(d2bits(m) >> 45) & 0x7Fu;
+    const double f = fma(m, short_log_table[j][0], -1.0);
+    const double p = f * fma(f, fma(f, fma(f, fma(f, fma(f, C6, C5), C4), C3), C2), 1.0);
+    return fma((double)(b - e), LN2, short_log_table[j][1]) - p;
+}
+
 /* exp(x) for x <= 0 (mixture log-sum-exp terms); fdlibm e_exp.c reduction/polynomial.
  * x < -708 returns 0 (the term is below 1e-307 of the leading one). */
 double orc_dexp(double x)
@@ -687,7 +708,9 @@ static inline void walker_variates(uint32_t k0, uint32_t k1, uint32_t gid, uint6
  * (walker, STREAM_STEP | 0x4000, P).  Half h = step & 1 uses the words a = w[2h], b = w[2h+1]:
  * sign = bit 31 of a (set = positive); exponential branch iff bits 30..20 of a < 676
  * (676 / 2048 = 0.33008, proposal.py:79); k_r = (a & 0xFFFFF) << 4 | b >> 28 (24 bits),
- * u_r = (2 k_r + 1) 2^-25; k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29. */
+ * u_r = (2 k_r + 1) 2^-25; k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29.  The two
+ * logarithms are short-argument ones (orc_neg_log_short). */
+void orc_pair_variates(uint64_t seed, uint32_t gid, uint64_t step, double* r_out, double* Ea_out);
 static inline void walker_variates_pair(uint32_t k0, uint32_t k1, uint32_t gid, uint64_t step,
                                         double* r_out, double* Ea_out)
 {
@@ -697,10 +720,15 @@ static inline void walker_variates_pair(uint32_t k0, uint32_t k1, uint32_t gid, 
     const uint32_t a = wd[2 * (step & 1)], b = wd[2 * (step & 1) + 1];
     const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28);
     const uint32_t ka = b & 0x0FFFFFFFu;
-    const double Er = -orc_dlog((double)(2 * kr + 1) * 0x1p-25);
+    const double Er = orc_neg_log_short(2 * kr + 1, 25);
     const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt(2.0 * Er);
     *r_out = (a & 0x80000000u) ? rr : -rr;
-    *Ea_out = -orc_dlog((double)(2 * ka + 1) * 0x1p-29);
+    *Ea_out = orc_neg_log_short(2 * ka + 1, 29);
+}
+
+void orc_pair_variates(uint64_t seed, uint32_t gid, uint64_t step, double* r_out, double* Ea_out)
+{
+    walker_variates_pair((uint32_t)seed, (uint32_t)(seed >> 32), gid, step, r_out, Ea_out);
 }
 
 /* mcmc.py:670-683 with the Exp(1) variate supplied */

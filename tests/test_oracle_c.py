@@ -3,6 +3,7 @@ known answers for the generator, libm for the fixed-order math, golden vectors G
 log-posterior, and a step-by-step replay of reference chains with the reference's own random
 draws injected (through oracle/ref_numpy.py, itself pinned to golden G6)."""
 import json
+import os
 import math
 
 import numpy as np
@@ -499,3 +500,54 @@ def test_paired_variates_have_the_specified_law():
     assert np.max(np.abs(np.cov(x.T) - cov) / np.outer(sig, sig)) < 0.03
     acc = st.n_accept.sum() / (4096 * st.step)
     assert 0.2 < acc < 0.45
+
+
+def test_short_argument_logarithm_and_its_table():
+    """The logarithm of the paired variates (orc_neg_log_short): within an ulp of libm on its
+    whole domain (odd n < 2^b, b = 25 and 29, edges included); the table the kernels and the
+    oracle compile is the one tools/make_short_log_table.py writes (one file, two places)."""
+    import importlib.util
+    import math
+    from oracle import cbind as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = open(os.path.join(root, "oracle", "short_log_table.h")).read()
+    b = open(os.path.join(root, "cobaya_amd", "csrc", "short_log_table.h")).read()
+    assert a == b
+    spec = importlib.util.spec_from_file_location(
+        "make_short_log_table", os.path.join(root, "tools", "make_short_log_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rows = gen.table()
+    for j, (rc, lrc) in enumerate(rows):
+        assert "{ %s, %s }" % (rc.hex(), lrc.hex()) in a
+        assert rc == float(np.float32(rc))                       # 24 significant bits
+        c = 0.5 + (j + 0.5) / 256
+        assert abs(rc * c - 1) < 2.0 ** -23 and abs(lrc - math.log(rc)) <= 2.3e-16 * lrc
+    rng = np.random.default_rng(0)
+    for nb in (25, 29):
+        ks = np.concatenate([rng.integers(0, 2 ** (nb - 1), 20000),
+                             [0, 1, 2, 3, 2 ** (nb - 1) - 1, 2 ** (nb - 1) - 2, 2 ** (nb - 2),
+                              2 ** (nb - 2) - 1]])
+        for k in ks:
+            n = 2 * int(k) + 1
+            v, t = O.neg_log_short(n, nb), -math.log(n * 2.0 ** -nb)
+            assert abs(v - t) <= 4e-16 * max(1.0, t), (n, nb, v, t)
+
+
+def test_paired_variates_follow_the_reference_laws():
+    """r and E_a of the paired stream, drawn directly: E_a is Exp(1); |r| is Exp(1) with
+    probability 676/2048 and chi(2) otherwise (proposal.py:71-82 for n >= 2); the sign is fair
+    and independent; r and E_a are uncorrelated; the two halves of a block differ."""
+    from scipy import stats
+    from oracle import cbind as O
+    n = 40000
+    v = np.array([O.pair_variates(77, 3 + (i % 7), i) for i in range(n)])
+    r, ea = v[:, 0], v[:, 1]
+    assert stats.kstest(ea, "expon").pvalue > 1e-3
+    p = 676 / 2048
+    cdf = lambda t: p * (1 - np.exp(-t)) + (1 - p) * (1 - np.exp(-0.5 * t * t))
+    assert stats.kstest(np.abs(r), cdf).pvalue > 1e-3
+    assert abs(np.mean(r > 0) - 0.5) < 4 * 0.5 / np.sqrt(n)
+    assert abs(np.corrcoef(np.abs(r), ea)[0, 1]) < 0.02
+    assert abs(np.corrcoef(r[0::2], r[1::2])[0, 1]) < 0.02
+    assert abs(np.corrcoef(ea[0::2], ea[1::2])[0, 1]) < 0.02
