@@ -316,7 +316,8 @@ struct mcmc_hip_ctx {
     // (dir_epoch); otherwise it is recomputed on the main stream.
     struct DirSet {
         DevBuf<double> V, Vf, VU;
-        DevBuf<int> vflag, vflag_f;
+        DevBuf<int> vflag, vflag_f, colflag;   // colflag: 1-D columns of the launch, in VU order
+        bool has_flags = false;
         hipEvent_t ready = nullptr;          // recorded on the stream that filled the set
         bool ahead = false;                  // filled ahead of its launch (on stream2)
         unsigned long long step0 = ~0ull, epoch = 0;
@@ -739,6 +740,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto& D : h->dirs) {
         D.V.release(); D.Vf.release(); D.VU.release(); D.vflag.release(); D.vflag_f.release();
+        D.colflag.release();
         if (D.ready) (void)hipEventDestroy(D.ready);
     }
     if (h->mark) (void)hipEventDestroy(h->mark);
@@ -1222,12 +1224,12 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
 {
     Timed t(h, 1, st);
     const int nd = P.nd;
+    bool any_1d = false, any_1d_f = false;
     if (h->blocked) {
-        bool any_1d = false;
         int rc = blocked_basis(h, P.drag ? 1 : 0, s.c0, s.ncyc, P.Lc, P.dd, D.V, D.vflag, any_1d, st);
         if (rc != MCMC_HIP_OK) return rc;
         if (P.drag) {
-            rc = blocked_basis(h, 2, s.cyc0_f, s.ncyc_f, P.Lf, P.ddf, D.Vf, D.vflag_f, any_1d, st);
+            rc = blocked_basis(h, 2, s.cyc0_f, s.ncyc_f, P.Lf, P.ddf, D.Vf, D.vflag_f, any_1d_f, st);
             if (rc != MCMC_HIP_OK) return rc;
         }
     } else {
@@ -1242,11 +1244,16 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
         else HIP_TRY(h, h->k->basis(b, h->BG, st));
     }
     HIP_TRY(h, D.VU.resize((size_t)h->BG * s.n * (1 + nd) * P.colb));
+    // one-parameter blocks: the columns that draw the RandProposer1D variates, in VU order
+    D.has_flags = any_1d || any_1d_f;
+    if (D.has_flags) HIP_TRY(h, D.colflag.resize((size_t)h->BG * s.n * (1 + nd)));
     mcmc::IncDirArgs w{};
     w.V = D.V.p; w.Lrow = h->inc_Lrow.p; w.VU = D.VU.p;
     w.step0 = s.step0; w.cycle0 = s.c0; w.n_steps = s.n; w.ncyc = s.ncyc;
     w.slab = (int)P.dd; w.ld = P.ld; w.d = P.d; w.dq = P.dq; w.n_modes = P.K; w.cps = P.Lc;
     w.out_total = s.n * (1 + nd);
+    w.colflag = D.has_flags ? D.colflag.p : nullptr;
+    w.vflag = any_1d ? D.vflag.p : nullptr;
     if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
     HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
     if (P.drag) {   // the fast directions of the n * n_drag interpolation steps
@@ -1254,6 +1261,7 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
         w.step0 = s.step0 * (unsigned long long)nd; w.cycle0 = s.cyc0_f;
         w.n_steps = s.n * nd; w.ncyc = s.ncyc_f; w.slab = (int)P.ddf; w.cps = P.Lf;
         w.out_div = nd; w.out_cols = 1 + nd; w.out_slot0 = 1;
+        w.vflag = any_1d_f ? D.vflag_f.p : nullptr;
         HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
     }
     D.step0 = s.step0; D.n = s.n; D.epoch = h->dir_epoch;
@@ -1275,11 +1283,11 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     P.chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + nd));
     const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)P.chunk_steps * (1 + nd) * 4 * dq;
     if (K < 1 || K > 4 || (K > 1 && (dq > 16 || P.drag)) || h->any_periodic ||
-        (h->blocked && one_param_block) || (P.drag && drag_lds > (128u << 10)))
+        (h->blocked && one_param_block && K > 1) || (P.drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation serves one Gaussian mode (or, without dragging, a "
-                    "mixture of up to four at d <= 64) with non-periodic priors and parameter "
-                    "blocks of at least two parameters; use evaluation: full for this model");
+                    "incremental evaluation serves one Gaussian mode (or, without dragging and "
+                    "with parameter blocks of at least two parameters, a mixture of up to four at "
+                    "d <= 64) with non-periodic priors; use evaluation: full for this model");
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                 : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
     if (!launch || !mcmc_hip_launch_whiten_directions)
@@ -1360,6 +1368,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                 a.box = h->lo[i] == h->lo[0] && h->hi[i] == h->hi[0];
             a.box_lo = h->lo[0]; a.box_hi = h->hi[0];
             a.n_drag = nd; a.chunk_steps = P.chunk_steps;
+            a.colflag = D.has_flags ? D.colflag.p : nullptr;
             HIP_TRY(h, launch(&a, h->stream));
             h->n_step_launches += 1;
             if (g_noted_kernel) {

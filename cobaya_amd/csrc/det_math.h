@@ -221,6 +221,29 @@ struct StepRng {
     }
 };
 
+// (r, E_a) of (walker, step, sub) on the un-paired stream (oracle: walker_variates); oned: the
+// column belongs to a one-parameter block -- RandProposer1D (proposal.py:85-93): chi(1) as
+// sqrt(2 E) |cos| of a Box-Muller pair, and E_a from a second block (| 0x100).
+__device__ __forceinline__ void step_variates(uint32_t key0, uint32_t key1, uint32_t gid,
+                                              unsigned long long step, uint32_t sub, bool oned,
+                                              double& r, double& Ea)
+{
+    StepRng rng;
+    rng.begin(key0, key1, gid, step, sub);
+    rng.run_all();
+    r = rng.r;
+    Ea = rng.Ea;
+    if (oned) {
+        double sn, cs;
+        sincos2pi(rng.ka, sn, cs);
+        const double rr = rng.expo ? rng.Er : sqrt(2.0 * rng.Er) * fabs(cs);
+        r = (rng.c0 & 0x80u) ? rr : -rr;
+        const u32x4 q4 = philox4x32_10(key0, key1, gid, kStreamStep | (sub << 16) | 0x100u,
+                                       (uint32_t)step, (uint32_t)(step >> 32));
+        Ea = -dlog(u52(((uint64_t)q4.w0 << 20) | (q4.w1 >> 12)));
+    }
+}
+
 // -log(n 2^-b) for an ODD integer n < 2^29: the logarithm of the paired variates, whose arguments
 // are short (25 / 29 significant bits), so that a table step is exact (oracle:
 // orc_neg_log_short; table: short_log_table.h).  n = m 2^e, m in [1/2, 1); j = top seven

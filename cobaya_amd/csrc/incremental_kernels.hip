@@ -26,6 +26,10 @@
 #include "det_math.h"
 #include "kernels.h"
 
+#ifndef MCMC_INC_PIPE_OVERRIDE
+#define MCMC_INC_PIPE_OVERRIDE (-1)    // developer switch: pairs fetched ahead in the trial loop
+#endif
+
 namespace mcmc {
 namespace {
 
@@ -83,10 +87,12 @@ __device__ __forceinline__ lds_doubles relaunder(const double* p)
     return (lds_doubles)(unsigned long long)off;
 }
 
-// columns of one LDS chunk: a multiple of 4 (the variates come in fours), <= 16 KiB of pairs
+// columns of one LDS chunk: a multiple of 4 (the variates come in fours); 16 KiB of pairs, 32 KiB
+// from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
+// workgroup barrier between chunks comes half as often)
 __host__ __device__ constexpr int inc_chunk(int dq)
 {
-    int c = (1024 / (4 * dq)) & ~3;
+    int c = ((dq >= 14 ? 2048 : 1024) / (4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }
 
@@ -109,7 +115,9 @@ __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
     return dq <= 4 ? 4 : dq <= 7 ? 3 : dq <= 15 ? 2 : 1;
 }
 
-template <int DQ, int MODE, bool UNIT_T>
+//   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
+//   RandProposer1D variates of the un-paired stream (step_variates), every lane for itself
+template <int DQ, int MODE, bool UNIT_T, bool ONED>
 __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem2[];
@@ -120,6 +128,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;
     constexpr bool NORMP = MODE == 2;
     constexpr bool kNormInRegs = NORMP && DQ <= 8;
+    constexpr int PIPE = MCMC_INC_PIPE_OVERRIDE >= 0 ? MCMC_INC_PIPE_OVERRIDE
+                       : (inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
@@ -194,6 +204,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         const double2* __restrict__ cur = sVU + (k & 1) * CHUNK;
         stage(k + 1);     // travels while this chunk is consumed
         const int cols = ncols - base < C ? ncols - base : C;
+        unsigned long long oned_cols = 0;   // bit sl: column sl of the chunk is a 1-D one
+        if (ONED)
+            oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
         // (the step loop is rolled: an unrolled body lets the scheduler hoist the LDS reads of
         // several steps and costs the registers that decide the occupancy)
 #pragma unroll 1
@@ -210,6 +223,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                     }
                     double r, Ea;
+                    if (ONED && ((oned_cols >> sl) & 1ull)) {   // wave-uniform
+                        step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
+                    } else
                     switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
                     case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
                     case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
@@ -225,9 +241,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // (the support test is kept as the wave's lane mask: every comparison lands
                     // in a scalar register pair and the ANDs run on the scalar unit)
                     unsigned long long inb = ~0ull;
-#pragma unroll
-                    for (int kk = 0; kk < DQ; ++kk) {
-                        const double2 p = col[4 * kk];
+                    auto trial = [&](int kk, const double2 p) {
                         const double t = fma(r, p.x, x[kk]);
                         if (MODE == 0) inb &= lanes(t <= bhi) & lanes(t >= blo);
                         else if (kBoundsInRegs) inb &= lanes(t <= hi[kk]) & lanes(t >= lo[kk]);
@@ -244,6 +258,29 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             const double mls = kNormInRegs ? nmls[kk] : a.prior[4 * dpad + i];
                             const double qq = (t - loc) * inv;
                             sc = sc + fma(-0.5 * qq, qq, mls);
+                        }
+                    };
+                    if constexpr (PIPE == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) trial(kk, col[4 * kk]);
+                    } else {
+                        // (kernels held to one or two waves per SIMD have registers to spare
+                        // and little else to cover the LDS latency: the pairs are fetched PIPE
+                        // at a time, one batch ahead of the arithmetic)
+                        constexpr int NB = (DQ + PIPE - 1) / PIPE;
+                        double2 buf[2][PIPE];
+#pragma unroll
+                        for (int j = 0; j < PIPE; ++j)
+                            if (j < DQ) buf[0][j] = col[4 * j];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                            for (int j = 0; j < PIPE; ++j)
+                                if (b + 1 < NB && (b + 1) * PIPE + j < DQ)
+                                    buf[(b + 1) & 1][j] = col[4 * ((b + 1) * PIPE + j)];
+#pragma unroll
+                            for (int j = 0; j < PIPE; ++j)
+                                if (b * PIPE + j < DQ) trial(b * PIPE + j, buf[b & 1][j]);
                         }
                     }
                     // inside the prior support = all four lanes of the walker are: the AND over
@@ -264,15 +301,40 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // (the pairs are read AGAIN from LDS: the pointer passes through an empty
                     // asm so that the compiler cannot keep the first reads alive in 4 DQ registers)
                     lds_pairs col2 = relaunder(col);
+                    if constexpr (PIPE == 0) {
 #pragma unroll
-                    for (int kk = 0; kk < DQ; ++kk) {
-                        // (four pairs at a time: the pointer of the next four depends, through
-                        // an empty asm, on the last result of these four -- else all DQ reads
-                        // are issued up front into 4 DQ registers)
-                        if (kk % 4 == 0 && kk) col2 = relaunder_after(col2, y[kk - 1]);
-                        const pair_t p = col2[4 * kk];
-                        x[kk] = fma(ra, p.x, x[kk]);
-                        y[kk] = fma(ra, p.y, y[kk]);
+                        for (int kk = 0; kk < DQ; ++kk) {
+                            // (four pairs at a time: the pointer of the next four depends, through
+                            // an empty asm, on the last result of these four -- else all DQ reads
+                            // are issued up front into 4 DQ registers)
+                            if (kk % 4 == 0 && kk) col2 = relaunder_after(col2, y[kk - 1]);
+                            const pair_t p = col2[4 * kk];
+                            x[kk] = fma(ra, p.x, x[kk]);
+                            y[kk] = fma(ra, p.y, y[kk]);
+                        }
+                    } else {   // one batch ahead, as in the trial loop
+                        constexpr int NB = (DQ + PIPE - 1) / PIPE;
+                        pair_t buf[2][PIPE];
+#pragma unroll
+                        for (int j = 0; j < PIPE; ++j)
+                            if (j < DQ) buf[0][j] = col2[4 * j];
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            // (the batch after next must not start before this one is used)
+                            if (b + 1 < NB && b > 0) col2 = relaunder_after(col2, y[b * PIPE - 1]);
+#pragma unroll
+                            for (int j = 0; j < PIPE; ++j)
+                                if (b + 1 < NB && (b + 1) * PIPE + j < DQ)
+                                    buf[(b + 1) & 1][j] = col2[4 * ((b + 1) * PIPE + j)];
+#pragma unroll
+                            for (int j = 0; j < PIPE; ++j) {
+                                const int kk = b * PIPE + j;
+                                if (kk < DQ) {
+                                    x[kk] = fma(ra, buf[b & 1][j].x, x[kk]);
+                                    y[kk] = fma(ra, buf[b & 1][j].y, y[kk]);
+                                }
+                            }
+                        }
                     }
                     // (logprior and loglike of the current point are formed once, after the
                     // loop, from the committed x and y: the same chains on the same values)
@@ -326,16 +388,18 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 // steps -- and 1 + 2 n_drag evaluations, every one of them O(d): the start and the end point
 // carry their whitened residuals (ys, ye), a move by r v moves them by fma(r, u, .).  The variates
 // (r_i, E_i) of the sub-steps i = 0 .. n_drag are drawn four at a time, one per lane class.
-template <int DQ, int MODE, bool UNIT_T>
-__global__ void __launch_bounds__(256, (MODE == 0 ? (DQ <= 5 ? 3 : DQ <= 16 ? 2 : 1)
-                                                  : (DQ <= 3 ? 3 : DQ <= 11 ? 2 : 1)))
+template <int DQ, int MODE, bool UNIT_T, bool ONED>
+__global__ void __launch_bounds__(256, (MODE == 0 ? (DQ <= 5 ? 3 : DQ <= 10 ? 2 : 1)
+                                                  : (DQ <= 3 ? 3 : DQ <= 8 ? 2 : 1)))
 drag_inc_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem2[];
     constexpr int COLB = 4 * DQ;
-    constexpr bool kBoundsInRegs = MODE > 0;     // (bounds in registers at every DQ here)
+    constexpr bool kBoundsInRegs = MODE > 0 && DQ <= 12;
+    constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;   // (six DQ-long arrays live already)
     constexpr bool NORMP = MODE == 2;
     constexpr int dpad = 4 * DQ;
+    __shared__ double2 sLH[kBoundsInLds ? 4 * DQ : 1];   // (lo, hi) per dimension
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d, nd = a.n_drag, cps = 1 + nd;
@@ -376,6 +440,8 @@ drag_inc_kernel(const IncStepArgs a)
             hi[kk] = a.prior[dpad + i];
         }
     }
+    if (kBoundsInLds)   // (read after the barrier that precedes the step loop)
+        for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     long long nacc = s.n_accept[w];
@@ -395,6 +461,10 @@ drag_inc_kernel(const IncStepArgs a)
     };
     auto inside = [&](double t, int kk) -> bool {
         if (MODE == 0) return (t <= bhi) & (t >= blo);
+        if (kBoundsInLds) {
+            const double2 lh = sLH[4 * kk + c];
+            return (t <= lh.y) & (t >= lh.x);
+        }
         return (t <= hi[kk]) & (t >= lo[kk]);
     };
     auto prior_term = [&](double t, int kk, double sc) -> double {
@@ -426,11 +496,12 @@ drag_inc_kernel(const IncStepArgs a)
             for (int kk = 0; kk < DQ; ++kk) { cs[kk] = x0[kk]; ys[kk] = y0[kk]; }
 #pragma unroll 1
             for (int i4 = 0; i4 < cps; i4 += 4) {
-                // lane class c draws the variates of sub-step i4 + c
-                StepRng rng;
-                rng.begin(s.key0, s.key1, gid, step, (uint32_t)(i4 + c));
-                rng.run_all();
-                const double r4 = rng.r, E4 = rng.Ea;
+                // lane class c draws the variates of sub-step i4 + c (ONED: those of
+                // RandProposer1D where the sub-step's column belongs to a one-parameter block)
+                double r4, E4;
+                const bool od = ONED && i4 + c < cps &&
+                                a.colflag[((size_t)g * nsteps + base + sl) * cps + i4 + c] != 0;
+                step_variates(s.key0, s.key1, gid, step, (uint32_t)(i4 + c), od, r4, E4);
                 const int nq = cps - i4 < 4 ? cps - i4 : 4;
 #pragma unroll 1
                 for (int q = 0; q < nq; ++q) {
@@ -608,12 +679,14 @@ __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs
     const int g = blockIdx.y;
     const int d = a.d;
     const bool live = sr < a.n_steps;
+    int flag1d = 0;
     if (live) {
         const unsigned long long step = a.step0 + (unsigned long long)sr;
         const int cyc = (int)(step / (unsigned long long)a.cps - a.cycle0);
         const int col = (int)(step % (unsigned long long)a.cps);
         const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
         for (int i = part; i < d; i += 4) sv[i * 64 + l] = v[i];
+        if (a.vflag) flag1d = a.vflag[((size_t)g * a.ncyc + cyc) * a.cps + col];
     }
     __syncthreads();
     if (!live) return;
@@ -622,6 +695,7 @@ __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs
     const size_t ocol = a.out_div ? (size_t)(sr / a.out_div) * a.out_cols + a.out_slot0 + sr % a.out_div
                                   : (size_t)sr;
     double2* __restrict__ out = (double2*)a.VU + ((size_t)g * a.out_total + ocol) * (4 * a.dq);
+    if (a.colflag && part == 0) a.colflag[(size_t)g * a.out_total + ocol] = flag1d;
     // Four rows at a time: four independent chains share every v_i read from LDS (each chain is
     // still one ascending fma chain from +0.0 -- the order of orc_whiten_directions); the row
     // blocks of a column are dealt to the four waves of the workgroup (the long ones last).
@@ -709,7 +783,7 @@ __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 }
 
 template <int DQ, int KM, bool UNIT_T>
-__global__ void __launch_bounds__(256, (DQ * (KM + 3) <= 28 ? 3 : 2))
+__global__ void __launch_bounds__(256, (DQ * (KM + 3) <= 28 ? 3 : DQ * (KM + 3) <= 45 ? 2 : 1))
 step_inc_mix_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -906,18 +980,27 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
     const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);
-    static const kern_t kerns[6] = {
-        step_inc_kernel<DQ, 0, false>, step_inc_kernel<DQ, 0, true>,
-        step_inc_kernel<DQ, 1, false>, step_inc_kernel<DQ, 1, true>,
-        step_inc_kernel<DQ, 2, false>, step_inc_kernel<DQ, 2, true>};
-    static const std::string names[6] = {
+    static const kern_t kerns[12] = {
+        step_inc_kernel<DQ, 0, false, false>, step_inc_kernel<DQ, 0, true, false>,
+        step_inc_kernel<DQ, 1, false, false>, step_inc_kernel<DQ, 1, true, false>,
+        step_inc_kernel<DQ, 2, false, false>, step_inc_kernel<DQ, 2, true, false>,
+        step_inc_kernel<DQ, 0, false, true>, step_inc_kernel<DQ, 0, true, true>,
+        step_inc_kernel<DQ, 1, false, true>, step_inc_kernel<DQ, 1, true, true>,
+        step_inc_kernel<DQ, 2, false, true>, step_inc_kernel<DQ, 2, true, true>};
+    static const std::string names[12] = {
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, false>",
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, true>",
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, false>",
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, true>",
         "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false>",
-        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true>"};
-    const int v = 2 * mode + (unit_t ? 1 : 0);
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, false, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, true, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, false, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, true, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true, 1-D blocks>"};
+    const int v = 2 * mode + (unit_t ? 1 : 0) + (a.colflag ? 6 : 0);
     if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -935,18 +1018,27 @@ hipError_t launch_drag_dq(const IncStepArgs& a, hipStream_t st)
     const size_t lds = sizeof(double2) * 2 * (size_t)a.chunk_steps * (1 + a.n_drag) * 4 * DQ;
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);
-    static const kern_t kerns[6] = {
-        drag_inc_kernel<DQ, 0, false>, drag_inc_kernel<DQ, 0, true>,
-        drag_inc_kernel<DQ, 1, false>, drag_inc_kernel<DQ, 1, true>,
-        drag_inc_kernel<DQ, 2, false>, drag_inc_kernel<DQ, 2, true>};
-    static const std::string names[6] = {
+    static const kern_t kerns[12] = {
+        drag_inc_kernel<DQ, 0, false, false>, drag_inc_kernel<DQ, 0, true, false>,
+        drag_inc_kernel<DQ, 1, false, false>, drag_inc_kernel<DQ, 1, true, false>,
+        drag_inc_kernel<DQ, 2, false, false>, drag_inc_kernel<DQ, 2, true, false>,
+        drag_inc_kernel<DQ, 0, false, true>, drag_inc_kernel<DQ, 0, true, true>,
+        drag_inc_kernel<DQ, 1, false, true>, drag_inc_kernel<DQ, 1, true, true>,
+        drag_inc_kernel<DQ, 2, false, true>, drag_inc_kernel<DQ, 2, true, true>};
+    static const std::string names[12] = {
         "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 0, false>",
         "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 0, true>",
         "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 1, false>",
         "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 1, true>",
         "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, false>",
-        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, true>"};
-    const int v = 2 * mode + (unit_t ? 1 : 0);
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, true>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 0, false, 1-D blocks>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 0, true, 1-D blocks>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 1, false, 1-D blocks>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 1, true, 1-D blocks>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, false, 1-D blocks>",
+        "mcmc::drag_inc_kernel<" + std::to_string(DQ) + ", 2, true, 1-D blocks>"};
+    const int v = 2 * mode + (unit_t ? 1 : 0) + (a.colflag ? 6 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kerns[v],

@@ -215,6 +215,9 @@ struct IncStepArgs {
     // dragging (drag_inc_kernel): interpolation steps per dragging step (0: plain steps); VU then
     // holds 1 + n_drag columns per step; chunk_steps dragging steps per LDS chunk
     int n_drag, chunk_steps;
+    // one-parameter blocks: colflag[G][columns of the launch] (written with VU) marks the columns
+    // whose step draws the RandProposer1D variates (proposal.py:85-93); null if no block has one
+    const int* colflag;
 };
 
 struct IncDirArgs {
@@ -228,6 +231,10 @@ struct IncDirArgs {
     // where column sr goes: out_div == 0: column sr of out_total; else column
     // (sr / out_div) * out_cols + out_slot0 + sr % out_div (dragging: slow / fast interleaved)
     int out_div, out_cols, out_slot0, out_total;
+    // one-parameter blocks: the basis kernel's flags [G][ncyc][cps] of this sequence (null: none)
+    // are copied to colflag[G][out_total] (null: nothing to write) at the columns' places in VU
+    const int* vflag;
+    int* colflag;
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

@@ -920,7 +920,12 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                     double r, Ea;
                     if (step % (uint64_t)p->refresh_every == 0)
                         orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * K * d);
-                    if (p->paired_variates)
+                    /* a column of a one-parameter block draws the RandProposer1D variates of
+                     * the un-paired stream, as in full evaluation (its half of the pair block
+                     * stays unused) */
+                    if (f1[col])
+                        walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 1, &r, &Ea);
+                    else if (p->paired_variates)
                         walker_variates_pair(k0, k1, walker0 + (uint32_t)w, step, &r, &Ea);
                     else
                         walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);

@@ -167,8 +167,8 @@ class OracleEngine:
             raise EngineError(ERR_ARG, "shared_basis: False serves a single parameter block "
                                        "without dragging")
         if self.incremental and (not 1 <= self.K <= 4 or (self.K > 1 and self.d > 64)
-                                 or (self._blocking and (
-                                     (self._blocking["drag_last_slow"] >= 0 and self.K != 1) or
+                                 or (self._blocking and self.K != 1 and (
+                                     self._blocking["drag_last_slow"] >= 0 or
                                      min(len(b) for b in self._blocking["blocks"]) < 2)) or
                                  (self._prior[3] is not None and self._prior[3].any())):
             raise EngineError(ERR_ARG, "incremental evaluation serves one Gaussian mode with "

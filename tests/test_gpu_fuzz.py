@@ -105,8 +105,8 @@ def test_random_big_dimensions_bit_exact(seed):
 
 def draw_incremental_case(seed):
     """A random problem incremental evaluation serves: d = 2..128, 1..4 modes (d <= 64 above one
-    mode), uniform / normal priors, temperature, burn-in, blocks of >= 2 parameters with
-    oversampling, or dragging (one mode)."""
+    mode), uniform / normal priors, temperature, burn-in, parameter blocks (of any size for one
+    mode, of >= 2 parameters for a mixture) with oversampling, or dragging (one mode)."""
     rng = np.random.default_rng(seed)
     d = int(rng.choice([int(rng.integers(2, 33)), int(rng.integers(33, 65)), int(rng.integers(65, 129))],
                        p=[0.6, 0.25, 0.15]))
@@ -132,9 +132,10 @@ def draw_incremental_case(seed):
     if rng.random() < 0.5 and d >= 4:
         perm = rng.permutation(d).tolist()
         nb = int(rng.integers(2, min(4, d // 2) + 1))
-        cuts = sorted(rng.choice(np.arange(2, d - 1, 2), size=nb - 1, replace=False).tolist())
+        cuts = sorted(rng.choice(np.arange(1, d), size=nb - 1, replace=False).tolist())
         blocks = [perm[a:b] for a, b in zip([0] + cuts, cuts + [d])]
-        if min(len(b) for b in blocks) >= 2:
+        # (a mixture keeps to blocks of at least two parameters)
+        if K == 1 or min(len(b) for b in blocks) >= 2:
             over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
             kw.update(blocks=blocks, over=over)
             L = sum(o * len(b) for o, b in zip(over, blocks))

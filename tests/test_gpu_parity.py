@@ -823,11 +823,18 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
      [1, 2, 3]),
     (100, 128, 64, 1, [list(range(0, 100, 5)) + list(range(1, 100, 5)),
                        [i for i in range(100) if i % 5 >= 2]], [1, 2]),
-    (48, 128, 64, 2, [list(range(40)), list(range(40, 48))], [1, 4])])
+    (48, 128, 64, 2, [list(range(40)), list(range(40, 48))], [1, 4]),
+    # one-parameter blocks (RandProposer1D variates on their columns): the 1-D variants
+    (4, 256, 64, 1, [[0], [1, 2, 3]], [1, 2]),
+    (27, 256, 128, 1, [list(range(6)), list(range(6, 26)), [26]], [1, 2, 4]),
+    (7, 128, 64, 1, [[3], [0], [1, 2, 4, 5, 6]], [1, 1, 3]),
+    (40, 128, 64, 1, [[39], list(range(20)), list(range(20, 39))], [1, 1, 2]),
+    (100, 128, 64, 1, [list(range(50)), [99], list(range(50, 99))], [1, 2, 2])])
 def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, over):
     """Parameter blocks with oversampling (proposal.py:96-260) in incremental mode: a cycle has
     L = sum_b oversample_b n_b columns, each with its whitened image; the refresh falls every
-    40 L steps.  (One-parameter blocks and dragging stay with `evaluation: full`.)"""
+    40 L steps.  Columns of one-parameter blocks draw the RandProposer1D variates
+    (proposal.py:85-93) of the un-paired stream."""
     kw = {"weights": [0.3, 0.7]} if K == 2 else {}
     eng, prob, st = make_pair(d, W, gs, K=K, blocks=blocks, over=over, incremental=True, **kw)
     L = eng.cycle_length()
@@ -840,10 +847,12 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
         compare_state(eng, st)
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
     assert st.step > 40 * L and "step_inc" in eng.last_step_kernel()
+    assert ("1-D blocks" in eng.last_step_kernel()) == (min(len(b) for b in blocks) == 1)
+    # a MIXTURE with a one-parameter block stays with `evaluation: full`
     eng2 = E.Engine(4, 256, group_size=64, incremental=True)
     eng2.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
-    m, c = random_target(4, 1, np.random.default_rng(0))
-    eng2.set_target_gaussian_mixture(m, c)
+    m, c = random_target(4, 2, np.random.default_rng(0))
+    eng2.set_target_gaussian_mixture(m, c, [0.5, 0.5])
     eng2.set_blocking([[0], [1, 2, 3]], [1, 2])
     eng2.set_proposal_cov(c[0])
     eng2.set_state(np.full((256, 4), 0.5))
@@ -861,7 +870,11 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
      dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.25] * 21)),
     # d > 32: the general blocked-direction kernel feeds the slow and the fast sequence
     (40, 128, 64, [list(range(12)), list(range(12, 40))], 0, 5, {}),
-    (100, 128, 64, [list(range(30)), list(range(30, 100))], 0, 3, {})])
+    (100, 128, 64, [list(range(30)), list(range(30, 100))], 0, 3, {}),
+    # one-parameter blocks among the slow and among the fast ones
+    (8, 256, 64, [[0], [1, 2, 3], [4, 5, 6, 7]], 1, 5, {}),
+    (27, 256, 128, [list(range(6)), [26], list(range(6, 26))], 0, 7, {"T": 1.3}),
+    (40, 128, 64, [[7], list(range(7)), [39], list(range(8, 39))], 1, 4, {})])
 def test_incremental_dragging_steps_bit_exact(d, W, gs, blocks, last_slow, n_drag, extra):
     """The dragging step (mcmc.py:564-668) in incremental mode (drag_inc_kernel against the
     oracle's drag_core_inc): every one of its 1 + 2 n evaluations is O(d), the whitened

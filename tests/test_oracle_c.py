@@ -443,6 +443,38 @@ def test_incremental_with_blocks_is_the_same_posterior():
     np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
 
 
+def test_incremental_with_one_parameter_blocks_is_the_same_sampler():
+    """Columns of a one-parameter block draw the RandProposer1D variates (proposal.py:85-93) in
+    incremental mode too: with un-paired variates the incremental and the from-scratch run take
+    the same decisions; with paired ones the 1-D columns still use the un-paired stream."""
+    from oracle import cbind as O
+    d = 7
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.003
+    mean = np.full(d, 0.5)
+    blocks, over = [[3], [0, 1, 2], [4, 5, 6]], [1, 1, 3]
+    T = O.blocked_transform(cov, blocks, 2.4)
+    mk = lambda inc, paired: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov,
+                                       T=T, group_size=64, seed=4, blocks=blocks,
+                                       oversampling=over, incremental=inc, paired_variates=paired)
+    full, inc = mk(False, False), mk(True, False)
+    x0 = np.clip(mean + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
+    a, b = O.State(full, x0), O.State(inc, x0)
+    a.run(700, n_threads=4)
+    b.run(700, n_threads=4)
+    assert np.array_equal(a.weight, b.weight) and np.array_equal(a.n_accept, b.n_accept)
+    np.testing.assert_allclose(a.x, b.x, rtol=0, atol=1e-12)
+    # paired: a run restricted to the steps of 1-D columns moves only parameter 3, by the same
+    # amounts as the full run does on those steps when both start from the same points
+    pair = mk(True, True)
+    c = O.State(pair, x0)
+    c.run(700, n_threads=4)
+    lp, ll = full.evaluate(c.x)
+    np.testing.assert_allclose(c.logpost, lp + ll, rtol=2e-13, atol=1e-11)
+    assert 0.05 < c.n_accept.sum() / (128 * 700) < 0.8
+
+
 def test_incremental_dragging_is_the_same_sampler():
     """Dragging (mcmc.py:564-668) in incremental mode: the whitened residuals of the start and
     end points are carried through the interpolation steps -- same accept decisions as

@@ -15,7 +15,7 @@ lo = idx[-4]
 prev_end = None
 for r in rows[lo:]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    name = r["Kernel_Name"].split("(")[0].split("::")[-1][:28]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("mcmc::", "").split("(")[0][:28]
     gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
     print("%-28s q%-3s start %10.1f us  dur %8.1f us  gap-from-prev-end %7.1f us" % (name, r.get("Queue_Id", "?"), s / 1e3, (e - s) / 1e3, gap))
     prev_end = max(prev_end or 0, e)
