@@ -110,6 +110,9 @@ __host__ __device__ constexpr int inc_chunk(int dq)
 // every DQ and MODE: the largest occupancy that does not spill)
 __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
 {
+#ifdef MCMC_INC_WAVES_OVERRIDE   // developer switch (timing experiments)
+    return MCMC_INC_WAVES_OVERRIDE;
+#endif
     if (mode == 0) return dq <= 8 ? 4 : dq <= 13 ? 3 : dq <= 25 ? 2 : 1;
     if (mode == 1) return dq <= 4 ? 4 : dq <= 8 ? 3 : dq <= 25 ? 2 : 1;
     return dq <= 4 ? 4 : dq <= 7 ? 3 : dq <= 15 ? 2 : 1;
@@ -196,6 +199,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     const short_log_tab slog = short_log_load(short_log_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
     PairRng pr;
     pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
@@ -295,8 +299,14 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const double lt = lp + ll;
                     const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
                     const bool accept = inside & ((lt > lpost) | (Ea > delta));
-                    const int lim = burn > 0 ? lim10 : lim1;
-                    burn -= (accept & (burn > 0)) ? 1 : 0;
+                    // (burn-in, mcmc.py:685-690, ends early in a run: its bookkeeping sits
+                    // behind a wave-uniform test of "some lane is still burning in")
+                    int lim = lim1;
+                    if (burning) {
+                        lim = burn > 0 ? lim10 : lim1;
+                        burn -= (accept & (burn > 0)) ? 1 : 0;
+                        burning = lanes(burn > 0) != 0ull;
+                    }
                     const double ra = accept ? r : 0.0;
                     // (the pairs are read AGAIN from LDS: the pointer passes through an empty
                     // asm so that the compiler cannot keep the first reads alive in 4 DQ registers)
@@ -616,52 +626,60 @@ drag_inc_kernel(const IncStepArgs a)
 }
 
 // ---------------------------------------------------------------- y = L^-1 (x - mu)
-// One thread per walker, 64 walkers per workgroup; the deviations of the workgroup sit in LDS
-// ([i][lane]) and the rows of L^-1 are read at wave-uniform addresses (scalar loads).  One
+// 64 walkers per workgroup of four waves; the deviations of the workgroup sit in LDS
+// ([i][walker]) and the rows of L^-1 are read at wave-uniform addresses (scalar loads).  One
 // ascending fma chain per row from +0.0 (orc_whiten); four rows advance together on every
-// deviation read, which gives the lane four independent chains.  Runs once per `refresh_every`
-// steps.
-__global__ void __launch_bounds__(64) whiten_state_kernel(const double* __restrict__ x,
-                                                          double* __restrict__ y,
-                                                          const double* __restrict__ mean,
-                                                          const double* __restrict__ Lrow, int d,
-                                                          int W, int K)
+// deviation read (four independent chains per lane), and the blocks of four rows are dealt to
+// the four waves in turn.  Runs once per `refresh_every` steps.
+__global__ void __launch_bounds__(256) whiten_state_kernel(const double* __restrict__ x,
+                                                           double* __restrict__ y,
+                                                           const double* __restrict__ mean,
+                                                           const double* __restrict__ Lrow, int d,
+                                                           int W, int K)
 {
     extern __shared__ __attribute__((aligned(16))) double sdev[];
-    const int l = threadIdx.x, w = blockIdx.x * 64 + l;
-    if (w >= W) return;    // (no barrier below: a lane reads only what it wrote)
+    const int l = threadIdx.x & 63, part = threadIdx.x >> 6, w = blockIdx.x * 64 + l;
+    const bool live = w < W;
+    const int nblk = (d + 3) / 4;
     for (int k = 0; k < K; ++k) {   // y is [K][d][W]
-        for (int i = 0; i < d; ++i) sdev[i * 64 + l] = x[(size_t)i * W + w] - mean[k * d + i];
-        int j0 = 0;
-        for (; j0 + 4 <= d; j0 += 4) {
-            const double* __restrict__ r0 = Lrow + ((size_t)k * d + j0) * d;
-            const double* __restrict__ r1 = r0 + d;
-            const double* __restrict__ r2 = r1 + d;
-            const double* __restrict__ r3 = r2 + d;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            for (int i = 0; i <= j0; ++i) {
-                const double dv = sdev[i * 64 + l];
-                a0 = fma(r0[i], dv, a0);
-                a1 = fma(r1[i], dv, a1);
-                a2 = fma(r2[i], dv, a2);
-                a3 = fma(r3[i], dv, a3);
+        __syncthreads();            // (the previous mode's deviations have been used)
+        if (live)
+            for (int i = part; i < d; i += 4) sdev[i * 64 + l] = x[(size_t)i * W + w] - mean[k * d + i];
+        __syncthreads();
+        if (!live) continue;
+        for (int rb = part; rb < nblk; rb += 4) {
+            const int j0 = 4 * rb;
+            if (j0 + 4 <= d) {
+                const double* __restrict__ r0 = Lrow + ((size_t)k * d + j0) * d;
+                const double* __restrict__ r1 = r0 + d;
+                const double* __restrict__ r2 = r1 + d;
+                const double* __restrict__ r3 = r2 + d;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                for (int i = 0; i <= j0; ++i) {
+                    const double dv = sdev[i * 64 + l];
+                    a0 = fma(r0[i], dv, a0);
+                    a1 = fma(r1[i], dv, a1);
+                    a2 = fma(r2[i], dv, a2);
+                    a3 = fma(r3[i], dv, a3);
+                }
+                const double d1 = sdev[(j0 + 1) * 64 + l], d2 = sdev[(j0 + 2) * 64 + l],
+                             d3 = sdev[(j0 + 3) * 64 + l];
+                a1 = fma(r1[j0 + 1], d1, a1);
+                a2 = fma(r2[j0 + 1], d1, a2);
+                a3 = fma(r3[j0 + 1], d1, a3);
+                a2 = fma(r2[j0 + 2], d2, a2);
+                a3 = fma(r3[j0 + 2], d2, a3);
+                a3 = fma(r3[j0 + 3], d3, a3);
+                double* __restrict__ out = y + ((size_t)k * d + j0) * W + w;
+                out[0] = a0; out[(size_t)W] = a1; out[2 * (size_t)W] = a2; out[3 * (size_t)W] = a3;
+            } else {
+                for (int j = j0; j < d; ++j) {
+                    const double* __restrict__ row = Lrow + ((size_t)k * d + j) * d;
+                    double acc = 0.0;
+                    for (int i = 0; i <= j; ++i) acc = fma(row[i], sdev[i * 64 + l], acc);
+                    y[((size_t)k * d + j) * W + w] = acc;
+                }
             }
-            const double d1 = sdev[(j0 + 1) * 64 + l], d2 = sdev[(j0 + 2) * 64 + l],
-                         d3 = sdev[(j0 + 3) * 64 + l];
-            a1 = fma(r1[j0 + 1], d1, a1);
-            a2 = fma(r2[j0 + 1], d1, a2);
-            a3 = fma(r3[j0 + 1], d1, a3);
-            a2 = fma(r2[j0 + 2], d2, a2);
-            a3 = fma(r3[j0 + 2], d2, a3);
-            a3 = fma(r3[j0 + 3], d3, a3);
-            double* __restrict__ out = y + ((size_t)k * d + j0) * W + w;
-            out[0] = a0; out[(size_t)W] = a1; out[2 * (size_t)W] = a2; out[3 * (size_t)W] = a3;
-        }
-        for (int j = j0; j < d; ++j) {
-            const double* __restrict__ row = Lrow + ((size_t)k * d + j) * d;
-            double acc = 0.0;
-            for (int i = 0; i <= j; ++i) acc = fma(row[i], sdev[i * 64 + l], acc);
-            y[((size_t)k * d + j) * W + w] = acc;
         }
     }
 }
@@ -1090,7 +1108,7 @@ extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, c
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(mcmc::whiten_state_kernel, dim3((W + 63) / 64), dim3(64), lds, st, x, y,
+    hipLaunchKernelGGL(mcmc::whiten_state_kernel, dim3((W + 63) / 64), dim3(256), lds, st, x, y,
                        mean, Lrow, d, W, K);
     return hipGetLastError();
 }

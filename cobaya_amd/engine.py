@@ -104,7 +104,8 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    # MCMC_HIP_LIB (developer switch): an experiment build of the same ABI (tools/exp_*.sh)
+    path = path or os.environ.get("MCMC_HIP_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise EngineError(ERR_DEVICE,
                           f"{path} not found: build it with `python -m cobaya_amd.build` "
