@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) k(double* out, int iters)
     }
     const double c = 1.0000001, e = 1e-12;
     const unsigned m = 0xD2511F53u;
+    if (OP == 12) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(u[0]), "v"(m) : "vcc");
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rep = 0; rep < 4; ++rep) {
@@ -33,7 +34,9 @@ __global__ void __launch_bounds__(256) k(double* out, int iters)
 #define CVT(i) asm volatile("v_cvt_f64_u32 %0, %1" : "+v"(a[i]) : "v"(u[i]));
 #define CMP(i) asm volatile("v_cmp_le_f64 vcc, %0, %1" : : "v"(a[i]), "v"(c) : "vcc");
 #define DPP(i) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(u[i]));
-#define CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(m) : "vcc");
+// (vcc is set once before the loop and only read here: declaring it clobbered makes the
+// compiler put an s_nop between the selects)
+#define CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(m));
 #define FREXPM(i) asm volatile("v_frexp_mant_f64 %0, %0" : "+v"(a[i]));
 #define LDEXP(i) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(a[i]) : "v"(u[i]));
 #define MAD64(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(u[i]), "v"(m) : "vcc");
