@@ -17,6 +17,25 @@ constexpr uint32_t kStreamStep = 0u;
 constexpr uint32_t kStreamBasis = 1u;
 constexpr uint32_t kBranchExp24 = 5536481u;  // floor(0.33 * 2^24), proposal.py:79
 
+// The wave's lane mask of a condition (a v_cmp writes it to a scalar register pair), and
+// selects that take such a mask.  The selects are written as the VOP3 encoding
+// (v_cndmask_b32_e64) in inline asm on purpose: on gfx950 the VOP2 encoding the compiler prefers
+// (v_cndmask_b32_e32 ... vcc) issues at 23.6 clocks per wave-instruction, the VOP3 one -- with
+// vcc or any scalar pair as the mask -- at 4.4 (tools/probes/cndmask_cost.hip,
+// profiles/r02_probe_cndmask_cost.log).
+__device__ __forceinline__ unsigned long long lanes(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ int sel(unsigned long long m, int a, int b)   // lane in m ? a : b
+{
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double sel(unsigned long long m, double a, double b)
+{
+    return __hiloint2double(sel(m, __double2hiint(a), __double2hiint(b)),
+                            sel(m, __double2loint(a), __double2loint(b)));
+}
+
 struct u32x4 {
     uint32_t w0, w1, w2, w3;
 };
@@ -78,7 +97,7 @@ __device__ __forceinline__ double dexp(double x)
                      invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
                      P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
                      P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
-    if (!(x >= -708.0)) return 0.0;
+    const unsigned long long in_range = lanes(x >= -708.0);   // else 0 (also for NaN)
     const double kf = rint(x * invln2);
     const double hi = fma(-kf, ln2_hi, x);
     const double lo = kf * ln2_lo;
@@ -87,7 +106,7 @@ __device__ __forceinline__ double dexp(double x)
     const double c = r - t * fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1);
     const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
     const int k = (int)kf;
-    return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
+    return sel(in_range, __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52)), 0.0);
 }
 
 __device__ __forceinline__ double ksin(double x)
@@ -204,7 +223,7 @@ struct StepRng {
         else if (k == 13) log_a(u52(ka));
         else if (k == 14) Ea = -log_b();
         else if (k == 15) r = sqrt(2.0 * Er);
-        else if (k == 16) r = expo ? Er : r;
+        else if (k == 16) r = sel(lanes(expo), Er, r);
         // the walker's PRIVATE sign (bit 7 of w0; set = positive, as for one-parameter blocks):
         // the basis column is shared by the group, and x + r v with r > 0 is a symmetric
         // proposal only on average over v and -v.  With its own sign every walker's kernel is
@@ -318,8 +337,10 @@ struct PairRng {
             const uint32_t ka = b & 0x0FFFFFFFu;
             const double Er = neg_log_short(2u * kr + 1u, 25, tab);
             // (2 E_r lies in [2^-24, 35])
-            const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt_midrange(2.0 * Er);
-            r[h] = (a & 0x80000000u) ? rr : -rr;
+            const double rr = sel(lanes(((a >> 20) & 0x7FFu) < 676u), Er, sqrt_midrange(2.0 * Er));
+            // sign: bit 31 of a set = positive
+            r[h] = __longlong_as_double(__double_as_longlong(rr) ^
+                                        ((long long)(~a & 0x80000000u) << 32));
             Ea[h] = neg_log_short(2u * ka + 1u, 29, tab);
         }
     }

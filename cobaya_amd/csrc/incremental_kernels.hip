@@ -49,15 +49,20 @@ __device__ __forceinline__ double quad_sum(double p)
     return q + quad_perm<0x4E>(q);             // [2,3,0,1]
 }
 
-// the wave's lane mask of a condition (a v_cmp writes it to a scalar register pair)
-__device__ __forceinline__ unsigned long long lanes(bool b) { return __builtin_amdgcn_ballot_w64(b); }
-// lane mask -> true in the four lanes of a quad iff the mask holds all four of its lanes
-__device__ __forceinline__ bool quad_all(unsigned long long m)
+// (lanes(cond) -- the wave's lane mask of a condition -- and the mask-taking selects sel(m, a, b)
+// are in det_math.h)
+// lane mask -> the mask of the lanes whose quad is held completely
+__device__ __forceinline__ unsigned long long quad_all_mask(unsigned long long m)
 {
     m &= m >> 1;
     m &= m >> 2;
     m &= 0x1111111111111111ull;
-    return __builtin_amdgcn_inverse_ballot_w64(m * 15ull);
+    return m * 15ull;
+}
+// ... and the same as a lane predicate
+__device__ __forceinline__ bool quad_all(unsigned long long m)
+{
+    return __builtin_amdgcn_inverse_ballot_w64(quad_all_mask(m));
 }
 
 // A pointer into LDS that the optimiser has to take as new (so that it re-reads what it read
@@ -463,11 +468,13 @@ drag_inc_kernel(const IncStepArgs a)
     const double navg = (double)cps;
 
     // log-posterior of the point t (already formed) with residual yt: lp, ll, lt (-inf outside)
+    // (every select below takes its condition as a lane mask and is a VOP3 v_cndmask: sel(),
+    // det_math.h)
     auto finish = [&](bool inb, double pc, double sc, double& lp, double& ll) -> double {
-        const double chi2 = quad_sum(inb ? pc : INFINITY);
+        const double chi2 = quad_sum(sel(lanes(inb), pc, INFINITY));
         lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
         ll = -0.5 * (s.cnorm0 + chi2);
-        return chi2 < INFINITY ? lp + ll : -INFINITY;
+        return sel(lanes(chi2 < INFINITY), lp + ll, -INFINITY);
     };
     auto inside = [&](double t, int kk) -> bool {
         if (MODE == 0) return (t <= bhi) & (t >= blo);
@@ -483,9 +490,9 @@ drag_inc_kernel(const IncStepArgs a)
         const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
         return sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
     };
-    auto metropolis = [&](double trial, double current, double Ea) -> bool {
+    auto metropolis = [&](double trial, double current, double Ea) -> unsigned long long {
         const double delta = UNIT_T ? (current - trial) : (current - trial) / s.temperature;
-        return (trial != -INFINITY) & ((trial > current) | (Ea > delta));
+        return lanes(trial != -INFINITY) & (lanes(trial > current) | lanes(Ea > delta));
     };
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -566,9 +573,10 @@ drag_inc_kernel(const IncStepArgs a)
                         const double frac = (double)i / navg;
                         const double pi = (1.0 - frac) * ps_lt + frac * pe_lt;
                         const double ci = (1.0 - frac) * cs_lt + frac * ce_lt;
-                        const bool acc = (ps_lt != -INFINITY) & (pe_lt != -INFINITY) &
-                                         metropolis(pi, ci, Ea);
-                        const double ra = acc ? r : 0.0;
+                        const unsigned long long acc_m = lanes(ps_lt != -INFINITY) &
+                                                         lanes(pe_lt != -INFINITY) &
+                                                         metropolis(pi, ci, Ea);
+                        const double ra = sel(acc_m, r, 0.0);
                         const lds_pairs col2 = relaunder(col);
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
@@ -579,31 +587,33 @@ drag_inc_kernel(const IncStepArgs a)
                             ys[kk] = fma(ra, p.y, ys[kk]);
                             ye[kk] = fma(ra, p.y, ye[kk]);
                         }
-                        cs_lt = acc ? ps_lt : cs_lt;
-                        ce_lp = acc ? pe_lp : ce_lp;
-                        ce_ll = acc ? pe_ll : ce_ll;
-                        ce_lt = acc ? pe_lt : ce_lt;
+                        cs_lt = sel(acc_m, ps_lt, cs_lt);
+                        ce_lp = sel(acc_m, pe_lp, ce_lp);
+                        ce_ll = sel(acc_m, pe_ll, ce_ll);
+                        ce_lt = sel(acc_m, pe_lt, ce_lt);
                         start_acc += cs_lt;
                         end_acc += ce_lt;
                     }
                 }
             }
-            const bool accept = !dead & metropolis(end_acc / navg, start_acc / navg, Ea0);
+            const unsigned long long accept_m =
+                ~lanes(dead) & metropolis(end_acc / navg, start_acc / navg, Ea0);
+            const bool accept = __builtin_amdgcn_inverse_ballot_w64(accept_m);
             const int lim = burn > 0 ? lim10 : lim1;
             burn -= (accept & (burn > 0)) ? 1 : 0;
-            lpri = accept ? ce_lp : lpri;
-            llik = accept ? ce_ll : llik;
-            lpost = accept ? ce_lt : lpost;
-            prej = accept ? 0 : prej;
-            wt = accept ? 1 : wt + 1;
-            nacc += accept ? 1 : 0;
+            lpri = sel(accept_m, ce_lp, lpri);
+            llik = sel(accept_m, ce_ll, llik);
+            lpost = sel(accept_m, ce_lt, lpost);
+            prej = sel(accept_m, 0, prej);
+            wt = sel(accept_m, 1, wt + 1);
+            nacc += sel(accept_m, 1, 0);
             if (!accept & !dead & (wt - prej > lim) && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
             // the walker's point: the dragged end point on accept (cs / ys were dragged along and
             // are re-seeded from it at the next step)
 #pragma unroll
             for (int kk = 0; kk < DQ; ++kk) {
-                x0[kk] = accept ? ce[kk] : x0[kk];
-                y0[kk] = accept ? ye[kk] : y0[kk];
+                x0[kk] = sel(accept_m, ce[kk], x0[kk]);
+                y0[kk] = sel(accept_m, ye[kk], y0[kk]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -847,8 +857,8 @@ step_inc_mix_kernel(const IncStepArgs a)
     for (int k = 0; k < KM; ++k) { cn[k] = s.cblock[a.cnorm_off + k]; wk[k] = s.cblock[a.weight_off + k]; }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
-    long long nacc = s.n_accept[w];
-    const long long nacc0 = nacc;
+    const long long nacc0 = s.n_accept[w];
+    int nacc = 0;     // accepted steps of this launch
     const uint32_t gid = s.walker0 + (uint32_t)w;
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
@@ -857,6 +867,7 @@ step_inc_mix_kernel(const IncStepArgs a)
     const short_log_tab slog = short_log_load(short_log_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
     PairRng pr;
     pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
@@ -885,12 +896,12 @@ step_inc_mix_kernel(const IncStepArgs a)
                 default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
                 }
                 const double* __restrict__ col = cur + sl * COL + c;
-                bool inb = true;
+                unsigned long long inb = ~0ull;   // the support test as a lane mask
                 double sc = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {
                     const double t = fma(r, col[4 * kk], x[kk]);
-                    inb = inb & (t <= hi[kk]) & (t >= lo[kk]);
+                    inb &= lanes(t <= hi[kk]) & lanes(t >= lo[kk]);
                     if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
                         const int i = 4 * kk + c;
                         const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
@@ -907,22 +918,30 @@ step_inc_mix_kernel(const IncStepArgs a)
                         const double yt = fma(r, uk[4 * kk], y[k][kk]);
                         pc = fma(yt, yt, pc);
                     }
-                    const double chi2 = quad_sum(k == 0 ? (inb ? pc : INFINITY) : pc);
+                    const double chi2 = quad_sum(pc);
                     ak[k] = -0.5 * (cn[k] + chi2);
-                    amax = ak[k] > amax ? ak[k] : amax;
+                    amax = fmax(ak[k], amax);
                 }
-                const bool inside = ak[0] > -INFINITY;   // chi2_0 = +inf outside the support
+                // inside the support = all four lanes of the walker are (outside, what follows is
+                // computed and not used)
+                const unsigned long long inside_m = quad_all_mask(inb);
+                const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
                 const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
                 double Ssum = 0.0;
 #pragma unroll
                 for (int k = 0; k < KM; ++k) Ssum = fma(wk[k], dexp(ak[k] - amax), Ssum);
                 const double ll = dlog(Ssum) + amax;
-                const double lt = inside ? lp + ll : -INFINITY;
+                const double lt = lp + ll;   // (finite: the sum of the weights' terms is >= w_max)
                 const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
-                const bool accept = inside & (lt != -INFINITY) & ((lt > lpost) | (Ea > delta));
-                const int lim = burn > 0 ? lim10 : lim1;
-                burn -= (accept & (burn > 0)) ? 1 : 0;
-                const double ra = accept ? r : 0.0;
+                const unsigned long long acc_m = inside_m & (lanes(lt > lpost) | lanes(Ea > delta));
+                const bool accept = __builtin_amdgcn_inverse_ballot_w64(acc_m);
+                int lim = lim1;
+                if (burning) {   // wave-uniform (see step_inc_kernel)
+                    lim = burn > 0 ? lim10 : lim1;
+                    burn -= (accept & (burn > 0)) ? 1 : 0;
+                    burning = lanes(burn > 0) != 0ull;
+                }
+                const double ra = sel(acc_m, r, 0.0);
                 const lds_doubles col2 = relaunder(col);
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {
@@ -931,12 +950,12 @@ step_inc_mix_kernel(const IncStepArgs a)
                     for (int k = 0; k < KM; ++k)
                         y[k][kk] = fma(ra, col2[(1 + k) * dpad + 4 * kk], y[k][kk]);
                 }
-                lpri = accept ? lp : lpri;
-                llik = accept ? ll : llik;
-                lpost = accept ? lt : lpost;
-                prej = accept ? 0 : (prej + (inside ? 0 : 1));
-                wt = accept ? 1 : wt + 1;
-                nacc += accept ? 1 : 0;
+                lpri = sel(acc_m, lp, lpri);
+                llik = sel(acc_m, ll, llik);
+                lpost = sel(acc_m, lt, lpost);
+                prej = sel(acc_m, 0, prej + sel(inside_m, 0, 1));
+                wt = sel(acc_m, 1, wt + 1);
+                nacc += sel(acc_m, 1, 0);
                 if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
             }
         }
@@ -955,9 +974,9 @@ step_inc_mix_kernel(const IncStepArgs a)
     if (c == 0) {
         s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
-        s.n_accept[w] = nacc;
+        s.n_accept[w] = nacc0 + nacc;
     }
-    wave_add_accepts(s.accept_total, (c == 0) ? nacc - nacc0 : 0);
+    wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
 
 template <int DQ, int KM>

@@ -707,6 +707,60 @@ def test_incremental_steps_bit_exact(d, W, gs, normal, T):
     eng.close()
 
 
+@pytest.mark.parametrize("d,W,gs,kw", [
+    (30, 512, 64, {}), (12, 256, 64, {"blocks": [[0, 1, 2], [3], list(range(4, 12))],
+                                      "over": [1, 2, 3]}),
+    (9, 256, 64, {"blocks": [[0, 1, 2, 3], [4, 5, 6, 7, 8]], "over": [1, 1],
+                  "drag_last_slow": 0, "drag_steps": 3})])
+def test_directions_computed_ahead_never_change_the_results(d, W, gs, kw):
+    """The directions of the next launch are computed on a second stream while a step kernel
+    runs (capi.hip, DirSet), on the guess that the next call is like this one.  Whatever comes
+    instead -- the same call (the set is used), another length, a new proposal covariance, a
+    restored state -- the states are those of the oracle, bit for bit: a set computed ahead is
+    dropped when it does not fit."""
+    eng, prob, st = make_pair(d, W, gs, incremental=True, **kw)
+
+    def go(n):
+        eng.step(n)
+        st.run(n, n_threads=8)
+
+    def check():
+        eng.sync()
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residual")
+
+    for _ in range(3):          # equal calls: the second and third use the set computed ahead
+        go(17)
+    check()
+    go(5)                       # another length: recomputed in line
+    go(17)
+    check()
+    # a proposal refresh between two equal calls (what a learn checkpoint does): the set computed
+    # ahead with the old transform must not be used
+    cov2 = eng.get_proposal_cov() * 1.7 + np.diag(np.full(d, 1e-5))
+    eng.set_proposal_cov(cov2)
+    prob.set_T(eng.get_proposal_transform())
+    go(17)
+    go(17)
+    check()
+    # a restored state: the step counter jumps back
+    snap = eng.get_full_state()
+    snap_o = {k: getattr(st, k).copy() for k in ("x", "y", "logpost", "logprior", "loglike",
+                                                 "weight", "prior_rej", "burn_left", "n_accept")}
+    step_o = st.step
+    go(17)
+    go(17)
+    eng.set_full_state(snap)
+    for k, v in snap_o.items():
+        getattr(st, k)[...] = v
+    st.step = step_o
+    go(17)
+    check()
+    go(2 * 40 * eng.cycle_length() + 3)     # across refreshes: several launches in one call
+    check()
+    eng.close()
+
+
 def test_incremental_mode_refuses_what_it_does_not_cover():
     with pytest.raises(E.EngineError, match="incremental"):
         E.Engine(1, 256, group_size=64, incremental=True)
