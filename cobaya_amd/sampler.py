@@ -80,8 +80,9 @@ HIP_DEFAULTS = {
     "evaluation": "auto",     # "full": every trial is evaluated from scratch (O(d^2));
                               # "incremental": the whitened residual L^-1 (x - mu) is carried
                               # and moved along the whitened shared direction (O(d), same
-                              # posterior; one Gaussian mode, non-periodic, one block,
-                              # snapshots); "auto": incremental where it applies
+                              # posterior; one Gaussian mode or a mixture of <= 4 at d <= 64,
+                              # non-periodic priors, parameter blocks / oversampling /
+                              # dragging, snapshots); "auto": incremental where it applies
     "shared_basis": True,     # True: the walkers of a group share one Haar basis per cycle;
                               # False: every walker draws its own (proposal.py:59-69 to the
                               # letter: the reference-faithful control, much slower)
