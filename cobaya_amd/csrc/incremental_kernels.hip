@@ -803,15 +803,24 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
 // ---------------------------------------------------------------- the step kernel, mixtures
 // KM = 2..4 modes, DQ <= 16 (d <= 64): one carried residual y_k per mode, the direction planes
 // (v, u_1 .. u_KM) of a step read with ds_read_b64, chi2_k per mode through the quad, then the
-// log-sum-exp of eval_point (gaussian_mixture.py:158-163) -- evaluated by every lane of the quad.
+// log-sum-exp of eval_point (gaussian_mixture.py:158-163) -- the exponential of mode k evaluated by
+// lane class k, the logarithm by every lane.
 __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 {
     int c = (2048 / ((1 + km) * 4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }
 
+__host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
+{
+#ifdef MCMC_INC_MIX_WAVES_OVERRIDE   // developer switch (timing experiments)
+    return MCMC_INC_MIX_WAVES_OVERRIDE;
+#endif
+    return dq * (km + 1) <= 18 ? 3 : dq * (km + 1) <= 40 ? 2 : 1;
+}
+
 template <int DQ, int KM, bool UNIT_T>
-__global__ void __launch_bounds__(256, (DQ * (KM + 3) <= 28 ? 3 : DQ * (KM + 3) <= 45 ? 2 : 1))
+__global__ void __launch_bounds__(256, inc_mix_min_waves(DQ, KM))
 step_inc_mix_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -841,7 +850,10 @@ step_inc_mix_kernel(const IncStepArgs a)
         }
     };
     stage(0);
-    double x[DQ], y[KM][DQ], lo[DQ], hi[DQ];
+    // (the bounds sit in LDS as (lo, hi) pairs: registers are for x and the KM residuals)
+    __shared__ double2 sLH[4 * DQ];
+    for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+    double x[DQ], y[KM][DQ];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
@@ -849,8 +861,6 @@ step_inc_mix_kernel(const IncStepArgs a)
         x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;
 #pragma unroll
         for (int k = 0; k < KM; ++k) y[k][kk] = in ? a.y[((size_t)k * d + i) * W + w] : 0.0;
-        lo[kk] = a.prior[i];
-        hi[kk] = a.prior[dpad + i];
     }
     double cn[KM], wk[KM];
 #pragma unroll
@@ -867,6 +877,7 @@ step_inc_mix_kernel(const IncStepArgs a)
     const short_log_tab slog = short_log_load(short_log_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const unsigned long long class1 = lanes(c == 1), class2 = lanes(c == 2), class3 = lanes(c == 3);
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
     PairRng pr;
@@ -901,7 +912,8 @@ step_inc_mix_kernel(const IncStepArgs a)
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {
                     const double t = fma(r, col[4 * kk], x[kk]);
-                    inb &= lanes(t <= hi[kk]) & lanes(t >= lo[kk]);
+                    const double2 lh = sLH[4 * kk + c];
+                    inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
                     if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
                         const int i = 4 * kk + c;
                         const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
@@ -927,9 +939,17 @@ step_inc_mix_kernel(const IncStepArgs a)
                 const unsigned long long inside_m = quad_all_mask(inb);
                 const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
                 const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
-                double Ssum = 0.0;
-#pragma unroll
-                for (int k = 0; k < KM; ++k) Ssum = fma(wk[k], dexp(ak[k] - amax), Ssum);
+                // one exponential per lane: lane class k (< KM) takes the one of mode k, and the
+                // weighted sum gathers them by quad broadcasts in the order of the specification
+                double mine = ak[0];
+                if (KM > 1) mine = sel(class1, ak[1], mine);
+                if (KM > 2) mine = sel(class2, ak[2 < KM ? 2 : 0], mine);
+                if (KM > 3) mine = sel(class3, ak[3 < KM ? 3 : 0], mine);
+                const double e_mine = dexp(mine - amax);
+                double Ssum = fma(wk[0], quad_perm<0x00>(e_mine), 0.0);
+                if (KM > 1) Ssum = fma(wk[1], quad_perm<0x55>(e_mine), Ssum);
+                if (KM > 2) Ssum = fma(wk[2 < KM ? 2 : 0], quad_perm<0xAA>(e_mine), Ssum);
+                if (KM > 3) Ssum = fma(wk[3 < KM ? 3 : 0], quad_perm<0xFF>(e_mine), Ssum);
                 const double ll = dlog(Ssum) + amax;
                 const double lt = lp + ll;   // (finite: the sum of the weights' terms is >= w_max)
                 const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from cobaya_amd.engine import Engine  # noqa: E402
+from cobaya_amd.engine import Engine  # noqa: E402  (MCMC_HIP_LIB selects an experiment build)
 
 
 def run(K, inc, d=30, W=65536, gs=256, launches=4):
