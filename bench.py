@@ -219,7 +219,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
     kt = eng.kernel_times()
     res = {"dt": dt, "spl": spl, "kt": kt, "kernel": eng.last_step_kernel(),
            "evaluation": "incremental" if sampler.incremental else "full",
-           "group_size": int(sampler.group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
+           "group_size": int(sampler.group_size),
+           "basis_group_size": int(sampler.basis_group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
     sampler.close()
     return res
@@ -341,7 +342,7 @@ def main():
                              else f"{d}-dim single-mode gaussian_mixture, {a.walkers} walkers "
                                   "per GPU (non-default)"),
                 "d": d, "walkers_per_gpu": a.walkers, "group_size": m["group_size"],
-                "emit": a.emit, "evaluation": m["evaluation"],
+                "basis_group_size": m["basis_group_size"], "emit": a.emit, "evaluation": m["evaluation"],
                 "metropolis_steps_per_launch": spl,
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": m["n_ckpt"],

@@ -642,7 +642,8 @@ def test_steps_with_the_oracles_own_constants(d, W, gs, K, steps, kw):
     eng.close()
 
 
-@pytest.mark.parametrize("incremental,bgs", [(False, None), (True, None), (True, 1024)])
+@pytest.mark.parametrize("incremental,bgs", [(False, None), (True, None), (True, 1024),
+                                             (True, 8192)])   # 8192: ONE basis for all
 def test_walkers_of_a_group_are_independent_chains(incremental, bgs):
     """The walkers of a group share the Haar basis of every cycle but draw their own sign,
     radial distance and accept variate: given the bases each walker's kernel is symmetric and
