@@ -21,10 +21,16 @@ For N > 1 the driver launches one process per GPU with torch.distributed.run; wa
 by rank (walker_offset = rank * n_walkers, weak scaling), the only collective is the
 per-checkpoint all-reduce of pooled sufficient statistics (RCCL).
 
+Before the W warmup steps the device is spun up with untimed launches of the same step for
+`--spinup-ms` (default 60) milliseconds: an idle MI355X runs the same kernel 18 % slower until
+it has been under load for about 35 ms (tools/ramp_probe.py), which is longer than W = 5
+warmup steps of 1.3 ms.  The timed region is untouched: exactly K full steps.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -61,6 +67,8 @@ def parse():
     ap.add_argument("--group-size", type=int, default=None,
                     help="walkers per Haar-basis group (default: the sampler's choice, 256 at "
                          "the benchmark size)")
+    ap.add_argument("--basis-group-size", type=int, default=None,
+                    help="walkers sharing one Haar basis (default: the sampler's choice)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
                     help="default 40*d (the sampler's default)")
     ap.add_argument("--emit", choices=("snapshots", "chains"), default="snapshots",
@@ -71,6 +79,10 @@ def parse():
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra, separately labelled measurements (emit: chains)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup-ms", type=float, default=60.0,
+                    help="untimed launches before the W warmup steps until the device has been "
+                         "under load this long (a cold MI355X runs the same kernel 18 %% slower "
+                         "for its first ~35 ms: tools/ramp_probe.py); 0 = none")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -172,6 +184,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
     spl_req = a.steps_per_launch or 40 * d
     info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit,
                      evaluation or a.evaluation)
+    if a.basis_group_size and (evaluation or a.evaluation) != "full":
+        info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -191,6 +205,20 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
     one_step = sampler.advance
 
     sampler._next_ckpt = sampler._checkpoint_steps()
+    # device spin-up (untimed, reported as config.device_spinup_ms): the clocks of an idle
+    # MI355X need ~35 ms under load to reach their steady state -- with W = 5 and K = 20 the
+    # whole measurement would otherwise sit on that ramp
+    # (the same number of launches on every rank: checkpoints hold a collective)
+    if a.spinup_ms > 0:
+        t_spin = time.perf_counter()
+        one_step()
+        eng.sync()
+        t_one = max(time.perf_counter() - t_spin, 1e-4)
+        n_spin = np.array([min(500.0, math.ceil(1e-3 * a.spinup_ms / t_one))])
+        n_spin = int(round(float(dist.all_reduce_sum(n_spin)[0]) / size))
+        for _ in range(n_spin):
+            one_step()
+        eng.sync()
     for _ in range(warmup):
         one_step()
     eng.sync()
@@ -342,7 +370,8 @@ def main():
                              else f"{d}-dim single-mode gaussian_mixture, {a.walkers} walkers "
                                   "per GPU (non-default)"),
                 "d": d, "walkers_per_gpu": a.walkers, "group_size": m["group_size"],
-                "basis_group_size": m["basis_group_size"], "emit": a.emit, "evaluation": m["evaluation"],
+                "basis_group_size": m["basis_group_size"], "emit": a.emit,
+                "device_spinup_ms": a.spinup_ms, "evaluation": m["evaluation"],
                 "metropolis_steps_per_launch": spl,
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": m["n_ckpt"],
