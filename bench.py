@@ -210,6 +210,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
     # whole measurement would otherwise sit on that ramp
     # (the same number of launches on every rank: checkpoints hold a collective)
     if a.spinup_ms > 0:
+        one_step()            # (the first launch also allocates the direction buffers)
+        eng.sync()
         t_spin = time.perf_counter()
         one_step()
         eng.sync()
