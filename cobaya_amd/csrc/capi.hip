@@ -1641,6 +1641,7 @@ int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_s
     if (!h) return MCMC_HIP_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));   // (events of the direction kernels)
     resolve_timing(h);
     const size_t d = h->d, G = h->G, np = d * (d + 1) / 2;
     if (n_snapshots) *n_snapshots = h->n_snapshots;
@@ -1830,6 +1831,7 @@ int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launche
     if (!h || !ms) return MCMC_HIP_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(h, hipStreamSynchronize(h->stream2));   // (events of the direction kernels)
     resolve_timing(h);
     for (int i = 0; i < 3; ++i) ms[i] = h->ms[i];
     if (n_step_launches) *n_step_launches = h->n_step_launches;

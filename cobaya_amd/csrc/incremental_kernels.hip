@@ -17,9 +17,10 @@
 // Layout: FOUR lanes serve one walker; lane class c = lane & 3 holds the dimensions i = 4 kk + c
 // of x and y in registers.  The sums over dimensions (chi2, normal-prior terms) are four
 // interleaved chains, one per lane class, combined (p0 + p1) + (p2 + p3) through two DPP quad
-// permutes -- no LDS, no barrier inside a step.  The random variates of four consecutive steps
-// are drawn at once, one step per lane class, and fetched by quad broadcasts.  Per step a lane
-// reads its (v_i, u_i) pairs from LDS, where the columns of the launch are staged in chunks
+// permutes -- no LDS, no barrier inside a step.  The random variates of eight consecutive steps
+// are drawn at once, one pair of steps per lane class, and fetched by quad broadcasts; the
+// prior-support test and the accept decision live in scalar registers as lane masks.  Per step a
+// lane reads its (v_i, u_i) pairs from LDS, where the columns of the launch are staged in chunks
 // (double-buffered, one workgroup barrier per chunk).
 #include <string>
 
