@@ -73,6 +73,8 @@ __device__ __forceinline__ bool quad_all(unsigned long long m)
 typedef double __attribute__((ext_vector_type(2))) pair_t;   // (v_i, u_i): .x, .y
 typedef const pair_t __attribute__((address_space(3))) * lds_pairs;
 typedef const double __attribute__((address_space(3))) * lds_doubles;
+// read-only data at wave-uniform addresses, read through the scalar cache
+typedef const double __attribute__((address_space(4))) * cdoubles;
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
 __device__ __forceinline__ lds_pairs relaunder(const double2* p)
 {
@@ -649,7 +651,10 @@ __global__ void __launch_bounds__(256) whiten_state_kernel(const double* __restr
                                                            int W, int K)
 {
     extern __shared__ __attribute__((aligned(16))) double sdev[];
-    const int l = threadIdx.x & 63, part = threadIdx.x >> 6, w = blockIdx.x * 64 + l;
+    // (part is wave-uniform, and said so: the rows of L^-1 it selects are then read by scalar
+    // loads and enter the FMAs as scalar operands instead of one vector load per lane)
+    const int l = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6),
+              w = blockIdx.x * 64 + l;
     const bool live = w < W;
     const int nblk = (d + 3) / 4;
     for (int k = 0; k < K; ++k) {   // y is [K][d][W]
@@ -703,7 +708,8 @@ __global__ void __launch_bounds__(256) whiten_state_kernel(const double* __restr
 __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sv[];   // [d][64]
-    const int l = threadIdx.x & 63, part = threadIdx.x >> 6;     // 64 columns x 4 row parts
+    // 64 columns x 4 row parts (part is wave-uniform: scalar loads of the rows of L^-1)
+    const int l = threadIdx.x & 63, part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sr = blockIdx.x * 64 + l;          // step of the launch
     const int g = blockIdx.y;
     const int d = a.d;
@@ -732,10 +738,11 @@ __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs
     for (int rb = part; rb < nblk; rb += 4) {
         const int j = 4 * rb;
         if (j + 4 <= d) {
-            const double* __restrict__ r0 = a.Lrow + (size_t)j * d;
-            const double* __restrict__ r1 = r0 + d;
-            const double* __restrict__ r2 = r1 + d;
-            const double* __restrict__ r3 = r2 + d;
+            // (the rows of L^-1 through the constant address space: scalar loads, scalar operands)
+            const cdoubles r0 = (cdoubles)(unsigned long long)(a.Lrow + (size_t)j * d);
+            const cdoubles r1 = r0 + d;
+            const cdoubles r2 = r1 + d;
+            const cdoubles r3 = r2 + d;
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             for (int i = 0; i <= j; ++i) {
                 const double v = sv[i * 64 + l];
@@ -757,7 +764,7 @@ __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs
             out[j + 3] = make_double2(v3, a3);
         } else {
             for (int jj = j; jj < d; ++jj) {
-                const double* __restrict__ row = a.Lrow + (size_t)jj * d;
+                const cdoubles row = (cdoubles)(unsigned long long)(a.Lrow + (size_t)jj * d);
                 double acc = 0.0;
                 for (int i = 0; i <= jj; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
                 out[jj] = make_double2(sv[jj * 64 + l], acc);
