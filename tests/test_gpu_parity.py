@@ -884,7 +884,10 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (27, 256, 128, 1, [list(range(6)), list(range(6, 26)), [26]], [1, 2, 4]),
     (7, 128, 64, 1, [[3], [0], [1, 2, 4, 5, 6]], [1, 1, 3]),
     (40, 128, 64, 1, [[39], list(range(20)), list(range(20, 39))], [1, 1, 2]),
-    (100, 128, 64, 1, [list(range(50)), [99], list(range(50, 99))], [1, 2, 2])])
+    (100, 128, 64, 1, [list(range(50)), [99], list(range(50, 99))], [1, 2, 2]),
+    # every block has one parameter: every step draws the 1-D variates
+    (3, 128, 64, 1, [[2], [0], [1]], [1, 2, 3]),
+    (2, 64, 64, 1, [[1], [0]], [1, 1])])
 def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, over):
     """Parameter blocks with oversampling (proposal.py:96-260) in incremental mode: a cycle has
     L = sum_b oversample_b n_b columns, each with its whitened image; the refresh falls every
@@ -929,7 +932,12 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
     # one-parameter blocks among the slow and among the fast ones
     (8, 256, 64, [[0], [1, 2, 3], [4, 5, 6, 7]], 1, 5, {}),
     (27, 256, 128, [list(range(6)), [26], list(range(6, 26))], 0, 7, {"T": 1.3}),
-    (40, 128, 64, [[7], list(range(7)), [39], list(range(8, 39))], 1, 4, {})])
+    (40, 128, 64, [[7], list(range(7)), [39], list(range(8, 39))], 1, 4, {}),
+    # the fast block is ONE parameter; normal priors and a temperature with 1-D columns
+    (6, 128, 64, [[0, 1, 2, 3, 4], [5]], 0, 3, {}),
+    (9, 128, 64, [[4], [0, 1, 2, 3], [5, 6, 7, 8]], 1, 2,
+     dict(kinds=[0, 1, 0, 1, 1, 0, 0, 1, 0], a=[0, .5, 0, .5, .5, 0, 0, .5, 0],
+          b=[1, .2, 1, .3, .25, 1, 1, .2, 1], T=1.6))])
 def test_incremental_dragging_steps_bit_exact(d, W, gs, blocks, last_slow, n_drag, extra):
     """The dragging step (mcmc.py:564-668) in incremental mode (drag_inc_kernel against the
     oracle's drag_core_inc): every one of its 1 + 2 n evaluations is O(d), the whitened
