@@ -155,6 +155,40 @@ def two_speeds(tmp):
                                             rtol=1e-9, atol=1e-9))}
 
 
+def one_nuisance(tmp):
+    """The shape of a likelihood with ONE nuisance parameter (as plik-lite's A_planck): a slow
+    block of several parameters and a fast block of one.  `evaluation: auto` must still pick
+    the incremental path (one-parameter blocks draw the RandProposer1D variates there too)."""
+    from cobaya.run import run
+    fake_seam()
+    info = {
+        "likelihood": {
+            "slow": {"class": "gaussian_mixture", "means": [[0.2, 0.0, 0.4]],
+                     "covs": [[[0.1, 0.05, 0.0], [0.05, 0.2, 0.02], [0.0, 0.02, 0.05]]],
+                     "input_params_prefix": "a_", "speed": 1},
+            "fast": {"class": "gaussian_mixture", "means": [[1.0]], "covs": [[[0.0025]]],
+                     "input_params_prefix": "cal_", "speed": 30}},
+        "params": {**{f"a_{i}": {"prior": {"min": -3, "max": 3}, "ref": 0.1, "proposal": 0.3}
+                      for i in range(3)},
+                   "cal_0": {"prior": {"dist": "norm", "loc": 1.0, "scale": 0.1}, "ref": 1.0,
+                             "proposal": 0.05}},
+        "sampler": {"mcmc_hip": {"seed": 8, "n_walkers": 256, "group_size": 64,
+                                 "oversample_power": 0.4, "steps_per_launch": "10d",
+                                 "measure_speeds": False, "Rminus1_stop": 0.0,
+                                 "max_samples": 120000, "snapshot_every": 30}}}
+    updated, sampler = run(info)
+    coll = sampler.products(skip_samples=0.3)["sample"]
+    m, c = coll.mean(), coll.cov()
+    tm = np.array([0.2, 0.0, 0.4, 1.0])
+    tc = np.zeros((4, 4))
+    tc[:3, :3] = [[0.1, 0.05, 0.0], [0.05, 0.2, 0.02], [0.0, 0.02, 0.05]]
+    # likelihood N(1, 0.05^2) times prior N(1, 0.1^2) on the calibration parameter
+    tc[3, 3] = 1.0 / (1.0 / 0.0025 + 1.0 / 0.01)
+    return {"blocking": updated["sampler"]["mcmc_hip"]["blocking"],
+            "incremental": bool(sampler.incremental), "kl": kl_norm(tm, tc, m, c),
+            "cycle_length": int(sampler.cycle_length)}
+
+
 def reference_test_mcmc(tmp):
     """The reference's own tests/test_mcmc.py::test_mcmc, with `mcmc` replaced by `mcmc_hip`:
     the SAME input -- `fixed_info` imported from the reference's tests/common_sampler.py, the

@@ -83,6 +83,13 @@ def test_speed_blocking_from_the_live_model(tmp_path):
     assert r["kl"] < 0.03
 
 
+def test_a_one_parameter_fast_block_runs_incrementally(tmp_path):
+    r = scenario("one_nuisance", tmp_path)
+    assert [b for _, b in r["blocking"]] == [["a_0", "a_1", "a_2"], ["cal_0"]]
+    assert r["incremental"] and r["cycle_length"] == 3 + r["blocking"][1][0]
+    assert r["kl"] < 0.03
+
+
 def test_dragging_from_the_live_model(tmp_path):
     r = scenario("two_speeds_drag", tmp_path)
     assert r["drag"] and r["interp"] >= 2 and r["incremental"]
