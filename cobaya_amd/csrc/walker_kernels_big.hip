@@ -822,14 +822,54 @@ __global__ void __launch_bounds__(256) group_moments_big_kernel(const MomentArgs
                 if (l0 + slice >= gs) a.group_sum[(size_t)g * d + i] += s;
             }
         }
-        for (int p = tid; p < npair; p += gs) {
-            int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= p) ++i;
-            while (i * (i + 1) / 2 > p) --i;
-            const int j = p - i * (i + 1) / 2;
-            double s = l0 ? a.Sg[(size_t)g * npair + p] : 0.0;
-            for (int l = 0; l < slice; ++l) s = fma(sX[l * ldx + i], sX[l * ldx + j], s);
-            a.Sg[(size_t)g * npair + p] = s;
+        // pair sums in 4 x 4 register tiles over the lower triangle (tile (I, J), I >= J: the
+        // pairs i = 4I + a, j = 4J + b): a walker costs a tile 8 LDS reads for 16 fmas instead
+        // of 32 -- the kernel is bound by LDS bandwidth.  Every pair is still ONE chain over
+        // the walkers in ascending order.
+        const int nb = (d + 3) / 4, ntile = nb * (nb + 1) / 2;
+        double* __restrict__ Sg = a.Sg + (size_t)g * npair;
+        for (int t = tid; t < ntile; t += gs) {
+            int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while ((I + 1) * (I + 2) / 2 <= t) ++I;
+            while (I * (I + 1) / 2 > t) --I;
+            const int J = t - I * (I + 1) / 2;
+            const int i0 = 4 * I, j0 = 4 * J;
+            double acc[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = i0 + u, j = j0 + v;
+                    acc[u][v] = (l0 && i < d && j <= i) ? Sg[(size_t)i * (i + 1) / 2 + j] : 0.0;
+                }
+            // (columns beyond d: read inside the row -- ldx >= d + 1 only for even d -- and not
+            // stored; clamp the index instead of branching)
+            int iu[4], jv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                iu[u] = i0 + u < d ? i0 + u : d - 1;
+                jv[u] = j0 + u < d ? j0 + u : d - 1;
+            }
+            for (int l = 0; l < slice; ++l) {
+                const double* __restrict__ row = sX + l * ldx;
+                const double xi0 = row[iu[0]], xi1 = row[iu[1]], xi2 = row[iu[2]], xi3 = row[iu[3]];
+                const double xj0 = row[jv[0]], xj1 = row[jv[1]], xj2 = row[jv[2]], xj3 = row[jv[3]];
+                acc[0][0] = fma(xi0, xj0, acc[0][0]); acc[0][1] = fma(xi0, xj1, acc[0][1]);
+                acc[0][2] = fma(xi0, xj2, acc[0][2]); acc[0][3] = fma(xi0, xj3, acc[0][3]);
+                acc[1][0] = fma(xi1, xj0, acc[1][0]); acc[1][1] = fma(xi1, xj1, acc[1][1]);
+                acc[1][2] = fma(xi1, xj2, acc[1][2]); acc[1][3] = fma(xi1, xj3, acc[1][3]);
+                acc[2][0] = fma(xi2, xj0, acc[2][0]); acc[2][1] = fma(xi2, xj1, acc[2][1]);
+                acc[2][2] = fma(xi2, xj2, acc[2][2]); acc[2][3] = fma(xi2, xj3, acc[2][3]);
+                acc[3][0] = fma(xi3, xj0, acc[3][0]); acc[3][1] = fma(xi3, xj1, acc[3][1]);
+                acc[3][2] = fma(xi3, xj2, acc[3][2]); acc[3][3] = fma(xi3, xj3, acc[3][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = i0 + u, j = j0 + v;
+                    if (i < d && j <= i) Sg[(size_t)i * (i + 1) / 2 + j] = acc[u][v];
+                }
         }
     }
 }
