@@ -114,16 +114,21 @@ __host__ __device__ constexpr int inc_chunk(int dq)
 // are read from LDS twice (trial, commit) -- ds_read_b128 costs 4 LDS cycles per wave, far below
 // what the step's VALU work takes.  The columns of the launch reach LDS by global->LDS DMA,
 // one chunk ahead (double-buffered; one s_waitcnt + workgroup barrier per chunk).
-// waves per SIMD the register allocation is held to (from a scan of the allocator's output for
-// every DQ and MODE: the largest occupancy that does not spill)
+// waves per SIMD the register allocation is held to: MEASURED, per DQ and MODE, with builds held to
+// 1, 2, 3 and 4 waves (tools/occupancy_sweep.py over tools/exp_inc_variants.sh builds; 65 536
+// walkers = 4 waves per SIMD at most).  Not "the largest occupancy that does not spill": four
+// waves with a few spilled registers beat three without up to DQ = 12 (d = 40: +40 %), three are
+// almost never the best choice, and above that two waves -- which also get the read-ahead of
+// the LDS pairs (PIPE) -- beat one even where they spill (d = 128, MODE 0: +12 %).  The odd
+// entries (13, 15) are where the per-dimension constants move from registers to LDS.
 __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
 {
 #ifdef MCMC_INC_WAVES_OVERRIDE   // developer switch (timing experiments)
     return MCMC_INC_WAVES_OVERRIDE;
 #endif
-    if (mode == 0) return dq <= 8 ? 4 : dq <= 13 ? 3 : dq <= 25 ? 2 : 1;
-    if (mode == 1) return dq <= 4 ? 4 : dq <= 8 ? 3 : dq <= 25 ? 2 : 1;
-    return dq <= 4 ? 4 : dq <= 7 ? 3 : dq <= 15 ? 2 : 1;
+    if (mode == 0) return dq <= 12 ? 4 : 2;
+    if (mode == 1) return (dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1;
+    return dq <= 5 ? 4 : dq == 6 ? 3 : dq == 13 ? 4 : dq == 15 ? 3 : dq <= 31 ? 2 : 1;
 }
 
 //   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
@@ -139,6 +144,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;
     constexpr bool NORMP = MODE == 2;
     constexpr bool kNormInRegs = NORMP && DQ <= 8;
+    constexpr bool kNormInLds = NORMP && DQ > 8;   // (loc, 1/scale) pairs and mls in LDS
+    __shared__ double2 sNA[kNormInLds ? 4 * DQ : 1];
+    __shared__ double sNM[kNormInLds ? 4 * DQ : 1];
     constexpr int PIPE = MCMC_INC_PIPE_OVERRIDE >= 0 ? MCMC_INC_PIPE_OVERRIDE
                        : (inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
     const StepArgs& s = a.s;
@@ -193,6 +201,11 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     }
     if (kBoundsInLds)
         for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+    if (kNormInLds)
+        for (int i = tid; i < dpad; i += 256) {
+            sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
+            sNM[i] = a.prior[4 * dpad + i];
+        }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
@@ -265,9 +278,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         pc = fma(yt, yt, pc);
                         if (NORMP) {
                             const int i = 4 * kk + c;
-                            const double loc = kNormInRegs ? nloc[kk] : a.prior[2 * dpad + i];
-                            const double inv = kNormInRegs ? ninv[kk] : a.prior[3 * dpad + i];
-                            const double mls = kNormInRegs ? nmls[kk] : a.prior[4 * dpad + i];
+                            const double loc = kNormInRegs ? nloc[kk] : sNA[i].x;
+                            const double inv = kNormInRegs ? ninv[kk] : sNA[i].y;
+                            const double mls = kNormInRegs ? nmls[kk] : sNM[i];
                             const double qq = (t - loc) * inv;
                             sc = sc + fma(-0.5 * qq, qq, mls);
                         }
@@ -374,9 +387,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
             pc = fma(y[kk], y[kk], pc);
             if (NORMP) {
                 const int i = 4 * kk + c;
-                const double loc = kNormInRegs ? nloc[kk] : a.prior[2 * dpad + i];
-                const double inv = kNormInRegs ? ninv[kk] : a.prior[3 * dpad + i];
-                const double mls = kNormInRegs ? nmls[kk] : a.prior[4 * dpad + i];
+                const double loc = kNormInRegs ? nloc[kk] : sNA[i].x;
+                const double inv = kNormInRegs ? ninv[kk] : sNA[i].y;
+                const double mls = kNormInRegs ? nmls[kk] : sNM[i];
                 const double qq = (x[kk] - loc) * inv;
                 sc = sc + fma(-0.5 * qq, qq, mls);
             }
@@ -418,6 +431,8 @@ drag_inc_kernel(const IncStepArgs a)
     constexpr bool NORMP = MODE == 2;
     constexpr int dpad = 4 * DQ;
     __shared__ double2 sLH[kBoundsInLds ? 4 * DQ : 1];   // (lo, hi) per dimension
+    __shared__ double2 sNA[NORMP ? 4 * DQ : 1];          // normal priors: (loc, 1/scale)
+    __shared__ double sNM[NORMP ? 4 * DQ : 1];           //                -log(scale sqrt(2 pi))
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d, nd = a.n_drag, cps = 1 + nd;
@@ -460,6 +475,11 @@ drag_inc_kernel(const IncStepArgs a)
     }
     if (kBoundsInLds)   // (read after the barrier that precedes the step loop)
         for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+    if (NORMP)
+        for (int i = tid; i < dpad; i += 256) {
+            sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
+            sNM[i] = a.prior[4 * dpad + i];
+        }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     long long nacc = s.n_accept[w];
@@ -490,8 +510,9 @@ drag_inc_kernel(const IncStepArgs a)
     auto prior_term = [&](double t, int kk, double sc) -> double {
         if (!NORMP) return sc;
         const int i = 4 * kk + c;
-        const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
-        return sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
+        const double2 li = sNA[i];
+        const double qq = (t - li.x) * li.y;
+        return sc + fma(-0.5 * qq, qq, sNM[i]);
     };
     auto metropolis = [&](double trial, double current, double Ea) -> unsigned long long {
         const double delta = UNIT_T ? (current - trial) : (current - trial) / s.temperature;
@@ -860,7 +881,13 @@ step_inc_mix_kernel(const IncStepArgs a)
     stage(0);
     // (the bounds sit in LDS as (lo, hi) pairs: registers are for x and the KM residuals)
     __shared__ double2 sLH[4 * DQ];
-    for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+    __shared__ double2 sNA[4 * DQ];     // normal priors: (loc, 1/scale) and -log(scale sqrt(2 pi))
+    __shared__ double sNM[4 * DQ];
+    for (int i = tid; i < dpad; i += 256) {
+        sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+        sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
+        sNM[i] = a.prior[4 * dpad + i];
+    }
     double x[DQ], y[KM][DQ];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
@@ -924,8 +951,9 @@ step_inc_mix_kernel(const IncStepArgs a)
                     inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
                     if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
                         const int i = 4 * kk + c;
-                        const double qq = (t - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
-                        sc = sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
+                        const double2 li = sNA[i];
+                        const double qq = (t - li.x) * li.y;
+                        sc = sc + fma(-0.5 * qq, qq, sNM[i]);
                     }
                 }
                 double ak[KM], amax = -INFINITY;

@@ -7,10 +7,11 @@ set -e
 cd "$(dirname "$0")/.."
 CS=cobaya_amd/csrc; mkdir -p $CS/_exp
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -pragma-unroll-threshold=1000000"
-OBJS=$(ls $CS/_obj/*.o | grep -v incremental_1.o)
+LO=${DQ_LO:-1}; HI=${DQ_HI:-8}     # the translation unit to rebuild: incremental_<LO>.o
+OBJS=$(ls $CS/_obj/*.o | grep -v incremental_$LO.o)
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
-  ( hipcc $FL $flags -DMCMC_DQ_LO=1 -DMCMC_DQ_HI=8 -c $CS/incremental_kernels.hip -o $CS/_exp/inc_$name.o 2>/dev/null &&
+  ( hipcc $FL $flags -DMCMC_DQ_LO=$LO -DMCMC_DQ_HI=$HI -c $CS/incremental_kernels.hip -o $CS/_exp/inc_$name.o 2>/dev/null &&
     hipcc -shared -fPIC --offload-arch=gfx950 $CS/_exp/inc_$name.o $OBJS -o $CS/_exp/lib_$name.so &&
     echo "built $name" ) &
 done
