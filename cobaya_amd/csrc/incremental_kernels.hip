@@ -419,9 +419,19 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 // steps -- and 1 + 2 n_drag evaluations, every one of them O(d): the start and the end point
 // carry their whitened residuals (ys, ye), a move by r v moves them by fma(r, u, .).  The variates
 // (r_i, E_i) of the sub-steps i = 0 .. n_drag are drawn four at a time, one per lane class.
+__host__ __device__ constexpr int inc_drag_min_waves(int dq, int mode)
+{
+#ifdef MCMC_INC_DRAG_WAVES_OVERRIDE   // developer switch (timing experiments)
+    return MCMC_INC_DRAG_WAVES_OVERRIDE;
+#endif
+    // (measured like inc_min_waves, tools/drag_bench.py over builds held to 1..4 waves: two waves
+    // with some spilled registers beat one up to d = 68 -- d = 44: 3.3e10 against 1.9e10 --, one
+    // wave wins from d = 80 on)
+    return mode == 0 ? (dq <= 3 ? 4 : dq <= 5 ? 3 : dq <= 17 ? 2 : 1) : (dq <= 3 ? 3 : dq <= 17 ? 2 : 1);
+}
+
 template <int DQ, int MODE, bool UNIT_T, bool ONED>
-__global__ void __launch_bounds__(256, (MODE == 0 ? (DQ <= 5 ? 3 : DQ <= 10 ? 2 : 1)
-                                                  : (DQ <= 3 ? 3 : DQ <= 8 ? 2 : 1)))
+__global__ void __launch_bounds__(256, inc_drag_min_waves(DQ, MODE))
 drag_inc_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem2[];

@@ -47,6 +47,11 @@ def run(d, n_slow, n_drag, inc, normal, W=65536, gs=256, launches=4):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # d n_slow n_drag normal [d n_slow n_drag normal ...]: incremental only
+        v = [int(x) for x in sys.argv[1:]]
+        for k in range(0, len(v), 4):
+            run(v[k], v[k + 1], v[k + 2], True, bool(v[k + 3]))
+        sys.exit(0)
     for inc in (False, True):
         run(27, 6, 7, inc, True)
     run(30, 10, 4, False, False)
