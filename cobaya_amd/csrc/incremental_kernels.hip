@@ -855,7 +855,9 @@ __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
 #ifdef MCMC_INC_MIX_WAVES_OVERRIDE   // developer switch (timing experiments)
     return MCMC_INC_MIX_WAVES_OVERRIDE;
 #endif
-    return dq * (km + 1) <= 18 ? 3 : dq * (km + 1) <= 40 ? 2 : 1;
+    // (measured like inc_min_waves, tools/mix_bench.py d:K over builds held to 1..4 waves; the
+    // state is dq (km + 1) doubles per lane)
+    return dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3 : dq * (km + 1) <= 50 ? 2 : 1;
 }
 
 template <int DQ, int KM, bool UNIT_T>

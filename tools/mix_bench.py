@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the incremental step kernel on a K-mode mixture at d = 30 (engine level):
-tools/mix_bench.py [K ...]"""
+tools/mix_bench.py [K ...]   or   tools/mix_bench.py d:K [d:K ...]  (incremental only)"""
 import os
 import sys
 
@@ -13,7 +13,15 @@ from cobaya_amd.engine import Engine  # noqa: E402  (MCMC_HIP_LIB selects an exp
 
 def run(K, inc, d=30, W=65536, gs=256, launches=4):
     g = np.load(os.path.join(ROOT, "tests", "golden", "targets.npz"))
-    mean, cov = g["mean_d30"], g["cov_d30"]
+    if d == 30:
+        mean, cov = g["mean_d30"], g["cov_d30"]
+    else:
+        r0 = np.random.default_rng(d)
+        A = r0.normal(size=(d, d))
+        sd = 10 ** r0.uniform(-2, np.log10(0.05), size=d)
+        c = A @ A.T / d + np.eye(d)
+        cov = c / np.sqrt(np.outer(np.diag(c), np.diag(c))) * np.outer(sd, sd)
+        mean = np.full(d, 0.5)
     rng = np.random.default_rng(11)
     means = [mean] + [np.clip(mean + rng.normal(size=d) * np.sqrt(np.diag(cov)), 0.05, 0.95)
                       for _ in range(K - 1)]
@@ -24,7 +32,7 @@ def run(K, inc, d=30, W=65536, gs=256, launches=4):
     eng.set_proposal_cov(cov)
     x0 = np.clip(mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov)), 1e-6, 1 - 1e-6)
     eng.set_state(x0)
-    spl = 1200
+    spl = 40 * d
     eng.step(spl)
     eng.sync()
     eng.enable_timing(True)
@@ -41,6 +49,11 @@ def run(K, inc, d=30, W=65536, gs=256, launches=4):
 
 
 if __name__ == "__main__":
-    for K in [int(a) for a in sys.argv[1:]] or [2, 4]:
-        for inc in (False, True):
-            run(K, inc)
+    args = sys.argv[1:] or ["2", "4"]
+    for a in args:
+        if ":" in a:      # d:K -- incremental only (occupancy sweeps)
+            d, K = (int(v) for v in a.split(":"))
+            run(K, True, d=d, launches=2)
+        else:
+            for inc in (False, True):
+                run(int(a), inc)
