@@ -703,13 +703,14 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     acc(hipHostMalloc((void**)&h->pin_T, sizeof(double) * 4 * d * d, hipHostMallocDefault));
     acc(hipEventCreateWithFlags(&h->mom_event, hipEventDisableTiming));
     if (h->incremental) {
-        // (highest priority: when a step kernel and the next launch's directions become
-        // runnable together, the small direction kernels are placed first and the step
-        // kernel's workgroups fill the chip around them -- the other way round they would
-        // wait for the step kernel's last workgroup)
+        // (LOWEST priority: the step kernel's 1024 workgroups are exactly what the chip holds
+        // at once, four per compute unit; a direction kernel that took some of those places
+        // first would push the displaced step workgroups into a second round -- 1.74 ms
+        // instead of 1.22, measured with the order of the two reversed.  The direction kernels
+        // are meant to fill the places that free up in the step kernel's ragged tail.)
         int prio_least = 0, prio_greatest = 0;
         acc(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        acc(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_greatest));
+        acc(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_least));
         acc(hipEventCreateWithFlags(&h->mark, hipEventDisableTiming));
         for (auto& D : h->dirs) acc(hipEventCreateWithFlags(&D.ready, hipEventDisableTiming));
         // MCMC_HIP_NO_PREFETCH (developer switch): directions on the main stream, in line
