@@ -31,6 +31,19 @@
 #define MCMC_INC_PIPE_OVERRIDE (-1)    // developer switch: pairs fetched ahead in the trial loop
 #endif
 
+#ifdef MCMC_INC_BLOCK_TIMES   // developer instrumentation: start / end clock of every workgroup
+__device__ unsigned long long g_block_times[2 * 4096];
+__device__ unsigned int g_wave_place[2 * 4 * 4096];   // per wave: HW_ID, XCC_ID
+extern "C" int mcmc_hip_debug_block_times(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_times), sizeof(g_block_times));
+}
+extern "C" int mcmc_hip_debug_wave_place(unsigned int* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_place), sizeof(g_wave_place));
+}
+#endif
+
 namespace mcmc {
 namespace {
 
@@ -52,6 +65,32 @@ __device__ __forceinline__ double quad_sum(double p)
 
 // (lanes(cond) -- the wave's lane mask of a condition -- and the mask-taking selects sel(m, a, b)
 // are in det_math.h)
+// The issue arbiter of a SIMD serves its resident waves by priority, then by AGE.  Left alone, the
+// oldest of the waves that share a SIMD for a whole launch finishes first and the youngest
+// runs the last part of it alone, with nothing to cover its latencies (step kernel at d = 30:
+// the workgroups of one launch end between 0.68 and 1.20 ms, tools/block_times.py).  The
+// kernels therefore rotate their priority every few steps over the hardware wave slots -- the
+// waves of a SIMD hold distinct slots -- so that they advance together: 1.22 -> 1.07 ms.
+__device__ __forceinline__ int hw_wave_slot()
+{
+    return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
+}
+template <int NW>   // NW: the waves that share a SIMD (the kernel's occupancy)
+__device__ __forceinline__ void rotate_priority(int slot, int turn)
+{
+#ifndef MCMC_INC_NO_ROTATE_PRIO   // developer switch (timing experiments)
+    // (a rotation over NW levels: over four levels two waves would not get equal turns; kernels
+    // held to three waves are left alone -- measured: rotating them loses 2-8 %)
+    if (NW != 2 && NW != 4) return;
+    switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
+}
+
 // lane mask -> the mask of the lanes whose quad is held completely
 __device__ __forceinline__ unsigned long long quad_all_mask(unsigned long long m)
 {
@@ -176,6 +215,13 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         }
     };
     stage(0);
+#ifdef MCMC_INC_BLOCK_TIMES
+    if (tid == 0 && blockIdx.x < 4096) g_block_times[2 * blockIdx.x] = wall_clock64();
+    if (lane == 0 && blockIdx.x < 4096) {
+        g_wave_place[2 * (4 * blockIdx.x + wave)] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        g_wave_place[2 * (4 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+    }
+#endif
 
     const double blo = a.box_lo, bhi = a.box_hi;
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
@@ -224,6 +270,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     unsigned long long cur_oct = ~0ull;
     PairRng pr;
     pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+    const int hw_slot = hw_wave_slot();
 
     for (int base = 0, k = 0; base < ncols; base += C, ++k) {
         const double2* __restrict__ cur = sVU + (k & 1) * CHUNK;
@@ -245,6 +292,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                     if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
                         cur_oct = S >> 3;
+                        rotate_priority<inc_min_waves(DQ, MODE)>(hw_slot, (int)cur_oct);
                         pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                     }
                     double r, Ea;
@@ -411,6 +459,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         s.n_accept[w] = nacc0 + nacc;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
+#ifdef MCMC_INC_BLOCK_TIMES
+    if (tid == 0 && blockIdx.x < 4096) g_block_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------- the dragging step
@@ -499,6 +550,7 @@ drag_inc_kernel(const IncStepArgs a)
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
     const double navg = (double)cps;
+    const int hw_slot = hw_wave_slot();
 
     // log-posterior of the point t (already formed) with residual yt: lp, ll, lt (-inf outside)
     // (every select below takes its condition as a lane mask and is a VOP3 v_cndmask: sel(),
@@ -539,6 +591,7 @@ drag_inc_kernel(const IncStepArgs a)
 #pragma unroll 1
         for (int sl = 0; sl < nhere; ++sl) {
             const unsigned long long step = s.step0 + (unsigned long long)(base + sl);
+            rotate_priority<inc_drag_min_waves(DQ, MODE)>(hw_slot, (int)step);
             const double2* __restrict__ col0 = cur + (size_t)sl * cps * COLB + c;
             double cs_lt = lpost, ce_lt = -INFINITY, ce_lp = 0.0, ce_ll = 0.0;
             double start_acc = 0.0, end_acc = 0.0, Ea0 = 0.0;
@@ -925,6 +978,7 @@ step_inc_mix_kernel(const IncStepArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long class1 = lanes(c == 1), class2 = lanes(c == 2), class3 = lanes(c == 3);
+    const int hw_slot = hw_wave_slot();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
     PairRng pr;
@@ -940,6 +994,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                 const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                 if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                     cur_oct = S >> 3;
+                    rotate_priority<inc_mix_min_waves(DQ, KM)>(hw_slot, (int)cur_oct);
                     pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                 }
                 double r, Ea;
