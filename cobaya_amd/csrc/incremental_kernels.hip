@@ -69,19 +69,26 @@ __device__ __forceinline__ double quad_sum(double p)
 // oldest of the waves that share a SIMD for a whole launch finishes first and the youngest
 // runs the last part of it alone, with nothing to cover its latencies (step kernel at d = 30:
 // the workgroups of one launch end between 0.68 and 1.20 ms, tools/block_times.py).  The
-// kernels therefore rotate their priority every few steps over the hardware wave slots -- the
-// waves of a SIMD hold distinct slots -- so that they advance together: 1.22 -> 1.07 ms.
+// kernels therefore rotate their priority over the hardware wave slots -- the waves of a SIMD
+// hold distinct slots -- so that they advance together: 1.22 -> 1.04 ms.  The turn is taken
+// from the shader clock (a new level every 2^17 cycles, about 60 us), not from the wave's own
+// progress: the waves of a SIMD then hold distinct levels at every moment however far apart
+// they have drifted (with turns counted in steps the two oldest slots still finished 13 % early).
 __device__ __forceinline__ int hw_wave_slot()
 {
     return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
 }
+#ifndef MCMC_INC_ROTATE_CLOCK_SHIFT
+#define MCMC_INC_ROTATE_CLOCK_SHIFT 17
+#endif
 template <int NW>   // NW: the waves that share a SIMD (the kernel's occupancy)
-__device__ __forceinline__ void rotate_priority(int slot, int turn)
+__device__ __forceinline__ void rotate_priority(int slot)
 {
 #ifndef MCMC_INC_NO_ROTATE_PRIO   // developer switch (timing experiments)
     // (a rotation over NW levels: over four levels two waves would not get equal turns; kernels
     // held to three waves are left alone -- measured: rotating them loses 2-8 %)
     if (NW != 2 && NW != 4) return;
+    const int turn = (int)(__builtin_amdgcn_s_memtime() >> MCMC_INC_ROTATE_CLOCK_SHIFT);
     switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -292,7 +299,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                     if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
                         cur_oct = S >> 3;
-                        rotate_priority<inc_min_waves(DQ, MODE)>(hw_slot, (int)cur_oct);
+                        rotate_priority<inc_min_waves(DQ, MODE)>(hw_slot);
                         pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                     }
                     double r, Ea;
@@ -591,7 +598,7 @@ drag_inc_kernel(const IncStepArgs a)
 #pragma unroll 1
         for (int sl = 0; sl < nhere; ++sl) {
             const unsigned long long step = s.step0 + (unsigned long long)(base + sl);
-            rotate_priority<inc_drag_min_waves(DQ, MODE)>(hw_slot, (int)step);
+            rotate_priority<inc_drag_min_waves(DQ, MODE)>(hw_slot);
             const double2* __restrict__ col0 = cur + (size_t)sl * cps * COLB + c;
             double cs_lt = lpost, ce_lt = -INFINITY, ce_lp = 0.0, ce_ll = 0.0;
             double start_acc = 0.0, end_acc = 0.0, Ea0 = 0.0;
@@ -994,7 +1001,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                 const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                 if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                     cur_oct = S >> 3;
-                    rotate_priority<inc_mix_min_waves(DQ, KM)>(hw_slot, (int)cur_oct);
+                    rotate_priority<inc_mix_min_waves(DQ, KM)>(hw_slot);
                     pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                 }
                 double r, Ea;

@@ -48,6 +48,16 @@ print("distinct SIMDs per block histogram:", sorted(Counter(same).items()))
 nb = np.array([blocks_per_cu[c] for c in cuid[:, 0]])
 for k in sorted(set(nb.tolist())):
     print("blocks on a CU holding %d blocks: n %d  dur mean %.1f min %.1f max %.1f" % (k, (nb == k).sum(), dur[nb == k].mean(), dur[nb == k].min(), dur[nb == k].max()))
+slot0 = hw[:, 0] & 0xF
+for sl in sorted(set(slot0.tolist())):
+    m = slot0 == sl
+    print("wave slot %d: n %d  dur mean %.1f  min %.1f  max %.1f" % (sl, m.sum(), dur[m].mean(), dur[m].min(), dur[m].max()))
+percu = {}
+for b in range(1024):
+    percu.setdefault(int(cuid[b, 0]), []).append(dur[b])
+spread = np.array([max(v) - min(v) for v in percu.values()])
+cumax = np.array([max(v) for v in percu.values()])
+print("per CU: spread of its 4 workgroups mean %.1f max %.1f; last-finisher mean %.1f min %.1f max %.1f" % (spread.mean(), spread.max(), cumax.mean(), cumax.min(), cumax.max()))
 # by XCD guess: block index mod 8
 for x in range(8):
     sel = np.arange(1024) % 8 == x
