@@ -326,7 +326,7 @@ struct mcmc_hip_ctx {
     int dir_cur = 0;
     unsigned long long dir_epoch = 0;
     hipStream_t stream2 = nullptr;
-    hipEvent_t mark = nullptr;               // main stream: "the step kernel is next"
+    hipEvent_t mark = nullptr;               // main stream: behind the last step kernel
     bool prefetch = true;
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
     // stream-ordered proposal refresh: pinned host staging
@@ -1328,20 +1328,6 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             const int rc = make_directions(h, P, seg, D, h->stream);
             if (rc != MCMC_HIP_OK) return rc;
         }
-        if (h->prefetch) {
-            // the launch expected next: the rest of this call, or a call like this one.  Its
-            // directions start once the main stream has reached this point (the proposal
-            // transform and the other set's last reader are behind it) and run beside the step
-            // kernel.
-            auto& N = h->dirs[h->dir_cur ^ 1];
-            const IncSeg nxt = plan_segment(P, h->step + (unsigned long long)n,
-                                            left > n ? left - n : n_steps);
-            HIP_TRY(h, hipEventRecord(h->mark, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
-            const int rc = make_directions(h, P, nxt, N, h->stream2);
-            if (rc != MCMC_HIP_OK) return rc;
-            N.ahead = true;
-        }
         {
             Timed t(h, 0);
             mcmc::IncStepArgs a{};
@@ -1376,6 +1362,24 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                 h->last_step_kernel = std::string(g_noted_kernel) + " (d=" + std::to_string(d) + ")";
                 g_noted_kernel = nullptr;
             }
+        }
+        if (h->prefetch) {
+            // the launch expected next: the rest of this call, or a call like this one.  Its
+            // directions are computed on the second stream BEHIND this step kernel (the event
+            // is recorded after it), beside the moment snapshot and the refresh of y that the
+            // main stream runs between two step kernels.  Never beside the step kernel: its
+            // 1024 workgroups are exactly what the chip holds at once, and a direction kernel
+            // that takes a few of those places first -- it happened once in a hundred launches
+            // when both became runnable together -- costs the displaced workgroups a second
+            // round (1.78 ms instead of 1.04).
+            auto& N = h->dirs[h->dir_cur ^ 1];
+            const IncSeg nxt = plan_segment(P, h->step + (unsigned long long)n,
+                                            left > n ? left - n : n_steps);
+            HIP_TRY(h, hipEventRecord(h->mark, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
+            const int rc = make_directions(h, P, nxt, N, h->stream2);
+            if (rc != MCMC_HIP_OK) return rc;
+            N.ahead = true;
         }
         h->dir_cur ^= 1;
         h->step += (unsigned long long)n;

@@ -41,10 +41,10 @@ def main():
     tot = sum(r[2] for r in rows)
     with open(os.path.join(DST, f"{rnd}_kernel_stats.txt"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- {CMD}   (MI355X)\n")
-        if bench["roofline"].get("basis_overlapped_with_step_kernel"):
-            f.write("# (basis_* and whiten_directions_kernel run on a second stream BESIDE the step "
-                    "kernel: their durations are stretched by sharing the chip and overlap it -- "
-                    "pct is of the sum of durations, not of wall time)\n")
+        if bench["roofline"].get("basis_on_second_stream"):
+            f.write("# (basis_* and whiten_directions_kernel run on a second stream, beside the "
+                    "moment snapshot and the y refresh of the main stream: pct is of the sum of "
+                    "durations, not of wall time)\n")
         f.write("# name, calls, total_us, avg_us, pct\n")
         for n, k, t, a in rows:
             f.write(f"{n}, {k}, {t:.3f}, {a:.3f}, {100 * t / tot:.3f}\n")
