@@ -75,8 +75,8 @@ HIP_DEFAULTS = {
     "max_rows": 1 << 21,      # cap on stored rows per process
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
                               # power of two; incremental evaluation only).  Default: 1024
-                              # from 16384 walkers per process up (4096 above d = 64 from
-                              # 65536 walkers up), else group_size.  The R-1
+                              # from 16384 walkers per process up, 4096 from 65536 walkers
+                              # up, else group_size.  The R-1
                               # "chains" stay the groups of group_size walkers.
     "evaluation": "auto",     # "full": every trial is evaluated from scratch (O(d^2));
                               # "incremental": the whitened residual L^-1 (x - mu) is carried
@@ -252,9 +252,10 @@ class EnsembleMCMC:
             self.basis_group_size = int(self.group_size)
             if self.incremental and W >= 16384 and W % 1024 == 0 and 1024 % int(self.group_size) == 0:
                 self.basis_group_size = 1024
-                # above d = 64 the Haar bases and the whitened columns of a launch cost a tenth
-                # of the step kernel: a basis per 4096 walkers there
-                if d > 64 and W >= 65536 and W % 4096 == 0:
+                # at the benchmark size the Haar bases and the whitened columns of a launch
+                # are 6 % of the step kernel with a basis per 1024 walkers (a tenth above
+                # d = 64): a basis per 4096 walkers there
+                if W >= 65536 and W % 4096 == 0:
                     self.basis_group_size = 4096
         if int(self.basis_group_size) != int(self.group_size) and not self.incremental:
             self._fail("basis_group_size (%s) differs from group_size (%s): this needs "

@@ -62,6 +62,9 @@ def main():
             lines.append(f"{p}, {n}, {v:.6g}, {k}, {dur:.0f}")
             vals[n] = v
     wl = bench["config"]
+    if not lines:   # a kernel-trace-only run: the counters of the last PMC run stay
+        print(open(os.path.join(DST, f"{rnd}_kernel_stats.txt")).read())
+        return
     with open(os.path.join(DST, f"{rnd}_pmc.txt"), "w") as f:
         f.write(f"# rocprofv3 --pmc <counters> (one pass per line group) -- {CMD}\n")
         f.write(f"# per-dispatch averages for {bench['roofline']['kernel']}, "
