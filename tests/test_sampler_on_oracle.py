@@ -171,3 +171,29 @@ def test_own_basis_option_and_incremental_option_reach_the_engine():
                   "shared_basis": False}, spec)
     with pytest.raises(LoggedError, match="evaluation must be"):
         OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "sometimes"}, spec)
+
+
+@pytest.mark.parametrize("walkers, expect", [(4096, 256), (16384, 1024), (65536, 4096),
+                                             (65536 + 1024, 1024)])
+def test_default_width_of_the_basis_groups(walkers, expect):
+    """`basis_group_size` left at its default: the R-1 group below 16384 walkers per process,
+    1024 walkers from there, 4096 from 65536 walkers up (when they divide the ensemble) -- and
+    only with incremental evaluation, the from-scratch kernels keep a basis per R-1 group."""
+    from cobaya_amd.engine import EngineError
+    seen = {}
+
+    class Recorder:
+        def __init__(self, d, W, **kw):
+            seen.update(kw, W=W)
+            raise EngineError(-1, "recorded")
+
+    class Rec(MCMCHip):
+        _engine_factory = staticmethod(Recorder)
+
+    for evaluation, want in (("auto", expect), ("full", 256)):
+        seen.clear()
+        with pytest.raises(LoggedError, match="recorded"):
+            Rec({"seed": 1, "n_walkers": walkers, "group_size": 256, "evaluation": evaluation},
+                ProblemSpec.from_info(QUICK), output=None)
+        assert seen["W"] == walkers and seen["basis_group_size"] == want
+        assert seen["incremental"] == (evaluation == "auto")
