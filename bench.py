@@ -251,6 +251,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
            "evaluation": "incremental" if sampler.incremental else "full",
            "group_size": int(sampler.group_size),
            "basis_group_size": int(sampler.basis_group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
+           "checkpoint_lag": int(sampler.checkpoint_lag),
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
     sampler.close()
     return res
@@ -377,6 +378,7 @@ def main():
                 "metropolis_steps_per_launch": spl,
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": m["n_ckpt"],
+                "checkpoint_lag_launches": m["checkpoint_lag"],
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
             "collective": collective,

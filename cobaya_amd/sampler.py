@@ -84,6 +84,11 @@ HIP_DEFAULTS = {
                               # posterior; one Gaussian mode or a mixture of <= 4 at d <= 64,
                               # non-periodic priors, parameter blocks / oversampling /
                               # dragging, snapshots); "auto": incremental where it applies
+    "checkpoint_lag": None,   # launches between the request of a learn / convergence checkpoint
+                              # and its processing on the host (the refreshed proposal takes
+                              # effect with the launch queued after that).  Default: 1 for a
+                              # single process, 2 when the checkpoint holds a collective -- see
+                              # `advance`
     "shared_basis": True,     # True: the walkers of a group share one Haar basis per cycle;
                               # False: every walker draws its own (proposal.py:59-69 to the
                               # letter: the reference-faithful control, much slower)
@@ -197,6 +202,11 @@ class EnsembleMCMC:
             self._fail("emit must be 'snapshots' or 'chains', got %r", self.emit)
         dist.init_from_env()
         self.rank, self.size = dist.rank(), dist.size()
+        if self.checkpoint_lag is None:
+            self.checkpoint_lag = 1 if self.size == 1 else 2
+        if int(self.checkpoint_lag) != self.checkpoint_lag or int(self.checkpoint_lag) < 1:
+            self._fail("checkpoint_lag must be an integer >= 1, got %r", self.checkpoint_lag)
+        self._ckpt_lag = int(self.checkpoint_lag)
         # seed: one key for the whole job; walkers are keyed by their global id
         if self.seed is None:
             seed = np.array([float(int.from_bytes(os.urandom(4), "little"))])
@@ -415,6 +425,7 @@ class EnsembleMCMC:
         self._since_snapshot = 0
         self._next_ckpt = None   # steps per walker at which the next learn checkpoint is due
         self._ckpt_pending = False  # moments requested, checkpoint not processed yet
+        self._ckpt_age = 0       # launches queued since the request
 
     # ------------------------------------------------------------------ a17
     def initial_proposal_covmat(self):
@@ -540,7 +551,16 @@ class EnsembleMCMC:
         the launch (`request_moments`); the next launch is queued right after it, and while
         that one runs the host fetches the statistics, all-reduces them, forms R-1 and uploads
         the refreshed proposal in stream order.  The new proposal therefore takes effect one
-        launch after the checkpoint (deterministically, also across a resume)."""
+        launch after the checkpoint (deterministically, also across a resume).
+
+        With several processes the checkpoint holds a collective, and the step kernel leaves
+        no room on the device beside it (its workgroups are exactly what the chip
+        holds): the RCCL kernel only runs when the first workgroups of the launch in flight
+        retire, i.e. the host gets the reduced statistics at the END of that launch and would
+        queue the next one late.  `checkpoint_lag: 2` (the default for more than one process)
+        therefore processes a checkpoint one launch later: a launch is always queued behind
+        the one whose tail the collective waits for, and the new proposal takes effect two
+        launches after the checkpoint -- as deterministically as before."""
         eng, spl = self.engine, self.steps_per_launch
         eng.step(spl)
         self.n_steps_raw += spl
@@ -554,7 +574,9 @@ class EnsembleMCMC:
         elif snap_every and self._since_snapshot >= snap_every:
             self._snapshot()
         if self._ckpt_pending:
-            self._finish_checkpoint()
+            self._ckpt_age += 1
+            if self._ckpt_age >= self._ckpt_lag:
+                self._finish_checkpoint()
         self._request_checkpoint_if_due()
 
     def _request_checkpoint_if_due(self):
@@ -563,6 +585,7 @@ class EnsembleMCMC:
         if hasattr(self.engine, "request_moments"):
             self.engine.request_moments()
         self._ckpt_pending = True
+        self._ckpt_age = 0
         self._next_ckpt = self.n_steps_raw + self._checkpoint_steps()
 
     def _finish_checkpoint(self):

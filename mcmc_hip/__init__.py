@@ -49,6 +49,7 @@ else:
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]
         evaluation: str = HIP_DEFAULTS["evaluation"]
         basis_group_size: int | None = HIP_DEFAULTS["basis_group_size"]
+        checkpoint_lag: int | None = HIP_DEFAULTS["checkpoint_lag"]
 
         def _export_collection(self, coll):
             """Our table -> `cobaya.collection.SampleCollection` (same columns,

@@ -1,0 +1,63 @@
+"""Worker of tests/test_distributed_gloo.py::test_run_loop_world_size_2: one rank of a
+world_size-2 `gloo` group running the WHOLE sampler loop (`MCMCHip.run`: fused launches,
+moment snapshots, the checkpoint with its all-reduce processed `checkpoint_lag` launches
+after its request, proposal refresh) with the ctypes seam served by the oracle-backed double
+(tests/oracle_engine.py), every rank owning its shard of the walkers."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from cobaya_amd import dist  # noqa: E402
+from cobaya_amd.model import ProblemSpec  # noqa: E402
+from cobaya_amd.sampler import MCMCHip  # noqa: E402
+from tests.oracle_engine import OracleEngine  # noqa: E402
+from tests.test_host_logic import QUICK  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist.init_from_env(backend="gloo")
+    log = []
+
+    class Spy(OracleEngine):
+        launches = 0
+
+        def step(self, n):
+            self.launches += 1
+            return super().step(n)
+
+        def request_moments(self):
+            log.append(["request", self.launches])
+            return super().request_moments()
+
+        def set_proposal_cov(self, cov):
+            log.append(["refresh", self.launches])
+            return super().set_proposal_cov(cov)
+
+    class S(MCMCHip):
+        _engine_factory = staticmethod(Spy)
+
+    s = S({"seed": 5, "n_walkers": 128, "group_size": 64, "steps_per_launch": 40,
+           "max_samples": 60000, "Rminus1_stop": 0.0, "learn_every": "40d"},
+          ProblemSpec.from_info(QUICK), output=os.path.join(out_dir, "run"))
+    s.run()
+    st = s.engine.get_full_state()
+    prog = s.progress
+    res = {"rank": dist.rank(), "size": dist.size(), "lag": s._ckpt_lag, "log": log,
+           "walker_offset": int(s.engine.walker_offset),
+           "Rminus1": [float(v) for v in prog["Rminus1"]],
+           "N": [int(v) for v in prog["N"]],
+           "acc": [float(v) for v in prog["acceptance_rate"]],
+           "cov": np.asarray(s.engine.get_proposal_cov()).tolist(),
+           "xsum": float(np.sum(st["x"])), "steps": int(s.n_steps_raw)}
+    with open(os.path.join(out_dir, f"run_rank{dist.rank()}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

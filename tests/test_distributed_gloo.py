@@ -52,3 +52,35 @@ def test_checkpoint_allreduce_world_size_2(tmp_path):
         np.testing.assert_allclose(r["buf"], np.arange(6).reshape(2, 3) * 3.0)
     assert res[0]["Rminus1"] == res[1]["Rminus1"] and res[0]["new_cov"] == res[1]["new_cov"]
     assert res[1]["gathered"] is None and len(res[0]["gathered"]) == 2
+
+
+def test_run_loop_world_size_2(tmp_path):
+    """The whole `run()` loop on two ranks (oracle-backed engine double, each rank its shard
+    of the walkers): the checkpoints are processed two launches after their request (the
+    multi-process default, sampler.advance), every rank sees the same R-1, acceptance rate
+    and learned covariance at every checkpoint, and the ranks really hold different walkers."""
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_run_worker.py"),
+                                       str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out.decode()[-3000:]
+    a, b = (json.load(open(tmp_path / f"run_rank{r}.json")) for r in range(2))
+    assert a["size"] == b["size"] == 2 and a["lag"] == b["lag"] == 2
+    assert (a["walker_offset"], b["walker_offset"]) == (0, 128)
+    assert len(a["Rminus1"]) >= 3 and a["steps"] == b["steps"]
+    for k in ("Rminus1", "N", "acc", "cov"):
+        assert a[k] == b[k], k                 # one all-reduce: bit-identical on every rank
+    assert a["xsum"] != b["xsum"]
+    for r in (a, b):
+        req = [n for what, n in r["log"] if what == "request"]
+        ref = [n for what, n in r["log"] if what == "refresh"][1:]
+        assert len(ref) >= 3 and all(y - x == 2 for x, y in zip(req, ref)), r["log"]
+    for ext in (".checkpoint", ".covmat", ".progress", ".1.txt", ".2.txt", ".1.state.npz",
+                ".2.state.npz"):
+        assert os.path.exists(str(tmp_path / "run") + ext), ext

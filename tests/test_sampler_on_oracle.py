@@ -30,16 +30,19 @@ def lines(path):
         return f.read().splitlines()
 
 
-def test_resume_keeps_rows_and_continues_bit_identically(tmp_path):
+@pytest.mark.parametrize("lag", [1, 2])
+def test_resume_keeps_rows_and_continues_bit_identically(tmp_path, lag):
+    """(`checkpoint_lag: 2` is the default of multi-process runs: a checkpoint is processed
+    one launch later, the resumed run must still retrace the uninterrupted one.)"""
     p = str(tmp_path / "b")
-    one = make(str(tmp_path / "a"), 40000)
+    one = make(str(tmp_path / "a"), 40000, checkpoint_lag=lag)
     one.run()
-    b1 = make(p, 20000)
+    b1 = make(p, 20000, checkpoint_lag=lag)
     b1.run()
     head = lines(p + ".1.txt")
     for ext in (".checkpoint", ".covmat", ".progress", ".1.state.npz", ".1.txt"):
         assert os.path.exists(p + ext), ext
-    b2 = make(p, 40000, resume=True)
+    b2 = make(p, 40000, resume=True, checkpoint_lag=lag)
     assert b2.n_steps_raw == b1.n_steps_raw and len(b2.progress) == len(b1.progress)
     b2.run()
     full = lines(p + ".1.txt")
@@ -197,3 +200,43 @@ def test_default_width_of_the_basis_groups(walkers, expect):
                 ProblemSpec.from_info(QUICK), output=None)
         assert seen["W"] == walkers and seen["basis_group_size"] == want
         assert seen["incremental"] == (evaluation == "auto")
+
+
+def test_checkpoint_lag_moves_the_proposal_refresh_by_one_launch(tmp_path):
+    """`checkpoint_lag` launches are queued between the request of a checkpoint and the
+    upload of the refreshed proposal: 1 for a single process (the refresh follows the launch
+    queued after the request), 2 by default with several processes (sampler.advance)."""
+    logs = {}
+    for lag in (1, 2):
+        log = logs[lag] = []
+
+        class Spy(OracleEngine):
+            launches = 0
+
+            def step(self, n):
+                self.launches += 1
+                return super().step(n)
+
+            def request_moments(self):
+                log.append(("request", self.launches))
+                return super().request_moments()
+
+            def set_proposal_cov(self, cov):
+                log.append(("refresh", self.launches))
+                return super().set_proposal_cov(cov)
+
+        class S(MCMCHip):
+            _engine_factory = staticmethod(Spy)
+
+        s = S({"seed": 21, "n_walkers": 128, "group_size": 64, "steps_per_launch": 40,
+               "max_samples": 30000, "Rminus1_stop": 0.0, "learn_every": "40d",
+               "checkpoint_lag": lag}, ProblemSpec.from_info(QUICK), output=None)
+        s.run()
+        assert s._ckpt_lag == lag and len(s.progress) >= 3
+    for lag, log in logs.items():
+        req = [n for what, n in log if what == "request"]
+        ref = [n for what, n in log if what == "refresh"][1:]   # (the first: initialize)
+        assert len(ref) >= 3 and len(req) >= len(ref)
+        assert all(b - a == lag for a, b in zip(req, ref)), (lag, log)
+    with pytest.raises(LoggedError, match="checkpoint_lag"):
+        make(str(tmp_path / "x"), 100, checkpoint_lag=0)
