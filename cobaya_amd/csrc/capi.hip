@@ -1371,7 +1371,8 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             // 1024 workgroups are exactly what the chip holds at once, and a direction kernel
             // that takes a few of those places first -- it happened once in a hundred launches
             // when both became runnable together -- costs the displaced workgroups a second
-            // round (1.78 ms instead of 1.04).
+            // round (1.78 ms instead of 1.04; with the event recorded BEFORE the step kernel
+            // d = 64 ran 6.13 ms per launch instead of 4.24, d = 48 and d = 100 unchanged).
             auto& N = h->dirs[h->dir_cur ^ 1];
             const IncSeg nxt = plan_segment(P, h->step + (unsigned long long)n,
                                             left > n ? left - n : n_steps);

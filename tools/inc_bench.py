@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Quick throughput of the step kernels, full vs incremental evaluation, at the BASELINE
-shapes (engine level, no sampler): tools/inc_bench.py [d ...]"""
+shapes (engine level, no sampler): [INC_ONLY=1] tools/inc_bench.py [d ...]"""
 import os
 import sys
 import time
@@ -55,5 +55,5 @@ def run(d, W, inc, gs=256, launches=6):
 if __name__ == "__main__":
     dims = [int(a) for a in sys.argv[1:]] or [30, 100]
     for d in dims:
-        for inc in (False, True):
+        for inc in ((True,) if os.environ.get("INC_ONLY") else (False, True)):
             run(d, 65536, inc)
