@@ -978,7 +978,8 @@ step_inc_mix_kernel(const IncStepArgs a)
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
         const bool in = i < d;
-        x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;
+        // (one box for all dimensions: a padded dimension rests at its middle, inside for every step)
+        x[kk] = in ? s.x[(size_t)i * W + w] : (a.box ? 0.5 * (a.box_lo + a.box_hi) : 0.0);
 #pragma unroll
         for (int k = 0; k < KM; ++k) y[k][kk] = in ? a.y[((size_t)k * d + i) * W + w] : 0.0;
     }
@@ -1031,16 +1032,29 @@ step_inc_mix_kernel(const IncStepArgs a)
                 const double* __restrict__ col = cur + sl * COL + c;
                 unsigned long long inb = ~0ull;   // the support test as a lane mask
                 double sc = 0.0;
+                if (a.box) {   // wave-uniform: one box for every dimension, no normal priors --
+                    // the test is taken on the extremes of the trial (no bounds read from LDS,
+                    // no mask arithmetic per dimension; a trial coordinate is never NaN)
+                    double tmx = -INFINITY, tmn = INFINITY;
 #pragma unroll
-                for (int kk = 0; kk < DQ; ++kk) {
-                    const double t = fma(r, col[4 * kk], x[kk]);
-                    const double2 lh = sLH[4 * kk + c];
-                    inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
-                    if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
-                        const int i = 4 * kk + c;
-                        const double2 li = sNA[i];
-                        const double qq = (t - li.x) * li.y;
-                        sc = sc + fma(-0.5 * qq, qq, sNM[i]);
+                    for (int kk = 0; kk < DQ; ++kk) {
+                        const double t = fma(r, col[4 * kk], x[kk]);
+                        tmx = __builtin_fmax(tmx, t);
+                        tmn = __builtin_fmin(tmn, t);
+                    }
+                    inb = lanes(tmx <= a.box_hi) & lanes(tmn >= a.box_lo);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) {
+                        const double t = fma(r, col[4 * kk], x[kk]);
+                        const double2 lh = sLH[4 * kk + c];
+                        inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
+                        if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
+                            const int i = 4 * kk + c;
+                            const double2 li = sNA[i];
+                            const double qq = (t - li.x) * li.y;
+                            sc = sc + fma(-0.5 * qq, qq, sNM[i]);
+                        }
                     }
                 }
                 double ak[KM], amax = -INFINITY;

@@ -839,13 +839,20 @@ def test_own_basis_periodic_rows_and_offsets_bit_exact():
 
 @pytest.mark.parametrize("d,W,gs,K,normal,T", [
     (4, 256, 64, 2, False, 1.0), (30, 256, 64, 2, False, 1.0), (30, 256, 256, 3, False, 1.0),
-    (9, 128, 64, 4, True, 1.0), (64, 128, 64, 2, False, 2.0), (27, 256, 128, 2, True, 1.0)])
+    (9, 128, 64, 4, True, 1.0), (64, 128, 64, 2, False, 2.0), (27, 256, 128, 2, True, 1.0),
+    (30, 256, 64, 2, "box off the origin", 1.0), (30, 256, 64, 4, "bounds differ", 1.0)])
 def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     """Mixtures of 2..4 modes in incremental mode (step_inc_mix_kernel): a carried residual and
     a whitened direction per mode, the log-sum-exp of eval_point -- bit for bit against the
-    oracle, across the refresh at 40 d steps."""
+    oracle, across the refresh at 40 d steps.  With one box for all dimensions the kernel takes
+    the support test on the extremes of the trial (its padded dimensions rest at the middle of
+    the box: the box of one case does not contain 0), with per-dimension bounds on lane masks."""
     kw = {}
-    if normal:
+    if normal == "box off the origin":
+        kw = dict(a=[2.0 ** -12] * d, b=[1.5] * d)
+    elif normal == "bounds differ":
+        kw = dict(a=[-0.25 * (i % 3) for i in range(d)], b=[1.0 + 0.5 * (i % 2) for i in range(d)])
+    elif normal:
         rng = np.random.default_rng(7100 + d)
         kinds = (rng.random(d) < 0.5).astype(int).tolist()
         kw = dict(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
