@@ -581,6 +581,13 @@ drag_inc_kernel(const IncStepArgs a)
         ll = -0.5 * (s.cnorm0 + chi2);
         return sel(lanes(chi2 < INFINITY), lp + ll, -INFINITY);
     };
+    // One box for all dimensions and at most two waves per SIMD: the support test is taken on
+    // the largest and smallest trial coordinate, as in step_inc_kernel (kBoxMinMax there).
+    constexpr bool kBoxMinMax = MODE == 0 && inc_drag_min_waves(DQ, MODE) <= 2;
+    struct Support {
+        double mx = -INFINITY, mn = INFINITY;
+        bool ok = true;
+    };
     auto inside = [&](double t, int kk) -> bool {
         if (MODE == 0) return (t <= bhi) & (t >= blo);
         if (kBoundsInLds) {
@@ -588,6 +595,15 @@ drag_inc_kernel(const IncStepArgs a)
             return (t <= lh.y) & (t >= lh.x);
         }
         return (t <= hi[kk]) & (t >= lo[kk]);
+    };
+    auto test = [&](Support& sp, double t, int kk) {
+        if (kBoxMinMax) {
+            sp.mx = __builtin_fmax(sp.mx, t);
+            sp.mn = __builtin_fmin(sp.mn, t);
+        } else sp.ok = sp.ok & inside(t, kk);
+    };
+    auto supported = [&](const Support& sp) -> bool {
+        return kBoxMinMax ? ((sp.mx <= bhi) & (sp.mn >= blo)) : sp.ok;
     };
     auto prior_term = [&](double t, int kk, double sc) -> double {
         if (!NORMP) return sc;
@@ -641,25 +657,25 @@ drag_inc_kernel(const IncStepArgs a)
                     if (i == 0) {
                         // the slow proposal: end = x + r0 v_slow (fused, as drag_core)
                         Ea0 = Ea;
-                        bool inb = true;
+                        Support inb;
                         double pc = 0.0, sc = 0.0;
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
                             const double2 p = col[4 * kk];
                             ce[kk] = fma(r, p.x, cs[kk]);
                             ye[kk] = fma(r, p.y, ys[kk]);
-                            inb = inb & inside(ce[kk], kk);
+                            test(inb, ce[kk], kk);
                             sc = prior_term(ce[kk], kk, sc);
                             pc = fma(ye[kk], ye[kk], pc);
                         }
-                        ce_lt = finish(inb, pc, sc, ce_lp, ce_ll);
+                        ce_lt = finish(supported(inb), pc, sc, ce_lp, ce_ll);
                         dead = ce_lt == -INFINITY;      // mcmc.py:590-592: only the weight grows
                         start_acc = cs_lt;
                         end_acc = ce_lt;
                     } else {
                         // interpolation step i: both points move by delta = r v_fast (a product,
                         // then a sum -- not fused, as drag_core)
-                        bool in_s = true, in_e = true;
+                        Support in_s, in_e;
                         double pcs = 0.0, pce = 0.0, scs = 0.0, sce = 0.0;
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
@@ -667,16 +683,16 @@ drag_inc_kernel(const IncStepArgs a)
                             const double delta = r * p.x;
                             const double t = cs[kk] + delta, te = ce[kk] + delta;
                             const double yst = fma(r, p.y, ys[kk]), yet = fma(r, p.y, ye[kk]);
-                            in_s = in_s & inside(t, kk);
-                            in_e = in_e & inside(te, kk);
+                            test(in_s, t, kk);
+                            test(in_e, te, kk);
                             scs = prior_term(t, kk, scs);
                             sce = prior_term(te, kk, sce);
                             pcs = fma(yst, yst, pcs);
                             pce = fma(yet, yet, pce);
                         }
                         double ps_lp, ps_ll, pe_lp, pe_ll;
-                        const double ps_lt = finish(in_s, pcs, scs, ps_lp, ps_ll);
-                        const double pe_lt = finish(in_e, pce, sce, pe_lp, pe_ll);
+                        const double ps_lt = finish(supported(in_s), pcs, scs, ps_lp, ps_ll);
+                        const double pe_lt = finish(supported(in_e), pce, sce, pe_lp, pe_ll);
                         const double frac = (double)i / navg;
                         const double pi = (1.0 - frac) * ps_lt + frac * pe_lt;
                         const double ci = (1.0 - frac) * cs_lt + frac * ce_lt;
