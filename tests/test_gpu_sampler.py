@@ -235,18 +235,21 @@ def test_bench_two_ranks_share_one_gpu():
     assert res["value"] > 1e8 and res["cpu_baseline"] is None
 
 
-def test_resume_continues_bit_identically(tmp_path):
+@pytest.mark.parametrize("lag", [1, 2])
+def test_resume_continues_bit_identically(tmp_path, lag):
     """checkpoint files + resume.  One run of 2N launches equals a run of N
     launches, a checkpoint, a fresh process-like restart (`resume: True`) and N more: walkers,
     counters and the R-1 window all come back (the reference cannot do this: its RNG state is
-    not saved, sampler.py:373)."""
+    not saved, sampler.py:373).  `checkpoint_lag: 2` is the default of multi-process runs (a
+    checkpoint is processed two launches after its request)."""
     from cobaya_amd.sampler import MCMCHip
     from cobaya_amd.model import ProblemSpec
 
     def make(prefix, resume, max_samples):
         info = dict(QUICK)
         opts = {"seed": 21, "n_walkers": 512, "group_size": 64, "steps_per_launch": 40,
-                "max_samples": max_samples, "Rminus1_stop": 0.0, "learn_every": "20d"}
+                "max_samples": max_samples, "Rminus1_stop": 0.0, "learn_every": "20d",
+                "checkpoint_lag": lag}
         return MCMCHip(opts, ProblemSpec.from_info(info), output=prefix, resume=resume)
 
     a = make(str(tmp_path / "a"), False, 60000)
