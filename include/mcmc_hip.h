@@ -205,7 +205,9 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
 
 /* HIP-event time (ms) spent in step kernels / basis kernels / moment kernels since the last
  * call with reset != 0, and the number of step-kernel launches: the live measurement
- * bench.py's roofline block uses.  Timing is enabled by mcmc_hip_enable_timing(h, 1). */
+ * bench.py's roofline block uses.  Timing is enabled by mcmc_hip_enable_timing(h, 1).  Every
+ * step kernel is timed; of the direction and moment regions one in eight, scaled to all of
+ * them (an event record costs the stream about 6 us between two dependent kernels). */
 int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
 /* incremental mode: the carried y[n_walkers][n_modes * d] -- part of the state a bit-identical resume
  * needs (call mcmc_hip_set_whitened after mcmc_hip_set_full_state) */
