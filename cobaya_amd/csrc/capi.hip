@@ -701,9 +701,16 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     acc(h->x.resize(W * d)); acc(h->logpost.resize(W)); acc(h->logprior.resize(W));
     acc(h->loglike.resize(W)); acc(h->weight_i.resize(W)); acc(h->prej.resize(W));
     acc(h->burn.resize(W)); acc(h->nacc.resize(W)); acc(h->stuck.resize(1));
-    acc(h->acc_total.resize(1));
-    acc(h->dT.resize(d * d + 16)); /* +16: wide scalar loads at the end of T */ acc(h->gsum.resize(G * d)); acc(h->Sg.resize(G * np));
-    acc(h->pooled.resize(np)); acc(h->dshift.resize(d));
+    acc(h->dT.resize(d * d + 16)); /* +16: wide scalar loads at the end of T */ acc(h->Sg.resize(G * np));
+    // the checkpoint's read-out in ONE block (one copy and one fill per checkpoint instead of
+    // three and two): [group sums | pooled second moments | accept counter]; `pooled` and
+    // `acc_total` are views into it (n = 0: not owned)
+    acc(h->gsum.resize(G * d + np + 1));
+    if (r == hipSuccess) {
+        h->pooled.p = h->gsum.p + G * d;
+        h->acc_total.p = reinterpret_cast<unsigned long long*>(h->gsum.p + G * d + np);
+    }
+    acc(h->dshift.resize(d));
     if (cfg->emit_capacity > 0) {
         acc(h->rows.resize(W * (size_t)cfg->emit_capacity * (d + 4)));
         acc(h->nrows.resize(W));
@@ -717,7 +724,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         // at once, four per compute unit; a direction kernel that took some of those places
         // first would push the displaced step workgroups into a second round -- 1.74 ms
         // instead of 1.22, measured with the order of the two reversed.  The direction kernels
-        // are meant to fill the places that free up in the step kernel's ragged tail.)
+        // run behind the step kernel, beside the moment snapshot: step_incremental.)
         int prio_least = 0, prio_greatest = 0;
         acc(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         acc(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_least));
@@ -758,11 +765,11 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     h->x.release(); h->logpost.release(); h->logprior.release(); h->loglike.release();
     h->cblock.release(); h->dT.release(); h->V.release(); h->rows.release(); h->gsum.release();
-    h->Sg.release(); h->pooled.release(); h->dshift.release(); h->ex.release(); h->elp.release();
+    h->Sg.release(); h->pooled.p = nullptr; /* (a view into gsum) */ h->dshift.release(); h->ex.release(); h->elp.release();
     h->ell.release(); h->eder.release(); h->escratch.release(); h->dLrow.release();
     h->dLcol.release(); h->weight_i.release(); h->prej.release();
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
-    h->acc_total.release();
+    h->acc_total.p = nullptr;   // (a view into gsum)
     h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
     if (h->pin_mom) (void)hipHostFree(h->pin_mom);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
@@ -1702,13 +1709,10 @@ int mcmc_hip_request_moments(mcmc_hip_ctx* h)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     const size_t d = h->d, G = h->G, np = d * (d + 1) / 2;
     hipStream_t s = h->stream;
-    HIP_TRY(h, hipMemcpyAsync(h->pin_mom, h->gsum.p, sizeof(double) * G * d, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(h->pin_mom + G * d, h->pooled.p, sizeof(double) * np,
+    // (gsum, pooled and the accept counter are one block: one copy, one fill)
+    HIP_TRY(h, hipMemcpyAsync(h->pin_mom, h->gsum.p, sizeof(double) * (G * d + np + 1),
                               hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(h->pin_mom + G * d + np, h->acc_total.p, sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemsetAsync(h->gsum.p, 0, sizeof(double) * G * d, s));
-    HIP_TRY(h, hipMemsetAsync(h->pooled.p, 0, sizeof(double) * np, s));
+    HIP_TRY(h, hipMemsetAsync(h->gsum.p, 0, sizeof(double) * (G * d + np), s));
     HIP_TRY(h, hipEventRecord(h->mom_event, s));
     h->mom_n = h->n_snapshots;
     h->mom_step = h->step;
