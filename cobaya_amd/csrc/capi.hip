@@ -1295,17 +1295,15 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     P.d = d; P.dq = dq; P.K = K;
     P.drag = h->drag_last_slow >= 0;
     const int nd = P.nd = P.drag ? h->drag_steps : 0;
-    bool one_param_block = false;
-    for (int n : h->blk_size) one_param_block = one_param_block || n == 1;
     // dragging: a step's 1 + n_drag columns must fit the LDS twice over
     P.chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + nd));
     const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)P.chunk_steps * (1 + nd) * 4 * dq;
     if (K < 1 || K > 4 || (K > 1 && (dq > 16 || P.drag)) || h->any_periodic ||
-        (h->blocked && one_param_block && K > 1) || (P.drag && drag_lds > (128u << 10)))
+        (P.drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation serves one Gaussian mode (or, without dragging and "
-                    "with parameter blocks of at least two parameters, a mixture of up to four at "
-                    "d <= 64) with non-periodic priors; use evaluation: full for this model");
+                    "incremental evaluation serves one Gaussian mode (or, without dragging, a "
+                    "mixture of up to four at d <= 64) with non-periodic priors; use "
+                    "evaluation: full for this model");
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                 : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
     if (!launch || !mcmc_hip_launch_whiten_directions)

@@ -911,6 +911,10 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
         const int col = (int)(step % (unsigned long long)a.cps);
         const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
         for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
+        // (columns of one-parameter blocks: the step kernel draws RandProposer1D variates there)
+        if (a.colflag)
+            a.colflag[(size_t)g * a.n_steps + sr] =
+                a.vflag ? a.vflag[((size_t)g * a.ncyc + cyc) * a.cps + col] : 0;
     }
     if (!live) return;
     double* __restrict__ out = a.VU + ((size_t)g * a.n_steps + sr) * (size_t)((1 + K) * dpad);
@@ -949,7 +953,7 @@ __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
     return dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3 : dq * (km + 1) <= 50 ? 2 : 1;
 }
 
-template <int DQ, int KM, bool UNIT_T>
+template <int DQ, int KM, bool UNIT_T, bool ONED>
 __global__ void __launch_bounds__(256, inc_mix_min_waves(DQ, KM))
 step_inc_mix_kernel(const IncStepArgs a)
 {
@@ -1025,6 +1029,11 @@ step_inc_mix_kernel(const IncStepArgs a)
         const double* __restrict__ cur = smem + (kc & 1) * CHUNK;
         stage(kc + 1);
         const int cols = ncols - base < C ? ncols - base : C;
+        // bit sl: column sl of the chunk belongs to a one-parameter block (the ONED
+        // instantiations, chosen when the blocking has such a block: a.colflag)
+        unsigned long long oned_cols = 0;
+        if (ONED)
+            oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
 #pragma unroll 1
         for (int sl = 0; sl < cols; ++sl) {
             {
@@ -1035,6 +1044,9 @@ step_inc_mix_kernel(const IncStepArgs a)
                     pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                 }
                 double r, Ea;
+                if (ONED && ((oned_cols >> sl) & 1ull)) {   // wave-uniform: the un-paired 1-D variates
+                    step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
+                } else
                 switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
                 case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
                 case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
@@ -1158,12 +1170,16 @@ hipError_t launch_inc_mix(const IncStepArgs& a, hipStream_t st)
     constexpr int C = inc_chunk_mix(DQ, KM);
     const size_t lds = sizeof(double) * 2 * C * (1 + KM) * 4 * DQ;
     const bool unit_t = a.s.temperature == 1.0;
-    static const std::string names[2] = {
-        "mcmc::step_inc_mix_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ", false>",
-        "mcmc::step_inc_mix_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ", true>"};
-    mcmc_hip_note_step_kernel(names[unit_t ? 1 : 0].c_str());
-    if (unit_t) hipLaunchKernelGGL((step_inc_mix_kernel<DQ, KM, true>), dim3(a.s.W / 64), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((step_inc_mix_kernel<DQ, KM, false>), dim3(a.s.W / 64), dim3(256), lds, st, a);
+    typedef void (*kern_t)(const IncStepArgs);
+    static const kern_t kerns[4] = {
+        step_inc_mix_kernel<DQ, KM, false, false>, step_inc_mix_kernel<DQ, KM, true, false>,
+        step_inc_mix_kernel<DQ, KM, false, true>, step_inc_mix_kernel<DQ, KM, true, true>};
+    const std::string stem = "mcmc::step_inc_mix_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM);
+    static const std::string names[4] = {stem + ", false>", stem + ", true>",
+                                         stem + ", false, 1-D blocks>", stem + ", true, 1-D blocks>"};
+    const int v = (unit_t ? 1 : 0) + (a.colflag ? 2 : 0);
+    mcmc_hip_note_step_kernel(names[v].c_str());
+    hipLaunchKernelGGL(kerns[v], dim3(a.s.W / 64), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

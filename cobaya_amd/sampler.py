@@ -245,8 +245,6 @@ class EnsembleMCMC:
         can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64 and not self.drag))
                    and not np.any(spec.periodic)
                    and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
-                   and (spec.n_modes == 1 or min(len(b) for b in self.blocks) >= 2
-                        or (len(self.blocks) == 1 and self.oversampling_factors[0] == 1))
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
         if not self.shared_basis and (len(self.blocks) > 1 or self.oversampling_factors[0] != 1):
@@ -254,9 +252,9 @@ class EnsembleMCMC:
                        "oversampling or dragging")
         if self.evaluation == "incremental" and not can_inc:
             self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
-                       "four at d <= 64 without dragging and with parameter blocks of at least two "
-                       "parameters) with non-periodic priors, emit: snapshots, d >= 2 and a "
-                       "group_size that is a multiple of 64; use 'full' (or 'auto')")
+                       "four at d <= 64 without dragging) with non-periodic priors, emit: "
+                       "snapshots, d >= 2 and a group_size that is a multiple of 64; use 'full' "
+                       "(or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         if self.basis_group_size is None:
             self.basis_group_size = int(self.group_size)

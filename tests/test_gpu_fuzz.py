@@ -134,8 +134,7 @@ def draw_incremental_case(seed):
         nb = int(rng.integers(2, min(4, d // 2) + 1))
         cuts = sorted(rng.choice(np.arange(1, d), size=nb - 1, replace=False).tolist())
         blocks = [perm[a:b] for a, b in zip([0] + cuts, cuts + [d])]
-        # (a mixture keeps to blocks of at least two parameters)
-        if K == 1 or min(len(b) for b in blocks) >= 2:
+        if True:   # (one-parameter blocks too, also under a mixture)
             over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
             kw.update(blocks=blocks, over=over)
             L = sum(o * len(b) for o, b in zip(over, blocks))

@@ -892,6 +892,9 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (7, 128, 64, 1, [[3], [0], [1, 2, 4, 5, 6]], [1, 1, 3]),
     (40, 128, 64, 1, [[39], list(range(20)), list(range(20, 39))], [1, 1, 2]),
     (100, 128, 64, 1, [list(range(50)), [99], list(range(50, 99))], [1, 2, 2]),
+    # ... and under a mixture (the flag of the column is a run-time one in step_inc_mix_kernel)
+    (9, 128, 64, 2, [[4], [0, 1, 2, 3], [5, 6, 7, 8]], [1, 2, 2]),
+    (30, 128, 64, 2, [list(range(10)), [29], list(range(10, 29))], [1, 1, 2]),
     # every block has one parameter: every step draws the 1-D variates
     (3, 128, 64, 1, [[2], [0], [1]], [1, 2, 3]),
     (2, 64, 64, 1, [[1], [0]], [1, 1])])
@@ -912,16 +915,17 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
         compare_state(eng, st)
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
     assert st.step > 40 * L and "step_inc" in eng.last_step_kernel()
-    assert ("1-D blocks" in eng.last_step_kernel()) == (min(len(b) for b in blocks) == 1)
-    # a MIXTURE with a one-parameter block stays with `evaluation: full`
+    if K == 1:
+        assert ("1-D blocks" in eng.last_step_kernel()) == (min(len(b) for b in blocks) == 1)
+    # a PERIODIC parameter stays with `evaluation: full`
     eng2 = E.Engine(4, 256, group_size=64, incremental=True)
-    eng2.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
-    m, c = random_target(4, 2, np.random.default_rng(0))
-    eng2.set_target_gaussian_mixture(m, c, [0.5, 0.5])
+    eng2.set_prior([0] * 4, [0.0] * 4, [1.0] * 4, [True, False, False, False])
+    m, c = random_target(4, 1, np.random.default_rng(0))
+    eng2.set_target_gaussian_mixture(m, c)
     eng2.set_blocking([[0], [1, 2, 3]], [1, 2])
     eng2.set_proposal_cov(c[0])
     eng2.set_state(np.full((256, 4), 0.5))
-    with pytest.raises(E.EngineError, match="at least two parameters"):
+    with pytest.raises(E.EngineError, match="non-periodic"):
         eng2.step(3)
     eng.close(), eng2.close()
 

@@ -443,10 +443,12 @@ def test_incremental_with_blocks_is_the_same_posterior():
     np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
 
 
-def test_incremental_with_one_parameter_blocks_is_the_same_sampler():
+@pytest.mark.parametrize("K", [1, 2])
+def test_incremental_with_one_parameter_blocks_is_the_same_sampler(K):
     """Columns of a one-parameter block draw the RandProposer1D variates (proposal.py:85-93) in
     incremental mode too: with un-paired variates the incremental and the from-scratch run take
-    the same decisions; with paired ones the 1-D columns still use the un-paired stream."""
+    the same decisions; with paired ones the 1-D columns still use the un-paired stream.  One
+    Gaussian mode and a mixture of two."""
     from oracle import cbind as O
     d = 7
     rng = np.random.default_rng(5)
@@ -455,7 +457,9 @@ def test_incremental_with_one_parameter_blocks_is_the_same_sampler():
     mean = np.full(d, 0.5)
     blocks, over = [[3], [0, 1, 2], [4, 5, 6]], [1, 1, 3]
     T = O.blocked_transform(cov, blocks, 2.4)
-    mk = lambda inc, paired: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov,
+    tgt = (dict(means=mean, covs=cov) if K == 1 else
+           dict(means=[mean, mean + 0.04], covs=[cov, 1.5 * cov], weights=[0.4, 0.6]))
+    mk = lambda inc, paired: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, **tgt,
                                        T=T, group_size=64, seed=4, blocks=blocks,
                                        oversampling=over, incremental=inc, paired_variates=paired)
     full, inc = mk(False, False), mk(True, False)
