@@ -1298,12 +1298,15 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     // dragging: a step's 1 + n_drag columns must fit the LDS twice over
     P.chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + nd));
     const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)P.chunk_steps * (1 + nd) * 4 * dq;
-    if (K < 1 || K > 4 || (K > 1 && (dq > 16 || P.drag)) || h->any_periodic ||
+    int n_periodic = 0;
+    for (int i = 0; i < d; ++i) n_periodic += h->periodic[i] ? 1 : 0;
+    if (K < 1 || K > 4 || (K > 1 && (dq > 16 || P.drag)) ||
+        (n_periodic > 0 && (K > 1 || P.drag || n_periodic > 8)) ||
         (P.drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation serves one Gaussian mode (or, without dragging, a "
-                    "mixture of up to four at d <= 64) with non-periodic priors; use "
-                    "evaluation: full for this model");
+                    "incremental evaluation serves one Gaussian mode (or, without dragging and "
+                    "with non-periodic priors, a mixture of up to four at d <= 64); up to eight "
+                    "periodic parameters without dragging; use evaluation: full for this model");
     auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                 : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
     if (!launch || !mcmc_hip_launch_whiten_directions)
@@ -1371,6 +1374,9 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.box_lo = h->lo[0]; a.box_hi = h->hi[0];
             a.n_drag = nd; a.chunk_steps = P.chunk_steps;
             a.colflag = D.has_flags ? D.colflag.p : nullptr;
+            a.Lrow = h->inc_Lrow.p;
+            for (int i = 0; i < d; ++i)
+                if (h->periodic[i]) a.periodic_mask4[i >> 5] |= 1u << (i & 31);
             HIP_TRY(h, launch(&a, h->stream));
             h->n_step_launches += 1;
             if (g_noted_kernel) {

@@ -218,6 +218,10 @@ struct IncStepArgs {
     // one-parameter blocks: colflag[G][columns of the launch] (written with VU) marks the columns
     // whose step draws the RandProposer1D variates (proposal.py:85-93); null if no block has one
     const int* colflag;
+    // periodic parameters (step_inc_periodic_kernel): bit i of periodic_mask4[i / 32] marks
+    // dimension i; Lrow = L^-1 row-major [d][d] (a wrap moves the residual by a column of it)
+    unsigned periodic_mask4[4];
+    const double* Lrow;
 };
 
 struct IncDirArgs {

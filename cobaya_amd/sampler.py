@@ -243,7 +243,8 @@ class EnsembleMCMC:
             self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
                        self.evaluation)
         can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64 and not self.drag))
-                   and not np.any(spec.periodic)
+                   and (not np.any(spec.periodic) or (spec.n_modes == 1 and not self.drag
+                                                      and int(np.sum(spec.periodic)) <= 8))
                    and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
@@ -252,9 +253,9 @@ class EnsembleMCMC:
                        "oversampling or dragging")
         if self.evaluation == "incremental" and not can_inc:
             self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
-                       "four at d <= 64 without dragging) with non-periodic priors, emit: "
-                       "snapshots, d >= 2 and a group_size that is a multiple of 64; use 'full' "
-                       "(or 'auto')")
+                       "four at d <= 64 without dragging and with non-periodic priors; up to eight "
+                       "periodic parameters without dragging), emit: snapshots, d >= 2 and a group_size "
+                       "that is a multiple of 64; use 'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         if self.basis_group_size is None:
             self.basis_group_size = int(self.group_size)

@@ -57,8 +57,8 @@ typedef struct mcmc_hip_config {
  * of sharing the group's: the reference-faithful control, much slower */
 #define MCMC_HIP_FLAG_OWN_BASIS 1
 /* incremental evaluation (one Gaussian mode with parameter blocks of any size, oversampling or
- * dragging -- or, without dragging, a mixture of up to four modes at d <= 64 --, non-periodic
- * priors, emit_capacity 0, 2 <= d <= 128): every
+ * dragging -- or, without dragging, a mixture of up to four modes at d <= 64 --; up to eight
+ * periodic parameters for one mode without dragging; emit_capacity 0, 2 <= d <= 128): every
  * walker carries y = L^-1 (x - mu) and a trial moves it along the whitened shared direction,
  * y' = y + r L^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in O(d) per step;
  * y is recomputed from x every 40 cycle lengths (40 d steps for one block).  What the mode does

@@ -563,7 +563,7 @@ static inline int step_core(const orc_problem* p, orc_state* st, int w, const do
     return accept;
 }
 
-/* ---- incremental evaluation (Gaussian modes, non-periodic priors, one block) -------------
+/* ---- incremental evaluation (Gaussian modes; periodic parameters: step_core_inc) ---------
  * y[k*d + j] = sum_{i<=j} Linv_k[j][i] (x_i - mu_k,i), ascending fma chain from +0.0 (==
  * `derived` of eval_point): what a walker carries per mode, recomputed at every step s with
  * s % refresh_every == 0 */
@@ -606,12 +606,26 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
                                 const double* const* u, double r, double exp_draw)
 {
     int d = p->d, K = p->n_modes;
-    double t[128], yt[16 * 128];
+    double t[128], yt[16 * 128], sh[128];
     const double* x = st->x + (size_t)w * d;
     double* y = st->y + (size_t)w * K * d;
-    int inb = 1;
+    int inb = 1, wound = 0;
     for (int i = 0; i < d; ++i) {
         t[i] = fma(r, v[i], x[i]);
+        sh[i] = 0.0;
+        if (p->has_periodic && p->periodic[i]) {
+            /* prior.py:675 (wrap_periodic, spelled out): the coordinate is the wrapped one; when
+             * the winding number changes (floor != 0) the move of the coordinate, sh = t' - t, is
+             * carried into the whitened residual below -- otherwise t' differs from t by the
+             * rounding of the wrap alone, which y does not follow (as it does not follow the
+             * rounding of its own updates: bounded by the refresh every refresh_every steps) */
+            double wd = p->hi[i] - p->lo[i];
+            double yv = (t[i] - p->lo[i]) / wd;
+            double fl = floor(yv);
+            double tw = (yv - fl) * wd + p->lo[i];
+            if (fl != 0.0) { sh[i] = tw - t[i]; wound |= sh[i] != 0.0; }
+            t[i] = tw;
+        }
         inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
     }
     double lp = -INFINITY, ll = -INFINITY, lt = -INFINITY;
@@ -628,10 +642,16 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
         double a[16], amax = -INFINITY;
         for (int k = 0; k < K; ++k) {
             double pc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int i = 0; i < d; ++i) {
-                yt[k * d + i] = fma(r, u[k][i], y[k * d + i]);
-                pc[i & 3] = fma(yt[k * d + i], yt[k * d + i], pc[i & 3]);
+            for (int i = 0; i < d; ++i) yt[k * d + i] = fma(r, u[k][i], y[k * d + i]);
+            if (wound) {   /* a wrap by sh_i moves the residual by sh_i (column i of L^-1) */
+                const double* Li = p->Linv + (size_t)k * d * d;
+                for (int i = 0; i < d; ++i)
+                    if (sh[i] != 0.0)
+                        for (int j = i; j < d; ++j)
+                            yt[k * d + j] = fma(sh[i], Li[j * d + i], yt[k * d + j]);
             }
+            for (int i = 0; i < d; ++i)
+                pc[i & 3] = fma(yt[k * d + i], yt[k * d + i], pc[i & 3]);
             a[k] = -0.5 * (p->cnorm[k] + ((pc[0] + pc[1]) + (pc[2] + pc[3])));
             if (a[k] > amax) amax = a[k];
         }

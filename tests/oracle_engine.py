@@ -166,13 +166,14 @@ class OracleEngine:
         if self.own_basis and self._blocking:
             raise EngineError(ERR_ARG, "shared_basis: False serves a single parameter block "
                                        "without dragging")
+        drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
+        periodic = self._prior[3] is not None and self._prior[3].any()
         if self.incremental and (not 1 <= self.K <= 4 or (self.K > 1 and self.d > 64)
-                                 or (self._blocking and self.K != 1 and (
-                                     self._blocking["drag_last_slow"] >= 0 or
-                                     min(len(b) for b in self._blocking["blocks"]) < 2)) or
-                                 (self._prior[3] is not None and self._prior[3].any())):
-            raise EngineError(ERR_ARG, "incremental evaluation serves one Gaussian mode with "
-                                       "non-periodic priors and a single parameter block")
+                                 or (self.K != 1 and drag)
+                                 or (periodic and (self.K != 1 or drag))):
+            raise EngineError(ERR_ARG, "incremental evaluation serves one Gaussian mode (or a "
+                                       "mixture without dragging and with non-periodic priors; "
+                                       "periodic parameters without dragging)")
         self._prob()
         self._state.run(int(n_steps), walker0=self.walker_offset, n_threads=self.n_threads)
         self._steps = self._state.step

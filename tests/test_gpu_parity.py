@@ -90,6 +90,10 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
         for i, k in enumerate(kinds):
             if k == 1:
                 x0[:, i] = a[i] + rng.normal(size=W) * b[i]
+    if periodic is not None:   # a periodic parameter starts inside its interval
+        for i, per in enumerate(periodic):
+            if per and (a[i], b[i]) != (0.0, 1.0):
+                x0[:, i] = a[i] + (x0[:, i] - a[i]) % (b[i] - a[i])
     eng.set_state(x0)
     st = O.State(prob, x0, burn_in=burn_in, row_cap=cap)
     return eng, prob, st
@@ -873,6 +877,48 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     eng.close()
 
 
+@pytest.mark.parametrize("d,W,gs,per,extra", [
+    (6, 256, 64, [0, 2, 5], {}),
+    (30, 256, 128, [0, 7, 29], {"T": 1.7, "burn_in": 2}),
+    (27, 128, 64, [3], {"normal": True}),
+    (9, 128, 64, [4], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
+    (33, 128, 64, [32, 1], {}),
+    (100, 128, 64, [5, 50, 99], {})])
+def test_incremental_periodic_steps_bit_exact(d, W, gs, per, extra):
+    """Periodic parameters in incremental mode (step_inc_periodic_kernel; oracle step_core_inc):
+    the coordinate is the wrapped one at every step, and a wrap that changes the winding number
+    moves the carried residual by the wrap times a column of L^-1.  The periodic intervals are
+    a few sigma wide around the mode, so that walkers cross the seam all the time."""
+    extra = dict(extra)
+    periodic = [int(i in per) for i in range(d)]
+    a = [0.42 if p else 0.0 for p in periodic]
+    b = [0.58 if p else 1.0 for p in periodic]
+    kinds = [0] * d
+    if extra.pop("normal", False):
+        rng = np.random.default_rng(7300 + d)
+        kinds = [int(not p and rng.random() < 0.5) for p in periodic]
+        a = [0.5 if k else v for k, v in zip(kinds, a)]
+        b = [float(rng.uniform(0.1, 0.4)) if k else v for k, v in zip(kinds, b)]
+    eng, prob, st = make_pair(d, W, gs, kinds=kinds, a=a, b=b, periodic=periodic,
+                              incremental=True, rng=np.random.default_rng(6300 + d), **extra)
+    L = eng.cycle_length()
+    compare_state(eng, st)
+    wraps = 0
+    for n in (1, 6, L + 3, 40 * L - (L + 10) - 2, 9, L + 1):
+        before = st.x.copy()
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
+        wraps += int(np.sum(np.abs(st.x - before)[:, per] > 0.08))
+    assert st.step > 40 * L and "step_inc_periodic_kernel" in eng.last_step_kernel()
+    assert wraps > 20 and eng.counters()["accepted"] == int(st.n_accept.sum())
+    x = eng.get_full_state()["x"]
+    assert np.all((x[:, per] >= 0.42) & (x[:, per] <= 0.58))
+    eng.close()
+
+
 @pytest.mark.parametrize("d,W,gs,K,blocks,over", [
     (9, 256, 64, 1, [[0, 1, 2, 3], [4, 5, 6, 7, 8]], [1, 3]),
     (30, 256, 256, 1, [list(range(10)), list(range(10, 30))], [1, 2]),
@@ -917,11 +963,11 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
     assert st.step > 40 * L and "step_inc" in eng.last_step_kernel()
     if K == 1:
         assert ("1-D blocks" in eng.last_step_kernel()) == (min(len(b) for b in blocks) == 1)
-    # a PERIODIC parameter stays with `evaluation: full`
+    # a PERIODIC parameter under a mixture stays with `evaluation: full`
     eng2 = E.Engine(4, 256, group_size=64, incremental=True)
     eng2.set_prior([0] * 4, [0.0] * 4, [1.0] * 4, [True, False, False, False])
-    m, c = random_target(4, 1, np.random.default_rng(0))
-    eng2.set_target_gaussian_mixture(m, c)
+    m, c = random_target(4, 2, np.random.default_rng(0))
+    eng2.set_target_gaussian_mixture(m, c, [0.5, 0.5])
     eng2.set_blocking([[0], [1, 2, 3]], [1, 2])
     eng2.set_proposal_cov(c[0])
     eng2.set_state(np.full((256, 4), 0.5))
