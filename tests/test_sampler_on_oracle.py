@@ -240,3 +240,38 @@ def test_checkpoint_lag_moves_the_proposal_refresh_by_one_launch(tmp_path):
         assert all(b - a == lag for a, b in zip(req, ref)), (lag, log)
     with pytest.raises(LoggedError, match="checkpoint_lag"):
         make(str(tmp_path / "x"), 100, checkpoint_lag=0)
+
+
+def test_periodic_parameters_are_sampled_incrementally(tmp_path):
+    """A periodic parameter (prior.py:658-676) no longer sends the run to `evaluation: full`: one
+    Gaussian mode with up to eight periodic parameters, without dragging, is evaluated
+    incrementally (`auto`); a mixture or a dragging run with a periodic parameter is not.  The
+    likelihood itself is not periodic, so the posterior of the periodic parameter is the
+    Gaussian cut to its interval -- reached from both ends through the seam."""
+    from scipy.stats import truncnorm
+    info = {"likelihood": {"gaussian_mixture": {"means": [0.02, 0.5, 0.3],
+                                                "covs": np.diag([0.0064, 0.004, 0.003]).tolist()}},
+            "params": {"phase": {"prior": {"min": 0, "max": 0.2}, "periodic": True},
+                       "b": {"prior": {"min": 0, "max": 1}},
+                       "c": {"prior": {"min": 0, "max": 1}}}}
+    spec = ProblemSpec.from_info(info)
+    assert spec.periodic.tolist() == [1, 0, 0]
+    s = OnOracle({"n_walkers": 512, "group_size": 64, "seed": 3, "max_samples": 150000,
+                  "Rminus1_stop": 0.0, "learn_every": "20d"}, spec, output=str(tmp_path / "p"))
+    assert s.incremental and s.engine.incremental
+    s.run()
+    x = s.engine.get_state()["x"]
+    assert np.all((x[:, 0] >= 0) & (x[:, 0] <= 0.2))
+    assert np.sum(x[:, 0] > 0.15) > 15 and np.sum(x[:, 0] < 0.05) > 60    # both ends of the seam
+    tn = truncnorm((0 - 0.02) / 0.08, (0.2 - 0.02) / 0.08, loc=0.02, scale=0.08)
+    assert abs(x[:, 0].mean() - tn.mean()) < 4 * tn.std() / np.sqrt(512)
+    assert abs(x[:, 1].mean() - 0.5) < 4 * np.sqrt(0.004 / 512)
+    # what stays with the from-scratch kernels
+    two = dict(info, likelihood={"gaussian_mixture": {
+        "means": [[0.02, 0.5, 0.3], [0.1, 0.4, 0.3]],
+        "covs": [np.diag([0.0064, 0.004, 0.003]).tolist()] * 2}})
+    s2 = OnOracle({"n_walkers": 128, "group_size": 64, "seed": 3}, ProblemSpec.from_info(two))
+    assert not s2.incremental
+    with pytest.raises(LoggedError, match="incremental"):
+        OnOracle({"n_walkers": 128, "group_size": 64, "seed": 3, "evaluation": "incremental"},
+                 ProblemSpec.from_info(two))
