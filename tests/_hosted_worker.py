@@ -189,6 +189,31 @@ def one_nuisance(tmp):
             "cycle_length": int(sampler.cycle_length)}
 
 
+def periodic_phase(tmp):
+    """A `periodic: True` parameter (prior.py:658-676, mcmc.py `supports_periodic_params`) under
+    the real Cobaya: read from the live model's prior, sampled on the incremental path."""
+    from cobaya.run import run
+    fake_seam()
+    info = {
+        "likelihood": {"gaussian_mixture": {"means": [[0.02, 0.5, 0.3]],
+                                            "covs": [np.diag([0.0064, 0.004, 0.003]).tolist()],
+                                            "input_params_prefix": "p_"}},
+        "params": {"p_0": {"prior": {"min": 0, "max": 0.2}, "periodic": True, "ref": 0.05,
+                           "proposal": 0.05},
+                   "p_1": {"prior": {"min": 0, "max": 1}, "ref": 0.5, "proposal": 0.05},
+                   "p_2": {"prior": {"min": 0, "max": 1}, "ref": 0.3, "proposal": 0.05}},
+        "sampler": {"mcmc_hip": {"seed": 3, "n_walkers": 512, "group_size": 64,
+                                 "Rminus1_stop": 0.0, "max_samples": 150000,
+                                 "learn_every": "20d"}}}
+    updated, sampler = run(info)
+    x = sampler.engine.get_state()["x"]
+    return {"incremental": bool(sampler.incremental),
+            "periodic": [int(v) for v in sampler.spec.periodic],
+            "inside": bool(np.all((x[:, 0] >= 0) & (x[:, 0] <= 0.2))),
+            "high_end": int(np.sum(x[:, 0] > 0.15)), "low_end": int(np.sum(x[:, 0] < 0.05)),
+            "mean0": float(x[:, 0].mean()), "mean1": float(x[:, 1].mean())}
+
+
 def reference_test_mcmc(tmp):
     """The reference's own tests/test_mcmc.py::test_mcmc, with `mcmc` replaced by `mcmc_hip`:
     the SAME input -- `fixed_info` imported from the reference's tests/common_sampler.py, the

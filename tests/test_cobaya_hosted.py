@@ -14,6 +14,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -88,6 +89,16 @@ def test_a_one_parameter_fast_block_runs_incrementally(tmp_path):
     assert [b for _, b in r["blocking"]] == [["a_0", "a_1", "a_2"], ["cal_0"]]
     assert r["incremental"] and r["cycle_length"] == 3 + r["blocking"][1][0]
     assert r["kl"] < 0.03
+
+
+def test_a_periodic_parameter_from_the_live_model_runs_incrementally(tmp_path):
+    from scipy.stats import truncnorm
+    r = scenario("periodic_phase", tmp_path)
+    assert r["incremental"] and r["periodic"] == [1, 0, 0] and r["inside"]
+    assert r["high_end"] > 15 and r["low_end"] > 60      # the interval is entered from both ends
+    tn = truncnorm((0 - 0.02) / 0.08, (0.2 - 0.02) / 0.08, loc=0.02, scale=0.08)
+    assert abs(r["mean0"] - tn.mean()) < 4 * tn.std() / np.sqrt(512)
+    assert abs(r["mean1"] - 0.5) < 4 * np.sqrt(0.004 / 512)
 
 
 def test_dragging_from_the_live_model(tmp_path):
