@@ -632,3 +632,59 @@ def test_incremental_with_periodic_parameters_is_the_same_sampler(blocked):
     c.run(900, n_threads=4)
     lp, ll = full.evaluate(c.x)
     np.testing.assert_allclose(c.logpost, lp + ll, rtol=2e-13, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_incremental_periodic_random_shapes_walk_the_same_chains(seed):
+    """Random shapes of the periodic branch of step_core_inc (dimension, which parameters are
+    periodic and on which interval, normal priors on others, temperature, parameter blocks with a
+    one-parameter block): with un-paired variates the incremental and the from-scratch oracle
+    take the same decisions and keep the same wrapped coordinates, and the carried residual
+    stays L^-1 (x - mu)."""
+    from oracle import cbind as O
+    rng = np.random.default_rng(4400 + seed)
+    d = int(rng.integers(2, 14))
+    A = rng.normal(size=(d, d))
+    sd = rng.uniform(0.02, 0.06, d)
+    c = A @ A.T / d + np.eye(d)
+    cov = c / np.sqrt(np.outer(np.diag(c), np.diag(c))) * np.outer(sd, sd)
+    mean = rng.uniform(0.4, 0.6, d)
+    periodic = (rng.random(d) < 0.4).astype(int)
+    periodic[int(rng.integers(0, d))] = 1
+    kinds = [int(not p and rng.random() < 0.3) for p in periodic]
+    half = rng.uniform(1.0, 3.0, d) * sd                     # periodic: a few sigma wide
+    a = [float(mean[i] - half[i]) if periodic[i] else (0.5 if kinds[i] else -0.5) for i in range(d)]
+    b = [float(mean[i] + half[i]) if periodic[i] else (float(rng.uniform(0.2, 0.5)) if kinds[i] else 1.5)
+         for i in range(d)]
+    T = float(rng.choice([1.0, 1.0, 1.8]))
+    kw = {}
+    if d >= 4 and rng.random() < 0.5:
+        perm = rng.permutation(d).tolist()
+        blocks, over = [perm[:1], perm[1:d // 2 + 1], perm[d // 2 + 1:]], [1, 2, 3]
+        blocks = [bl for bl in blocks if bl]
+        over = over[:len(blocks)]
+        kw = dict(T=O.blocked_transform(cov * T, blocks, 2.4), blocks=blocks, oversampling=over)
+    else:
+        kw = dict(T=O.proposal_transform(cov * T, 2.4))
+    mk = lambda inc: O.Problem(d, kinds, a, b, periodic=periodic.tolist(), means=mean, covs=cov,
+                               group_size=64, seed=seed + 1, temperature=T, incremental=inc,
+                               paired_variates=False, **kw)
+    full, inc = mk(False), mk(True)
+    x0 = mean + rng.normal(size=(64, d)) * sd
+    for i in range(d):
+        if periodic[i]:
+            x0[:, i] = a[i] + (x0[:, i] - a[i]) % (b[i] - a[i])
+    sa, sb = O.State(full, x0), O.State(inc, x0)
+    Linv = np.linalg.inv(np.linalg.cholesky(cov))
+    moved = 0
+    for n in (1, 37, 400, 163):
+        before = sa.x.copy()
+        sa.run(n, n_threads=2)
+        sb.run(n, n_threads=2)
+        assert np.array_equal(sa.weight, sb.weight) and np.array_equal(sa.n_accept, sb.n_accept)
+        np.testing.assert_allclose(sa.x, sb.x, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(sb.y.reshape(64, d), (sb.x - mean) @ Linv.T, rtol=0, atol=1e-9)
+        per = np.flatnonzero(periodic)
+        moved += int(np.sum(np.abs(sa.x - before)[:, per] > 0.8 * (np.array(b) - np.array(a))[per]))
+        assert np.all(sb.x[:, per] >= np.array(a)[per]) and np.all(sb.x[:, per] <= np.array(b)[per])
+    assert sa.n_accept.sum() > 64 * 20
