@@ -134,14 +134,30 @@ def draw_incremental_case(seed):
         nb = int(rng.integers(2, min(4, d // 2) + 1))
         cuts = sorted(rng.choice(np.arange(1, d), size=nb - 1, replace=False).tolist())
         blocks = [perm[a:b] for a, b in zip([0] + cuts, cuts + [d])]
-        if True:   # (one-parameter blocks too, also under a mixture)
-            over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
-            kw.update(blocks=blocks, over=over)
-            L = sum(o * len(b) for o, b in zip(over, blocks))
-            if K == 1 and rng.random() < 0.5:
-                last = int(rng.integers(0, nb - 1))
-                kw.update(drag_last_slow=last, drag_steps=int(rng.integers(2, 6)), over=[1] * nb)
-                L = sum(len(b) for b in blocks[:last + 1])
+        # (one-parameter blocks too, also under a mixture)
+        over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
+        kw.update(blocks=blocks, over=over)
+        L = sum(o * len(b) for o, b in zip(over, blocks))
+        if K == 1 and rng.random() < 0.5:
+            last = int(rng.integers(0, nb - 1))
+            kw.update(drag_last_slow=last, drag_steps=int(rng.integers(2, 6)), over=[1] * nb)
+            L = sum(len(b) for b in blocks[:last + 1])
+    # MCMC_FUZZ_INC_PERIODIC=1 (developer switch, off in the committed runs: the periodic kernel
+    # has its own cases in test_gpu_parity.py): one to three periodic parameters, a few sigma
+    # wide around the mode, on shapes the periodic kernel serves (one mode, no dragging).  Drawn
+    # from a generator of its own, so that the shapes above stay what they are.
+    if os.environ.get("MCMC_FUZZ_INC_PERIODIC") and K == 1 and "drag_last_slow" not in kw:
+        r2 = np.random.default_rng(77000 + seed)
+        kinds = kw.get("kinds", [0] * d)
+        a = list(kw.get("a", [0.0] * d))
+        b = list(kw.get("b", [1.0] * d))
+        per = [0] * d
+        for i in r2.choice(d, size=int(r2.integers(1, min(3, d) + 1)), replace=False):
+            if not kinds[i]:
+                per[int(i)] = 1
+                a[int(i)], b[int(i)] = 0.42, 0.58
+        if any(per):
+            kw.update(kinds=kinds, a=a, b=b, periodic=per)
     steps = [int(rng.integers(1, 12)), int(rng.integers(1, L + 5)), 40 * L - int(rng.integers(0, 20)),
              int(rng.integers(1, 30))]
     return d, W, gs, K, kw, steps
