@@ -30,7 +30,7 @@ PAIR_DIMS = list(range(33, 57))  # 32 < d <= 48: walker_kernels.hip's two-wave s
 # -pragma-unroll-threshold: the operand-stream loops must be unrolled completely (their
 # register arrays are only addressable with compile-time indices).
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
-         "-fno-fast-math", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
+         "-fno-fast-math", "-fvisibility=hidden", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
          "-Wno-unused-result"]
 
 

@@ -986,6 +986,10 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
     h->pin_T_slot = (h->pin_T_slot + 1) & 3;
     if (h->pin_T_slot == 0) HIP_TRY(h, hipStreamSynchronize(h->stream));   // ring wrapped
     std::copy(h->T.begin(), h->T.end(), slot);
+    // a direction set being filled ahead on the second stream still reads dT: the copy waits for
+    // it (that set is stale after ++dir_epoch and is recomputed, but it must not read a torn T)
+    for (auto& D : h->dirs)
+        if (D.ahead && D.ready) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
     HIP_TRY(h, hipMemcpyAsync(h->dT.p, slot, sizeof(double) * d * d, hipMemcpyHostToDevice,
                               h->stream));
     h->have_cov = true;
@@ -1716,6 +1720,11 @@ int mcmc_hip_request_moments(mcmc_hip_ctx* h)
     // (gsum, pooled and the accept counter are one block: one copy, one fill)
     HIP_TRY(h, hipMemcpyAsync(h->pin_mom, h->gsum.p, sizeof(double) * (G * d + np + 1),
                               hipMemcpyDeviceToHost, s));
+    // the stuck flag travels with the read-out (the spare word behind the accept counter): the
+    // run loop never synchronises, so this is where a walker that tripped max_tries is seen
+    // (mcmc.py:717-743 stops at once)
+    HIP_TRY(h, hipMemcpyAsync(h->pin_mom + G * d + np + 1, h->stuck.p, sizeof(int),
+                              hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemsetAsync(h->gsum.p, 0, sizeof(double) * (G * d + np), s));
     HIP_TRY(h, hipEventRecord(h->mom_event, s));
     h->mom_n = h->n_snapshots;
@@ -1748,6 +1757,12 @@ int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_
         counters[0] = (int64_t)h->mom_step;
         counters[1] = (int64_t)tot;
     }
+    int stuck = 0;
+    std::memcpy(&stuck, h->pin_mom + G * d + np + 1, sizeof stuck);
+    if (stuck)
+        return fail(h, MCMC_HIP_ERR_STUCK,
+                    "The chain has been stuck for %g attempts (walker %d), stopping sampling.",
+                    h->cfg.max_tries, stuck - 1);
     return MCMC_HIP_OK;
 }
 

@@ -27,21 +27,17 @@
 #include "det_math.h"
 #include "kernels.h"
 
-#ifndef MCMC_INC_PIPE_OVERRIDE
-#define MCMC_INC_PIPE_OVERRIDE (-1)    // developer switch: pairs fetched ahead in the trial loop
-#endif
-
-#ifdef MCMC_INC_BLOCK_TIMES   // developer instrumentation: start / end clock of every workgroup
-__device__ unsigned long long g_block_times[2 * 4096];
-__device__ unsigned int g_wave_place[2 * 4 * 4096];   // per wave: HW_ID, XCC_ID
-extern "C" int mcmc_hip_debug_block_times(unsigned long long* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_times), sizeof(g_block_times));
-}
-extern "C" int mcmc_hip_debug_wave_place(unsigned int* out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_place), sizeof(g_wave_place));
-}
+// Experiment hooks.  The shipped build uses the tuned values: MCMC_EXP_* are identities / no-ops.
+// Timing experiments (occupancy sweeps, read-ahead depth, per-workgroup clocks) force-include
+// _exp/inc_experiment.h (`-include`, tools/exp_inc_variants.sh), which defines them instead;
+// nothing of that is compiled into libmcmc_hip.so.
+#ifndef MCMC_EXP_WAVES
+#define MCMC_EXP_WAVES(family, tuned) (tuned)    // waves per SIMD of a kernel family
+#define MCMC_EXP_PIPE(tuned) (tuned)             // pairs fetched ahead in the trial loop
+#define MCMC_EXP_BLOCK_BEGIN() ((void)0)         // per-workgroup clock and placement records
+#define MCMC_EXP_BLOCK_END() ((void)0)
+#define MCMC_EXP_ROTATE_SHIFT(tuned) (tuned)     // log2 of the shader clocks per priority turn
+#define MCMC_EXP_ROTATE(on) (on)                 // rotate the wave priorities at all
 #endif
 
 namespace mcmc {
@@ -78,24 +74,20 @@ __device__ __forceinline__ int hw_wave_slot()
 {
     return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
 }
-#ifndef MCMC_INC_ROTATE_CLOCK_SHIFT
-#define MCMC_INC_ROTATE_CLOCK_SHIFT 17
-#endif
 template <int NW>   // NW: the waves that share a SIMD (the kernel's occupancy)
 __device__ __forceinline__ void rotate_priority(int slot)
 {
-#ifndef MCMC_INC_NO_ROTATE_PRIO   // developer switch (timing experiments)
+    if (!MCMC_EXP_ROTATE(true)) return;
     // (a rotation over NW levels: over four levels two waves would not get equal turns; kernels
     // held to three waves are left alone -- measured: rotating them loses 2-8 %)
     if (NW != 2 && NW != 4) return;
-    const int turn = (int)(__builtin_amdgcn_s_memtime() >> MCMC_INC_ROTATE_CLOCK_SHIFT);
+    const int turn = (int)(__builtin_amdgcn_s_memtime() >> MCMC_EXP_ROTATE_SHIFT(17));
     switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
     case 2: __builtin_amdgcn_s_setprio(2); break;
     default: __builtin_amdgcn_s_setprio(3); break;
     }
-#endif
 }
 
 // lane mask -> the mask of the lanes whose quad is held completely
@@ -169,12 +161,10 @@ __host__ __device__ constexpr int inc_chunk(int dq)
 // entries (13, 15) are where the per-dimension constants move from registers to LDS.
 __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
 {
-#ifdef MCMC_INC_WAVES_OVERRIDE   // developer switch (timing experiments)
-    return MCMC_INC_WAVES_OVERRIDE;
-#endif
-    if (mode == 0) return dq <= 12 ? 4 : 2;
-    if (mode == 1) return (dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1;
-    return dq <= 5 ? 4 : dq == 6 ? 3 : dq == 13 ? 4 : dq == 15 ? 3 : dq <= 31 ? 2 : 1;
+    return MCMC_EXP_WAVES(STEP,
+        mode == 0 ? (dq <= 12 ? 4 : 2)
+        : mode == 1 ? ((dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1)
+        : (dq <= 5 ? 4 : dq == 6 ? 3 : dq == 13 ? 4 : dq == 15 ? 3 : dq <= 31 ? 2 : 1));
 }
 
 //   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
@@ -201,8 +191,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     // (d = 100: 9.97 -> 9.32 ms per 4 000 steps); with four they are, and v_max/v_min cost
     // more than the compares (d = 30: 1.031 -> 1.053 ms), so those kernels keep the masks.
     constexpr bool kBoxMinMax = MODE == 0 && inc_min_waves(DQ, MODE) == 2;
-    constexpr int PIPE = MCMC_INC_PIPE_OVERRIDE >= 0 ? MCMC_INC_PIPE_OVERRIDE
-                       : (inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
+    constexpr int PIPE = MCMC_EXP_PIPE(inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
@@ -230,13 +219,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         }
     };
     stage(0);
-#ifdef MCMC_INC_BLOCK_TIMES
-    if (tid == 0 && blockIdx.x < 4096) g_block_times[2 * blockIdx.x] = wall_clock64();
-    if (lane == 0 && blockIdx.x < 4096) {
-        g_wave_place[2 * (4 * blockIdx.x + wave)] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
-        g_wave_place[2 * (4 * blockIdx.x + wave) + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-    }
-#endif
+    MCMC_EXP_BLOCK_BEGIN();
 
     const double blo = a.box_lo, bhi = a.box_hi;
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
@@ -479,9 +462,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         s.n_accept[w] = nacc0 + nacc;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
-#ifdef MCMC_INC_BLOCK_TIMES
-    if (tid == 0 && blockIdx.x < 4096) g_block_times[2 * blockIdx.x + 1] = wall_clock64();
-#endif
+    MCMC_EXP_BLOCK_END();
 }
 
 // ---------------------------------------------------------------- periodic parameters
@@ -714,13 +695,11 @@ step_inc_periodic_kernel(const IncStepArgs a)
 // (r_i, E_i) of the sub-steps i = 0 .. n_drag are drawn four at a time, one per lane class.
 __host__ __device__ constexpr int inc_drag_min_waves(int dq, int mode)
 {
-#ifdef MCMC_INC_DRAG_WAVES_OVERRIDE   // developer switch (timing experiments)
-    return MCMC_INC_DRAG_WAVES_OVERRIDE;
-#endif
     // (measured like inc_min_waves, tools/drag_bench.py over builds held to 1..4 waves: two waves
     // with some spilled registers beat one up to d = 68 -- d = 44: 3.3e10 against 1.9e10 --, one
     // wave wins from d = 80 on)
-    return mode == 0 ? (dq <= 3 ? 4 : dq <= 5 ? 3 : dq <= 17 ? 2 : 1) : (dq <= 3 ? 3 : dq <= 17 ? 2 : 1);
+    return MCMC_EXP_WAVES(DRAG, mode == 0 ? (dq <= 3 ? 4 : dq <= 5 ? 3 : dq <= 17 ? 2 : 1)
+                                          : (dq <= 3 ? 3 : dq <= 17 ? 2 : 1));
 }
 
 template <int DQ, int MODE, bool UNIT_T, bool ONED>
@@ -1167,12 +1146,10 @@ __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 
 __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
 {
-#ifdef MCMC_INC_MIX_WAVES_OVERRIDE   // developer switch (timing experiments)
-    return MCMC_INC_MIX_WAVES_OVERRIDE;
-#endif
     // (measured like inc_min_waves, tools/mix_bench.py d:K over builds held to 1..4 waves; the
     // state is dq (km + 1) doubles per lane)
-    return dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3 : dq * (km + 1) <= 50 ? 2 : 1;
+    return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3
+                                                     : dq * (km + 1) <= 50 ? 2 : 1);
 }
 
 template <int DQ, int KM, bool UNIT_T, bool ONED>

@@ -576,7 +576,11 @@ class EnsembleMCMC:
             self._ckpt_age += 1
             if self._ckpt_age >= self._ckpt_lag:
                 self._finish_checkpoint()
-        self._request_checkpoint_if_due()
+        # (a run that has just converged or reached max_samples leaves the loop: a request
+        # queued now would be processed after convergence -- an extra progress row, possibly
+        # `converged` flipped back under a "Sampling complete" log, mcmc.py:470)
+        if not self.converged and self._accepted_total < self.max_samples:
+            self._request_checkpoint_if_due()
 
     def _request_checkpoint_if_due(self):
         if self._ckpt_pending or self._next_ckpt is None or self.n_steps_raw < self._next_ckpt:

@@ -27,6 +27,10 @@ extern "C" {
 
 typedef struct mcmc_hip_ctx mcmc_hip_ctx;
 
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header
+ * are exported (tests/test_host_logic.py compares `nm -D` with it). */
+#define MCMC_HIP_API __attribute__((visibility("default")))
+
 enum {
     MCMC_HIP_OK = 0,
     MCMC_HIP_ERR_ARG = -1,       /* invalid argument / unsupported configuration */
@@ -70,30 +74,30 @@ typedef struct mcmc_hip_config {
  * launch */
 #define MCMC_HIP_FLAG_BASIS_GROUP_MASK 0x0F00
 
-const char* mcmc_hip_version(void);
+MCMC_HIP_API const char* mcmc_hip_version(void);
 /* message of the last error on this handle (or of the last failed create if h == NULL) */
-const char* mcmc_hip_last_error(const mcmc_hip_ctx* h);
+MCMC_HIP_API const char* mcmc_hip_last_error(const mcmc_hip_ctx* h);
 /* 1 if the lane-per-walker kernels for dimension d were compiled into this library */
-int mcmc_hip_dim_supported(int d);
+MCMC_HIP_API int mcmc_hip_dim_supported(int d);
 
 /* Sampler.__init__ + MCMC.initialize (cobaya/sampler.py:257-322, mcmc.py:111-271) */
-int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out);
-void mcmc_hip_destroy(mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out);
+MCMC_HIP_API void mcmc_hip_destroy(mcmc_hip_ctx* h);
 
 /* Prior.__init__ constants (cobaya/prior.py:464-533): kind[i] 0 = uniform on [a,b],
  * 1 = normal(loc=a, scale=b); periodic[i] != 0 wraps into [a,b) (prior.py:658-676). */
-int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, const double* b,
+MCMC_HIP_API int mcmc_hip_set_prior(mcmc_hip_ctx* h, const int32_t* kind, const double* a, const double* b,
                        const int32_t* periodic);
 
 /* GaussianMixture.initialize_with_params (gaussian_mixture.py:45-136): means[K*d],
  * covs[K*d*d] row-major, weights[K] (NULL = equal; renormalised if they do not sum to 1). */
-int mcmc_hip_set_target_gaussian_mixture(mcmc_hip_ctx* h, int32_t n_modes, const double* means,
+MCMC_HIP_API int mcmc_hip_set_target_gaussian_mixture(mcmc_hip_ctx* h, int32_t n_modes, const double* means,
                                          const double* covs, const double* weights);
 /* Gaussian.initialize_with_params (gaussian/gaussian.py:30-94) */
-int mcmc_hip_set_target_gaussian(mcmc_hip_ctx* h, const double* mean, const double* cov,
+MCMC_HIP_API int mcmc_hip_set_target_gaussian(mcmc_hip_ctx* h, const double* mean, const double* cov,
                                  int32_t normalized);
 /* likelihoods/one/one.py:27-29: loglike = 0 (prior-only sampling) */
-int mcmc_hip_set_target_one(mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_set_target_one(mcmc_hip_ctx* h);
 
 /* BlockedProposer.__init__ (proposal.py:96-196) + MCMC.set_proposer_blocking (mcmc.py:320-410):
  * n_blocks parameter blocks sorted slow -> fast, block b holding block_size[b] consecutive
@@ -102,34 +106,34 @@ int mcmc_hip_set_target_one(mcmc_hip_ctx* h);
  * step (mcmc.py:564-668) with blocks 0..drag_last_slow slow and drag_steps interpolation
  * steps; -1 keeps Metropolis steps.  d <= 32 only.  Must precede set_proposal_cov (a previous
  * covariance is forgotten).  One block with factor 1 and the identity order is the default. */
-int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* block_size,
+MCMC_HIP_API int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* block_size,
                           const int32_t* oversampling, const int32_t* i_of_j,
                           int32_t drag_last_slow, int32_t drag_steps);
 /* steps per cycle: d for one block, sum_b oversampling_b n_b with blocks, the number of slow
  * parameters when dragging (mcmc.py:400-407) */
-int mcmc_hip_cycle_length(const mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_cycle_length(const mcmc_hip_ctx* h);
 
 /* BlockedProposer.set_covariance (proposal.py:226-260); with blocks the covariance is
  * reordered by i_of_j first and get_proposal_transform returns T in that sorted order:
  * checks symmetric positive definite, builds T = scale * diag(std) * chol(corr).  `cov`
  * must already carry the temperature factor (mcmc.py:438-440), as in the reference. */
-int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov);
-int mcmc_hip_get_proposal_cov(const mcmc_hip_ctx* h, double* cov);          /* proposal.py:262 */
-int mcmc_hip_get_proposal_transform(const mcmc_hip_ctx* h, double* T);      /* transform[0] * scale */
+MCMC_HIP_API int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov);
+MCMC_HIP_API int mcmc_hip_get_proposal_cov(const mcmc_hip_ctx* h, double* cov);          /* proposal.py:262 */
+MCMC_HIP_API int mcmc_hip_get_proposal_transform(const mcmc_hip_ctx* h, double* T);      /* transform[0] * scale */
 
 /* Model.logposterior for a batch (cobaya/model.py:579-678): x[n*d] point-major ->
  * logprior[n], loglike[n] (-inf outside the prior support), derived[n*K*d] or NULL =
  * L_k^-1 (x - mu_k) (gaussian_mixture.py:146-156). */
-int mcmc_hip_evaluate(mcmc_hip_ctx* h, int32_t n, const double* x, double* logprior,
+MCMC_HIP_API int mcmc_hip_evaluate(mcmc_hip_ctx* h, int32_t n, const double* x, double* logprior,
                       double* loglike, double* derived);
 
 /* OneSamplePoint.add of the initial points (mcmc.py:219-222): x[n_walkers*d] walker-major.
  * Evaluates their log-posterior on the device; n_bad (may be NULL) receives the number of
  * walkers with a non-finite posterior (an error, as in model.py:707-754). */
-int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad);
+MCMC_HIP_API int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad);
 /* current point of every walker: x[W*d], logpost[W], logprior[W], loglike[W], weight[W];
  * any pointer may be NULL */
-int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
+MCMC_HIP_API int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
                        double* loglike, int32_t* weight);
 
 /* Complete per-walker state for checkpoint/resume (mcmc.py:189-214, 1045-1078 -- the reference
@@ -138,60 +142,63 @@ int mcmc_hip_get_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logp
  * walker-major, logpost/logprior/loglike[W], weight/prior_rej/burn_left[W] (int32),
  * n_accept[W] (int64), *step = Metropolis steps taken per walker.  set_ restores all of it
  * without re-evaluating anything (set_prior, a set_target call and set_proposal_cov must precede). */
-int mcmc_hip_get_full_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
+MCMC_HIP_API int mcmc_hip_get_full_state(mcmc_hip_ctx* h, double* x, double* logpost, double* logprior,
                             double* loglike, int32_t* weight, int32_t* prior_rej,
                             int32_t* burn_left, int64_t* n_accept, uint64_t* step);
-int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logpost,
+MCMC_HIP_API int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logpost,
                             const double* logprior, const double* loglike, const int32_t* weight,
                             const int32_t* prior_rej, const int32_t* burn_left,
                             const int64_t* n_accept, uint64_t step);
 
 /* n_steps iterations of MCMC.get_new_sample_metropolis (mcmc.py:545-562) for every walker,
  * asynchronously on the engine's stream; generates the Haar bases the steps need. */
-int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps);
+MCMC_HIP_API int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps);
 /* wait for queued work; returns MCMC_HIP_ERR_STUCK if a walker tripped max_tries */
-int mcmc_hip_sync(mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_sync(mcmc_hip_ctx* h);
 
 /* counters[0] steps per walker so far, [1] accepted steps summed over walkers (n_steps_raw /
  * acceptance of mcmc.py:311-318, 472), [2] id+1 of a stuck walker or 0, [3] rows dropped
  * because emit_capacity was exceeded */
-int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4]);
+MCMC_HIP_API int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4]);
 
 /* SampleCollection.add rows accumulated since the last drain (mcmc.py:691-707,
  * collection.py:402-427): rows[n][d+5] = (walker id, weight, logpost, logprior, loglike,
  * x[0..d)), walker-major then in chain order.  cap_rows = capacity of `rows` in rows. */
-int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int64_t* n_rows);
+MCMC_HIP_API int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int64_t* n_rows);
 
 /* Constants the engine derived from set_prior / set_target_* (uniform_logp of prior.py:528-533,
  * mls[d] of tools.py:723, Linv[K*d*d] row-major of functions.py:81-89, cnorm[K] =
  * d log 2pi + log|S_k|, weight[K]); any pointer may be NULL.  Lets tests hand the CPU oracle
  * exactly the problem the kernels evaluate. */
-int mcmc_hip_get_derived_constants(const mcmc_hip_ctx* h, double* uniform_logp, double* mls,
+MCMC_HIP_API int mcmc_hip_get_derived_constants(const mcmc_hip_ctx* h, double* uniform_logp, double* mls,
                                    double* Linv, double* cnorm, double* weight);
 
 /* Vector subtracted from every walker before its moments are accumulated (numerical
  * conditioning only; R-1 and covariances are shift invariant).  Only right after a reset. */
-int mcmc_hip_set_moment_shift(mcmc_hip_ctx* h, const double* shift);
+MCMC_HIP_API int mcmc_hip_set_moment_shift(mcmc_hip_ctx* h, const double* shift);
 
 /* Streaming replacement of SampleCollection.mean/cov (collection.py:893-981): adds the
  * current state of every walker to the interval accumulators (one "snapshot"). */
-int mcmc_hip_accumulate_moments(mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_accumulate_moments(mcmc_hip_ctx* h);
 /* n_snapshots since the last reset; group_sum[G*d] = sum over snapshots and the group's
  * walkers of x; pooled_S[d*d] = sum over everything of x x^T.  reset != 0 clears them. */
-int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
+MCMC_HIP_API int mcmc_hip_read_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
                           double* pooled_S, int32_t reset);
 /* restores accumulators read with reset == 0 (resume: the snapshots taken since the last
  * read-out are part of the state) */
-int mcmc_hip_set_moments(mcmc_hip_ctx* h, int64_t n_snapshots, const double* group_sum,
+MCMC_HIP_API int mcmc_hip_set_moments(mcmc_hip_ctx* h, int64_t n_snapshots, const double* group_sum,
                          const double* pooled_S);
 /* The same read-out without stalling the host (the learn/convergence checkpoint off the
  * critical path): `request` queues the device->host copies of the accumulators and of the
  * accept counter behind the work already in the stream, resets the accumulators in stream
  * order and returns at once; `fetch` waits for those copies only -- launches queued AFTER the
  * request keep running meanwhile.  counters[2] = (steps per walker, accepted steps of all
- * walkers) at the time of the request.  One request may be pending at a time. */
-int mcmc_hip_request_moments(mcmc_hip_ctx* h);
-int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
+ * walkers) at the time of the request.  One request may be pending at a time.  The stuck flag
+ * travels with the read-out: `fetch` returns MCMC_HIP_ERR_STUCK (after filling its outputs) if
+ * a walker had tripped max_tries when the request was served (mcmc.py:717-743) -- the run loop
+ * never calls mcmc_hip_sync, so this is where it learns of it. */
+MCMC_HIP_API int mcmc_hip_request_moments(mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
                            double* pooled_S, int64_t counters[2]);
 
 /* The R-1 arithmetic of MCMC.check_convergence_and_learn_proposal (mcmc.py:856-889) on
@@ -199,7 +206,7 @@ int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_
  * n_chains, sum_N = sum_c N_c, sum_Ncov[d*d] = sum_c N_c cov_c, sum_mean[d] = sum_c m_c,
  * sum_mm[d*d] = sum_c m_c m_c^T.  Outputs Rminus1 and mean_of_covs[d*d].
  * Returns MCMC_HIP_ERR_NOT_PD where the reference catches LinAlgError (mcmc.py:870-887). */
-int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double* sum_Ncov,
+MCMC_HIP_API int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double* sum_Ncov,
                           const double* sum_mean, const double* sum_mm, double* Rminus1,
                           double* mean_of_covs);
 
@@ -208,17 +215,17 @@ int mcmc_hip_gelman_rubin(int32_t d, double n_chains, double sum_N, const double
  * bench.py's roofline block uses.  Timing is enabled by mcmc_hip_enable_timing(h, 1).  Every
  * step kernel is timed; of the direction and moment regions one in eight, scaled to all of
  * them (an event record costs the stream about 6 us between two dependent kernels). */
-int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
+MCMC_HIP_API int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
 /* incremental mode: the carried y[n_walkers][n_modes * d] -- part of the state a bit-identical resume
  * needs (call mcmc_hip_set_whitened after mcmc_hip_set_full_state) */
-int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y);
-int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
+MCMC_HIP_API int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y);
+MCMC_HIP_API int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
 
 /* name of the step kernel the last mcmc_hip_step launched, e.g.
  * "mcmc::step_pair_kernel<true, false> (d=30)" -- reported by the launcher itself, so that
  * profiles and bench lines quote the kernel that ran ("" before the first step) */
-const char* mcmc_hip_last_step_kernel(const mcmc_hip_ctx* h);
-int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset);
+MCMC_HIP_API const char* mcmc_hip_last_step_kernel(const mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset);
 
 #ifdef __cplusplus
 }

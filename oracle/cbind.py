@@ -45,7 +45,15 @@ class _Problem(C.Structure):
         ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
         ("weight", c_double_p), ("T", c_double_p), ("blocking", C.c_void_p),
         ("incremental", C.c_int32), ("refresh_every", C.c_int32),
-        ("paired_variates", C.c_int32),
+        ("paired_variates", C.c_int32), ("binned", C.c_void_p),
+    ]
+
+
+class _Binned(C.Structure):
+    _fields_ = [
+        ("n_bins", C.c_int32), ("lmax", C.c_int32), ("n_lin", C.c_int32), ("calib", C.c_int32),
+        ("bins", c_int32_p), ("weights", c_double_p), ("X", c_double_p), ("Linv", c_double_p),
+        ("theta0", c_double_p), ("D0", c_double_p), ("J", c_double_p),
     ]
 
 
@@ -116,6 +124,11 @@ def lib():
         L.orc_whiten.argtypes = [C.POINTER(_Problem), c_double_p, c_double_p]
         L.orc_whiten_directions.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p]
         L.orc_max_threads.restype = C.c_int
+        L.orc_binned_chi2_of_delta.restype = C.c_double
+        L.orc_binned_chi2_of_delta.argtypes = [C.POINTER(_Binned), c_double_p]
+        L.orc_binned_delta.argtypes = [C.POINTER(_Binned), c_double_p, c_double_p]
+        L.orc_binned_chi2_of_cl.argtypes = [C.POINTER(_Binned), C.c_int, C.c_int, C.c_int,
+                                            c_double_p, c_double_p, c_double_p]
         _lib = L
     return _lib
 
@@ -184,6 +197,62 @@ def blocked_transform(cov, blocks, scale):
     return proposal_transform(cov[np.ix_(i_of_j, i_of_j)], scale)
 
 
+class Binned:
+    """Owns the arrays behind an `orc_binned`: the plik-lite arithmetic
+    (planck_pliklite.py:143-155) in the device's operation order.  `bins` [n][3] =
+    (spectrum, first l, last l); `weights` [lmax + 1] in D_l space; `cov` or its inverse
+    Cholesky factor `Linv`; the linear emulator (theta0, D0, J) and the position `calib` of the
+    calibration parameter among the sampled ones (both optional for `chi2_of_cl`)."""
+
+    def __init__(self, bins, weights, X, cov=None, Linv=None, theta0=None, D0=None, J=None,
+                 calib=0):
+        self.bins = np.ascontiguousarray(bins, dtype=np.int32).reshape(-1, 3)
+        self.weights = np.ascontiguousarray(weights, dtype=np.float64)
+        self.X = np.ascontiguousarray(X, dtype=np.float64)
+        n = len(self.X)
+        if Linv is None:
+            Linv = np.linalg.inv(np.linalg.cholesky(np.asarray(cov, dtype=np.float64)))
+        self.Linv = np.ascontiguousarray(np.tril(Linv), dtype=np.float64)
+        assert self.Linv.shape == (n, n) and len(self.bins) == n
+        self.lmax = len(self.weights) - 1
+        self.theta0 = np.ascontiguousarray(np.zeros(1) if theta0 is None else theta0, np.float64)
+        self.n_lin = 0 if theta0 is None else len(self.theta0)
+        self.D0 = np.ascontiguousarray(np.zeros((3, self.lmax + 1)) if D0 is None else D0,
+                                       dtype=np.float64)
+        self.J = np.ascontiguousarray(np.zeros((3, self.lmax + 1, max(self.n_lin, 1)))
+                                      if J is None else J, dtype=np.float64)
+        assert self.D0.shape == (3, self.lmax + 1)
+        assert self.J.shape == (3, self.lmax + 1, max(self.n_lin, 1))
+        b = _Binned()
+        b.n_bins, b.lmax, b.n_lin, b.calib = n, self.lmax, self.n_lin, int(calib)
+        b.bins, b.weights, b.X, b.Linv = _ip(self.bins), _dp(self.weights), _dp(self.X), _dp(self.Linv)
+        b.theta0, b.D0, b.J = _dp(self.theta0), _dp(self.D0), _dp(self.J)
+        self.calib = int(calib)
+        self.c = b
+
+    def chi2_of_cl(self, L0, cl, A):
+        """get_chi_squared for explicit spectra cl[n][3][m] (element l - L0 = D_l)."""
+        cl = np.ascontiguousarray(cl, dtype=np.float64)
+        A = np.ascontiguousarray(np.atleast_1d(A), dtype=np.float64)
+        n, three, stride = cl.shape
+        assert three == 3 and len(A) == n and stride + L0 > self.lmax
+        out = np.empty(n)
+        lib().orc_binned_chi2_of_cl(C.byref(self.c), n, int(L0), stride, _dp(cl), _dp(A), _dp(out))
+        return out
+
+    def delta(self, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        assert x.shape[1] == self.n_lin + 1
+        out = np.empty((len(x), len(self.X)))
+        for k in range(len(x)):
+            lib().orc_binned_delta(C.byref(self.c), _dp(x[k]), _dp(out[k]))
+        return out
+
+    def chi2_of_delta(self, delta):
+        delta = np.ascontiguousarray(np.atleast_2d(delta), dtype=np.float64)
+        return np.array([lib().orc_binned_chi2_of_delta(C.byref(self.c), _dp(r)) for r in delta])
+
+
 class Problem:
     """Owns the arrays behind an `orc_problem`.  All derived constants may be passed in
     (e.g. the ones the HIP engine reports) so that oracle and engine see one problem."""
@@ -192,8 +261,10 @@ class Problem:
                  normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
                  max_tries=None, derived=None, blocks=None, oversampling=None,
                  drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None,
-                 paired_variates=None):
+                 paired_variates=None, binned=None):
         self.d = d
+        self.binned = binned    # a `Binned` target instead of the mixture (means must be None)
+        assert binned is None or (means is None and binned.n_lin == d - 1 and not incremental)
         # incremental evaluation (one Gaussian mode, non-periodic, one block): the whitened
         # residual is carried and refreshed every `refresh_every` (default 40 d) steps
         self.incremental = bool(incremental)
@@ -279,8 +350,8 @@ class Problem:
         p.weight, p.T = _dp(self.weight), _dp(self.T)
         p.blocking = (C.cast(C.pointer(self.blocking), C.c_void_p) if self.blocking is not None
                       else None)
-        p.blocking = (C.cast(C.pointer(self.blocking), C.c_void_p) if self.blocking is not None
-                      else None)
+        p.binned = (C.cast(C.pointer(self.binned.c), C.c_void_p) if self.binned is not None
+                    else None)
         self.c = p    # (orc_block_slots below reads the blocking through it)
         self.refresh_every = int(self._refresh_every or
                                  40 * (lib().orc_block_slots(

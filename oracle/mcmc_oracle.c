@@ -212,7 +212,40 @@ typedef struct {
      * block (walker_variates_pair) -- what the incremental kernels do; 0 = one block per step as
      * everywhere else (kept so that tests can run both modes on the same proposal stream) */
     int32_t paired_variates;
+    /* binned-bandpower Gaussian likelihood (planck_pliklite.py:143-155) instead of the mixture
+     * (n_modes must be 0): see orc_binned below */
+    const struct orc_binned* binned;
 } orc_problem;
+
+/* The plik-lite arithmetic (cobaya/likelihoods/base_classes/planck_pliklite.py:143-155 +
+ * functions.py:64-78) with the operation order of the device kernels (pliklite_kernels.hip):
+ *   spectra   D_l = D0[tp][l] then fma(J[tp][l][p], theta_p - theta0_p, .) for p ascending
+ *             (the linear stand-in for provider.get_Cl, planck_pliklite.py:170-178; theta = the
+ *             sampled parameters without the calibration parameter, in order);
+ *   binning   cl_b = fma chain over l = first..last ascending of D_l * weights[l], from +0
+ *             (np.dot of planck_pliklite.py:148-151);
+ *   residual  delta_b = fma(-cl_b, 1 / (A A), X_b)        (cl /= A_planck**2; diff = X - cl);
+ *   chi2      y_j = fma chain over i = 0..j ascending of Linv[j][i] delta_i from +0, with
+ *             cov = L L^T (the same quadratic form as invcov.dot(diff).dot(diff));  the squares
+ *             are summed in 32 interleaved chains p[q][c] over the rows with j mod 4 = c and
+ *             class(j div 16) = q, class(R) = (R mod 16 < 8) ? R mod 8 : 7 - R mod 8 (wave q of
+ *             the chi2 kernel owns the 16-row tiles of class q, lane class c their rows 4r + c),
+ *             s_q = (p[q][0] + p[q][1]) + (p[q][2] + p[q][3]),
+ *             chi2 = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+ *   loglike   -chi2 / 2. */
+typedef struct orc_binned {
+    int32_t n_bins;        /* used bins, in data-vector order (planck_pliklite.py:126-141) */
+    int32_t lmax;
+    int32_t n_lin;         /* emulator parameters (= d - 1 when sampling) */
+    int32_t calib;         /* index of the calibration parameter among the sampled ones */
+    const int32_t* bins;   /* [n_bins][3] = (spectrum 0 tt / 1 te / 2 ee, first l, last l) */
+    const double* weights; /* [lmax + 1], D_l space (planck_pliklite.py:52-56) */
+    const double* X;       /* [n_bins] */
+    const double* Linv;    /* [n_bins][n_bins] row-major, lower triangle used */
+    const double* theta0;  /* [n_lin] */
+    const double* D0;      /* [3][lmax + 1] */
+    const double* J;       /* [3][lmax + 1][n_lin] */
+} orc_binned;
 
 /* Blocked proposal (proposal.py:96-224): blocks sorted slow -> fast; parameter j of the
  * sorted order is sampler parameter i_of_j[j]; block b covers n_b consecutive j from
@@ -432,6 +465,80 @@ static inline double wrap_periodic(double t, double lo, double hi)
     return m * w + lo;
 }
 
+/* ------------------------------------------------------------------ binned Gaussian (plik-lite) */
+static inline int binned_class(int R) { int m = R & 15; return m < 8 ? m : 15 - m; }
+
+/* chi2 of a residual vector (order: see orc_binned) */
+double orc_binned_chi2_of_delta(const orc_binned* b, const double* delta)
+{
+    const int n = b->n_bins;
+    double p[8][4];
+    for (int q = 0; q < 8; ++q) for (int c = 0; c < 4; ++c) p[q][c] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double* Lj = b->Linv + (size_t)j * n;
+        double y = 0.0;
+        for (int i = 0; i <= j; ++i) y = fma(Lj[i], delta[i], y);
+        double* pc = &p[binned_class(j >> 4)][j & 3];
+        *pc = fma(y, y, *pc);
+    }
+    double s[8];
+    for (int q = 0; q < 8; ++q) s[q] = (p[q][0] + p[q][1]) + (p[q][2] + p[q][3]);
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+/* residual of the sampled point x[d] through the linear emulator */
+void orc_binned_delta(const orc_binned* b, const double* x, double* delta)
+{
+    double dth[32];
+    const int n = b->n_lin, L1 = b->lmax + 1;
+    for (int p = 0, i = 0; p < n; ++p, ++i) {
+        if (i == b->calib) ++i;
+        dth[p] = x[i] - b->theta0[p];
+    }
+    const double A = x[b->calib];
+    const double iA2 = 1.0 / (A * A);
+    for (int ib = 0; ib < b->n_bins; ++ib) {
+        const int tp = b->bins[3 * ib], l0 = b->bins[3 * ib + 1], l1 = b->bins[3 * ib + 2];
+        double acc = 0.0;
+        for (int l = l0; l <= l1; ++l) {
+            double cl = b->D0[(size_t)tp * L1 + l];
+            const double* Jl = b->J + ((size_t)tp * L1 + l) * n;
+            for (int p = 0; p < n; ++p) cl = fma(Jl[p], dth[p], cl);
+            acc = fma(cl, b->weights[l], acc);
+        }
+        delta[ib] = fma(-acc, iA2, b->X[ib]);
+    }
+}
+
+/* PlanckPlikLite.get_chi_squared(L0, ctt, cte, cee, A_planck) (planck_pliklite.py:143-155) for
+ * n_pts sets of explicit spectra: cl[pt][3][stride], element l - L0 of a row is D_l */
+void orc_binned_chi2_of_cl(const orc_binned* b, int n_pts, int L0, int stride, const double* cl,
+                           const double* A, double* chi2)
+{
+    double* delta = (double*)malloc(sizeof(double) * (size_t)b->n_bins);
+    for (int k = 0; k < n_pts; ++k) {
+        const double iA2 = 1.0 / (A[k] * A[k]);
+        for (int ib = 0; ib < b->n_bins; ++ib) {
+            const int tp = b->bins[3 * ib], l0 = b->bins[3 * ib + 1], l1 = b->bins[3 * ib + 2];
+            const double* cell = cl + ((size_t)k * 3 + tp) * stride;
+            double acc = 0.0;
+            for (int l = l0; l <= l1; ++l) acc = fma(cell[l - L0], b->weights[l], acc);
+            delta[ib] = fma(-acc, iA2, b->X[ib]);
+        }
+        chi2[k] = orc_binned_chi2_of_delta(b, delta);
+    }
+    free(delta);
+}
+
+static double binned_loglike(const orc_binned* b, const double* t)
+{
+    double* delta = (double*)malloc(sizeof(double) * (size_t)b->n_bins);
+    orc_binned_delta(b, t, delta);
+    const double chi2 = orc_binned_chi2_of_delta(b, delta);
+    free(delta);
+    return -0.5 * chi2;
+}
+
 /* returns 1 if inside the prior support; fills lp, ll (ll only if inside) and optionally
  * derived[k*d + j] = (L_k^-1 (t - mu_k))_j */
 static int eval_point(const orc_problem* p, const double* t, double* lp_out, double* ll_out,
@@ -454,6 +561,7 @@ static int eval_point(const orc_problem* p, const double* t, double* lp_out, dou
     const double s = d > 32 ? (sc[0] + sc[1]) + (sc[2] + sc[3]) : sc[0];
     *lp_out = p->uniform_logp + s;
     int K = p->n_modes;
+    if (p->binned) { *ll_out = binned_loglike(p->binned, t); return 1; }
     if (K == 0) { *ll_out = 0.0; return 1; }
     double a[64];
     double amax = -INFINITY;

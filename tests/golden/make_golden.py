@@ -9,11 +9,13 @@ copied: only numeric inputs/outputs of its functions are stored, as small .npz f
 
 Versions that produced the committed fixtures: numpy 2.2.6, scipy 1.15.3, python 3.10.12,
 reference cobaya v3.6.2 (no numba => scipy special_ortho_group fallback).  The third-party
-`getdist` is absent here; a 4-name stand-in (tests/golden/_getdist_stub) satisfies the
-import in cobaya/collection.py:18-19 and is never called.
+`getdist` is absent here; a 6-name stand-in (tests/golden/_getdist_stub) satisfies the
+imports in cobaya/collection.py:18-19 and likelihoods/base_classes/cmblikes.py:15 and is never called.
 
 Fixture ids follow SURVEY.md §8c (G1..G9); G10 (blocked / oversampled / dragging chains), G11
-(parameter-blocking decisions) and G12 (detempering, reweighting) were added for §8f; G2 and G8
+(parameter-blocking decisions), G12 (detempering, reweighting) and G13 (the plik-lite
+arithmetic, planck_pliklite.py:32-155, on a SYNTHETIC plik-lite-shaped data set: the Planck
+data itself is not available offline) were added for §8f; G2 and G8
 share one file (g2_g8_haar_chainstats.npz).  G3 (radial law) is a statistical test of the
 oracle's own stream (tests/test_oracle_c.py), not a stored vector.
 """
@@ -507,6 +509,114 @@ def g9_initial_covmat():
          got=s.proposer.get_covariance())
 
 
+# ---------------------------------------------------------------------------- G13
+class _Ini:
+    """The five accessors `PlanckPlikLite.init_params` uses of getdist's IniFile
+    (planck_pliklite.py:32-76), over a dict: this hands the reference its INPUT (key -> value,
+    file names under a scratch directory); it implements nothing of the likelihood."""
+
+    def __init__(self, folder, params):
+        self.folder, self.params = folder, dict(params)
+
+    def list(self, key):
+        return str(self.params[key]).split()
+
+    def int(self, key):
+        return int(self.params[key])
+
+    def int_list(self, key, default=None):
+        return [int(x) for x in str(self.params[key]).split()] if key in self.params else default
+
+    def string(self, key, default=None):
+        return str(self.params.get(key, default))
+
+    def relativeFileName(self, key):
+        return os.path.join(self.folder, self.params[key])
+
+
+def g13_pliklite():
+    """§8f-4 / BASELINE configs[4]: `PlanckPlikLite.init_params` + `get_chi_squared`
+    (planck_pliklite.py:32-155, `functions.chi_squared` 64-78) run on a synthetic data set with
+    the layout of plik_lite_v22 (215 TT + 199 TE + 199 EE bins, l = 30..2508) written to a
+    scratch directory in the reference's own file formats.  The REAL Planck data
+    (plik_lite_2018_AL.zip) and a Boltzmann code are not available here: this pins the
+    arithmetic, not the Planck numbers (tests/test_cosmo_planck_2018.py's chi2 = 584.24 stays
+    unpinned)."""
+    import tempfile
+
+    from cobaya.likelihoods.base_classes.planck_pliklite import PlanckPlikLite
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from cobaya_amd import pliklite as P  # the committed generator of the synthetic inputs
+
+    ds = P.synthetic_dataset(seed=0)
+    emu = P.synthetic_emulator(26, ds.lmax)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savetxt(os.path.join(tmp, "data.txt"), ds.data, fmt="%.17g")
+        np.savetxt(os.path.join(tmp, "blmin.txt"), ds.blmin, fmt="%d")
+        np.savetxt(os.path.join(tmp, "blmax.txt"), ds.blmax, fmt="%d")
+        np.savetxt(os.path.join(tmp, "weights.txt"), ds.weights, fmt="%.17g")
+        np.savetxt(os.path.join(tmp, "cov.txt"), ds.cov, fmt="%.17g")
+        base = {"nbintt": ds.nbintt, "nbinte": ds.nbinte, "nbinee": ds.nbinee, "lmax": ds.lmax,
+                "bin_lmin_offset": ds.bin_lmin_offset, "data": "data.txt", "blmin": "blmin.txt",
+                "blmax": "blmax.txt", "weights": "weights.txt", "cov_file": "cov.txt",
+                "cov_file_binary": "absent.bin"}
+
+        def reference_object(**over):
+            like = object.__new__(PlanckPlikLite)   # no file loader, no installer, no provider
+            like.init_params(_Ini(tmp, {**base, **over}))
+            return like
+
+        full = reference_object(use_cl="tt te ee")
+        out.update(nbintt=ds.nbintt, nbinte=ds.nbinte, nbinee=ds.nbinee, lmax=ds.lmax,
+                   bin_lmin_offset=ds.bin_lmin_offset, blmin=ds.blmin, blmax=ds.blmax,
+                   weights_file=ds.weights, data=ds.data, cov=ds.cov.astype(np.float32),
+                   ref_weights=full.weights, ref_blmin=full.blmin, ref_blmax=full.blmax,
+                   ref_X_data=full.X_data, ref_used_indices=full.used_indices,
+                   ref_invcov_diag=np.diag(full.invcov).copy(),
+                   ref_invcov_row300=full.invcov[300].copy())
+        assert np.array_equal(full.cov, ds.cov)     # the text round trip is exact
+        # (a) 64 parameter draws of the committed linear emulator, a few sigma about the fiducial
+        rs = np.random.default_rng(1313)
+        bg = P.BinnedGaussian.from_dataset(ds)
+        C = P.fisher_covariance(bg, emu)
+        Lc = np.linalg.cholesky(C)
+        z = rs.standard_normal((64, emu.n + 1)) * rs.choice([0.5, 1.0, 3.0], size=(64, 1))
+        pts = z @ Lc.T
+        theta, A = emu.theta0 + pts[:, :emu.n], 1.0 + pts[:, emu.n]
+        A[:4] = [1.0, 0.99, 1.0025, 1.01]
+        theta[0] = emu.theta0
+        chi2 = np.empty(64)
+        clsum = np.empty((64, 3))
+        for k in range(64):
+            D = emu.cl(theta[k])
+            clsum[k] = D.sum(axis=1)
+            chi2[k] = full.get_chi_squared(0, D[0], D[1], D[2], A[k])
+        out.update(emu_theta=theta, emu_A=A, emu_chi2=chi2, emu_clsum=clsum)
+        # (b) 8 explicit spectra (not from the emulator), float32-representable; L0 = 0 and 2
+        D0 = emu.D0
+        raw = (D0[None] * (1.0 + 0.05 * rs.standard_normal((8, 3, ds.lmax + 1)))).astype(np.float32)
+        raw_A = np.array([1.0, 1.0, 0.995, 1.004, 1.0, 1.02, 0.98, 1.0])
+        raw_L0 = np.array([0, 0, 0, 0, 2, 2, 2, 2])
+        raw_chi2 = np.array([full.get_chi_squared(int(L0), *(r.astype(np.float64)[:, L0:]), A_planck=a)
+                             for r, a, L0 in zip(raw, raw_A, raw_L0)])
+        out.update(raw_cl=raw, raw_A=raw_A, raw_L0=raw_L0, raw_chi2=raw_chi2)
+        # (c) bin / spectrum selections (planck_pliklite.py:84-125): TT only (the TT_lite_native
+        # flavour), an explicit bin list, an l range
+        for tag, over in (("tt", dict(use_cl="tt")),
+                          ("bins", dict(use_cl="tt te ee", use_bins=" ".join(map(str, range(10, 120, 3))))),
+                          ("lrange", dict(use_cl="te ee", bins_for_L_range="500 1200"))):
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):   # (the reference prints the l range)
+                sub = reference_object(**over)
+            out[f"sel_{tag}_used_indices"] = sub.used_indices
+            out[f"sel_{tag}_chi2"] = np.array([
+                sub.get_chi_squared(0, *emu.cl(theta[k]), A_planck=A[k]) for k in range(8)])
+    save("g13_pliklite", **out)
+
+
 if __name__ == "__main__":
     make_targets()
     g1_transforms()
@@ -519,3 +629,4 @@ if __name__ == "__main__":
     g11_param_blocking()
     g12_detempering()
     g2_g8_haar_and_chain_stats()
+    g13_pliklite()

@@ -177,12 +177,16 @@ class OracleEngine:
         self._prob()
         self._state.run(int(n_steps), walker0=self.walker_offset, n_threads=self.n_threads)
         self._steps = self._state.step
+
+    def _raise_if_stuck(self):
+        # like the real engine: only mcmc_hip_sync and mcmc_hip_fetch_moments report a walker
+        # that tripped max_tries (step is asynchronous there)
         if int(self._state.stuck[0]):
             raise ChainStuck(ERR_STUCK, "The chain has been stuck for %g attempts, stopping "
                                         "sampling." % self.max_tries)
 
     def sync(self):
-        pass
+        self._raise_if_stuck()
 
     def counters(self):
         s = self._state
@@ -220,9 +224,12 @@ class OracleEngine:
         n, gs, S = self.read_moments(reset=True)
         c = self.counters()
         self._requested = (n, gs, S, {"steps": c["steps"], "accepted": c["accepted"]})
+        self._requested_stuck = int(self._state.stuck[0])
 
     def fetch_moments(self):
         out, self._requested = self._requested, None
+        if self._requested_stuck:
+            self._raise_if_stuck()
         return out
 
     def close(self):

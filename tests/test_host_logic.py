@@ -4,6 +4,8 @@ reference-pinned oracle, and the Python mirror of the reference interface (model
 initial covmat, collection, option handling) behaves like the reference."""
 import math
 import os
+import shutil
+import subprocess
 import re
 
 import numpy as np
@@ -31,15 +33,26 @@ def test_capi_exports_every_declared_symbol():
     assert all(lib.mcmc_hip_dim_supported(d) for d in range(1, 129))
     assert not lib.mcmc_hip_dim_supported(129) and not lib.mcmc_hip_dim_supported(0)
     # every kernel translation unit the build lists is linked in (the C ABI finds them through
-    # weak per-dimension getters: a missing object would silently drop a fast path)
+    # weak per-dimension getters: a missing object would silently drop a fast path).  The getters
+    # and launchers are internal (-fvisibility=hidden): they show in the static symbol table only
     from cobaya_amd import build as B
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    local = set(subprocess.run([nm, "--defined-only", B.LIB], capture_output=True, text=True,
+                               check=True).stdout.split())
     for d in B.ALL_DIMS:
-        assert hasattr(lib, f"mcmc_hip_dim_{d}")
+        assert f"mcmc_hip_dim_{d}" in local
     for d in B.PAIR_DIMS:
-        assert hasattr(lib, f"mcmc_hip_pair_{d}")
+        assert f"mcmc_hip_pair_{d}" in local
     for dp in B.BIG_DPS:
-        assert hasattr(lib, f"mcmc_hip_big_{dp}")
-    assert hasattr(lib, "mcmc_hip_launch_general_step") and hasattr(lib, "mcmc_hip_launch_blocked_basis")
+        assert f"mcmc_hip_big_{dp}" in local
+    for name in ("mcmc_hip_launch_general_step", "mcmc_hip_launch_blocked_basis",
+                 "mcmc_hip_launch_inc_step_1", "mcmc_hip_launch_inc_step_25"):
+        assert name in local, name
+    # ... and the dynamic symbol table exports the C ABI of include/mcmc_hip.h, nothing else of ours
+    dyn = subprocess.run([nm, "-D", "--defined-only", B.LIB], capture_output=True, text=True,
+                         check=True).stdout.split()
+    exported = {t for t in dyn if t.startswith("mcmc_hip") or "mcmc" in t}
+    assert exported == declared, sorted(exported ^ declared)
     with open(os.path.join(ROOT, "cobaya_amd", "csrc", "capi.hip")) as f:
         capi = f.read()
     assert {int(x) for x in re.findall(r"MCMC_DECLARE_PAIR\((\d+)\)", capi)} == set(B.PAIR_DIMS)

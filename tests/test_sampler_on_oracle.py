@@ -275,3 +275,35 @@ def test_periodic_parameters_are_sampled_incrementally(tmp_path):
     with pytest.raises(LoggedError, match="incremental"):
         OnOracle({"n_walkers": 128, "group_size": 64, "seed": 3, "evaluation": "incremental"},
                  ProblemSpec.from_info(two))
+
+
+def test_a_stuck_walker_stops_the_run_at_the_next_checkpoint(tmp_path):
+    """the asynchronous checkpoint path (`request_moments` /
+    `fetch_moments`) never called `sync`, the only entry point that reported
+    MCMC_HIP_ERR_STUCK -- with `max_samples: inf` a stuck walker was never reported.  The stuck
+    flag now travels with the checkpoint read-out; the reference stops at once
+    (mcmc.py:717-743).  The double raises from `sync`/`fetch_moments` only, like the engine."""
+    s = make(None, np.inf, max_tries=3, learn_every="2d", steps_per_launch=8, Rminus1_stop=0.0)
+    # (acceptance ~0.3: three consecutive rejections happen within a few steps of 128 walkers)
+    with pytest.raises(LoggedError, match="stuck"):
+        s.run()
+    assert s.n_steps_raw < 200     # at the first checkpoint, not at the end of time
+
+
+@pytest.mark.parametrize("lag", [1, 2])
+def test_no_checkpoint_is_processed_after_convergence(lag):
+    """with a checkpoint interval of at most `checkpoint_lag` launches a new
+    request was queued in the pass that set `converged`, and processed after the loop: an
+    extra progress row, possibly `converged` flipped back."""
+    s = make(None, 1e9, Rminus1_stop=0.5, Rminus1_cl_stop=10.0, learn_every="5d",
+             steps_per_launch=40, checkpoint_lag=lag)
+    seen = []
+    orig = s.check_convergence_and_learn_proposal
+
+    def spy(moments=None):
+        orig(moments)
+        seen.append(bool(s.converged))
+    s.check_convergence_and_learn_proposal = spy
+    s.run()
+    assert s.converged and seen[-1] and seen.count(True) == 1
+    assert len(s.progress) == len(seen)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Start / end clock and hardware placement of every workgroup of the incremental step kernel
-(config 2), read back from a build with -DMCMC_INC_BLOCK_TIMES:
+(config 2), read back from a build with -DEXP_BLOCK_TIMES:
 
-    DQ_LO=1 DQ_HI=8 tools/exp_inc_variants.sh bt "-DMCMC_INC_BLOCK_TIMES"
+    DQ_LO=1 DQ_HI=8 tools/exp_inc_variants.sh bt "-DEXP_BLOCK_TIMES"
     MCMC_HIP_LIB=$PWD/cobaya_amd/csrc/_exp/lib_bt.so python tools/block_times.py
 
-(add -DMCMC_INC_NO_ROTATE_PRIO to see the age-ordered arbitration: workgroups ending between
+(add -DEXP_NO_ROTATE to see the age-ordered arbitration: workgroups ending between
 0.68 and 1.20 ms in three clusters)."""
 import os, sys, ctypes as C
 import numpy as np
