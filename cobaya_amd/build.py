@@ -100,13 +100,17 @@ def build(dims=None, jobs=None, verbose=True):
     general = os.path.join(CSRC, "general_kernels.hip")
     tasks.append((general, os.path.join(OBJ, "general.o"), [],
                   _digest([general] + hdrs, extra=" ".join(FLAGS))))
+    pl = os.path.join(CSRC, "pliklite_kernels.hip")
+    pl_hdr = os.path.join(CSRC, "pliklite_args.h")
+    tasks.append((pl, os.path.join(OBJ, "pliklite.o"), [],
+                  _digest([pl, pl_hdr] + hdrs, extra=" ".join(FLAGS))))
     inc = os.path.join(CSRC, "incremental_kernels.hip")
     for lo_, hi_ in INC_DQ_RANGES:
         tasks.append((inc, os.path.join(OBJ, f"incremental_{lo_}.o"),
                       [f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
                       _digest([inc] + hdrs, extra=f"inc{lo_}-{hi_}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
-                  _digest([capi, root_hdr] + hdrs, extra=" ".join(FLAGS))))
+                  _digest([capi, root_hdr, pl_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         rebuilt = list(ex.map(lambda t: _compile(*t), tasks))

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "pliklite_args.h"
 
 MCMC_DECLARE_DIM(1) MCMC_DECLARE_DIM(2) MCMC_DECLARE_DIM(3) MCMC_DECLARE_DIM(4)
 MCMC_DECLARE_DIM(5) MCMC_DECLARE_DIM(6) MCMC_DECLARE_DIM(7) MCMC_DECLARE_DIM(8)
@@ -271,6 +272,16 @@ extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, c
 extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* a, int n_groups,
                                                         hipStream_t st) __attribute__((weak));
 
+// pliklite_kernels.hip
+extern "C" hipError_t mcmc_hip_launch_pl_walker(const mcmc::PlWalkerArgs* a, int accept, int propose,
+                                                hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_prior(const double* t, int n, int d, const double* C,
+                                               uint32_t norm_mask, double uniform_logp, double* lp,
+                                               hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_residual(const mcmc::PlResidualArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_bin(const mcmc::PlBinArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_chi2(const mcmc::PlChi2Args* a, int n_walkers, hipStream_t st);
+
 struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
     const DimKernels* k = nullptr;    // d <= 32: lane-per-walker kernels of that dimension
@@ -352,10 +363,25 @@ struct mcmc_hip_ctx {
     };
     std::vector<Ev> pending;
     std::vector<hipEvent_t> pool;
-    double ms[3] = {0, 0, 0};
-    int64_t n_seen[3] = {0, 0, 0}, n_timed[3] = {0, 0, 0};   // timed regions per kind (Timed)
+    // kinds 0..2: step kernels / directions / moment snapshots; 3..5: the three kernels of a
+    // step on the binned target (pl_walker, pl_residual, pl_chi2), each launch timed
+    double ms[6] = {0, 0, 0, 0, 0, 0};
+    int64_t n_seen[6] = {0, 0, 0, 0, 0, 0}, n_timed[6] = {0, 0, 0, 0, 0, 0};   // timed regions per kind (Timed)
     int64_t n_step_launches = 0;
     std::string last_step_kernel;     // what the last step launcher said it launched
+    // binned-bandpower Gaussian target (planck_pliklite.py:143-155; pliklite_kernels.hip)
+    struct Binned {
+        bool on = false;
+        int n_bins = 0, KT = 0, ntw = 0, n_lin = 0, nlp = 0, calib = 0, lmax = 0;
+        std::vector<int32_t> bins;                       // [n_bins][3]
+        std::vector<double> Linv, Bc0, BJ;               // host copies (tests hand them to the oracle)
+        DevBuf<double> resp, theta0, Astream, weights, X;
+        DevBuf<int> dbins;
+        DevBuf<double> delta, trial, lp_t, Ea, chi2;     // step scratch, W walkers
+        DevBuf<double> edelta, etrial, elp, echi2, ecl, eA;   // evaluate scratch
+        unsigned long long tile_off[8][5];
+        int nk[8][5];
+    } bg;
 };
 
 namespace {
@@ -418,7 +444,7 @@ struct Timed {
         : h(h_), kind(kind_), st(st_ ? st_ : h_->stream)
     {
         if (h->timing) {
-            on = kind == 0 || (h->n_seen[kind] % 8) == 0;
+            on = kind == 0 || kind >= 3 || (h->n_seen[kind] % 8) == 0;
             h->n_seen[kind] += 1;
         }
         if (on) {
@@ -590,12 +616,155 @@ int set_target_common(mcmc_hip_ctx* h, int K, const double* means, const double*
         for (int k = 0; k < K; ++k) h->weight[k] = renorm ? weights[k] / s : weights[k];
     }
     h->K = K;
+    h->bg.on = false;
     h->have_target = true;
     ++h->dir_epoch;
     h->have_state = false;
     int rc = lds_check(h);
     if (rc) return rc;
     return upload_constants(h);
+}
+
+
+// ------------------------------------------------------------------ binned Gaussian target
+inline int binned_class(int R) { const int m = R & 15; return m < 8 ? m : 15 - m; }
+
+// chi2 of the residuals held in `delta` (n walkers, a multiple of 64) -> chi2
+int binned_chi2(mcmc_hip_ctx* h, const double* delta, double* chi2, int n)
+{
+    auto& B = h->bg;
+    mcmc::PlChi2Args c{};
+    c.delta = delta; c.Astream = B.Astream.p; c.chi2 = chi2;
+    std::memcpy(c.tile_off, B.tile_off, sizeof c.tile_off);
+    std::memcpy(c.nk, B.nk, sizeof c.nk);
+    c.KT = B.KT; c.ntw = B.ntw;
+    HIP_TRY(h, mcmc_hip_launch_pl_chi2(&c, n, h->stream));
+    return MCMC_HIP_OK;
+}
+
+int binned_residual(mcmc_hip_ctx* h, const double* trial, double* delta, int n)
+{
+    auto& B = h->bg;
+    mcmc::PlResidualArgs r{};
+    r.trial = trial; r.theta0 = B.theta0.p; r.resp = B.resp.p; r.delta = delta;
+    r.W = n; r.n_bins = B.n_bins; r.KT = B.KT; r.n_lin = B.n_lin; r.nlp = B.nlp; r.calib = B.calib;
+    HIP_TRY(h, mcmc_hip_launch_pl_residual(&r, h->stream));
+    return MCMC_HIP_OK;
+}
+
+// Model.logposterior for n points on the binned target (mcmc_hip_evaluate)
+int evaluate_binned_points(mcmc_hip_ctx* h, int n, const double* x, double* logprior, double* loglike)
+{
+    auto& B = h->bg;
+    const size_t d = h->d, np = ((size_t)n + 63) & ~(size_t)63;
+    std::vector<double> t(d * np);
+    for (size_t w = 0; w < np; ++w)
+        for (size_t i = 0; i < d; ++i) t[i * np + w] = x[(w < (size_t)n ? w : 0) * d + i];
+    HIP_TRY(h, B.etrial.resize(d * np));
+    HIP_TRY(h, B.elp.resize(np));
+    HIP_TRY(h, B.echi2.resize(np));
+    HIP_TRY(h, B.edelta.resize((np / 64) * (size_t)B.KT * 256 + 256));
+    HIP_TRY(h, hipMemcpyAsync(B.etrial.p, t.data(), sizeof(double) * d * np, hipMemcpyHostToDevice,
+                              h->stream));
+    HIP_TRY(h, mcmc_hip_launch_pl_prior(B.etrial.p, (int)np, (int)d, h->cblock.p, h->norm_mask,
+                                        h->uniform_logp, B.elp.p, h->stream));
+    int rc = binned_residual(h, B.etrial.p, B.edelta.p, (int)np);
+    if (rc) return rc;
+    rc = binned_chi2(h, B.edelta.p, B.echi2.p, (int)np);
+    if (rc) return rc;
+    std::vector<double> c2(np), lp(np);
+    HIP_TRY(h, hipMemcpyAsync(lp.data(), B.elp.p, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(c2.data(), B.echi2.p, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int w = 0; w < n; ++w) {
+        logprior[w] = lp[w];
+        // (the likelihood is skipped outside the prior support, model.py:650-653)
+        loglike[w] = std::isinf(lp[w]) ? -INFINITY : -0.5 * c2[w];
+    }
+    return MCMC_HIP_OK;
+}
+
+// mcmc_hip_step on the binned target: per step  [accept of the previous trial +] proposal ->
+// residuals -> chi2 on the matrix cores; a call ends with the accept of its last trial, so the
+// state is complete between calls.
+int step_binned(mcmc_hip_ctx* h, int n_steps)
+{
+    auto& B = h->bg;
+    const int d = h->d, W = h->W;
+    if (h->blocked || h->drag_last_slow >= 0 || h->own_basis || h->cfg.emit_capacity > 0 || h->any_periodic)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "the binned Gaussian target serves one parameter block, the shared basis, "
+                    "non-periodic priors and emit_capacity 0");
+    HIP_TRY(h, B.trial.resize((size_t)d * W));
+    HIP_TRY(h, B.lp_t.resize(W));
+    HIP_TRY(h, B.Ea.resize(W));
+    HIP_TRY(h, B.chi2.resize(W));
+    HIP_TRY(h, B.delta.resize(((size_t)W / 64) * (size_t)B.KT * 256 + 256));
+    const size_t dd = (size_t)mcmc::v_slab(d);
+    const int max_cyc = (int)std::max<size_t>(1, (64u << 20) / (sizeof(double) * dd * (size_t)h->G));
+    mcmc::PlWalkerArgs a{};
+    a.s.x = h->x.p; a.s.logpost = h->logpost.p; a.s.logprior = h->logprior.p;
+    a.s.loglike = h->loglike.p; a.s.weight = h->weight_i.p; a.s.prior_rej = h->prej.p;
+    a.s.burn_left = h->burn.p; a.s.n_accept = h->nacc.p; a.s.stuck = h->stuck.p;
+    a.s.accept_total = h->acc_total.p;
+    a.s.cblock = h->cblock.p; a.s.W = W; a.s.group_size = h->gs; a.s.n_modes = 0;
+    a.s.norm_mask = h->norm_mask; a.s.walker0 = h->cfg.walker_offset;
+    a.s.key0 = (uint32_t)h->cfg.seed; a.s.key1 = (uint32_t)(h->cfg.seed >> 32);
+    a.s.uniform_logp = h->uniform_logp; a.s.temperature = h->cfg.temperature;
+    a.s.max_tries = h->cfg.max_tries; a.s.cps = d; a.s.slab = (int)dd;
+    a.d = d; a.trial = B.trial.p; a.lp_t = B.lp_t.p; a.Ea = B.Ea.p; a.chi2_t = B.chi2.p;
+    int left = n_steps;
+    bool pending = false;   // a trial has been proposed and evaluated, not yet accepted / rejected
+    while (left > 0) {
+        const unsigned long long c0 = h->step / (unsigned long long)d;
+        const unsigned long long room = (c0 + (unsigned long long)max_cyc) * d - h->step;
+        const int n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+        const int ncyc = (int)((h->step + (unsigned long long)n - 1) / d - c0 + 1);
+        {
+            Timed t(h, 1);
+            HIP_TRY(h, h->V.resize((size_t)h->G * ncyc * dd));
+            mcmc::BasisArgs b{};
+            b.T = h->dT.p; b.V = h->V.p;
+            b.group0 = h->cfg.walker_offset / (uint32_t)h->gs;
+            b.cycle0 = (uint32_t)c0;
+            b.key0 = (uint32_t)h->cfg.seed; b.key1 = (uint32_t)(h->cfg.seed >> 32);
+            b.ncyc = ncyc;
+            HIP_TRY(h, h->k->basis(b, h->G, h->stream));
+        }
+        a.s.V = h->V.p; a.s.ncyc = ncyc;
+        for (int s = 0; s < n; ++s) {
+            a.s.step0 = h->step;
+            a.cyc = (int)(h->step / (unsigned long long)d - c0);
+            a.col = (int)(h->step % (unsigned long long)d);
+            {
+                Timed t(h, 3);
+                HIP_TRY(h, mcmc_hip_launch_pl_walker(&a, pending ? 1 : 0, 1, h->stream));
+            }
+            {
+                Timed t(h, 4);
+                const int rc = binned_residual(h, B.trial.p, B.delta.p, W);
+                if (rc) return rc;
+            }
+            {
+                Timed t(h, 5);
+                const int rc = binned_chi2(h, B.delta.p, B.chi2.p, W);
+                if (rc) return rc;
+                h->n_step_launches += 1;
+            }
+            pending = true;
+            h->step += 1;
+        }
+        left -= n;
+    }
+    if (pending) {
+        Timed t(h, 3);
+        HIP_TRY(h, mcmc_hip_launch_pl_walker(&a, 1, 0, h->stream));
+    }
+    if (g_noted_kernel) {
+        h->last_step_kernel = std::string(g_noted_kernel) + " (n_bins=" + std::to_string(B.n_bins) + ")";
+        g_noted_kernel = nullptr;
+    }
+    return MCMC_HIP_OK;
 }
 
 }  // namespace
@@ -777,6 +946,13 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->pack_out.release(); h->pack_off.release();
     h->y.release(); h->inc_prior.release(); h->inc_Lrow.release();
     h->inc_mean.release();
+    {
+        auto& B = h->bg;
+        B.resp.release(); B.theta0.release(); B.Astream.release(); B.weights.release();
+        B.X.release(); B.dbins.release(); B.delta.release(); B.trial.release(); B.lp_t.release();
+        B.Ea.release(); B.chi2.release(); B.edelta.release(); B.etrial.release(); B.elp.release();
+        B.echi2.release(); B.ecl.release(); B.eA.release();
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -850,11 +1026,164 @@ int mcmc_hip_set_target_one(mcmc_hip_ctx* h)
 {
     if (!h) return MCMC_HIP_ERR_ARG;
     h->K = 0;
+    h->bg.on = false;
     h->mean.clear(); h->Linv.clear(); h->cnorm.clear(); h->weight.clear();
     h->have_target = true;
     ++h->dir_epoch;
     h->have_state = false;
     return upload_constants(h);
+}
+
+int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const int32_t* bins,
+                                        int32_t lmax, const double* weights, const double* X,
+                                        const double* cov, int32_t n_lin, const double* theta0,
+                                        const double* D0, const double* J, int32_t calib_index)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!bins || !weights || !X || !cov || !theta0 || !D0 || !J)
+        return fail(h, MCMC_HIP_ERR_ARG, "null argument");
+    const int d = h->d;
+    if (!h->k || n_lin != d - 1 || n_lin < 1 || calib_index < 0 || calib_index >= d)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "the binned Gaussian target takes d - 1 = %d emulator parameters and one "
+                    "calibration parameter among 2 <= d <= 32 sampled ones (n_lin=%d, calib=%d)",
+                    d - 1, n_lin, calib_index);
+    if (n_bins < 1 || n_bins > 640 || lmax < 1)
+        return fail(h, MCMC_HIP_ERR_ARG, "n_bins must be in 1..640 (got %d) and lmax >= 1", n_bins);
+    if (h->incremental || h->own_basis || h->cfg.emit_capacity > 0)
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "the binned Gaussian target is evaluated from scratch with the shared basis "
+                    "and emit_capacity 0 (it is not Gaussian in the calibration parameter)");
+    for (int b = 0; b < n_bins; ++b) {
+        const int tp = bins[3 * b], l0 = bins[3 * b + 1], l1 = bins[3 * b + 2];
+        if (tp < 0 || tp > 2 || l0 < 0 || l1 < l0 || l1 > lmax)
+            return fail(h, MCMC_HIP_ERR_ARG, "bin %d = (%d, %d, %d) is not inside 0..%d", b, tp, l0, l1, lmax);
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto& B = h->bg;
+    const size_t n = n_bins, L1 = (size_t)lmax + 1;
+    // cov = L L^T; chi2 = |L^-1 delta|^2 (the quadratic form of functions.py:64-78)
+    std::vector<double> L(n * n);
+    B.Linv.assign(n * n, 0.0);
+    if (!is_symmetric(n_bins, cov) || !cholesky_lower(n_bins, cov, L.data()))
+        return fail(h, MCMC_HIP_ERR_NOT_PD,
+                    "the covariance of the binned data is not a symmetric positive-definite matrix");
+    tri_inverse_lower(n_bins, L.data(), B.Linv.data());
+    // binned response of the linear emulator (oracle: orc_binned_collapse)
+    B.Bc0.assign(n, 0.0);
+    B.BJ.assign(n * (size_t)n_lin, 0.0);
+    for (size_t b = 0; b < n; ++b) {
+        const size_t tp = bins[3 * b], l0 = bins[3 * b + 1], l1 = bins[3 * b + 2];
+        double acc = 0.0;
+        for (size_t l = l0; l <= l1; ++l) acc = std::fma(D0[tp * L1 + l], weights[l], acc);
+        B.Bc0[b] = acc;
+        for (int p = 0; p < n_lin; ++p) {
+            double a = 0.0;
+            for (size_t l = l0; l <= l1; ++l) a = std::fma(J[(tp * L1 + l) * n_lin + p], weights[l], a);
+            B.BJ[b * n_lin + p] = a;
+        }
+    }
+    B.n_bins = n_bins; B.lmax = lmax; B.n_lin = n_lin; B.calib = calib_index;
+    B.nlp = (n_lin + 3) & ~3;
+    B.KT = (n_bins + 3) / 4;
+    B.bins.assign(bins, bins + 3 * n);
+    const int NT = (n_bins + 15) / 16;
+    B.ntw = (NT + 7) / 8;
+    // records (Bc0_b, BJ_b0 .. BJ_b,nlp-1, X_b) and the padded fiducial point
+    std::vector<double> resp(n * (size_t)(B.nlp + 2), 0.0), th((size_t)B.nlp, 0.0);
+    for (size_t b = 0; b < n; ++b) {
+        double* r = resp.data() + b * (size_t)(B.nlp + 2);
+        r[0] = B.Bc0[b];
+        for (int p = 0; p < n_lin; ++p) r[1 + p] = B.BJ[b * n_lin + p];
+        r[1 + B.nlp] = X[b];
+    }
+    std::copy(theta0, theta0 + n_lin, th.begin());
+    // tiles of L^-1 per wave of pl_chi2_kernel: wave q owns the 16-row tiles of class q in
+    // ascending order, absent tiles first; tile R has min(4 R + 4, KT) k-steps
+    std::vector<double> As;
+    for (int q = 0; q < 8; ++q) {
+        std::vector<int> mine;
+        for (int R = 0; R < NT; ++R)
+            if (binned_class(R) == q) mine.push_back(R);
+        const int absent = B.ntw - (int)mine.size();
+        for (int t = 0; t < 5; ++t) { B.nk[q][t] = 0; B.tile_off[q][t] = 0; }
+        for (int t = 0; t < (int)mine.size(); ++t) {
+            const int R = mine[t], nk = std::min(4 * R + 4, B.KT);
+            B.nk[q][absent + t] = nk;
+            B.tile_off[q][absent + t] = As.size();
+            for (int kk = 0; kk < nk; ++kk)
+                for (int l = 0; l < 64; ++l) {
+                    const size_t j = 16 * (size_t)R + (l & 15), i = 4 * (size_t)kk + (l >> 4);
+                    As.push_back((j < n && i <= j) ? B.Linv[j * n + i] : 0.0);
+                }
+        }
+    }
+    As.resize(As.size() + 64, 0.0);   // (the fetch one k-step ahead)
+    HIP_TRY(h, B.resp.resize(resp.size()));
+    HIP_TRY(h, B.theta0.resize(th.size()));
+    HIP_TRY(h, B.Astream.resize(As.size()));
+    HIP_TRY(h, B.weights.resize(L1));
+    HIP_TRY(h, B.X.resize(n));
+    HIP_TRY(h, B.dbins.resize(3 * n));
+    HIP_TRY(h, hipMemcpy(B.resp.p, resp.data(), sizeof(double) * resp.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(B.theta0.p, th.data(), sizeof(double) * th.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(B.Astream.p, As.data(), sizeof(double) * As.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(B.weights.p, weights, sizeof(double) * L1, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(B.X.p, X, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(B.dbins.p, bins, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice));
+    B.on = true;
+    h->K = 0;
+    h->mean.clear(); h->Linv.clear(); h->cnorm.clear(); h->weight.clear();
+    h->have_target = true;
+    ++h->dir_epoch;
+    h->have_state = false;
+    return upload_constants(h);
+}
+
+int mcmc_hip_get_binned_constants(const mcmc_hip_ctx* h, double* Linv, double* Bc0, double* BJ)
+{
+    if (!h || !h->bg.on) return MCMC_HIP_ERR_STATE;
+    const auto& B = h->bg;
+    if (Linv) std::copy(B.Linv.begin(), B.Linv.end(), Linv);
+    if (Bc0) std::copy(B.Bc0.begin(), B.Bc0.end(), Bc0);
+    if (BJ) std::copy(B.BJ.begin(), B.BJ.end(), BJ);
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_evaluate_binned(mcmc_hip_ctx* h, int32_t n_pts, int32_t L0, int32_t n_ell,
+                             const double* cl, const double* A, double* chi2)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!h->bg.on) return fail(h, MCMC_HIP_ERR_STATE, "set_target_binned_gaussian must precede evaluate_binned");
+    auto& B = h->bg;
+    if (n_pts <= 0 || !cl || !A || !chi2 || L0 < 0 || n_ell <= 0)
+        return fail(h, MCMC_HIP_ERR_ARG, "bad argument");
+    for (int b = 0; b < B.n_bins; ++b)
+        if (B.bins[3 * b + 1] < L0 || B.bins[3 * b + 2] - L0 >= n_ell)
+            return fail(h, MCMC_HIP_ERR_ARG, "bin %d (l = %d..%d) is outside the spectra given (l = %d..%d)",
+                        b, B.bins[3 * b + 1], B.bins[3 * b + 2], L0, L0 + n_ell - 1);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t np = ((size_t)n_pts + 63) & ~(size_t)63;
+    HIP_TRY(h, B.ecl.resize((size_t)n_pts * 3 * n_ell));
+    HIP_TRY(h, B.eA.resize(n_pts));
+    HIP_TRY(h, B.echi2.resize(np));
+    HIP_TRY(h, B.edelta.resize((np / 64) * (size_t)B.KT * 256 + 256));
+    HIP_TRY(h, hipMemcpyAsync(B.ecl.p, cl, sizeof(double) * (size_t)n_pts * 3 * n_ell,
+                              hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(B.eA.p, A, sizeof(double) * n_pts, hipMemcpyHostToDevice, h->stream));
+    mcmc::PlBinArgs b{};
+    b.cl = B.ecl.p; b.A = B.eA.p; b.bins = B.dbins.p; b.weights = B.weights.p; b.X = B.X.p;
+    b.delta = B.edelta.p; b.n_pts = n_pts; b.n_bins = B.n_bins; b.KT = B.KT; b.L0 = L0; b.stride = n_ell;
+    HIP_TRY(h, mcmc_hip_launch_pl_bin(&b, h->stream));
+    const int rc = binned_chi2(h, B.edelta.p, B.echi2.p, (int)np);
+    if (rc) return rc;
+    std::vector<double> c2(np);
+    HIP_TRY(h, hipMemcpyAsync(c2.data(), B.echi2.p, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::copy(c2.begin(), c2.begin() + n_pts, chi2);
+    g_noted_kernel = nullptr;
+    return MCMC_HIP_OK;
 }
 
 int mcmc_hip_get_derived_constants(const mcmc_hip_ctx* h, double* uniform_logp, double* mls,
@@ -1020,6 +1349,10 @@ int mcmc_hip_evaluate(mcmc_hip_ctx* h, int32_t n, const double* x, double* logpr
     if (n <= 0 || !x || !logprior || !loglike) return fail(h, MCMC_HIP_ERR_ARG, "bad argument");
     const size_t d = h->d, Kd = (size_t)std::max(h->K, 1) * d;
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->bg.on) {
+        if (derived) return fail(h, MCMC_HIP_ERR_ARG, "the binned Gaussian target has no derived parameters");
+        return evaluate_binned_points(h, n, x, logprior, loglike);
+    }
     HIP_TRY(h, h->ex.resize((size_t)n * d));
     HIP_TRY(h, h->elp.resize(n));
     HIP_TRY(h, h->ell.resize(n));
@@ -1423,6 +1756,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         return fail(h, MCMC_HIP_ERR_STATE, "set_state and set_proposal_cov must precede step");
     if (n_steps <= 0) return fail(h, MCMC_HIP_ERR_ARG, "n_steps must be > 0");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (h->bg.on) return step_binned(h, n_steps);
     if (h->incremental) return step_incremental(h, n_steps);
     const bool drag = h->drag_last_slow >= 0;
     // steps (= direction columns) per cycle, doubles per (group, cycle) slab of directions
@@ -1874,10 +2208,25 @@ int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launche
     resolve_timing(h);
     for (int i = 0; i < 3; ++i)   // (kinds 1 and 2 are sampled: scaled to all their regions)
         ms[i] = h->n_timed[i] > 0 ? h->ms[i] * ((double)h->n_seen[i] / (double)h->n_timed[i]) : 0.0;
+    if (h->bg.on) ms[0] = h->ms[3] + h->ms[4] + h->ms[5];   // the three kernels of a step
     if (n_step_launches) *n_step_launches = h->n_step_launches;
     if (reset) {
-        for (int i = 0; i < 3; ++i) { h->ms[i] = 0.0; h->n_seen[i] = h->n_timed[i] = 0; }
+        for (int i = 0; i < 6; ++i) { h->ms[i] = 0.0; h->n_seen[i] = h->n_timed[i] = 0; }
         h->n_step_launches = 0;
+    }
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_binned_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t n_launches[3], int32_t reset)
+{
+    if (!h || !ms || !n_launches) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    resolve_timing(h);
+    for (int i = 0; i < 3; ++i) {
+        ms[i] = h->ms[3 + i];
+        n_launches[i] = h->n_timed[3 + i];
+        if (reset) { h->ms[3 + i] = 0.0; h->n_seen[3 + i] = h->n_timed[3 + i] = 0; }
     }
     return MCMC_HIP_OK;
 }

@@ -1,0 +1,45 @@
+// Kernel arguments of pliklite_kernels.hip (shared with capi.hip).
+#pragma once
+#include "kernels.h"
+
+namespace mcmc {
+
+// ---- binned-bandpower Gaussian likelihood (pliklite_kernels.hip; planck_pliklite.py:143-155)
+struct PlWalkerArgs {
+    StepArgs s;            // state, prior constants (cblock, ConstLayout{d, 0}), V, keys;
+                           // s.step0 = the step PROPOSED by this launch, s.ncyc cycles in V
+    int d;
+    int cyc, col;          // cycle (relative to the first one held in V) and column of that step
+    double* trial;         // [d][W] trial points
+    double* lp_t;          // [W] log-prior of the trial, -inf outside the support
+    double* Ea;            // [W] Exp(1) variate of the accept test
+    const double* chi2_t;  // [W] chi2 of the trial (pl_chi2_kernel)
+};
+struct PlResidualArgs {
+    const double* trial;   // [d][W]
+    const double* theta0;  // [nlp] fiducial parameters (zero beyond n_lin)
+    const double* resp;    // [n_bins][nlp + 2] records (Bc0_b, BJ_b0 .. BJ_b,nlp-1, X_b)
+    double* delta;         // [W / 64][KT][4][64]: B-operand order of pl_chi2_kernel
+    int W, n_bins, KT, n_lin, nlp, calib;
+};
+struct PlBinArgs {
+    const double* cl;      // [n_pts][3][stride], element l - L0 of a row is D_l
+    const double* A;       // [n_pts] calibration
+    const int* bins;       // [n_bins][3] (spectrum, first l, last l)
+    const double* weights; // [lmax + 1]
+    const double* X;       // [n_bins]
+    double* delta;         // as PlResidualArgs
+    int n_pts, n_bins, KT, L0, stride;
+};
+struct PlChi2Args {
+    const double* delta;   // [W / 64][KT][4][64] + one k-step (256 doubles) of padding
+    const double* Astream; // tile t of wave q at tile_off[q][t]: [nk[q][t]][64] doubles,
+                           // k-step kk = L^-1[16 R + (l & 15)][4 kk + (l >> 4)]; 64 doubles of
+                           // padding behind the last tile (the fetch one k-step ahead)
+    double* chi2;          // [W]
+    unsigned long long tile_off[8][5];   // (absent tiles: any valid offset)
+    int nk[8][5];          // k-steps of tile t of wave q: ascending in t, absent tiles first (0)
+    int KT, ntw;
+};
+
+}  // namespace mcmc

@@ -1,0 +1,343 @@
+// The binned-bandpower Gaussian likelihood of cobaya/likelihoods/base_classes/planck_pliklite.py
+// (PlanckPlikLite.get_chi_squared, 143-155, + functions.chi_squared, functions.py:64-78) for an
+// ensemble of walkers on gfx950, and the Metropolis step around it (mcmc.py:545-562, 670-748).
+//
+//     chi2(x) = delta^T Sigma^-1 delta,   delta_b = X_b - cl_b / A_planck^2,
+//     cl_b    = sum_{l in bin b} D_l weights_l           (613 bins at plik_lite_v22's layout)
+//
+// The 2 n_bins^2 flops of the quadratic form are the evaluation (751 kflop at 613 bins, against
+// 15 kflop of binning), and the one place on Cobaya's mcmc path where a batched dense FP64 GEMM is
+// the natural kernel: with cov = L L^T,  chi2 = |L^-1 delta|^2  is a TRIANGULAR product
+// Y[n_bins x walkers] = L^-1 Delta followed by a column sum of squares -- half the flops of
+// Sigma^-1 delta, on v_mfma_f64_16x16x4_f64, which accumulates k in ascending order with one
+// rounding per product-sum (tools/probes/mfma_f64_order.hip), i.e. y_j is bit for bit the fma
+// chain of the oracle (oracle/mcmc_oracle.c: orc_binned_chi2_of_delta).
+//
+// A Metropolis step is four launches -- the calibration parameter A_planck makes the target
+// non-Gaussian in x, so there is no incremental form and every trial is evaluated from scratch:
+//     pl_walker_kernel    accept/reject of the previous trial, variates and trial of this step,
+//                         prior (lane per walker)
+//     pl_residual_kernel  delta of every trial from the binned response of the linear Cl(theta)
+//                         stand-in (lane per walker, wave-uniform operands through the scalar cache)
+//     pl_chi2_kernel      the triangular GEMM on the matrix cores (below)
+// (the accept of step s and the proposal of step s + 1 share a launch).  The intermediate delta
+// crosses HBM once each way (9.8 KB per evaluation against 376 kflop: 38 flop/B, MFMA-bound).
+//
+// pl_chi2_kernel: a workgroup of 8 waves owns 64 walkers (4 walker tiles of 16 = the N of the
+// MFMA); wave q owns the 16-row tiles R of L^-1 with class(R) = q (a snake deal: the cost of a
+// tile grows with R) and keeps ALL their accumulators -- 5 tiles x 4 walker tiles x 4 doubles --
+// in registers while the k loop runs OUTSIDE: per k-step (4 columns) it loads one 16 x 4 tile of
+// L^-1 per active row tile (global memory, 512 B in A-operand lane order, used for 4 MFMAs) and
+// the 4 x 16 slices of delta of its four walker tiles (B operands, shared by the active tiles:
+// used for up to 5 MFMAs each), one k-step ahead of the MFMAs; the loop is cut into one phase per
+// set of active tiles (tile R is finished after k-step 4 R + 3), so an iteration has no branch.  Every tile of L^-1 is read once
+// per workgroup (1.5 MB per 64 walkers from L2), delta once per wave; nothing passes through LDS
+// but the final 8 x 4 partial sums per walker.
+#include "det_math.h"
+#include "pliklite_args.h"
+
+namespace mcmc {
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(4))) * cptr;
+__device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(unsigned long long)p; }
+
+// ------------------------------------------------------------------------------ walkers
+// ACCEPT: the Metropolis test of the trial a previous launch proposed and evaluated
+// (mcmc.py:670-683) and the bookkeeping of mcmc.py:685-748 -- step_general_kernel's, without
+// emitted rows.  PROPOSE: variates of step a.step (un-paired stream), trial t = fma(r, v, x)
+// along the group's direction (proposal.py:69, 224), prior support and normal priors
+// (prior.py:733-763; one ascending chain, d <= 32).
+template <bool ACCEPT, bool PROPOSE>
+__global__ void __launch_bounds__(64) pl_walker_kernel(const PlWalkerArgs a)
+{
+    const StepArgs& s = a.s;
+    const int d = a.d, W = s.W;
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    const ConstLayout cl{d, 0};
+    const double* __restrict__ C = s.cblock;
+    const uint32_t gid = s.walker0 + (uint32_t)w;
+    bool accept = false;
+    if (ACCEPT) {
+        double lpost = s.logpost[w];
+        int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
+        const double lp = a.lp_t[w], Ea = a.Ea[w];
+        const bool inb = lp != -INFINITY;
+        const double ll = -0.5 * a.chi2_t[w];                  // planck_pliklite.py:171
+        const double lt = inb ? lp + ll : -INFINITY;
+        accept = inb && lt != -INFINITY && (lt > lpost || Ea > (lpost - lt) / s.temperature);
+        if (accept) {
+            if (burn > 0) --burn;
+            s.logprior[w] = lp; s.loglike[w] = ll; s.logpost[w] = lt;
+            s.n_accept[w] += 1;
+        }
+        prej = accept ? 0 : (prej + (inb ? 0 : 1));
+        wt = accept ? 1 : wt + 1;
+        if (!accept) {
+            const double max_now = s.max_tries * (burn > 0 ? 10.0 : 1.0);
+            if ((double)(wt - prej) > max_now) atomicCAS(s.stuck, 0, 1 + (int)gid);
+        }
+        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
+        wave_add_accepts(s.accept_total, accept ? 1 : 0);
+    }
+    double r = 0.0, Ea = 0.0;
+    const double* __restrict__ v = nullptr;
+    if (PROPOSE) {
+        StepRng rng;
+        rng.begin(s.key0, s.key1, gid, s.step0);
+        rng.run_all();
+        r = rng.r; Ea = rng.Ea;
+        const int group = __builtin_amdgcn_readfirstlane(w / s.group_size);
+        v = s.V + ((size_t)group * s.ncyc + a.cyc) * (size_t)s.slab + (size_t)a.col * d;
+    }
+    bool inb = true;
+    double sc = 0.0;
+    for (int i = 0; i < d; ++i) {
+        double xi = s.x[(size_t)i * W + w];
+        if (ACCEPT && accept) {
+            xi = a.trial[(size_t)i * W + w];
+            s.x[(size_t)i * W + w] = xi;
+        }
+        if (PROPOSE) {
+            const double t = fma(r, v[i], xi);
+            a.trial[(size_t)i * W + w] = t;
+            inb = inb && t <= C[cl.hi() + i] && t >= C[cl.lo() + i];
+            if ((s.norm_mask >> i) & 1u) {
+                const double q = (t - C[cl.loc() + i]) / C[cl.scale() + i];
+                sc = sc + fma(-0.5 * q, q, C[cl.mls() + i]);
+            }
+        }
+    }
+    if (PROPOSE) {
+        a.lp_t[w] = inb ? s.uniform_logp + sc : -INFINITY;
+        a.Ea[w] = Ea;
+    }
+}
+
+// log-prior of given points t[d][n] (mcmc_hip_evaluate; prior.py:733-763)
+__global__ void __launch_bounds__(64) pl_prior_kernel(const double* __restrict__ t, int n, int d,
+                                                     const double* __restrict__ C,
+                                                     uint32_t norm_mask, double uniform_logp,
+                                                     double* __restrict__ lp)
+{
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w >= n) return;
+    const ConstLayout cl{d, 0};
+    bool inb = true;
+    double sc = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double ti = t[(size_t)i * n + w];
+        inb = inb && ti <= C[cl.hi() + i] && ti >= C[cl.lo() + i];
+        if ((norm_mask >> i) & 1u) {
+            const double q = (ti - C[cl.loc() + i]) / C[cl.scale() + i];
+            sc = sc + fma(-0.5 * q, q, C[cl.mls() + i]);
+        }
+    }
+    lp[w] = inb ? uniform_logp + sc : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------ residuals
+// delta_b = fma(-cl_b, 1 / A^2, X_b), cl_b = Bc0_b then fma(BJ_bp, theta_p - theta0_p, .) for p
+// ascending (oracle: orc_binned_delta).  One lane per walker, 4 waves per 64 walkers, each taking
+// a quarter of the k-steps (4 bins); the records (Bc0_b, BJ_b0 .. BJ_b,NLP-1, X_b) are the same
+// for every lane: constant address space -> s_load -> SGPR operands of v_fma_f64.  Output in the
+// B-operand order of pl_chi2_kernel: delta[wg][kk][wt][16 c + n] = residual of bin 4 kk + c for
+// walker 64 wg + 16 wt + n (zero for the padding bins).
+template <int NLP>   // emulator parameters padded to a multiple of 4 (BJ and theta0 zero beyond n_lin)
+__global__ void __launch_bounds__(256) pl_residual_kernel(const PlResidualArgs a)
+{
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int wg = blockIdx.x, w = wg * 64 + lane;
+    const int W = a.W, calib = a.calib;
+    double dth[NLP];
+#pragma unroll
+    for (int p = 0; p < NLP; ++p) {
+        const int i = p + (p >= calib ? 1 : 0);
+        dth[p] = p < a.n_lin ? a.trial[(size_t)i * W + w] - a.theta0[p] : 0.0;
+    }
+    const double A = a.trial[(size_t)calib * W + w];
+    const double iA2 = 1.0 / (A * A);
+    const int KT = a.KT;
+    const int k0 = (KT * part) / 4, k1 = (KT * (part + 1)) / 4;
+    const cptr rec0 = as_const(a.resp);
+    double* __restrict__ out = a.delta + (size_t)wg * KT * 256 + (lane >> 4) * 64 + (lane & 15);
+    constexpr int RL = NLP + 2;
+    for (int kk = k0; kk < k1; ++kk) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int b = 4 * kk + c;
+            double dl = 0.0;
+            if (b < a.n_bins) {            // (wave-uniform)
+                const cptr rec = rec0 + (size_t)b * RL;
+                double cl = rec[0];
+#pragma unroll
+                for (int p = 0; p < NLP; ++p) cl = fma(rec[1 + p], dth[p], cl);
+                dl = fma(-cl, iA2, rec[1 + NLP]);
+            }
+            out[(size_t)kk * 256 + c * 16] = dl;
+        }
+    }
+}
+
+// explicit spectra (mcmc_hip_evaluate_binned = get_chi_squared's own arguments): cl_b = fma chain
+// over l ascending of D_l weights_l (np.dot, planck_pliklite.py:148-151).  One thread per
+// (point, bin); n_pts is small (tests, checks).
+__global__ void __launch_bounds__(64) pl_bin_kernel(const PlBinArgs a)
+{
+    const int pt = blockIdx.y, b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= 4 * a.KT) return;
+    double dl = 0.0;
+    if (b < a.n_bins && pt < a.n_pts) {
+        const int tp = a.bins[3 * b], l0 = a.bins[3 * b + 1], l1 = a.bins[3 * b + 2];
+        const double* __restrict__ cell = a.cl + ((size_t)pt * 3 + tp) * a.stride;
+        double acc = 0.0;
+        for (int l = l0; l <= l1; ++l) acc = fma(cell[l - a.L0], a.weights[l], acc);
+        const double A = a.A[pt];
+        dl = fma(-acc, 1.0 / (A * A), a.X[b]);
+    }
+    const int wg = pt >> 6, wt = (pt >> 4) & 3, n = pt & 15;
+    a.delta[(((size_t)wg * a.KT + (b >> 2)) * 4 + wt) * 64 + (b & 3) * 16 + n] = dl;
+}
+
+// ------------------------------------------------------------------------------ chi2
+// See the header.  NTW = row tiles per wave (ceil(ceil(n_bins / 16) / 8), <= 5).
+template <int NTW>
+__global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
+{
+    __shared__ double sp[8][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x;
+    int nk[NTW];
+    const double* __restrict__ ap[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        nk[t] = a.nk[wave][t];          // ascending in t; absent tiles first (0)
+        ap[t] = a.Astream + a.tile_off[wave][t] + lane;
+    }
+    const double* __restrict__ dl = a.delta + (size_t)wg * a.KT * 256 + lane;
+    d4 acc[NTW][4];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int wt = 0; wt < 4; ++wt) acc[t][wt] = d4{0.0, 0.0, 0.0, 0.0};
+    // operands of k-step 0; every iteration fetches those of the NEXT k-step before its own
+    // MFMAs (the streams and delta are padded by one k-step, so the last fetch is harmless)
+    double av[NTW], bv[4];
+#pragma unroll
+    for (int wt = 0; wt < 4; ++wt) bv[wt] = dl[wt * 64];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) av[t] = ap[t][0];
+    int kk = 0;
+    // phase P: the k-steps on which the tiles t >= P are active (tile t ends at k-step nk[t], and
+    // nk ascends): a fixed set of loads and MFMAs per iteration, no branch inside
+#pragma unroll
+    for (int P = 0; P < NTW; ++P) {
+        for (; kk < nk[P]; ++kk) {
+            double an[NTW], bn[4];
+#pragma unroll
+            for (int wt = 0; wt < 4; ++wt) bn[wt] = dl[((size_t)(kk + 1) * 4 + wt) * 64];
+#pragma unroll
+            for (int t = P; t < NTW; ++t) an[t] = ap[t][(size_t)(kk + 1) * 64];
+#pragma unroll
+            for (int t = P; t < NTW; ++t)
+#pragma unroll
+                for (int wt = 0; wt < 4; ++wt)
+                    acc[t][wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[wt], acc[t][wt], 0, 0, 0);
+#pragma unroll
+            for (int t = P; t < NTW; ++t) av[t] = an[t];
+#pragma unroll
+            for (int wt = 0; wt < 4; ++wt) bv[wt] = bn[wt];
+        }
+    }
+    // lane 16 c + n holds the rows 16 R + 4 r + c of walker n (tile R, register r): the chain
+    // p[q][c] runs over the wave's tiles in ascending R, r = 0..3
+    const int c = lane >> 4, n = lane & 15;
+#pragma unroll
+    for (int wt = 0; wt < 4; ++wt) {
+        double p = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+            if (nk[t] > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p = fma(acc[t][wt][r], acc[t][wt][r], p);
+            }
+        sp[wave][c][wt * 16 + n] = p;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double sq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            sq[q] = (sp[q][0][tid] + sp[q][1][tid]) + (sp[q][2][tid] + sp[q][3][tid]);
+        a.chi2[(size_t)wg * 64 + tid] =
+            ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
+    }
+}
+
+}  // namespace
+}  // namespace mcmc
+
+using namespace mcmc;
+
+extern "C" hipError_t mcmc_hip_launch_pl_walker(const PlWalkerArgs* a, int accept, int propose,
+                                                hipStream_t st)
+{
+    const dim3 g(a->s.W / 64), b(64);
+    if (accept && propose) hipLaunchKernelGGL((pl_walker_kernel<true, true>), g, b, 0, st, *a);
+    else if (accept) hipLaunchKernelGGL((pl_walker_kernel<true, false>), g, b, 0, st, *a);
+    else hipLaunchKernelGGL((pl_walker_kernel<false, true>), g, b, 0, st, *a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_prior(const double* t, int n, int d, const double* C,
+                                               uint32_t norm_mask, double uniform_logp, double* lp,
+                                               hipStream_t st)
+{
+    hipLaunchKernelGGL(pl_prior_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t, n, d, C, norm_mask,
+                       uniform_logp, lp);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_residual(const PlResidualArgs* a, hipStream_t st)
+{
+    const dim3 g(a->W / 64), b(256);
+    switch (a->nlp) {
+    case 4: hipLaunchKernelGGL(pl_residual_kernel<4>, g, b, 0, st, *a); break;
+    case 8: hipLaunchKernelGGL(pl_residual_kernel<8>, g, b, 0, st, *a); break;
+    case 12: hipLaunchKernelGGL(pl_residual_kernel<12>, g, b, 0, st, *a); break;
+    case 16: hipLaunchKernelGGL(pl_residual_kernel<16>, g, b, 0, st, *a); break;
+    case 20: hipLaunchKernelGGL(pl_residual_kernel<20>, g, b, 0, st, *a); break;
+    case 24: hipLaunchKernelGGL(pl_residual_kernel<24>, g, b, 0, st, *a); break;
+    case 28: hipLaunchKernelGGL(pl_residual_kernel<28>, g, b, 0, st, *a); break;
+    case 32: hipLaunchKernelGGL(pl_residual_kernel<32>, g, b, 0, st, *a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_bin(const PlBinArgs* a, hipStream_t st)
+{
+    const int padded = (a->n_pts + 63) & ~63;
+    hipLaunchKernelGGL(pl_bin_kernel, dim3((4 * a->KT + 63) / 64, padded), dim3(64), 0, st, *a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_chi2(const PlChi2Args* a, int n_walkers, hipStream_t st)
+{
+    const dim3 g(n_walkers / 64), b(512);
+    switch (a->ntw) {
+    case 1: hipLaunchKernelGGL(pl_chi2_kernel<1>, g, b, 0, st, *a); break;
+    case 2: hipLaunchKernelGGL(pl_chi2_kernel<2>, g, b, 0, st, *a); break;
+    case 3: hipLaunchKernelGGL(pl_chi2_kernel<3>, g, b, 0, st, *a); break;
+    case 4: hipLaunchKernelGGL(pl_chi2_kernel<4>, g, b, 0, st, *a); break;
+    case 5: hipLaunchKernelGGL(pl_chi2_kernel<5>, g, b, 0, st, *a); break;
+    default: return hipErrorInvalidValue;
+    }
+    static const char* const names[5] = {"mcmc::pl_chi2_kernel<1>", "mcmc::pl_chi2_kernel<2>",
+                                         "mcmc::pl_chi2_kernel<3>", "mcmc::pl_chi2_kernel<4>",
+                                         "mcmc::pl_chi2_kernel<5>"};
+    mcmc_hip_note_step_kernel(names[a->ntw - 1]);
+    return hipGetLastError();
+}

@@ -58,6 +58,13 @@ SYMBOLS = [
      [_H, C.c_int32, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_set_target_gaussian", C.c_int, [_H, c_double_p, c_double_p, C.c_int32]),
     ("mcmc_hip_set_target_one", C.c_int, [_H]),
+    ("mcmc_hip_set_target_binned_gaussian", C.c_int,
+     [_H, C.c_int32, c_int32_p, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int32,
+      c_double_p, c_double_p, c_double_p, C.c_int32]),
+    ("mcmc_hip_evaluate_binned", C.c_int,
+     [_H, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
+    ("mcmc_hip_get_binned_constants", C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
+    ("mcmc_hip_binned_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
     ("mcmc_hip_set_blocking", C.c_int, [_H, C.c_int32, c_int32_p, c_int32_p, c_int32_p,
                                         C.c_int32, C.c_int32]),
     ("mcmc_hip_cycle_length", C.c_int, [_H]),
@@ -233,6 +240,48 @@ class Engine:
         self._check(self._lib.mcmc_hip_set_target_gaussian(self._h, _dp(mean), _dp(cov),
                                                            int(bool(normalized))))
         self.K = 1
+
+    def set_target_binned_gaussian(self, target, emulator, calib_index):
+        """`target`: a `cobaya_amd.pliklite.BinnedGaussian` (what PlanckPlikLite.init_params
+        leaves on the likelihood, planck_pliklite.py:32-141); `emulator`: a `LinearClEmulator`
+        for the d - 1 other sampled parameters; `calib_index`: position of the calibration
+        parameter among the sampled ones."""
+        bins = np.ascontiguousarray(target.bin_table(), dtype=np.int32)
+        n = len(bins)
+        w = _f64(target.weights, (target.lmax + 1,))
+        X, cov = _f64(target.X_data, (n,)), _f64(target.cov, (n, n))
+        th = _f64(emulator.theta0, (self.d - 1,))
+        D0 = _f64(emulator.D0, (3, target.lmax + 1))
+        J = _f64(emulator.J, (3, target.lmax + 1, self.d - 1))
+        self._check(self._lib.mcmc_hip_set_target_binned_gaussian(
+            self._h, n, _ip(bins), int(target.lmax), _dp(w), _dp(X), _dp(cov), self.d - 1,
+            _dp(th), _dp(D0), _dp(J), int(calib_index)))
+        self.K = 0
+        self.n_bins = n
+
+    def binned_constants(self):
+        n = self.n_bins
+        Linv, Bc0, BJ = np.empty((n, n)), np.empty(n), np.empty((n, self.d - 1))
+        self._check(self._lib.mcmc_hip_get_binned_constants(self._h, _dp(Linv), _dp(Bc0), _dp(BJ)))
+        return {"Linv": Linv, "Bc0": Bc0, "BJ": BJ}
+
+    def evaluate_binned(self, L0, cl, A):
+        """chi2[n] = get_chi_squared(L0, cl[k, 0], cl[k, 1], cl[k, 2], A[k]) on the device."""
+        cl = _f64(cl)
+        n, three, n_ell = cl.shape
+        assert three == 3
+        A = _f64(np.broadcast_to(np.asarray(A, dtype=np.float64), (n,)))
+        out = np.empty(n)
+        self._check(self._lib.mcmc_hip_evaluate_binned(self._h, n, int(L0), n_ell, _dp(cl), _dp(A),
+                                                       _dp(out)))
+        return out
+
+    def binned_kernel_times(self, reset=False):
+        ms, n = np.zeros(3), np.zeros(3, np.int64)
+        self._check(self._lib.mcmc_hip_binned_kernel_times(self._h, _dp(ms), n.ctypes.data_as(c_int64_p),
+                                                           int(bool(reset))))
+        return {"walker_ms": ms[0], "residual_ms": ms[1], "chi2_ms": ms[2],
+                "launches": [int(v) for v in n]}
 
     def set_target_one(self):
         self._check(self._lib.mcmc_hip_set_target_one(self._h))

@@ -167,7 +167,7 @@ def plik_lite_bins(lmin=30, lmax=2508, nbin_pol=199):
     (l <= 1996).  Returns (blmin, blmax) relative to `lmin`, and the pol bin count."""
     edges, l = [], lmin
     for width, stop in ((5, 100), (9, 1504), (17, 2014), (33, lmax + 1)):
-        while l < stop:
+        while l < min(stop, lmax + 1):
             edges.append((l, min(l + width - 1, lmax)))
             l += width
     edges = np.array(edges, dtype=int)
@@ -278,10 +278,12 @@ def synthetic_dataset(seed=0, lmin=30, lmax=2508, nbin_pol=199, band=8):
                            blmin=bmin, blmax=bmax, weights=w, data=data, cov=cov)
 
 
-def fisher_covariance(target: BinnedGaussian, emu: LinearClEmulator, calib_prior_sigma=0.0025):
+def fisher_covariance(target: BinnedGaussian, emu: LinearClEmulator, calib_prior_sigma=0.0025,
+                      theta_prior_sigma=10.0):
     """Gaussian approximation of the posterior of (theta, A_planck) at the fiducial point: the
     Fisher matrix of the binned model (a proposal covariance for the sampler, sampler.py:485-685
-    `covmat`; at A = 1, d binned / dA = -2 binned)."""
+    `covmat`; at A = 1, d binned / dA = -2 binned).  `theta_prior_sigma` bounds the directions
+    the selected bins do not constrain (e.g. the polarisation amplitude with TT alone)."""
     L = target.lmax
     tab = target.bin_table()
     Bm = np.zeros((target.n_bins, emu.n + 1))
@@ -292,4 +294,5 @@ def fisher_covariance(target: BinnedGaussian, emu: LinearClEmulator, calib_prior
     assert L == emu.lmax
     F = Bm.T @ np.linalg.solve(target.cov, Bm)
     F[emu.n, emu.n] += 1.0 / calib_prior_sigma ** 2
+    F[np.arange(emu.n), np.arange(emu.n)] += 1.0 / theta_prior_sigma ** 2
     return np.linalg.inv(F)

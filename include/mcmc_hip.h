@@ -99,6 +99,35 @@ MCMC_HIP_API int mcmc_hip_set_target_gaussian(mcmc_hip_ctx* h, const double* mea
 /* likelihoods/one/one.py:27-29: loglike = 0 (prior-only sampling) */
 MCMC_HIP_API int mcmc_hip_set_target_one(mcmc_hip_ctx* h);
 
+/* PlanckPlikLite.init_params (cobaya/likelihoods/base_classes/planck_pliklite.py:32-141) for the
+ * used bins, + the Cl provider of `logp` (planck_pliklite.py:170-178) as a LINEAR emulator:
+ *   bins[n_bins*3] = (spectrum 0 tt / 1 te / 2 ee, first l, last l) of every used bin in
+ *   data-vector order (`used_indices`); weights[lmax+1] in D_l space (planck_pliklite.py:52-56);
+ *   X[n_bins] = X_data; cov[n_bins*n_bins] row-major (the reference inverts it, :141; here
+ *   chi2 = |L^-1 delta|^2 with cov = L L^T, the same quadratic form);
+ *   D_l(theta) = D0[tp*(lmax+1)+l] + sum_p J[(tp*(lmax+1)+l)*n_lin+p] (theta_p - theta0_p), theta =
+ *   the sampled parameters without the calibration parameter (`calibration_param`, A_planck) at
+ *   position calib_index, in order; n_lin = d - 1.
+ * loglike = -chi2/2, chi2 = get_chi_squared(0, D_tt, D_te, D_ee, A) (planck_pliklite.py:143-155).
+ * Binning commutes with the linear emulator: the library bins D0 and J once and evaluates
+ * cl_b(theta) from that binned response (specification: oracle/mcmc_oracle.c, orc_binned).
+ * n_bins <= 640, 2 <= d <= 32, evaluation from scratch (no MCMC_HIP_FLAG_INCREMENTAL: the
+ * posterior is not Gaussian in the calibration parameter), shared basis, emit_capacity 0. */
+MCMC_HIP_API int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const int32_t* bins,
+                                        int32_t lmax, const double* weights, const double* X,
+                                        const double* cov, int32_t n_lin, const double* theta0,
+                                        const double* D0, const double* J, int32_t calib_index);
+/* PlanckPlikLite.get_chi_squared(L0, ctt, cte, cee, A_planck) (planck_pliklite.py:143-155) for
+ * n_pts sets of EXPLICIT spectra: cl[n_pts*3*n_ell], element l - L0 of row (pt, spectrum) is
+ * D_l; A[n_pts]; chi2[n_pts] out.  Binning on the device as the banded product it is, then the
+ * same matrix-core kernel as the sampler's steps. */
+MCMC_HIP_API int mcmc_hip_evaluate_binned(mcmc_hip_ctx* h, int32_t n_pts, int32_t L0, int32_t n_ell,
+                             const double* cl, const double* A, double* chi2);
+/* Constants derived by set_target_binned_gaussian: Linv[n_bins*n_bins] (functions.py:81-89 of
+ * cov), the binned response Bc0[n_bins], BJ[n_bins*n_lin]; any pointer may be NULL.  Lets tests
+ * hand the CPU oracle exactly the problem the kernels evaluate. */
+MCMC_HIP_API int mcmc_hip_get_binned_constants(const mcmc_hip_ctx* h, double* Linv, double* Bc0, double* BJ);
+
 /* BlockedProposer.__init__ (proposal.py:96-196) + MCMC.set_proposer_blocking (mcmc.py:320-410):
  * n_blocks parameter blocks sorted slow -> fast, block b holding block_size[b] consecutive
  * entries of i_of_j[d] (sampler indices in sorted order) and visited oversampling[b] *
@@ -226,6 +255,9 @@ MCMC_HIP_API int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
  * profiles and bench lines quote the kernel that ran ("" before the first step) */
 MCMC_HIP_API const char* mcmc_hip_last_step_kernel(const mcmc_hip_ctx* h);
 MCMC_HIP_API int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset);
+/* binned Gaussian target: HIP-event time (ms) and number of launches of the three kernels of a
+ * step -- pl_walker_kernel, pl_residual_kernel, pl_chi2_kernel -- since the last reset */
+MCMC_HIP_API int mcmc_hip_binned_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t n_launches[3], int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ class _Binned(C.Structure):
         ("n_bins", C.c_int32), ("lmax", C.c_int32), ("n_lin", C.c_int32), ("calib", C.c_int32),
         ("bins", c_int32_p), ("weights", c_double_p), ("X", c_double_p), ("Linv", c_double_p),
         ("theta0", c_double_p), ("D0", c_double_p), ("J", c_double_p),
+        ("Bc0", c_double_p), ("BJ", c_double_p),
     ]
 
 
@@ -127,6 +128,7 @@ def lib():
         L.orc_binned_chi2_of_delta.restype = C.c_double
         L.orc_binned_chi2_of_delta.argtypes = [C.POINTER(_Binned), c_double_p]
         L.orc_binned_delta.argtypes = [C.POINTER(_Binned), c_double_p, c_double_p]
+        L.orc_binned_collapse.argtypes = [C.POINTER(_Binned), c_double_p, c_double_p]
         L.orc_binned_chi2_of_cl.argtypes = [C.POINTER(_Binned), C.c_int, C.c_int, C.c_int,
                                             c_double_p, c_double_p, c_double_p]
         _lib = L
@@ -228,6 +230,11 @@ class Binned:
         b.bins, b.weights, b.X, b.Linv = _ip(self.bins), _dp(self.weights), _dp(self.X), _dp(self.Linv)
         b.theta0, b.D0, b.J = _dp(self.theta0), _dp(self.D0), _dp(self.J)
         self.calib = int(calib)
+        # the binned response of the linear emulator (formed once, in the specified order)
+        self.Bc0 = np.zeros(n)
+        self.BJ = np.zeros((n, max(self.n_lin, 1)))
+        lib().orc_binned_collapse(C.byref(b), _dp(self.Bc0), _dp(self.BJ))
+        b.Bc0, b.BJ = _dp(self.Bc0), _dp(self.BJ)
         self.c = b
 
     def chi2_of_cl(self, L0, cl, A):

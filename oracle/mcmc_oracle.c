@@ -219,11 +219,16 @@ typedef struct {
 
 /* The plik-lite arithmetic (cobaya/likelihoods/base_classes/planck_pliklite.py:143-155 +
  * functions.py:64-78) with the operation order of the device kernels (pliklite_kernels.hip):
- *   spectra   D_l = D0[tp][l] then fma(J[tp][l][p], theta_p - theta0_p, .) for p ascending
- *             (the linear stand-in for provider.get_Cl, planck_pliklite.py:170-178; theta = the
- *             sampled parameters without the calibration parameter, in order);
- *   binning   cl_b = fma chain over l = first..last ascending of D_l * weights[l], from +0
- *             (np.dot of planck_pliklite.py:148-151);
+ *   response  the stand-in for provider.get_Cl (planck_pliklite.py:170-178) is LINEAR,
+ *             D_l(theta) = D0[tp][l] + sum_p J[tp][l][p] (theta_p - theta0_p), theta = the sampled
+ *             parameters without the calibration parameter, in order; binning (np.dot of
+ *             planck_pliklite.py:148-151) commutes with it, so the binned response is formed ONCE
+ *             (orc_binned_collapse; mcmc_hip_set_target_binned_gaussian does the same):
+ *             Bc0_b = fma chain over l = first..last ascending of D0[tp][l] * weights[l] from +0,
+ *             BJ_bp likewise with J[tp][l][p];
+ *   binning   per point cl_b = Bc0_b then fma(BJ_bp, theta_p - theta0_p, .) for p ascending.
+ *             For EXPLICIT spectra (orc_binned_chi2_of_cl = get_chi_squared's own signature)
+ *             cl_b = fma chain over l ascending of D_l * weights[l] from +0;
  *   residual  delta_b = fma(-cl_b, 1 / (A A), X_b)        (cl /= A_planck**2; diff = X - cl);
  *   chi2      y_j = fma chain over i = 0..j ascending of Linv[j][i] delta_i from +0, with
  *             cov = L L^T (the same quadratic form as invcov.dot(diff).dot(diff));  the squares
@@ -245,6 +250,8 @@ typedef struct orc_binned {
     const double* theta0;  /* [n_lin] */
     const double* D0;      /* [3][lmax + 1] */
     const double* J;       /* [3][lmax + 1][n_lin] */
+    const double* Bc0;     /* [n_bins]          binned response, filled by orc_binned_collapse */
+    const double* BJ;      /* [n_bins][n_lin] */
 } orc_binned;
 
 /* Blocked proposal (proposal.py:96-224): blocks sorted slow -> fast; parameter j of the
@@ -486,11 +493,29 @@ double orc_binned_chi2_of_delta(const orc_binned* b, const double* delta)
     return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-/* residual of the sampled point x[d] through the linear emulator */
+/* binned response of the linear emulator (see orc_binned): Bc0[n_bins], BJ[n_bins][n_lin] */
+void orc_binned_collapse(const orc_binned* b, double* Bc0, double* BJ)
+{
+    const int n = b->n_lin, L1 = b->lmax + 1;
+    for (int ib = 0; ib < b->n_bins; ++ib) {
+        const int tp = b->bins[3 * ib], l0 = b->bins[3 * ib + 1], l1 = b->bins[3 * ib + 2];
+        double acc = 0.0;
+        for (int l = l0; l <= l1; ++l) acc = fma(b->D0[(size_t)tp * L1 + l], b->weights[l], acc);
+        Bc0[ib] = acc;
+        for (int p = 0; p < n; ++p) {
+            double a = 0.0;
+            for (int l = l0; l <= l1; ++l)
+                a = fma(b->J[((size_t)tp * L1 + l) * n + p], b->weights[l], a);
+            BJ[(size_t)ib * n + p] = a;
+        }
+    }
+}
+
+/* residual of the sampled point x[d] through the binned response */
 void orc_binned_delta(const orc_binned* b, const double* x, double* delta)
 {
     double dth[32];
-    const int n = b->n_lin, L1 = b->lmax + 1;
+    const int n = b->n_lin;
     for (int p = 0, i = 0; p < n; ++p, ++i) {
         if (i == b->calib) ++i;
         dth[p] = x[i] - b->theta0[p];
@@ -498,15 +523,10 @@ void orc_binned_delta(const orc_binned* b, const double* x, double* delta)
     const double A = x[b->calib];
     const double iA2 = 1.0 / (A * A);
     for (int ib = 0; ib < b->n_bins; ++ib) {
-        const int tp = b->bins[3 * ib], l0 = b->bins[3 * ib + 1], l1 = b->bins[3 * ib + 2];
-        double acc = 0.0;
-        for (int l = l0; l <= l1; ++l) {
-            double cl = b->D0[(size_t)tp * L1 + l];
-            const double* Jl = b->J + ((size_t)tp * L1 + l) * n;
-            for (int p = 0; p < n; ++p) cl = fma(Jl[p], dth[p], cl);
-            acc = fma(cl, b->weights[l], acc);
-        }
-        delta[ib] = fma(-acc, iA2, b->X[ib]);
+        double cl = b->Bc0[ib];
+        const double* BJb = b->BJ + (size_t)ib * n;
+        for (int p = 0; p < n; ++p) cl = fma(BJb[p], dth[p], cl);
+        delta[ib] = fma(-cl, iA2, b->X[ib]);
     }
 }
 

@@ -688,3 +688,74 @@ def test_incremental_periodic_random_shapes_walk_the_same_chains(seed):
         moved += int(np.sum(np.abs(sa.x - before)[:, per] > 0.8 * (np.array(b) - np.array(a))[per]))
         assert np.all(sb.x[:, per] >= np.array(a)[per]) and np.all(sb.x[:, per] <= np.array(b)[per])
     assert sa.n_accept.sum() > 64 * 20
+
+
+def test_binned_gaussian_oracle_against_reference_golden_g13():
+    """§8f-4: the oracle's restatement of planck_pliklite.py:143-155 (orc_binned: binned response,
+    triangular whitening, 32 interleaved chains) against the reference's own `get_chi_squared`,
+    run on a synthetic plik-lite-shaped data set (golden G13; the Planck data is unavailable)."""
+    from cobaya_amd import pliklite as P
+    from tests.pliklite_common import load_g13
+    g, ds = load_g13()
+    t = P.BinnedGaussian.from_dataset(ds)
+    # the host mirror of init_params leaves what the reference's leaves (planck_pliklite.py:32-141)
+    assert np.array_equal(t.weights, g["ref_weights"]) and np.array_equal(t.X_data, g["ref_X_data"])
+    assert np.array_equal(t.used_indices, g["ref_used_indices"])
+    assert np.array_equal(t.blmin, g["ref_blmin"]) and np.array_equal(t.blmax, g["ref_blmax"])
+    inv = np.linalg.inv(t.cov)
+    np.testing.assert_allclose(np.diag(inv), g["ref_invcov_diag"], rtol=1e-10)
+    np.testing.assert_allclose(inv[300], g["ref_invcov_row300"], rtol=1e-8, atol=1e-12)
+    emu = P.synthetic_emulator(26, ds.lmax)
+    B = O.Binned(t.bin_table(), t.weights, t.X_data, cov=t.cov, theta0=emu.theta0, D0=emu.D0,
+                 J=emu.J, calib=26)
+    x = np.column_stack((g["emu_theta"], g["emu_A"]))
+    np.testing.assert_allclose(B.chi2_of_delta(B.delta(x)), g["emu_chi2"], rtol=1e-12)
+    cl = np.array([emu.cl(th) for th in g["emu_theta"]])
+    assert np.array_equal(cl.sum(axis=2), g["emu_clsum"])
+    np.testing.assert_allclose(B.chi2_of_cl(0, cl, g["emu_A"]), g["emu_chi2"], rtol=1e-12)
+    raw = g["raw_cl"].astype(np.float64)
+    for k in range(len(raw)):
+        L0 = int(g["raw_L0"][k])
+        np.testing.assert_allclose(B.chi2_of_cl(L0, raw[k:k + 1, :, L0:], g["raw_A"][k:k + 1]),
+                                   g["raw_chi2"][k:k + 1], rtol=1e-12)
+    for tag, kw in (("tt", dict(use_cl=["tt"])), ("bins", dict(use_bins=list(range(10, 120, 3)))),
+                    ("lrange", dict(use_cl=["te", "ee"], bins_for_L_range=[500, 1200]))):
+        s = P.BinnedGaussian.from_dataset(ds, **kw)
+        assert np.array_equal(s.used_indices, g[f"sel_{tag}_used_indices"])
+        Bs = O.Binned(s.bin_table(), s.weights, s.X_data, cov=s.cov, theta0=emu.theta0, D0=emu.D0,
+                      J=emu.J, calib=26)
+        np.testing.assert_allclose(Bs.chi2_of_delta(Bs.delta(x[:8])), g[f"sel_{tag}_chi2"], rtol=1e-12)
+    # the plain numpy statement of the same lines (cobaya_amd.pliklite) agrees too
+    np.testing.assert_allclose(t.chi_squared(0, cl[3][0], cl[3][1], cl[3][2], g["emu_A"][3]),
+                               g["emu_chi2"][3], rtol=1e-12)
+
+
+def test_binned_gaussian_steps_sample_the_posterior():
+    """The oracle's Metropolis steps on the binned target (small case, 6 parameters): mean and
+    covariance of the walkers agree with the Gaussian (Fisher) approximation of the posterior --
+    exact in theta for fixed calibration, and the calibration prior is narrow."""
+    from cobaya_amd import pliklite as P
+    from tests.pliklite_common import sampling_problem, small_dataset
+    ds = small_dataset()
+    t = P.BinnedGaussian.from_dataset(ds)
+    emu = P.synthetic_emulator(5, ds.lmax)
+    kinds, a, b, C = sampling_problem(t, emu)
+    B = O.Binned(t.bin_table(), t.weights, t.X_data, cov=t.cov, theta0=emu.theta0, D0=emu.D0,
+                 J=emu.J, calib=5)
+    prob = O.Problem(6, kinds, a, b, T=O.proposal_transform(C, 2.4), group_size=64, seed=11, binned=B)
+    rng = np.random.default_rng(5)
+    W = 512
+    x0 = np.concatenate((emu.theta0, [1.0])) + rng.standard_normal((W, 6)) @ np.linalg.cholesky(C).T
+    st = O.State(prob, x0)
+    acc = st.run(400, n_threads=O.max_threads())
+    assert 0.1 < acc / (W * 400) < 0.6
+    # the posterior mean: maximum of the binned chi2 in theta at A = 1 (linear least squares)
+    Bm = np.column_stack((B.BJ, -2.0 * B.Bc0))
+    F = Bm.T @ np.linalg.solve(t.cov, Bm)
+    F[5, 5] += 1.0 / 0.0025 ** 2
+    best = np.linalg.solve(F, Bm.T @ np.linalg.solve(t.cov, t.X_data - B.Bc0))
+    mean = st.x.mean(axis=0) - np.concatenate((emu.theta0, [1.0]))
+    sig = np.sqrt(np.diag(C))
+    assert np.all(np.abs(mean - best) < 5 * sig / np.sqrt(W / 8)), (mean - best) / sig
+    ratio = st.x.std(axis=0) / sig
+    assert np.all((ratio > 0.8) & (ratio < 1.25)), ratio
