@@ -77,13 +77,17 @@ def parse():
     ap.add_argument("--evaluation", choices=("auto", "full", "incremental"), default="auto",
                     help="auto (the sampler's default): incremental evaluation where it applies")
     ap.add_argument("--no-variants", action="store_true",
-                    help="skip the extra, separately labelled measurements (emit: chains)")
+                    help="skip the extra, separately labelled measurements (evaluation: full, "
+                         "emit: chains, d = 100, the config-5 shape, planck_pliklite)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spinup-ms", type=float, default=60.0,
                     help="untimed launches before the W warmup steps until the device has been "
                          "under load this long (a cold MI355X runs the same kernel 18 %% slower "
                          "for its first ~35 ms: tools/ramp_probe.py); 0 = none")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--workload", choices=("gaussian_mixture", "pliklite"), default="gaussian_mixture",
+                    help="pliklite: ONLY the planck_pliklite variant (613 bins, d = 27), as its "
+                         "own line -- the command the profiles of pl_chi2_kernel are taken with")
     return ap.parse_args()
 
 
@@ -99,15 +103,23 @@ def target(d):
     return np.full(d, 0.5), c
 
 
-def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots", evaluation="auto"):
+def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots", evaluation="auto",
+              normal_from=None):
+    """normal_from = k: the config-5 SHAPE -- parameters k.. get normal priors N(0.5, 0.3) and the
+    likelihood is `gaussian` (delta^T Sigma^-1 delta), as the d = 27 stand-in of SURVEY 8d."""
     names = [f"a__{i}" for i in range(d)]
     sig = np.sqrt(np.diag(cov))
+    params = {n: {"prior": {"min": 0.0, "max": 1.0},
+                  "ref": {"dist": "norm", "loc": float(mean[i]), "scale": float(sig[i])}}
+              for i, n in enumerate(names)}
+    like = {"gaussian_mixture": {"means": [mean], "covs": [cov], "input_params_prefix": "a_"}}
+    if normal_from is not None:
+        for n in names[normal_from:]:
+            params[n]["prior"] = {"dist": "norm", "loc": 0.5, "scale": 0.3}
+        like = {"gaussian": {"mean": mean, "cov": cov, "input_params_prefix": "a_"}}
     return {
-        "likelihood": {"gaussian_mixture": {"means": [mean], "covs": [cov],
-                                            "input_params_prefix": "a_"}},
-        "params": {n: {"prior": {"min": 0.0, "max": 1.0},
-                       "ref": {"dist": "norm", "loc": float(mean[i]), "scale": float(sig[i])}}
-                   for i, n in enumerate(names)},
+        "likelihood": like,
+        "params": params,
         "sampler": {"mcmc_hip": {
             "seed": 1, "n_walkers": walkers, "group_size": group_size,
             "steps_per_launch": spl, "covmat": cov, "covmat_params": names,
@@ -117,6 +129,39 @@ def make_info(d, mean, cov, walkers, group_size, spl, emit="snapshots", evaluati
             "learn_proposal": True, "emit": emit, "evaluation": evaluation,
             "max_rows": 0 if emit == "snapshots" else 1 << 22}},
     }
+
+
+def pliklite_problem(n_lin):
+    """BASELINE configs[4]'s arithmetic on synthetic data (the Planck files cannot be downloaded
+    here): plik-lite-shaped data set (613 bins), linear Cl(theta) of n_lin parameters + the
+    calibration A_planck with the reference's prior (planck_calib.yaml), uniform boxes of +- 8
+    posterior sigmas on the others, proposal covariance = Fisher estimate."""
+    from cobaya_amd import pliklite as P
+    ds = P.synthetic_dataset(0)
+    tgt = P.BinnedGaussian.from_dataset(ds)
+    emu = P.synthetic_emulator(n_lin, ds.lmax)
+    C = P.fisher_covariance(tgt, emu)
+    sig = np.sqrt(np.diag(C))
+    params = {n: {"prior": {"min": float(emu.theta0[i] - 8 * sig[i]),
+                            "max": float(emu.theta0[i] + 8 * sig[i])},
+                  "ref": {"dist": "norm", "loc": float(emu.theta0[i]), "scale": float(sig[i])}}
+              for i, n in enumerate(emu.names)}
+    params["A_planck"] = {"prior": {"dist": "norm", "loc": 1.0, "scale": 0.0025},
+                          "ref": {"dist": "norm", "loc": 1.0, "scale": 0.002}}
+    return ds, tgt, emu, C, params
+
+
+def make_pliklite_info(n_lin, walkers, group_size, spl):
+    ds, tgt, emu, C, params = pliklite_problem(n_lin)
+    return {
+        "likelihood": {"plik_lite": {"class": "planck_pliklite", "dataset": ds,
+                                     "cl_emulator": emu}},
+        "params": params,
+        "sampler": {"mcmc_hip": {
+            "seed": 1, "n_walkers": walkers, "group_size": group_size, "steps_per_launch": spl,
+            "covmat": C, "covmat_params": list(params), "Rminus1_stop": 0.0,
+            "learn_proposal": True, "emit": "snapshots", "max_rows": 0}},
+    }, tgt
 
 
 def cpu_baseline(d, mean, cov, group_size, seconds, incremental):
@@ -143,6 +188,34 @@ def cpu_baseline(d, mean, cov, group_size, seconds, incremental):
             "sample": f"{W} walkers x {steps} steps of the same d={d} workload, "
                       f"{'incremental' if incremental else 'full'} evaluation, "
                       f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c)"}
+
+
+def cpu_baseline_pliklite(n_lin, seconds):
+    """The oracle's steps on the binned (plik-lite) target on this host's cores."""
+    from oracle import cbind as O
+    threads = O.max_threads()
+    ds, tgt, emu, C, params = pliklite_problem(n_lin)
+    kinds = np.array([0] * n_lin + [1], dtype=np.int32)
+    a = np.array([params[n]["prior"]["min"] for n in emu.names] + [1.0])
+    b = np.array([params[n]["prior"]["max"] for n in emu.names] + [0.0025])
+    B = O.Binned(tgt.bin_table(), tgt.weights, tgt.X_data, cov=tgt.cov, theta0=emu.theta0,
+                 D0=emu.D0, J=emu.J, calib=n_lin)
+    prob = O.Problem(n_lin + 1, kinds, a, b, T=O.proposal_transform(C, 2.4), group_size=64, seed=1,
+                     binned=B)
+    rng = np.random.default_rng(1)
+    W = 64 * max(threads // 16, 1) * 16
+    x0 = np.concatenate((emu.theta0, [1.0])) + rng.standard_normal((W, n_lin + 1)) @ np.linalg.cholesky(C).T
+    st = O.State(prob, x0)
+    st.run(1, n_threads=threads)
+    steps, dt = 0, 0.0
+    while dt < seconds:
+        t0 = time.perf_counter()
+        st.run(2, n_threads=threads)
+        dt += time.perf_counter() - t0
+        steps += 2
+    return {"value": W * steps / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{W} walkers x {steps} steps of the same {tgt.n_bins}-bin workload, "
+                      f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c, orc_binned)"}
 
 
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 1024 SIMDs, one per 4 clocks, 2.4 GHz
@@ -175,17 +248,19 @@ def measured_traffic(d, walkers, spl, kernel):
     return None, None
 
 
-def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
-    """W untimed + K timed bench steps of one sampler; returns the raw measurements."""
+def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
+    """W untimed + K timed bench steps of one sampler; returns the raw measurements.  `info`:
+    an explicit input (variants); default: the d-dim gaussian_mixture workload."""
     from cobaya_amd import dist
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
     size = dist.size()
-    spl_req = a.steps_per_launch or 40 * d
-    info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit,
-                     evaluation or a.evaluation)
-    if a.basis_group_size and (evaluation or a.evaluation) != "full":
-        info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
+    if info is None:
+        spl_req = a.steps_per_launch or 40 * d
+        info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit,
+                         evaluation or a.evaluation)
+        if a.basis_group_size and (evaluation or a.evaluation) != "full":
+            info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -247,6 +322,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.cpu()[0])
     kt = eng.kernel_times()
+    if sampler.spec.like_kind == "planck_pliklite":
+        kt["binned"] = eng.binned_kernel_times()
     res = {"dt": dt, "spl": spl, "kt": kt, "kernel": eng.last_step_kernel(),
            "evaluation": "incremental" if sampler.incremental else "full",
            "group_size": int(sampler.group_size),
@@ -255,6 +332,124 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None):
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
     sampler.close()
     return res
+
+
+def gaussian_roofline(m, d, walkers, steps):
+    """The roofline block of a Gaussian(-mixture) workload from the raw measurements of
+    `run_timed` (HIP-event kernel time of THIS run; counters from the committed PMC passes)."""
+    spl, kt, dt = m["spl"], m["kt"], m["dt"]
+    # one bench step = one engine.step(spl) call; the engine splits it into several kernel
+    # launches when the directions of spl steps exceed its 256 MiB buffer (d = 100)
+    launches_per_step = kt["step_launches"] / max(steps, 1)
+    step_ms = kt["step_ms"] / max(kt["step_launches"], 1)      # per KERNEL launch
+    evals_per_launch = walkers * spl / max(launches_per_step, 1)
+    flops = algo_flops_per_eval(d) * evals_per_launch
+    algo_bytes = algo_bytes_per_eval(d) * evals_per_launch
+    tflops = flops / (step_ms * 1e-3) / 1e12 if step_ms > 0 else None
+    algo_gbs = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None
+    kernel = m["kernel"]
+    on_matrix_cores = "mfma" in kernel
+    traffic, traffic_source = measured_traffic(d, walkers, spl, kernel)
+    overlapped = m["evaluation"] == "incremental" and not os.environ.get("MCMC_HIP_NO_PREFETCH")
+    common = {
+        "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
+        "kernel_ms_per_launch": step_ms, "kernel_launches_per_step": launches_per_step,
+        "evals_per_kernel_launch": evals_per_launch,
+        # SURVEY 8d's HBM figure, kept for reference: what the state would move if it were
+        # persisted every step.  It is NOT a bandwidth the kernel achieves (x_peak may
+        # exceed 1): compare `traffic`, the bytes that really cross HBM.
+        "algorithmic_hbm": {
+            "bytes_per_eval": algo_bytes_per_eval(d), "bytes_per_launch": algo_bytes,
+            "GBps": algo_gbs, "x_peak": algo_gbs / HBM_PEAK_GBS if algo_gbs else None,
+            "measured_fraction_of_algorithmic": (traffic / algo_bytes) if traffic else None},
+        # incremental evaluation: the directions of the NEXT launch are computed on a second
+        # stream behind the step kernel, beside the moment snapshot and the refresh of y
+        # (capi.hip, DirSet); their elapsed time is then not part of the critical path
+        "basis_kernel_ms_per_launch": kt["basis_ms"] / max(steps, 1),
+        "basis_on_second_stream": overlapped,
+        "moments_ms_per_launch": kt["moments_ms"] / max(steps, 1),
+        "host_and_checkpoint_ms_per_step": 1e3 * dt / steps - (
+            kt["step_ms"] + (0.0 if overlapped else kt["basis_ms"]) + kt["moments_ms"])
+        / max(steps, 1)}
+    if m["evaluation"] == "incremental":
+        # O(d) per step: most of the instructions are not FP64 multiply-adds (two compares
+        # per dimension for the prior support, Philox, two logarithms, a square root), so
+        # the roof that binds is the VALU ISSUE rate -- one wave-instruction per SIMD every
+        # four clocks.  achieved = SQ_INSTS_VALU of one launch (PMC pass of this command,
+        # see traffic_source) / HIP-event duration of the kernel in THIS run.
+        insts = (traffic_source or {}).get("sq_insts_valu_per_launch")
+        ach = insts / (step_ms * 1e-3) if insts and step_ms > 0 else None
+        tf = algo_flops_incremental(d) * evals_per_launch / (step_ms * 1e-3) / 1e12
+        return {
+            "bound": "valu_issue", "achieved": ach / 1e9 if ach else None,
+            "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
+            "frac": ach / VALU_ISSUE_PEAK if ach else None,
+            "fp64": {"flops_per_eval_executed": algo_flops_incremental(d),
+                     "achieved_tflops": tf, "frac_of_peak": tf / FP64_PEAK_TFLOPS,
+                     "flops_per_eval_from_scratch": algo_flops_per_eval(d),
+                     "equivalent_from_scratch_tflops": tflops},
+            **common}
+    # The fused launch keeps the walker state in registers for `spl` steps, so the roof
+    # that binds is FP64 arithmetic -- vector FMA for d <= 56, the matrix cores above --
+    # not HBM.  achieved = algorithmic flops of one launch / HIP-event kernel duration.
+    return {
+        "bound": "mfma" if on_matrix_cores else "fp64_valu",
+        "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": tflops / FP64_PEAK_TFLOPS if tflops else None,
+        "flops_per_eval": algo_flops_per_eval(d),
+        "algorithmic_flops_per_launch": flops, **common}
+
+
+def pliklite_roofline(m, n_bins, walkers, steps):
+    """The binned (plik-lite) target: the dominant kernel is the triangular FP64 GEMM on the
+    matrix cores, Y = L^-1 Delta (n_bins (n_bins + 1) flops per evaluation; the reference's
+    Sigma^-1 delta . delta is 2 n_bins^2), fed by delta through HBM (8 n_bins B written by
+    pl_residual_kernel, read once per wave of pl_chi2_kernel's workgroup)."""
+    kb = m["kt"]["binned"]
+    n_chi2 = max(kb["launches"][2], 1)
+    chi2_ms = kb["chi2_ms"] / n_chi2
+    flops = float(n_bins) * (n_bins + 1) * walkers
+    tf = flops / (chi2_ms * 1e-3) / 1e12
+    spl = m["spl"]
+    traffic, traffic_source = measured_traffic(27, walkers, spl, m["kernel"])
+    return {
+        "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": tf / FP64_PEAK_TFLOPS, "kernel": m["kernel"], "kernel_ms_per_launch": chi2_ms,
+        "evals_per_kernel_launch": walkers, "flops_per_eval": n_bins * (n_bins + 1),
+        "flops_per_eval_as_the_reference_counts": 2 * n_bins * n_bins,
+        "achieved_counting_2n2_tflops": 2.0 * n_bins * n_bins * walkers / (chi2_ms * 1e-3) / 1e12,
+        "traffic": traffic, "traffic_source": traffic_source,
+        "algorithmic_hbm": {"bytes_per_eval": 16 * n_bins,
+                            "note": "delta written once and read once per evaluation"},
+        "other_kernels_ms_per_metropolis_step": {
+            "pl_walker_kernel": kb["walker_ms"] / max(steps * spl, 1),
+            "pl_residual_kernel": kb["residual_ms"] / max(steps * spl, 1)},
+        "metropolis_step_ms": m["dt"] * 1e3 / max(steps * spl, 1)}
+
+
+def main_pliklite(a, rank, size):
+    """`--workload pliklite`: the planck_pliklite variant alone, as its own JSON line."""
+    spl = a.steps_per_launch or 24
+    info, tgt = make_pliklite_info(26, a.walkers, a.group_size, spl)
+    m = run_timed(a, 27, None, None, "snapshots", a.steps, a.warmup, info=info)
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "log-posterior evals/sec (whole node), 27-dim planck_pliklite (613 bins)",
+            "value": m["evals"] / m["dt"], "unit": "evals/s", "n_gpus": size, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * m["dt"] / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (plik-lite-shaped; the Planck data is not available offline)",
+            "config": {"workload": "BASELINE configs[4] arithmetic: planck_pliklite, 613 bins, "
+                                   "26-parameter linear Cl(theta) + A_planck, "
+                                   f"{a.walkers} walkers per GPU",
+                       "d": 27, "walkers_per_gpu": a.walkers, "group_size": m["group_size"],
+                       "metropolis_steps_per_launch": m["spl"], "evaluation": m["evaluation"],
+                       "learn_checkpoints_in_timed_region": m["n_ckpt"]},
+            "roofline": pliklite_roofline(m, tgt.n_bins, a.walkers, a.steps),
+            "cpu_baseline": None if a.no_cpu_baseline else cpu_baseline_pliklite(26, a.cpu_seconds)}
+        print(json.dumps(out))
+    return out
 
 
 def main():
@@ -266,6 +461,8 @@ def main():
     if size != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={size}; launch with "
               "torch.distributed.run for N > 1", file=sys.stderr)
+    if a.workload == "pliklite":
+        return main_pliklite(a, rank, size)
     d = a.dim
     mean, cov = target(d)
     m = run_timed(a, d, mean, cov, a.emit, a.steps, a.warmup)
@@ -298,70 +495,73 @@ def main():
             "kernel_ms_per_launch": v["kt"]["step_ms"] / 40,
             "accepted_rows_per_s": v["rows"] / v["dt"],
             "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"]})
+    headline = (d, a.walkers, a.emit) == (30, 65536, "snapshots")
+    if size == 1 and not a.no_variants and headline:
+        # BASELINE configs[3]: the 100-dim gaussian_mixture, same walkers (default path)
+        d4 = 100
+        m4, c4 = target(d4)
+        n_v = 6
+        v = run_timed(a, d4, m4, c4, "snapshots", n_v, 2)
+        variants.append({
+            "variant": "BASELINE configs[3]: 100-dim single-mode gaussian_mixture, 65536 walkers",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"], "roofline": gaussian_roofline(v, d4, a.walkers, n_v)})
+        # configs[4]'s SHAPE (SURVEY 8d "Config 5"): d = 27, 6 uniform + 21 normal priors, a
+        # `gaussian` likelihood with a seeded SPD covariance -- synthetic, no Planck data
+        d5 = 27
+        m5, c5 = target(d5)
+        n_v = 10
+        info5 = make_info(d5, m5, c5, a.walkers, a.group_size, 40 * d5, normal_from=6)
+        v = run_timed(a, d5, m5, c5, "snapshots", n_v, 3, info=info5)
+        variants.append({
+            "variant": "BASELINE configs[4] shape: 27-dim `gaussian` likelihood, 6 uniform + 21 "
+                       "normal priors (synthetic stand-in), 65536 walkers",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 3, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"], "roofline": gaussian_roofline(v, d5, a.walkers, n_v)})
+        # configs[4]'s ARITHMETIC: the plik-lite likelihood (planck_pliklite.py:143-155) -- 613
+        # bins, chi2 = delta^T Sigma^-1 delta on the matrix cores -- with a 26-parameter linear
+        # Cl(theta) + A_planck (d = 27); synthetic plik-lite-shaped data (the Planck files and a
+        # Boltzmann code are not available offline)
+        n_v, spl6 = 8, 24
+        info6, tgt6 = make_pliklite_info(26, a.walkers, a.group_size, spl6)
+        v = run_timed(a, 27, None, None, "snapshots", n_v, 2, info=info6)
+        entry = {
+            "variant": "BASELINE configs[4] arithmetic: planck_pliklite (613 bins, FP64-MFMA "
+                       "triangular GEMM), 26-parameter linear Cl(theta) + A_planck, 65536 walkers; "
+                       "synthetic plik-lite-shaped data",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"],
+            "roofline": pliklite_roofline(v, tgt6.n_bins, a.walkers, n_v)}
+        if not a.no_cpu_baseline:
+            entry["cpu_baseline"] = cpu_baseline_pliklite(26, 3.0)
+        variants.append(entry)
+    if size > 1:
+        # diagnostics of a scaling run: the step-kernel time of every rank and the cost of the
+        # checkpoint's all-reduce (2 d^2 + d + 5 doubles), measured after the timed region
+        per = np.zeros(size)
+        per[rank] = m["kt"]["step_ms"] / max(m["kt"]["step_launches"], 1)
+        dist.all_reduce_sum(per)
+        wall = np.zeros(size)
+        wall[rank] = m["dt"]
+        dist.all_reduce_sum(wall)
+        buf = np.zeros(2 * d * d + d + 5)
+        dist.all_reduce_sum(buf)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce_sum(buf)
+        collective = dict(collective or {})
+        collective.update(per_rank_step_kernel_ms=[float(x) for x in per],
+                          per_rank_timed_region_s=[float(x) for x in wall],
+                          checkpoint_allreduce_us=1e6 * (time.perf_counter() - t0) / 20,
+                          checkpoint_allreduce_doubles=len(buf))
     out = None
     if rank == 0:
-        spl, kt, dt = m["spl"], m["kt"], m["dt"]
-        # one bench step = one engine.step(spl) call; the engine splits it into several kernel
-        # launches when the directions of spl steps exceed its 256 MiB buffer (d = 100)
-        launches_per_step = kt["step_launches"] / max(a.steps, 1)
-        step_ms = kt["step_ms"] / max(kt["step_launches"], 1)      # per KERNEL launch
-        evals_per_launch = a.walkers * spl / max(launches_per_step, 1)
-        flops = algo_flops_per_eval(d) * evals_per_launch
-        algo_bytes = algo_bytes_per_eval(d) * evals_per_launch
-        tflops = flops / (step_ms * 1e-3) / 1e12 if step_ms > 0 else None
-        algo_gbs = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None
-        kernel = m["kernel"]
-        on_matrix_cores = "mfma" in kernel
-        traffic, traffic_source = measured_traffic(d, a.walkers, spl, kernel)
-        overlapped = m["evaluation"] == "incremental" and not os.environ.get("MCMC_HIP_NO_PREFETCH")
-        common = {
-            "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
-            "kernel_ms_per_launch": step_ms, "kernel_launches_per_step": launches_per_step,
-            "evals_per_kernel_launch": evals_per_launch,
-            # SURVEY 8d's HBM figure, kept for reference: what the state would move if it were
-            # persisted every step.  It is NOT a bandwidth the kernel achieves (x_peak may
-            # exceed 1): compare `traffic`, the bytes that really cross HBM.
-            "algorithmic_hbm": {
-                "bytes_per_eval": algo_bytes_per_eval(d), "bytes_per_launch": algo_bytes,
-                "GBps": algo_gbs, "x_peak": algo_gbs / HBM_PEAK_GBS if algo_gbs else None,
-                "measured_fraction_of_algorithmic": (traffic / algo_bytes) if traffic else None},
-            # incremental evaluation: the directions of the NEXT launch are computed on a second
-            # stream behind the step kernel, beside the moment snapshot and the refresh of y
-            # (capi.hip, DirSet); their elapsed time is then not part of the critical path
-            "basis_kernel_ms_per_launch": kt["basis_ms"] / max(a.steps, 1),
-            "basis_on_second_stream": overlapped,
-            "moments_ms_per_launch": kt["moments_ms"] / max(a.steps, 1),
-            "host_and_checkpoint_ms_per_step": 1e3 * dt / a.steps - (
-                kt["step_ms"] + (0.0 if overlapped else kt["basis_ms"]) + kt["moments_ms"])
-            / max(a.steps, 1)}
-        if m["evaluation"] == "incremental":
-            # O(d) per step: most of the instructions are not FP64 multiply-adds (two compares
-            # per dimension for the prior support, Philox, two logarithms, a square root), so
-            # the roof that binds is the VALU ISSUE rate -- one wave-instruction per SIMD every
-            # four clocks.  achieved = SQ_INSTS_VALU of one launch (PMC pass of this command,
-            # see traffic_source) / HIP-event duration of the kernel in THIS run.
-            insts = (traffic_source or {}).get("sq_insts_valu_per_launch")
-            ach = insts / (step_ms * 1e-3) if insts and step_ms > 0 else None
-            tf = algo_flops_incremental(d) * evals_per_launch / (step_ms * 1e-3) / 1e12
-            roofline = {
-                "bound": "valu_issue", "achieved": ach / 1e9 if ach else None,
-                "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
-                "frac": ach / VALU_ISSUE_PEAK if ach else None,
-                "fp64": {"flops_per_eval_executed": algo_flops_incremental(d),
-                         "achieved_tflops": tf, "frac_of_peak": tf / FP64_PEAK_TFLOPS,
-                         "flops_per_eval_from_scratch": algo_flops_per_eval(d),
-                         "equivalent_from_scratch_tflops": tflops},
-                **common}
-        else:
-            # The fused launch keeps the walker state in registers for `spl` steps, so the roof
-            # that binds is FP64 arithmetic -- vector FMA for d <= 56, the matrix cores above --
-            # not HBM.  achieved = algorithmic flops of one launch / HIP-event kernel duration.
-            roofline = {
-                "bound": "mfma" if on_matrix_cores else "fp64_valu",
-                "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / FP64_PEAK_TFLOPS if tflops else None,
-                "flops_per_eval": algo_flops_per_eval(d),
-                "algorithmic_flops_per_launch": flops, **common}
+        spl, dt = m["spl"], m["dt"]
+        roofline = gaussian_roofline(m, d, a.walkers, a.steps)
         out = {
             "metric": "log-posterior evals/sec (whole node), %d-dim gaussian_mixture" % d,
             "value": m["evals"] / dt, "unit": "evals/s", "n_gpus": size, "steps": a.steps,

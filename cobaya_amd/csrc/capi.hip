@@ -627,7 +627,9 @@ int set_target_common(mcmc_hip_ctx* h, int K, const double* means, const double*
 
 
 // ------------------------------------------------------------------ binned Gaussian target
-inline int binned_class(int R) { const int m = R & 15; return m < 8 ? m : 15 - m; }
+// wave of pl_chi2_kernel that owns row tile R of NT (oracle: binned_class): a snake deal from
+// the last -- the most expensive -- tile down
+inline int binned_class(int R, int NT) { const int m = (NT - 1 - R) & 15; return m < 8 ? m : 15 - m; }
 
 // chi2 of the residuals held in `delta` (n walkers, a multiple of 64) -> chi2
 int binned_chi2(mcmc_hip_ctx* h, const double* delta, double* chi2, int n)
@@ -663,7 +665,7 @@ int evaluate_binned_points(mcmc_hip_ctx* h, int n, const double* x, double* logp
     HIP_TRY(h, B.etrial.resize(d * np));
     HIP_TRY(h, B.elp.resize(np));
     HIP_TRY(h, B.echi2.resize(np));
-    HIP_TRY(h, B.edelta.resize((np / 64) * (size_t)B.KT * 256 + 256));
+    HIP_TRY(h, B.edelta.resize((np / 64) * (size_t)B.KT * 256 + (size_t)mcmc::kPlPad * 256));
     HIP_TRY(h, hipMemcpyAsync(B.etrial.p, t.data(), sizeof(double) * d * np, hipMemcpyHostToDevice,
                               h->stream));
     HIP_TRY(h, mcmc_hip_launch_pl_prior(B.etrial.p, (int)np, (int)d, h->cblock.p, h->norm_mask,
@@ -699,7 +701,7 @@ int step_binned(mcmc_hip_ctx* h, int n_steps)
     HIP_TRY(h, B.lp_t.resize(W));
     HIP_TRY(h, B.Ea.resize(W));
     HIP_TRY(h, B.chi2.resize(W));
-    HIP_TRY(h, B.delta.resize(((size_t)W / 64) * (size_t)B.KT * 256 + 256));
+    HIP_TRY(h, B.delta.resize(((size_t)W / 64) * (size_t)B.KT * 256 + (size_t)mcmc::kPlPad * 256));
     const size_t dd = (size_t)mcmc::v_slab(d);
     const int max_cyc = (int)std::max<size_t>(1, (64u << 20) / (sizeof(double) * dd * (size_t)h->G));
     mcmc::PlWalkerArgs a{};
@@ -1105,7 +1107,7 @@ int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const i
     for (int q = 0; q < 8; ++q) {
         std::vector<int> mine;
         for (int R = 0; R < NT; ++R)
-            if (binned_class(R) == q) mine.push_back(R);
+            if (binned_class(R, NT) == q) mine.push_back(R);
         const int absent = B.ntw - (int)mine.size();
         for (int t = 0; t < 5; ++t) { B.nk[q][t] = 0; B.tile_off[q][t] = 0; }
         for (int t = 0; t < (int)mine.size(); ++t) {
@@ -1119,7 +1121,7 @@ int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const i
                 }
         }
     }
-    As.resize(As.size() + 64, 0.0);   // (the fetch one k-step ahead)
+    As.resize(As.size() + (size_t)mcmc::kPlPad * 64, 0.0);   // (operands are fetched ahead)
     HIP_TRY(h, B.resp.resize(resp.size()));
     HIP_TRY(h, B.theta0.resize(th.size()));
     HIP_TRY(h, B.Astream.resize(As.size()));
@@ -1168,7 +1170,7 @@ int mcmc_hip_evaluate_binned(mcmc_hip_ctx* h, int32_t n_pts, int32_t L0, int32_t
     HIP_TRY(h, B.ecl.resize((size_t)n_pts * 3 * n_ell));
     HIP_TRY(h, B.eA.resize(n_pts));
     HIP_TRY(h, B.echi2.resize(np));
-    HIP_TRY(h, B.edelta.resize((np / 64) * (size_t)B.KT * 256 + 256));
+    HIP_TRY(h, B.edelta.resize((np / 64) * (size_t)B.KT * 256 + (size_t)mcmc::kPlPad * 256));
     HIP_TRY(h, hipMemcpyAsync(B.ecl.p, cl, sizeof(double) * (size_t)n_pts * 3 * n_ell,
                               hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(B.eA.p, A, sizeof(double) * n_pts, hipMemcpyHostToDevice, h->stream));

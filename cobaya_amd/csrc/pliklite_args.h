@@ -4,6 +4,8 @@
 
 namespace mcmc {
 
+constexpr int kPlPad = 8;   // k-steps of padding behind delta and the tile streams (>= the prefetch depth)
+
 // ---- binned-bandpower Gaussian likelihood (pliklite_kernels.hip; planck_pliklite.py:143-155)
 struct PlWalkerArgs {
     StepArgs s;            // state, prior constants (cblock, ConstLayout{d, 0}), V, keys;
@@ -32,10 +34,10 @@ struct PlBinArgs {
     int n_pts, n_bins, KT, L0, stride;
 };
 struct PlChi2Args {
-    const double* delta;   // [W / 64][KT][4][64] + one k-step (256 doubles) of padding
+    const double* delta;   // [W / 64][KT][4][64] + kPlPad k-steps (256 doubles each) of padding
     const double* Astream; // tile t of wave q at tile_off[q][t]: [nk[q][t]][64] doubles,
-                           // k-step kk = L^-1[16 R + (l & 15)][4 kk + (l >> 4)]; 64 doubles of
-                           // padding behind the last tile (the fetch one k-step ahead)
+                           // k-step kk = L^-1[16 R + (l & 15)][4 kk + (l >> 4)]; kPlPad k-steps of
+                           // padding behind the last tile (operands are fetched ahead)
     double* chi2;          // [W]
     unsigned long long tile_off[8][5];   // (absent tiles: any valid offset)
     int nk[8][5];          // k-steps of tile t of wave q: ascending in t, absent tiles first (0)

@@ -40,6 +40,10 @@ namespace mcmc {
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+#ifndef MCMC_PL_PREFETCH
+#define MCMC_PL_PREFETCH 3
+#endif
+constexpr int kPlPrefetch = MCMC_PL_PREFETCH;   // k-steps the operands of pl_chi2_kernel are fetched ahead
 typedef const double __attribute__((address_space(4))) * cptr;
 __device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(unsigned long long)p; }
 
@@ -147,7 +151,8 @@ __global__ void __launch_bounds__(64) pl_prior_kernel(const double* __restrict__
 template <int NLP>   // emulator parameters padded to a multiple of 4 (BJ and theta0 zero beyond n_lin)
 __global__ void __launch_bounds__(256) pl_residual_kernel(const PlResidualArgs a)
 {
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform: scalar)
     const int wg = blockIdx.x, w = wg * 64 + lane;
     const int W = a.W, calib = a.calib;
     double dth[NLP];
@@ -222,13 +227,19 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int wt = 0; wt < 4; ++wt) acc[t][wt] = d4{0.0, 0.0, 0.0, 0.0};
-    // operands of k-step 0; every iteration fetches those of the NEXT k-step before its own
-    // MFMAs (the streams and delta are padded by one k-step, so the last fetch is harmless)
-    double av[NTW], bv[4];
+    // Operands are fetched PF k-steps ahead of their MFMAs (registers av[j], bv[j] = k-step kk + j):
+    // in the late phases a wave has one or two active tiles left -- 4 or 8 MFMAs = 256 or 512
+    // clocks per k-step -- and a fetch one k-step ahead would expose the L2 latency there.  The
+    // streams and delta are padded by PF k-steps, so the fetches past the end are harmless.
+    constexpr int PF = kPlPrefetch;
+    double av[PF][NTW], bv[PF][4];
 #pragma unroll
-    for (int wt = 0; wt < 4; ++wt) bv[wt] = dl[wt * 64];
+    for (int j = 0; j < PF; ++j) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) av[t] = ap[t][0];
+        for (int wt = 0; wt < 4; ++wt) bv[j][wt] = dl[((size_t)j * 4 + wt) * 64];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) av[j][t] = ap[t][(size_t)j * 64];
+    }
     int kk = 0;
     // phase P: the k-steps on which the tiles t >= P are active (tile t ends at k-step nk[t], and
     // nk ascends): a fixed set of loads and MFMAs per iteration, no branch inside
@@ -237,18 +248,25 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
         for (; kk < nk[P]; ++kk) {
             double an[NTW], bn[4];
 #pragma unroll
-            for (int wt = 0; wt < 4; ++wt) bn[wt] = dl[((size_t)(kk + 1) * 4 + wt) * 64];
+            for (int wt = 0; wt < 4; ++wt) bn[wt] = dl[((size_t)(kk + PF) * 4 + wt) * 64];
 #pragma unroll
-            for (int t = P; t < NTW; ++t) an[t] = ap[t][(size_t)(kk + 1) * 64];
+            for (int t = P; t < NTW; ++t) an[t] = ap[t][(size_t)(kk + PF) * 64];
 #pragma unroll
             for (int t = P; t < NTW; ++t)
 #pragma unroll
                 for (int wt = 0; wt < 4; ++wt)
-                    acc[t][wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[wt], acc[t][wt], 0, 0, 0);
+                    acc[t][wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][t], bv[0][wt], acc[t][wt], 0, 0, 0);
 #pragma unroll
-            for (int t = P; t < NTW; ++t) av[t] = an[t];
+            for (int j = 0; j + 1 < PF; ++j) {
 #pragma unroll
-            for (int wt = 0; wt < 4; ++wt) bv[wt] = bn[wt];
+                for (int t = P; t < NTW; ++t) av[j][t] = av[j + 1][t];
+#pragma unroll
+                for (int wt = 0; wt < 4; ++wt) bv[j][wt] = bv[j + 1][wt];
+            }
+#pragma unroll
+            for (int t = P; t < NTW; ++t) av[PF - 1][t] = an[t];
+#pragma unroll
+            for (int wt = 0; wt < 4; ++wt) bv[PF - 1][wt] = bn[wt];
         }
     }
     // lane 16 c + n holds the rows 16 R + 4 r + c of walker n (tile R, register r): the chain

@@ -119,7 +119,7 @@ class ProblemSpec:
     refs: list  # RefPdf per sampled parameter
     proposal: list  # `proposal` width or None
     like_name: str = "one"
-    like_kind: str = "one"  # one | gaussian_mixture | gaussian
+    like_kind: str = "one"  # one | gaussian_mixture | gaussian | planck_pliklite
     means: np.ndarray | None = None
     covs: np.ndarray | None = None
     weights: np.ndarray | None = None
@@ -127,6 +127,11 @@ class ProblemSpec:
     has_derived: bool = False
     labels: dict = field(default_factory=dict)
     components: list = field(default_factory=list)  # one dict per likelihood (_parse_likelihood)
+    # planck_pliklite (cobaya_amd.pliklite): the binned data, the linear Cl(theta) stand-in and
+    # the position of the calibration parameter among the sampled ones
+    binned: object = None
+    emulator: object = None
+    calib_index: int = -1
 
     @property
     def d(self):
@@ -134,7 +139,7 @@ class ProblemSpec:
 
     @property
     def n_modes(self):
-        return 0 if self.like_kind == "one" else len(self.means)
+        return 0 if self.like_kind in ("one", "planck_pliklite") else len(self.means)
 
     # ----------------------------------------------------------------- prior facts
     def prior_variances(self):
@@ -261,6 +266,9 @@ class ProblemSpec:
             spec.like_name, spec.like_kind = c["name"], c["kind"]
             spec.means, spec.covs, spec.weights = c["means"], c["covs"], c["weights"]
             spec.normalized, spec.has_derived = c["normalized"], c["has_derived"]
+            if c["kind"] == "planck_pliklite":
+                spec.binned, spec.emulator = c["binned"], c["emulator"]
+                spec.calib_index = c["calib_index"]
             return spec
         # several likelihoods over disjoint parameter sets: the posterior is the product, i.e.
         # ONE mixture whose modes are all combinations of the components' modes, with
@@ -272,6 +280,9 @@ class ProblemSpec:
                 "with several likelihoods every sampled parameter must be the input of "
                 "exactly one of them (distinct `input_params_prefix`es)")
         for c in comps:
+            if c["kind"] == "planck_pliklite":
+                raise UnsupportedModel(
+                    f"likelihood '{c['name']}' (planck_pliklite) cannot be combined with others")
             if c["kind"] == "one" or not c["normalized"] or c["has_derived"]:
                 raise UnsupportedModel(
                     f"likelihood '{c['name']}': only normalized gaussian / gaussian_mixture "
@@ -317,9 +328,11 @@ class ProblemSpec:
         if lclass == "one":
             linfo.pop("noise", None)
             return cls._component(lname, "one", [], [], sampled, derived, single, speed=speed)
+        if lclass in ("planckpliklite", "ttteeelitenative", "ttlitenative"):
+            return cls._pliklite_component(lname, linfo, sampled, derived, speed)
         if lclass not in ("gaussianmixture", "gaussian"):
             raise UnsupportedModel(f"likelihood '{lname}' is not one of gaussian_mixture, "
-                                   "gaussian, one")
+                                   "gaussian, one, planck_pliklite")
         if not isinstance(inputs, (list, tuple)):
             inputs = [p for p in sampled if p.startswith(in_prefix)]  # model.py:1169-1172
         if not isinstance(outputs, (list, tuple)):
@@ -338,6 +351,79 @@ class ProblemSpec:
                                    f"{sorted(linfo)}")
         return cls._component(lname, kind, list(inputs), list(outputs), sampled, derived,
                               single, speed=speed, **kw)
+
+    @staticmethod
+    def _pliklite_component(lname, linfo, sampled, derived, speed):
+        """`planck_pliklite` (base_classes/planck_pliklite.py): `dataset` = the contents of the
+        .dataset file and its companions (a `pliklite.PlikLiteDataset`, a dict of its fields, a
+        path to an .npz of them, or `{synthetic: seed}` for the plik-lite-shaped stand-in -- the
+        Planck data cannot be downloaded here), the options of planck_pliklite.py:33-43
+        (`use_cl`, `use_bins`, `bins_for_L_range`, `calibration_param`), and `cl_emulator` = the
+        linear stand-in for the theory code (`provider.get_Cl`, planck_pliklite.py:170-178): a
+        `pliklite.LinearClEmulator`, a dict / .npz of its fields, or `{synthetic: n}`; its
+        parameters are the sampled ones other than the calibration parameter, in order."""
+        from . import pliklite as P
+        linfo = dict(linfo)
+
+        def load(obj, what):
+            if isinstance(obj, str):
+                with np.load(obj, allow_pickle=False) as z:
+                    return {k: z[k] for k in z.files}
+            if not isinstance(obj, dict):
+                raise UnsupportedModel(f"likelihood '{lname}': cannot interpret `{what}`")
+            return dict(obj)
+
+        ds = linfo.pop("dataset", None)
+        if ds is None:
+            raise UnsupportedModel(
+                f"likelihood '{lname}': `dataset` is required (the Planck data files are not "
+                "available to mcmc_hip; pass the arrays, or {synthetic: seed})")
+        if not isinstance(ds, P.PlikLiteDataset):
+            ds = load(ds, "dataset")
+            ds = (P.synthetic_dataset(int(ds["synthetic"])) if "synthetic" in ds
+                  else P.PlikLiteDataset(**{k: (int(v) if np.ndim(v) == 0 else np.asarray(v))
+                                            for k, v in ds.items()}))
+        use_cl = linfo.pop("use_cl", None) or (linfo.pop("dataset_params", None) or {}).get(
+            "use_cl", "tt te ee")
+        use_cl = use_cl.split() if isinstance(use_cl, str) else list(use_cl)
+        calib = str(linfo.pop("calibration_param", "A_planck"))
+        try:
+            target = P.BinnedGaussian.from_dataset(
+                ds, use_cl=use_cl, use_bins=linfo.pop("use_bins", ()) or (),
+                bins_for_L_range=linfo.pop("bins_for_L_range", ()) or (), calibration_param=calib)
+        except ValueError as e:
+            raise UnsupportedModel(f"likelihood '{lname}': {e}") from e
+        if calib not in sampled:
+            raise UnsupportedModel(f"likelihood '{lname}': the calibration parameter '{calib}' "
+                                   "must be a sampled parameter")
+        emu = linfo.pop("cl_emulator", None)
+        if emu is None:
+            raise UnsupportedModel(
+                f"likelihood '{lname}': `cl_emulator` is required (theory codes are out of scope: "
+                "Cl(theta) is a linear emulator)")
+        if not isinstance(emu, P.LinearClEmulator):
+            emu = load(emu, "cl_emulator")
+            emu = (P.synthetic_emulator(int(emu["synthetic"]), target.lmax) if "synthetic" in emu
+                   else P.LinearClEmulator(np.asarray(emu["theta0"], float), np.asarray(emu["D0"], float),
+                                           np.asarray(emu["J"], float), list(emu.get("names", []))))
+        for k in ("path", "dataset_file", "aliases"):
+            linfo.pop(k, None)
+        if linfo:
+            raise UnsupportedModel(f"unknown options for likelihood '{lname}': {sorted(linfo)}")
+        if derived:
+            raise UnsupportedModel("planck_pliklite has no derived parameters")
+        d = len(sampled)
+        if emu.n != d - 1 or emu.lmax != target.lmax or not 2 <= d <= 32:
+            raise UnsupportedModel(
+                f"likelihood '{lname}': the emulator has {emu.n} parameters up to l = {emu.lmax}; "
+                f"it must serve the {d - 1} sampled parameters other than '{calib}' "
+                f"(2 <= d <= 32) up to lmax = {target.lmax}")
+        if target.n_bins > 640:
+            raise UnsupportedModel(f"likelihood '{lname}': {target.n_bins} bins (max 640)")
+        return {"name": lname, "kind": "planck_pliklite", "idx": list(range(d)), "means": None,
+                "covs": None, "weights": None, "normalized": True, "has_derived": False,
+                "speed": float(speed if speed is not None else -1), "binned": target,
+                "emulator": emu, "calib_index": sampled.index(calib)}
 
     @staticmethod
     def _component(lname, kind, inputs, outputs, sampled, derived, single, means=None,
@@ -520,6 +606,8 @@ class ProblemSpec:
         engine.set_prior(self.kinds, self.a, self.b, self.periodic)
         if self.like_kind == "one":
             engine.set_target_one()
+        elif self.like_kind == "planck_pliklite":
+            engine.set_target_binned_gaussian(self.binned, self.emulator, self.calib_index)
         elif self.like_kind == "gaussian":
             engine.set_target_gaussian(self.means[0], self.covs[0], self.normalized)
         else:

@@ -248,6 +248,14 @@ class EnsembleMCMC:
                    and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
                    and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
+        if spec.like_kind == "planck_pliklite":
+            # not Gaussian in the calibration parameter: every trial is evaluated from scratch,
+            # on the matrix cores (pliklite_kernels.hip); one launch = a few steps of 3 kernels
+            can_inc = False
+            if (len(self.blocks) > 1 or self.oversampling_factors[0] != 1 or self.drag
+                    or self.emit != "snapshots" or not self.shared_basis or np.any(spec.periodic)):
+                self._fail("the planck_pliklite likelihood is sampled with one parameter block, "
+                           "the shared basis, non-periodic priors and emit: snapshots")
         if not self.shared_basis and (len(self.blocks) > 1 or self.oversampling_factors[0] != 1):
             self._fail("shared_basis: False serves a single parameter block without "
                        "oversampling or dragging")

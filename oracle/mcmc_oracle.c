@@ -233,8 +233,10 @@ typedef struct {
  *   chi2      y_j = fma chain over i = 0..j ascending of Linv[j][i] delta_i from +0, with
  *             cov = L L^T (the same quadratic form as invcov.dot(diff).dot(diff));  the squares
  *             are summed in 32 interleaved chains p[q][c] over the rows with j mod 4 = c and
- *             class(j div 16) = q, class(R) = (R mod 16 < 8) ? R mod 8 : 7 - R mod 8 (wave q of
- *             the chi2 kernel owns the 16-row tiles of class q, lane class c their rows 4r + c),
+ *             class(j div 16) = q; with NT = ceil(n_bins / 16) tiles and m = (NT - 1 - R) mod 16,
+ *             class(R) = m < 8 ? m : 15 - m (wave q of the chi2 kernel owns the 16-row tiles of
+ *             class q -- a snake deal from the last, most expensive, tile down -- and lane
+ *             class c their rows 4r + c),
  *             s_q = (p[q][0] + p[q][1]) + (p[q][2] + p[q][3]),
  *             chi2 = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
  *   loglike   -chi2 / 2. */
@@ -473,19 +475,19 @@ static inline double wrap_periodic(double t, double lo, double hi)
 }
 
 /* ------------------------------------------------------------------ binned Gaussian (plik-lite) */
-static inline int binned_class(int R) { int m = R & 15; return m < 8 ? m : 15 - m; }
+static inline int binned_class(int R, int NT) { int m = (NT - 1 - R) & 15; return m < 8 ? m : 15 - m; }
 
 /* chi2 of a residual vector (order: see orc_binned) */
 double orc_binned_chi2_of_delta(const orc_binned* b, const double* delta)
 {
-    const int n = b->n_bins;
+    const int n = b->n_bins, NT = (n + 15) / 16;
     double p[8][4];
     for (int q = 0; q < 8; ++q) for (int c = 0; c < 4; ++c) p[q][c] = 0.0;
     for (int j = 0; j < n; ++j) {
         const double* Lj = b->Linv + (size_t)j * n;
         double y = 0.0;
         for (int i = 0; i <= j; ++i) y = fma(Lj[i], delta[i], y);
-        double* pc = &p[binned_class(j >> 4)][j & 3];
+        double* pc = &p[binned_class(j >> 4, NT)][j & 3];
         *pc = fma(y, y, *pc);
     }
     double s[8];

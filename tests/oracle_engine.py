@@ -80,6 +80,24 @@ class OracleEngine:
         self._target = dict(means=None, covs=None, weights=None, normalized=True)
         self._problem = None
 
+    def set_target_binned_gaussian(self, target, emulator, calib_index):
+        if self.incremental or self.own_basis or self.cap:
+            raise EngineError(ERR_ARG, "the binned Gaussian target is evaluated from scratch with "
+                                       "the shared basis and emit_capacity 0")
+        if emulator.n != self.d - 1 or not 0 <= calib_index < self.d:
+            raise EngineError(ERR_ARG, "the binned Gaussian target takes d - 1 emulator "
+                                       "parameters and one calibration parameter")
+        try:
+            B = O.Binned(target.bin_table(), target.weights, target.X_data, cov=target.cov,
+                         theta0=emulator.theta0, D0=emulator.D0, J=emulator.J, calib=calib_index)
+        except np.linalg.LinAlgError:
+            raise NotPositiveDefinite(ERR_NOT_PD, "the covariance of the binned data is not a "
+                                                  "symmetric positive-definite matrix")
+        self.K = 0
+        self.n_bins = len(B.X)
+        self._target = dict(means=None, covs=None, weights=None, normalized=True, binned=B)
+        self._problem = None
+
     def set_blocking(self, blocks, oversampling=None, drag_last_slow=-1, drag_steps=0):
         blocks = [list(map(int, b)) for b in blocks]
         if sorted(i for b in blocks for i in b) != list(range(self.d)):

@@ -307,3 +307,66 @@ def test_no_checkpoint_is_processed_after_convergence(lag):
     s.run()
     assert s.converged and seen[-1] and seen.count(True) == 1
     assert len(s.progress) == len(seen)
+
+
+def pliklite_info(n_lin=5, **like):
+    """A `planck_pliklite` input for the standalone driver: the small plik-lite-shaped data set,
+    the synthetic linear Cl(theta), uniform boxes on its parameters and the reference's prior on
+    the calibration (base_classes/planck_calib.yaml)."""
+    from cobaya_amd import pliklite as P
+    from tests.pliklite_common import sampling_problem, small_dataset
+    ds = small_dataset()
+    emu = P.synthetic_emulator(n_lin, ds.lmax)
+    target = P.BinnedGaussian.from_dataset(ds, **{k: v for k, v in like.items() if k != "dataset"})
+    kinds, a, b, C = sampling_problem(target, emu)
+    params = {name: {"prior": {"min": float(a[i]), "max": float(b[i])}, "ref": float(emu.theta0[i]),
+                     "proposal": float(np.sqrt(C[i, i]))} for i, name in enumerate(emu.names)}
+    params["A_planck"] = {"prior": {"dist": "norm", "loc": 1, "scale": 0.0025},
+                          "ref": {"dist": "norm", "loc": 1, "scale": 0.002}, "proposal": 0.0005}
+    info = {"params": params,
+            "likelihood": {"plik": {"class": "planck_pliklite", "dataset": ds, "cl_emulator": emu,
+                                    **like}}}
+    return info, target, emu, C
+
+
+def test_planck_pliklite_runs_through_the_sampler():
+    """§8f-4: `likelihood: {class: planck_pliklite}` parsed like PlanckPlikLite.init_params
+    (planck_pliklite.py:32-141), configured through `set_target_binned_gaussian`, sampled by the
+    run loop (checkpoints, learned covariance) -- on the oracle double; the posterior mean of
+    the emulator parameters is the least-squares solution of the binned model."""
+    info, target, emu, C = pliklite_info()
+    spec = ProblemSpec.from_info(info)
+    assert spec.like_kind == "planck_pliklite" and spec.calib_index == 5 and spec.n_modes == 0
+    assert spec.binned.n_bins == target.n_bins == 88
+    s = OnOracle({"seed": 4, "n_walkers": 256, "group_size": 64, "steps_per_launch": 30,
+                  "max_samples": 60000, "Rminus1_stop": 0.0, "learn_every": "20d",
+                  "snapshot_every": 30, "covmat": C, "covmat_params": spec.sampled}, spec)
+    assert not s.incremental
+    s.run()
+    x = s.products()["sample"]
+    rows = np.array([x[p] for p in spec.sampled]).T
+    w = np.asarray(x["weight"])
+    mean = np.average(rows, axis=0, weights=w)
+    from oracle import cbind as O
+    B = s.engine._prob().binned
+    Bm = np.column_stack((B.BJ, -2.0 * B.Bc0))
+    F = Bm.T @ np.linalg.solve(target.cov, Bm)
+    F[5, 5] += 1.0 / 0.0025 ** 2
+    best = np.linalg.solve(F, Bm.T @ np.linalg.solve(target.cov, target.X_data - B.Bc0))
+    best[5] += 1.0
+    sig = np.sqrt(np.diag(C))
+    assert np.all(np.abs(mean - best) < 0.25 * sig), (mean - best) / sig
+    assert np.all(np.asarray(x["chi2__plik"]) > 0)
+    # the learned proposal covariance is the posterior's
+    learned = s.proposer.get_covariance()
+    assert np.all(np.abs(np.sqrt(np.diag(learned)) / sig - 1) < 0.3)
+    # what the kind does not cover fails loudly
+    with pytest.raises(LoggedError, match="one parameter block"):
+        OnOracle({"n_walkers": 128, "emit": "chains"}, ProblemSpec.from_info(info))
+    bad = pliklite_info()[0]
+    bad["likelihood"]["plik"].pop("cl_emulator")
+    from cobaya_amd.model import UnsupportedModel
+    with pytest.raises(UnsupportedModel, match="cl_emulator"):
+        ProblemSpec.from_info(bad)
+    sel = ProblemSpec.from_info(pliklite_info(use_cl=["tt"])[0])
+    assert sel.binned.n_bins == 48
