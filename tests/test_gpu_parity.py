@@ -480,18 +480,19 @@ def test_stuck_chain_is_reported():
         eng.sync()
 
 
-@pytest.mark.parametrize("mode", ["full", "incremental", "incremental-1024"])
+@pytest.mark.parametrize("mode", ["full", "incremental", "incremental-1024", "incremental-4096"])
 def test_posterior_moments_full_size(mode):
     """Tier C at BASELINE config-2 size: 65 536 walkers, d=30 target of the golden fixture;
     mean within 1% of sigma and covariance within 1% (north star) after >= 1e6 accepted --
-    with every trial evaluated from scratch, with incremental evaluation, and with the
-    benchmark's basis groups of 1 024 walkers."""
+    with every trial evaluated from scratch, with incremental evaluation, with basis groups of
+    1 024 walkers and with the 4 096 the sampler picks at this size (what bench.py runs: 16
+    Haar bases for the ensemble)."""
     g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden",
                                            "targets.npz"))
     mean, cov = g["mean_d30"], g["cov_d30"]
     d, W = 30, 65536
     eng = E.Engine(d, W, group_size=64, seed=1, incremental=mode != "full",
-                   basis_group_size=1024 if mode.endswith("1024") else None)
+                   basis_group_size=int(mode.split("-")[1]) if "-" in mode else None)
     eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
     eng.set_target_gaussian_mixture([mean], [cov])
     eng.set_proposal_cov(cov)

@@ -207,6 +207,40 @@ def test_config4_d100_posterior():
     sampler.close()
 
 
+def test_config4_d100_posterior_full_size_to_one_percent():
+    """BASELINE config 4 at the benchmark size, the north star's bar: 100-dim golden target,
+    65 536 walkers, the sampler's defaults (incremental evaluation, a Haar basis per 4 096
+    walkers); ensemble mean within 1 % of sigma and covariance within 1 % after >= 1e6 accepted
+    steps, from moment snapshots (as test_posterior_moments_full_size does at d = 30)."""
+    import os
+    from cobaya_amd.engine import Engine
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
+    mean, cov = g["mean_d100"], g["cov_d100"]
+    d, W = 100, 65536
+    eng = Engine(d, W, group_size=256, seed=4, incremental=True, basis_group_size=4096)
+    eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
+    eng.set_target_gaussian_mixture([mean], [cov])
+    eng.set_proposal_cov(cov)
+    rng = np.random.default_rng(2)
+    x0 = mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov))
+    eng.set_state(np.clip(x0, 1e-6, 1 - 1e-6))
+    eng.step(40 * d)          # burn-in from the ref pdf (narrower than the posterior)
+    eng.set_moment_shift(mean)
+    for _ in range(160):      # (32 000 steps of 65 536 walkers: 80 ms of step kernels)
+        eng.step(2 * d)
+        eng.accumulate_moments()
+    eng.sync()
+    assert "step_inc_kernel<25" in eng.last_step_kernel()
+    n, gs, S = eng.read_moments()
+    N = n * W
+    m = gs.sum(0) / N
+    c = S / N - np.outer(m, m)
+    assert eng.counters()["accepted"] >= 1e6
+    sig = np.sqrt(np.diag(cov))
+    assert np.max(np.abs(m) / sig) < 0.01
+    assert np.max(np.abs((c - cov) / np.outer(sig, sig))) < 0.01
+
+
 def test_bench_two_ranks_share_one_gpu():
     """The N > 1 launch path of bench.py end to end (torch.distributed.run, walker sharding by
     rank, the per-checkpoint all-reduce, MAX-over-ranks timing) with 2 ranks on this one GPU
