@@ -269,9 +269,9 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
     if emit == "chains":   # count what the drains deliver
         store = sampler._store_rows
 
-        def counting_store(rows):
+        def counting_store(rows, **kw):
             rows_kept[0] += len(rows)
-            store(rows)
+            store(rows, **kw)
         sampler._store_rows = counting_store
 
     # one bench step = one pass of the sampler's own hot loop (EnsembleMCMC.advance): a fused

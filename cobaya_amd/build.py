@@ -109,6 +109,10 @@ def build(dims=None, jobs=None, verbose=True):
         tasks.append((inc, os.path.join(OBJ, f"incremental_{lo_}.o"),
                       [f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
                       _digest([inc] + hdrs, extra=f"inc{lo_}-{hi_}|{' '.join(FLAGS)}")))
+    for lo_, hi_ in INC_DQ_RANGES:   # the EMIT instantiations of step_inc_kernel (emit: chains)
+        tasks.append((inc, os.path.join(OBJ, f"incremental_emit_{lo_}.o"),
+                      ["-DMCMC_INC_EMIT_TU", f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
+                      _digest([inc] + hdrs, extra=f"incemit{lo_}-{hi_}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr, pl_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

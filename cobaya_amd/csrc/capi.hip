@@ -266,6 +266,11 @@ extern "C" hipError_t mcmc_hip_launch_inc_step_1(const mcmc::IncStepArgs*, hipSt
 extern "C" hipError_t mcmc_hip_launch_inc_step_9(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_inc_step_17(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_inc_step_25(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+// ... and their EMIT instantiations (accepted rows stored, `emit: chains`): -DMCMC_INC_EMIT_TU
+extern "C" hipError_t mcmc_hip_launch_inc_emit_1(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_emit_9(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_emit_17(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_emit_25(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, const double* mean,
                                                    const double* Lrow, int d, int W, int K,
                                                    hipStream_t st) __attribute__((weak));
@@ -348,6 +353,11 @@ struct mcmc_hip_ctx {
     bool mom_pending = false;
     int64_t mom_n = 0;
     unsigned long long mom_step = 0;
+    // drain_samples_pinned: ring of pinned host slots the packed rows are copied into (PCIe at
+    // full rate, and the caller reads them in place)
+    struct HostSlot { double* p = nullptr; size_t cap_rows = 0; };
+    std::vector<HostSlot> slots = std::vector<HostSlot>(4);
+    int slot_next = 0;
     DevBuf<double> pack_out;                        // drain_samples: packed rows
     DevBuf<long long> pack_off;
     DevBuf<int> weight_i, prej, burn, stuck, nrows;
@@ -823,11 +833,9 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
                     "incremental evaluation needs the shared basis (the whitened direction is "
                     "shared with it)");
     if ((cfg->flags & MCMC_HIP_FLAG_INCREMENTAL) &&
-        (cfg->d < 2 || cfg->group_size % 64 != 0 || cfg->emit_capacity > 0 ||
-         !mcmc_hip_launch_whiten_state))
+        (cfg->d < 2 || cfg->group_size % 64 != 0 || !mcmc_hip_launch_whiten_state))
         return fail(nullptr, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation needs d >= 2, a group_size that is a multiple of 64 "
-                    "and emit_capacity 0 (snapshots)");
+                    "incremental evaluation needs d >= 2 and a group_size that is a multiple of 64");
     if (cfg->emit_capacity < 0 || cfg->burn_in < 0)
         return fail(nullptr, MCMC_HIP_ERR_ARG, "emit_capacity and burn_in must be >= 0");
     int ndev = 0;
@@ -942,6 +950,8 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
     h->acc_total.p = nullptr;   // (a view into gsum)
     h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
+    for (auto& sl : h->slots)
+        if (sl.p) (void)hipHostFree(sl.p);
     if (h->pin_mom) (void)hipHostFree(h->pin_mom);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->mom_event) (void)hipEventDestroy(h->mom_event);
@@ -1646,8 +1656,20 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                     "incremental evaluation serves one Gaussian mode (or, without dragging and "
                     "with non-periodic priors, a mixture of up to four at d <= 64); up to eight "
                     "periodic parameters without dragging; use evaluation: full for this model");
-    auto launch = dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
-                : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25;
+    const bool emit = h->cfg.emit_capacity > 0;
+    if (emit) {
+        bool one_d = false;   // (a block of one parameter: its columns draw other variates)
+        for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b) one_d = one_d || h->blk_size[b] == 1;
+        if (K != 1 || n_periodic > 0 || P.drag || one_d)
+            return fail(h, MCMC_HIP_ERR_ARG,
+                        "incremental evaluation emits rows (emit_capacity > 0) for one Gaussian "
+                        "mode with non-periodic priors, blocks of at least two parameters and "
+                        "Metropolis steps; use evaluation: full for this model");
+    }
+    auto launch = emit ? (dq <= 8 ? mcmc_hip_launch_inc_emit_1 : dq <= 16 ? mcmc_hip_launch_inc_emit_9
+                          : dq <= 24 ? mcmc_hip_launch_inc_emit_17 : mcmc_hip_launch_inc_emit_25)
+                       : (dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
+                          : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25);
     if (!launch || !mcmc_hip_launch_whiten_directions)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
     // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks, the slow
@@ -1692,6 +1714,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.s.loglike = h->loglike.p; a.s.weight = h->weight_i.p; a.s.prior_rej = h->prej.p;
             a.s.burn_left = h->burn.p; a.s.n_accept = h->nacc.p; a.s.stuck = h->stuck.p;
             a.s.accept_total = h->acc_total.p;
+            a.s.rows = h->rows.p; a.s.n_rows = h->nrows.p; a.s.row_cap = h->cfg.emit_capacity;
             a.s.W = h->W; a.s.n_modes = K; a.s.group_size = h->bgs;   // the walkers that share a column of VU
             a.s.cblock = h->cblock.p;
             {
@@ -1960,7 +1983,7 @@ int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int6
     for (size_t w = 0; w < W; ++w) { off[w] = run; run += std::min<int>(nr[w], (int)cap); }
     if (total > 0) {
         HIP_TRY(h, h->pack_off.resize(W));
-        HIP_TRY(h, h->pack_out.resize(W * cap * (d + 5)));   // worst case once: no regrowth
+        HIP_TRY(h, h->pack_out.resize(std::min<size_t>(W * cap, (size_t)total + (size_t)total / 4 + 1024) * (d + 5)));
         HIP_TRY(h, hipMemcpyAsync(h->pack_off.p, off.data(), sizeof(long long) * W,
                                   hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, mcmc_hip_launch_pack_rows(h->rows.p, h->nrows.p, h->pack_off.p, h->pack_out.p,
@@ -1971,6 +1994,65 @@ int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int6
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_drain_slots(mcmc_hip_ctx* h, int32_t n_slots)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (n_slots < 2 || n_slots > 64) return fail(h, MCMC_HIP_ERR_ARG, "n_slots must be in 2..64");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    for (auto& sl : h->slots)
+        if (sl.p) (void)hipHostFree(sl.p);
+    h->slots.assign((size_t)n_slots, mcmc_hip_ctx::HostSlot{});
+    h->slot_next = 0;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_drain_samples_pinned(mcmc_hip_ctx* h, const double** rows, int64_t* n_rows)
+{
+    if (!h || !rows || !n_rows) return MCMC_HIP_ERR_ARG;
+    *rows = nullptr;
+    *n_rows = 0;
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    if (h->cfg.emit_capacity <= 0) return MCMC_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t W = h->W, d = h->d, cap = h->cfg.emit_capacity;
+    std::vector<int> nr(W);
+    HIP_TRY(h, hipMemcpy(nr.data(), h->nrows.p, sizeof(int) * W, hipMemcpyDeviceToHost));
+    std::vector<long long> off(W);
+    long long total = 0;
+    for (size_t w = 0; w < W; ++w) { off[w] = total; total += std::min<int>(nr[w], (int)cap); }
+    auto& sl = h->slots[(size_t)h->slot_next];
+    h->slot_next = (h->slot_next + 1) % (int)h->slots.size();
+    if (total > 0) {
+        if ((size_t)total > sl.cap_rows) {   // (grown with headroom: pinning memory is slow)
+            if (sl.p) (void)hipHostFree(sl.p);
+            sl.p = nullptr;
+            sl.cap_rows = 0;
+            const size_t want = std::min<size_t>(W * cap, (size_t)total + (size_t)total / 4 + 1024);
+            HIP_TRY(h, hipHostMalloc((void**)&sl.p, sizeof(double) * want * (d + 5), hipHostMallocDefault));
+            sl.cap_rows = want;
+        }
+        HIP_TRY(h, h->pack_off.resize(W));
+        // (the packed rows that exist: ~ acceptance x steps of the device buffer; sized to what
+        // is there, with headroom, since the device buffer itself may be many GiB)
+        HIP_TRY(h, h->pack_out.resize(std::min<size_t>(W * cap, (size_t)total + (size_t)total / 4 + 1024) * (d + 5)));
+        HIP_TRY(h, hipMemcpyAsync(h->pack_off.p, off.data(), sizeof(long long) * W,
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, mcmc_hip_launch_pack_rows(h->rows.p, h->nrows.p, h->pack_off.p, h->pack_out.p,
+                                             (int)W, (int)cap, (int)d, h->cfg.walker_offset,
+                                             h->stream));
+        HIP_TRY(h, hipMemcpyAsync(sl.p, h->pack_out.p, sizeof(double) * (size_t)total * (d + 5),
+                                  hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->nrows.p, 0, sizeof(int) * W, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        *rows = sl.p;
+    } else {
+        HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
+    }
+    *n_rows = total;
     return MCMC_HIP_OK;
 }
 

@@ -169,7 +169,10 @@ __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
 
 //   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
 //   RandProposer1D variates of the un-paired stream (step_variates), every lane for itself
-template <int DQ, int MODE, bool UNIT_T, bool ONED>
+//   EMIT: every accepted step past the burn-in stores the point it LEAVES with its weight
+//   (mcmc.py:691-707: rows[w][n_rows[w]++] = (weight, logpost, logprior, loglike, x), a.s.rows /
+//   n_rows / row_cap as in the from-scratch kernels) -- the reference's own product, `emit: chains`
+template <int DQ, int MODE, bool UNIT_T, bool ONED, bool EMIT = false>
 __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem2[];
@@ -254,6 +257,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;     // accepted steps of this launch (< 2^31)
+    int nrow = EMIT ? s.n_rows[w] : 0;
     const uint32_t gid = s.walker0 + (uint32_t)w;
     // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
     const double mt10 = s.max_tries * 10.0;
@@ -371,6 +375,25 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const double lt = lp + ll;
                     const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
                     const bool accept = inside & ((lt > lpost) | (Ea > delta));
+                    if (EMIT) {
+                        // the point the walker leaves, with its weight (mcmc.py:691-707); each of
+                        // the walker's four lanes stores its quarter: header word c, then the
+                        // dimensions 4 kk + c -- 32 contiguous bytes per walker and instruction
+                        const bool em = accept & (burn <= 0);
+                        if (lanes(em) != 0ull) {   // (wave-uniform: some walker emits)
+                            if (em & (nrow < s.row_cap)) {
+                                double* __restrict__ row =
+                                    s.rows + ((size_t)w * s.row_cap + nrow) * (size_t)(d + 4);
+                                row[c] = c == 0 ? (double)wt : c == 1 ? lpost : c == 2 ? lpri : llik;
+#pragma unroll
+                                for (int kk = 0; kk < DQ; ++kk)
+                                    if (4 * kk + c < d) row[4 + 4 * kk + c] = x[kk];
+                            }
+                            nrow += em ? 1 : 0;   // rows beyond the capacity are counted as dropped
+                        }
+                        lpri = accept ? lp : lpri;
+                        llik = accept ? ll : llik;
+                    }
                     // (burn-in, mcmc.py:685-690, ends early in a run: its bookkeeping sits
                     // behind a wave-uniform test of "some lane is still burning in")
                     int lim = lim1;
@@ -431,7 +454,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed
         __syncthreads();
     }
-    if (nacc != 0) {   // (the same in the four lanes of a walker: the quad sums are safe)
+    if (!EMIT && nacc != 0) {   // (the same in the four lanes of a walker: the quad sums are safe)
         double pc = 0.0, sc = 0.0;
 #pragma unroll
         for (int kk = 0; kk < DQ; ++kk) {
@@ -460,6 +483,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;
+        if (EMIT) s.n_rows[w] = nrow;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
     MCMC_EXP_BLOCK_END();
@@ -1397,6 +1421,39 @@ hipError_t dispatch_inc_mix(const IncStepArgs& a, hipStream_t st)
 }
 #endif  // MCMC_DQ_LO <= 16
 
+#ifdef MCMC_INC_EMIT_TU
+// (this translation unit holds the EMIT instantiations alone: incremental_emit.hip)
+template <int DQ>
+hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
+{
+    constexpr int C = inc_chunk(DQ);
+    const int mode = a.has_norm ? 2 : (a.box ? 0 : 1);
+    const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    const bool unit_t = a.s.temperature == 1.0;
+    typedef void (*kern_t)(const IncStepArgs);
+    static const kern_t kerns[6] = {
+        step_inc_kernel<DQ, 0, false, false, true>, step_inc_kernel<DQ, 0, true, false, true>,
+        step_inc_kernel<DQ, 1, false, false, true>, step_inc_kernel<DQ, 1, true, false, true>,
+        step_inc_kernel<DQ, 2, false, false, true>, step_inc_kernel<DQ, 2, true, false, true>};
+    static const std::string names[6] = {
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, false, emit>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 0, true, emit>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, false, emit>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, true, emit>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false, emit>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true, emit>"};
+    if (a.colflag || !a.s.rows) return hipErrorInvalidValue;
+    const int v = 2 * mode + (unit_t ? 1 : 0);
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    mcmc_hip_note_step_kernel(names[v].c_str());
+    hipLaunchKernelGGL(kerns[v], dim3(a.s.W / 64), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+#else
 template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
@@ -1435,6 +1492,7 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
     hipLaunchKernelGGL(kerns[v], dim3(a.s.W / 64), dim3(256), lds, st, a);
     return hipGetLastError();
 }
+#endif  // MCMC_INC_EMIT_TU
 
 template <int DQ>
 hipError_t launch_drag_dq(const IncStepArgs& a, hipStream_t st)
@@ -1494,6 +1552,18 @@ hipError_t launch_periodic_dq(const IncStepArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
+#ifdef MCMC_INC_EMIT_TU
+template <int DQ>
+hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
+{
+    if constexpr (DQ > MCMC_DQ_HI) {
+        return hipErrorInvalidValue;
+    } else {
+        if (a.dq == DQ) return launch_inc_dq<DQ>(a, st);
+        return dispatch_inc<DQ + 1>(a, st);
+    }
+}
+#else
 template <int DQ>
 hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
 {
@@ -1508,12 +1578,23 @@ hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
         return dispatch_inc<DQ + 1>(a, st);
     }
 }
+#endif  // MCMC_INC_EMIT_TU
 
 }  // namespace
 }  // namespace mcmc
 
 #define MCMC_CAT2(a, b) a##b
 #define MCMC_CAT(a, b) MCMC_CAT2(a, b)
+#ifdef MCMC_INC_EMIT_TU
+// the EMIT instantiations of step_inc_kernel, one translation unit per range of DQ
+extern "C" hipError_t MCMC_CAT(mcmc_hip_launch_inc_emit_, MCMC_DQ_LO)(const mcmc::IncStepArgs* a,
+                                                                    hipStream_t st)
+{
+    if (a->dq < MCMC_DQ_LO || a->dq > MCMC_DQ_HI || a->n_modes != 1 || a->n_drag > 0)
+        return hipErrorInvalidValue;
+    return mcmc::dispatch_inc<MCMC_DQ_LO>(*a, st);
+}
+#else
 // one translation unit per range of DQ = ceil(d / 4) (build.py: -DMCMC_DQ_LO=.. -DMCMC_DQ_HI=..)
 extern "C" hipError_t MCMC_CAT(mcmc_hip_launch_inc_step_, MCMC_DQ_LO)(const mcmc::IncStepArgs* a,
                                                                     hipStream_t st)
@@ -1526,8 +1607,9 @@ extern "C" hipError_t MCMC_CAT(mcmc_hip_launch_inc_step_, MCMC_DQ_LO)(const mcmc
 #endif
     return mcmc::dispatch_inc<MCMC_DQ_LO>(*a, st);
 }
+#endif  // MCMC_INC_EMIT_TU
 
-#if MCMC_DQ_LO == 1
+#if MCMC_DQ_LO == 1 && !defined(MCMC_INC_EMIT_TU)
 extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, const double* mean,
                                                    const double* Lrow, int d, int W, int K,
                                                    hipStream_t st)

@@ -58,6 +58,8 @@ SYMBOLS = [
      [_H, C.c_int32, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_set_target_gaussian", C.c_int, [_H, c_double_p, c_double_p, C.c_int32]),
     ("mcmc_hip_set_target_one", C.c_int, [_H]),
+    ("mcmc_hip_drain_samples_pinned", C.c_int, [_H, C.POINTER(c_double_p), c_int64_p]),
+    ("mcmc_hip_set_drain_slots", C.c_int, [_H, C.c_int32]),
     ("mcmc_hip_set_target_binned_gaussian", C.c_int,
      [_H, C.c_int32, c_int32_p, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int32,
       c_double_p, c_double_p, c_double_p, C.c_int32]),
@@ -404,6 +406,26 @@ class Engine:
         if n.value:
             self._check(self._lib.mcmc_hip_drain_samples(self._h, _dp(rows), n.value,
                                                          C.byref(n)))
+        return rows
+
+    def set_drain_slots(self, n_slots):
+        self._check(self._lib.mcmc_hip_set_drain_slots(self._h, int(n_slots)))
+        self.drain_slots = int(n_slots)
+
+    drain_slots = 4
+
+    def drain_samples_view(self):
+        """The rows accumulated since the last drain as a READ-ONLY view of a pinned host slot
+        the library owns: no host-side copy.  The view stays valid for `drain_slots - 1`
+        further drains (then its slot is reused) and dies with the engine -- copy what must
+        live longer."""
+        p = c_double_p()
+        n = C.c_int64()
+        self._check(self._lib.mcmc_hip_drain_samples_pinned(self._h, C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.empty((0, self.d + 5))
+        rows = np.ctypeslib.as_array(p, shape=(n.value, self.d + 5))
+        rows.flags.writeable = False
         return rows
 
     # -- moments

@@ -73,6 +73,8 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
+    "row_buffer_bytes": 1 << 32,  # emit: chains -- device buffer of accepted rows between two
+                              # drains (bounds steps_per_launch: every step may accept)
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
                               # power of two; incremental evaluation only).  Default: 1024
                               # from 16384 walkers per process up, 4096 from 65536 walkers
@@ -237,7 +239,7 @@ class EnsembleMCMC:
             # every accepted row is kept on the device between drains: bound the buffer
             row_bytes = 8 * (d + 4) * W
             self.steps_per_launch = int(max(1, min(self.steps_per_launch,
-                                                   (1 << 30) // row_bytes)))
+                                                   int(self.row_buffer_bytes) // row_bytes)))
             cap = self.steps_per_launch
         if self.evaluation not in ("auto", "full", "incremental"):
             self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
@@ -246,7 +248,12 @@ class EnsembleMCMC:
                    and (not np.any(spec.periodic) or (spec.n_modes == 1 and not self.drag
                                                       and int(np.sum(spec.periodic)) <= 8))
                    and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
-                   and self.emit == "snapshots" and d >= 2 and int(self.group_size) % 64 == 0
+                   # accepted rows (emit: chains): one mode, non-periodic, Metropolis steps,
+                   # blocks of at least two parameters
+                   and (self.emit == "snapshots"
+                        or (spec.n_modes == 1 and not np.any(spec.periodic) and not self.drag
+                            and all(len(b) >= 2 for b in self.blocks)))
+                   and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
         if spec.like_kind == "planck_pliklite":
             # not Gaussian in the calibration parameter: every trial is evaluated from scratch,
@@ -262,8 +269,9 @@ class EnsembleMCMC:
         if self.evaluation == "incremental" and not can_inc:
             self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
                        "four at d <= 64 without dragging and with non-periodic priors; up to eight "
-                       "periodic parameters without dragging), emit: snapshots, d >= 2 and a group_size "
-                       "that is a multiple of 64; use 'full' (or 'auto')")
+                       "periodic parameters without dragging), d >= 2 and a group_size that is a "
+                       "multiple of 64; emit: chains for one mode with non-periodic priors, "
+                       "Metropolis steps and blocks of >= 2 parameters; use 'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         if self.basis_group_size is None:
             self.basis_group_size = int(self.group_size)
@@ -577,7 +585,12 @@ class EnsembleMCMC:
             eng.accumulate_moments()
         snap_every = int(self.snapshot_every) if self.snapshot_every else None
         if self.emit == "chains":
-            self._store_rows(eng.drain_samples())
+            if hasattr(eng, "drain_samples_view"):
+                # rows land in a pinned host slot of the engine at PCIe speed and are read there
+                self._expire_row_views()
+                self._store_rows(eng.drain_samples_view(), view=True)
+            else:
+                self._store_rows(eng.drain_samples())
         elif snap_every and self._since_snapshot >= snap_every:
             self._snapshot()
         if self._ckpt_pending:
@@ -774,17 +787,34 @@ class EnsembleMCMC:
         out[:, 1] = (q - q_prev)[keep]
         return out
 
-    def _store_rows(self, rows):
+    def _expire_row_views(self):
+        """Before a drain: blocks of `_rows` that are views of the engine's pinned slots stay
+        readable for `drain_slots - 1` further drains only; the ones that would not survive the
+        drain that comes are dropped here (they are the oldest rows of the store)."""
+        views = [i for i, r in enumerate(self._rows) if getattr(r, "base", None) is not None
+                 and not r.flags.owndata and not r.flags.writeable]
+        keep = max(0, getattr(self.engine, "drain_slots", 4) - 2)
+        for i in reversed(views[:max(0, len(views) - keep)]):
+            self._n_rows -= len(self._rows[i])
+            del self._rows[i]
+
+    def _store_rows(self, rows, view=False):
         """Keeps at most `max_rows` rows per process WITHOUT freezing: the bounds criterion
         (mcmc.py:918-1002) looks at the later half of the stored samples, so the store must
         keep following the run.  Snapshots: when full, every other stored snapshot is dropped
         and from then on only every second (fourth, ...) snapshot is kept -- a uniformly
-        thinned record of the whole run.  Chains: the oldest half of the rows is dropped."""
+        thinned record of the whole run.  Chains: the oldest half of the rows is dropped.
+        `view`: the block is a read-only view of an engine-owned pinned slot (zero-copy drain);
+        it is kept as such unless something has to outlive the slot (the chain file's pending
+        rows, thinned rows)."""
         if len(rows) and self.emit == "chains" and self.output_thin > 1:
             rows = self._thin_rows(rows)
+            view = False
         if not len(rows) or self.max_rows <= 0:
             return
-        if self.emit == "chains":
+        if view and self.output:
+            rows, view = np.array(rows), False    # the chain file receives them later
+        if self.emit == "chains" and not view:
             # within a launch: chain after chain; launches follow each other in time -- the
             # order of the collection and of the chain file alike
             if np.any(rows[1:, 0] < rows[:-1, 0]):   # (the engine already drains in this order)

@@ -62,7 +62,8 @@ typedef struct mcmc_hip_config {
 #define MCMC_HIP_FLAG_OWN_BASIS 1
 /* incremental evaluation (one Gaussian mode with parameter blocks of any size, oversampling or
  * dragging -- or, without dragging, a mixture of up to four modes at d <= 64 --; up to eight
- * periodic parameters for one mode without dragging; emit_capacity 0, 2 <= d <= 128): every
+ * periodic parameters for one mode without dragging; 2 <= d <= 128; emitted rows, emit_capacity
+ * > 0, for one mode with non-periodic priors, blocks of >= 2 parameters, Metropolis steps): every
  * walker carries y = L^-1 (x - mu) and a trial moves it along the whitened shared direction,
  * y' = y + r L^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in O(d) per step;
  * y is recomputed from x every 40 cycle lengths (40 d steps for one block).  What the mode does
@@ -194,6 +195,15 @@ MCMC_HIP_API int mcmc_hip_get_counters(mcmc_hip_ctx* h, int64_t counters[4]);
  * collection.py:402-427): rows[n][d+5] = (walker id, weight, logpost, logprior, loglike,
  * x[0..d)), walker-major then in chain order.  cap_rows = capacity of `rows` in rows. */
 MCMC_HIP_API int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int64_t* n_rows);
+
+/* The same drain at PCIe speed and without a host-side copy: the packed rows are copied into a
+ * pinned host slot owned by the library and `*rows` points at them ([*n_rows][d+5], as
+ * drain_samples); the slot is reused after `n_slots - 1` further calls (ring of 4 slots unless
+ * mcmc_hip_set_drain_slots changed it; 2..64), so the caller may keep reading the rows of the
+ * last n_slots - 1 drains in place.  (The exception to "the library never hands out memory":
+ * stated here.) */
+MCMC_HIP_API int mcmc_hip_drain_samples_pinned(mcmc_hip_ctx* h, const double** rows, int64_t* n_rows);
+MCMC_HIP_API int mcmc_hip_set_drain_slots(mcmc_hip_ctx* h, int32_t n_slots);
 
 /* Constants the engine derived from set_prior / set_target_* (uniform_logp of prior.py:528-533,
  * mls[d] of tools.py:723, Linv[K*d*d] row-major of functions.py:81-89, cnorm[K] =

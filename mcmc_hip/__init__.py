@@ -46,6 +46,7 @@ else:
         emit: str = HIP_DEFAULTS["emit"]
         snapshot_every: int | None = HIP_DEFAULTS["snapshot_every"]
         max_rows: int = HIP_DEFAULTS["max_rows"]
+        row_buffer_bytes: int = HIP_DEFAULTS["row_buffer_bytes"]
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]
         evaluation: str = HIP_DEFAULTS["evaluation"]
         basis_group_size: int | None = HIP_DEFAULTS["basis_group_size"]

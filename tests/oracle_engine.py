@@ -44,9 +44,8 @@ class OracleEngine:
                 or walker_offset % self.basis_group_size):
             raise EngineError(ERR_ARG, "a basis group wider than group_size needs incremental "
                                        "evaluation and must divide n_walkers and walker_offset")
-        if self.incremental and (d < 2 or group_size % 64 or emit_capacity):
-            raise EngineError(ERR_ARG, "incremental evaluation needs d >= 2, group_size % 64 == "
-                                       "0 and emit_capacity 0")
+        if self.incremental and (d < 2 or group_size % 64):
+            raise EngineError(ERR_ARG, "incremental evaluation needs d >= 2 and group_size % 64 == 0")
         self._prior = self._target = self._blocking = None
         self._cov = None
         self._problem = self._state = None
@@ -215,6 +214,18 @@ class OracleEngine:
         rows = self._state.drain()
         if len(rows):
             rows[:, 0] += self.walker_offset
+        return rows
+
+    drain_slots = 4
+
+    def set_drain_slots(self, n):
+        self.drain_slots = int(n)
+
+    def drain_samples_view(self):
+        """Like the engine's: a read-only view the caller must not keep beyond
+        `drain_slots - 1` further drains (here the memory simply stays alive)."""
+        rows = self.drain_samples().view()
+        rows.flags.writeable = False
         return rows
 
     # -- moments ------------------------------------------------------------------------

@@ -770,8 +770,15 @@ def test_directions_computed_ahead_never_change_the_results(d, W, gs, kw):
 def test_incremental_mode_refuses_what_it_does_not_cover():
     with pytest.raises(E.EngineError, match="incremental"):
         E.Engine(1, 256, group_size=64, incremental=True)
-    with pytest.raises(E.EngineError, match="incremental"):
-        E.Engine(4, 256, group_size=64, incremental=True, emit_capacity=8)
+    emi = E.Engine(4, 256, group_size=64, incremental=True, emit_capacity=8)
+    emi.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
+    m2, c2 = random_target(4, 2, np.random.default_rng(0))   # rows are emitted for ONE mode
+    emi.set_target_gaussian_mixture(m2, c2)
+    emi.set_proposal_cov(c2[0])
+    emi.set_state(np.full((256, 4), 0.5))
+    with pytest.raises(E.EngineError, match="emits rows"):
+        emi.step(3)
+    emi.close()
     eng = E.Engine(4, 256, group_size=64, incremental=True)
     eng.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
     m, c = random_target(4, 5, np.random.default_rng(0))     # five modes: more than it serves
@@ -780,6 +787,52 @@ def test_incremental_mode_refuses_what_it_does_not_cover():
     eng.set_state(np.full((256, 4), 0.5))
     with pytest.raises(E.EngineError, match="one Gaussian mode"):
         eng.step(3)
+    eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,kw", [
+    (30, 256, 64, dict()),                                   # MODE 0: one box
+    (30, 512, 256, dict(burn_in=3, T=2.0)),
+    (27, 256, 64, dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.3] * 21)),
+    (9, 256, 64, dict(a=[0.0] * 4 + [-1.0] * 5, b=[1.0] * 4 + [2.0] * 5)),   # MODE 1: own bounds
+    (100, 256, 64, dict()),                                  # two waves per SIMD, read-ahead
+    (12, 256, 64, dict(blocks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]], over=[1, 3]))])
+def test_incremental_emitted_rows_bit_exact(d, W, gs, kw):
+    """`emit: chains` on the incremental path (missing 5): every accepted step past
+    the burn-in stores the point it leaves with its weight (mcmc.py:691-707,
+    collection.py:402-427); rows, counters and state bit for bit the oracle's, through both
+    drains (the copying one and the pinned zero-copy view)."""
+    cap = 80
+    eng, prob, st = make_pair(d, W, gs, incremental=True, cap=cap, **kw)
+    total = 0
+    for i, n in enumerate((1, 40, 37)):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        ref = st.drain()
+        rows = eng.drain_samples() if i % 2 == 0 else np.array(eng.drain_samples_view())
+        assert rows.shape == ref.shape
+        assert_bit_equal(rows, ref, "rows")
+        total += len(rows)
+        compare_state(eng, st)
+    assert total > W and eng.counters()["dropped_rows"] == 0
+    assert "emit" in eng.last_step_kernel()
+    eng.close()
+
+
+def test_pinned_drain_views_stay_valid_for_the_ring():
+    """drain_samples_view hands out library-owned pinned memory: a view is valid until its slot
+    comes round again (drain_slots - 1 further drains)."""
+    eng, prob, st = make_pair(8, 256, 64, incremental=True, cap=40)
+    eng.set_drain_slots(3)
+    kept = []
+    for _ in range(5):
+        eng.step(30)
+        v = eng.drain_samples_view()
+        assert not v.flags.writeable and len(v) > 0
+        kept.append((v, np.array(v)))
+        for view, copy in kept[-2:]:        # the last two drains are still readable in place
+            assert np.array_equal(view, copy)
     eng.close()
 
 

