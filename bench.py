@@ -227,6 +227,20 @@ def algo_flops_incremental(d):
     return 10 * d
 
 
+def csrc_sha16():
+    """sha256[:16] over the kernel sources (cobaya_amd/csrc/*.hip, *.h, sorted by name): lets a
+    bench line say whether the committed counter passes were taken on the code that runs now."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "cobaya_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(d, walkers, spl, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/traffic.json, written by tools/collect_evidence.py from `rocprofv3 --pmc
@@ -237,13 +251,17 @@ def measured_traffic(d, walkers, spl, kernel):
         return None, None
     with open(tj) as f:
         table = json.load(f)
-    for key, t in table.items():
+    for key, t in reversed(list(table.items())):     # (the most recent measurement first)
         if (t.get("d"), t.get("walkers"), t.get("steps_per_launch")) == (d, walkers, spl) and \
                 t.get("kernel", kernel).split("(")[0].strip() == kernel.split("(")[0].strip():
             return t.get("hbm_bytes_per_launch"), {
                 "sq_insts_valu_per_launch": t.get("sq_insts_valu"),
                 "file": "profiles/traffic.json#" + key, "pmc": t.get("pmc_file"),
                 "measured_at_commit": t.get("commit"),
+                # True: the kernel sources are byte for byte the ones the counters were taken on
+                # (commits after the measurement touched documentation / tests only)
+                "kernel_sources_unchanged_since_measurement":
+                    (t.get("csrc_sha16") == csrc_sha16()) if t.get("csrc_sha16") else None,
                 "note": "PMC passes of an earlier run of this command, not of this run"}
     return None, None
 

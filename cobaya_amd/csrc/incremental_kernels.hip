@@ -59,6 +59,15 @@ __device__ __forceinline__ double quad_sum(double p)
     return q + quad_perm<0x4E>(q);             // [2,3,0,1]
 }
 
+// max over the four lanes of a quad (unsigned)
+__device__ __forceinline__ unsigned quad_max_u32(unsigned v)
+{
+    unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+    v = v > o ? v : o;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+    return v > o ? v : o;
+}
+
 // (lanes(cond) -- the wave's lane mask of a condition -- and the mask-taking selects sel(m, a, b)
 // are in det_math.h)
 // The issue arbiter of a SIMD serves its resident waves by priority, then by AGE.  Left alone, the
@@ -186,14 +195,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     constexpr bool kNormInLds = NORMP && DQ > 8;   // (loc, 1/scale) pairs and mls in LDS
     __shared__ double2 sNA[kNormInLds ? 4 * DQ : 1];
     __shared__ double sNM[kNormInLds ? 4 * DQ : 1];
-    // One box for every dimension (MODE 0) and at most two waves per SIMD: the support test
-    // is taken on the largest and the smallest trial coordinate -- the same decision (a trial
-    // coordinate is never NaN: r, v and x are finite), two v_max/v_min instead of two compares
-    // AND two scalar ANDs of lane masks per dimension.  With two waves per SIMD the scalar
-    // instructions of a wave are not hidden behind the vector instructions of others
-    // (d = 100: 9.97 -> 9.32 ms per 4 000 steps); with four they are, and v_max/v_min cost
-    // more than the compares (d = 30: 1.031 -> 1.053 ms), so those kernels keep the masks.
-    constexpr bool kBoxMinMax = MODE == 0 && inc_min_waves(DQ, MODE) == 2;
+    // (MODE 0 = ONE box [0, hi] for every dimension, BASELINE configs 2-4: its support test works
+    // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
+    // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step
+    // either way; now DQ 32-bit ones.)
     constexpr int PIPE = MCMC_EXP_PIPE(inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
@@ -225,6 +230,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     MCMC_EXP_BLOCK_BEGIN();
 
     const double blo = a.box_lo, bhi = a.box_hi;
+    const unsigned bhi_word = (unsigned)__double2hiint(bhi);   // (MODE 0: blo == +0, 0 < bhi < inf)
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
     // normal priors, branch-free: a dimension without one has 1/scale = 0 and mls = 0, so its
     // term is fma(-0, 0, 0) = +0 and leaves the chain untouched
@@ -316,13 +322,19 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // (the support test is kept as the wave's lane mask: every comparison lands
                     // in a scalar register pair and the ANDs run on the scalar unit)
                     unsigned long long inb = ~0ull;
-                    double tmx = -INFINITY, tmn = INFINITY;   // kBoxMinMax: extremes of the trial
+                    // MODE 0 (one box [0, bhi] for every dimension): non-negative doubles order
+                    // like their bit patterns, so a trial coordinate whose HIGH WORD is below
+                    // bhi's is inside for certain -- one 32-bit max per dimension instead of two
+                    // FP64 compares (or min / max); whatever is not certain (within 2^-20 of bhi,
+                    // beyond it, negative, -0) is decided by the exact comparisons below, a
+                    // wave-uniform branch that a posterior away from the walls never takes
+                    unsigned hmx = 0u;
                     auto trial = [&](int kk, const double2 p) {
                         const double t = fma(r, p.x, x[kk]);
-                        if (kBoxMinMax) {
-                            tmx = __builtin_fmax(tmx, t);
-                            tmn = __builtin_fmin(tmn, t);
-                        } else if (MODE == 0) inb &= lanes(t <= bhi) & lanes(t >= blo);
+                        if (MODE == 0) {
+                            const unsigned h = (unsigned)__double2hiint(t);
+                            hmx = hmx > h ? hmx : h;
+                        }
                         else if (kBoundsInRegs) inb &= lanes(t <= hi[kk]) & lanes(t >= lo[kk]);
                         else {
                             const double2 lh = sLH[4 * kk + c];
@@ -364,8 +376,21 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     }
                     // inside the prior support = all four lanes of the walker are: the AND over
                     // the quad is taken on the wave's lane mask (scalar unit, no vector work)
-                    if (kBoxMinMax) inb = lanes(tmx <= bhi) & lanes(tmn >= blo);
-                    const bool inside = quad_all(inb);
+                    bool inside;
+                    if (MODE == 0) {
+                        inside = quad_max_u32(hmx) < bhi_word;
+                        if (lanes(!inside) != 0ull) {   // (wave-uniform, rare) the exact test
+                            lds_pairs colx = relaunder(col);
+#pragma unroll 4
+                            for (int kk = 0; kk < DQ; ++kk) {
+                                const double t = fma(r, colx[4 * kk].x, x[kk]);
+                                inb &= lanes(t <= bhi) & lanes(t >= blo);
+                            }
+                            inside = quad_all(inb);
+                        }
+                    } else {
+                        inside = quad_all(inb);
+                    }
                     const double chi2 = quad_sum(pc);
                     const double lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
                     const double ll = -0.5 * (s.cnorm0 + chi2);
@@ -1427,7 +1452,7 @@ template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
     constexpr int C = inc_chunk(DQ);
-    const int mode = a.has_norm ? 2 : (a.box ? 0 : 1);
+    const int mode = a.has_norm ? 2 : ((a.box && a.box_lo == 0.0) ? 0 : 1);   // MODE 0: [0, hi]
     const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);
@@ -1458,7 +1483,7 @@ template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
     constexpr int C = inc_chunk(DQ);
-    const int mode = a.has_norm ? 2 : (a.box ? 0 : 1);
+    const int mode = a.has_norm ? 2 : ((a.box && a.box_lo == 0.0) ? 0 : 1);   // MODE 0: [0, hi]
     const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);

@@ -51,7 +51,7 @@ def main():
 
     vals = {}
     lines = []
-    for p in ("pmc_fetch", "pmc_lds", "pmc_sq", "pmc_write"):
+    for p in ("pmc_fetch", "pmc_lds", "pmc_sq", "pmc_write", "pmc_mfma", "pmc_l2"):
         db = os.path.join(SRC, p, "p_results.db")
         if not os.path.exists(db):
             continue
@@ -82,6 +82,9 @@ def main():
                     "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced stream, "
                     "MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated"}
         import subprocess
+        sys.path.insert(0, ROOT)
+        from bench import csrc_sha16   # hash of the kernel sources the measurement was taken on
+        traffic.update(csrc_sha16=csrc_sha16())
         traffic.update(kernel=bench["roofline"]["kernel"].split("(")[0].strip(),
                        pmc_file=f"profiles/{rnd}_pmc.txt",
                        commit=subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT,
