@@ -15,13 +15,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
-DST = os.path.join(ROOT, "profiles")
+# (EVIDENCE_DST: on the GPU box the summaries are written under gpurun_out/ -- the result databases
+# are too big to travel back -- and copied into profiles/ afterwards)
+DST = os.environ.get("EVIDENCE_DST") or os.path.join(ROOT, "profiles")
 CMD = "python bench.py --no-cpu-baseline --no-variants --steps 20 --warmup 4"
 
 
 def main():
     global SRC
     global CMD
+    os.makedirs(DST, exist_ok=True)
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
     if len(sys.argv) > 2:
         SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2])
@@ -87,8 +90,9 @@ def main():
         traffic.update(csrc_sha16=csrc_sha16())
         traffic.update(kernel=bench["roofline"]["kernel"].split("(")[0].strip(),
                        pmc_file=f"profiles/{rnd}_pmc.txt",
-                       commit=subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT,
-                                             capture_output=True, text=True).stdout.strip())
+                       commit=os.environ.get("EVIDENCE_COMMIT") or subprocess.run(
+                           ["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True,
+                           text=True).stdout.strip())
         tj = os.path.join(DST, "traffic.json")   # keyed table; bench.py looks its workload up
         table = {}
         if os.path.exists(tj):

@@ -33,5 +33,15 @@ prof gpurun_out/final_full --evaluation full
 prof gpurun_out/final_d100 --dim 100 --steps 10 --warmup 2
 prof gpurun_out/final_pl --workload pliklite --steps 8 --warmup 2
 [ -f gpurun_out/final_gpu_tests.log ] && cp gpurun_out/final_gpu_tests.log gpurun_out/final/gpu_tests.log
-[ -f gpurun_out/final_bench.json ] && cp gpurun_out/final_bench.json gpurun_out/final/bench_full_line.json
-du -sh gpurun_out/final*; ls gpurun_out/final gpurun_out/final_pl
+# summaries on the box (the databases exceed what gpurun carries back), then drop the databases
+export EVIDENCE_DST=$PWD/gpurun_out/evidence EVIDENCE_COMMIT=$(cat tools/.evidence_commit 2>/dev/null)
+rm -rf $EVIDENCE_DST; mkdir -p $EVIDENCE_DST
+cp profiles/traffic.json $EVIDENCE_DST/traffic.json
+python tools/collect_evidence.py r03 final > /dev/null
+python tools/collect_evidence.py r03_full final_full > /dev/null
+python tools/collect_evidence.py r03_d100 final_d100 > /dev/null
+python tools/collect_evidence.py r03_pl final_pl > /dev/null
+[ -f gpurun_out/final_bench.json ] && cp gpurun_out/final_bench.json $EVIDENCE_DST/r03_bench_full_line.json
+cp gpurun_out/final_smoke.log $EVIDENCE_DST/r03_smoke.log 2>/dev/null
+rm -rf gpurun_out/final gpurun_out/final_full gpurun_out/final_d100 gpurun_out/final_pl
+du -sh gpurun_out; ls $EVIDENCE_DST
