@@ -84,6 +84,9 @@ def parse():
                     help="untimed launches before the W warmup steps until the device has been "
                          "under load this long (a cold MI355X runs the same kernel 18 %% slower "
                          "for its first ~35 ms: tools/ramp_probe.py); 0 = none")
+    ap.add_argument("--device-checkpoint", action="store_true",
+                    help="R-1 and the proposal refresh on the device (`device_checkpoint: True`) "
+                         "instead of on the host beside the next launch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--workload", choices=("gaussian_mixture", "pliklite"), default="gaussian_mixture",
                     help="pliklite: ONLY the planck_pliklite variant (613 bins, d = 27), as its "
@@ -279,6 +282,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
                          evaluation or a.evaluation)
         if a.basis_group_size and (evaluation or a.evaluation) != "full":
             info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
+    if a.device_checkpoint:
+        info["sampler"]["mcmc_hip"]["device_checkpoint"] = True
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -597,6 +602,7 @@ def main():
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": m["n_ckpt"],
                 "checkpoint_lag_launches": m["checkpoint_lag"],
+                "checkpoint_on": "device" if a.device_checkpoint else "host",
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
             "collective": collective,

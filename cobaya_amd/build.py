@@ -104,6 +104,10 @@ def build(dims=None, jobs=None, verbose=True):
     pl_hdr = os.path.join(CSRC, "pliklite_args.h")
     tasks.append((pl, os.path.join(OBJ, "pliklite.o"), [],
                   _digest([pl, pl_hdr] + hdrs, extra=" ".join(FLAGS))))
+    ck = os.path.join(CSRC, "checkpoint_kernels.hip")
+    ck_hdr = os.path.join(CSRC, "checkpoint_args.h")
+    tasks.append((ck, os.path.join(OBJ, "checkpoint.o"), [],
+                  _digest([ck, ck_hdr], extra=" ".join(FLAGS))))
     inc = os.path.join(CSRC, "incremental_kernels.hip")
     for lo_, hi_ in INC_DQ_RANGES:
         tasks.append((inc, os.path.join(OBJ, f"incremental_{lo_}.o"),
@@ -114,7 +118,7 @@ def build(dims=None, jobs=None, verbose=True):
                       ["-DMCMC_INC_EMIT_TU", f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
                       _digest([inc] + hdrs, extra=f"incemit{lo_}-{hi_}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
-                  _digest([capi, root_hdr, pl_hdr] + hdrs, extra=" ".join(FLAGS))))
+                  _digest([capi, root_hdr, pl_hdr, ck_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         rebuilt = list(ex.map(lambda t: _compile(*t), tasks))

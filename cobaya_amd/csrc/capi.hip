@@ -13,6 +13,7 @@
 
 #include "kernels.h"
 #include "pliklite_args.h"
+#include "checkpoint_args.h"
 
 MCMC_DECLARE_DIM(1) MCMC_DECLARE_DIM(2) MCMC_DECLARE_DIM(3) MCMC_DECLARE_DIM(4)
 MCMC_DECLARE_DIM(5) MCMC_DECLARE_DIM(6) MCMC_DECLARE_DIM(7) MCMC_DECLARE_DIM(8)
@@ -277,6 +278,10 @@ extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, c
 extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* a, int n_groups,
                                                         hipStream_t st) __attribute__((weak));
 
+// checkpoint_kernels.hip
+extern "C" hipError_t mcmc_hip_launch_ckpt_window(const mcmc::CkptWindowArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_ckpt_payload(const mcmc::CkptPayloadArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_ckpt_solve(const mcmc::CkptSolveArgs* a, hipStream_t st);
 // pliklite_kernels.hip
 extern "C" hipError_t mcmc_hip_launch_pl_walker(const mcmc::PlWalkerArgs* a, int accept, int propose,
                                                 hipStream_t st);
@@ -379,6 +384,16 @@ struct mcmc_hip_ctx {
     int64_t n_seen[6] = {0, 0, 0, 0, 0, 0}, n_timed[6] = {0, 0, 0, 0, 0, 0};   // timed regions per kind (Timed)
     int64_t n_step_launches = 0;
     std::string last_step_kernel;     // what the last step launcher said it launched
+    // device-side learn / convergence checkpoint (checkpoint_kernels.hip)
+    struct Ckpt {
+        DevBuf<double> ring, wsum, payload, ws, out;
+        DevBuf<unsigned long long> acc_prev;
+        int cap = 0;               // ring slots
+        long long n_done = 0;      // checkpoints taken so far (the next one goes to slot n_done % cap)
+        double* pin_out = nullptr; // [8 + 2 d^2]
+        hipEvent_t ev = nullptr;
+        bool begun = false, pending = false;
+    } ck;
     // binned-bandpower Gaussian target (planck_pliklite.py:143-155; pliklite_kernels.hip)
     struct Binned {
         bool on = false;
@@ -952,6 +967,10 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
     for (auto& sl : h->slots)
         if (sl.p) (void)hipHostFree(sl.p);
+    h->ck.ring.release(); h->ck.wsum.release(); h->ck.payload.release(); h->ck.ws.release();
+    h->ck.out.release(); h->ck.acc_prev.release();
+    if (h->ck.pin_out) (void)hipHostFree(h->ck.pin_out);
+    if (h->ck.ev) (void)hipEventDestroy(h->ck.ev);
     if (h->pin_mom) (void)hipHostFree(h->pin_mom);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->mom_event) (void)hipEventDestroy(h->mom_event);
@@ -2143,7 +2162,9 @@ int mcmc_hip_request_moments(mcmc_hip_ctx* h)
     // (mcmc.py:717-743 stops at once)
     HIP_TRY(h, hipMemcpyAsync(h->pin_mom + G * d + np + 1, h->stuck.p, sizeof(int),
                               hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemsetAsync(h->gsum.p, 0, sizeof(double) * (G * d + np), s));
+    // (with the device-side checkpoint the accumulators are reset by ckpt_window_kernel, which
+    // first files them in the ring: mcmc_hip_checkpoint_begin must follow)
+    if (!h->ck.ring.p) HIP_TRY(h, hipMemsetAsync(h->gsum.p, 0, sizeof(double) * (G * d + np), s));
     HIP_TRY(h, hipEventRecord(h->mom_event, s));
     h->mom_n = h->n_snapshots;
     h->mom_step = h->step;
@@ -2181,6 +2202,135 @@ int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_
         return fail(h, MCMC_HIP_ERR_STUCK,
                     "The chain has been stuck for %g attempts (walker %d), stopping sampling.",
                     h->cfg.max_tries, stuck - 1);
+    return MCMC_HIP_OK;
+}
+
+// ---- the checkpoint on the device -------------------------------------------------------------
+int mcmc_hip_checkpoint_set_ring(mcmc_hip_ctx* h, int32_t n_intervals, const double* group_sum,
+                                 const double* pooled_S, int32_t min_capacity)
+{
+    if (!h || n_intervals < 0 || (n_intervals > 0 && (!group_sum || !pooled_S))) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto& K = h->ck;
+    const size_t d = h->d, G = h->G, np = d * (d + 1) / 2, ne = G * d + np;
+    int cap = 16;
+    while (cap < std::max(n_intervals + 2, (int)min_capacity)) cap *= 2;
+    K.ring.release();
+    HIP_TRY(h, K.ring.resize((size_t)cap * ne));
+    K.cap = cap;
+    K.n_done = n_intervals;      // (slot of interval k of the list = k)
+    std::vector<double> buf((size_t)std::max(n_intervals, 1) * ne, 0.0);
+    for (int k = 0; k < n_intervals; ++k) {
+        double* dst = buf.data() + (size_t)k * ne;
+        std::copy(group_sum + (size_t)k * G * d, group_sum + (size_t)(k + 1) * G * d, dst);
+        const double* S = pooled_S + (size_t)k * d * d;
+        for (size_t i = 0; i < d; ++i)
+            for (size_t j = 0; j <= i; ++j) dst[G * d + i * (i + 1) / 2 + j] = S[i * d + j];
+    }
+    if (n_intervals > 0)
+        HIP_TRY(h, hipMemcpy(K.ring.p, buf.data(), sizeof(double) * (size_t)n_intervals * ne,
+                             hipMemcpyHostToDevice));
+    HIP_TRY(h, K.wsum.resize(ne + G * d));   // window sums | chain means
+    HIP_TRY(h, K.payload.resize(5 + 2 * d * d + d));
+    HIP_TRY(h, K.ws.resize(7 * d * d + 5 * d + 16));
+    HIP_TRY(h, K.out.resize(8 + 2 * d * d));
+    if (!K.acc_prev.p) {   // (a reload of the ring keeps the counter of the last checkpoint)
+        HIP_TRY(h, K.acc_prev.resize(1));
+        HIP_TRY(h, hipMemset(K.acc_prev.p, 0, sizeof(unsigned long long)));
+    }
+    if (!K.pin_out)
+        HIP_TRY(h, hipHostMalloc((void**)&K.pin_out, sizeof(double) * (8 + 2 * d * d), hipHostMallocDefault));
+    if (!K.ev) HIP_TRY(h, hipEventCreateWithFlags(&K.ev, hipEventDisableTiming));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_checkpoint_set_accepted(mcmc_hip_ctx* h, int64_t accepted_at_last_checkpoint)
+{
+    if (!h || !h->ck.acc_prev.p) return MCMC_HIP_ERR_STATE;
+    const unsigned long long v = (unsigned long long)accepted_at_last_checkpoint;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipMemcpy(h->ck.acc_prev.p, &v, sizeof v, hipMemcpyHostToDevice));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_checkpoint_begin(mcmc_hip_ctx* h, int32_t n_window_intervals, int64_t n_window_snapshots,
+                              double steps_since, uint64_t* payload_device_ptr, int32_t* payload_len)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    auto& K = h->ck;
+    if (!K.ring.p) return fail(h, MCMC_HIP_ERR_STATE, "checkpoint_set_ring must precede checkpoint_begin");
+    if (K.begun || K.pending) return fail(h, MCMC_HIP_ERR_STATE, "a device checkpoint is already in flight");
+    if (!h->mom_pending)
+        return fail(h, MCMC_HIP_ERR_STATE, "request_moments (the read-out of this interval) must precede checkpoint_begin");
+    if (n_window_intervals < 1 || n_window_intervals > K.cap || n_window_snapshots < 1)
+        return fail(h, MCMC_HIP_ERR_ARG, "the window holds %d intervals (ring capacity %d)", n_window_intervals, K.cap);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t d = h->d, G = h->G, np = d * (d + 1) / 2, ne = G * d + np;
+    // (mcmc_hip_request_moments copied the interval out for the host's books and, with a ring,
+    // left the accumulators alone: ckpt_window_kernel files them in the ring and resets them)
+    mcmc::CkptWindowArgs w{};
+    w.acc = h->gsum.p; w.ring = K.ring.p; w.wsum = K.wsum.p; w.n_elem = ne;
+    w.means = K.wsum.p + ne; w.n_mean = G * d;
+    w.n_per_chain = (double)n_window_snapshots * (double)h->gs;
+    w.cap = K.cap; w.slot = (int)(K.n_done % K.cap);
+    w.n_slots = n_window_intervals;
+    w.first = (int)(((K.n_done - (n_window_intervals - 1)) % K.cap + K.cap) % K.cap);
+    HIP_TRY(h, mcmc_hip_launch_ckpt_window(&w, h->stream));
+    K.n_done += 1;
+    mcmc::CkptPayloadArgs p{};
+    p.wsum = K.wsum.p; p.means = K.wsum.p + ne; p.payload = K.payload.p; p.accept_total = h->acc_total.p;
+    p.accept_prev = K.acc_prev.p; p.d = (int)d; p.G = (int)G; p.W = h->W;
+    p.n_per_chain = (double)n_window_snapshots * (double)h->gs;
+    p.steps_since = steps_since;
+    HIP_TRY(h, mcmc_hip_launch_ckpt_payload(&p, h->stream));
+    K.begun = true;
+    if (payload_device_ptr) *payload_device_ptr = (uint64_t)(uintptr_t)K.payload.p;
+    if (payload_len) *payload_len = (int32_t)(5 + 2 * d * d + d);
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_checkpoint_solve(mcmc_hip_ctx* h, double learn_lo, double learn_hi)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    auto& K = h->ck;
+    if (!K.begun) return fail(h, MCMC_HIP_ERR_STATE, "checkpoint_begin must precede checkpoint_solve");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t d = h->d;
+    // a direction set being filled ahead still reads the transform (as in set_proposal_cov)
+    for (auto& D : h->dirs)
+        if (D.ahead && D.ready) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
+    mcmc::CkptSolveArgs s{};
+    s.payload = K.payload.p; s.ws = K.ws.p; s.out = K.out.p; s.T = h->dT.p;
+    s.i_of_j = h->blocked ? h->dblk.p + 2 * (int)h->blk_size.size() : nullptr;
+    s.d = (int)d; s.group_size = (double)h->gs; s.learn_lo = learn_lo; s.learn_hi = learn_hi;
+    s.proposal_scale = h->cfg.proposal_scale;
+    HIP_TRY(h, mcmc_hip_launch_ckpt_solve(&s, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(K.pin_out, K.out.p, sizeof(double) * (8 + 2 * d * d),
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(K.ev, h->stream));
+    ++h->dir_epoch;     // the transform may have changed: directions computed ahead are stale
+    K.begun = false;
+    K.pending = true;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_covs)
+{
+    if (!h || !stats) return MCMC_HIP_ERR_ARG;
+    auto& K = h->ck;
+    if (!K.pending) return fail(h, MCMC_HIP_ERR_STATE, "no device checkpoint is pending");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(K.ev));
+    K.pending = false;
+    const size_t d = h->d, nn = d * d;
+    std::copy(K.pin_out, K.pin_out + 8, stats);
+    if (mean_of_covs) std::copy(K.pin_out + 8, K.pin_out + 8 + nn, mean_of_covs);
+    if (K.pin_out[2] != 0.0) {    // the proposal was refreshed on the device: mirror it on the host
+        h->cov.assign(K.pin_out + 8, K.pin_out + 8 + nn);
+        h->T.assign(K.pin_out + 8 + nn, K.pin_out + 8 + 2 * nn);
+        h->have_cov = true;
+    }
     return MCMC_HIP_OK;
 }
 
@@ -2282,6 +2432,8 @@ int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on)
     h->timing = on != 0;
     return MCMC_HIP_OK;
 }
+
+uint64_t mcmc_hip_stream_handle(const mcmc_hip_ctx* h) { return h ? (uint64_t)(uintptr_t)h->stream : 0; }
 
 int mcmc_hip_kernel_times(mcmc_hip_ctx* h, double ms[3], int64_t* n_step_launches, int32_t reset)
 {

@@ -85,6 +85,36 @@ def all_reduce_sum(buf: np.ndarray) -> np.ndarray:
     return buf
 
 
+def device_collective() -> bool:
+    """True if an all-reduce can run on device memory in place (no process group, or RCCL)."""
+    return not is_initialized() or str(_td().get_backend()) == "nccl"
+
+
+class _DeviceBuffer:
+    """A device allocation of another library seen through `__cuda_array_interface__`."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def all_reduce_sum_device(ptr: int, n: int, stream_handle: int):
+    """In-place RCCL all-reduce(sum) of n float64 at the device pointer `ptr`, queued IN ORDER on
+    the HIP stream `stream_handle` (the engine's): what precedes it on that stream has written the
+    buffer, what follows reads the reduced one -- no host bounce, no synchronisation.  Without a
+    process group: nothing to do."""
+    if not is_initialized():
+        return
+    import torch
+    td = _td()
+    if str(td.get_backend()) != "nccl":
+        raise RuntimeError("all_reduce_sum_device needs the nccl (RCCL) backend")
+    dev = torch.device("cuda", local_rank())
+    t = torch.as_tensor(_DeviceBuffer(ptr, n), device=dev)
+    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream_handle), device=dev)):
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+
+
 def describe():
     """What the collective layer really is in this process, measured rather than assumed:
     backend, world size and the number of ranks an all-reduce of ones actually summed."""

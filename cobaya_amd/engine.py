@@ -58,6 +58,13 @@ SYMBOLS = [
      [_H, C.c_int32, c_double_p, c_double_p, c_double_p]),
     ("mcmc_hip_set_target_gaussian", C.c_int, [_H, c_double_p, c_double_p, C.c_int32]),
     ("mcmc_hip_set_target_one", C.c_int, [_H]),
+    ("mcmc_hip_checkpoint_set_ring", C.c_int, [_H, C.c_int32, c_double_p, c_double_p, C.c_int32]),
+    ("mcmc_hip_checkpoint_set_accepted", C.c_int, [_H, C.c_int64]),
+    ("mcmc_hip_checkpoint_begin", C.c_int, [_H, C.c_int32, C.c_int64, C.c_double,
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    ("mcmc_hip_checkpoint_solve", C.c_int, [_H, C.c_double, C.c_double]),
+    ("mcmc_hip_checkpoint_fetch", C.c_int, [_H, c_double_p, c_double_p]),
+    ("mcmc_hip_stream_handle", C.c_uint64, [_H]),
     ("mcmc_hip_drain_samples_pinned", C.c_int, [_H, C.POINTER(c_double_p), c_int64_p]),
     ("mcmc_hip_set_drain_slots", C.c_int, [_H, C.c_int32]),
     ("mcmc_hip_set_target_binned_gaussian", C.c_int,
@@ -463,6 +470,44 @@ class Engine:
         self._check(self._lib.mcmc_hip_fetch_moments(self._h, C.byref(n), _dp(gs), _dp(S),
                                                      c.ctypes.data_as(c_int64_p)))
         return n.value, gs, S, {"steps": int(c[0]), "accepted": int(c[1])}
+
+    # -- the checkpoint on the device
+    def checkpoint_set_ring(self, intervals=(), min_capacity=16):
+        """`intervals`: the (n_snapshots, group_sum[G][d], pooled_S[d][d]) the caller still
+        holds, oldest first (none at the start of a run)."""
+        n = len(intervals)
+        gs = _f64(np.array([iv[1] for iv in intervals]).reshape(n, self.G * self.d)) if n else None
+        S = _f64(np.array([iv[2] for iv in intervals]).reshape(n, self.d * self.d)) if n else None
+        self._check(self._lib.mcmc_hip_checkpoint_set_ring(
+            self._h, n, _dp(gs) if n else None, _dp(S) if n else None, int(min_capacity)))
+        self.ckpt_capacity = 16
+        while self.ckpt_capacity < max(n + 2, int(min_capacity)):
+            self.ckpt_capacity *= 2
+
+    def checkpoint_set_accepted(self, accepted):
+        self._check(self._lib.mcmc_hip_checkpoint_set_accepted(self._h, int(accepted)))
+
+    def checkpoint_begin(self, n_window_intervals, n_window_snapshots, steps_since):
+        """-> (device pointer, length in doubles) of the buffer an all-reduce carries."""
+        ptr, n = C.c_uint64(), C.c_int32()
+        self._check(self._lib.mcmc_hip_checkpoint_begin(
+            self._h, int(n_window_intervals), int(n_window_snapshots), float(steps_since),
+            C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def checkpoint_solve(self, learn_lo, learn_hi):
+        self._check(self._lib.mcmc_hip_checkpoint_solve(self._h, float(learn_lo), float(learn_hi)))
+
+    def checkpoint_fetch(self):
+        st = np.zeros(8)
+        cov = np.empty((self.d, self.d))
+        self._check(self._lib.mcmc_hip_checkpoint_fetch(self._h, _dp(st), _dp(cov)))
+        return {"Rminus1_groups": st[0], "status": int(st[1]), "refreshed": bool(st[2]),
+                "n_chains": st[3], "sum_N": st[4], "d_accepted": st[5], "d_steps": st[6],
+                "accepted": st[7], "mean_of_covs": cov}
+
+    def stream_handle(self):
+        return int(self._lib.mcmc_hip_stream_handle(self._h))
 
     # -- timing
     def enable_timing(self, on=True):

@@ -73,6 +73,14 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
+    "device_checkpoint": False,  # True: R-1 and the proposal refresh ON THE DEVICE, in stream order
+                              # (checkpoint_kernels.hip): the refreshed proposal is in force for
+                              # the very next launch and, with several processes, the all-reduce
+                              # runs on device memory (RCCL, no host bounce).  False (default): on
+                              # the host from the pinned read-back while the next launch runs --
+                              # measured faster on one GPU (the device's
+                              # single-workgroup linear algebra sits ON the critical path, the
+                              # host's beside it)
     "row_buffer_bytes": 1 << 32,  # emit: chains -- device buffer of accepted rows between two
                               # drains (bounds steps_per_launch: every step may accept)
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
@@ -322,6 +330,7 @@ class EnsembleMCMC:
         if self._is_resuming() and self.output and os.path.exists(self._state_file()):
             self._init_bookkeeping()
             self._load_checkpoint()
+            self._init_device_checkpoint()
             return
         # initial points (model.py:707-754 get_valid_point, one per walker)
         self.log.info("Getting initial points... (%d walkers)", W)
@@ -341,6 +350,19 @@ class EnsembleMCMC:
         self._shift = shift[:d] / shift[d]
         self.engine.set_moment_shift(self._shift)
         self._init_bookkeeping()
+        self._init_device_checkpoint()
+
+    def _init_device_checkpoint(self):
+        """`device_checkpoint`: R-1 and the proposal refresh on the device (the default where the
+        engine offers it and the collective can run on device memory)."""
+        can = hasattr(self.engine, "checkpoint_begin") and dist.device_collective()
+        if self.device_checkpoint and not can:
+            self._fail("device_checkpoint: True needs the HIP engine and, with several processes, "
+                       "the nccl (RCCL) backend")
+        self._device_ckpt = bool(self.device_checkpoint)
+        if self._device_ckpt:
+            self.engine.checkpoint_set_ring(self._intervals)
+            self.engine.checkpoint_set_accepted(self._acc_last)
 
     def set_proposer_blocking(self):
         """mcmc.py:320-410: parameter blocks and oversampling factors (manual `blocking` or
@@ -441,6 +463,9 @@ class EnsembleMCMC:
         self._next_ckpt = None   # steps per walker at which the next learn checkpoint is due
         self._ckpt_pending = False  # moments requested, checkpoint not processed yet
         self._ckpt_age = 0       # launches queued since the request
+        self._ckpt_on_device = False   # the pending checkpoint was solved on the device
+        self._snaps_in_interval = 0    # moment snapshots since the last checkpoint request
+        self._ckpt_steps_last = 0      # steps per walker at the last request
 
     # ------------------------------------------------------------------ a17
     def initial_proposal_covmat(self):
@@ -583,6 +608,7 @@ class EnsembleMCMC:
         self._since_snapshot += spl
         if self._launches % max(1, int(self.moments_every)) == 0:
             eng.accumulate_moments()
+            self._snaps_in_interval += 1
         snap_every = int(self.snapshot_every) if self.snapshot_every else None
         if self.emit == "chains":
             if hasattr(eng, "drain_samples_view"):
@@ -608,15 +634,50 @@ class EnsembleMCMC:
             return
         if hasattr(self.engine, "request_moments"):
             self.engine.request_moments()
+        self._ckpt_on_device = False
+        if self._device_ckpt and self._snaps_in_interval > 0:
+            self._begin_device_checkpoint()
+        self._snaps_in_interval = 0
+        self._ckpt_steps_last = self.n_steps_raw
         self._ckpt_pending = True
         self._ckpt_age = 0
         self._next_ckpt = self.n_steps_raw + self._checkpoint_steps()
+
+    @staticmethod
+    def _window_len(counts, dropped):
+        """Intervals of the window (`_window`): the shortest suffix of `counts` (snapshots per
+        checkpoint interval) holding at least half of all snapshots taken so far."""
+        total = dropped + sum(counts)
+        k = 0
+        while k + 1 < len(counts) and sum(counts[k + 1:]) >= total / 2:
+            k += 1
+        return len(counts) - k
+
+    def _begin_device_checkpoint(self):
+        """Queue the checkpoint ON THE DEVICE behind the launch (mcmc_hip_checkpoint_*): window
+        sums over the ring of intervals, the all-reduce in place (RCCL, on the engine's stream),
+        R-1 and -- inside the learning window -- the refreshed transform, written where the next
+        launch reads it.  The host only reads the outcome later (`_finish_checkpoint`)."""
+        eng = self.engine
+        counts = [iv[0] for iv in self._intervals] + [self._snaps_in_interval]
+        k = self._window_len(counts, self._dropped_snapshots)
+        if k + 1 > eng.ckpt_capacity:     # the window outgrew the ring: reload it, larger
+            eng.checkpoint_set_ring(self._intervals, min_capacity=2 * (k + 1))
+        ptr, n = eng.checkpoint_begin(k, sum(counts[-k:]), self.n_steps_raw - self._ckpt_steps_last)
+        if self.size > 1:
+            dist.all_reduce_sum_device(ptr, n, eng.stream_handle())
+        learn = bool(self.learn_proposal)
+        eng.checkpoint_solve(self.learn_proposal_Rminus1_min if learn else np.inf,
+                             self.learn_proposal_Rminus1_max if learn else -np.inf)
+        self._ckpt_on_device = True
 
     def _finish_checkpoint(self):
         self._ckpt_pending = False
         moments = (self.engine.fetch_moments() if hasattr(self.engine, "fetch_moments")
                    else None)
-        self.check_convergence_and_learn_proposal(moments)
+        dev = self.engine.checkpoint_fetch() if self._ckpt_on_device else None
+        self._ckpt_on_device = False
+        self.check_convergence_and_learn_proposal(moments, dev)
         self.i_learn += 1
         if self.emit == "snapshots" and not self.snapshot_every:
             self._snapshot()
@@ -712,10 +773,12 @@ class EnsembleMCMC:
         self.engine.set_moment_shift(self._shift)
         if "acc_n" in z:   # snapshots accumulated on the device since the last read-out
             self.engine.set_moments(int(z["acc_n"]), z["acc_gs"], z["acc_S"])
+            self._snaps_in_interval = int(z["acc_n"])   # (snapshots since the last request)
         self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]
         (self.n_steps_raw, self.i_learn, self._acc_last, self._steps_last, self._launches,
          self._dropped_snapshots, self._accepted_total) = (int(v) for v in book[:7])
         self._next_ckpt = int(book[10]) or None
+        self._ckpt_steps_last = self._steps_last     # (steps per walker at the last request)
         if len(book) > 12:
             self._snap_stride, self._snap_count = int(book[11]), int(book[12])
         txt_rows = int(book[13]) if len(book) > 13 else 0
@@ -872,10 +935,13 @@ class EnsembleMCMC:
         self._intervals = ivs = ivs[k:]
         return (sum(iv[0] for iv in ivs), sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs))
 
-    def check_convergence_and_learn_proposal(self, moments=None):
+    def check_convergence_and_learn_proposal(self, moments=None, dev=None):
         """mcmc.py:773-1032 on pooled sufficient statistics; one all-reduce.
         `moments`: what `engine.fetch_moments()` returned for the checkpoint (None: read them
-        out now, synchronously)."""
+        out now, synchronously).  `dev`: the outcome of the same checkpoint solved ON THE DEVICE
+        (`engine.checkpoint_fetch()`): R-1, the mean of covariances and whether the proposal was
+        refreshed there -- the host then only keeps the books (window, progress table, stop
+        criteria) and logs."""
         d, eng = self.spec.d, self.engine
         if moments is None:
             n_snap, gs, S = eng.read_moments(reset=True)  # synchronises the stream
@@ -887,20 +953,24 @@ class EnsembleMCMC:
             self._intervals.append((n_snap, gs, S))
         if not self._intervals:
             return
-        n, gsum, Ssum = self._window()
         gsz = eng.group_size
-        N_c = float(n * gsz)                       # samples per chain (= group)
-        means = gsum / N_c                         # [G, d], relative to the shift
-        sum_mm = means.T @ means
-        payload = np.concatenate((
-            [float(eng.G), N_c * eng.G, float(c["accepted"] - self._acc_last),
-             float((c["steps"] - self._steps_last) * eng.W), float(c["accepted"])],
-            (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
-        dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
-        n_chains, sum_N, d_acc, d_steps, n_acc_all = payload[:5]
-        sum_Ncov = payload[5:5 + d * d].reshape(d, d)
-        sum_mean = payload[5 + d * d:5 + d * d + d]
-        sum_mm = payload[5 + d * d + d:].reshape(d, d)
+        if dev is None:
+            n, gsum, Ssum = self._window()
+            N_c = float(n * gsz)                       # samples per chain (= group)
+            means = gsum / N_c                         # [G, d], relative to the shift
+            sum_mm = means.T @ means
+            payload = np.concatenate((
+                [float(eng.G), N_c * eng.G, float(c["accepted"] - self._acc_last),
+                 float((c["steps"] - self._steps_last) * eng.W), float(c["accepted"])],
+                (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
+            dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
+            n_chains, sum_N, d_acc, d_steps, n_acc_all = payload[:5]
+            sum_Ncov = payload[5:5 + d * d].reshape(d, d)
+            sum_mean = payload[5 + d * d:5 + d * d + d]
+            sum_mm = payload[5 + d * d + d:].reshape(d, d)
+        else:
+            self._window()      # (the books only: which intervals the window holds from now on)
+            d_acc, d_steps, n_acc_all = dev["d_accepted"], dev["d_steps"], dev["accepted"]
         self._acc_last, self._steps_last = c["accepted"], c["steps"]
         acceptance_rate = d_acc / max(d_steps, 1.0)
         self._acc_rate = acceptance_rate
@@ -913,7 +983,12 @@ class EnsembleMCMC:
         self.log.info("Learn + convergence test @ %d samples accepted.", self._accepted_total)
         self.log.info(" - Acceptance rate: %.3f", acceptance_rate)
         try:
-            Rminus1, mean_of_covs = gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm)
+            if dev is None:
+                Rminus1, mean_of_covs = gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm)
+            elif dev["status"] != 0:
+                raise NotPositiveDefinite(dev["status"], "device checkpoint: matrix not positive definite")
+            else:
+                Rminus1, mean_of_covs = dev["Rminus1_groups"], dev["mean_of_covs"]
         except NotPositiveDefinite:
             self.log.warning("Negative covariance eigenvectors. This may mean that the covariance of "
                         "the samples does not contain enough information at this point. "
@@ -951,6 +1026,14 @@ class EnsembleMCMC:
             elif Rminus1 < self.learn_proposal_Rminus1_min:
                 self.log.info("Convergence better than `learn_proposal_Rminus1_min`: covmat will "
                          "not be updated.")
+            elif dev is not None:
+                # (the device refreshed its transform in stream order when it solved the
+                # checkpoint: the launches queued since already propose with it)
+                if dev["refreshed"]:
+                    self.log.info(" - Updated covariance matrix of proposal pdf.")
+                else:
+                    self.log.debug("Updating covariance matrix failed unexpectedly. waiting until "
+                                   "next covmat learning attempt.")
             else:
                 try:
                     eng.set_proposal_cov(mean_of_covs)  # is already tempered (mcmc.py:1023)

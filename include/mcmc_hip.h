@@ -240,6 +240,35 @@ MCMC_HIP_API int mcmc_hip_request_moments(mcmc_hip_ctx* h);
 MCMC_HIP_API int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, double* group_sum,
                            double* pooled_S, int64_t counters[2]);
 
+/* The learn / convergence checkpoint ON THE DEVICE (MCMC.check_convergence_and_learn_proposal,
+ * mcmc.py:773-1032; checkpoint_kernels.hip): the intervals between checkpoints are kept in a
+ * device ring, the statistics of the window (the later half of the run, mcmc.py:787-790) are
+ * summed there, R-1 of the means is formed (mcmc.py:856-889, functions.py:81-89) and -- when
+ * learn_lo <= R-1 x group_size <= learn_hi (mcmc.py:1009-1023) -- the proposal transform is
+ * refreshed IN PLACE (proposal.py:226-260) with the operations of mcmc_hip_set_proposal_cov, all
+ * in stream order: launches queued after checkpoint_solve use the new proposal, no host round
+ * trip.  Call order per checkpoint: request_moments (the host's copy of the interval) ->
+ * checkpoint_begin (window sums + the buffer an all-reduce carries: *payload_device_ptr is a
+ * device pointer to *payload_len doubles = [chains, sum N, accepted since the last checkpoint,
+ * steps x walkers since, accepted | sum N cov (d*d) | sum of chain means (d) | sum of m m^T (d*d)];
+ * with several processes the caller all-reduces it on the engine's stream, see
+ * mcmc_hip_stream_handle) -> checkpoint_solve -> [more launches] -> checkpoint_fetch:
+ * stats = {R-1 of the chain (= group) means, status (0 ok; 1, 2, 3: the LinAlgError cases of
+ * mcmc.py:870-887), 1 if the proposal was refreshed, chains, sum N, accepted since the last
+ * checkpoint, steps x walkers since, accepted}, mean_of_covs[d*d].
+ * checkpoint_set_ring (re)loads the ring with the intervals the caller still holds (start: none;
+ * resume; growth of the window beyond the capacity): group_sum[n][G*d], pooled_S[n][d*d]. */
+MCMC_HIP_API int mcmc_hip_checkpoint_set_ring(mcmc_hip_ctx* h, int32_t n_intervals, const double* group_sum,
+                                 const double* pooled_S, int32_t min_capacity);
+MCMC_HIP_API int mcmc_hip_checkpoint_set_accepted(mcmc_hip_ctx* h, int64_t accepted_at_last_checkpoint);
+MCMC_HIP_API int mcmc_hip_checkpoint_begin(mcmc_hip_ctx* h, int32_t n_window_intervals, int64_t n_window_snapshots,
+                              double steps_since, uint64_t* payload_device_ptr, int32_t* payload_len);
+MCMC_HIP_API int mcmc_hip_checkpoint_solve(mcmc_hip_ctx* h, double learn_lo, double learn_hi);
+MCMC_HIP_API int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_covs);
+/* the engine's HIP stream (a hipStream_t as an integer), for callers that queue their own work
+ * -- the all-reduce of a multi-process checkpoint -- in order with the engine's */
+MCMC_HIP_API uint64_t mcmc_hip_stream_handle(const mcmc_hip_ctx* h);
+
 /* The R-1 arithmetic of MCMC.check_convergence_and_learn_proposal (mcmc.py:856-889) on
  * reduced sufficient statistics (what the RCCL all-reduce of SURVEY 8e carries):
  * n_chains, sum_N = sum_c N_c, sum_Ncov[d*d] = sum_c N_c cov_c, sum_mean[d] = sum_c m_c,

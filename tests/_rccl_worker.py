@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 
 
-def run_checkpoints(use_group):
+def run_checkpoints(use_group, device_checkpoint=False):
     from cobaya_amd import dist
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
@@ -32,7 +32,8 @@ def run_checkpoints(use_group):
                        for i, n in enumerate(names)}}
     s = MCMCHip({"seed": 9, "n_walkers": 2048, "group_size": 64, "steps_per_launch": "10d",
                  "learn_every": "10d", "max_samples": 6e6, "Rminus1_stop": 0.0,
-                 "proposal_scale": 2.4}, ProblemSpec.from_info(info))
+                 "proposal_scale": 2.4, "device_checkpoint": bool(device_checkpoint)},
+                ProblemSpec.from_info(info))
     s.run()
     out = {"collective": dist.describe(), "progress": s.progress[["N", "acceptance_rate",
                                                                   "Rminus1"]].to_numpy().tolist(),
@@ -47,4 +48,5 @@ def run_checkpoints(use_group):
 
 
 if __name__ == "__main__":
-    print("RESULT " + json.dumps(run_checkpoints(sys.argv[1] == "nccl")))
+    print("RESULT " + json.dumps(run_checkpoints(sys.argv[1] == "nccl",
+                                                 len(sys.argv) > 3 and sys.argv[3] == "device")))

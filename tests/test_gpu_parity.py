@@ -1099,3 +1099,69 @@ def test_wide_basis_groups_bit_exact(d, W, gs, bgs, kw):
     with pytest.raises(E.EngineError, match="incremental"):
         E.Engine(4, 512, group_size=64, basis_group_size=256)
     eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,blocks", [(30, 1024, 64, None), (3, 512, 128, None),
+                                            (100, 512, 64, None),
+                                            (12, 512, 64, [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]])])
+def test_device_checkpoint_matches_the_host_arithmetic(d, W, gs, blocks):
+    """Row N2: the learn / convergence checkpoint on the device -- window sums over
+    the ring of intervals, R-1 of the means (mcmc.py:856-889) and the refreshed transform
+    (proposal.py:226-260) -- against the host routines on the same statistics
+    (`gelman_rubin`, golden G7's arithmetic, and `set_proposal_cov`)."""
+    eng, prob, st = make_pair(d, W, gs, incremental=True, blocks=blocks,
+                              over=[1, 2] if blocks else None)
+    eng.set_moment_shift(np.full(d, 0.5))
+    eng.checkpoint_set_ring()
+    T0 = eng.get_proposal_transform()
+    intervals, acc_last, steps_last = [], 0, 0
+    for k, (n_launch, window, learn) in enumerate([(3, 1, False), (2, 2, False), (4, 2, True),
+                                                   (3, 4, True)]):
+        for _ in range(n_launch):
+            eng.step(2 * d)
+            eng.accumulate_moments()
+        eng.request_moments()
+        lo, hi = (0.0, np.inf) if learn else (np.inf, -np.inf)
+        n_win = sum(iv[0] for iv in intervals[len(intervals) + 1 - window:]) + n_launch
+        steps = eng.counters()["steps"]
+        ptr, n = eng.checkpoint_begin(window, n_win, steps - steps_last)
+        assert n == 5 + 2 * d * d + d and ptr != 0
+        eng.checkpoint_solve(lo, hi)
+        eng.step(d)                                   # (work queued behind the checkpoint)
+        n_snap, gsum, S, c = eng.fetch_moments()
+        assert n_snap == n_launch
+        intervals.append((n_snap, gsum, S))
+        dev = eng.checkpoint_fetch()
+        # the host's version of the same checkpoint (sampler.check_convergence_and_learn_proposal)
+        ivs = intervals[-window:]
+        n_tot = sum(iv[0] for iv in ivs)
+        g_sum, S_sum = sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs)
+        N_c = float(n_tot * gs)
+        means = g_sum / N_c
+        mm = means.T @ means
+        R, mean_of_covs = E.gelman_rubin(float(W // gs), N_c * (W // gs), S_sum - N_c * mm,
+                                         means.sum(0), mm)
+        assert dev["status"] == 0 and dev["n_chains"] == W // gs and dev["sum_N"] == N_c * (W // gs)
+        assert dev["accepted"] == c["accepted"] and dev["d_accepted"] == c["accepted"] - acc_last
+        assert dev["d_steps"] == (steps - steps_last) * W
+        np.testing.assert_allclose(dev["mean_of_covs"], mean_of_covs, rtol=1e-9, atol=1e-18)
+        np.testing.assert_allclose(dev["Rminus1_groups"], R, rtol=1e-8)
+        T1 = eng.get_proposal_transform()
+        if learn:
+            assert dev["refreshed"]
+            ref = E.Engine(d, gs, group_size=gs, incremental=True)
+            ref.set_prior([0] * d, [0.0] * d, [1.0] * d)
+            if blocks:
+                ref.set_blocking(blocks, [1, 2])
+            ref.set_proposal_cov(dev["mean_of_covs"])
+            # from the device's own mean of covariances the transform is the host's, bit for bit
+            assert_bit_equal(T1, ref.get_proposal_transform(), "T")
+            assert_bit_equal(eng.get_proposal_cov(), dev["mean_of_covs"], "cov")
+            ref.close()
+        else:
+            assert not dev["refreshed"]
+            assert_bit_equal(T1, T0, "T untouched")
+        T0 = T1
+        acc_last, steps_last = c["accepted"], steps + d
+        steps_last = steps
+    eng.close()

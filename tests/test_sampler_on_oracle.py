@@ -300,8 +300,8 @@ def test_no_checkpoint_is_processed_after_convergence(lag):
     seen = []
     orig = s.check_convergence_and_learn_proposal
 
-    def spy(moments=None):
-        orig(moments)
+    def spy(*a, **k):
+        orig(*a, **k)
         seen.append(bool(s.converged))
     s.check_convergence_and_learn_proposal = spy
     s.run()
