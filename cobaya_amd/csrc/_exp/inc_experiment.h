@@ -3,6 +3,7 @@
 // of cobaya_amd/csrc/_exp/lib_<name>.so, selected by -D flags:
 //   -DEXP_STEP_WAVES=n / -DEXP_DRAG_WAVES=n / -DEXP_MIX_WAVES=n   waves per SIMD of a kernel family
 //   -DEXP_PIPE=n              pairs fetched ahead in the trial loop of step_inc_kernel
+//   -DEXP_KEEP=1              the step's (v, u) pairs stay in registers (no second LDS read)
 //   -DEXP_NO_ROTATE           no wave-priority rotation;  -DEXP_ROTATE_SHIFT=k  its period
 //   -DEXP_BLOCK_TIMES         start / end clock and hardware placement of every workgroup
 //                             (read back by tools/block_times.py)
@@ -34,6 +35,11 @@
 #define MCMC_EXP_ROTATE_SHIFT(tuned) (EXP_ROTATE_SHIFT)
 #else
 #define MCMC_EXP_ROTATE_SHIFT(tuned) (tuned)
+#endif
+#ifdef EXP_KEEP
+#define MCMC_EXP_KEEP(tuned) (EXP_KEEP != 0)
+#else
+#define MCMC_EXP_KEEP(tuned) (tuned)
 #endif
 #ifdef EXP_NO_ROTATE
 #define MCMC_EXP_ROTATE(on) (false)

@@ -38,6 +38,7 @@
 #define MCMC_EXP_BLOCK_END() ((void)0)
 #define MCMC_EXP_ROTATE_SHIFT(tuned) (tuned)     // log2 of the shader clocks per priority turn
 #define MCMC_EXP_ROTATE(on) (on)                 // rotate the wave priorities at all
+#define MCMC_EXP_KEEP(tuned) (tuned)             // keep a step's (v, u) pairs in registers
 #endif
 
 namespace mcmc {
@@ -166,14 +167,26 @@ __host__ __device__ constexpr int inc_chunk(int dq)
 // walkers = 4 waves per SIMD at most).  Not "the largest occupancy that does not spill": four
 // waves with a few spilled registers beat three without up to DQ = 12 (d = 40: +40 %), three are
 // almost never the best choice, and above that two waves -- which also get the read-ahead of
-// the LDS pairs (PIPE) -- beat one even where they spill (d = 128, MODE 0: +12 %).  The odd
-// entries (13, 15) are where the per-dimension constants move from registers to LDS.
+// the LDS pairs (PIPE) -- beat one even where they spill (d = 128, MODE 0: +12 % in round 2;
+// round 3, with the pairs kept in registers, one wave wins from dq = 31: see inc_keep_pairs).
+// The odd entries (13, 15) are where the per-dimension constants move from registers to LDS.
 __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
 {
     return MCMC_EXP_WAVES(STEP,
-        mode == 0 ? (dq <= 12 ? 4 : 2)
+        mode == 0 ? (dq <= 12 ? 4 : dq <= 30 ? 2 : 1)
         : mode == 1 ? ((dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1)
         : (dq <= 5 ? 4 : dq == 6 ? 3 : dq == 13 ? 4 : dq == 15 ? 3 : dq <= 31 ? 2 : 1));
+}
+
+// The step's (v, u) pairs kept in registers from the trial to the commit (no second LDS read):
+// MEASURED (round 3, tools/exp_inc_variants.sh with -DEXP_KEEP=1 / -DEXP_STEP_WAVES=1, 65 536
+// walkers, step kernel ms per 40 d steps, default -> kept): d = 52: 3.15 -> 3.01, 64: 4.25 -> 3.81,
+// 80: 5.98 -> 5.36, 96: 8.25 -> 7.28, 100: 9.83 -> 8.96, 112: 11.99 -> 11.42, 116: 14.5 -> 13.9;
+// d = 124 / 128 (one wave per SIMD now, inc_min_waves): 24.9 -> 17.7 / 35.4 -> 19.5.  The kernels
+// at four waves per SIMD (dq <= 12, 128 registers) cannot afford the 4 dq registers.
+__host__ __device__ constexpr bool inc_keep_pairs(int dq, int mode)
+{
+    return mode == 0 && dq >= 13;
 }
 
 //   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
@@ -199,7 +212,11 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
     // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step
     // either way; now DQ 32-bit ones.)
-    constexpr int PIPE = MCMC_EXP_PIPE(inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
+    // KEEP: the step's DQ (v, u) pairs stay in registers from the trial to the commit instead of
+    // being read from LDS twice (4 DQ VGPRs: only where the kernel runs two waves per SIMD on
+    // 256 registers and the LDS pipe, not the register file, is what binds)
+    constexpr bool KEEP = MCMC_EXP_KEEP(inc_keep_pairs(DQ, MODE));
+    constexpr int PIPE = KEEP ? 0 : MCMC_EXP_PIPE(inc_min_waves(DQ, MODE) <= 2 ? 4 : 0);   // pairs fetched ahead
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
@@ -351,7 +368,13 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             sc = sc + fma(-0.5 * qq, qq, mls);
                         }
                     };
-                    if constexpr (PIPE == 0) {
+                    double2 pk[KEEP ? DQ : 1];
+                    if constexpr (KEEP) {
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) pk[kk] = col[4 * kk];
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) trial(kk, pk[kk]);
+                    } else if constexpr (PIPE == 0) {
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) trial(kk, col[4 * kk]);
                     } else {
@@ -381,7 +404,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         inside = quad_max_u32(hmx) < bhi_word;
                         if (lanes(!inside) != 0ull) {   // (wave-uniform, rare) the exact test
                             lds_pairs colx = relaunder(col);
-#pragma unroll 4
+                            // (fully unrolled: a rolled loop would index x[] at run time and
+                            // move the walker's state from registers to scratch memory)
+#pragma unroll
                             for (int kk = 0; kk < DQ; ++kk) {
                                 const double t = fma(r, colx[4 * kk].x, x[kk]);
                                 inb &= lanes(t <= bhi) & lanes(t >= blo);
@@ -431,7 +456,13 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // (the pairs are read AGAIN from LDS: the pointer passes through an empty
                     // asm so that the compiler cannot keep the first reads alive in 4 DQ registers)
                     lds_pairs col2 = relaunder(col);
-                    if constexpr (PIPE == 0) {
+                    if constexpr (KEEP) {
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) {
+                            x[kk] = fma(ra, pk[kk].x, x[kk]);
+                            y[kk] = fma(ra, pk[kk].y, y[kk]);
+                        }
+                    } else if constexpr (PIPE == 0) {
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
                             // (four pairs at a time: the pointer of the next four depends, through
