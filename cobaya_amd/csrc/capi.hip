@@ -290,7 +290,8 @@ extern "C" hipError_t mcmc_hip_launch_pl_prior(const double* t, int n, int d, co
                                                hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_residual(const mcmc::PlResidualArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_bin(const mcmc::PlBinArgs* a, hipStream_t st);
-extern "C" hipError_t mcmc_hip_launch_pl_chi2(const mcmc::PlChi2Args* a, int n_walkers, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_chi2(const mcmc::PlChi2Args* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_combine(const double* psum, double* chi2, int n, hipStream_t st);
 
 struct mcmc_hip_ctx {
     mcmc_hip_config cfg{};
@@ -402,8 +403,8 @@ struct mcmc_hip_ctx {
         std::vector<double> Linv, Bc0, BJ;               // host copies (tests hand them to the oracle)
         DevBuf<double> resp, theta0, Astream, weights, X;
         DevBuf<int> dbins;
-        DevBuf<double> delta, trial, lp_t, Ea, chi2;     // step scratch, W walkers
-        DevBuf<double> edelta, etrial, elp, echi2, ecl, eA;   // evaluate scratch
+        DevBuf<double> delta, trial, lp_t, Ea, psum;     // step scratch, W walkers
+        DevBuf<double> edelta, etrial, elp, echi2, epsum, ecl, eA;   // evaluate scratch
         unsigned long long tile_off[8][5];
         int nk[8][5];
     } bg;
@@ -656,16 +657,18 @@ int set_target_common(mcmc_hip_ctx* h, int K, const double* means, const double*
 // the last -- the most expensive -- tile down
 inline int binned_class(int R, int NT) { const int m = (NT - 1 - R) & 15; return m < 8 ? m : 15 - m; }
 
-// chi2 of the residuals held in `delta` (n walkers, a multiple of 64) -> chi2
-int binned_chi2(mcmc_hip_ctx* h, const double* delta, double* chi2, int n)
+// the 32 partial sums of chi2 per walker of the residuals held in `delta` (n walkers, a multiple
+// of 64) -> psum[32][n]; chi2 (may be null): their combination, one value per walker
+int binned_chi2(mcmc_hip_ctx* h, const double* delta, double* psum, double* chi2, int n)
 {
     auto& B = h->bg;
     mcmc::PlChi2Args c{};
-    c.delta = delta; c.Astream = B.Astream.p; c.chi2 = chi2;
+    c.delta = delta; c.Astream = B.Astream.p; c.psum = psum;
     std::memcpy(c.tile_off, B.tile_off, sizeof c.tile_off);
     std::memcpy(c.nk, B.nk, sizeof c.nk);
-    c.KT = B.KT; c.ntw = B.ntw;
-    HIP_TRY(h, mcmc_hip_launch_pl_chi2(&c, n, h->stream));
+    c.KT = B.KT; c.ntw = B.ntw; c.n_walkers = n; c.n_sets = n / 64;
+    HIP_TRY(h, mcmc_hip_launch_pl_chi2(&c, h->stream));
+    if (chi2) HIP_TRY(h, mcmc_hip_launch_pl_combine(psum, chi2, n, h->stream));
     return MCMC_HIP_OK;
 }
 
@@ -697,7 +700,8 @@ int evaluate_binned_points(mcmc_hip_ctx* h, int n, const double* x, double* logp
                                         h->uniform_logp, B.elp.p, h->stream));
     int rc = binned_residual(h, B.etrial.p, B.edelta.p, (int)np);
     if (rc) return rc;
-    rc = binned_chi2(h, B.edelta.p, B.echi2.p, (int)np);
+    HIP_TRY(h, B.epsum.resize(32 * np));
+    rc = binned_chi2(h, B.edelta.p, B.epsum.p, B.echi2.p, (int)np);
     if (rc) return rc;
     std::vector<double> c2(np), lp(np);
     HIP_TRY(h, hipMemcpyAsync(lp.data(), B.elp.p, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));
@@ -725,7 +729,7 @@ int step_binned(mcmc_hip_ctx* h, int n_steps)
     HIP_TRY(h, B.trial.resize((size_t)d * W));
     HIP_TRY(h, B.lp_t.resize(W));
     HIP_TRY(h, B.Ea.resize(W));
-    HIP_TRY(h, B.chi2.resize(W));
+    HIP_TRY(h, B.psum.resize((size_t)32 * W));
     HIP_TRY(h, B.delta.resize(((size_t)W / 64) * (size_t)B.KT * 256 + (size_t)mcmc::kPlPad * 256));
     const size_t dd = (size_t)mcmc::v_slab(d);
     const int max_cyc = (int)std::max<size_t>(1, (64u << 20) / (sizeof(double) * dd * (size_t)h->G));
@@ -739,7 +743,7 @@ int step_binned(mcmc_hip_ctx* h, int n_steps)
     a.s.key0 = (uint32_t)h->cfg.seed; a.s.key1 = (uint32_t)(h->cfg.seed >> 32);
     a.s.uniform_logp = h->uniform_logp; a.s.temperature = h->cfg.temperature;
     a.s.max_tries = h->cfg.max_tries; a.s.cps = d; a.s.slab = (int)dd;
-    a.d = d; a.trial = B.trial.p; a.lp_t = B.lp_t.p; a.Ea = B.Ea.p; a.chi2_t = B.chi2.p;
+    a.d = d; a.trial = B.trial.p; a.lp_t = B.lp_t.p; a.Ea = B.Ea.p; a.psum_t = B.psum.p;
     int left = n_steps;
     bool pending = false;   // a trial has been proposed and evaluated, not yet accepted / rejected
     while (left > 0) {
@@ -774,7 +778,7 @@ int step_binned(mcmc_hip_ctx* h, int n_steps)
             }
             {
                 Timed t(h, 5);
-                const int rc = binned_chi2(h, B.delta.p, B.chi2.p, W);
+                const int rc = binned_chi2(h, B.delta.p, B.psum.p, nullptr, W);
                 if (rc) return rc;
                 h->n_step_launches += 1;
             }
@@ -981,7 +985,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
         auto& B = h->bg;
         B.resp.release(); B.theta0.release(); B.Astream.release(); B.weights.release();
         B.X.release(); B.dbins.release(); B.delta.release(); B.trial.release(); B.lp_t.release();
-        B.Ea.release(); B.chi2.release(); B.edelta.release(); B.etrial.release(); B.elp.release();
+        B.Ea.release(); B.psum.release(); B.epsum.release(); B.edelta.release(); B.etrial.release(); B.elp.release();
         B.echi2.release(); B.ecl.release(); B.eA.release();
     }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1207,7 +1211,8 @@ int mcmc_hip_evaluate_binned(mcmc_hip_ctx* h, int32_t n_pts, int32_t L0, int32_t
     b.cl = B.ecl.p; b.A = B.eA.p; b.bins = B.dbins.p; b.weights = B.weights.p; b.X = B.X.p;
     b.delta = B.edelta.p; b.n_pts = n_pts; b.n_bins = B.n_bins; b.KT = B.KT; b.L0 = L0; b.stride = n_ell;
     HIP_TRY(h, mcmc_hip_launch_pl_bin(&b, h->stream));
-    const int rc = binned_chi2(h, B.edelta.p, B.echi2.p, (int)np);
+    HIP_TRY(h, B.epsum.resize(32 * np));
+    const int rc = binned_chi2(h, B.edelta.p, B.epsum.p, B.echi2.p, (int)np);
     if (rc) return rc;
     std::vector<double> c2(np);
     HIP_TRY(h, hipMemcpyAsync(c2.data(), B.echi2.p, sizeof(double) * np, hipMemcpyDeviceToHost, h->stream));

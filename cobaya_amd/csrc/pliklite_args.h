@@ -15,7 +15,7 @@ struct PlWalkerArgs {
     double* trial;         // [d][W] trial points
     double* lp_t;          // [W] log-prior of the trial, -inf outside the support
     double* Ea;            // [W] Exp(1) variate of the accept test
-    const double* chi2_t;  // [W] chi2 of the trial (pl_chi2_kernel)
+    const double* psum_t;  // [32][W] partial sums of the trial's chi2 (pl_chi2_kernel)
 };
 struct PlResidualArgs {
     const double* trial;   // [d][W]
@@ -38,10 +38,12 @@ struct PlChi2Args {
     const double* Astream; // tile t of wave q at tile_off[q][t]: [nk[q][t]][64] doubles,
                            // k-step kk = L^-1[16 R + (l & 15)][4 kk + (l >> 4)]; kPlPad k-steps of
                            // padding behind the last tile (operands are fetched ahead)
-    double* chi2;          // [W]
+    double* psum;          // [8][4][n_walkers]: p[q][c] of every walker (chains of its chi2)
     unsigned long long tile_off[8][5];   // (absent tiles: any valid offset)
     int nk[8][5];          // k-steps of tile t of wave q: ascending in t, absent tiles first (0)
     int KT, ntw;
+    int n_walkers, n_sets; // walkers = 64 n_sets
+    int batches;           // (set by the launcher) sets of 64 walkers per workgroup
 };
 
 }  // namespace mcmc

@@ -31,8 +31,9 @@
 // the 4 x 16 slices of delta of its four walker tiles (B operands, shared by the active tiles:
 // used for up to 5 MFMAs each), one k-step ahead of the MFMAs; the loop is cut into one phase per
 // set of active tiles (tile R is finished after k-step 4 R + 3), so an iteration has no branch.  Every tile of L^-1 is read once
-// per workgroup (1.5 MB per 64 walkers from L2), delta once per wave; nothing passes through LDS
-// but the final 8 x 4 partial sums per walker.
+// per 64 walkers (1.5 MB from L2), delta once per wave; nothing passes through LDS and there is NO
+// barrier: a workgroup takes several sets of 64 walkers in turn (one workgroup per CU for the whole
+// launch), its waves run free and leave their partial sums p[q][c] per walker in memory.
 #include "det_math.h"
 #include "pliklite_args.h"
 
@@ -53,6 +54,8 @@ __device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(unsign
 // emitted rows.  PROPOSE: variates of step a.step (un-paired stream), trial t = fma(r, v, x)
 // along the group's direction (proposal.py:69, 224), prior support and normal priors
 // (prior.py:733-763; one ascending chain, d <= 32).
+__device__ __forceinline__ double pl_combine(const double* __restrict__ psum, size_t W, size_t w);
+
 template <bool ACCEPT, bool PROPOSE>
 __global__ void __launch_bounds__(64) pl_walker_kernel(const PlWalkerArgs a)
 {
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(64) pl_walker_kernel(const PlWalkerArgs a)
         int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
         const double lp = a.lp_t[w], Ea = a.Ea[w];
         const bool inb = lp != -INFINITY;
-        const double ll = -0.5 * a.chi2_t[w];                  // planck_pliklite.py:171
+        const double ll = -0.5 * pl_combine(a.psum_t, (size_t)W, (size_t)w);   // planck_pliklite.py:171
         const double lt = inb ? lp + ll : -INFINITY;
         accept = inb && lt != -INFINITY && (lt > lpost || Ea > (lpost - lt) / s.temperature);
         if (accept) {
@@ -210,10 +213,8 @@ __global__ void __launch_bounds__(64) pl_bin_kernel(const PlBinArgs a)
 template <int NTW>
 __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
 {
-    __shared__ double sp[8][4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = blockIdx.x;
     int nk[NTW];
     const double* __restrict__ ap[NTW];
 #pragma unroll
@@ -221,6 +222,14 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
         nk[t] = a.nk[wave][t];          // ascending in t; absent tiles first (0)
         ap[t] = a.Astream + a.tile_off[wave][t] + lane;
     }
+    // a workgroup takes `batches` consecutive sets of 64 walkers; its eight waves run FREE -- no
+    // barrier anywhere: every wave leaves the 4 partial sums p[q][c] of its rows per walker in
+    // psum[q][c][walker] and the walker kernel (or the host) combines the 32 of a walker in the
+    // specified order.  With one workgroup per CU for the whole launch the only idle time left is
+    // the difference between the waves' totals (1.4 %), not a ramp and a tail per 64 walkers.
+    for (int bt = 0; bt < a.batches; ++bt) {
+    const int wg = blockIdx.x * a.batches + bt;
+    if (wg >= a.n_sets) break;
     const double* __restrict__ dl = a.delta + (size_t)wg * a.KT * 256 + lane;
     d4 acc[NTW][4];
 #pragma unroll
@@ -281,17 +290,27 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p = fma(acc[t][wt][r], acc[t][wt][r], p);
             }
-        sp[wave][c][wt * 16 + n] = p;
+        a.psum[(size_t)(wave * 4 + c) * a.n_walkers + (size_t)wg * 64 + wt * 16 + n] = p;
     }
-    __syncthreads();
-    if (tid < 64) {
-        double sq[8];
+    }   // batches
+}
+
+// chi2 of a walker from the 32 partial sums pl_chi2_kernel left (oracle: orc_binned_chi2_of_delta)
+__device__ __forceinline__ double pl_combine(const double* __restrict__ psum, size_t W, size_t w)
+{
+    double sq[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            sq[q] = (sp[q][0][tid] + sp[q][1][tid]) + (sp[q][2][tid] + sp[q][3][tid]);
-        a.chi2[(size_t)wg * 64 + tid] =
-            ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
-    }
+    for (int q = 0; q < 8; ++q)
+        sq[q] = (psum[(size_t)(4 * q + 0) * W + w] + psum[(size_t)(4 * q + 1) * W + w]) +
+                (psum[(size_t)(4 * q + 2) * W + w] + psum[(size_t)(4 * q + 3) * W + w]);
+    return ((sq[0] + sq[1]) + (sq[2] + sq[3])) + ((sq[4] + sq[5]) + (sq[6] + sq[7]));
+}
+
+__global__ void __launch_bounds__(64) pl_combine_kernel(const double* __restrict__ psum,
+                                                       double* __restrict__ chi2, int n)
+{
+    const int w = blockIdx.x * 64 + threadIdx.x;
+    if (w < n) chi2[w] = pl_combine(psum, (size_t)n, (size_t)w);
 }
 
 }  // namespace
@@ -342,20 +361,29 @@ extern "C" hipError_t mcmc_hip_launch_pl_bin(const PlBinArgs* a, hipStream_t st)
     return hipGetLastError();
 }
 
-extern "C" hipError_t mcmc_hip_launch_pl_chi2(const PlChi2Args* a, int n_walkers, hipStream_t st)
+extern "C" hipError_t mcmc_hip_launch_pl_chi2(const PlChi2Args* a, hipStream_t st)
 {
-    const dim3 g(n_walkers / 64), b(512);
+    // one workgroup per CU for the whole launch where the ensemble is large enough
+    PlChi2Args b = *a;
+    b.batches = (a->n_sets + 255) / 256;
+    const dim3 g((a->n_sets + b.batches - 1) / b.batches), blk(512);
     switch (a->ntw) {
-    case 1: hipLaunchKernelGGL(pl_chi2_kernel<1>, g, b, 0, st, *a); break;
-    case 2: hipLaunchKernelGGL(pl_chi2_kernel<2>, g, b, 0, st, *a); break;
-    case 3: hipLaunchKernelGGL(pl_chi2_kernel<3>, g, b, 0, st, *a); break;
-    case 4: hipLaunchKernelGGL(pl_chi2_kernel<4>, g, b, 0, st, *a); break;
-    case 5: hipLaunchKernelGGL(pl_chi2_kernel<5>, g, b, 0, st, *a); break;
+    case 1: hipLaunchKernelGGL(pl_chi2_kernel<1>, g, blk, 0, st, b); break;
+    case 2: hipLaunchKernelGGL(pl_chi2_kernel<2>, g, blk, 0, st, b); break;
+    case 3: hipLaunchKernelGGL(pl_chi2_kernel<3>, g, blk, 0, st, b); break;
+    case 4: hipLaunchKernelGGL(pl_chi2_kernel<4>, g, blk, 0, st, b); break;
+    case 5: hipLaunchKernelGGL(pl_chi2_kernel<5>, g, blk, 0, st, b); break;
     default: return hipErrorInvalidValue;
     }
     static const char* const names[5] = {"mcmc::pl_chi2_kernel<1>", "mcmc::pl_chi2_kernel<2>",
                                          "mcmc::pl_chi2_kernel<3>", "mcmc::pl_chi2_kernel<4>",
                                          "mcmc::pl_chi2_kernel<5>"};
     mcmc_hip_note_step_kernel(names[a->ntw - 1]);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_combine(const double* psum, double* chi2, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(pl_combine_kernel, dim3((n + 63) / 64), dim3(64), 0, st, psum, chi2, n);
     return hipGetLastError();
 }
