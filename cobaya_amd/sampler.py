@@ -353,8 +353,8 @@ class EnsembleMCMC:
         self._init_device_checkpoint()
 
     def _init_device_checkpoint(self):
-        """`device_checkpoint`: R-1 and the proposal refresh on the device (the default where the
-        engine offers it and the collective can run on device memory)."""
+        """`device_checkpoint: True`: R-1 and the proposal refresh on the device (an option, not the
+        default: on one GPU the host path hides the same work behind the next launch)."""
         can = hasattr(self.engine, "checkpoint_begin") and dist.device_collective()
         if self.device_checkpoint and not can:
             self._fail("device_checkpoint: True needs the HIP engine and, with several processes, "
