@@ -117,6 +117,10 @@ def build(dims=None, jobs=None, verbose=True):
         tasks.append((inc, os.path.join(OBJ, f"incremental_emit_{lo_}.o"),
                       ["-DMCMC_INC_EMIT_TU", f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
                       _digest([inc] + hdrs, extra=f"incemit{lo_}-{hi_}|{' '.join(FLAGS)}")))
+    anyk = os.path.join(CSRC, "incremental_any.hip")   # the general incremental kernel
+    for part in (0, 1, 2):   # the LDS kernel + KM = 4 | KM = 8 | KM = 16 register planes
+        tasks.append((anyk, os.path.join(OBJ, f"incremental_any_{part}.o"), [f"-DANY_PART={part}"],
+                      _digest([anyk] + hdrs, extra=f"any{part}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr, pl_hdr, ck_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

@@ -272,6 +272,12 @@ extern "C" hipError_t mcmc_hip_launch_inc_emit_1(const mcmc::IncStepArgs*, hipSt
 extern "C" hipError_t mcmc_hip_launch_inc_emit_9(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_inc_emit_17(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_inc_emit_25(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+// incremental_any.hip: the general incremental kernel (any number of modes / periodic parameters)
+extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_whiten_directions_planes(const mcmc::IncDirArgs*, int,
+                                                               hipStream_t) __attribute__((weak));
+extern "C" int mcmc_hip_inc_any_fits(int d, int n_modes, int n_periodic, int n_walkers,
+                                     int group_size) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_whiten_state(const double* x, double* y, const double* mean,
                                                    const double* Lrow, int d, int W, int K,
                                                    hipStream_t st) __attribute__((weak));
@@ -566,7 +572,7 @@ int upload_constants(mcmc_hip_ctx* h)
         HIP_TRY(h, hipMemcpyAsync(h->dLcol.p, lcol.data(), sizeof(double) * lcol.size(),
                                   hipMemcpyHostToDevice, h->stream));
     }
-    if (h->incremental && K >= 1 && K <= 4) {
+    if (h->incremental && K >= 1 && K <= mcmc::kMaxModes) {
         const int dq = (d + 3) / 4, dpad = 4 * dq;
         HIP_TRY(h, h->y.resize((size_t)K * d * h->W));
         std::vector<double> pr((size_t)5 * dpad, 0.0);
@@ -812,6 +818,25 @@ const char* mcmc_hip_last_error(const mcmc_hip_ctx* h)
 int mcmc_hip_dim_supported(int d)
 {
     return kernels_for_dim(d) != nullptr || big_for_dim(d) != nullptr;
+}
+
+int mcmc_hip_incremental_supported(int32_t d, int32_t n_modes, int32_t n_periodic, int32_t n_drag,
+                                   int32_t n_walkers, int32_t basis_group_size)
+{
+    const int dq = (d + 3) / 4, K = n_modes;
+    if (d < 2 || d > 128 || K < 1 || K > mcmc::kMaxModes || n_periodic < 0 || n_periodic > d ||
+        n_drag < 0 || n_walkers <= 0 || basis_group_size <= 0 || basis_group_size % 64 != 0 ||
+        n_walkers % basis_group_size != 0 || !mcmc_hip_launch_whiten_state)
+        return 0;
+    if (n_drag > 0) {   // (step_incremental: a step's 1 + n_drag columns fit the LDS twice over)
+        const int chunk_steps = std::max(1, (1024 / (4 * dq)) / (1 + n_drag));
+        const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)chunk_steps * (1 + n_drag) * 4 * dq;
+        return K == 1 && n_periodic == 0 && drag_lds <= (128u << 10);
+    }
+    if ((K == 1 || (K <= 4 && dq <= 16)) && (n_periodic == 0 || (K == 1 && n_periodic <= 8)))
+        return 1;
+    return mcmc_hip_inc_any_fits &&
+           mcmc_hip_inc_any_fits(d, K, n_periodic, n_walkers, basis_group_size) ? 1 : 0;
 }
 
 int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
@@ -1579,6 +1604,7 @@ struct IncPlan {   // what the cutting of launches depends on besides the step c
     size_t colb, dd, ddf;
     unsigned long long R;
     bool drag;
+    bool any;   // the general kernel (incremental_any.hip): columns as planes (v, u_1 .. u_K)
 };
 struct IncSeg {    // one launch: steps [step0, step0 + n)
     unsigned long long step0, c0, cyc0_f;
@@ -1646,7 +1672,8 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
     w.colflag = D.has_flags ? D.colflag.p : nullptr;
     w.vflag = any_1d ? D.vflag.p : nullptr;
     if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
-    HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
+    if (P.any) HIP_TRY(h, mcmc_hip_launch_whiten_directions_planes(&w, h->BG, st));
+    else HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
     if (P.drag) {   // the fast directions of the n * n_drag interpolation steps
         w.V = D.Vf.p;
         w.step0 = s.step0 * (unsigned long long)nd; w.cycle0 = s.cyc0_f;
@@ -1673,24 +1700,32 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)P.chunk_steps * (1 + nd) * 4 * dq;
     int n_periodic = 0;
     for (int i = 0; i < d; ++i) n_periodic += h->periodic[i] ? 1 : 0;
-    if (K < 1 || K > 4 || (K > 1 && (dq > 16 || P.drag)) ||
-        (n_periodic > 0 && (K > 1 || P.drag || n_periodic > 8)) ||
+    // what the tuned kernels leave out runs on the general one (incremental_any.hip): more than
+    // four modes, mixtures above d = 64, periodic parameters with a mixture, more than eight of
+    // them -- Metropolis steps only
+    P.any = !P.drag && (K > 4 || (K > 1 && dq > 16) || (n_periodic > 0 && (K > 1 || n_periodic > 8)));
+    if (K < 1 || K > mcmc::kMaxModes || (P.drag && (K > 1 || n_periodic > 0)) ||
         (P.drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "incremental evaluation serves one Gaussian mode (or, without dragging and "
-                    "with non-periodic priors, a mixture of up to four at d <= 64); up to eight "
-                    "periodic parameters without dragging; use evaluation: full for this model");
+                    "incremental evaluation with dragging serves one Gaussian mode with "
+                    "non-periodic priors; use evaluation: full for this model");
+    if (P.any && (!mcmc_hip_launch_inc_any || !mcmc_hip_inc_any_fits ||
+                  !mcmc_hip_inc_any_fits(d, K, n_periodic, h->W, h->bgs)))
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "incremental evaluation: %d modes at d=%d with %d periodic parameters do not "
+                    "fit the LDS of a CU; use evaluation: full for this model", K, d, n_periodic);
     const bool emit = h->cfg.emit_capacity > 0;
     if (emit) {
         bool one_d = false;   // (a block of one parameter: its columns draw other variates)
         for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b) one_d = one_d || h->blk_size[b] == 1;
-        if (K != 1 || n_periodic > 0 || P.drag || one_d)
+        if (K != 1 || n_periodic > 0 || P.drag || one_d || P.any)
             return fail(h, MCMC_HIP_ERR_ARG,
                         "incremental evaluation emits rows (emit_capacity > 0) for one Gaussian "
                         "mode with non-periodic priors, blocks of at least two parameters and "
                         "Metropolis steps; use evaluation: full for this model");
     }
-    auto launch = emit ? (dq <= 8 ? mcmc_hip_launch_inc_emit_1 : dq <= 16 ? mcmc_hip_launch_inc_emit_9
+    auto launch = P.any ? mcmc_hip_launch_inc_any
+                  : emit ? (dq <= 8 ? mcmc_hip_launch_inc_emit_1 : dq <= 16 ? mcmc_hip_launch_inc_emit_9
                           : dq <= 24 ? mcmc_hip_launch_inc_emit_17 : mcmc_hip_launch_inc_emit_25)
                        : (dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                           : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25);
@@ -1702,7 +1737,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     P.Lf = P.drag ? block_slots(h, 2) : 0;
     P.R = 40ull * (unsigned long long)P.Lc;
     // doubles per column: (v, u) pairs, or the planes v, u_1 .. u_K of a mixture
-    P.colb = (K == 1 ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
+    P.colb = ((K == 1 && !P.any) ? 8 : 4 * (size_t)(1 + K)) * (size_t)dq;
     P.max_steps_vu = (int)std::max<size_t>(
         4, ((size_t)512 << 20) / (sizeof(double) * P.colb * (size_t)(1 + nd) * (size_t)h->BG));
     // (blocked directions are written with column stride d at every d)

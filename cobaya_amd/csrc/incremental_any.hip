@@ -1,0 +1,861 @@
+// mcmc_hip -- the GENERAL incremental step kernel (gfx950 only), 2 <= d <= 128.
+//
+// What the tuned incremental kernels (incremental_kernels.hip) leave out: mixtures of more than
+// four modes (gaussian_mixture.py:138-163, up to kMaxModes), mixtures above d = 64, periodic
+// parameters (prior.py:658-676) together with a mixture, and more than eight periodic
+// parameters.  Same specification (oracle/mcmc_oracle.c, step_core_inc), same O(d) step: the trial
+// t = x + r v has the whitened residuals yt_k = y_k + r u_k, u_k = L_k^-1 v shared by the walkers
+// of a basis group; a periodic coordinate that changes its winding number by the wrap carries the
+// move sh = t' - t into every residual, yt_k[j] += sh L_k^-1[j][i] for j >= i.
+//
+// Layout: FOUR lanes per walker as in the tuned kernels (lane class c = lane & 3 owns the
+// dimensions i = 4 kk + c; chi2 and the normal-prior terms are four interleaved chains combined
+// (p0 + p1) + (p2 + p3)), x in registers -- but the K residuals of a walker live in LDS, lane-major
+// ([mode][kk][lane]: conflict-free 8-byte accesses), because K dq doubles per lane do not fit the
+// register file at an occupancy worth having, and K and the periodic set are run-time values.
+// A workgroup is 1, 2 or 4 waves (16 walkers each) of ONE basis group: the launcher picks the
+// width that puts the most waves on a CU given the LDS the state needs.  The columns
+// (v, u_1 .. u_K) of the launch are staged through LDS in chunks, double-buffered, by
+// global->LDS DMA, as PLANES ([1 + K][4 dq], whiten_directions_planes_kernel below).
+// The trial point and the trial residuals are NOT kept: the commit recomputes them from the
+// column (x += ra v, y_k += ra u_k with ra = r where the walker accepts and 0 elsewhere; with a
+// wrap in the wave the residuals are selected instead).
+//
+// Mixtures WITHOUT periodic parameters whose residuals fit the register file -- up to 4 modes at
+// 64 < d <= 128, up to 8 at d <= 92, up to 16 at d <= 48 -- run on step_inc_regs_kernel<DQ, KM>
+// instead: step_inc_mix_kernel's design (everything in registers, KM = 4, 8 or 16 register
+// planes of which the first n_modes are live), which does not pay the LDS round trips and is not
+// held to one wave per SIMD by the LDS the state takes.  One translation unit per KM
+// (build.py: -DANY_PART=0 / 1 / 2).
+#include <string>
+
+#include "det_math.h"
+#include "kernels.h"
+
+extern "C" void mcmc_hip_note_step_kernel(const char* name);
+
+#ifndef ANY_REGS_TWO_WAVES
+#define ANY_REGS_TWO_WAVES 80   // doubles of state per lane up to which two waves share a SIMD
+#endif
+#ifndef ANY_PART
+#define ANY_PART 0   // 0: the LDS kernel, the planes, KM = 4; 1: KM = 8; 2: KM = 16
+#endif
+namespace mcmc {
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double p)
+{
+    const double q = p + quad_perm<0xB1>(p);
+    return q + quad_perm<0x4E>(q);
+}
+__device__ __forceinline__ unsigned long long quad_all_mask(unsigned long long m)
+{
+    m &= m >> 1;
+    m &= m >> 2;
+    m &= 0x1111111111111111ull;
+    return m * 15ull;
+}
+
+#if ANY_PART == 0
+// LDS the kernel needs (bytes) for `nw` waves: the column chunks, the residuals, the per-mode
+// log-densities of a step and the wrap moves; `fixed` = the statically allocated part
+struct AnyGeom {
+    int nw, C, npad;
+    int lcols;   // the columns of L_k^-1 of the periodic dimensions sit in LDS (else: read from HBM)
+    size_t dynamic;
+};
+constexpr size_t kAnyStatic = 16 * 128 * 2 + 8 * 128 + 4 * 128 + 16 * SHORT_LOG_TABLE_SIZE + 16 * kMaxModes + 256;
+constexpr size_t kLdsPerCu = 160u << 10;
+constexpr size_t kLdsPerWg = 160u << 10;   // (a single workgroup may hold all of it)
+
+inline int any_chunk(int K, int dq)
+{
+    const int col_bytes = (1 + K) * 4 * dq * 8;
+    int c = (4096 / col_bytes) & ~3;
+    return c < 4 ? 4 : (c > 32 ? 32 : c);
+}
+inline size_t any_dynamic(int K, int dq, int npad, int nw, int C, int lcols)
+{
+    const size_t col = (size_t)(1 + K) * 4 * dq;
+    return sizeof(double) * (2 * (size_t)C * col + (size_t)nw * K * dq * 64 + (size_t)nw * K * 64 +
+                             (size_t)nw * 16 * npad + (lcols ? (size_t)K * npad * 4 * dq : 0));
+}
+inline bool any_geometry(int K, int dq, int n_periodic, int W, int group_size, AnyGeom& g)
+{
+    g.C = any_chunk(K, dq);
+    g.npad = n_periodic > 0 ? n_periodic : 1;
+    // a wrap moves every residual by a column of L_k^-1: the columns of the periodic dimensions
+    // are kept in LDS where that takes at most 32 KiB (else each element is a load from HBM
+    // in the middle of a step)
+    for (int lcols = (n_periodic > 0 && (size_t)K * n_periodic * 4 * dq * 8 <= (32u << 10)) ? 1 : 0;
+         lcols >= 0; --lcols) {
+        int best = 0;
+        for (int nw = 4; nw >= 1; nw >>= 1) {
+            if (W % (16 * nw) != 0 || group_size % (16 * nw) != 0) continue;
+            const size_t need = any_dynamic(K, dq, g.npad, nw, g.C, lcols) + kAnyStatic;
+            if (need > kLdsPerWg) continue;
+            const int waves = (int)(kLdsPerCu / need) * nw;
+            if (waves > best) { best = waves; g.nw = nw; g.dynamic = need - kAnyStatic; }
+        }
+        g.lcols = lcols;
+        if (best > 0) return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ double wrap_into(double t, double lo, double w, double& fl)
+{
+    const double yv = (t - lo) / w;
+    fl = floor(yv);
+    return (yv - fl) * w + lo;
+}
+
+template <int DQ>
+__global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, int C, int npad, int lcols)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int dpad = 4 * DQ;
+    __shared__ double2 sLH[dpad];      // (lo, hi); beyond d: (-inf, +inf)
+    __shared__ double2 sNA[dpad];      // normal priors: (loc, 1/scale); 1/scale = 0: none here
+    __shared__ double sNM[dpad];       //                -log(scale sqrt(2 pi))
+    __shared__ int sPdim[dpad];        // the periodic dimensions, ascending
+    __shared__ double2 sMode[kMaxModes];   // (log-normalisation, weight) of the modes
+    __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
+    const StepArgs& s = a.s;
+    const int K = a.n_modes, d = a.d, W = s.W;
+    const int COL = (1 + K) * dpad;
+    const int CHUNK = C * COL;
+    const int nw = (int)(blockDim.x >> 6);
+    const int tid = threadIdx.x, c = tid & 3, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wl = lane >> 2;                                   // walker of the wave
+    const int w = blockIdx.x * 16 * nw + (tid >> 2);
+    const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
+    const int ncols = s.n_steps;
+    const double* __restrict__ gVU = a.VU + (size_t)g * ncols * COL;
+    double* const sCol = smem;                                                   // [2][CHUNK]
+    double* const sY = smem + 2 * CHUNK + (size_t)wave * K * DQ * 64 + lane;     // [K][DQ][64]
+    double* const sA = smem + 2 * CHUNK + (size_t)nw * K * DQ * 64 + (size_t)wave * K * 64;   // [K][64]
+    double* const sSh = smem + 2 * CHUNK + (size_t)nw * K * (DQ + 1) * 64 +
+                        ((size_t)wave * 16 + wl) * npad;                         // [16][npad]
+    // [K][np][dpad]: L_k^-1[j][i_q] for j >= i_q, the q-th periodic dimension (lcols)
+    double* const sLc = smem + 2 * CHUNK + (size_t)nw * K * (DQ + 1) * 64 + (size_t)nw * 16 * npad;
+    // (read through an LDS-typed pointer: beside the HBM read of the other branch a generic one
+    // would be merged with it into a flat load)
+    typedef const double __attribute__((address_space(3))) * lds_cdoubles;
+    const lds_cdoubles pLc = (lds_cdoubles)(unsigned long long)(unsigned)(unsigned long long)sLc;
+    auto stage = [&](int k) {
+        const int first = k * C;
+        if (first >= ncols) return;
+        const int cols = ncols - first < C ? ncols - first : C;
+        const int bytes = cols * COL * 8;
+        const char* src = (const char*)(gVU + (size_t)first * COL);
+        char* dst = (char*)(sCol + (k & 1) * CHUNK);
+        for (int kb = wave; kb * 1024 < bytes; kb += nw) {
+            if (kb * 1024 + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+    for (int i = tid; i < dpad; i += (int)blockDim.x) {
+        sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+        sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
+        sNM[i] = a.prior[4 * dpad + i];
+    }
+    auto is_periodic = [&](int i) { return (a.periodic_mask4[i >> 5] >> (i & 31)) & 1u; };
+    int np = 0;
+    for (int q = 0; q < 4; ++q) np += __builtin_popcount(a.periodic_mask4[q]);
+    if (tid < K) sMode[tid] = make_double2(s.cblock[a.cnorm_off + tid], s.cblock[a.weight_off + tid]);
+    if (tid == 0) {
+        int n = 0;
+        for (int i = 0; i < d; ++i)
+            if (is_periodic(i)) sPdim[n++] = i;
+    }
+    if (lcols) {   // (wave-uniform; the barrier makes sPdim visible to every thread)
+        __syncthreads();
+        for (int e = tid; e < K * np * dpad; e += (int)blockDim.x) {
+            const int j = e % dpad, q = (e / dpad) % np, k = e / (dpad * np);
+            const int i = sPdim[q];
+            sLc[e] = (j >= i && j < d) ? a.Lrow[((size_t)k * d + j) * d + i] : 0.0;
+        }
+    }
+    double x[DQ];
+    unsigned mine = 0;     // bit kk: dimension 4 kk + c of this lane is periodic
+    unsigned anyp = 0;     // bit kk: one of the dimensions 4 kk .. 4 kk + 3 is (wave-uniform)
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        const bool in = i < d;
+        x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;
+        for (int k = 0; k < K; ++k) sY[(k * DQ + kk) * 64] = in ? a.y[((size_t)k * d + i) * W + w] : 0.0;
+        if (in && is_periodic(i)) mine |= 1u << kk;
+        if ((a.periodic_mask4[(4 * kk) >> 5] >> ((4 * kk) & 31)) & 0xFu) anyp |= 1u << kk;
+    }
+    anyp = (unsigned)__builtin_amdgcn_readfirstlane((int)anyp);
+    // the slot of a periodic dimension in sPdim = the number of periodic dimensions below it
+    auto slot_of = [&](int i) {
+        int n = 0;
+        for (int q = 0; q < (i >> 5); ++q) n += __builtin_popcount(a.periodic_mask4[q]);
+        return n + __builtin_popcount(a.periodic_mask4[i >> 5] & ((1u << (i & 31)) - 1u));
+    };
+    double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
+    const long long nacc0 = s.n_accept[w];
+    int nacc = 0;
+    const uint32_t gid = s.walker0 + (uint32_t)w;
+    const double mt10 = s.max_tries * 10.0;
+    const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
+    const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
+    const short_log_tab slog = short_log_load(short_log_lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned long long cur_oct = ~0ull;
+    PairRng pr;
+    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+
+    for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
+        const double* __restrict__ cur = sCol + (kc & 1) * CHUNK;
+        stage(kc + 1);
+        const int cols = ncols - base < C ? ncols - base : C;
+        unsigned long long oned_cols = 0;   // bit sl: the column belongs to a one-parameter block
+        if (a.colflag)
+            oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
+#pragma unroll 1
+        for (int sl = 0; sl < cols; ++sl) {
+            const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
+            if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
+                cur_oct = S >> 3;
+                pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+            }
+            double r, Ea;
+            if ((oned_cols >> sl) & 1ull) {   // wave-uniform: the un-paired 1-D variates
+                step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
+            } else
+            switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
+            case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
+            case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
+            case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
+            case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
+            case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
+            case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
+            case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
+            default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+            }
+            const double* __restrict__ col = cur + sl * COL + c;
+            // ---- the trial point: support, normal priors, wraps
+            unsigned long long inb = ~0ull, wound = 0ull;
+            double sc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) {
+                const double2 lh = sLH[4 * kk + c];
+                double tk = fma(r, col[4 * kk], x[kk]);
+                if ((anyp >> kk) & 1u) {   // wave-uniform: some lane's dimension here is periodic
+                    double fl;
+                    const double tw = wrap_into(tk, lh.x, lh.y - lh.x, fl);
+                    const bool per = (mine >> kk) & 1u;
+                    const double shk = (per & (fl != 0.0)) ? tw - tk : 0.0;
+                    tk = per ? tw : tk;
+                    wound |= lanes(shk != 0.0);
+                    if (per) sSh[slot_of(4 * kk + c)] = shk;
+                }
+                inb &= lanes(tk <= lh.y) & lanes(tk >= lh.x);
+                if (a.has_norm) {   // wave-uniform; branch-free inside
+                    const double2 li = sNA[4 * kk + c];
+                    const double qq = (tk - li.x) * li.y;
+                    sc = sc + fma(-0.5 * qq, qq, sNM[4 * kk + c]);
+                }
+            }
+            // the wrap moves of this step that are not zero somewhere in the wave, as slot masks
+            unsigned long long act0 = 0ull, act1 = 0ull;
+            if (wound != 0ull) {   // wave-uniform
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes
+                for (int q = 0; q < np; ++q)
+                    if (lanes(sSh[q] != 0.0) != 0ull) {
+                        if (q < 64) act0 |= 1ull << q;
+                        else act1 |= 1ull << (q - 64);
+                    }
+            }
+            // the residual of the trial in mode k with a wrap in the wave: fma(r, u, y) for every row,
+            // then the wrap moves slot by slot -- ascending dimension, the order of the
+            // specification for every element -- with the rows unrolled (their reads of the
+            // column of L^-1 are independent; lcols: from LDS, else from HBM)
+            auto shifted = [&](int k, const double* __restrict__ uk, const double* __restrict__ yk,
+                               double (&yt)[DQ]) {
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) yt[kk] = fma(r, uk[4 * kk], yk[kk * 64]);
+                for (int half = 0; half < 2; ++half) {
+                    unsigned long long m = half ? act1 : act0;
+                    while (m != 0ull) {
+                        const int q = __builtin_ctzll(m) + 64 * half;
+                        m &= m - 1ull;
+                        const double sv = sSh[q];
+                        const int i = sPdim[q];
+                        if (lcols) {
+#pragma unroll
+                            for (int kk = 0; kk < DQ; ++kk) {
+                                const int j = 4 * kk + c;
+                                const bool on = (sv != 0.0) & (j >= i) & (j < d);
+                                const double lji = pLc[(k * np + q) * dpad + j];
+                                yt[kk] = on ? fma(sv, lji, yt[kk]) : yt[kk];
+                            }
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < DQ; ++kk) {
+                                const int j = 4 * kk + c;
+                                const bool on = (sv != 0.0) & (j >= i) & (j < d);
+                                const double lji = on ? a.Lrow[((size_t)k * d + j) * d + i] : 0.0;
+                                yt[kk] = on ? fma(sv, lji, yt[kk]) : yt[kk];
+                            }
+                        }
+                    }
+                }
+            };
+            // ---- chi2 per mode, log-sum-exp (eval_point / step_core_inc)
+            double amax = -INFINITY, a_last = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const double* __restrict__ uk = col + (1 + k) * dpad;
+                const double* __restrict__ yk = sY + (size_t)k * DQ * 64;
+                double pc = 0.0;
+                if (wound != 0ull) {   // wave-uniform
+                    double yt[DQ];
+                    shifted(k, uk, yk, yt);
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) pc = fma(yt[kk], yt[kk], pc);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) {
+                        const double yt = fma(r, uk[4 * kk], yk[kk * 64]);
+                        pc = fma(yt, yt, pc);
+                    }
+                }
+                a_last = -0.5 * (sMode[k].x + quad_sum(pc));
+                amax = fmax(a_last, amax);
+                if (K > 1) sA[k * 64 + lane] = a_last;
+            }
+            double ll = a_last;
+            if (K > 1) {
+                // one exponential per (walker, mode): lane class c takes the modes k = c mod 4
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int k = c; k < K; k += 4) sA[k * 64 + lane] = dexp(sA[k * 64 + lane] - amax);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double Ssum = 0.0;
+                for (int k = 0; k < K; ++k) Ssum = fma(sMode[k].y, sA[k * 64 + (lane & ~3) + (k & 3)], Ssum);
+                ll = dlog(Ssum) + amax;
+            }
+            const unsigned long long inside_m = quad_all_mask(inb);
+            const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
+            const double lt = lp + ll;
+            const double delta = (lpost - lt) / s.temperature;   // (T = 1: x / 1.0 == x)
+            const unsigned long long acc_m =
+                inside_m & lanes(lt != -INFINITY) & (lanes(lt > lpost) | lanes(Ea > delta));
+            const int lim = sel(lanes(burn > 0), lim10, lim1);
+            burn -= sel(acc_m & lanes(burn > 0), 1, 0);
+            // ---- commit: recomputed from the column
+            const double ra = sel(acc_m, r, 0.0);
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) {
+                if ((anyp >> kk) & 1u) {   // wave-uniform
+                    const double2 lh = sLH[4 * kk + c];
+                    const double tk = fma(r, col[4 * kk], x[kk]);
+                    double fl;
+                    const double tw = wrap_into(tk, lh.x, lh.y - lh.x, fl);
+                    x[kk] = sel(acc_m, ((mine >> kk) & 1u) ? tw : tk, x[kk]);
+                } else {
+                    x[kk] = fma(ra, col[4 * kk], x[kk]);
+                }
+            }
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+                const double* __restrict__ uk = col + (1 + k) * dpad;
+                double* __restrict__ yk = sY + (size_t)k * DQ * 64;
+                if (wound != 0ull) {
+                    double yt[DQ];
+                    shifted(k, uk, yk, yt);
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) yk[kk * 64] = sel(acc_m, yt[kk], yk[kk * 64]);
+                } else {
+                    // (every read before the first write: the compiler cannot tell that the
+                    // residuals and the column chunk are different parts of the LDS)
+                    double u_[DQ], y_[DQ];
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) { u_[kk] = uk[4 * kk]; y_[kk] = yk[kk * 64]; }
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) yk[kk * 64] = fma(ra, u_[kk], y_[kk]);
+                }
+            }
+            lpri = sel(acc_m, lp, lpri);
+            llik = sel(acc_m, ll, llik);
+            lpost = sel(acc_m, lt, lpost);
+            prej = sel(acc_m, 0, prej + sel(inside_m, 0, 1));
+            wt = sel(acc_m, 1, wt + 1);
+            nacc += sel(acc_m, 1, 0);
+            if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        if (i < d) {
+            s.x[(size_t)i * W + w] = x[kk];
+            for (int k = 0; k < K; ++k) a.y[((size_t)k * d + i) * W + w] = sY[(k * DQ + kk) * 64];
+        }
+    }
+    if (c == 0) {
+        s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
+        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
+        s.n_accept[w] = nacc0 + nacc;
+    }
+    wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
+}
+
+#endif  // ANY_PART == 0
+
+// ---------------------------------------------------------------- mixtures in registers
+__device__ __forceinline__ int hw_wave_slot()
+{
+    return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
+}
+template <int NW>   // (see rotate_priority in incremental_kernels.hip)
+__device__ __forceinline__ void rotate_priority(int slot)
+{
+    if (NW != 2 && NW != 4) return;
+    const int turn = (int)(__builtin_amdgcn_s_memtime() >> 17);
+    switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+typedef const double __attribute__((address_space(3))) * lds_doubles;
+__device__ __forceinline__ lds_doubles relaunder(const double* p)
+{
+    unsigned off = (unsigned)(unsigned long long)p;
+    asm volatile("" : "+v"(off));
+    return (lds_doubles)(unsigned long long)off;
+}
+
+__host__ __device__ constexpr int regs_chunk(int dq, int km)
+{
+    int c = (2048 / ((1 + km) * 4 * dq)) & ~3;
+    return c < 4 ? 4 : (c > 64 ? 64 : c);
+}
+__host__ __device__ constexpr int regs_min_waves(int dq, int km)
+{
+    // (the state is dq (km + 1) doubles per lane: step_inc_mix_kernel's table, continued)
+    // (more than four planes: the per-mode log-densities and exponentials of a step alone take
+    // some forty registers -- never more than two waves)
+    return km > 4 ? (dq * (km + 1) <= ANY_REGS_TWO_WAVES ? 2 : 1)
+                  : dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3 : dq * (km + 1) <= 50 ? 2 : 1;
+}
+// what fits the 512 registers of a lane at one wave per SIMD
+__host__ __device__ constexpr bool regs_fits(int dq, int km) { return dq * (km + 1) <= 208; }
+__host__ __device__ constexpr int regs_bucket(int K) { return K <= 4 ? 4 : K <= 8 ? 8 : 16; }
+
+// KM register planes, the first a.n_modes of them live (a plane beyond that is never touched:
+// the tests on k < K are wave-uniform branches around fully unrolled code).  The columns are
+// planes of 4 DQ doubles, 1 + n_modes of them.  One-parameter blocks and the temperature are
+// run-time properties here.
+template <int DQ, int KM>
+__global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_kernel(const IncStepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int dpad = 4 * DQ;
+    constexpr int C = regs_chunk(DQ, KM);
+    const StepArgs& s = a.s;
+    const int K = a.n_modes;
+    const int COL = (1 + K) * dpad;               // doubles per column
+    const int CHUNK = C * (1 + KM) * dpad;        // (the buffers are sized for KM planes)
+    const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
+    const int W = s.W, d = a.d;
+    const int w = blockIdx.x * 64 + (tid >> 2);
+    const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
+    const int ncols = s.n_steps;
+    const double* __restrict__ gVU = a.VU + (size_t)g * ncols * COL;
+    auto stage = [&](int k) {
+        const int first = k * C;
+        if (first >= ncols) return;
+        const int cols = ncols - first < C ? ncols - first : C;
+        const int bytes = cols * COL * 8;
+        const char* src = (const char*)(gVU + (size_t)first * COL);
+        char* dst = (char*)(smem + (k & 1) * CHUNK);
+        for (int kb = wave; kb * 1024 < bytes; kb += 4) {
+            if (kb * 1024 + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
+        }
+    };
+    stage(0);
+    __shared__ double2 sLH[4 * DQ];
+    __shared__ double2 sNA[4 * DQ];     // normal priors: (loc, 1/scale) and -log(scale sqrt(2 pi))
+    __shared__ double sNM[4 * DQ];
+    __shared__ double2 sMode[kMaxModes];   // (log-normalisation, weight) of the modes
+    for (int i = tid; i < dpad; i += 256) {
+        sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+        sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
+        sNM[i] = a.prior[4 * dpad + i];
+    }
+    if (tid < K) sMode[tid] = make_double2(s.cblock[a.cnorm_off + tid], s.cblock[a.weight_off + tid]);
+    double x[DQ], y[KM][DQ];
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        const bool in = i < d;
+        // (one box for all dimensions: a padded dimension rests at its middle, inside for every step)
+        x[kk] = in ? s.x[(size_t)i * W + w] : (a.box ? 0.5 * (a.box_lo + a.box_hi) : 0.0);
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            y[k][kk] = (in && k < K) ? a.y[((size_t)k * d + i) * W + w] : 0.0;
+    }
+    double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
+    const long long nacc0 = s.n_accept[w];
+    int nacc = 0;     // accepted steps of this launch
+    const uint32_t gid = s.walker0 + (uint32_t)w;
+    const double mt10 = s.max_tries * 10.0;
+    const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
+    const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
+    __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
+    const short_log_tab slog = short_log_load(short_log_lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long class1 = lanes(c == 1), class2 = lanes(c == 2), class3 = lanes(c == 3);
+    const int hw_slot = hw_wave_slot();
+    bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
+    unsigned long long cur_oct = ~0ull;
+    PairRng pr;
+    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+
+    for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
+        const double* __restrict__ cur = smem + (kc & 1) * CHUNK;
+        stage(kc + 1);
+        const int cols = ncols - base < C ? ncols - base : C;
+        unsigned long long oned_cols = 0;   // bit sl: the column belongs to a one-parameter block
+        if (a.colflag)
+            oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
+#pragma unroll 1
+        for (int sl = 0; sl < cols; ++sl) {
+            const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
+            if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
+                cur_oct = S >> 3;
+                rotate_priority<regs_min_waves(DQ, KM)>(hw_slot);
+                pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+            }
+            double r, Ea;
+            if ((oned_cols >> sl) & 1ull) {   // wave-uniform: the un-paired 1-D variates
+                step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
+            } else
+            switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
+            case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
+            case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
+            case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
+            case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
+            case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
+            case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
+            case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
+            default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+            }
+            const double* __restrict__ col = cur + sl * COL + c;
+            unsigned long long inb = ~0ull;   // the support test as a lane mask
+            double sc = 0.0;
+            if (a.box) {   // wave-uniform: one box for every dimension, no normal priors
+                double tmx = -INFINITY, tmn = INFINITY;
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) {
+                    const double t = fma(r, col[4 * kk], x[kk]);
+                    tmx = __builtin_fmax(tmx, t);
+                    tmn = __builtin_fmin(tmn, t);
+                }
+                inb = lanes(tmx <= a.box_hi) & lanes(tmn >= a.box_lo);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) {
+                    const double t = fma(r, col[4 * kk], x[kk]);
+                    const double2 lh = sLH[4 * kk + c];
+                    inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
+                    if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
+                        const int i = 4 * kk + c;
+                        const double2 li = sNA[i];
+                        const double qq = (t - li.x) * li.y;
+                        sc = sc + fma(-0.5 * qq, qq, sNM[i]);
+                    }
+                }
+            }
+            double ak[KM], amax = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) {
+                ak[k] = -INFINITY;
+                if (k < K) {   // wave-uniform
+                    const double* __restrict__ uk = col + (1 + k) * dpad;
+                    double pc = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) {
+                        const double yt = fma(r, uk[4 * kk], y[k][kk]);
+                        pc = fma(yt, yt, pc);
+                    }
+                    ak[k] = -0.5 * (sMode[k].x + quad_sum(pc));
+                    amax = fmax(ak[k], amax);
+                }
+            }
+            const unsigned long long inside_m = quad_all_mask(inb);
+            const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
+            // one exponential per lane and four modes: lane class q takes the modes 4 j + q, and
+            // the weighted sum gathers them by quad broadcasts in the order of the specification
+            double ll = ak[0];
+            if (K > 1) {   // wave-uniform
+                double e[KM / 4];
+#pragma unroll
+                for (int j = 0; j < KM / 4; ++j)
+                    if (4 * j < K) {
+                        double mine = ak[4 * j];
+                        mine = sel(class1, ak[4 * j + 1], mine);
+                        mine = sel(class2, ak[4 * j + 2], mine);
+                        mine = sel(class3, ak[4 * j + 3], mine);
+                        e[j] = dexp(mine - amax);
+                    }
+                double Ssum = 0.0;
+#pragma unroll
+                for (int j = 0; j < KM / 4; ++j) {
+                    if (4 * j + 0 < K) Ssum = fma(sMode[4 * j + 0].y, quad_perm<0x00>(e[j]), Ssum);
+                    if (4 * j + 1 < K) Ssum = fma(sMode[4 * j + 1].y, quad_perm<0x55>(e[j]), Ssum);
+                    if (4 * j + 2 < K) Ssum = fma(sMode[4 * j + 2].y, quad_perm<0xAA>(e[j]), Ssum);
+                    if (4 * j + 3 < K) Ssum = fma(sMode[4 * j + 3].y, quad_perm<0xFF>(e[j]), Ssum);
+                }
+                ll = dlog(Ssum) + amax;
+            }
+            const double lt = lp + ll;
+            const double delta = (lpost - lt) / s.temperature;   // (T = 1: x / 1.0 == x)
+            const unsigned long long acc_m =
+                inside_m & lanes(lt != -INFINITY) & (lanes(lt > lpost) | lanes(Ea > delta));
+            const bool accept = __builtin_amdgcn_inverse_ballot_w64(acc_m);
+            int lim = lim1;
+            if (burning) {   // wave-uniform (see step_inc_kernel)
+                lim = burn > 0 ? lim10 : lim1;
+                burn -= (accept & (burn > 0)) ? 1 : 0;
+                burning = lanes(burn > 0) != 0ull;
+            }
+            const double ra = sel(acc_m, r, 0.0);
+            const lds_doubles col2 = relaunder(col);
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) x[kk] = fma(ra, col2[4 * kk], x[kk]);
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {   // wave-uniform
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk)
+                        y[k][kk] = fma(ra, col2[(1 + k) * dpad + 4 * kk], y[k][kk]);
+                }
+            lpri = sel(acc_m, lp, lpri);
+            llik = sel(acc_m, ll, llik);
+            lpost = sel(acc_m, lt, lpost);
+            prej = sel(acc_m, 0, prej + sel(inside_m, 0, 1));
+            wt = sel(acc_m, 1, wt + 1);
+            nacc += sel(acc_m, 1, 0);
+            if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+        const int i = 4 * kk + c;
+        if (i < d) {
+            s.x[(size_t)i * W + w] = x[kk];
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) a.y[((size_t)k * d + i) * W + w] = y[k][kk];
+        }
+    }
+    if (c == 0) {
+        s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
+        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
+        s.n_accept[w] = nacc0 + nacc;
+    }
+    wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
+}
+
+template <int DQ, int KM>
+hipError_t launch_regs(const IncStepArgs& a, hipStream_t st)
+{
+    constexpr int C = regs_chunk(DQ, KM);
+    const size_t lds = sizeof(double) * 2 * C * (1 + KM) * 4 * DQ;
+    static const std::string name =
+        "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ">";
+    auto kern = step_inc_regs_kernel<DQ, KM>;
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    mcmc_hip_note_step_kernel(name.c_str());
+    hipLaunchKernelGGL(kern, dim3(a.s.W / 64), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// the (DQ, KM) this translation unit instantiates: KM = 4 for 17 <= DQ <= 32 (the tuned
+// step_inc_mix_kernel serves DQ <= 16), KM = 8 and 16 for every DQ that fits
+template <int DQ, int KM>
+hipError_t dispatch_regs(const IncStepArgs& a, hipStream_t st)
+{
+    if constexpr (DQ > 32 || !regs_fits(DQ, KM)) {
+        return hipErrorInvalidValue;
+    } else {
+        if (a.dq == DQ) return launch_regs<DQ, KM>(a, st);
+        return dispatch_regs<DQ + 1, KM>(a, st);
+    }
+}
+
+#if ANY_PART == 0
+// (v, u_k = L_k^-1 v) of every step of the launch as PLANES: VU[g][step][0] = v, [1 + k] = u_k,
+// each 4 dq doubles (zero beyond d); one ascending fma chain from +0.0 per element
+// (orc_whiten_directions).  One thread per (column, mode): 64 columns per workgroup, the modes
+// dealt to blockIdx.z.
+__global__ void __launch_bounds__(64) whiten_directions_planes_kernel(const IncDirArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sv[];   // [d][64]
+    const int l = threadIdx.x;
+    const int sr = blockIdx.x * 64 + l;
+    const int g = blockIdx.y, k = blockIdx.z;
+    const int d = a.d, K = a.n_modes, dpad = 4 * a.dq;
+    if (sr >= a.n_steps) return;
+    const unsigned long long step = a.step0 + (unsigned long long)sr;
+    const int cyc = (int)(step / (unsigned long long)a.cps - a.cycle0);
+    const int col = (int)(step % (unsigned long long)a.cps);
+    const double* __restrict__ v = a.V + ((size_t)g * a.ncyc + cyc) * a.slab + (size_t)col * a.ld;
+    for (int i = 0; i < d; ++i) sv[i * 64 + l] = v[i];
+    double* __restrict__ out = a.VU + ((size_t)g * a.n_steps + sr) * (size_t)((1 + K) * dpad);
+    if (k == 0) {
+        if (a.colflag)
+            a.colflag[(size_t)g * a.n_steps + sr] =
+                a.vflag ? a.vflag[((size_t)g * a.ncyc + cyc) * a.cps + col] : 0;
+        for (int j = 0; j < dpad; ++j) out[j] = j < d ? sv[j * 64 + l] : 0.0;
+    }
+    double* __restrict__ uk = out + (size_t)(1 + k) * dpad;
+    for (int j = 0; j < d; ++j) {
+        const double* __restrict__ row = a.Lrow + ((size_t)k * d + j) * d;
+        double acc = 0.0;
+        for (int i = 0; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
+        uk[j] = acc;
+    }
+    for (int j = d; j < dpad; ++j) uk[j] = 0.0;
+}
+
+template <int DQ>
+hipError_t launch_any(const IncStepArgs& a, const AnyGeom& g, hipStream_t st)
+{
+    static const std::string name = "mcmc::step_inc_any_kernel<" + std::to_string(DQ) + ">";
+    auto kern = step_inc_any_kernel<DQ>;
+    if (g.dynamic > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)g.dynamic);
+        if (e != hipSuccess) return e;
+    }
+    mcmc_hip_note_step_kernel(name.c_str());
+    hipLaunchKernelGGL(kern, dim3(a.s.W / (16 * g.nw)), dim3(64 * g.nw), g.dynamic, st, a, g.C, g.npad,
+                       g.lcols);
+    return hipGetLastError();
+}
+
+template <int DQ>
+hipError_t dispatch_any(const IncStepArgs& a, const AnyGeom& g, hipStream_t st)
+{
+    if constexpr (DQ > 32) {
+        return hipErrorInvalidValue;
+    } else {
+        if (a.dq == DQ) return launch_any<DQ>(a, g, st);
+        return dispatch_any<DQ + 1>(a, g, st);
+    }
+}
+
+int count_periodic(const IncStepArgs& a)
+{
+    int n = 0;
+    for (int q = 0; q < 4; ++q) n += __builtin_popcount(a.periodic_mask4[q]);
+    return n;
+}
+
+#endif  // ANY_PART == 0
+
+}  // namespace
+}  // namespace mcmc
+
+#if ANY_PART == 1
+extern "C" hipError_t mcmc_hip_launch_inc_regs_8(const mcmc::IncStepArgs* a, hipStream_t st)
+{
+    return mcmc::dispatch_regs<1, 8>(*a, st);
+}
+#elif ANY_PART == 2
+extern "C" hipError_t mcmc_hip_launch_inc_regs_16(const mcmc::IncStepArgs* a, hipStream_t st)
+{
+    return mcmc::dispatch_regs<1, 16>(*a, st);
+}
+#else
+extern "C" hipError_t mcmc_hip_launch_inc_regs_8(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_regs_16(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+
+namespace mcmc {
+namespace {
+// the register kernel serves mixtures without periodic parameters that the tuned
+// step_inc_mix_kernel (K <= 4, dq <= 16) does not, as far as the registers hold them
+bool regs_serves(int K, int dq, int n_periodic)
+{
+    if (n_periodic > 0 || K < 2 || (K <= 4 && dq <= 16)) return false;
+    const int km = regs_bucket(K);
+    if (!regs_fits(dq, km)) return false;
+    return km == 4 || (km == 8 ? mcmc_hip_launch_inc_regs_8 != nullptr : mcmc_hip_launch_inc_regs_16 != nullptr);
+}
+}  // namespace
+}  // namespace mcmc
+
+// 1 if the general incremental kernels serve (d, n_modes, n_periodic) at this ensemble shape
+extern "C" int mcmc_hip_inc_any_fits(int d, int n_modes, int n_periodic, int n_walkers, int group_size)
+{
+    mcmc::AnyGeom g{};
+    if (d < 2 || d > 128 || n_modes < 1 || n_modes > mcmc::kMaxModes) return 0;
+    if (n_walkers % 64 == 0 && group_size % 64 == 0 && mcmc::regs_serves(n_modes, (d + 3) / 4, n_periodic))
+        return 1;
+    return mcmc::any_geometry(n_modes, (d + 3) / 4, n_periodic, n_walkers, group_size, g) ? 1 : 0;
+}
+
+extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs* a, hipStream_t st)
+{
+    const int np = mcmc::count_periodic(*a);
+    if (a->s.W % 64 == 0 && a->s.group_size % 64 == 0 && mcmc::regs_serves(a->n_modes, a->dq, np)) {
+        const int km = mcmc::regs_bucket(a->n_modes);
+        return km == 4 ? mcmc::dispatch_regs<17, 4>(*a, st)
+             : km == 8 ? mcmc_hip_launch_inc_regs_8(a, st) : mcmc_hip_launch_inc_regs_16(a, st);
+    }
+    mcmc::AnyGeom g{};
+    if (!mcmc::any_geometry(a->n_modes, a->dq, np, a->s.W, a->s.group_size, g))
+        return hipErrorInvalidValue;
+    return mcmc::dispatch_any<1>(*a, g, st);
+}
+
+extern "C" hipError_t mcmc_hip_launch_whiten_directions_planes(const mcmc::IncDirArgs* a, int n_groups,
+                                                               hipStream_t st)
+{
+    const size_t lds = sizeof(double) * 64 * (size_t)a->d;
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)mcmc::whiten_directions_planes_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(mcmc::whiten_directions_planes_kernel,
+                       dim3((a->n_steps + 63) / 64, n_groups, a->n_modes), dim3(64), lds, st, *a);
+    return hipGetLastError();
+}
+#endif  // ANY_PART

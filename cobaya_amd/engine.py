@@ -51,6 +51,7 @@ SYMBOLS = [
     ("mcmc_hip_version", C.c_char_p, []),
     ("mcmc_hip_last_error", C.c_char_p, [_H]),
     ("mcmc_hip_dim_supported", C.c_int, [C.c_int]),
+    ("mcmc_hip_incremental_supported", C.c_int, [C.c_int32] * 6),
     ("mcmc_hip_create", C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     ("mcmc_hip_destroy", None, [_H]),
     ("mcmc_hip_set_prior", C.c_int, [_H, c_int32_p, c_double_p, c_double_p, c_int32_p]),
@@ -148,6 +149,13 @@ def _f64(a, shape=None):
     if shape is not None and a.shape != tuple(shape):
         raise ValueError(f"expected array of shape {tuple(shape)}, got {a.shape}")
     return a
+
+
+def incremental_supported(d, n_modes, n_periodic, n_drag, n_walkers, basis_group_size):
+    """Does incremental evaluation (O(d) steps on carried whitened residuals) serve this model
+    shape?  (mcmc_hip_incremental_supported: a pure function of the library, no device.)"""
+    return bool(load_library().mcmc_hip_incremental_supported(
+        int(d), int(n_modes), int(n_periodic), int(n_drag), int(n_walkers), int(basis_group_size)))
 
 
 def gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm):

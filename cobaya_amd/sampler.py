@@ -33,7 +33,8 @@ import pandas as pd
 
 from . import dist
 from .collection import SampleCollection
-from .engine import ChainStuck, Engine, EngineError, NotPositiveDefinite, gelman_rubin
+from .engine import (ChainStuck, Engine, EngineError, NotPositiveDefinite, gelman_rubin,
+                     incremental_supported)
 from .model import ProblemSpec, UnsupportedModel
 
 log = logging.getLogger("mcmc_hip")
@@ -252,9 +253,13 @@ class EnsembleMCMC:
         if self.evaluation not in ("auto", "full", "incremental"):
             self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
                        self.evaluation)
-        can_inc = ((spec.n_modes == 1 or (2 <= spec.n_modes <= 4 and d <= 64 and not self.drag))
-                   and (not np.any(spec.periodic) or (spec.n_modes == 1 and not self.drag
-                                                      and int(np.sum(spec.periodic)) <= 8))
+        # (the engine's own answer: tuned kernels for one mode, up to four at d <= 64, up to
+        # eight periodic parameters, dragging of one non-periodic mode; the general kernel for
+        # any other mixture / periodic set whose residuals fit the LDS)
+        can_inc = (d >= 2 and int(self.group_size) % 64 == 0 and W % int(self.group_size) == 0
+                   and incremental_supported(d, spec.n_modes, int(np.sum(spec.periodic)),
+                                             self.drag_interp_steps if self.drag else 0,
+                                             W, int(self.group_size))
                    and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
                    # accepted rows (emit: chains): one mode, non-periodic, Metropolis steps,
                    # blocks of at least two parameters
@@ -275,11 +280,12 @@ class EnsembleMCMC:
             self._fail("shared_basis: False serves a single parameter block without "
                        "oversampling or dragging")
         if self.evaluation == "incremental" and not can_inc:
-            self._fail("evaluation: incremental serves one Gaussian mode (or a mixture of up to "
-                       "four at d <= 64 without dragging and with non-periodic priors; up to eight "
-                       "periodic parameters without dragging), d >= 2 and a group_size that is a "
-                       "multiple of 64; emit: chains for one mode with non-periodic priors, "
-                       "Metropolis steps and blocks of >= 2 parameters; use 'full' (or 'auto')")
+            self._fail("evaluation: incremental serves Gaussian mixtures whose whitened residuals "
+                       "(n_modes * d doubles per walker) fit the LDS, with Metropolis steps; "
+                       "dragging for one Gaussian mode with non-periodic priors; d >= 2 and a "
+                       "group_size that is a multiple of 64; emit: chains for one mode with "
+                       "non-periodic priors, Metropolis steps and blocks of >= 2 parameters; use "
+                       "'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         if self.basis_group_size is None:
             self.basis_group_size = int(self.group_size)

@@ -80,6 +80,15 @@ MCMC_HIP_API const char* mcmc_hip_version(void);
 MCMC_HIP_API const char* mcmc_hip_last_error(const mcmc_hip_ctx* h);
 /* 1 if the lane-per-walker kernels for dimension d were compiled into this library */
 MCMC_HIP_API int mcmc_hip_dim_supported(int d);
+/* 1 if MCMC_HIP_FLAG_INCREMENTAL serves a Gaussian mixture of n_modes (>= 1) modes in d dimensions
+ * of which n_periodic are periodic (prior.py:658-676), with n_drag interpolation steps per dragging
+ * step (0: Metropolis steps), for n_walkers walkers of which basis_group_size share a proposal
+ * direction: the tuned kernels (one mode; up to four at d <= 64; up to eight periodic parameters
+ * of one mode; dragging of one non-periodic mode) or the general one (anything else without
+ * dragging whose per-walker state -- n_modes * d doubles -- fits the LDS of a CU).  0: such a model
+ * is sampled from scratch (no flag).  A pure function: no device is touched. */
+MCMC_HIP_API int mcmc_hip_incremental_supported(int32_t d, int32_t n_modes, int32_t n_periodic, int32_t n_drag,
+                                   int32_t n_walkers, int32_t basis_group_size);
 
 /* Sampler.__init__ + MCMC.initialize (cobaya/sampler.py:257-322, mcmc.py:111-271) */
 MCMC_HIP_API int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out);

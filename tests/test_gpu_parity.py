@@ -779,13 +779,13 @@ def test_incremental_mode_refuses_what_it_does_not_cover():
     with pytest.raises(E.EngineError, match="emits rows"):
         emi.step(3)
     emi.close()
-    eng = E.Engine(4, 256, group_size=64, incremental=True)
-    eng.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
-    m, c = random_target(4, 5, np.random.default_rng(0))     # five modes: more than it serves
+    eng = E.Engine(128, 256, group_size=64, incremental=True)
+    eng.set_prior([0] * 128, [0.0] * 128, [1.0] * 128)
+    m, c = random_target(128, 16, np.random.default_rng(0))  # 16 modes at d = 128: 0.5 MB per wave
     eng.set_target_gaussian_mixture(m, c)
     eng.set_proposal_cov(c[0])
-    eng.set_state(np.full((256, 4), 0.5))
-    with pytest.raises(E.EngineError, match="one Gaussian mode"):
+    eng.set_state(np.full((256, 128), 0.5))
+    with pytest.raises(E.EngineError, match="do not fit the LDS"):
         eng.step(3)
     eng.close()
 
@@ -928,6 +928,68 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
     assert st.step > R and "step_inc_mix_kernel" in eng.last_step_kernel()
     assert eng.counters()["accepted"] == int(st.n_accept.sum())
+    eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,K,per,extra", [
+    (4, 256, 64, 5, [], {}),                                   # more than four modes
+    (30, 256, 64, 6, [], {"T": 1.7, "burn_in": 2}),
+    (10, 128, 64, 16, [], {}),                                 # kMaxModes
+    (80, 128, 64, 2, [], {}),                                  # a mixture above d = 64
+    (100, 128, 64, 3, [], {"normal": True}),
+    (30, 256, 128, 3, [0, 7, 29], {}),                         # periodic parameters and a mixture
+    (27, 128, 64, 5, [3], {"normal": True}),
+    (40, 128, 64, 1, list(range(0, 40, 3)), {}),               # more than eight periodic parameters
+    (128, 128, 64, 1, list(range(0, 128)), {}),                # ... every one of 128
+    (9, 128, 64, 6, [4], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
+    (30, 1024, 256, 8, [2], {"bgs": 1024}),
+    (9, 128, 64, 6, [], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
+    (40, 128, 64, 12, [], {}),                                 # 16 register planes, 12 live
+    (90, 128, 64, 7, [], {"normal": True})])                   # 8 planes at dq = 23
+def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
+    """What the tuned incremental kernels leave out -- more than four modes, mixtures above d = 64,
+    periodic parameters with a mixture, more than eight periodic parameters -- on the general
+    incremental kernel (step_inc_any_kernel, residuals in LDS): bit for bit against the oracle's
+    step_core_inc, carried residuals included, across the refresh at 40 cycle lengths."""
+    extra = dict(extra)
+    periodic = [int(i in per) for i in range(d)]
+    a = [0.42 if p else 0.0 for p in periodic]
+    b = [0.58 if p else 1.0 for p in periodic]
+    kinds = [0] * d
+    if extra.pop("normal", False):
+        rng = np.random.default_rng(7400 + d)
+        kinds = [int(not p and rng.random() < 0.5) for p in periodic]
+        a = [0.5 if k else v for k, v in zip(kinds, a)]
+        b = [float(rng.uniform(0.1, 0.4)) if k else v for k, v in zip(kinds, b)]
+    kw = dict(kinds=kinds, a=a, b=b, incremental=True, rng=np.random.default_rng(6400 + d + K))
+    if per:
+        kw["periodic"] = periodic
+    if K > 1:
+        wm = np.random.default_rng(d + K).uniform(0.5, 1.5, K)
+        kw["weights"] = (wm / wm.sum()).tolist()
+    if "bgs" in extra:
+        kw["basis_group_size"] = extra.pop("bgs")
+    eng, prob, st = make_pair(d, W, gs, K=K, **kw, **extra)
+    L = eng.cycle_length()
+    compare_state(eng, st)
+    wraps = 0
+    for n in (1, 6, L + 3, 40 * L - (L + 10) - 2, 9, L + 1):
+        before = st.x.copy()
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
+        if per:
+            wraps += int(np.sum(np.abs(st.x - before)[:, per] > 0.08))
+    # (mixtures without periodic parameters that fit the register file: step_inc_regs_kernel)
+    want = "step_inc_any_kernel" if (per or K == 1) else "step_inc_regs_kernel"
+    assert st.step > 40 * L and want in eng.last_step_kernel(), eng.last_step_kernel()
+    assert eng.counters()["accepted"] == int(st.n_accept.sum()) > 0
+    if per:
+        assert wraps > 20
+        x = eng.get_full_state()["x"]
+        assert np.all((x[:, per] >= 0.42) & (x[:, per] <= 0.58))
     eng.close()
 
 

@@ -526,6 +526,46 @@ def test_two_mode_mixture_at_d40_chains_mode():
     assert np.max(np.abs(np.sqrt(np.diag(c)) / np.sqrt(np.diag(truth)) - 1)) < 0.1
 
 
+@pytest.mark.parametrize("periodic", [False, True])
+def test_six_mode_mixture_runs_incrementally(periodic):
+    """More than four modes (and, second case, a periodic parameter beside them) through
+    `run(info)` with `evaluation: auto`: the run is incremental -- the general kernels of
+    incremental_any.hip, not the from-scratch fallback -- and the pooled walkers recover the
+    mean and the covariance of the mixture (modes within 1.5 sigma of each other)."""
+    d, K = 12, 6
+    rng = np.random.default_rng(66)
+    sig = 0.03
+    mus = 0.5 + 0.02 * rng.standard_normal((K, d))
+    cov = np.eye(d) * sig ** 2
+    w = rng.uniform(0.5, 1.5, K)
+    w /= w.sum()
+    names = [f"a__{i}" for i in range(d)]
+    params = {n: {"prior": {"min": 0.0, "max": 1.0},
+                  "ref": {"dist": "norm", "loc": 0.5, "scale": 0.03}} for n in names}
+    if periodic:   # +-3.3 sigma around the middle: the seam is crossed
+        params[names[2]] = {"prior": {"min": 0.4, "max": 0.6}, "periodic": True,
+                            "ref": {"dist": "norm", "loc": 0.5, "scale": 0.03}}
+    info = {"likelihood": {"gaussian_mixture": {"means": mus, "covs": [cov] * K, "weights": w,
+                                                "input_params_prefix": "a_"}},
+            "params": params,
+            "sampler": {"mcmc_hip": {"seed": 5, "n_walkers": 4096, "group_size": 64,
+                                     "max_samples": 3_000_000, "Rminus1_stop": 0.0}}}
+    updated, sampler = run(info)
+    assert sampler.incremental
+    kern = sampler.engine.last_step_kernel()
+    assert ("step_inc_any_kernel" if periodic else "step_inc_regs_kernel") in kern, kern
+    x = sampler.engine.get_state()["x"]
+    mean = w @ mus
+    truth = cov + (mus - mean).T @ np.diag(w) @ (mus - mean)
+    keep = [i for i in range(d) if not (periodic and i == 2)]   # (the periodic one is cut at 3.3 sigma)
+    se = np.sqrt(np.diag(truth) / 4096)
+    assert np.max(np.abs(x.mean(axis=0) - mean)[keep] / se[keep]) < 4.5
+    assert np.max(np.abs(x.std(axis=0)[keep] / np.sqrt(np.diag(truth))[keep] - 1)) < 0.06
+    if periodic:
+        assert np.all((x[:, 2] >= 0.4) & (x[:, 2] <= 0.6))
+    sampler.close()
+
+
 def test_rccl_path_with_one_rank():
     """the RCCL path executes.  A process group with backend `nccl`, world size
     1, on cuda:0: every checkpoint's all-reduce goes H2D -> ncclAllReduce -> D2H

@@ -693,6 +693,60 @@ def test_incremental_periodic_random_shapes_walk_the_same_chains(seed):
     assert sa.n_accept.sum() > 64 * 20
 
 
+@pytest.mark.parametrize("d,K,n_per", [(5, 6, 0), (12, 16, 0), (72, 2, 0), (9, 3, 2), (30, 5, 3),
+                                       (20, 1, 12)])
+def test_incremental_general_shapes_walk_the_same_chains(d, K, n_per):
+    """What the general incremental kernel serves (step_inc_any_kernel): more than four modes, a
+    mixture above d = 64, periodic parameters together with a mixture, more than eight periodic
+    parameters -- the oracle's step_core_inc against its from-scratch step on the same
+    (un-paired) proposal stream: same decisions, same wrapped coordinates, and every carried
+    residual stays L_k^-1 (x - mu_k)."""
+    from oracle import cbind as O
+    rng = np.random.default_rng(5200 + 10 * d + K)
+    sd = rng.uniform(0.02, 0.05, d)
+    means = 0.5 + rng.normal(size=(K, d)) * sd * 0.7
+    covs = []
+    for _ in range(K):
+        A = rng.normal(size=(d, d))
+        c = A @ A.T / d + np.eye(d)
+        covs.append(c / np.sqrt(np.outer(np.diag(c), np.diag(c))) * np.outer(sd, sd) * rng.uniform(0.7, 1.4))
+    covs = np.array(covs)
+    w = rng.uniform(0.5, 1.5, K)
+    w /= w.sum()
+    periodic = np.zeros(d, dtype=int)
+    periodic[rng.choice(d, n_per, replace=False)] = 1
+    half = rng.uniform(1.0, 2.0, d) * sd                     # periodic: a few sigma wide
+    a = [float(0.5 - half[i]) if periodic[i] else -0.5 for i in range(d)]
+    b = [float(0.5 + half[i]) if periodic[i] else 1.5 for i in range(d)]
+    tgt = dict(means=means, covs=covs, weights=w) if K > 1 else dict(means=means[0], covs=covs[0])
+    mk = lambda inc: O.Problem(d, [0] * d, a, b, periodic=periodic.tolist() if n_per else None,
+                               T=O.proposal_transform(covs[0], 2.4), group_size=64, seed=11,
+                               incremental=inc, paired_variates=False, **tgt)
+    full, inc = mk(False), mk(True)
+    x0 = means[0] + rng.normal(size=(64, d)) * sd
+    per = np.flatnonzero(periodic)
+    for i in per:
+        x0[:, i] = a[i] + (x0[:, i] - a[i]) % (b[i] - a[i])
+    sa, sb = O.State(full, x0), O.State(inc, x0)
+    assert sb.y.shape == (64, K * d)
+    Linv = [np.linalg.inv(np.linalg.cholesky(c)) for c in covs]
+    moved = 0
+    for n in (1, 40 * d - 7, 90, 23):      # across the refresh
+        before = sa.x.copy()
+        sa.run(n, n_threads=4)
+        sb.run(n, n_threads=4)
+        assert np.array_equal(sa.weight, sb.weight) and np.array_equal(sa.n_accept, sb.n_accept)
+        np.testing.assert_allclose(sa.x, sb.x, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(sa.logpost, sb.logpost, rtol=1e-12, atol=1e-9)
+        y = sb.y.reshape(64, K, d)
+        for k in range(K):
+            np.testing.assert_allclose(y[:, k], (sb.x - means[k]) @ Linv[k].T, rtol=0, atol=1e-9)
+        if n_per:
+            moved += int(np.sum(np.abs(sa.x - before)[:, per] > 0.6 * (np.array(b) - np.array(a))[per]))
+            assert np.all(sb.x[:, per] >= np.array(a)[per]) and np.all(sb.x[:, per] <= np.array(b)[per])
+    assert sa.n_accept.sum() > 64 * 20 and (not n_per or moved > 10), moved
+
+
 def test_binned_gaussian_oracle_against_reference_golden_g13():
     """§8f-4: the oracle's restatement of planck_pliklite.py:143-155 (orc_binned: binned response,
     triangular whitening, 32 interleaved chains) against the reference's own `get_chi_squared`,

@@ -243,9 +243,9 @@ def test_checkpoint_lag_moves_the_proposal_refresh_by_one_launch(tmp_path):
 
 
 def test_periodic_parameters_are_sampled_incrementally(tmp_path):
-    """A periodic parameter (prior.py:658-676) no longer sends the run to `evaluation: full`: one
-    Gaussian mode with up to eight periodic parameters, without dragging, is evaluated
-    incrementally (`auto`); a mixture or a dragging run with a periodic parameter is not.  The
+    """A periodic parameter (prior.py:658-676) does not send the run to `evaluation: full`:
+    Gaussian modes with periodic parameters, without dragging, are evaluated incrementally
+    (`auto`); a dragging run with a periodic parameter is not.  The
     likelihood itself is not periodic, so the posterior of the periodic parameter is the
     Gaussian cut to its interval -- reached from both ends through the seam."""
     from scipy.stats import truncnorm
@@ -266,15 +266,19 @@ def test_periodic_parameters_are_sampled_incrementally(tmp_path):
     tn = truncnorm((0 - 0.02) / 0.08, (0.2 - 0.02) / 0.08, loc=0.02, scale=0.08)
     assert abs(x[:, 0].mean() - tn.mean()) < 4 * tn.std() / np.sqrt(512)
     assert abs(x[:, 1].mean() - 0.5) < 4 * np.sqrt(0.004 / 512)
-    # what stays with the from-scratch kernels
+    # a mixture with a periodic parameter: incremental as well (the general kernel) ...
     two = dict(info, likelihood={"gaussian_mixture": {
         "means": [[0.02, 0.5, 0.3], [0.1, 0.4, 0.3]],
         "covs": [np.diag([0.0064, 0.004, 0.003]).tolist()] * 2}})
     s2 = OnOracle({"n_walkers": 128, "group_size": 64, "seed": 3}, ProblemSpec.from_info(two))
-    assert not s2.incremental
+    assert s2.incremental
+    # ... what stays with the from-scratch kernels: dragging with a periodic parameter
+    drag = {"n_walkers": 128, "group_size": 64, "seed": 3, "drag": True,
+            "blocking": [[1, ["phase"]], [4, ["b", "c"]]]}
+    s3 = OnOracle(dict(drag), ProblemSpec.from_info(info))
+    assert s3.drag and not s3.incremental
     with pytest.raises(LoggedError, match="incremental"):
-        OnOracle({"n_walkers": 128, "group_size": 64, "seed": 3, "evaluation": "incremental"},
-                 ProblemSpec.from_info(two))
+        OnOracle(dict(drag, evaluation="incremental"), ProblemSpec.from_info(info))
 
 
 def test_a_stuck_walker_stops_the_run_at_the_next_checkpoint(tmp_path):
