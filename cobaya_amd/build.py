@@ -109,18 +109,22 @@ def build(dims=None, jobs=None, verbose=True):
     tasks.append((ck, os.path.join(OBJ, "checkpoint.o"), [],
                   _digest([ck, ck_hdr], extra=" ".join(FLAGS))))
     inc = os.path.join(CSRC, "incremental_kernels.hip")
+    inc_hdr = os.path.join(CSRC, "incremental_common.h")
     for lo_, hi_ in INC_DQ_RANGES:
         tasks.append((inc, os.path.join(OBJ, f"incremental_{lo_}.o"),
                       [f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
-                      _digest([inc] + hdrs, extra=f"inc{lo_}-{hi_}|{' '.join(FLAGS)}")))
+                      _digest([inc, inc_hdr] + hdrs, extra=f"inc{lo_}-{hi_}|{' '.join(FLAGS)}")))
     for lo_, hi_ in INC_DQ_RANGES:   # the EMIT instantiations of step_inc_kernel (emit: chains)
         tasks.append((inc, os.path.join(OBJ, f"incremental_emit_{lo_}.o"),
                       ["-DMCMC_INC_EMIT_TU", f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
-                      _digest([inc] + hdrs, extra=f"incemit{lo_}-{hi_}|{' '.join(FLAGS)}")))
+                      _digest([inc, inc_hdr] + hdrs, extra=f"incemit{lo_}-{hi_}|{' '.join(FLAGS)}")))
+    perk = os.path.join(CSRC, "incremental_periodic.hip")   # one mode with periodic parameters
+    tasks.append((perk, os.path.join(OBJ, "incremental_periodic.o"), [],
+                  _digest([perk, inc_hdr] + hdrs, extra=" ".join(FLAGS))))
     anyk = os.path.join(CSRC, "incremental_any.hip")   # the general incremental kernel
     for part in (0, 1, 2):   # the LDS kernel + KM = 4 | KM = 8 | KM = 16 register planes
         tasks.append((anyk, os.path.join(OBJ, f"incremental_any_{part}.o"), [f"-DANY_PART={part}"],
-                      _digest([anyk] + hdrs, extra=f"any{part}|{' '.join(FLAGS)}")))
+                      _digest([anyk, inc_hdr] + hdrs, extra=f"any{part}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr, pl_hdr, ck_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

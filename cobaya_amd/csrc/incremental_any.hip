@@ -29,10 +29,7 @@
 // (build.py: -DANY_PART=0 / 1 / 2).
 #include <string>
 
-#include "det_math.h"
-#include "kernels.h"
-
-extern "C" void mcmc_hip_note_step_kernel(const char* name);
+#include "incremental_common.h"
 
 #ifndef ANY_REGS_TWO_WAVES
 #define ANY_REGS_TWO_WAVES 80   // doubles of state per lane up to which two waves share a SIMD
@@ -42,27 +39,6 @@ extern "C" void mcmc_hip_note_step_kernel(const char* name);
 #endif
 namespace mcmc {
 namespace {
-
-template <int CTRL>
-__device__ __forceinline__ double quad_perm(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_sum(double p)
-{
-    const double q = p + quad_perm<0xB1>(p);
-    return q + quad_perm<0x4E>(q);
-}
-__device__ __forceinline__ unsigned long long quad_all_mask(unsigned long long m)
-{
-    m &= m >> 1;
-    m &= m >> 2;
-    m &= 0x1111111111111111ull;
-    return m * 15ull;
-}
 
 #if ANY_PART == 0
 // LDS the kernel needs (bytes) for `nw` waves: the column chunks, the residuals, the per-mode
@@ -424,30 +400,6 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
 #endif  // ANY_PART == 0
 
 // ---------------------------------------------------------------- mixtures in registers
-__device__ __forceinline__ int hw_wave_slot()
-{
-    return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
-}
-template <int NW>   // (see rotate_priority in incremental_kernels.hip)
-__device__ __forceinline__ void rotate_priority(int slot)
-{
-    if (NW != 2 && NW != 4) return;
-    const int turn = (int)(__builtin_amdgcn_s_memtime() >> 17);
-    switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-typedef const double __attribute__((address_space(3))) * lds_doubles;
-__device__ __forceinline__ lds_doubles relaunder(const double* p)
-{
-    unsigned off = (unsigned)(unsigned long long)p;
-    asm volatile("" : "+v"(off));
-    return (lds_doubles)(unsigned long long)off;
-}
-
 __host__ __device__ constexpr int regs_chunk(int dq, int km)
 {
     int c = (2048 / ((1 + km) * 4 * dq)) & ~3;

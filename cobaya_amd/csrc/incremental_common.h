@@ -1,0 +1,134 @@
+// Shared device helpers of the incremental kernels (incremental_kernels.hip, incremental_any.hip,
+// incremental_periodic.hip): DPP quad permutes and sums, lane-mask helpers, the priority rotation,
+// laundered LDS pointers, the size of a column chunk.  gfx950 only.
+#pragma once
+#include "det_math.h"
+#include "kernels.h"
+
+// Experiment hooks.  The shipped build uses the tuned values: MCMC_EXP_* are identities / no-ops.
+// Timing experiments (occupancy sweeps, read-ahead depth, per-workgroup clocks) force-include
+// _exp/inc_experiment.h (`-include`, tools/exp_inc_variants.sh), which defines them instead;
+// nothing of that is compiled into libmcmc_hip.so.
+#ifndef MCMC_EXP_WAVES
+#define MCMC_EXP_WAVES(family, tuned) (tuned)    // waves per SIMD of a kernel family
+#define MCMC_EXP_PIPE(tuned) (tuned)             // pairs fetched ahead in the trial loop
+#define MCMC_EXP_BLOCK_BEGIN() ((void)0)         // per-workgroup clock and placement records
+#define MCMC_EXP_BLOCK_END() ((void)0)
+#define MCMC_EXP_ROTATE_SHIFT(tuned) (tuned)     // log2 of the shader clocks per priority turn
+#define MCMC_EXP_ROTATE(on) (on)                 // rotate the wave priorities at all
+#define MCMC_EXP_KEEP(tuned) (tuned)             // keep a step's (v, u) pairs in registers
+#endif
+
+namespace mcmc {
+namespace {
+
+// ---------------------------------------------------------------- DPP quad helpers
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// (p0 + p1) + (p2 + p3) in every lane of the quad; lane c holds p_c
+__device__ __forceinline__ double quad_sum(double p)
+{
+    const double q = p + quad_perm<0xB1>(p);   // [1,0,3,2]: p0+p1 | p0+p1 | p2+p3 | p2+p3
+    return q + quad_perm<0x4E>(q);             // [2,3,0,1]
+}
+
+// max over the four lanes of a quad (unsigned)
+__device__ __forceinline__ unsigned quad_max_u32(unsigned v)
+{
+    unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+    v = v > o ? v : o;
+    o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+    return v > o ? v : o;
+}
+
+// (lanes(cond) -- the wave's lane mask of a condition -- and the mask-taking selects sel(m, a, b)
+// are in det_math.h)
+// The issue arbiter of a SIMD serves its resident waves by priority, then by AGE.  Left alone, the
+// oldest of the waves that share a SIMD for a whole launch finishes first and the youngest
+// runs the last part of it alone, with nothing to cover its latencies (step kernel at d = 30:
+// the workgroups of one launch end between 0.68 and 1.20 ms, tools/block_times.py).  The
+// kernels therefore rotate their priority over the hardware wave slots -- the waves of a SIMD
+// hold distinct slots -- so that they advance together: 1.22 -> 1.04 ms.  The turn is taken
+// from the shader clock (a new level every 2^17 cycles, about 60 us), not from the wave's own
+// progress: the waves of a SIMD then hold distinct levels at every moment however far apart
+// they have drifted (with turns counted in steps the two oldest slots still finished 13 % early).
+__device__ __forceinline__ int hw_wave_slot()
+{
+    return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
+}
+template <int NW>   // NW: the waves that share a SIMD (the kernel's occupancy)
+__device__ __forceinline__ void rotate_priority(int slot)
+{
+    if (!MCMC_EXP_ROTATE(true)) return;
+    // (a rotation over NW levels: over four levels two waves would not get equal turns; kernels
+    // held to three waves are left alone -- measured: rotating them loses 2-8 %)
+    if (NW != 2 && NW != 4) return;
+    const int turn = (int)(__builtin_amdgcn_s_memtime() >> MCMC_EXP_ROTATE_SHIFT(17));
+    switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
+// lane mask -> the mask of the lanes whose quad is held completely
+__device__ __forceinline__ unsigned long long quad_all_mask(unsigned long long m)
+{
+    m &= m >> 1;
+    m &= m >> 2;
+    m &= 0x1111111111111111ull;
+    return m * 15ull;
+}
+// ... and the same as a lane predicate
+__device__ __forceinline__ bool quad_all(unsigned long long m)
+{
+    return __builtin_amdgcn_inverse_ballot_w64(quad_all_mask(m));
+}
+
+// A pointer into LDS that the optimiser has to take as new (so that it re-reads what it read
+// before instead of keeping it in registers) and that stays an LDS pointer: the 32-bit LDS offset
+// goes through the empty asm, not the generic pointer -- a laundered generic pointer makes every
+// read a flat_load_dwordx4 (64-bit address, both memory counters).
+typedef double __attribute__((ext_vector_type(2))) pair_t;   // (v_i, u_i): .x, .y
+typedef const pair_t __attribute__((address_space(3))) * lds_pairs;
+typedef const double __attribute__((address_space(3))) * lds_doubles;
+// read-only data at wave-uniform addresses, read through the scalar cache
+typedef const double __attribute__((address_space(4))) * cdoubles;
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
+__device__ __forceinline__ lds_pairs relaunder(const double2* p)
+{
+    unsigned off = lds_offset(p);
+    asm volatile("" : "+v"(off));
+    return (lds_pairs)(unsigned long long)off;
+}
+__device__ __forceinline__ lds_pairs relaunder_after(lds_pairs p, double anchor)
+{
+    unsigned off = (unsigned)(unsigned long long)p;
+    asm volatile("" : "+v"(off) : "v"(anchor));
+    return (lds_pairs)(unsigned long long)off;
+}
+__device__ __forceinline__ lds_doubles relaunder(const double* p)
+{
+    unsigned off = lds_offset(p);
+    asm volatile("" : "+v"(off));
+    return (lds_doubles)(unsigned long long)off;
+}
+
+// columns of one LDS chunk: a multiple of 4 (the variates come in fours); 16 KiB of pairs, 32 KiB
+// from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
+// workgroup barrier between chunks comes half as often)
+__host__ __device__ constexpr int inc_chunk(int dq)
+{
+    int c = ((dq >= 14 ? 2048 : 1024) / (4 * dq)) & ~3;
+    return c < 4 ? 4 : (c > 64 ? 64 : c);
+}
+
+}  // namespace
+}  // namespace mcmc

@@ -24,133 +24,12 @@
 // (double-buffered, one workgroup barrier per chunk).
 #include <string>
 
-#include "det_math.h"
-#include "kernels.h"
+#include "incremental_common.h"
 
-// Experiment hooks.  The shipped build uses the tuned values: MCMC_EXP_* are identities / no-ops.
-// Timing experiments (occupancy sweeps, read-ahead depth, per-workgroup clocks) force-include
-// _exp/inc_experiment.h (`-include`, tools/exp_inc_variants.sh), which defines them instead;
-// nothing of that is compiled into libmcmc_hip.so.
-#ifndef MCMC_EXP_WAVES
-#define MCMC_EXP_WAVES(family, tuned) (tuned)    // waves per SIMD of a kernel family
-#define MCMC_EXP_PIPE(tuned) (tuned)             // pairs fetched ahead in the trial loop
-#define MCMC_EXP_BLOCK_BEGIN() ((void)0)         // per-workgroup clock and placement records
-#define MCMC_EXP_BLOCK_END() ((void)0)
-#define MCMC_EXP_ROTATE_SHIFT(tuned) (tuned)     // log2 of the shader clocks per priority turn
-#define MCMC_EXP_ROTATE(on) (on)                 // rotate the wave priorities at all
-#define MCMC_EXP_KEEP(tuned) (tuned)             // keep a step's (v, u) pairs in registers
-#endif
+extern "C" hipError_t mcmc_hip_launch_inc_periodic(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 
 namespace mcmc {
 namespace {
-
-// ---------------------------------------------------------------- DPP quad helpers
-template <int CTRL>
-__device__ __forceinline__ double quad_perm(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-// (p0 + p1) + (p2 + p3) in every lane of the quad; lane c holds p_c
-__device__ __forceinline__ double quad_sum(double p)
-{
-    const double q = p + quad_perm<0xB1>(p);   // [1,0,3,2]: p0+p1 | p0+p1 | p2+p3 | p2+p3
-    return q + quad_perm<0x4E>(q);             // [2,3,0,1]
-}
-
-// max over the four lanes of a quad (unsigned)
-__device__ __forceinline__ unsigned quad_max_u32(unsigned v)
-{
-    unsigned o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
-    v = v > o ? v : o;
-    o = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
-    return v > o ? v : o;
-}
-
-// (lanes(cond) -- the wave's lane mask of a condition -- and the mask-taking selects sel(m, a, b)
-// are in det_math.h)
-// The issue arbiter of a SIMD serves its resident waves by priority, then by AGE.  Left alone, the
-// oldest of the waves that share a SIMD for a whole launch finishes first and the youngest
-// runs the last part of it alone, with nothing to cover its latencies (step kernel at d = 30:
-// the workgroups of one launch end between 0.68 and 1.20 ms, tools/block_times.py).  The
-// kernels therefore rotate their priority over the hardware wave slots -- the waves of a SIMD
-// hold distinct slots -- so that they advance together: 1.22 -> 1.04 ms.  The turn is taken
-// from the shader clock (a new level every 2^17 cycles, about 60 us), not from the wave's own
-// progress: the waves of a SIMD then hold distinct levels at every moment however far apart
-// they have drifted (with turns counted in steps the two oldest slots still finished 13 % early).
-__device__ __forceinline__ int hw_wave_slot()
-{
-    return (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u);   // HW_ID.WAVE_ID
-}
-template <int NW>   // NW: the waves that share a SIMD (the kernel's occupancy)
-__device__ __forceinline__ void rotate_priority(int slot)
-{
-    if (!MCMC_EXP_ROTATE(true)) return;
-    // (a rotation over NW levels: over four levels two waves would not get equal turns; kernels
-    // held to three waves are left alone -- measured: rotating them loses 2-8 %)
-    if (NW != 2 && NW != 4) return;
-    const int turn = (int)(__builtin_amdgcn_s_memtime() >> MCMC_EXP_ROTATE_SHIFT(17));
-    switch (NW == 4 ? ((slot + turn) & 3) : ((slot + turn) & 1)) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-
-// lane mask -> the mask of the lanes whose quad is held completely
-__device__ __forceinline__ unsigned long long quad_all_mask(unsigned long long m)
-{
-    m &= m >> 1;
-    m &= m >> 2;
-    m &= 0x1111111111111111ull;
-    return m * 15ull;
-}
-// ... and the same as a lane predicate
-__device__ __forceinline__ bool quad_all(unsigned long long m)
-{
-    return __builtin_amdgcn_inverse_ballot_w64(quad_all_mask(m));
-}
-
-// A pointer into LDS that the optimiser has to take as new (so that it re-reads what it read
-// before instead of keeping it in registers) and that stays an LDS pointer: the 32-bit LDS offset
-// goes through the empty asm, not the generic pointer -- a laundered generic pointer makes every
-// read a flat_load_dwordx4 (64-bit address, both memory counters).
-typedef double __attribute__((ext_vector_type(2))) pair_t;   // (v_i, u_i): .x, .y
-typedef const pair_t __attribute__((address_space(3))) * lds_pairs;
-typedef const double __attribute__((address_space(3))) * lds_doubles;
-// read-only data at wave-uniform addresses, read through the scalar cache
-typedef const double __attribute__((address_space(4))) * cdoubles;
-__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(unsigned long long)p; }
-__device__ __forceinline__ lds_pairs relaunder(const double2* p)
-{
-    unsigned off = lds_offset(p);
-    asm volatile("" : "+v"(off));
-    return (lds_pairs)(unsigned long long)off;
-}
-__device__ __forceinline__ lds_pairs relaunder_after(lds_pairs p, double anchor)
-{
-    unsigned off = (unsigned)(unsigned long long)p;
-    asm volatile("" : "+v"(off) : "v"(anchor));
-    return (lds_pairs)(unsigned long long)off;
-}
-__device__ __forceinline__ lds_doubles relaunder(const double* p)
-{
-    unsigned off = lds_offset(p);
-    asm volatile("" : "+v"(off));
-    return (lds_doubles)(unsigned long long)off;
-}
-
-// columns of one LDS chunk: a multiple of 4 (the variates come in fours); 16 KiB of pairs, 32 KiB
-// from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
-// workgroup barrier between chunks comes half as often)
-__host__ __device__ constexpr int inc_chunk(int dq)
-{
-    int c = ((dq >= 14 ? 2048 : 1024) / (4 * dq)) & ~3;
-    return c < 4 ? 4 : (c > 64 ? 64 : c);
-}
 
 // ---------------------------------------------------------------- the step kernel
 // 256 threads = 64 walkers of ONE group (group_size is a multiple of 64).
@@ -543,228 +422,6 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
     MCMC_EXP_BLOCK_END();
-}
-
-// ---------------------------------------------------------------- periodic parameters
-// One Gaussian mode with PERIODIC parameters (prior.py:675; oracle: step_core_inc).  The trial
-// coordinate of a periodic dimension is the wrapped one, t' = ((t - lo) / w - floor(.)) w + lo,
-// for every step; when the winding number changes (floor != 0) the move sh = t' - t is carried
-// into the whitened residual, y'_j += sh L^-1[j][i] for j >= i (ascending i), before chi2 is
-// summed.  The plain design: trial point and trial residual stay in registers and are committed
-// by selects (the tuned step_inc_kernel re-reads the column instead); per-dimension bounds and
-// normal-prior constants sit in LDS; one-parameter blocks by the run-time flag of the column.
-constexpr int kMaxPeriodic = 8;   // periodic parameters this kernel serves (capi.hip checks)
-__host__ __device__ constexpr int inc_periodic_min_waves(int dq)
-{
-    return dq <= 6 ? 4 : dq <= 20 ? 2 : 1;
-}
-
-__device__ __forceinline__ double wrap_into(double t, double lo, double w, double& fl)
-{
-    const double yv = (t - lo) / w;
-    fl = floor(yv);
-    return (yv - fl) * w + lo;
-}
-
-template <int DQ>
-__global__ void __launch_bounds__(256, inc_periodic_min_waves(DQ))
-step_inc_periodic_kernel(const IncStepArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double2 smem2[];
-    constexpr int COLB = 4 * DQ;
-    constexpr int C = inc_chunk(DQ);
-    constexpr int CHUNK = C * COLB;
-    constexpr int dpad = 4 * DQ;
-    __shared__ double2 sLH[4 * DQ];     // (lo, hi)
-    __shared__ double2 sNA[4 * DQ];     // normal priors: (loc, 1/scale)
-    __shared__ double sNM[4 * DQ];      //                -log(scale sqrt(2 pi))
-    // the wrap moves of a step: [walker of the workgroup][periodic parameter] (at most
-    // kMaxPeriodic of them; written by the lane that owns the dimension, read by its quad)
-    __shared__ double sShift[64][kMaxPeriodic];
-    const StepArgs& s = a.s;
-    const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
-    const int W = s.W, d = a.d;
-    const int w = blockIdx.x * 64 + (tid >> 2);
-    const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
-    const int ncols = s.n_steps;
-    const double2* __restrict__ gVU = (const double2*)a.VU + (size_t)g * ncols * COLB;
-    double2* const sVU = smem2;
-    auto stage = [&](int k) {
-        const int first = k * C;
-        if (first >= ncols) return;
-        const int cols = ncols - first < C ? ncols - first : C;
-        const int bytes = cols * COLB * 16;
-        const char* src = (const char*)(gVU + (size_t)first * COLB);
-        char* dst = (char*)(sVU + (k & 1) * CHUNK);
-        for (int kb = wave; kb * 1024 < bytes; kb += 4) {
-            if (kb * 1024 + lane * 16 < bytes)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
-                    (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
-        }
-    };
-    stage(0);
-    for (int i = tid; i < dpad; i += 256) {
-        sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
-        sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
-        sNM[i] = a.prior[4 * dpad + i];
-    }
-    double x[DQ], y[DQ];
-    unsigned mine = 0;     // bit kk: dimension 4 kk + c of this lane is periodic
-    unsigned anyp = 0;     // bit kk: one of the dimensions 4 kk .. 4 kk + 3 is (wave-uniform)
-    auto is_periodic = [&](int i) { return (a.periodic_mask4[i >> 5] >> (i & 31)) & 1u; };
-    // the periodic dimensions in ascending order (wave-uniform list) ...
-    int pdim[kMaxPeriodic], np = 0;
-    for (int i = 0; i < d; ++i)
-        if (is_periodic(i) && np < kMaxPeriodic) pdim[np++] = i;
-#pragma unroll
-    for (int kk = 0; kk < DQ; ++kk) {
-        const int i = 4 * kk + c;
-        const bool in = i < d;
-        x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;     // (beyond d: bounds -inf / +inf)
-        y[kk] = in ? a.y[(size_t)i * W + w] : 0.0;
-        if (in && is_periodic(i)) mine |= 1u << kk;
-        if ((a.periodic_mask4[(4 * kk) >> 5] >> ((4 * kk) & 31)) & 0xFu) anyp |= 1u << kk;
-    }
-    // ... and the slot of a lane's own periodic dimension in that list (the number of periodic
-    // dimensions below it)
-    auto slot_of = [&](int i) {
-        int n = 0;
-        for (int q = 0; q < (i >> 5); ++q) n += __builtin_popcount(a.periodic_mask4[q]);
-        return n + __builtin_popcount(a.periodic_mask4[i >> 5] & ((1u << (i & 31)) - 1u));
-    };
-    double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
-    int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
-    const long long nacc0 = s.n_accept[w];
-    int nacc = 0;
-    const uint32_t gid = s.walker0 + (uint32_t)w;
-    const double mt10 = s.max_tries * 10.0;
-    const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
-    const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
-    __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
-    const short_log_tab slog = short_log_load(short_log_lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned long long cur_oct = ~0ull;
-    PairRng pr;
-    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
-
-    for (int base = 0, k = 0; base < ncols; base += C, ++k) {
-        const double2* __restrict__ cur = sVU + (k & 1) * CHUNK;
-        stage(k + 1);
-        const int cols = ncols - base < C ? ncols - base : C;
-        unsigned long long oned_cols = 0;
-        if (a.colflag)
-            oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
-#pragma unroll 1
-        for (int sl = 0; sl < cols; ++sl) {
-            const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
-            if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
-                cur_oct = S >> 3;
-                pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
-            }
-            double r, Ea;
-            if ((oned_cols >> sl) & 1ull) {   // wave-uniform
-                step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
-            } else
-            switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
-            case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
-            case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
-            case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
-            case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
-            case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
-            case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
-            case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
-            default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
-            }
-            const double2* __restrict__ col = cur + sl * COLB + c;
-            double t[DQ], yt[DQ];
-            unsigned long long inb = ~0ull, wound = 0ull;
-            double sc = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < DQ; ++kk) {
-                const double2 p = col[4 * kk];
-                const double2 lh = sLH[4 * kk + c];
-                double tk = fma(r, p.x, x[kk]);
-                if ((anyp >> kk) & 1u) {   // wave-uniform: some lane's dimension here is periodic
-                    double fl;
-                    const double tw = wrap_into(tk, lh.x, lh.y - lh.x, fl);
-                    const bool per = (mine >> kk) & 1u;
-                    const bool wind = per & (fl != 0.0);
-                    const double shk = wind ? tw - tk : 0.0;
-                    tk = per ? tw : tk;
-                    wound |= lanes(shk != 0.0);
-                    if (per) sShift[tid >> 2][slot_of(4 * kk + c)] = shk;
-                }
-                t[kk] = tk;
-                inb &= lanes(tk <= lh.y) & lanes(tk >= lh.x);
-                yt[kk] = fma(r, p.y, y[kk]);
-                if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
-                    const int i = 4 * kk + c;
-                    const double2 li = sNA[i];
-                    const double qq = (tk - li.x) * li.y;
-                    sc = sc + fma(-0.5 * qq, qq, sNM[i]);
-                }
-            }
-            if (wound != 0ull) {   // wave-uniform: some walker of the wave changed a winding number
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes
-#pragma unroll 1
-                for (int q = 0; q < np; ++q) {
-                    const double sv = sShift[tid >> 2][q];       // the same in the walker's quad
-                    if (lanes(sv != 0.0) == 0ull) continue;      // wave-uniform
-                    const int i = pdim[q];                       // the dimension that wrapped
-#pragma unroll
-                    for (int kk = 0; kk < DQ; ++kk) {
-                        const int j = 4 * kk + c;
-                        const bool on = (sv != 0.0) & (j >= i) & (j < d);
-                        const double lji = on ? a.Lrow[(size_t)j * d + i] : 0.0;
-                        yt[kk] = on ? fma(sv, lji, yt[kk]) : yt[kk];
-                    }
-                }
-            }
-            double pc = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < DQ; ++kk) pc = fma(yt[kk], yt[kk], pc);
-            const unsigned long long inside_m = quad_all_mask(inb);
-            const double chi2 = quad_sum(pc);
-            const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
-            const double ll = -0.5 * (s.cnorm0 + chi2);
-            const double lt = lp + ll;
-            const double delta = (lpost - lt) / s.temperature;   // (T = 1: x / 1.0 == x)
-            const unsigned long long acc_m =
-                inside_m & lanes(lt != -INFINITY) & (lanes(lt > lpost) | lanes(Ea > delta));
-            const int lim = sel(lanes(burn > 0), lim10, lim1);
-            burn -= sel(acc_m & lanes(burn > 0), 1, 0);
-#pragma unroll
-            for (int kk = 0; kk < DQ; ++kk) {
-                x[kk] = sel(acc_m, t[kk], x[kk]);
-                y[kk] = sel(acc_m, yt[kk], y[kk]);
-            }
-            lpri = sel(acc_m, lp, lpri);
-            llik = sel(acc_m, ll, llik);
-            lpost = sel(acc_m, lt, lpost);
-            prej = sel(acc_m, 0, prej + sel(inside_m, 0, 1));
-            wt = sel(acc_m, 1, wt + 1);
-            nacc += sel(acc_m, 1, 0);
-            if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#pragma unroll
-    for (int kk = 0; kk < DQ; ++kk) {
-        const int i = 4 * kk + c;
-        if (i < d) {
-            s.x[(size_t)i * W + w] = x[kk];
-            a.y[(size_t)i * W + w] = y[kk];
-        }
-    }
-    if (c == 0) {
-        s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
-        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
-        s.n_accept[w] = nacc0 + nacc;
-    }
-    wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
 
 // ---------------------------------------------------------------- the dragging step
@@ -1589,25 +1246,6 @@ hipError_t launch_drag_dq(const IncStepArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int DQ>
-hipError_t launch_periodic_dq(const IncStepArgs& a, hipStream_t st)
-{
-    constexpr int C = inc_chunk(DQ);
-    const size_t lds = sizeof(double2) * 2 * C * 4 * DQ;
-    int n_periodic = 0;
-    for (int q = 0; q < 4; ++q) n_periodic += __builtin_popcount(a.periodic_mask4[q]);
-    if (n_periodic > kMaxPeriodic) return hipErrorInvalidValue;
-    static const std::string name = "mcmc::step_inc_periodic_kernel<" + std::to_string(DQ) + ">";
-    if (lds > 40 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)step_inc_periodic_kernel<DQ>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    mcmc_hip_note_step_kernel(name.c_str());
-    hipLaunchKernelGGL(step_inc_periodic_kernel<DQ>, dim3(a.s.W / 64), dim3(256), lds, st, a);
-    return hipGetLastError();
-}
-
 #ifdef MCMC_INC_EMIT_TU
 template <int DQ>
 hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
@@ -1628,8 +1266,9 @@ hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
     } else {
         const bool periodic = (a.periodic_mask4[0] | a.periodic_mask4[1] | a.periodic_mask4[2] |
                                a.periodic_mask4[3]) != 0u;
-        if (a.dq == DQ && periodic)
-            return a.n_drag > 0 ? hipErrorInvalidValue : launch_periodic_dq<DQ>(a, st);
+        if (a.dq == DQ && periodic)   // (incremental_periodic.hip)
+            return (a.n_drag > 0 || !mcmc_hip_launch_inc_periodic) ? hipErrorInvalidValue
+                                                                   : mcmc_hip_launch_inc_periodic(&a, st);
         if (a.dq == DQ) return a.n_drag > 0 ? launch_drag_dq<DQ>(a, st) : launch_inc_dq<DQ>(a, st);
         return dispatch_inc<DQ + 1>(a, st);
     }

@@ -1079,17 +1079,7 @@ def test_incremental_blocked_oversampled_steps_bit_exact(d, W, gs, K, blocks, ov
     assert st.step > 40 * L and "step_inc" in eng.last_step_kernel()
     if K == 1:
         assert ("1-D blocks" in eng.last_step_kernel()) == (min(len(b) for b in blocks) == 1)
-    # a PERIODIC parameter under a mixture stays with `evaluation: full`
-    eng2 = E.Engine(4, 256, group_size=64, incremental=True)
-    eng2.set_prior([0] * 4, [0.0] * 4, [1.0] * 4, [True, False, False, False])
-    m, c = random_target(4, 2, np.random.default_rng(0))
-    eng2.set_target_gaussian_mixture(m, c, [0.5, 0.5])
-    eng2.set_blocking([[0], [1, 2, 3]], [1, 2])
-    eng2.set_proposal_cov(c[0])
-    eng2.set_state(np.full((256, 4), 0.5))
-    with pytest.raises(E.EngineError, match="non-periodic"):
-        eng2.step(3)
-    eng.close(), eng2.close()
+    eng.close()
 
 
 @pytest.mark.parametrize("d,W,gs,blocks,last_slow,n_drag,extra", [

@@ -28,9 +28,13 @@ def run(d, K, n_per, W=65536, gs=256, launches=2):
     cov = c / np.sqrt(np.outer(np.diag(c), np.diag(c))) * np.outer(sd, sd)
     mean = np.full(d, 0.5)
     means = [mean] + [np.clip(mean + rng.normal(size=d) * sd, 0.05, 0.95) for _ in range(K - 1)]
+    differ = n_per < 0      # d:K:-1 -- no periodic parameter, but bounds that differ (MODE 1)
+    n_per = max(n_per, 0)
     per = [int(i < n_per) for i in range(d)]
     lo = [0.5 - 4 * sd[i] if per[i] else 0.0 for i in range(d)]
     hi = [0.5 + 4 * sd[i] if per[i] else 1.0 for i in range(d)]
+    if differ:
+        lo[0] = -0.125
     if not incremental_supported(d, K, n_per, 0, W, 4096):
         print(f"d={d} K={K} periodic={n_per}: not served incrementally", flush=True)
         return
