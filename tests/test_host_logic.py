@@ -571,3 +571,53 @@ def test_g8_chain_statistics_match_the_reference(golden):
                                    g[f"mean_derived_{tag}"], rtol=1e-14)
         np.testing.assert_allclose(c.cov(first=first, last=last, derived=True),
                                    g[f"cov_derived_{tag}"], rtol=1e-12)
+
+
+def test_division_by_the_period_without_a_division_is_the_ieee_quotient(tmp_path):
+    """incremental_periodic.hip divides by the period of a periodic parameter as
+    q0 = a R, q1 = fma(fma(-q0, w, a), R, q0), q2 = fma(fma(-q1, w, a), R, q1) with R = RN(1 / w)
+    and claims q2 == a / w bit for bit (the oracle divides; prior.py:675).  The same five
+    operations in C (gcc, no contraction) against the division: 2 * 10^7 random operands over the
+    magnitudes a wrap sees, plus quotients engineered to sit next to rounding boundaries."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "divby.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+static uint64_t s = 88172645463325252ull;
+static uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+static double u01(void) { return (double)(rnd() >> 11) * 0x1p-53; }
+static double div_by(double a, double w, double R)
+{
+    double q = a * R;
+    q = fma(fma(-q, w, a), R, q);
+    return fma(fma(-q, w, a), R, q);
+}
+long check(long n)
+{
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        double w = ldexp(0.5 + 0.5 * u01(), (int)(rnd() % 40) - 20);
+        double a;
+        if (i & 1) a = ldexp(u01() - 0.5, (int)(rnd() % 44) - 20);
+        else {   /* next to a midpoint between two doubles times w */
+            double q = ldexp(1.0 + u01(), (int)(rnd() % 30) - 15);
+            uint64_t b; memcpy(&b, &q, 8); b |= 1; memcpy(&q, &b, 8);
+            a = fma(q, w, ldexp(w, -53 + (int)(rnd() % 3) - 1) * ((rnd() & 1) ? 1 : -1) * ldexp(q, 0) / q);
+            if (rnd() & 1) a = -a;
+        }
+        double R = 1.0 / w;
+        if (div_by(a, w, R) != a / w) ++bad;
+    }
+    if (div_by(0.0, 0.16, 1.0 / 0.16) != 0.0) ++bad;
+    return bad;
+}
+''')
+    lib = tmp_path / "divby.so"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", str(src), "-o", str(lib),
+                    "-lm"], check=True)
+    f = ctypes.CDLL(str(lib)).check
+    f.restype, f.argtypes = ctypes.c_long, [ctypes.c_long]
+    assert f(20_000_000) == 0
