@@ -1718,11 +1718,18 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     if (emit) {
         bool one_d = false;   // (a block of one parameter: its columns draw other variates)
         for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b) one_d = one_d || h->blk_size[b] == 1;
-        if (K != 1 || n_periodic > 0 || P.drag || one_d || P.any)
+        if (P.drag)
             return fail(h, MCMC_HIP_ERR_ARG,
-                        "incremental evaluation emits rows (emit_capacity > 0) for one Gaussian "
-                        "mode with non-periodic priors, blocks of at least two parameters and "
-                        "Metropolis steps; use evaluation: full for this model");
+                        "incremental evaluation emits rows (emit_capacity > 0) with Metropolis "
+                        "steps; use evaluation: full for dragging with emitted rows");
+        // step_inc_kernel<.., EMIT> emits for one mode with non-periodic priors and blocks of at
+        // least two parameters; every other shape on the general kernels, which emit at run time
+        if (K != 1 || n_periodic > 0 || one_d) P.any = true;
+        if (P.any && (!mcmc_hip_launch_inc_any || !mcmc_hip_inc_any_fits ||
+                      !mcmc_hip_inc_any_fits(d, K, n_periodic, h->W, h->bgs)))
+            return fail(h, MCMC_HIP_ERR_ARG,
+                        "incremental evaluation: %d modes at d=%d with %d periodic parameters do "
+                        "not fit the LDS of a CU; use evaluation: full for this model", K, d, n_periodic);
     }
     auto launch = P.any ? mcmc_hip_launch_inc_any
                   : emit ? (dq <= 8 ? mcmc_hip_launch_inc_emit_1 : dq <= 16 ? mcmc_hip_launch_inc_emit_9

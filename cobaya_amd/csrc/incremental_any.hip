@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;
+    // `emit: chains` (run-time here: s.rows): every accepted step past the burn-in stores the
+    // point it LEAVES with its weight (mcmc.py:691-707), as step_inc_kernel<.., EMIT> does
+    int nrow = s.rows ? s.n_rows[w] : 0;
     const uint32_t gid = s.walker0 + (uint32_t)w;
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
@@ -335,6 +338,20 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
             const double delta = (lpost - lt) / s.temperature;   // (T = 1: x / 1.0 == x)
             const unsigned long long acc_m =
                 inside_m & lanes(lt != -INFINITY) & (lanes(lt > lpost) | lanes(Ea > delta));
+            if (s.rows) {   // wave-uniform
+                const unsigned long long em_m = acc_m & lanes(burn <= 0);
+                if (em_m != 0ull) {   // some walker of the wave emits
+                    const bool em = __builtin_amdgcn_inverse_ballot_w64(em_m);
+                    if (em & (nrow < s.row_cap)) {
+                        double* __restrict__ row = s.rows + ((size_t)w * s.row_cap + nrow) * (size_t)(d + 4);
+                        row[c] = c == 0 ? (double)wt : c == 1 ? lpost : c == 2 ? lpri : llik;
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk)
+                            if (4 * kk + c < d) row[4 + 4 * kk + c] = x[kk];
+                    }
+                    nrow += em ? 1 : 0;   // rows beyond the capacity are counted as dropped
+                }
+            }
             const int lim = sel(lanes(burn > 0), lim10, lim1);
             burn -= sel(acc_m & lanes(burn > 0), 1, 0);
             // ---- commit: recomputed from the column
@@ -393,6 +410,7 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
         s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;
+        if (s.rows) s.n_rows[w] = nrow;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
@@ -477,6 +495,7 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;     // accepted steps of this launch
+    int nrow = s.rows ? s.n_rows[w] : 0;   // `emit: chains`, a run-time property here (s.rows)
     const uint32_t gid = s.walker0 + (uint32_t)w;
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
@@ -594,6 +613,19 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
             const unsigned long long acc_m =
                 inside_m & lanes(lt != -INFINITY) & (lanes(lt > lpost) | lanes(Ea > delta));
             const bool accept = __builtin_amdgcn_inverse_ballot_w64(acc_m);
+            if (s.rows) {   // wave-uniform: the point the walker leaves, with its weight
+                const bool em = accept & (burn <= 0);
+                if (lanes(em) != 0ull) {   // some walker of the wave emits
+                    if (em & (nrow < s.row_cap)) {
+                        double* __restrict__ row = s.rows + ((size_t)w * s.row_cap + nrow) * (size_t)(d + 4);
+                        row[c] = c == 0 ? (double)wt : c == 1 ? lpost : c == 2 ? lpri : llik;
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk)
+                            if (4 * kk + c < d) row[4 + 4 * kk + c] = x[kk];
+                    }
+                    nrow += em ? 1 : 0;   // rows beyond the capacity are counted as dropped
+                }
+            }
             int lim = lim1;
             if (burning) {   // wave-uniform (see step_inc_kernel)
                 lim = burn > 0 ? lim10 : lim1;
@@ -636,6 +668,7 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
         s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;
+        if (s.rows) s.n_rows[w] = nrow;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
@@ -645,8 +678,10 @@ hipError_t launch_regs(const IncStepArgs& a, hipStream_t st)
 {
     constexpr int C = regs_chunk(DQ, KM);
     const size_t lds = sizeof(double) * 2 * C * (1 + KM) * 4 * DQ;
-    static const std::string name =
-        "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ">";
+    static const std::string names[2] = {
+        "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ">",
+        "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ", emit>"};
+    const std::string& name = names[a.s.rows ? 1 : 0];
     auto kern = step_inc_regs_kernel<DQ, KM>;
     if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -658,8 +693,7 @@ hipError_t launch_regs(const IncStepArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 
-// the (DQ, KM) this translation unit instantiates: KM = 4 for 17 <= DQ <= 32 (the tuned
-// step_inc_mix_kernel serves DQ <= 16), KM = 8 and 16 for every DQ that fits
+// the (DQ, KM) this translation unit instantiates: every DQ that fits, for its KM
 template <int DQ, int KM>
 hipError_t dispatch_regs(const IncStepArgs& a, hipStream_t st)
 {
@@ -709,7 +743,9 @@ __global__ void __launch_bounds__(64) whiten_directions_planes_kernel(const IncD
 template <int DQ>
 hipError_t launch_any(const IncStepArgs& a, const AnyGeom& g, hipStream_t st)
 {
-    static const std::string name = "mcmc::step_inc_any_kernel<" + std::to_string(DQ) + ">";
+    static const std::string names[2] = {"mcmc::step_inc_any_kernel<" + std::to_string(DQ) + ">",
+                                         "mcmc::step_inc_any_kernel<" + std::to_string(DQ) + ", emit>"};
+    const std::string& name = names[a.s.rows ? 1 : 0];
     auto kern = step_inc_any_kernel<DQ>;
     if (g.dynamic > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -761,11 +797,13 @@ extern "C" hipError_t mcmc_hip_launch_inc_regs_16(const mcmc::IncStepArgs*, hipS
 
 namespace mcmc {
 namespace {
-// the register kernel serves mixtures without periodic parameters that the tuned
-// step_inc_mix_kernel (K <= 4, dq <= 16) does not, as far as the registers hold them
+// the register kernel serves what capi.hip sends here -- mixtures that the tuned
+// step_inc_mix_kernel (K <= 4, dq <= 16) does not serve, and emitted rows (`emit: chains`) of
+// anything but the one Gaussian mode of step_inc_kernel<.., EMIT> -- without periodic parameters,
+// as far as the registers hold the residuals
 bool regs_serves(int K, int dq, int n_periodic)
 {
-    if (n_periodic > 0 || K < 2 || (K <= 4 && dq <= 16)) return false;
+    if (n_periodic > 0 || K < 1) return false;
     const int km = regs_bucket(K);
     if (!regs_fits(dq, km)) return false;
     return km == 4 || (km == 8 ? mcmc_hip_launch_inc_regs_8 != nullptr : mcmc_hip_launch_inc_regs_16 != nullptr);
@@ -788,7 +826,7 @@ extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs* a, hipStr
     const int np = mcmc::count_periodic(*a);
     if (a->s.W % 64 == 0 && a->s.group_size % 64 == 0 && mcmc::regs_serves(a->n_modes, a->dq, np)) {
         const int km = mcmc::regs_bucket(a->n_modes);
-        return km == 4 ? mcmc::dispatch_regs<17, 4>(*a, st)
+        return km == 4 ? mcmc::dispatch_regs<1, 4>(*a, st)
              : km == 8 ? mcmc_hip_launch_inc_regs_8(a, st) : mcmc_hip_launch_inc_regs_16(a, st);
     }
     mcmc::AnyGeom g{};

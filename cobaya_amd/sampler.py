@@ -261,11 +261,8 @@ class EnsembleMCMC:
                                              self.drag_interp_steps if self.drag else 0,
                                              W, int(self.group_size))
                    and (not self.drag or (1 + self.drag_interp_steps) * ((d + 3) // 4) <= 128)
-                   # accepted rows (emit: chains): one mode, non-periodic, Metropolis steps,
-                   # blocks of at least two parameters
-                   and (self.emit == "snapshots"
-                        or (spec.n_modes == 1 and not np.any(spec.periodic) and not self.drag
-                            and all(len(b) >= 2 for b in self.blocks)))
+                   # accepted rows (emit: chains): Metropolis steps
+                   and (self.emit == "snapshots" or not self.drag)
                    and d >= 2 and int(self.group_size) % 64 == 0
                    and bool(self.shared_basis))
         if spec.like_kind == "planck_pliklite":
@@ -283,8 +280,7 @@ class EnsembleMCMC:
             self._fail("evaluation: incremental serves Gaussian mixtures whose whitened residuals "
                        "(n_modes * d doubles per walker) fit the LDS, with Metropolis steps; "
                        "dragging for one Gaussian mode with non-periodic priors; d >= 2 and a "
-                       "group_size that is a multiple of 64; emit: chains for one mode with "
-                       "non-periodic priors, Metropolis steps and blocks of >= 2 parameters; use "
+                       "group_size that is a multiple of 64; emit: chains with Metropolis steps; use "
                        "'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
         if self.basis_group_size is None:

@@ -60,15 +60,15 @@ typedef struct mcmc_hip_config {
 /* every walker draws its OWN Haar basis per cycle (proposal.py:59-69 to the letter) instead
  * of sharing the group's: the reference-faithful control, much slower */
 #define MCMC_HIP_FLAG_OWN_BASIS 1
-/* incremental evaluation (one Gaussian mode with parameter blocks of any size, oversampling or
- * dragging -- or, without dragging, a mixture of up to four modes at d <= 64 --; up to eight
- * periodic parameters for one mode without dragging; 2 <= d <= 128; emitted rows, emit_capacity
- * > 0, for one mode with non-periodic priors, blocks of >= 2 parameters, Metropolis steps): every
- * walker carries y = L^-1 (x - mu) and a trial moves it along the whitened shared direction,
- * y' = y + r L^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in O(d) per step;
- * y is recomputed from x every 40 cycle lengths (40 d steps for one block).  What the mode does
- * not serve is refused by mcmc_hip_step with MCMC_HIP_ERR_ARG.  Specified in
- * oracle/mcmc_oracle.c. */
+/* incremental evaluation (Gaussian mixtures of up to 16 modes with uniform / normal priors and
+ * any number of periodic parameters, parameter blocks of any size and oversampling, Metropolis
+ * steps -- mcmc_hip_incremental_supported says whether a shape fits; dragging for one mode with
+ * non-periodic priors; 2 <= d <= 128; emitted rows, emit_capacity > 0, with Metropolis steps):
+ * every walker carries y_k = L_k^-1 (x - mu_k) and a trial moves it along the whitened shared
+ * direction, y_k' = y_k + r L_k^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in
+ * O(d) per step and mode; y is recomputed from x every 40 cycle lengths (40 d steps for one
+ * block).  What the mode does not serve is refused by mcmc_hip_step with MCMC_HIP_ERR_ARG.
+ * Specified in oracle/mcmc_oracle.c. */
 #define MCMC_HIP_FLAG_INCREMENTAL 2
 /* incremental mode: the walkers that share one Haar basis = group_size << ((flags >> 8) & 15)
  * (the R-1 groups of the moments stay group_size wide): fewer bases and whitened columns per

@@ -772,12 +772,10 @@ def test_incremental_mode_refuses_what_it_does_not_cover():
         E.Engine(1, 256, group_size=64, incremental=True)
     emi = E.Engine(4, 256, group_size=64, incremental=True, emit_capacity=8)
     emi.set_prior([0] * 4, [0.0] * 4, [1.0] * 4)
-    m2, c2 = random_target(4, 2, np.random.default_rng(0))   # rows are emitted for ONE mode
+    m2, c2 = random_target(4, 1, np.random.default_rng(0))   # rows are emitted by Metropolis steps
     emi.set_target_gaussian_mixture(m2, c2)
-    emi.set_proposal_cov(c2[0])
-    emi.set_state(np.full((256, 4), 0.5))
-    with pytest.raises(E.EngineError, match="emits rows"):
-        emi.step(3)
+    with pytest.raises(E.EngineError, match="does not emit rows"):
+        emi.set_blocking([[0, 1], [2, 3]], [1, 1], 0, 3)     # ... not by dragging steps
     emi.close()
     eng = E.Engine(128, 256, group_size=64, incremental=True)
     eng.set_prior([0] * 128, [0.0] * 128, [1.0] * 128)
@@ -796,7 +794,14 @@ def test_incremental_mode_refuses_what_it_does_not_cover():
     (27, 256, 64, dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.3] * 21)),
     (9, 256, 64, dict(a=[0.0] * 4 + [-1.0] * 5, b=[1.0] * 4 + [2.0] * 5)),   # MODE 1: own bounds
     (100, 256, 64, dict()),                                  # two waves per SIMD, read-ahead
-    (12, 256, 64, dict(blocks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]], over=[1, 3]))])
+    (12, 256, 64, dict(blocks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]], over=[1, 3])),
+    # what step_inc_kernel<.., EMIT> leaves out: the general kernels emit at run time --
+    (30, 256, 64, dict(K=2, weights=[0.3, 0.7])),            # a mixture (register planes)
+    (40, 128, 64, dict(K=6, burn_in=2)),
+    (9, 256, 64, dict(blocks=[[4], [0, 1, 2, 3], [5, 6, 7, 8]], over=[1, 2, 2])),   # a 1-D block
+    (9, 256, 64, dict(periodic=[0, 0, 1, 0, 0, 0, 0, 0, 0], a=[0.0, 0.0, 0.42] + [0.0] * 6,
+                      b=[1.0, 1.0, 0.58] + [1.0] * 6)),      # a periodic parameter (residuals in LDS)
+    (30, 128, 64, dict(K=3, periodic=[1] + [0] * 29, a=[0.42] + [0.0] * 29, b=[0.58] + [1.0] * 29))])
 def test_incremental_emitted_rows_bit_exact(d, W, gs, kw):
     """`emit: chains` on the incremental path (missing 5): every accepted step past
     the burn-in stores the point it leaves with its weight (mcmc.py:691-707,

@@ -498,8 +498,9 @@ def test_config2_with_manual_blocking_recovers_the_posterior():
 
 def test_two_mode_mixture_at_d40_chains_mode():
     """d > 32 beyond the specialised kernels, through `run(info)`: a two-mode gaussian_mixture
-    with a periodic parameter and emitted chains (the general kernel).  The modes are close
-    enough for the walkers to cross; mean and covariance follow the mixture's."""
+    with a periodic parameter and emitted chains -- incremental since round 3 (the LDS-state
+    kernel emits at run time; it was `step_general_kernel`).  The modes are close enough for the
+    walkers to cross; mean and covariance follow the mixture's."""
     d = 40
     rng = np.random.default_rng(40)
     mu1 = np.full(d, 0.496) + 0.002 * rng.standard_normal(d)   # 1.7 sigma apart in all
@@ -518,6 +519,7 @@ def test_two_mode_mixture_at_d40_chains_mode():
                                      "steps_per_launch": 80, "emit": "chains", "burn_in": 50,
                                      "max_samples": 250000, "Rminus1_stop": 0.0}}}
     updated, sampler = run(info)
+    assert sampler.incremental and "step_inc_any_kernel" in sampler.engine.last_step_kernel()
     coll = sampler.products()["sample"]
     m, c = coll.mean(), coll.cov()
     mean = 0.5 * (mu1 + mu2)
