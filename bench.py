@@ -543,6 +543,23 @@ def main():
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
             "steps": n_v, "warmup": 3, "metropolis_steps_per_launch": v["spl"],
             "evaluation": v["evaluation"], "roofline": gaussian_roofline(v, d5, a.walkers, n_v)})
+        # off the tuned single-mode path (VERDICT r2 "cliffs"): an 8-mode gaussian_mixture at
+        # d = 30 -- incremental on the register-plane kernel of incremental_any.hip (round 2: the
+        # from-scratch kernels, 6e9 at four modes)
+        rng8 = np.random.default_rng(8)
+        sig8 = np.sqrt(np.diag(cov))
+        info8 = make_info(d, mean, cov, a.walkers, a.group_size, 40 * d)
+        info8["likelihood"] = {"gaussian_mixture": {
+            "means": [mean] + [np.clip(mean + rng8.normal(size=d) * sig8, 0.05, 0.95) for _ in range(7)],
+            "covs": [cov] * 8, "input_params_prefix": "a_"}}
+        n_v = 4
+        v = run_timed(a, d, mean, cov, "snapshots", n_v, 2, info=info8)
+        variants.append({
+            "variant": "8-mode gaussian_mixture at d = 30 (the general incremental kernels), 65536 walkers",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"], "kernel": v.get("kernel"),
+            "kernel_ms_per_launch": v["kt"]["step_ms"] / max(1, v["kt"]["step_launches"])})
         # configs[4]'s ARITHMETIC: the plik-lite likelihood (planck_pliklite.py:143-155) -- 613
         # bins, chi2 = delta^T Sigma^-1 delta on the matrix cores -- with a 26-parameter linear
         # Cl(theta) + A_planck (d = 27); synthetic plik-lite-shaped data (the Planck files and a
