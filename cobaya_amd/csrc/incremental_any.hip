@@ -427,13 +427,15 @@ __host__ __device__ constexpr int regs_min_waves(int dq, int km)
 {
     // (the state is dq (km + 1) doubles per lane: step_inc_mix_kernel's table, continued)
     // (more than four planes: the per-mode log-densities and exponentials of a step alone take
-    // some forty registers -- never more than two waves)
+    // some forty registers -- never more than two waves.  Two waves up to ANY_REGS_TWO_WAVES
+    // doubles of state per lane: measured, K = 5 at d = 30 14.9 -> 8.2 ms per 1200 steps)
     return km > 4 ? (dq * (km + 1) <= ANY_REGS_TWO_WAVES ? 2 : 1)
-                  : dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3 : dq * (km + 1) <= 50 ? 2 : 1;
+                  : dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3
+                  : dq * (km + 1) <= ANY_REGS_TWO_WAVES ? 2 : 1;
 }
 // what fits the 512 registers of a lane at one wave per SIMD
 __host__ __device__ constexpr bool regs_fits(int dq, int km) { return dq * (km + 1) <= 208; }
-__host__ __device__ constexpr int regs_bucket(int K) { return K <= 4 ? 4 : K <= 8 ? 8 : 16; }
+__host__ __device__ constexpr int regs_bucket(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : 16; }
 
 // KM register planes, the first a.n_modes of them live (a plane beyond that is never touched:
 // the tests on k < K are wave-uniform branches around fully unrolled code).  The columns are
@@ -588,19 +590,20 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
             // the weighted sum gathers them by quad broadcasts in the order of the specification
             double ll = ak[0];
             if (K > 1) {   // wave-uniform
-                double e[KM / 4];
+                constexpr int NJ = (KM + 3) / 4;
+                double e[NJ];
 #pragma unroll
-                for (int j = 0; j < KM / 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     if (4 * j < K) {
                         double mine = ak[4 * j];
-                        mine = sel(class1, ak[4 * j + 1], mine);
-                        mine = sel(class2, ak[4 * j + 2], mine);
-                        mine = sel(class3, ak[4 * j + 3], mine);
+                        if (4 * j + 1 < KM) mine = sel(class1, ak[4 * j + 1 < KM ? 4 * j + 1 : 0], mine);
+                        if (4 * j + 2 < KM) mine = sel(class2, ak[4 * j + 2 < KM ? 4 * j + 2 : 0], mine);
+                        if (4 * j + 3 < KM) mine = sel(class3, ak[4 * j + 3 < KM ? 4 * j + 3 : 0], mine);
                         e[j] = dexp(mine - amax);
                     }
                 double Ssum = 0.0;
 #pragma unroll
-                for (int j = 0; j < KM / 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     if (4 * j + 0 < K) Ssum = fma(sMode[4 * j + 0].y, quad_perm<0x00>(e[j]), Ssum);
                     if (4 * j + 1 < K) Ssum = fma(sMode[4 * j + 1].y, quad_perm<0x55>(e[j]), Ssum);
                     if (4 * j + 2 < K) Ssum = fma(sMode[4 * j + 2].y, quad_perm<0xAA>(e[j]), Ssum);
@@ -806,7 +809,7 @@ bool regs_serves(int K, int dq, int n_periodic)
     if (n_periodic > 0 || K < 1) return false;
     const int km = regs_bucket(K);
     if (!regs_fits(dq, km)) return false;
-    return km == 4 || (km == 8 ? mcmc_hip_launch_inc_regs_8 != nullptr : mcmc_hip_launch_inc_regs_16 != nullptr);
+    return km <= 4 || (km == 8 ? mcmc_hip_launch_inc_regs_8 != nullptr : mcmc_hip_launch_inc_regs_16 != nullptr);
 }
 }  // namespace
 }  // namespace mcmc
@@ -826,7 +829,8 @@ extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs* a, hipStr
     const int np = mcmc::count_periodic(*a);
     if (a->s.W % 64 == 0 && a->s.group_size % 64 == 0 && mcmc::regs_serves(a->n_modes, a->dq, np)) {
         const int km = mcmc::regs_bucket(a->n_modes);
-        return km == 4 ? mcmc::dispatch_regs<1, 4>(*a, st)
+        return km == 2 ? mcmc::dispatch_regs<1, 2>(*a, st)
+             : km == 4 ? mcmc::dispatch_regs<1, 4>(*a, st)
              : km == 8 ? mcmc_hip_launch_inc_regs_8(a, st) : mcmc_hip_launch_inc_regs_16(a, st);
     }
     mcmc::AnyGeom g{};
