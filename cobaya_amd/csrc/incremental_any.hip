@@ -437,11 +437,25 @@ __host__ __device__ constexpr int regs_min_waves(int dq, int km)
 __host__ __device__ constexpr bool regs_fits(int dq, int km) { return dq * (km + 1) <= 208; }
 __host__ __device__ constexpr int regs_bucket(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : 16; }
 
+// a / w given R = RN(1 / w): the correctly rounded quotient in five operations (see
+// incremental_periodic.hip: q1 is faithful, and a faithful quotient corrected once with the
+// correctly rounded reciprocal is the IEEE quotient)
+__device__ __forceinline__ double regs_div_by(double a, double w, double R)
+{
+    double q = a * R;
+    q = fma(fma(-q, w, a), R, q);
+    return fma(fma(-q, w, a), R, q);
+}
+
 // KM register planes, the first a.n_modes of them live (a plane beyond that is never touched:
 // the tests on k < K are wave-uniform branches around fully unrolled code).  The columns are
 // planes of 4 DQ doubles, 1 + n_modes of them.  One-parameter blocks and the temperature are
-// run-time properties here.
-template <int DQ, int KM>
+// run-time properties here.  PER: periodic parameters, as in incremental_periodic.hip -- the trial
+// and commit loops stay branch-free (a periodic dimension has the bounds (-inf, +inf) there);
+// behind each, the rows that hold a periodic dimension wrap their coordinate; a wrap in the
+// wave sends the trial residual of a mode to registers, which takes the wrap moves in ascending
+// dimension (columns of L_k^-1 in LDS) and is formed again for the commit.
+template <int DQ, int KM, bool PER>
 __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -476,23 +490,68 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
     __shared__ double2 sNA[4 * DQ];     // normal priors: (loc, 1/scale) and -log(scale sqrt(2 pi))
     __shared__ double sNM[4 * DQ];
     __shared__ double2 sMode[kMaxModes];   // (log-normalisation, weight) of the modes
+    __shared__ double4 sPer[PER ? 4 * DQ : 1];   // periodic dimensions: (lo, hi, w, RN(1 / w))
+    __shared__ int sPdim[PER ? 4 * DQ : 1];      // the periodic dimensions, ascending
+    auto is_periodic = [&](int i) { return (a.periodic_mask4[i >> 5] >> (i & 31)) & 1u; };
+    int np = 0;
+    if (PER)
+        for (int q = 0; q < 4; ++q) np += __builtin_popcount(a.periodic_mask4[q]);
+    // PER, behind the two column chunks: the wrap moves of a step [walker][periodic parameter]
+    // and the columns L_k^-1[j][i_q], j >= i_q, of the periodic dimensions [mode][q][4 DQ]
+    double* const sShift = smem + 2 * CHUNK;
+    double* const sLc = sShift + 64 * np;
+    const bool box = a.box && !PER;
     for (int i = tid; i < dpad; i += 256) {
-        sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+        const double lo = a.prior[i], hi = a.prior[dpad + i];
+        const bool per = PER && i < d && is_periodic(i);
+        sLH[i] = per ? make_double2(-INFINITY, INFINITY) : make_double2(lo, hi);
+        if (PER) sPer[i] = per ? make_double4(lo, hi, hi - lo, 1.0 / (hi - lo)) : make_double4(0.0, 1.0, 1.0, 1.0);
         sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
         sNM[i] = a.prior[4 * dpad + i];
     }
     if (tid < K) sMode[tid] = make_double2(s.cblock[a.cnorm_off + tid], s.cblock[a.weight_off + tid]);
+    if (PER) {
+        if (tid == 0) {
+            int n = 0;
+            for (int i = 0; i < d; ++i)
+                if (is_periodic(i)) sPdim[n++] = i;
+        }
+        __syncthreads();
+        for (int e = tid; e < K * np * dpad; e += 256) {
+            const int j = e % dpad, q = (e / dpad) % np, k = e / (dpad * np);
+            const int i = sPdim[q];
+            sLc[e] = (j >= i && j < d) ? a.Lrow[((size_t)k * d + j) * d + i] : 0.0;
+        }
+    }
     double x[DQ], y[KM][DQ];
+    unsigned mine = 0;     // PER, bit kk: dimension 4 kk + c of this lane is periodic
+    unsigned anyp = 0;     //      bit kk: one of the dimensions 4 kk .. 4 kk + 3 is (wave-uniform)
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
         const bool in = i < d;
         // (one box for all dimensions: a padded dimension rests at its middle, inside for every step)
-        x[kk] = in ? s.x[(size_t)i * W + w] : (a.box ? 0.5 * (a.box_lo + a.box_hi) : 0.0);
+        x[kk] = in ? s.x[(size_t)i * W + w] : (box ? 0.5 * (a.box_lo + a.box_hi) : 0.0);
 #pragma unroll
         for (int k = 0; k < KM; ++k)
             y[k][kk] = (in && k < K) ? a.y[((size_t)k * d + i) * W + w] : 0.0;
+        if (PER) {
+            if (in && is_periodic(i)) mine |= 1u << kk;
+            if ((a.periodic_mask4[(4 * kk) >> 5] >> ((4 * kk) & 31)) & 0xFu) anyp |= 1u << kk;
+        }
     }
+    if (PER) anyp = (unsigned)__builtin_amdgcn_readfirstlane((int)anyp);
+    // the slot of the periodic dimension 4 kk + c in sPdim: the periodic dimensions of the rows
+    // below (scalar) plus those of this row in the lane classes below c
+    const unsigned below_c = (1u << c) - 1u;
+    auto slot_of = [&](int kk) {
+        int n = 0;
+        for (int q = 0; q < ((4 * kk) >> 5); ++q) n += __builtin_popcount(a.periodic_mask4[q]);
+        const unsigned word = a.periodic_mask4[(4 * kk) >> 5];
+        n += __builtin_popcount(word & ((1u << ((4 * kk) & 31)) - 1u));
+        return n + __builtin_popcount((word >> ((4 * kk) & 31)) & below_c);
+    };
+    double* const myShift = sShift + (tid >> 2) * np;
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
@@ -544,8 +603,9 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
             }
             const double* __restrict__ col = cur + sl * COL + c;
             unsigned long long inb = ~0ull;   // the support test as a lane mask
+            unsigned long long wound = 0ull;  // PER: lanes whose periodic coordinate changed its winding
             double sc = 0.0;
-            if (a.box) {   // wave-uniform: one box for every dimension, no normal priors
+            if (box) {   // wave-uniform: one box for every dimension, no normal priors
                 double tmx = -INFINITY, tmn = INFINITY;
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {
@@ -568,6 +628,49 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
                     }
                 }
             }
+            // PER: the wrapped coordinate of a periodic row (prior.py:675, the division by the
+            // period as regs_div_by)
+            auto wrapped = [&](int kk, double tk, double& fl) {
+                const double4 pw = sPer[PER ? 4 * kk + c : 0];
+                const double yv = regs_div_by(tk - pw.x, pw.z, pw.w);
+                fl = floor(yv);
+                return (yv - fl) * pw.z + pw.x;
+            };
+            if (PER) {
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk)
+                    if ((anyp >> kk) & 1u) {   // wave-uniform: a periodic dimension in this row
+                        const bool per = (mine >> kk) & 1u;
+                        const double tk = fma(r, col[4 * kk], x[kk]);
+                        double fl;
+                        const double tw = wrapped(kk, tk, fl);
+                        const double4 pw = sPer[PER ? 4 * kk + c : 0];
+                        inb &= lanes(!per | ((tw <= pw.y) & (tw >= pw.x)));
+                        const double shk = (per & (fl != 0.0)) ? tw - tk : 0.0;
+                        wound |= lanes(shk != 0.0);
+                        if (per) myShift[slot_of(kk)] = shk;
+                    }
+                if (wound != 0ull) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes
+            }
+            // PER, a wrap in the wave: the trial residual of mode k -- fma(r, u, y) for every row,
+            // then the wrap moves in ascending dimension
+            auto shifted = [&](int k, const double* __restrict__ uk, const double (&yk)[DQ], double (&yt)[DQ]) {
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) yt[kk] = fma(r, uk[4 * kk], yk[kk]);
+#pragma unroll 1
+                for (int q = 0; q < np; ++q) {
+                    const double sv = myShift[q];                // the same in the walker's quad
+                    if (lanes(sv != 0.0) == 0ull) continue;      // wave-uniform
+                    const int i = sPdim[PER ? q : 0];
+                    const double* __restrict__ lc = sLc + ((size_t)k * np + q) * dpad + c;
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) {
+                        const int j = 4 * kk + c;
+                        const bool on = (sv != 0.0) & (j >= i) & (j < d);
+                        yt[kk] = on ? fma(sv, lc[4 * kk], yt[kk]) : yt[kk];
+                    }
+                }
+            };
             double ak[KM], amax = -INFINITY;
 #pragma unroll
             for (int k = 0; k < KM; ++k) {
@@ -575,10 +678,17 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
                 if (k < K) {   // wave-uniform
                     const double* __restrict__ uk = col + (1 + k) * dpad;
                     double pc = 0.0;
+                    if (PER && wound != 0ull) {   // wave-uniform
+                        double yt[DQ];
+                        shifted(k, uk, y[k], yt);
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) pc = fma(yt[kk], yt[kk], pc);
+                    } else {
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
                         const double yt = fma(r, uk[4 * kk], y[k][kk]);
                         pc = fma(yt, yt, pc);
+                    }
                     }
                     ak[k] = -0.5 * (sMode[k].x + quad_sum(pc));
                     amax = fmax(ak[k], amax);
@@ -639,12 +749,28 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
             const lds_doubles col2 = relaunder(col);
 #pragma unroll
             for (int kk = 0; kk < DQ; ++kk) x[kk] = fma(ra, col2[4 * kk], x[kk]);
+            if (PER) {   // an accepted periodic coordinate holds the moved value: wrapped now
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk)
+                    if ((anyp >> kk) & 1u) {   // wave-uniform
+                        double fl;
+                        const double tw = wrapped(kk, x[kk], fl);
+                        x[kk] = (accept & (bool)((mine >> kk) & 1u)) ? tw : x[kk];
+                    }
+            }
 #pragma unroll
             for (int k = 0; k < KM; ++k)
                 if (k < K) {   // wave-uniform
+                    if (PER && wound != 0ull) {   // wave-uniform: the residual that took the wrap moves
+                        double yt[DQ];
+                        shifted(k, col + (1 + k) * dpad, y[k], yt);
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) y[k][kk] = accept ? yt[kk] : y[k][kk];
+                    } else {
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk)
                         y[k][kk] = fma(ra, col2[(1 + k) * dpad + 4 * kk], y[k][kk]);
+                    }
                 }
             lpri = sel(acc_m, lp, lpri);
             llik = sel(acc_m, ll, llik);
@@ -676,16 +802,20 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
 
+// LDS of the periodic instantiations behind the column chunks: the wrap moves and the columns of
+// L_k^-1 of the periodic dimensions
+inline size_t regs_periodic_lds(int K, int dq, int np) { return sizeof(double) * (size_t)np * (64 + (size_t)K * 4 * dq); }
+
 template <int DQ, int KM>
-hipError_t launch_regs(const IncStepArgs& a, hipStream_t st)
+hipError_t launch_regs(const IncStepArgs& a, int np, hipStream_t st)
 {
     constexpr int C = regs_chunk(DQ, KM);
-    const size_t lds = sizeof(double) * 2 * C * (1 + KM) * 4 * DQ;
-    static const std::string names[2] = {
-        "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ">",
-        "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM) + ", emit>"};
-    const std::string& name = names[a.s.rows ? 1 : 0];
-    auto kern = step_inc_regs_kernel<DQ, KM>;
+    const size_t lds = sizeof(double) * 2 * C * (1 + KM) * 4 * DQ + regs_periodic_lds(a.n_modes, DQ, np);
+    const std::string stem = "mcmc::step_inc_regs_kernel<" + std::to_string(DQ) + ", " + std::to_string(KM);
+    static const std::string names[4] = {stem + ">", stem + ", emit>", stem + ", periodic>",
+                                         stem + ", periodic, emit>"};
+    const std::string& name = names[(a.s.rows ? 1 : 0) + (np > 0 ? 2 : 0)];
+    auto kern = np > 0 ? step_inc_regs_kernel<DQ, KM, true> : step_inc_regs_kernel<DQ, KM, false>;
     if (lds > 40 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
@@ -698,14 +828,21 @@ hipError_t launch_regs(const IncStepArgs& a, hipStream_t st)
 
 // the (DQ, KM) this translation unit instantiates: every DQ that fits, for its KM
 template <int DQ, int KM>
-hipError_t dispatch_regs(const IncStepArgs& a, hipStream_t st)
+hipError_t dispatch_regs(const IncStepArgs& a, int np, hipStream_t st)
 {
     if constexpr (DQ > 32 || !regs_fits(DQ, KM)) {
         return hipErrorInvalidValue;
     } else {
-        if (a.dq == DQ) return launch_regs<DQ, KM>(a, st);
-        return dispatch_regs<DQ + 1, KM>(a, st);
+        if (a.dq == DQ) return launch_regs<DQ, KM>(a, np, st);
+        return dispatch_regs<DQ + 1, KM>(a, np, st);
     }
+}
+
+inline int regs_count_periodic(const IncStepArgs& a)
+{
+    int n = 0;
+    for (int q = 0; q < 4; ++q) n += __builtin_popcount(a.periodic_mask4[q]);
+    return n;
 }
 
 #if ANY_PART == 0
@@ -787,12 +924,12 @@ int count_periodic(const IncStepArgs& a)
 #if ANY_PART == 1
 extern "C" hipError_t mcmc_hip_launch_inc_regs_8(const mcmc::IncStepArgs* a, hipStream_t st)
 {
-    return mcmc::dispatch_regs<1, 8>(*a, st);
+    return mcmc::dispatch_regs<1, 8>(*a, mcmc::regs_count_periodic(*a), st);
 }
 #elif ANY_PART == 2
 extern "C" hipError_t mcmc_hip_launch_inc_regs_16(const mcmc::IncStepArgs* a, hipStream_t st)
 {
-    return mcmc::dispatch_regs<1, 16>(*a, st);
+    return mcmc::dispatch_regs<1, 16>(*a, mcmc::regs_count_periodic(*a), st);
 }
 #else
 extern "C" hipError_t mcmc_hip_launch_inc_regs_8(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
@@ -806,9 +943,11 @@ namespace {
 // as far as the registers hold the residuals
 bool regs_serves(int K, int dq, int n_periodic)
 {
-    if (n_periodic > 0 || K < 1) return false;
+    if (K < 1) return false;
     const int km = regs_bucket(K);
     if (!regs_fits(dq, km)) return false;
+    // periodic parameters: their wrap moves and columns of L_k^-1 beside the column chunks in LDS
+    if (n_periodic > 0 && regs_periodic_lds(K, dq, n_periodic) > (24u << 10)) return false;
     return km <= 4 || (km == 8 ? mcmc_hip_launch_inc_regs_8 != nullptr : mcmc_hip_launch_inc_regs_16 != nullptr);
 }
 }  // namespace
@@ -829,8 +968,8 @@ extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs* a, hipStr
     const int np = mcmc::count_periodic(*a);
     if (a->s.W % 64 == 0 && a->s.group_size % 64 == 0 && mcmc::regs_serves(a->n_modes, a->dq, np)) {
         const int km = mcmc::regs_bucket(a->n_modes);
-        return km == 2 ? mcmc::dispatch_regs<1, 2>(*a, st)
-             : km == 4 ? mcmc::dispatch_regs<1, 4>(*a, st)
+        return km == 2 ? mcmc::dispatch_regs<1, 2>(*a, np, st)
+             : km == 4 ? mcmc::dispatch_regs<1, 4>(*a, np, st)
              : km == 8 ? mcmc_hip_launch_inc_regs_8(a, st) : mcmc_hip_launch_inc_regs_16(a, st);
     }
     mcmc::AnyGeom g{};

@@ -987,8 +987,9 @@ def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
         if per:
             wraps += int(np.sum(np.abs(st.x - before)[:, per] > 0.08))
-    # (mixtures without periodic parameters that fit the register file: step_inc_regs_kernel)
-    want = "step_inc_any_kernel" if (per or K == 1) else "step_inc_regs_kernel"
+    # (what fits the register file, a few periodic parameters included: step_inc_regs_kernel;
+    # 128 periodic parameters: their columns of L^-1 do not fit beside it -- residuals in LDS)
+    want = "step_inc_any_kernel" if len(per) > 100 else "step_inc_regs_kernel"
     assert st.step > 40 * L and want in eng.last_step_kernel(), eng.last_step_kernel()
     assert eng.counters()["accepted"] == int(st.n_accept.sum()) > 0
     if per:

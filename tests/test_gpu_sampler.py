@@ -498,7 +498,7 @@ def test_config2_with_manual_blocking_recovers_the_posterior():
 
 def test_two_mode_mixture_at_d40_chains_mode():
     """d > 32 beyond the specialised kernels, through `run(info)`: a two-mode gaussian_mixture
-    with a periodic parameter and emitted chains -- incremental since round 3 (the LDS-state
+    with a periodic parameter and emitted chains -- incremental since round 3 (the register-plane
     kernel emits at run time; it was `step_general_kernel`).  The modes are close enough for the
     walkers to cross; mean and covariance follow the mixture's."""
     d = 40
@@ -519,7 +519,7 @@ def test_two_mode_mixture_at_d40_chains_mode():
                                      "steps_per_launch": 80, "emit": "chains", "burn_in": 50,
                                      "max_samples": 250000, "Rminus1_stop": 0.0}}}
     updated, sampler = run(info)
-    assert sampler.incremental and "step_inc_any_kernel" in sampler.engine.last_step_kernel()
+    assert sampler.incremental and "step_inc_regs_kernel<10, 2, periodic, emit>" in sampler.engine.last_step_kernel()
     coll = sampler.products()["sample"]
     m, c = coll.mean(), coll.cov()
     mean = 0.5 * (mu1 + mu2)
@@ -555,7 +555,7 @@ def test_six_mode_mixture_runs_incrementally(periodic):
     updated, sampler = run(info)
     assert sampler.incremental
     kern = sampler.engine.last_step_kernel()
-    assert ("step_inc_any_kernel" if periodic else "step_inc_regs_kernel") in kern, kern
+    assert "step_inc_regs_kernel" in kern and ("periodic" in kern) == periodic, kern
     x = sampler.engine.get_state()["x"]
     mean = w @ mus
     truth = cov + (mus - mean).T @ np.diag(w) @ (mus - mean)
