@@ -292,6 +292,11 @@ class EnsembleMCMC:
                 # d = 64): a basis per 4096 walkers there
                 if W >= 65536 and W % 4096 == 0:
                     self.basis_group_size = 4096
+                    # ... and per 16 384 above d = 64, where the bases (sequential reflections,
+                    # 80 KB of LDS each) are the longest chain between two step kernels:
+                    # d = 100 whole job 3.03 -> 3.11e10 evals/s (8 192: 3.08)
+                    if d > 64 and W % 16384 == 0:
+                        self.basis_group_size = 16384
         if int(self.basis_group_size) != int(self.group_size) and not self.incremental:
             self._fail("basis_group_size (%s) differs from group_size (%s): this needs "
                        "incremental evaluation", self.basis_group_size, self.group_size)

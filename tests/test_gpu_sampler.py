@@ -209,15 +209,15 @@ def test_config4_d100_posterior():
 
 def test_config4_d100_posterior_full_size_to_one_percent():
     """BASELINE config 4 at the benchmark size, the north star's bar: 100-dim golden target,
-    65 536 walkers, the sampler's defaults (incremental evaluation, a Haar basis per 4 096
-    walkers); ensemble mean within 1 % of sigma and covariance within 1 % after >= 1e6 accepted
+    65 536 walkers, the sampler's defaults (incremental evaluation, a Haar basis per 16 384
+    walkers above d = 64); ensemble mean within 1 % of sigma and covariance within 1 % after >= 1e6 accepted
     steps, from moment snapshots (as test_posterior_moments_full_size does at d = 30)."""
     import os
     from cobaya_amd.engine import Engine
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
     mean, cov = g["mean_d100"], g["cov_d100"]
     d, W = 100, 65536
-    eng = Engine(d, W, group_size=256, seed=4, incremental=True, basis_group_size=4096)
+    eng = Engine(d, W, group_size=256, seed=4, incremental=True, basis_group_size=16384)
     eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
     eng.set_target_gaussian_mixture([mean], [cov])
     eng.set_proposal_cov(cov)
