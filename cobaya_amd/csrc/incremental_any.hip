@@ -1,9 +1,9 @@
 // mcmc_hip -- the GENERAL incremental step kernel (gfx950 only), 2 <= d <= 128.
 //
-// What the tuned incremental kernels (incremental_kernels.hip) leave out: mixtures of more than
-// four modes (gaussian_mixture.py:138-163, up to kMaxModes), mixtures above d = 64, periodic
-// parameters (prior.py:658-676) together with a mixture, and more than eight periodic
-// parameters.  Same specification (oracle/mcmc_oracle.c, step_core_inc), same O(d) step: the trial
+// What the tuned incremental kernels (incremental_kernels.hip, incremental_periodic.hip) leave
+// out: mixtures of more than four modes (gaussian_mixture.py:138-163, up to kMaxModes), mixtures
+// above d = 64, periodic parameters (prior.py:658-676) together with a mixture, more than eight
+// periodic parameters, and emitted rows of anything but one non-periodic mode.  Same specification (oracle/mcmc_oracle.c, step_core_inc), same O(d) step: the trial
 // t = x + r v has the whitened residuals yt_k = y_k + r u_k, u_k = L_k^-1 v shared by the walkers
 // of a basis group; a periodic coordinate that changes its winding number by the wrap carries the
 // move sh = t' - t into every residual, yt_k[j] += sh L_k^-1[j][i] for j >= i.
@@ -21,12 +21,14 @@
 // column (x += ra v, y_k += ra u_k with ra = r where the walker accepts and 0 elsewhere; with a
 // wrap in the wave the residuals are selected instead).
 //
-// Mixtures WITHOUT periodic parameters whose residuals fit the register file -- up to 4 modes at
-// 64 < d <= 128, up to 8 at d <= 92, up to 16 at d <= 48 -- run on step_inc_regs_kernel<DQ, KM>
-// instead: step_inc_mix_kernel's design (everything in registers, KM = 4, 8 or 16 register
-// planes of which the first n_modes are live), which does not pay the LDS round trips and is not
-// held to one wave per SIMD by the LDS the state takes.  One translation unit per KM
-// (build.py: -DANY_PART=0 / 1 / 2).
+// What fits the register file -- up to 2 / 4 / 8 / 16 modes while dq (modes + 1) <= 208 doubles per
+// lane, i.e. 4 modes at d = 128, 8 at d <= 92, 16 at d <= 48, and periodic sets whose columns of
+// L^-1 take at most 24 KiB of LDS -- runs on step_inc_regs_kernel<DQ, KM, PER> instead:
+// step_inc_mix_kernel's design (everything in registers, KM = 2, 4, 8 or 16 register planes of
+// which the first n_modes are live; PER adds incremental_periodic.hip's scheme for periodic
+// parameters), which does not pay the LDS round trips and is not held to one wave per SIMD by
+// the LDS the state takes.  One translation unit per group of KM (build.py: -DANY_PART=0 / 1 / 2).
+// Both kernels emit rows at run time (`emit: chains`, s.rows).
 #include <string>
 
 #include "incremental_common.h"
@@ -35,7 +37,7 @@
 #define ANY_REGS_TWO_WAVES 80   // doubles of state per lane up to which two waves share a SIMD
 #endif
 #ifndef ANY_PART
-#define ANY_PART 0   // 0: the LDS kernel, the planes, KM = 4; 1: KM = 8; 2: KM = 16
+#define ANY_PART 0   // 0: the LDS kernel, the planes, KM = 2 and 4; 1: KM = 8; 2: KM = 16
 #endif
 namespace mcmc {
 namespace {
