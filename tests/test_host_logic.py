@@ -621,3 +621,24 @@ long check(long n)
     f = ctypes.CDLL(str(lib)).check
     f.restype, f.argtypes = ctypes.c_long, [ctypes.c_long]
     assert f(20_000_000) == 0
+
+
+def test_incremental_supported_is_a_pure_function_of_the_shape():
+    """mcmc_hip_incremental_supported (what `evaluation: auto` asks): no device is touched, so it
+    answers in the build container too.  Tuned kernels for one mode / up to four at d <= 64 / up to
+    eight periodic parameters / dragging of one non-periodic mode; the general kernels for every
+    other Metropolis shape whose residuals fit registers or LDS; nothing for d < 2, more than 16
+    modes, dragging with a mixture or a periodic parameter, or 16 modes at d = 128."""
+    from cobaya_amd.engine import incremental_supported as ok
+    W, gs = 65536, 256
+    assert ok(30, 1, 0, 0, W, gs) and ok(128, 1, 0, 0, W, gs) and ok(2, 1, 0, 0, W, gs)
+    assert ok(30, 4, 0, 0, W, gs) and ok(30, 5, 0, 0, W, gs) and ok(30, 16, 0, 0, W, gs)
+    assert ok(100, 2, 0, 0, W, gs) and ok(128, 4, 0, 0, W, gs) and ok(64, 8, 0, 0, W, gs)
+    assert ok(30, 1, 8, 0, W, gs) and ok(30, 1, 30, 0, W, gs) and ok(128, 1, 128, 0, W, gs)
+    assert ok(30, 3, 2, 0, W, gs) and ok(100, 3, 3, 0, W, gs)
+    assert ok(27, 1, 0, 7, W, gs)                                  # dragging, one mode
+    assert not ok(27, 2, 0, 7, W, gs) and not ok(27, 1, 1, 7, W, gs)
+    assert not ok(1, 1, 0, 0, W, gs) and not ok(129, 1, 0, 0, W, gs)
+    assert not ok(30, 17, 0, 0, W, gs) and not ok(30, 0, 0, 0, W, gs)
+    assert not ok(128, 16, 0, 0, W, gs)                            # 0.5 MB of residuals per wave
+    assert not ok(30, 1, 0, 0, W, 100) and not ok(30, 1, 0, 0, 1000, 256)
