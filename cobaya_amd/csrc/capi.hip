@@ -1146,7 +1146,9 @@ int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const i
     }
     B.n_bins = n_bins; B.lmax = lmax; B.n_lin = n_lin; B.calib = calib_index;
     B.nlp = (n_lin + 3) & ~3;
-    B.KT = (n_bins + 3) / 4;
+    // k-steps of four bins, an EVEN number of them: pl_chi2_kernel fetches the operands of two
+    // k-steps with one 16-byte load (a padding k-step is zeros: exact no-ops at the end of a chain)
+    B.KT = (((n_bins + 3) / 4) + 1) & ~1;
     B.bins.assign(bins, bins + 3 * n);
     const int NT = (n_bins + 15) / 16;
     B.ntw = (NT + 7) / 8;
@@ -1169,14 +1171,16 @@ int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const i
         const int absent = B.ntw - (int)mine.size();
         for (int t = 0; t < 5; ++t) { B.nk[q][t] = 0; B.tile_off[q][t] = 0; }
         for (int t = 0; t < (int)mine.size(); ++t) {
-            const int R = mine[t], nk = std::min(4 * R + 4, B.KT);
+            const int R = mine[t], nk = std::min(4 * R + 4, B.KT);   // (even)
             B.nk[q][absent + t] = nk;
             B.tile_off[q][absent + t] = As.size();
-            for (int kk = 0; kk < nk; ++kk)
-                for (int l = 0; l < 64; ++l) {
-                    const size_t j = 16 * (size_t)R + (l & 15), i = 4 * (size_t)kk + (l >> 4);
-                    As.push_back((j < n && i <= j) ? B.Linv[j * n + i] : 0.0);
-                }
+            // (A-operand lane order, the k-steps 2 m and 2 m + 1 of a lane side by side)
+            for (int kk2 = 0; kk2 < nk / 2; ++kk2)
+                for (int l = 0; l < 64; ++l)
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const size_t j = 16 * (size_t)R + (l & 15), i = 4 * (size_t)(2 * kk2 + h2) + (l >> 4);
+                        As.push_back((j < n && i <= j) ? B.Linv[j * n + i] : 0.0);
+                    }
         }
     }
     As.resize(As.size() + (size_t)mcmc::kPlPad * 64, 0.0);   // (operands are fetched ahead)

@@ -21,7 +21,7 @@ struct PlResidualArgs {
     const double* trial;   // [d][W]
     const double* theta0;  // [nlp] fiducial parameters (zero beyond n_lin)
     const double* resp;    // [n_bins][nlp + 2] records (Bc0_b, BJ_b0 .. BJ_b,nlp-1, X_b)
-    double* delta;         // [W / 64][KT][4][64]: B-operand order of pl_chi2_kernel
+    double* delta;         // [W / 64][KT / 2][4][64][2]: B-operand order of pl_chi2_kernel, k-steps in pairs
     int W, n_bins, KT, n_lin, nlp, calib;
 };
 struct PlBinArgs {
@@ -34,10 +34,11 @@ struct PlBinArgs {
     int n_pts, n_bins, KT, L0, stride;
 };
 struct PlChi2Args {
-    const double* delta;   // [W / 64][KT][4][64] + kPlPad k-steps (256 doubles each) of padding
-    const double* Astream; // tile t of wave q at tile_off[q][t]: [nk[q][t]][64] doubles,
-                           // k-step kk = L^-1[16 R + (l & 15)][4 kk + (l >> 4)]; kPlPad k-steps of
-                           // padding behind the last tile (operands are fetched ahead)
+    const double* delta;   // [W / 64][KT / 2][4][64][2] (KT even: the k-steps 2 m, 2 m + 1 of a lane
+                           // side by side) + kPlPad k-steps (256 doubles each) of padding
+    const double* Astream; // tile t of wave q at tile_off[q][t]: [nk[q][t] / 2][64][2] doubles,
+                           // k-step kk of lane l = L^-1[16 R + (l & 15)][4 kk + (l >> 4)]; kPlPad
+                           // k-steps of padding behind the last tile (operands are fetched ahead)
     double* psum;          // [8][4][n_walkers]: p[q][c] of every walker (chains of its chi2)
     unsigned long long tile_off[8][5];   // (absent tiles: any valid offset)
     int nk[8][5];          // k-steps of tile t of wave q: ascending in t, absent tiles first (0)

@@ -26,10 +26,12 @@
 // pl_chi2_kernel: a workgroup of 8 waves owns 64 walkers (4 walker tiles of 16 = the N of the
 // MFMA); wave q owns the 16-row tiles R of L^-1 with class(R) = q (a snake deal: the cost of a
 // tile grows with R) and keeps ALL their accumulators -- 5 tiles x 4 walker tiles x 4 doubles --
-// in registers while the k loop runs OUTSIDE: per k-step (4 columns) it loads one 16 x 4 tile of
-// L^-1 per active row tile (global memory, 512 B in A-operand lane order, used for 4 MFMAs) and
-// the 4 x 16 slices of delta of its four walker tiles (B operands, shared by the active tiles:
-// used for up to 5 MFMAs each), one k-step ahead of the MFMAs; the loop is cut into one phase per
+// in registers while the k loop runs OUTSIDE: per PAIR of k-steps (2 x 4 columns) it loads, with
+// one 16-byte load per lane each, two 16 x 4 tiles of L^-1 per active row tile (global memory,
+// 1 KB in A-operand lane order, used for 8 MFMAs) and the two 4 x 16 slices of delta of each of
+// its four walker tiles (B operands, shared by the active tiles: used for up to 10 MFMAs each),
+// one pair ahead of the MFMAs (one 8-byte load per k-step and operand: 0.448 ms per launch; in
+// pairs: 0.391 -- what the loads cost is their NUMBER); the loop is cut into one phase per
 // set of active tiles (tile R is finished after k-step 4 R + 3), so an iteration has no branch.  Every tile of L^-1 is read once
 // per 64 walkers (1.5 MB from L2), delta once per wave; nothing passes through LDS and there is NO
 // barrier: a workgroup takes several sets of 64 walkers in turn (one workgroup per CU for the whole
@@ -42,9 +44,9 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 #ifndef MCMC_PL_PREFETCH
-#define MCMC_PL_PREFETCH 3
+#define MCMC_PL_PREFETCH 1
 #endif
-constexpr int kPlPrefetch = MCMC_PL_PREFETCH;   // k-steps the operands of pl_chi2_kernel are fetched ahead
+constexpr int kPlPrefetch = MCMC_PL_PREFETCH;   // PAIRS of k-steps the operands of pl_chi2_kernel are fetched ahead
 typedef const double __attribute__((address_space(4))) * cptr;
 __device__ __forceinline__ cptr as_const(const double* p) { return (cptr)(unsigned long long)p; }
 
@@ -149,7 +151,8 @@ __global__ void __launch_bounds__(64) pl_prior_kernel(const double* __restrict__
 // ascending (oracle: orc_binned_delta).  One lane per walker, 4 waves per 64 walkers, each taking
 // a quarter of the k-steps (4 bins); the records (Bc0_b, BJ_b0 .. BJ_b,NLP-1, X_b) are the same
 // for every lane: constant address space -> s_load -> SGPR operands of v_fma_f64.  Output in the
-// B-operand order of pl_chi2_kernel: delta[wg][kk][wt][16 c + n] = residual of bin 4 kk + c for
+// B-operand order of pl_chi2_kernel, two k-steps side by side: delta[wg][kk / 2][wt][16 c + n][kk & 1]
+// = residual of bin 4 kk + c for
 // walker 64 wg + 16 wt + n (zero for the padding bins).
 template <int NLP>   // emulator parameters padded to a multiple of 4 (BJ and theta0 zero beyond n_lin)
 __global__ void __launch_bounds__(256) pl_residual_kernel(const PlResidualArgs a)
@@ -166,25 +169,26 @@ __global__ void __launch_bounds__(256) pl_residual_kernel(const PlResidualArgs a
     }
     const double A = a.trial[(size_t)calib * W + w];
     const double iA2 = 1.0 / (A * A);
-    const int KT = a.KT;
-    const int k0 = (KT * part) / 4, k1 = (KT * (part + 1)) / 4;
+    const int KT2 = a.KT / 2;      // (KT is even: pairs of k-steps, one 16-byte store per pair)
+    const int k0 = (KT2 * part) / 4, k1 = (KT2 * (part + 1)) / 4;
     const cptr rec0 = as_const(a.resp);
-    double* __restrict__ out = a.delta + (size_t)wg * KT * 256 + (lane >> 4) * 64 + (lane & 15);
+    double2* __restrict__ out = (double2*)a.delta + (size_t)wg * KT2 * 256 + (lane >> 4) * 64 + (lane & 15);
     constexpr int RL = NLP + 2;
-    for (int kk = k0; kk < k1; ++kk) {
+    auto residual = [&](int b) {
+        double dl = 0.0;
+        if (b < a.n_bins) {            // (wave-uniform)
+            const cptr rec = rec0 + (size_t)b * RL;
+            double cl = rec[0];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int b = 4 * kk + c;
-            double dl = 0.0;
-            if (b < a.n_bins) {            // (wave-uniform)
-                const cptr rec = rec0 + (size_t)b * RL;
-                double cl = rec[0];
-#pragma unroll
-                for (int p = 0; p < NLP; ++p) cl = fma(rec[1 + p], dth[p], cl);
-                dl = fma(-cl, iA2, rec[1 + NLP]);
-            }
-            out[(size_t)kk * 256 + c * 16] = dl;
+            for (int p = 0; p < NLP; ++p) cl = fma(rec[1 + p], dth[p], cl);
+            dl = fma(-cl, iA2, rec[1 + NLP]);
         }
+        return dl;
+    };
+    for (int kk2 = k0; kk2 < k1; ++kk2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            out[(size_t)kk2 * 256 + c * 16] = make_double2(residual(8 * kk2 + c), residual(8 * kk2 + 4 + c));
     }
 }
 
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(64) pl_bin_kernel(const PlBinArgs a)
         dl = fma(-acc, 1.0 / (A * A), a.X[b]);
     }
     const int wg = pt >> 6, wt = (pt >> 4) & 3, n = pt & 15;
-    a.delta[(((size_t)wg * a.KT + (b >> 2)) * 4 + wt) * 64 + (b & 3) * 16 + n] = dl;
+    a.delta[((((size_t)wg * (a.KT / 2) + (b >> 3)) * 4 + wt) * 64 + (b & 3) * 16 + n) * 2 + ((b >> 2) & 1)] = dl;
 }
 
 // ------------------------------------------------------------------------------ chi2
@@ -216,11 +220,11 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int nk[NTW];
-    const double* __restrict__ ap[NTW];
+    const double2* __restrict__ ap[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         nk[t] = a.nk[wave][t];          // ascending in t; absent tiles first (0)
-        ap[t] = a.Astream + a.tile_off[wave][t] + lane;
+        ap[t] = (const double2*)(a.Astream + a.tile_off[wave][t]) + lane;
     }
     // a workgroup takes `batches` consecutive sets of 64 walkers; its eight waves run FREE -- no
     // barrier anywhere: every wave leaves the 4 partial sums p[q][c] of its rows per walker in
@@ -230,18 +234,18 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
     for (int bt = 0; bt < a.batches; ++bt) {
     const int wg = blockIdx.x * a.batches + bt;
     if (wg >= a.n_sets) break;
-    const double* __restrict__ dl = a.delta + (size_t)wg * a.KT * 256 + lane;
+    // (operands of TWO k-steps per 16-byte load: delta and the tiles of L^-1 hold the k-steps 2 m
+    // and 2 m + 1 of a lane side by side -- half the load instructions of one per k-step)
+    const double2* __restrict__ dl = (const double2*)a.delta + (size_t)wg * (a.KT / 2) * 256 + lane;
     d4 acc[NTW][4];
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int wt = 0; wt < 4; ++wt) acc[t][wt] = d4{0.0, 0.0, 0.0, 0.0};
-    // Operands are fetched PF k-steps ahead of their MFMAs (registers av[j], bv[j] = k-step kk + j):
-    // in the late phases a wave has one or two active tiles left -- 4 or 8 MFMAs = 256 or 512
-    // clocks per k-step -- and a fetch one k-step ahead would expose the L2 latency there.  The
-    // streams and delta are padded by PF k-steps, so the fetches past the end are harmless.
+    // Operands are fetched PF pairs of k-steps ahead of their MFMAs.  The streams and delta are
+    // padded, so the fetches past the end are harmless.
     constexpr int PF = kPlPrefetch;
-    double av[PF][NTW], bv[PF][4];
+    double2 av[PF][NTW], bv[PF][4];
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
 #pragma unroll
@@ -249,13 +253,13 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) av[j][t] = ap[t][(size_t)j * 64];
     }
-    int kk = 0;
-    // phase P: the k-steps on which the tiles t >= P are active (tile t ends at k-step nk[t], and
-    // nk ascends): a fixed set of loads and MFMAs per iteration, no branch inside
+    int kk = 0;   // pair of k-steps
+    // phase P: the k-steps on which the tiles t >= P are active (tile t ends at k-step nk[t], even,
+    // and nk ascends): a fixed set of loads and MFMAs per iteration, no branch inside
 #pragma unroll
     for (int P = 0; P < NTW; ++P) {
-        for (; kk < nk[P]; ++kk) {
-            double an[NTW], bn[4];
+        for (; 2 * kk < nk[P]; ++kk) {
+            double2 an[NTW], bn[4];
 #pragma unroll
             for (int wt = 0; wt < 4; ++wt) bn[wt] = dl[((size_t)(kk + PF) * 4 + wt) * 64];
 #pragma unroll
@@ -264,7 +268,12 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
             for (int t = P; t < NTW; ++t)
 #pragma unroll
                 for (int wt = 0; wt < 4; ++wt)
-                    acc[t][wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][t], bv[0][wt], acc[t][wt], 0, 0, 0);
+                    acc[t][wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][t].x, bv[0][wt].x, acc[t][wt], 0, 0, 0);
+#pragma unroll
+            for (int t = P; t < NTW; ++t)
+#pragma unroll
+                for (int wt = 0; wt < 4; ++wt)
+                    acc[t][wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][t].y, bv[0][wt].y, acc[t][wt], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j + 1 < PF; ++j) {
 #pragma unroll
