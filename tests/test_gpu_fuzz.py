@@ -182,3 +182,95 @@ def test_random_incremental_shapes_bit_exact(seed):
     assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
     assert "inc" in eng.last_step_kernel()
     eng.close()
+
+
+def draw_general_case(seed):
+    """A random shape only the general incremental kernels serve (incremental_any.hip): more than
+    four modes, a mixture above d = 64, periodic parameters beside a mixture, more than eight
+    periodic parameters -- with normal priors, temperature, burn-in, blocks (one-parameter blocks
+    too), and emitted rows on half of the cases."""
+    rng = np.random.default_rng(seed)
+    kind = int(rng.integers(0, 4))
+    if kind == 0:      # many modes
+        d, K = int(rng.integers(2, 41)), int(rng.integers(5, 17))
+        while ((d + 3) // 4) * (K + 1) > 208:
+            K -= 1
+    elif kind == 1:    # a mixture above d = 64
+        d, K = int(rng.integers(65, 129)), int(rng.integers(2, 5))
+    elif kind == 2:    # periodic parameters beside a mixture
+        d, K = int(rng.integers(3, 65)), int(rng.integers(2, 7))
+    else:              # many periodic parameters, one mode
+        d, K = int(rng.integers(12, 100)), 1
+    gs = int(rng.choice([64, 128]))
+    W = gs * int(rng.integers(1, 3))
+    kw = {}
+    kinds = [0] * d
+    a, b = [0.0] * d, [1.0] * d
+    if rng.random() < 0.4:
+        kinds = (rng.random(d) < 0.4).astype(int).tolist()
+        a = [0.5 if k else 0.0 for k in kinds]
+        b = [float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds]
+    per = [0] * d
+    if kind >= 2:
+        n_per = int(rng.integers(1, 4)) if kind == 2 else int(rng.integers(9, min(d, 40)))
+        for i in rng.choice(d, size=min(n_per, d), replace=False):
+            if not kinds[int(i)]:
+                per[int(i)] = 1
+                a[int(i)], b[int(i)] = 0.42, 0.58
+    kw.update(kinds=kinds, a=a, b=b)
+    if any(per):
+        kw["periodic"] = per
+    if rng.random() < 0.3:
+        kw["T"] = float(rng.choice([1.5, 2.0]))
+    if rng.random() < 0.3:
+        kw["burn_in"] = int(rng.integers(1, 4))
+    if K > 1:
+        w = rng.uniform(0.2, 1.0, K)
+        kw["weights"] = (w / w.sum()).tolist()
+    L = d
+    if rng.random() < 0.4 and d >= 4:
+        perm = rng.permutation(d).tolist()
+        nb = int(rng.integers(2, min(4, d // 2) + 1))
+        cuts = sorted(rng.choice(np.arange(1, d), size=nb - 1, replace=False).tolist())
+        blocks = [perm[p:q] for p, q in zip([0] + cuts, cuts + [d])]
+        over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
+        kw.update(blocks=blocks, over=over)
+        L = sum(o * len(bl) for o, bl in zip(over, blocks))
+    if rng.random() < 0.5:
+        kw["cap"] = 64
+    steps = [int(rng.integers(1, 12)), int(rng.integers(1, 40)), int(rng.integers(1, 20))]
+    if L <= 60:   # (short cycles: across the refresh at 40 cycle lengths)
+        steps[1] = 40 * L - int(rng.integers(0, 20))
+    return d, W, gs, K, kw, steps
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_GENERAL_CASES", "32")))))
+def test_random_general_incremental_shapes_bit_exact(seed):
+    """The general incremental kernels (register planes with and without periodic parameters, the
+    LDS-state kernel; snapshots or emitted rows) on randomly drawn shapes, bit for bit against the
+    oracle: state, carried residuals, counters and, where rows are emitted, the rows."""
+    from tests.test_gpu_parity import assert_bit_equal
+    d, W, gs, K, kw, steps = draw_general_case(12000 + seed)
+    cap = kw.get("cap", 0)
+    eng, prob, st = make_pair(d, W, gs, K=K, incremental=True, rng=np.random.default_rng(seed), **kw)
+    compare_state(eng, st)
+    for n in steps:
+        for n1 in ([n] if not cap else [min(cap, n)] * (n // min(cap, n)) + ([n % cap] if n % min(cap, n) else [])):
+            eng.step(n1)
+            eng.sync()
+            st.run(n1, n_threads=8)
+            if cap:
+                assert_bit_equal(eng.drain_samples(), st.drain(), "rows")
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
+    c = eng.counters()
+    assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
+    name = eng.last_step_kernel()
+    # (a draw whose periodic parameters mostly fell on normal priors is left with at most eight:
+    # the periodic kernel's, unless rows are emitted;
+    # or none: the tuned mixture kernel's)
+    general = "step_inc_regs_kernel" in name or "step_inc_any_kernel" in name
+    tuned = not cap and ("step_inc_periodic_kernel" in name or "step_inc_mix_kernel" in name)
+    assert general or tuned, name
+    assert ("emit" in name) == bool(cap), name
+    eng.close()
