@@ -860,13 +860,21 @@ class EnsembleMCMC:
     def _expire_row_views(self):
         """Before a drain: blocks of `_rows` that are views of the engine's pinned slots stay
         readable for `drain_slots - 1` further drains only; the ones that would not survive the
-        drain that comes are dropped here (they are the oldest rows of the store)."""
-        views = [i for i, r in enumerate(self._rows) if getattr(r, "base", None) is not None
-                 and not r.flags.owndata and not r.flags.writeable]
+        drain that comes are copied out of their slot here (they stay in the store, which only
+        `max_rows` bounds -- `_store_rows`)."""
+        views = [i for i, r in enumerate(self._rows) if self._is_slot_view(r)]
         keep = max(0, getattr(self.engine, "drain_slots", 4) - 2)
-        for i in reversed(views[:max(0, len(views) - keep)]):
-            self._n_rows -= len(self._rows[i])
-            del self._rows[i]
+        for i in views[:max(0, len(views) - keep)]:
+            self._rows[i] = np.array(self._rows[i])
+
+    @staticmethod
+    def _is_slot_view(r):
+        return getattr(r, "base", None) is not None and not r.flags.owndata and not r.flags.writeable
+
+    def _materialise_row_views(self):
+        """Every stored block becomes the sampler's own memory (the engine's pinned slots die
+        with it: `close`)."""
+        self._rows = [np.array(r) if self._is_slot_view(r) else r for r in self._rows]
 
     def _store_rows(self, rows, view=False):
         """Keeps at most `max_rows` rows per process WITHOUT freezing: the bounds criterion
@@ -979,6 +987,11 @@ class EnsembleMCMC:
             self._window()      # (the books only: which intervals the window holds from now on)
             d_acc, d_steps, n_acc_all = dev["d_accepted"], dev["d_steps"], dev["accepted"]
         self._acc_last, self._steps_last = c["accepted"], c["steps"]
+        if dev is None and getattr(self, "_device_ckpt", False):
+            # a checkpoint without new snapshots took the host path: the device's own copy of
+            # "accepted at the last checkpoint" must follow, or the next device checkpoint
+            # would report the accepted steps of two intervals over the steps of one
+            eng.checkpoint_set_accepted(self._acc_last)
         acceptance_rate = d_acc / max(d_steps, 1.0)
         self._acc_rate = acceptance_rate
         self._accepted_total = int(n_acc_all)
@@ -1223,6 +1236,7 @@ class EnsembleMCMC:
 
     def close(self):
         if self.engine is not None:
+            self._materialise_row_views()   # products()/samples() stay valid after close
             self.engine.close()
             self.engine = None
 

@@ -222,11 +222,20 @@ class OracleEngine:
         self.drain_slots = int(n)
 
     def drain_samples_view(self):
-        """Like the engine's: a read-only view the caller must not keep beyond
-        `drain_slots - 1` further drains (here the memory simply stays alive)."""
-        rows = self.drain_samples().view()
+        """Like the engine's: a read-only view of a slot that is REUSED `drain_slots` drains
+        later -- here the expired slot is poisoned with NaN, so a caller that keeps a view
+        too long is caught."""
+        ring = self.__dict__.setdefault("_slot_ring", [])
+        rows = self.drain_samples()
+        if len(ring) >= self.drain_slots:
+            old = ring.pop(0)
+            old.flags.writeable = True
+            old[...] = np.nan
+        ring.append(rows)
+        out = rows.view()
         rows.flags.writeable = False
-        return rows
+        out.flags.writeable = False
+        return out
 
     # -- moments ------------------------------------------------------------------------
     def set_moment_shift(self, shift):

@@ -396,3 +396,21 @@ def test_chains_mode_runs_on_the_incremental_path(tmp_path):
     f = make(p, 6000, emit="chains", steps_per_launch=20)
     f.run()
     assert len(lines(p + ".1.txt")) - 1 == len(f.products()["sample"])
+
+
+def test_chains_mode_keeps_every_accepted_row_without_output():
+    """with `emit: chains` and no `output`, rows read in place from the
+    engine's drain slots must be copied out before their slot is reused -- the product holds
+    every accepted row (up to `max_rows`), not the last three launches."""
+    s = make(None, 20000, emit="chains", steps_per_launch=20)
+    s.run()
+    coll = s.products()["sample"]
+    acc = s.engine.counters()["accepted"]
+    # every accepted step closes one row; the current points (one per walker) are still open
+    assert acc - 128 <= len(coll) <= acc
+    assert np.all(np.isfinite(coll.data.to_numpy()))
+    steps = s.engine.counters()["steps"]
+    assert steps * 128 - np.asarray(coll["weight"]).sum() <= 128 * 60   # open weights only
+    # the store outlives the engine (its pinned slots die with it)
+    s.close()
+    assert np.all(np.isfinite(np.vstack(s._rows))) and len(np.vstack(s._rows)) == len(coll)
