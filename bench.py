@@ -84,9 +84,14 @@ def parse():
                     help="untimed launches before the W warmup steps until the device has been "
                          "under load this long (a cold MI355X runs the same kernel 18 %% slower "
                          "for its first ~35 ms: tools/ramp_probe.py); 0 = none")
-    ap.add_argument("--device-checkpoint", action="store_true",
-                    help="R-1 and the proposal refresh on the device (`device_checkpoint: True`) "
-                         "instead of on the host beside the next launch")
+    ap.add_argument("--checkpoint-on", dest="device_checkpoint", choices=("device", "host"),
+                    default=None,
+                    help="device: R-1 and the proposal refresh on the device, the all-reduce in "
+                         "place on the engine's stream (`device_checkpoint: True`); host: from "
+                         "the pinned read-back beside the next launch.  Default: the sampler's "
+                         "(host on one GPU, device for N > 1)")
+    ap.add_argument("--device-checkpoint", dest="device_checkpoint", action="store_const",
+                    const="device", help="= --checkpoint-on device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--workload", choices=("gaussian_mixture", "pliklite"), default="gaussian_mixture",
                     help="pliklite: ONLY the planck_pliklite variant (613 bins, d = 27), as its "
@@ -282,8 +287,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
                          evaluation or a.evaluation)
         if a.basis_group_size and (evaluation or a.evaluation) != "full":
             info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
-    if a.device_checkpoint:
-        info["sampler"]["mcmc_hip"]["device_checkpoint"] = True
+    if a.device_checkpoint is not None:   # (default: the sampler's -- device for N > 1)
+        info["sampler"]["mcmc_hip"]["device_checkpoint"] = a.device_checkpoint == "device"
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -337,13 +342,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
     dist.barrier()
     dt = time.perf_counter() - t0
     if size > 1:   # MAX over ranks
-        import torch
-        import torch.distributed as td
-        t = torch.tensor([dt], dtype=torch.float64)
-        if td.get_backend() == "nccl":
-            t = t.cuda(dist.local_rank())
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.cpu()[0])
+        dt = float(dist.all_reduce_max(np.array([dt]))[0])
     kt = eng.kernel_times()
     if sampler.spec.like_kind == "planck_pliklite":
         kt["binned"] = eng.binned_kernel_times()
@@ -352,6 +351,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
            "group_size": int(sampler.group_size),
            "basis_group_size": int(sampler.basis_group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
            "checkpoint_lag": int(sampler.checkpoint_lag),
+           "checkpoint_on": "device" if sampler._device_ckpt else "host",
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
     sampler.close()
     return res
@@ -475,15 +475,47 @@ def main_pliklite(a, rank, size):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: spawn the N ranks here (one
+    process per GPU, the environment torch.distributed.run would give them, 127.0.0.1
+    rendezvous), wait, and pass rank 0's JSON line through.  Fewer visible GPUs than ranks: the
+    ranks share devices and the collective is the gloo stand-in (RCCL refuses two ranks on one
+    device) -- the line says so in `collective.backend`."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+            if rc:
+                break
+    finally:
+        for p in procs:        # a rank that failed must not leave the others in a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))
     from cobaya_amd import dist
 
     dist.init_from_env()
     rank, size = dist.rank(), dist.size()
     if size != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={size}; launch with "
-              "torch.distributed.run for N > 1", file=sys.stderr)
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={size}", file=sys.stderr)
     if a.workload == "pliklite":
         return main_pliklite(a, rank, size)
     d = a.dim
@@ -596,8 +628,16 @@ def main():
         collective = dict(collective or {})
         collective.update(per_rank_step_kernel_ms=[float(x) for x in per],
                           per_rank_timed_region_s=[float(x) for x in wall],
+                          # host buffer -> pinned -> H2D -> ncclAllReduce -> D2H, synchronous
+                          # (what a host-path checkpoint pays)
                           checkpoint_allreduce_us=1e6 * (time.perf_counter() - t0) / 20,
                           checkpoint_allreduce_doubles=len(buf))
+        comm = dist.native()
+        if comm is not None:
+            # what the device checkpoint queues: ncclAllReduce in place on a stream, no copies
+            # (20 back to back between two HIP events: mcmc_hip_comm_time_allreduce)
+            dist.barrier()
+            collective["checkpoint_allreduce_in_stream_us"] = comm.time_allreduce(len(buf), 20)
     out = None
     if rank == 0:
         spl, dt = m["spl"], m["dt"]
@@ -619,7 +659,7 @@ def main():
                 "evals_per_step": a.walkers * size * spl,
                 "learn_checkpoints_in_timed_region": m["n_ckpt"],
                 "checkpoint_lag_launches": m["checkpoint_lag"],
-                "checkpoint_on": "device" if a.device_checkpoint else "host",
+                "checkpoint_on": m["checkpoint_on"],
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
             "collective": collective,

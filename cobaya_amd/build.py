@@ -108,6 +108,10 @@ def build(dims=None, jobs=None, verbose=True):
     ck_hdr = os.path.join(CSRC, "checkpoint_args.h")
     tasks.append((ck, os.path.join(OBJ, "checkpoint.o"), [],
                   _digest([ck, ck_hdr], extra=" ".join(FLAGS))))
+    comm = os.path.join(CSRC, "comm.hip")   # the RCCL communicator (bound at run time)
+    comm_hdr = os.path.join(CSRC, "comm.h")
+    tasks.append((comm, os.path.join(OBJ, "comm.o"), [],
+                  _digest([comm, comm_hdr, root_hdr], extra=" ".join(FLAGS))))
     inc = os.path.join(CSRC, "incremental_kernels.hip")
     inc_hdr = os.path.join(CSRC, "incremental_common.h")
     for lo_, hi_ in INC_DQ_RANGES:
@@ -126,7 +130,7 @@ def build(dims=None, jobs=None, verbose=True):
         tasks.append((anyk, os.path.join(OBJ, f"incremental_any_{part}.o"), [f"-DANY_PART={part}"],
                       _digest([anyk, inc_hdr] + hdrs, extra=f"any{part}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
-                  _digest([capi, root_hdr, pl_hdr, ck_hdr] + hdrs, extra=" ".join(FLAGS))))
+                  _digest([capi, root_hdr, pl_hdr, ck_hdr, comm_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         rebuilt = list(ex.map(lambda t: _compile(*t), tasks))
@@ -138,7 +142,7 @@ def build(dims=None, jobs=None, verbose=True):
         with open(stamp_file) as f:
             need_link = f.read() != link_stamp
     if need_link:
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-ldl", "-o", LIB]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed: {' '.join(cmd)}\n{res.stdout}\n{res.stderr}")

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "pliklite_args.h"
 #include "checkpoint_args.h"
+#include "comm.h"
 
 MCMC_DECLARE_DIM(1) MCMC_DECLARE_DIM(2) MCMC_DECLARE_DIM(3) MCMC_DECLARE_DIM(4)
 MCMC_DECLARE_DIM(5) MCMC_DECLARE_DIM(6) MCMC_DECLARE_DIM(7) MCMC_DECLARE_DIM(8)
@@ -401,6 +402,9 @@ struct mcmc_hip_ctx {
         hipEvent_t ev = nullptr;
         bool begun = false, pending = false;
     } ck;
+    // the walker shards' communicator (comm.hip; not owned): the device checkpoint all-reduces
+    // its payload over it in stream order
+    mcmc_hip_comm* comm = nullptr;
     // binned-bandpower Gaussian target (planck_pliklite.py:143-155; pliklite_kernels.hip)
     struct Binned {
         bool on = false;
@@ -2335,6 +2339,11 @@ int mcmc_hip_checkpoint_begin(mcmc_hip_ctx* h, int32_t n_window_intervals, int64
     p.n_per_chain = (double)n_window_snapshots * (double)h->gs;
     p.steps_since = steps_since;
     HIP_TRY(h, mcmc_hip_launch_ckpt_payload(&p, h->stream));
+    if (h->comm) {   // (also a communicator of ONE rank: the same RCCL launch an 8-GPU job queues)
+        // ONE all-reduce per checkpoint, in place, in stream order: RCCL over xGMI
+        if (int rc = mcmc_comm_allreduce_on_stream(h->comm, K.payload.p, 5 + 2 * d * d + d, 0, h->stream))
+            return fail(h, rc, "%s", mcmc_comm_error(h->comm));
+    }
     K.begun = true;
     if (payload_device_ptr) *payload_device_ptr = (uint64_t)(uintptr_t)K.payload.p;
     if (payload_len) *payload_len = (int32_t)(5 + 2 * d * d + d);
@@ -2382,6 +2391,17 @@ int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_
         h->T.assign(K.pin_out + 8 + nn, K.pin_out + 8 + 2 * nn);
         h->have_cov = true;
     }
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_comm(mcmc_hip_ctx* h, mcmc_hip_comm* c)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (c && mcmc_comm_device(c) != h->cfg.device)
+        return fail(h, MCMC_HIP_ERR_ARG, "the communicator lives on device %d, the engine on device %d",
+                    mcmc_comm_device(c), h->cfg.device);
+    if (h->ck.begun) return fail(h, MCMC_HIP_ERR_STATE, "a device checkpoint is in flight");
+    h->comm = c;
     return MCMC_HIP_OK;
 }
 

@@ -111,6 +111,18 @@ SYMBOLS = [
     ("mcmc_hip_get_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_set_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
+    ("mcmc_hip_comm_version", C.c_char_p, []),
+    ("mcmc_hip_comm_last_error", C.c_char_p, [_H]),
+    ("mcmc_hip_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
+    ("mcmc_hip_comm_create", C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32,
+                                       C.POINTER(_H)]),
+    ("mcmc_hip_comm_destroy", None, [_H]),
+    ("mcmc_hip_comm_rank", C.c_int, [_H]),
+    ("mcmc_hip_comm_size", C.c_int, [_H]),
+    ("mcmc_hip_comm_allreduce", C.c_int, [_H, c_double_p, C.c_int64, C.c_int32]),
+    ("mcmc_hip_comm_allreduce_device", C.c_int, [_H, C.c_uint64, C.c_int64, C.c_int32, C.c_uint64]),
+    ("mcmc_hip_comm_time_allreduce", C.c_int, [_H, C.c_int64, C.c_int32, c_double_p]),
+    ("mcmc_hip_set_comm", C.c_int, [_H, _H]),
 ]
 
 _lib = None
@@ -176,6 +188,76 @@ def gelman_rubin(n_chains, sum_N, sum_Ncov, sum_mean, sum_mm):
     if rc:
         raise EngineError(rc, "gelman_rubin: invalid arguments")
     return R.value, W
+
+
+COMM_ID_BYTES = 128
+
+
+class Communicator:
+    """The walker shards' communicator inside libmcmc_hip.so (RCCL over xGMI; one handle of
+    `mcmc_hip_comm_*`).  Creation is collective over all ranks."""
+
+    _OPS = {"sum": 0, "max": 1}
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """Rank 0: the 128-byte id every rank's constructor needs (ncclGetUniqueId)."""
+        lib = load_library()
+        ident = (C.c_uint8 * COMM_ID_BYTES)()
+        if lib.mcmc_hip_comm_unique_id(ident):
+            raise EngineError(ERR_DEVICE, lib.mcmc_hip_comm_last_error(None).decode())
+        return bytes(ident)
+
+    def __init__(self, ident: bytes, rank: int, size: int, device: int):
+        self._lib = load_library()
+        if len(ident) != COMM_ID_BYTES:
+            raise EngineError(ERR_ARG, f"the communicator id has {COMM_ID_BYTES} bytes")
+        self._h = _H()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(ident)
+        rc = self._lib.mcmc_hip_comm_create(buf, int(rank), int(size), int(device), C.byref(self._h))
+        if rc:
+            self._h = _H()
+            raise EngineError(rc, "mcmc_hip_comm_create failed: "
+                              + self._lib.mcmc_hip_comm_last_error(None).decode())
+        self.rank, self.size, self.device = int(rank), int(size), int(device)
+        self.version = self._lib.mcmc_hip_comm_version().decode()
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError(rc, self._lib.mcmc_hip_comm_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def allreduce(self, buf: np.ndarray, op="sum") -> np.ndarray:
+        """In place over ranks, a float64 HOST buffer (staged through pinned memory; synchronous)."""
+        flat = np.ascontiguousarray(buf, dtype=np.float64).reshape(-1)
+        self._check(self._lib.mcmc_hip_comm_allreduce(self._h, _dp(flat), flat.size, self._OPS[op]))
+        buf[...] = flat.reshape(buf.shape)
+        return buf
+
+    def allreduce_device(self, ptr: int, n: int, op="sum", stream: int = 0):
+        """In place, n float64 at a device pointer, queued in order on `stream` (0: its own)."""
+        self._check(self._lib.mcmc_hip_comm_allreduce_device(self._h, int(ptr), int(n), self._OPS[op],
+                                                             int(stream)))
+
+    def time_allreduce(self, n: int, reps: int = 20) -> float:
+        """HIP-event microseconds per in-stream all-reduce of n float64 (collective)."""
+        us = C.c_double()
+        self._check(self._lib.mcmc_hip_comm_time_allreduce(self._h, int(n), int(reps), C.byref(us)))
+        return us.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mcmc_hip_comm_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine:
@@ -516,6 +598,15 @@ class Engine:
 
     def stream_handle(self):
         return int(self._lib.mcmc_hip_stream_handle(self._h))
+
+    def set_comm(self, comm):
+        """Attach the shards' communicator: `checkpoint_begin` then all-reduces its payload over
+        it, in place and in stream order.  The communicator must outlive the engine."""
+        self._check(self._lib.mcmc_hip_set_comm(self._h, comm.handle if comm is not None else None))
+        self._comm = comm
+        self.comm_attached = comm is not None
+
+    comm_attached = False
 
     # -- timing
     def enable_timing(self, on=True):

@@ -74,14 +74,16 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
-    "device_checkpoint": False,  # True: R-1 and the proposal refresh ON THE DEVICE, in stream order
+    "device_checkpoint": None,  # True: R-1 and the proposal refresh ON THE DEVICE, in stream order
                               # (checkpoint_kernels.hip): the refreshed proposal is in force for
                               # the very next launch and, with several processes, the all-reduce
-                              # runs on device memory (RCCL, no host bounce).  False (default): on
-                              # the host from the pinned read-back while the next launch runs --
-                              # measured faster on one GPU (the device's
-                              # single-workgroup linear algebra sits ON the critical path, the
-                              # host's beside it)
+                              # runs in place on device memory, queued by the library on the
+                              # engine's stream (RCCL, no host bounce, no host synchronisation).
+                              # False: on the host from the pinned read-back while the next
+                              # launch runs -- measured faster on one GPU (the
+                              # device's single-workgroup linear algebra sits ON the critical
+                              # path, the host's beside it).  None (default): True for several
+                              # processes joined by the library's RCCL communicator, else False
     "row_buffer_bytes": 1 << 32,  # emit: chains -- device buffer of accepted rows between two
                               # drains (bounds steps_per_launch: every step may accept)
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
@@ -341,13 +343,22 @@ class EnsembleMCMC:
             return
         # initial points (model.py:707-754 get_valid_point, one per walker)
         self.log.info("Getting initial points... (%d walkers)", W)
-        x0 = spec.sample_reference(W, self._rng)
+        # One generator per walker GROUP, keyed by the group's GLOBAL index: the initial points
+        # -- like the Philox streams of the steps -- do not depend on how the walkers are
+        # sharded, so a rank's shard equals the same slice of a single-process ensemble.
+        gsz = int(self.group_size)
+        g0 = self.rank * (W // gsz)
+        rngs = [np.random.default_rng(np.random.SeedSequence(self.seed, spawn_key=(g0 + g,)))
+                for g in range(W // gsz)]
+        x0 = np.vstack([spec.sample_reference(gsz, r) for r in rngs])
         for _ in range(int(min(self.max_tries, 1000))):
             lp, ll = self.engine.evaluate(x0)
             bad = ~np.isfinite(lp + ll)
             if not bad.any():
                 break
-            x0[bad] = spec.sample_reference(int(bad.sum()), self._rng)
+            for g in np.unique(np.flatnonzero(bad) // gsz):
+                idx = g * gsz + np.flatnonzero(bad[g * gsz:(g + 1) * gsz])
+                x0[idx] = spec.sample_reference(len(idx), rngs[g])
         else:
             self._fail("Could not find random point giving finite posterior after "
                                    "%g tries", self.max_tries)
@@ -365,7 +376,11 @@ class EnsembleMCMC:
         can = hasattr(self.engine, "checkpoint_begin") and dist.device_collective()
         if self.device_checkpoint and not can:
             self._fail("device_checkpoint: True needs the HIP engine and, with several processes, "
-                       "the nccl (RCCL) backend")
+                       "the library's RCCL communicator (not the gloo stand-in)")
+        # the communicator goes to the engine: its checkpoint reduces in place, in stream order
+        attached = can and dist.attach(self.engine)
+        if self.device_checkpoint is None:
+            self.device_checkpoint = bool(attached and self.size > 1)
         self._device_ckpt = bool(self.device_checkpoint)
         if self._device_ckpt:
             self.engine.checkpoint_set_ring(self._intervals)
@@ -671,7 +686,8 @@ class EnsembleMCMC:
         if k + 1 > eng.ckpt_capacity:     # the window outgrew the ring: reload it, larger
             eng.checkpoint_set_ring(self._intervals, min_capacity=2 * (k + 1))
         ptr, n = eng.checkpoint_begin(k, sum(counts[-k:]), self.n_steps_raw - self._ckpt_steps_last)
-        if self.size > 1:
+        if self.size > 1 and not getattr(eng, "comm_attached", False):
+            # (an engine the communicator is attached to has queued the all-reduce itself)
             dist.all_reduce_sum_device(ptr, n, eng.stream_handle())
         learn = bool(self.learn_proposal)
         eng.checkpoint_solve(self.learn_proposal_Rminus1_min if learn else np.inf,

@@ -260,8 +260,9 @@ MCMC_HIP_API int mcmc_hip_fetch_moments(mcmc_hip_ctx* h, int64_t* n_snapshots, d
  * checkpoint_begin (window sums + the buffer an all-reduce carries: *payload_device_ptr is a
  * device pointer to *payload_len doubles = [chains, sum N, accepted since the last checkpoint,
  * steps x walkers since, accepted | sum N cov (d*d) | sum of chain means (d) | sum of m m^T (d*d)];
- * with several processes the caller all-reduces it on the engine's stream, see
- * mcmc_hip_stream_handle) -> checkpoint_solve -> [more launches] -> checkpoint_fetch:
+ * with several processes it is all-reduced on the engine's stream before the solve -- by the
+ * library itself when a communicator is attached (mcmc_hip_set_comm: ncclAllReduce in place,
+ * queued by checkpoint_begin), else by the caller, see mcmc_hip_stream_handle) -> checkpoint_solve -> [more launches] -> checkpoint_fetch:
  * stats = {R-1 of the chain (= group) means, status (0 ok; 1, 2, 3: the LinAlgError cases of
  * mcmc.py:870-887), 1 if the proposal was refreshed, chains, sum N, accepted since the last
  * checkpoint, steps x walkers since, accepted}, mean_of_covs[d*d].
@@ -277,6 +278,46 @@ MCMC_HIP_API int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], dou
 /* the engine's HIP stream (a hipStream_t as an integer), for callers that queue their own work
  * -- the all-reduce of a multi-process checkpoint -- in order with the engine's */
 MCMC_HIP_API uint64_t mcmc_hip_stream_handle(const mcmc_hip_ctx* h);
+
+/* Multi-GPU: the communicator of the walker shards -- RCCL over xGMI, one process per GPU
+ * (SURVEY 8e).  Stands in for the mpi4py calls of the reference's checkpoint: the gather of
+ * (N, mean, cov, acceptance rate) to the root and the broadcasts back (mcmc.py:791-793
+ * `mpi.array_gather`, :1005-1007 and :1021 `mpi.share`; mpi.py:178-191) become ONE all-reduce(sum)
+ * of pooled sufficient statistics.  A communicator is a process-level object (created before
+ * the first engine: the job's seed is agreed through it, sampler.py:369-384):
+ *   rank 0: mcmc_hip_comm_unique_id(id) -> the host hands `id` to every rank out of band (any
+ *   launcher's store; cobaya_amd/dist.py uses MASTER_ADDR/MASTER_PORT) -> every rank:
+ *   mcmc_hip_comm_create(id, rank, n_ranks, device) [collective: ncclCommInitRank] ->
+ *   mcmc_hip_set_comm(engine, comm).
+ * With a communicator attached, mcmc_hip_checkpoint_begin queues `ncclAllReduce` of its payload
+ * IN PLACE on the engine's stream, between the payload and the solve kernel: every rank solves
+ * the same reduced statistics and refreshes its own proposal, no host bounce and no host
+ * synchronisation.  mcmc_hip_comm_allreduce reduces a HOST buffer (staged through pinned memory,
+ * synchronous; op 0 = sum, 1 = max): counters, the host-path checkpoint's payload, the bench
+ * clock.  mcmc_hip_comm_allreduce_device reduces n doubles at a device pointer in order on a
+ * caller's stream (0: the communicator's own).  RCCL is bound at run time (dlopen of
+ * librccl.so.1, or $MCMC_HIP_RCCL_LIB): single-GPU runs never load it.
+ * mcmc_hip_comm_last_error(NULL): the last failure before a communicator existed. */
+typedef struct mcmc_hip_comm mcmc_hip_comm;
+#define MCMC_HIP_COMM_ID_BYTES 128
+MCMC_HIP_API const char* mcmc_hip_comm_version(void);      /* "RCCL 2.x.y", "" if it cannot be loaded */
+MCMC_HIP_API const char* mcmc_hip_comm_last_error(const mcmc_hip_comm* c);
+MCMC_HIP_API int mcmc_hip_comm_unique_id(uint8_t id[MCMC_HIP_COMM_ID_BYTES]);
+MCMC_HIP_API int mcmc_hip_comm_create(const uint8_t id[MCMC_HIP_COMM_ID_BYTES], int32_t rank, int32_t n_ranks,
+                         int32_t device, mcmc_hip_comm** out);
+MCMC_HIP_API void mcmc_hip_comm_destroy(mcmc_hip_comm* c);
+MCMC_HIP_API int mcmc_hip_comm_rank(const mcmc_hip_comm* c);
+MCMC_HIP_API int mcmc_hip_comm_size(const mcmc_hip_comm* c);
+MCMC_HIP_API int mcmc_hip_comm_allreduce(mcmc_hip_comm* c, double* buf, int64_t n, int32_t op);
+MCMC_HIP_API int mcmc_hip_comm_allreduce_device(mcmc_hip_comm* c, uint64_t device_ptr, int64_t n, int32_t op,
+                                   uint64_t stream);
+/* HIP-event time (microseconds per call) of `reps` back-to-back in-stream all-reduces of n doubles
+ * on the communicator's own stream and scratch buffer -- what one device checkpoint's collective
+ * costs the stream (bench.py reports it).  Collective: every rank must call it alike. */
+MCMC_HIP_API int mcmc_hip_comm_time_allreduce(mcmc_hip_comm* c, int64_t n, int32_t reps, double* us_per_call);
+/* attach (or, with NULL, detach) the communicator the device checkpoint reduces over; the
+ * communicator must live on the engine's device and outlive the engine */
+MCMC_HIP_API int mcmc_hip_set_comm(mcmc_hip_ctx* h, mcmc_hip_comm* c);
 
 /* The R-1 arithmetic of MCMC.check_convergence_and_learn_proposal (mcmc.py:856-889) on
  * reduced sufficient statistics (what the RCCL all-reduce of SURVEY 8e carries):

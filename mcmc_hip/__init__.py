@@ -47,7 +47,7 @@ else:
         snapshot_every: int | None = HIP_DEFAULTS["snapshot_every"]
         max_rows: int = HIP_DEFAULTS["max_rows"]
         row_buffer_bytes: int = HIP_DEFAULTS["row_buffer_bytes"]
-        device_checkpoint: bool = HIP_DEFAULTS["device_checkpoint"]
+        device_checkpoint: bool | None = HIP_DEFAULTS["device_checkpoint"]
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]
         evaluation: str = HIP_DEFAULTS["evaluation"]
         basis_group_size: int | None = HIP_DEFAULTS["basis_group_size"]

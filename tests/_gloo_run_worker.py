@@ -41,11 +41,15 @@ def main():
     class S(MCMCHip):
         _engine_factory = staticmethod(Spy)
 
+    learn = len(sys.argv) < 3 or sys.argv[2] != "nolearn"
     s = S({"seed": 5, "n_walkers": 128, "group_size": 64, "steps_per_launch": 40,
-           "max_samples": 60000, "Rminus1_stop": 0.0, "learn_every": "40d"},
+           "max_samples": 30000 * dist.size(), "Rminus1_stop": 0.0, "learn_every": "40d",
+           "learn_proposal": learn},
           ProblemSpec.from_info(QUICK), output=os.path.join(out_dir, "run"))
     s.run()
     st = s.engine.get_full_state()
+    np.savez(os.path.join(out_dir, f"state_rank{dist.rank()}.npz"), x=st["x"], logpost=st["logpost"],
+             weight=st["weight"], n_accept=st["n_accept"])
     prog = s.progress
     res = {"rank": dist.rank(), "size": dist.size(), "lag": s._ckpt_lag, "log": log,
            "walker_offset": int(s.engine.walker_offset),

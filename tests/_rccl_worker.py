@@ -1,7 +1,6 @@
-"""Worker of tests/test_gpu_sampler.py::test_rccl_path_with_one_rank: initialises
-torch.distributed with backend `nccl` (= RCCL on ROCm), world_size 1, on cuda:0 and runs the
-sampler's collective layer and a full learn/convergence checkpoint of the real engine through
-it.  Prints one JSON line."""
+"""Worker of tests/test_gpu_sampler.py::test_rccl_path_with_one_rank: creates the library's RCCL
+communicator (mcmc_hip_comm_*, a world of one on cuda:0) and runs the sampler's collective layer
+and full learn/convergence checkpoints of the real engine through it.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -16,11 +15,9 @@ def run_checkpoints(use_group, device_checkpoint=False):
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
     if use_group:
-        import torch
-        import torch.distributed as td
-        torch.cuda.set_device(0)
-        td.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2],
-                              world_size=1, rank=0)
+        # the library's own RCCL communicator, a world of one on cuda:0 -- no PyTorch involved
+        dist.init_native_comm(0, 1, 0)
+        assert "torch" not in sys.modules
     t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
                              "targets.npz"))
     mean, cov = t["mean_d30"], t["cov_d30"]
@@ -43,7 +40,7 @@ def run_checkpoints(use_group, device_checkpoint=False):
     out["allreduce_identity"] = bool(np.array_equal(dist.all_reduce_sum(buf.copy()), buf))
     s.close()
     if use_group:
-        td.destroy_process_group()
+        dist.shutdown()
     return out
 
 

@@ -9,6 +9,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from oracle import ref_numpy as R
 
@@ -54,33 +55,72 @@ def test_checkpoint_allreduce_world_size_2(tmp_path):
     assert res[1]["gathered"] is None and len(res[0]["gathered"]) == 2
 
 
-def test_run_loop_world_size_2(tmp_path):
-    """The whole `run()` loop on two ranks (oracle-backed engine double, each rank its shard
-    of the walkers): the checkpoints are processed two launches after their request (the
-    multi-process default, sampler.advance), every rank sees the same R-1, acceptance rate
-    and learned covariance at every checkpoint, and the ranks really hold different walkers."""
+def _run_ranks(tmp_path, world, *args):
     port = free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_run_worker.py"),
-                                       str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                                       str(tmp_path), *args], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
-        out, _ = p.communicate(timeout=600)
+        out, _ = p.communicate(timeout=900)
         assert p.returncode == 0, out.decode()[-3000:]
-    a, b = (json.load(open(tmp_path / f"run_rank{r}.json")) for r in range(2))
-    assert a["size"] == b["size"] == 2 and a["lag"] == b["lag"] == 2
-    assert (a["walker_offset"], b["walker_offset"]) == (0, 128)
-    assert len(a["Rminus1"]) >= 3 and a["steps"] == b["steps"]
-    for k in ("Rminus1", "N", "acc", "cov"):
-        assert a[k] == b[k], k                 # one all-reduce: bit-identical on every rank
-    assert a["xsum"] != b["xsum"]
-    for r in (a, b):
+    return [json.load(open(tmp_path / f"run_rank{r}.json")) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_run_loop_on_several_ranks(tmp_path, world):
+    """The whole `run()` loop on 2, 4 and 8 ranks (oracle-backed engine double, each rank its
+    shard of the walkers -- BASELINE configs[2]'s layout): the checkpoints are processed two
+    launches after their request (the multi-process default, sampler.advance), every rank sees
+    the same R-1, acceptance rate and learned covariance at every checkpoint, and the ranks
+    really hold different walkers."""
+    res = _run_ranks(tmp_path, world)
+    a = res[0]
+    assert all(r["size"] == world and r["lag"] == 2 for r in res)
+    assert [r["walker_offset"] for r in res] == [128 * k for k in range(world)]
+    assert len(a["Rminus1"]) >= 3
+    for b in res[1:]:
+        assert a["steps"] == b["steps"]
+        for k in ("Rminus1", "N", "acc", "cov"):
+            assert a[k] == b[k], k                 # one all-reduce: bit-identical on every rank
+    assert len({r["xsum"] for r in res}) == world
+    for r in res:
         req = [n for what, n in r["log"] if what == "request"]
         ref = [n for what, n in r["log"] if what == "refresh"][1:]
         assert len(ref) >= 3 and all(y - x == 2 for x, y in zip(req, ref)), r["log"]
-    for ext in (".checkpoint", ".covmat", ".progress", ".1.txt", ".2.txt", ".1.state.npz",
-                ".2.state.npz"):
+    exts = [".checkpoint", ".covmat", ".progress"] + [f".{k}.{e}" for k in range(1, world + 1)
+                                                      for e in ("txt", "state.npz")]
+    for ext in exts:
         assert os.path.exists(str(tmp_path / "run") + ext), ext
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_shards_equal_the_slices_of_one_ensemble(tmp_path, world):
+    """"walker w -> GPU w // (W/G) ... results independent of G".  With the proposal
+    fixed, rank r's 128 walkers after the whole run ARE walkers [128 r, 128 (r + 1)) of a
+    single-process ensemble of 128 x world walkers, bit for bit (initial points and Philox
+    streams are keyed by GLOBAL group / walker ids); and the R-1 every rank forms from the
+    all-reduced statistics is the single process's to rounding (the summation order differs)."""
+    from cobaya_amd.model import ProblemSpec
+    from tests.test_host_logic import QUICK
+    from tests.test_sampler_on_oracle import OnOracle
+    res = _run_ranks(tmp_path, world, "nolearn")
+    one = OnOracle({"seed": 5, "n_walkers": 128 * world, "group_size": 64, "steps_per_launch": 40,
+                    "max_samples": 30000 * world, "Rminus1_stop": 0.0, "learn_every": "40d",
+                    "learn_proposal": False, "checkpoint_lag": 2}, ProblemSpec.from_info(QUICK))
+    one.run()
+    st = one.engine.get_full_state()
+    assert one.n_steps_raw == res[0]["steps"]
+    for r in range(world):
+        z = np.load(tmp_path / f"state_rank{r}.npz")
+        sl = slice(128 * r, 128 * (r + 1))
+        for k in ("x", "logpost", "weight", "n_accept"):
+            assert np.array_equal(z[k], st[k][sl]), (r, k)
+    prog = one.progress
+    assert [int(v) for v in prog["N"]] == res[0]["N"]
+    np.testing.assert_allclose(prog["Rminus1"].to_numpy(float), res[0]["Rminus1"], rtol=1e-9)
+    np.testing.assert_allclose(prog["acceptance_rate"].to_numpy(float), res[0]["acc"], rtol=1e-13)
