@@ -289,6 +289,8 @@ extern "C" hipError_t mcmc_hip_launch_whiten_directions(const mcmc::IncDirArgs* 
 extern "C" hipError_t mcmc_hip_launch_ckpt_window(const mcmc::CkptWindowArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_ckpt_payload(const mcmc::CkptPayloadArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_ckpt_solve(const mcmc::CkptSolveArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_ckpt_bounds(const mcmc::CkptBoundsArgs* a, int G, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_ckpt_bounds_reduce(const mcmc::CkptBoundsReduceArgs* a, hipStream_t st);
 // pliklite_kernels.hip
 extern "C" hipError_t mcmc_hip_launch_pl_walker(const mcmc::PlWalkerArgs* a, int accept, int propose,
                                                 hipStream_t st);
@@ -402,6 +404,12 @@ struct mcmc_hip_ctx {
         hipEvent_t ev = nullptr;
         bool begun = false, pending = false;
     } ck;
+    // R-1 of the confidence bounds (mcmc.py:918-1002): ring of ensemble snapshots [slot][d][W]
+    struct Bounds {
+        DevBuf<double> ring, bounds, payload;
+        int n_slots = 0;
+        double* pin = nullptr;     // [1 + 4 d + G d 2]
+    } bd;
     // the walker shards' communicator (comm.hip; not owned): the device checkpoint all-reduces
     // its payload over it in stream order
     mcmc_hip_comm* comm = nullptr;
@@ -1002,6 +1010,8 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
         if (sl.p) (void)hipHostFree(sl.p);
     h->ck.ring.release(); h->ck.wsum.release(); h->ck.payload.release(); h->ck.ws.release();
     h->ck.out.release(); h->ck.acc_prev.release();
+    h->bd.ring.release(); h->bd.bounds.release(); h->bd.payload.release();
+    if (h->bd.pin) (void)hipHostFree(h->bd.pin);
     if (h->ck.pin_out) (void)hipHostFree(h->ck.pin_out);
     if (h->ck.ev) (void)hipEventDestroy(h->ck.ev);
     if (h->pin_mom) (void)hipHostFree(h->pin_mom);
@@ -2391,6 +2401,114 @@ int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_
         h->T.assign(K.pin_out + 8 + nn, K.pin_out + 8 + 2 * nn);
         h->have_cov = true;
     }
+    return MCMC_HIP_OK;
+}
+
+// ---- R-1 of the confidence-interval bounds on the device ----------------------------------------
+int mcmc_hip_bounds_configure(mcmc_hip_ctx* h, int32_t n_slots)
+{
+    if (!h || n_slots < 0) return MCMC_HIP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    auto& B = h->bd;
+    const size_t d = h->d, W = h->W, G = h->G;
+    B.ring.release();
+    B.n_slots = 0;
+    if (n_slots == 0) return MCMC_HIP_OK;
+    HIP_TRY(h, B.ring.resize((size_t)n_slots * d * W));
+    HIP_TRY(h, B.bounds.resize(G * d * 2));
+    HIP_TRY(h, B.payload.resize(1 + 4 * d));
+    if (!B.pin) HIP_TRY(h, hipHostMalloc((void**)&B.pin, sizeof(double) * (1 + 4 * d + G * d * 2), hipHostMallocDefault));
+    B.n_slots = n_slots;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_bounds_snapshot(mcmc_hip_ctx* h, int32_t slot)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    auto& B = h->bd;
+    if (slot < 0 || slot >= B.n_slots) return fail(h, MCMC_HIP_ERR_ARG, "bounds slot %d of %d", slot, B.n_slots);
+    if (!h->have_state) return fail(h, MCMC_HIP_ERR_STATE, "no state");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t n = (size_t)h->d * h->W;
+    HIP_TRY(h, hipMemcpyAsync(B.ring.p + (size_t)slot * n, h->x.p, sizeof(double) * n,
+                              hipMemcpyDeviceToDevice, h->stream));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_bounds_get_slot(mcmc_hip_ctx* h, int32_t slot, double* x)
+{
+    if (!h || !x) return MCMC_HIP_ERR_ARG;
+    auto& B = h->bd;
+    if (slot < 0 || slot >= B.n_slots) return fail(h, MCMC_HIP_ERR_ARG, "bounds slot %d of %d", slot, B.n_slots);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t d = h->d, W = h->W;
+    std::vector<double> t(d * W);
+    HIP_TRY(h, hipMemcpy(t.data(), B.ring.p + (size_t)slot * d * W, sizeof(double) * d * W, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < W; ++w)
+        for (size_t i = 0; i < d; ++i) x[w * d + i] = t[i * W + w];
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_bounds_set_slot(mcmc_hip_ctx* h, int32_t slot, const double* x)
+{
+    if (!h || !x) return MCMC_HIP_ERR_ARG;
+    auto& B = h->bd;
+    if (slot < 0 || slot >= B.n_slots) return fail(h, MCMC_HIP_ERR_ARG, "bounds slot %d of %d", slot, B.n_slots);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t d = h->d, W = h->W;
+    std::vector<double> t(d * W);
+    for (size_t w = 0; w < W; ++w)
+        for (size_t i = 0; i < d; ++i) t[i * W + w] = x[w * d + i];
+    HIP_TRY(h, hipMemcpy(B.ring.p + (size_t)slot * d * W, t.data(), sizeof(double) * d * W, hipMemcpyHostToDevice));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_bounds_statistics(mcmc_hip_ctx* h, int32_t n_window, const int32_t* slots, double limfrac,
+                               double* stats, double* bounds)
+{
+    if (!h || !slots || !stats) return MCMC_HIP_ERR_ARG;
+    auto& B = h->bd;
+    if (B.n_slots == 0) return fail(h, MCMC_HIP_ERR_STATE, "bounds_configure must precede bounds_statistics");
+    if (n_window < 1 || n_window > mcmc::kBoundsMaxSlots || n_window > B.n_slots)
+        return fail(h, MCMC_HIP_ERR_ARG, "the window holds %d snapshots (at most %d)", n_window,
+                    std::min(mcmc::kBoundsMaxSlots, B.n_slots));
+    if (!(limfrac > 0.0 && limfrac < 1.0)) return fail(h, MCMC_HIP_ERR_ARG, "limfrac must lie in (0, 1)");
+    const long long n = (long long)n_window * h->gs;
+    if ((size_t)n * sizeof(double) > (size_t)mcmc::kBoundsLdsBytes)
+        return fail(h, MCMC_HIP_ERR_ARG, "%d snapshots of %d walkers do not fit the LDS of a compute unit", n_window, h->gs);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    mcmc::CkptBoundsArgs a{};
+    a.ring = B.ring.p; a.bounds = B.bounds.p; a.n_slots = n_window; a.d = h->d; a.W = h->W; a.gs = h->gs;
+    for (int s = 0; s < n_window; ++s) {
+        if (slots[s] < 0 || slots[s] >= B.n_slots) return fail(h, MCMC_HIP_ERR_ARG, "bounds slot %d of %d", slots[s], B.n_slots);
+        a.slots[s] = slots[s];
+    }
+    // GetDist's `confidence` (chains.py): index = searchsorted(cumsum(weights), target), capped at
+    // n - 1, target = norm * limfrac (lower) | norm * (1 - limfrac) (upper); unit weights:
+    // cumsum = 1, 2, ..., n, so the index is ceil(target) - 1
+    auto order = [n](double target) {
+        long long k = (long long)std::ceil(target) - 1;
+        return (int)std::min(std::max(k, 0ll), n - 1);
+    };
+    a.k_lo = order((double)n * limfrac);
+    a.k_hi = order((double)n * (1.0 - limfrac));
+    HIP_TRY(h, mcmc_hip_launch_ckpt_bounds(&a, h->G, h->stream));
+    mcmc::CkptBoundsReduceArgs r{};
+    r.bounds = B.bounds.p; r.shift = h->dshift.p; r.payload = B.payload.p; r.d = h->d; r.G = h->G;
+    HIP_TRY(h, mcmc_hip_launch_ckpt_bounds_reduce(&r, h->stream));
+    const size_t np_ = 1 + 4 * (size_t)h->d, nb = (size_t)h->G * h->d * 2;
+    if (h->comm)     // std over the chains of ALL ranks (mcmc.py:957 `mpi.gather(bound)`): one all-reduce
+        if (int rc = mcmc_comm_allreduce_on_stream(h->comm, B.payload.p, np_, 0, h->stream))
+            return fail(h, rc, "%s", mcmc_comm_error(h->comm));
+    HIP_TRY(h, hipMemcpyAsync(B.pin, B.payload.p, sizeof(double) * np_, hipMemcpyDeviceToHost, h->stream));
+    if (bounds)
+        HIP_TRY(h, hipMemcpyAsync(B.pin + np_, B.bounds.p, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::copy(B.pin, B.pin + np_, stats);
+    if (bounds) std::copy(B.pin + np_, B.pin + np_ + nb, bounds);
     return MCMC_HIP_OK;
 }
 

@@ -40,4 +40,24 @@ struct CkptSolveArgs {
     double proposal_scale;
 };
 
+// R-1 of the confidence-interval bounds (mcmc.py:918-1002): ckpt_bounds_kernel, ckpt_bounds_reduce_kernel
+constexpr int kBoundsMaxSlots = 64;          // snapshots one window may hold
+constexpr int kBoundsLdsBytes = 128 * 1024;  // the keys of one (chain, parameter) live in LDS
+
+struct CkptBoundsArgs {
+    const double* ring;            // [n_ring_slots][d][W] snapshots of the ensemble (x, dimension-major)
+    double* bounds;                // [G][d][2] lower / upper bound of every chain (= walker group)
+    int slots[kBoundsMaxSlots];    // the window's ring slots, oldest first
+    int n_slots;
+    int d, W, gs;
+    int k_lo, k_hi;                // 0-based order statistics of the n_slots * gs samples
+};
+
+struct CkptBoundsReduceArgs {
+    const double* bounds;          // [G][d][2]
+    const double* shift;           // [d] subtracted before squaring (conditioning only)
+    double* payload;               // [1 + 4 d]: chains | sum lo | sum hi | sum lo^2 | sum hi^2 (shifted)
+    int d, G;
+};
+
 }  // namespace mcmc

@@ -385,6 +385,95 @@ __global__ void __launch_bounds__(256) ckpt_solve_kernel(const CkptSolveArgs a)
 
 using namespace mcmc;
 
+namespace {
+// ---------------------------------------------------------------- R-1 of the bounds
+// mcmc.py:918-1002: per chain the lower / upper confidence bound of every parameter
+// (GetDist `MCSamples.confidence(i, limfrac, upper)` = the sample at which the cumulative weight
+// first reaches limfrac * norm, resp. (1 - limfrac) * norm; oracle/ref_numpy.py `confidence`),
+// then std over chains / sigma.  Here a chain is a walker group and its samples are the
+// ensemble snapshots of the window (weight 1 each), so a bound is an ORDER STATISTIC of
+// n = n_slots * gs values: selected exactly, without sorting, by fixing the bits of its
+// order-preserving integer key from the top -- 64 counting passes over keys held in LDS.
+// One workgroup per (chain, parameter); both bounds in the same passes.
+__device__ __forceinline__ unsigned long long order_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double key_value(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__global__ void __launch_bounds__(256) ckpt_bounds_kernel(const CkptBoundsArgs a)
+{
+    extern __shared__ unsigned long long keys[];      // [n]
+    __shared__ int cnt[2][4];
+    const int g = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
+    const int n = a.n_slots * a.gs;
+    for (int e = tid; e < n; e += 256) {
+        const int s = e / a.gs, w = e - s * a.gs;
+        keys[e] = order_key(a.ring[((size_t)a.slots[s] * a.d + i) * a.W + (size_t)g * a.gs + w]);
+    }
+    __syncthreads();
+    unsigned long long p_lo = 0, p_hi = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long c_lo = p_lo | (1ull << bit), c_hi = p_hi | (1ull << bit);
+        int n_lo = 0, n_hi = 0;
+        for (int e = tid; e < n; e += 256) {
+            const unsigned long long k = keys[e];
+            n_lo += k < c_lo;
+            n_hi += k < c_hi;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            n_lo += __shfl_down(n_lo, o);
+            n_hi += __shfl_down(n_hi, o);
+        }
+        if ((tid & 63) == 0) {
+            cnt[0][tid >> 6] = n_lo;
+            cnt[1][tid >> 6] = n_hi;
+        }
+        __syncthreads();
+        n_lo = cnt[0][0] + cnt[0][1] + cnt[0][2] + cnt[0][3];
+        n_hi = cnt[1][0] + cnt[1][1] + cnt[1][2] + cnt[1][3];
+        __syncthreads();
+        // the k-th smallest key (0-based) is >= c  iff  fewer than k + 1 keys are below c
+        if (n_lo <= a.k_lo) p_lo = c_lo;
+        if (n_hi <= a.k_hi) p_hi = c_hi;
+    }
+    if (tid == 0) {
+        double* b = a.bounds + ((size_t)g * a.d + i) * 2;
+        b[0] = key_value(p_lo);
+        b[1] = key_value(p_hi);
+    }
+}
+
+// sums over this rank's chains, ascending, from +0 (what the all-reduce carries; the statistic
+// is formed from the reduced sums: std over ALL chains, mcmc.py:977)
+__global__ void __launch_bounds__(128) ckpt_bounds_reduce_kernel(const CkptBoundsReduceArgs a)
+{
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i == 0) a.payload[0] = (double)a.G;
+    if (i >= a.d) return;
+    const double sh = a.shift[i];
+    double s_lo = 0.0, s_hi = 0.0, q_lo = 0.0, q_hi = 0.0;
+    for (int g = 0; g < a.G; ++g) {
+        const double lo = a.bounds[((size_t)g * a.d + i) * 2] - sh;
+        const double hi = a.bounds[((size_t)g * a.d + i) * 2 + 1] - sh;
+        s_lo = s_lo + lo;
+        s_hi = s_hi + hi;
+        q_lo = q_lo + lo * lo;
+        q_hi = q_hi + hi * hi;
+    }
+    a.payload[1 + i] = s_lo;
+    a.payload[1 + a.d + i] = s_hi;
+    a.payload[1 + 2 * a.d + i] = q_lo;
+    a.payload[1 + 3 * a.d + i] = q_hi;
+}
+}  // namespace
+
 extern "C" hipError_t mcmc_hip_launch_ckpt_window(const CkptWindowArgs* a, hipStream_t st)
 {
     hipLaunchKernelGGL(ckpt_window_kernel, dim3((unsigned)((a->n_elem + 255) / 256)), dim3(256), 0, st, *a);
@@ -411,5 +500,26 @@ extern "C" hipError_t mcmc_hip_launch_ckpt_solve(const CkptSolveArgs* a, hipStre
     } else {
         hipLaunchKernelGGL(ckpt_solve_kernel<false>, dim3(1), dim3(256), 0, st, *a);
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_ckpt_bounds(const mcmc::CkptBoundsArgs* a, int G, hipStream_t st)
+{
+    using namespace mcmc;
+    const size_t lds = sizeof(unsigned long long) * (size_t)a->n_slots * a->gs;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ckpt_bounds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kBoundsLdsBytes);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    ckpt_bounds_kernel<<<dim3(G, a->d), 256, lds, st>>>(*a);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_ckpt_bounds_reduce(const mcmc::CkptBoundsReduceArgs* a, hipStream_t st)
+{
+    ckpt_bounds_reduce_kernel<<<(a->d + 127) / 128, 128, 0, st>>>(*a);
     return hipGetLastError();
 }

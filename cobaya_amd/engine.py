@@ -111,6 +111,12 @@ SYMBOLS = [
     ("mcmc_hip_get_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_set_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
+    ("mcmc_hip_bounds_configure", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_bounds_snapshot", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_bounds_statistics", C.c_int, [_H, C.c_int32, c_int32_p, C.c_double, c_double_p,
+                                            c_double_p]),
+    ("mcmc_hip_bounds_get_slot", C.c_int, [_H, C.c_int32, c_double_p]),
+    ("mcmc_hip_bounds_set_slot", C.c_int, [_H, C.c_int32, c_double_p]),
     ("mcmc_hip_comm_version", C.c_char_p, []),
     ("mcmc_hip_comm_last_error", C.c_char_p, [_H]),
     ("mcmc_hip_comm_unique_id", C.c_int, [C.POINTER(C.c_uint8)]),
@@ -595,6 +601,37 @@ class Engine:
         return {"Rminus1_groups": st[0], "status": int(st[1]), "refreshed": bool(st[2]),
                 "n_chains": st[3], "sum_N": st[4], "d_accepted": st[5], "d_steps": st[6],
                 "accepted": st[7], "mean_of_covs": cov}
+
+    # -- R-1 of the confidence bounds on the device
+    BOUNDS_MAX_SLOTS = 64
+
+    def bounds_configure(self, n_slots):
+        """Ring of `n_slots` ensemble snapshots [slot][d][W] on the device (0 frees it)."""
+        self._check(self._lib.mcmc_hip_bounds_configure(self._h, int(n_slots)))
+
+    def bounds_snapshot(self, slot):
+        """The current points -> ring slot, in stream order."""
+        self._check(self._lib.mcmc_hip_bounds_snapshot(self._h, int(slot)))
+
+    def bounds_statistics(self, slots, limfrac, want_bounds=False):
+        """Per chain and parameter the lower / upper bound GetDist's `confidence(i, limfrac,
+        upper)` gives for the samples in `slots`; returns the [1 + 4 d] sums over the chains of
+        all ranks the statistic is formed from (and this rank's bounds [G][d][2] on request)."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        stats = np.empty(1 + 4 * self.d)
+        b = np.empty((self.G, self.d, 2)) if want_bounds else None
+        self._check(self._lib.mcmc_hip_bounds_statistics(
+            self._h, len(sl), _ip(sl), float(limfrac), _dp(stats), _dp(b) if want_bounds else None))
+        return (stats, b) if want_bounds else stats
+
+    def bounds_get_slot(self, slot):
+        x = np.empty((self.W, self.d))
+        self._check(self._lib.mcmc_hip_bounds_get_slot(self._h, int(slot), _dp(x)))
+        return x
+
+    def bounds_set_slot(self, slot, x):
+        x = _f64(x, (self.W, self.d))
+        self._check(self._lib.mcmc_hip_bounds_set_slot(self._h, int(slot), _dp(x)))
 
     def stream_handle(self):
         return int(self._lib.mcmc_hip_stream_handle(self._h))

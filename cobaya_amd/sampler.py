@@ -14,8 +14,9 @@ by design:
     all-reduce per checkpoint (RCCL over xGMI) instead of gather/bcast of means and covs
     (mcmc.py:791-793, 914, 1005, 1021);
   * `max_samples` counts accepted steps over ALL walkers; the R-1 of confidence-interval
-    bounds (mcmc.py:918-1002) is restated with weighted quantiles of the stored samples in
-    place of GetDist's `confidence` (absent here; parity unpinned for that number).
+    bounds (mcmc.py:918-1002) is formed on the device from a ring of ensemble snapshots
+    (`bounds_snapshots`), with GetDist's `confidence` restated as exact order statistics
+    (GetDist is absent here; parity unpinned for that number).
 
 There is no CPU fallback: constructing the sampler without a usable gfx950 device raises.
 """
@@ -84,6 +85,11 @@ HIP_DEFAULTS = {
                               # device's single-workgroup linear algebra sits ON the critical
                               # path, the host's beside it).  None (default): True for several
                               # processes joined by the library's RCCL communicator, else False
+    "bounds_snapshots": 16,   # R-1 of the confidence bounds (mcmc.py:918-1002) on the device: ring of
+                              # this many ensemble snapshots (d * n_walkers doubles each, a thinned
+                              # record of the later half of the run) the per-chain bounds are
+                              # selected from -- in every emit mode; at most 16384 / group_size.
+                              # 0: no ring, convergence is judged on the means only
     "row_buffer_bytes": 1 << 32,  # emit: chains -- device buffer of accepted rows between two
                               # drains (bounds steps_per_launch: every step may accept)
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
@@ -338,6 +344,7 @@ class EnsembleMCMC:
         self._last_state_dump = 0.0
         if self._is_resuming() and self.output and os.path.exists(self._state_file()):
             self._init_bookkeeping()
+            self._init_bounds_ring()
             self._load_checkpoint()
             self._init_device_checkpoint()
             return
@@ -368,7 +375,39 @@ class EnsembleMCMC:
         self._shift = shift[:d] / shift[d]
         self.engine.set_moment_shift(self._shift)
         self._init_bookkeeping()
+        self._init_bounds_ring()
         self._init_device_checkpoint()
+
+    def _init_bounds_ring(self):
+        """`bounds_snapshots` ensemble snapshots on the device (mcmc_hip_bounds_configure)."""
+        n = int(self.bounds_snapshots or 0)
+        if n < 0:
+            self._fail("bounds_snapshots must be >= 0, got %r", self.bounds_snapshots)
+        if n and hasattr(self.engine, "bounds_configure"):
+            n = min(n, getattr(self.engine, "BOUNDS_MAX_SLOTS", 64), 16384 // int(self.group_size))
+            self.engine.bounds_configure(n)
+            self._bslots = [-1] * n
+
+    def _bounds_take(self):
+        """Called with every moment snapshot (index i): the ring keeps every `stride`-th one of
+        the later half of the run -- the window of mcmc.py:787-790, `use_first = n / 2`.  A slot
+        is free once its snapshot has left that window; when none is, the record is thinned
+        (stride doubled, every other kept snapshot dropped)."""
+        i = self._bsnap_idx
+        self._bsnap_idx += 1
+        if not self._bslots or i % self._bstride:
+            return
+        start = (i + 1) / 2.0
+        free = [k for k, j in enumerate(self._bslots) if j < start]
+        if not free:
+            self._bstride *= 2
+            self._bslots = [j if j % self._bstride == 0 else -1 for j in self._bslots]
+            if i % self._bstride:
+                return
+            free = [k for k, j in enumerate(self._bslots) if j < 0]
+        k = min(free, key=lambda k_: self._bslots[k_])
+        self._bslots[k] = i
+        self.engine.bounds_snapshot(k)
 
     def _init_device_checkpoint(self):
         """`device_checkpoint: True`: R-1 and the proposal refresh on the device (an option, not the
@@ -488,6 +527,9 @@ class EnsembleMCMC:
         self._ckpt_on_device = False   # the pending checkpoint was solved on the device
         self._snaps_in_interval = 0    # moment snapshots since the last checkpoint request
         self._ckpt_steps_last = 0      # steps per walker at the last request
+        # the device ring behind R-1 of the bounds: slot -> index of the moment snapshot it holds
+        # (-1: free), the stride of the thinned record, moment snapshots taken so far
+        self._bslots, self._bstride, self._bsnap_idx = [], 1, 0
 
     # ------------------------------------------------------------------ a17
     def initial_proposal_covmat(self):
@@ -631,6 +673,7 @@ class EnsembleMCMC:
         if self._launches % max(1, int(self.moments_every)) == 0:
             eng.accumulate_moments()
             self._snaps_in_interval += 1
+            self._bounds_take()
         snap_every = int(self.snapshot_every) if self.snapshot_every else None
         if self.emit == "chains":
             if hasattr(eng, "drain_samples_view"):
@@ -722,6 +765,8 @@ class EnsembleMCMC:
     def _state_file(self):
         return self._chain_file("state.npz")
 
+    BOUNDS_RING_SAVE_BYTES = 1 << 26   # snapshots of the bounds ring kept in the state file
+
     # the options whose change re-opens a converged run (mcmc.py:1080-1088)
     CONVERGE_OPTIONS = ("Rminus1_stop", "Rminus1_cl_stop", "Rminus1_cl_level", "max_samples")
 
@@ -760,6 +805,14 @@ class EnsembleMCMC:
             acc_n, acc_gs, acc_S = self.engine.read_moments(reset=False)
             st.update(acc_n=np.int64(acc_n), acc_gs=acc_gs, acc_S=acc_S)
             ivs = self._intervals
+            # the bounds ring: its books always, its snapshots while they are small (a resumed run
+            # then forms the same Rminus1_cl; a large ring restarts empty)
+            held = [k for k, j in enumerate(self._bslots) if j >= 0]
+            ring_bytes = 8 * len(held) * int(self.n_walkers) * self.spec.d
+            if held and ring_bytes <= self.BOUNDS_RING_SAVE_BYTES:
+                st["bring"] = np.array([self.engine.bounds_get_slot(k) for k in held])
+            st["bslots"] = np.array(self._bslots, dtype=np.int64)
+            st["bbook"] = np.array([self._bstride, self._bsnap_idx], dtype=np.int64)
             tmp = self._state_file() + ".tmp.npz"
             np.savez(tmp, **st,
                      proposal_cov=self.engine.get_proposal_cov(), shift=self._shift,
@@ -797,6 +850,17 @@ class EnsembleMCMC:
         if "acc_n" in z:   # snapshots accumulated on the device since the last read-out
             self.engine.set_moments(int(z["acc_n"]), z["acc_gs"], z["acc_S"])
             self._snaps_in_interval = int(z["acc_n"])   # (snapshots since the last request)
+        if "bbook" in z and self._bslots:
+            self._bstride, self._bsnap_idx = (int(v) for v in z["bbook"])
+            saved = [int(j) for j in z["bslots"]]
+            held = [k for k, j in enumerate(saved) if j >= 0]
+            if "bring" in z and len(saved) == len(self._bslots):
+                self._bslots = saved
+                for k, x in zip(held, z["bring"]):
+                    self.engine.bounds_set_slot(k, x)
+            elif held:
+                self.log.info("The snapshots behind R-1 of the bounds were not kept in the state "
+                              "file (too large, or bounds_snapshots changed): that ring restarts empty.")
         self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]
         (self.n_steps_raw, self.i_learn, self._acc_last, self._steps_last, self._launches,
          self._dropped_snapshots, self._accepted_total) = (int(v) for v in book[:7])
@@ -1042,11 +1106,14 @@ class EnsembleMCMC:
                       self._accepted_total)
         # means criterion twice in a row (mcmc.py:908), then the bounds criterion (918-1002)
         if max(Rminus1, self.Rminus1_last) < self.Rminus1_stop:
-            Rcl = self._rminus1_of_bounds(mean_of_covs)
-            if Rcl is None:
-                self.log.info("Computation of the bounds was not possible (no stored samples): "
-                         "convergence judged on the means only.")
+            Rcl = self._rminus1_of_bounds(mean_of_covs) if self._bslots else None
+            if Rcl is None and not self._bslots:
+                self.log.info("bounds_snapshots: 0 -- no bounds criterion: convergence judged on "
+                              "the means only.")
                 self.converged = True
+            elif Rcl is None:     # mcmc.py:996-1001
+                self.log.info("Computation of the bounds was not possible. Waiting until the "
+                              "next converge check.")
             else:
                 row["Rminus1_cl"] = float(Rcl)
                 self.log.info(" - Convergence of bounds: R-1 = %f after %d accepted steps", Rcl,
@@ -1078,45 +1145,25 @@ class EnsembleMCMC:
                     self.log.debug("Updating covariance matrix failed unexpectedly. waiting until "
                               "next covmat learning attempt.")
 
-    def _rminus1_of_bounds(self, mean_of_covs, min_per_chain=40):
-        """R-1 of the confidence-interval bounds (mcmc.py:918-1002): per chain (= walker group)
-        the lower/upper `Rminus1_cl_level` bounds of every parameter, from the stored rows of
-        the later half of the run; statistic = max_i std_chains(bound_i) / sigma_i.  The
-        reference takes the bounds from GetDist's `MCSamples.confidence` (absent here): they
-        are restated as weighted quantiles of the chain's samples -- PARITY UNPINNED for this
-        number.  Returns None when no samples are stored."""
+    def _rminus1_of_bounds(self, mean_of_covs):
+        """R-1 of the confidence-interval bounds (mcmc.py:918-1002) ON THE DEVICE, in every emit
+        mode: per chain (= walker group) the lower / upper bound of every parameter as GetDist's
+        `confidence(i, limfrac=Rminus1_cl_level / 2, upper=which)` gives them (mcmc.py:927-929) for
+        the chain's samples in the window's ring snapshots -- exact order statistics, selected
+        in LDS (`ckpt_bounds_kernel`) --, summed over the chains of all ranks (one all-reduce,
+        in stream order with the library's communicator; mcmc.py:957 gathers the bounds
+        instead), then statistic = max_i std_chains(bound_i) / sigma_i (mcmc.py:977-979).
+        GetDist is absent from the build container: PARITY UNPINNED for this number (the
+        oracle restates its published `confidence`, oracle/ref_numpy.py).  Returns None when the
+        ring holds no snapshot of the window."""
         d, eng = self.spec.d, self.engine
-        rows = [r for r in self._rows if len(r)]
-        n_rows = sum(len(r) for r in rows)
-        stats = np.zeros(1 + 4 * d)  # n_chains, sum b_lo, sum b_hi, sum b_lo^2, sum b_hi^2
-        if n_rows:
-            keep, acc = [], 0
-            for r in reversed(rows):          # later half, whole blocks
-                keep.append(r)
-                acc += len(r)
-                if acc >= n_rows / 2:
-                    break
-            data = np.vstack(keep)
-            grp = ((data[:, 0].astype(np.int64) - self.rank * eng.W) // eng.group_size)
-            q = (1 - self.Rminus1_cl_level) / 2.0
-            order = np.argsort(grp, kind="stable")
-            data, grp = data[order], grp[order]
-            starts = np.flatnonzero(np.diff(np.concatenate(([-1], grp)))).tolist() + [len(grp)]
-            for a_, b_ in zip(starts[:-1], starts[1:]):
-                if b_ - a_ < min_per_chain:
-                    continue
-                w, x = data[a_:b_, 1], data[a_:b_, 5:5 + d]
-                lo, hi = np.empty(d), np.empty(d)
-                for i in range(d):
-                    o = np.argsort(x[:, i])
-                    cw = (np.cumsum(w[o]) - 0.5 * w[o]) / w.sum()
-                    lo[i], hi[i] = np.interp([q, 1 - q], cw, x[o, i])
-                stats[0] += 1
-                stats[1:1 + d] += lo
-                stats[1 + d:1 + 2 * d] += hi
-                stats[1 + 2 * d:1 + 3 * d] += lo ** 2
-                stats[1 + 3 * d:] += hi ** 2
-        dist.all_reduce_sum(stats)
+        start = self._bsnap_idx / 2.0
+        window = sorted((j, k) for k, j in enumerate(self._bslots) if j >= start)
+        if not window:
+            return None
+        stats = eng.bounds_statistics([k for _, k in window], self.Rminus1_cl_level / 2.0)
+        if self.size > 1 and not getattr(eng, "comm_attached", False):
+            dist.all_reduce_sum(stats)     # (the gloo stand-in; RCCL: reduced in stream order)
         m = stats[0]
         if m < 2:
             return None
@@ -1125,9 +1172,8 @@ class EnsembleMCMC:
         var_hi = np.maximum(stats[1 + 3 * d:] / m - mean_hi ** 2, 0.0)
         sig = np.sqrt(np.diag(mean_of_covs))
         # NOT rescaled per walker (unlike R-1 of the means, which certifies the mixing): this
-        # one is a precision test of the stored sample's tails, and the unit whose bounds must
-        # agree is the group -- the stored sample cannot hold hundreds of snapshots of 65 536
-        # walkers just to resolve single-walker tails
+        # one is a precision test of the sample's quantiles, and the unit whose bounds must
+        # agree is the group
         return float(max(np.max(np.sqrt(var_lo) / sig), np.max(np.sqrt(var_hi) / sig)))
 
     # ------------------------------------------------------------------ products

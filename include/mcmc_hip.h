@@ -275,6 +275,26 @@ MCMC_HIP_API int mcmc_hip_checkpoint_begin(mcmc_hip_ctx* h, int32_t n_window_int
                               double steps_since, uint64_t* payload_device_ptr, int32_t* payload_len);
 MCMC_HIP_API int mcmc_hip_checkpoint_solve(mcmc_hip_ctx* h, double learn_lo, double learn_hi);
 MCMC_HIP_API int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_covs);
+/* R-1 of the confidence-interval bounds ON THE DEVICE (mcmc.py:918-1002), in every emit mode: a ring
+ * of n_slots ensemble snapshots [slot][d][n_walkers] (bounds_configure; 0 frees it);
+ * bounds_snapshot(slot) copies the current points into a slot in stream order (the caller decides
+ * which: a thinned record of the later half of the run, sampler.py `_bounds_take`);
+ * bounds_statistics forms, per chain (= walker group) and parameter, the lower and the upper
+ * bound as GetDist's `MCSamples.confidence(i, limfrac, upper)` does (mcmc.py:927-929: the sample
+ * at which the cumulative weight first reaches limfrac * norm, resp. (1 - limfrac) * norm) from
+ * the chain's samples in the n_window listed slots (unit weights: exact order statistics,
+ * selected in LDS) and returns stats[1 + 4 d] = {chains, sum_c lo_i, sum_c hi_i, sum_c lo_i^2,
+ * sum_c hi_i^2} with the moment shift (mcmc_hip_set_moment_shift) subtracted from the bounds --
+ * summed over the chains of ALL ranks when a communicator is attached (mcmc.py:957
+ * `mpi.gather(bound)`); np.std(bounds, axis=0) of mcmc.py:977 follows from them.  `bounds`
+ * (may be NULL) receives this rank's [G][d][2].  Synchronous.  n_window * group_size <= 16384.
+ * get_slot / set_slot: a slot as x[n_walkers][d] (checkpoint / resume). */
+MCMC_HIP_API int mcmc_hip_bounds_configure(mcmc_hip_ctx* h, int32_t n_slots);
+MCMC_HIP_API int mcmc_hip_bounds_snapshot(mcmc_hip_ctx* h, int32_t slot);
+MCMC_HIP_API int mcmc_hip_bounds_statistics(mcmc_hip_ctx* h, int32_t n_window, const int32_t* slots, double limfrac,
+                               double* stats, double* bounds);
+MCMC_HIP_API int mcmc_hip_bounds_get_slot(mcmc_hip_ctx* h, int32_t slot, double* x);
+MCMC_HIP_API int mcmc_hip_bounds_set_slot(mcmc_hip_ctx* h, int32_t slot, const double* x);
 /* the engine's HIP stream (a hipStream_t as an integer), for callers that queue their own work
  * -- the all-reduce of a multi-process checkpoint -- in order with the engine's */
 MCMC_HIP_API uint64_t mcmc_hip_stream_handle(const mcmc_hip_ctx* h);

@@ -35,7 +35,9 @@ def run_checkpoints(use_group, device_checkpoint=False):
     out = {"collective": dist.describe(), "progress": s.progress[["N", "acceptance_rate",
                                                                   "Rminus1"]].to_numpy().tolist(),
            "proposal_cov": s.proposer.get_covariance().tolist(),
-           "x_sum": float(s.engine.get_state()["x"].sum())}
+           "x_sum": float(s.engine.get_state()["x"].sum()),
+           # R-1 of the bounds: its sums cross the communicator in stream order as well
+           "Rminus1_cl": s._rminus1_of_bounds(s.proposer.get_covariance())}
     buf = np.arange(12, dtype=float).reshape(3, 4)
     out["allreduce_identity"] = bool(np.array_equal(dist.all_reduce_sum(buf.copy()), buf))
     s.close()

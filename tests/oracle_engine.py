@@ -237,6 +237,32 @@ class OracleEngine:
         out.flags.writeable = False
         return out
 
+    # -- R-1 of the confidence bounds (the engine's mcmc_hip_bounds_*) ---------------------------
+    BOUNDS_MAX_SLOTS = 64
+
+    def bounds_configure(self, n_slots):
+        self._bring = [None] * int(n_slots)
+
+    def bounds_snapshot(self, slot):
+        self._bring[int(slot)] = self._state.x.copy()
+
+    def bounds_get_slot(self, slot):
+        return self._bring[int(slot)].copy()
+
+    def bounds_set_slot(self, slot, x):
+        self._bring[int(slot)] = np.array(x, float)
+
+    def bounds_statistics(self, slots, limfrac, want_bounds=False):
+        """oracle/ref_numpy.py: `confidence` per chain (= group: its walkers in every listed
+        snapshot, unit weights) and parameter, then the sums the all-reduce carries."""
+        from oracle import ref_numpy as R
+        gs = self.group_size
+        chains = [np.vstack([self._bring[int(s)][g * gs:(g + 1) * gs] for s in slots])
+                  for g in range(self.G)]
+        b = R.bounds_of_chains(chains, [np.ones(len(c)) for c in chains], 2.0 * limfrac)
+        stats = R.bounds_payload(b, self._shift)
+        return (stats, b) if want_bounds else stats
+
     # -- moments ------------------------------------------------------------------------
     def set_moment_shift(self, shift):
         self._shift = np.array(shift, float)

@@ -598,6 +598,7 @@ def test_rccl_path_with_one_rank():
     assert res["nccl"]["progress"] == res["none"]["progress"]
     assert res["nccl"]["proposal_cov"] == res["none"]["proposal_cov"]
     assert res["nccl"]["x_sum"] == res["none"]["x_sum"]
+    assert 0 < res["nccl"]["Rminus1_cl"] == res["none"]["Rminus1_cl"] < 1
 
 
 def test_device_checkpoint_through_the_sampler_and_rccl():

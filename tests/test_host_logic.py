@@ -278,44 +278,110 @@ print("RESOLVED")
     assert out.returncode == 0 and "RESOLVED" in out.stdout, out.stdout + out.stderr
 
 
+def test_getdist_confidence_restated():
+    """oracle/ref_numpy.py `confidence` = GetDist's published `WeightedSamples.confidence`: the
+    sample at which the cumulative weight first reaches the target, no interpolation (PARITY
+    UNPINNED: GetDist is absent).  Hand-checked cases."""
+    from oracle import ref_numpy as R
+    x = np.array([5.0, 1.0, 3.0, 2.0, 4.0])
+    w = np.ones(5)
+    # cumsum over the sorted samples 1..5 = 1, 2, 3, 4, 5; norm 5
+    assert R.confidence(x, w, 0.2) == 1.0             # target 1.0 -> index 0
+    assert R.confidence(x, w, 0.21) == 2.0            # target 1.05 -> first cumsum >= 1.05 is 2
+    assert R.confidence(x, w, 0.2, upper=True) == 4.0     # target 4.0 -> index 3
+    assert R.confidence(x, w, 0.19, upper=True) == 5.0    # target 4.05 -> index 4
+    assert R.confidence(x, w, 1e-9, upper=True) == 5.0    # capped at n - 1
+    w = np.array([1.0, 4.0, 1.0, 2.0, 2.0])           # of the samples 5, 1, 3, 2, 4
+    # sorted samples 1, 2, 3, 4, 5 carry 4, 2, 1, 2, 1: cumsum 4, 6, 7, 9, 10
+    assert R.confidence(x, w, 0.4) == 1.0 and R.confidence(x, w, 0.45) == 2.0
+    assert R.confidence(x, w, 0.3, upper=True) == 3.0 and R.confidence(x, w, 0.25, upper=True) == 4.0
+    # unit weights: the index is ceil(target) - 1 -- what the device kernel selects
+    rng = np.random.default_rng(3)
+    for n in (64, 192, 1000, 4096):
+        v = rng.normal(size=n)
+        sv = np.sort(v)
+        for lim in (0.475, 0.025, 0.3333, 0.5):
+            k_lo = min(max(int(np.ceil(n * lim)) - 1, 0), n - 1)
+            k_hi = min(max(int(np.ceil(n * (1 - lim))) - 1, 0), n - 1)
+            assert R.confidence(v, np.ones(n), lim) == sv[k_lo]
+            assert R.confidence(v, np.ones(n), lim, upper=True) == sv[k_hi]
+
+
 def test_rminus1_of_bounds_statistic():
-    """mcmc.py:918-1002 restated with weighted quantiles: for chains that sample the same
-    N(0,1), std over chains of the 2.5 % bound ~ sqrt(q(1-q)/n)/pdf(z_q); identical chains give
-    0; shifted chains are flagged."""
+    """mcmc.py:918-1002 through the sampler: the statistic formed from the reduced sums of the
+    (shifted) bounds equals np.std(bounds, axis=0).T / sigma of the reference arithmetic; for
+    chains that sample the same N(0,1) it is ~ sqrt(q(1-q)/n)/pdf(z_q) at q = 0.475; identical
+    chains give 0; a shifted chain is flagged; an empty ring gives None."""
+    from oracle import ref_numpy as R
+    from tests.oracle_engine import OracleEngine
     d = 3
     spec = ProblemSpec.from_info({"likelihood": {"one": None},
                                   "params": {f"p{i}": {"prior": [-10, 10]} for i in range(d)}})
     s = bare_sampler(spec)
     s.rank, s.size = 0, 1
+    s.Rminus1_cl_level = 0.95
 
     class Eng:
-        W, group_size, G = 1024, 64, 16
+        W, group_size, G, d = 1024, 64, 16, 3
+        _shift = np.full(3, 0.1)
+        bounds_statistics = OracleEngine.bounds_statistics
 
-    s.engine = Eng()
+    s.engine = eng = Eng()
     rng = np.random.default_rng(0)
 
-    def blocks(shift_group0=0.0, n_snap=40):
-        out = []
+    def fill(shift_group0=0.0, n_snap=40, same=False):
+        ring = []
         for _ in range(n_snap):
             x = rng.normal(size=(1024, d))
+            if same:
+                x = np.tile(x[:64], (16, 1))
             x[:64] += shift_group0
-            out.append(np.column_stack((np.arange(1024), np.ones(1024), np.zeros((1024, 3)), x)))
-        return out
+            ring.append(x)
+        eng._bring = ring
+        s._bslots, s._bsnap_idx = list(range(n_snap)), n_snap
 
-    s._rows = blocks()
-    R = s._rminus1_of_bounds(np.eye(d))
+    fill()
+    got = s._rminus1_of_bounds(np.eye(d))
+    chains = [np.vstack([eng._bring[k][g * 64:(g + 1) * 64] for k in range(20, 40)]) for g in range(16)]
+    b = R.bounds_of_chains(chains, [np.ones(len(c)) for c in chains], 0.95)
+    assert abs(got - R.rminus1_of_bounds(b, np.eye(d))) < 1e-12
+    assert abs(got - R.rminus1_of_bounds_from_payload(R.bounds_payload(b, eng._shift), np.eye(d))) < 1e-15
     n = 20 * 64  # later half of 40 snapshots, 64 walkers per chain
-    expect = np.sqrt(0.025 * 0.975 / n) / 0.0584
-    assert 0.5 * expect < R < 2.5 * expect and R < 0.2
-    s._rows = blocks(shift_group0=3.0)
+    expect = np.sqrt(0.475 * 0.525 / n) / 0.3982
+    assert 0.5 * expect < got < 2.5 * expect and got < 0.2
+    fill(shift_group0=3.0)
     assert s._rminus1_of_bounds(np.eye(d)) > 0.5
-    one = blocks(n_snap=2)[0]
-    s._rows = [one, one.copy()]
-    s.engine.group_size, s.engine.G = 512, 2   # two identical chains
-    s._rows = [np.vstack((one[:512], np.column_stack((one[:512, :1] + 512, one[:512, 1:]))))]
-    assert s._rminus1_of_bounds(np.eye(d)) == 0.0
-    s._rows = []
+    fill(same=True)
+    assert s._rminus1_of_bounds(np.eye(d)) < 1e-7    # (sqrt of the rounding of E b^2 - (E b)^2)
+    s._bslots = [-1] * 8
     assert s._rminus1_of_bounds(np.eye(d)) is None
+
+
+@pytest.mark.parametrize("C", [4, 16])
+def test_bounds_ring_follows_the_later_half_of_the_run(C):
+    """`_bounds_take`: at any time the ring holds only snapshots of the window (index >= n / 2),
+    all multiples of the current stride, no index twice -- and, once the run is long enough,
+    at least C / 4 of them, spread over the whole window."""
+    spec = ProblemSpec.from_info({"likelihood": {"one": None}, "params": {"p": {"prior": [-1, 1]}}})
+    s = bare_sampler(spec)
+    taken = []
+
+    class Eng:
+        def bounds_snapshot(self, k):
+            taken.append(k)
+
+    s.engine = Eng()
+    s._bslots, s._bstride, s._bsnap_idx = [-1] * C, 1, 0
+    for n in range(1, 2000):
+        s._bounds_take()
+        assert s._bsnap_idx == n
+        held = sorted(j for j in s._bslots if j >= n / 2.0)
+        assert len(set(held)) == len(held) and all(j % s._bstride == 0 for j in held)
+        assert all(j < n for j in s._bslots)
+        if n >= 8 * C:
+            assert len(held) >= C // 4, (n, s._bslots, s._bstride)
+            assert held[0] < n / 2.0 + 2.5 * s._bstride and held[-1] >= n - 2 * s._bstride
+    assert all(0 <= k < C for k in taken)
 
 
 # ----------------------------------------------------------------------------- (f)1 blocking

