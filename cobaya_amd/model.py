@@ -354,10 +354,14 @@ class ProblemSpec:
 
     @staticmethod
     def _pliklite_component(lname, linfo, sampled, derived, speed):
-        """`planck_pliklite` (base_classes/planck_pliklite.py): `dataset` = the contents of the
-        .dataset file and its companions (a `pliklite.PlikLiteDataset`, a dict of its fields, a
-        path to an .npz of them, or `{synthetic: seed}` for the plik-lite-shaped stand-in -- the
-        Planck data cannot be downloaded here), the options of planck_pliklite.py:33-43
+        """`planck_pliklite` (base_classes/planck_pliklite.py).  The data: `dataset_file`
+        (+ `path`) = the .dataset file of the installed likelihood, read with the files it names
+        as the reference does (planck_pliklite.py:44-73, `pliklite.PlikLiteDataset.from_files`:
+        text tables, the Fortran-binary covariance), with `dataset_params` overriding its keys;
+        or `dataset` = the same contents handed over directly (a `pliklite.PlikLiteDataset`, a
+        dict of its fields, a path to an .npz of them, or `{synthetic: seed}` for the
+        plik-lite-shaped stand-in -- the Planck zip cannot be downloaded in the build
+        container).  Then the options of planck_pliklite.py:33-43
         (`use_cl`, `use_bins`, `bins_for_L_range`, `calibration_param`), and `cl_emulator` = the
         linear stand-in for the theory code (`provider.get_Cl`, planck_pliklite.py:170-178): a
         `pliklite.LinearClEmulator`, a dict / .npz of its fields, or `{synthetic: n}`; its
@@ -373,24 +377,50 @@ class ProblemSpec:
                 raise UnsupportedModel(f"likelihood '{lname}': cannot interpret `{what}`")
             return dict(obj)
 
+        # `dataset_params` override the keys of the .dataset file (DataSetLikelihood.py:64,
+        # e.g. TT_lite_native.yaml's `use_cl: tt`); the same names given directly as options of
+        # the likelihood win over both
+        overrides = dict(linfo.pop("dataset_params", None) or {})
+        for k in ("use_cl", "use_bins", "bins_for_L_range", "calibration_param"):
+            if linfo.get(k) is not None:
+                overrides[k] = linfo[k]
+            linfo.pop(k, None)
         ds = linfo.pop("dataset", None)
+        dataset_file, path = linfo.pop("dataset_file", None), linfo.pop("path", None)
+        if ds is None and dataset_file:
+            # the real data: plik_lite_v22.dataset and the files it names (planck_pliklite.py:44-73;
+            # DataSetLikelihood.py:28-57: `dataset_file` absolute, or relative to `path`)
+            import os
+            full = dataset_file if os.path.isabs(dataset_file) else os.path.join(path or ".", dataset_file)
+            try:
+                ds = P.PlikLiteDataset.from_files(full, overrides)
+            except (OSError, ValueError, KeyError) as e:
+                raise UnsupportedModel(
+                    f"likelihood '{lname}': the data set '{full}' could not be read ({e}); "
+                    "install planck_2018_pliklite_native and set `path`") from e
         if ds is None:
             raise UnsupportedModel(
-                f"likelihood '{lname}': `dataset` is required (the Planck data files are not "
-                "available to mcmc_hip; pass the arrays, or {synthetic: seed})")
+                f"likelihood '{lname}': give `dataset_file` (+ `path`: the folder of "
+                "plik_lite_v22.dataset), or `dataset`: the arrays / {synthetic: seed}")
         if not isinstance(ds, P.PlikLiteDataset):
             ds = load(ds, "dataset")
             ds = (P.synthetic_dataset(int(ds["synthetic"])) if "synthetic" in ds
                   else P.PlikLiteDataset(**{k: (int(v) if np.ndim(v) == 0 else np.asarray(v))
                                             for k, v in ds.items()}))
-        use_cl = linfo.pop("use_cl", None) or (linfo.pop("dataset_params", None) or {}).get(
-            "use_cl", "tt te ee")
-        use_cl = use_cl.split() if isinstance(use_cl, str) else list(use_cl)
-        calib = str(linfo.pop("calibration_param", "A_planck"))
+        opts = {**{"use_cl": "tt te ee", "use_bins": (), "bins_for_L_range": (),
+                   "calibration_param": "A_planck"},
+                **{k: v for k, v in ds.options.items() if v not in (None, "", [], ())}, **overrides}
+
+        def as_ints(v):
+            return [int(x) for x in (v.split() if isinstance(v, str) else (v or ()))]
+
+        use_cl = opts["use_cl"]
+        use_cl = use_cl.lower().split() if isinstance(use_cl, str) else [str(c).lower() for c in use_cl]
+        calib = str(opts["calibration_param"])
         try:
             target = P.BinnedGaussian.from_dataset(
-                ds, use_cl=use_cl, use_bins=linfo.pop("use_bins", ()) or (),
-                bins_for_L_range=linfo.pop("bins_for_L_range", ()) or (), calibration_param=calib)
+                ds, use_cl=use_cl, use_bins=as_ints(opts["use_bins"]),
+                bins_for_L_range=as_ints(opts["bins_for_L_range"]), calibration_param=calib)
         except ValueError as e:
             raise UnsupportedModel(f"likelihood '{lname}': {e}") from e
         if calib not in sampled:
@@ -406,8 +436,7 @@ class ProblemSpec:
             emu = (P.synthetic_emulator(int(emu["synthetic"]), target.lmax) if "synthetic" in emu
                    else P.LinearClEmulator(np.asarray(emu["theta0"], float), np.asarray(emu["D0"], float),
                                            np.asarray(emu["J"], float), list(emu.get("names", []))))
-        for k in ("path", "dataset_file", "aliases"):
-            linfo.pop(k, None)
+        linfo.pop("aliases", None)
         if linfo:
             raise UnsupportedModel(f"unknown options for likelihood '{lname}': {sorted(linfo)}")
         if derived:

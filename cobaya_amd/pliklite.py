@@ -21,12 +21,69 @@ CL_NAMES = ("tt", "te", "ee")   # planck_pliklite.py:17 (the order of the bins i
 # ------------------------------------------------------------------------------------------
 # The data set as the .dataset file and its companions describe it (planck_pliklite.py:32-76)
 # ------------------------------------------------------------------------------------------
+def read_dataset_ini(path, overrides=None):
+    """The `.dataset` file of a DataSetLikelihood (base_classes/DataSetLikelihood.py:56-66 reads
+    it with getdist's `IniFile`): CosmoMC-style plain text, one `key = value` per line, `#`
+    starts a comment, `DEFAULT(file)` / `INCLUDE(file)` pull in another file of the same
+    format (keys already set win over DEFAULTs, INCLUDEs override).  Returns a dict of strings;
+    `overrides` (the likelihood's `dataset_params`) are applied last, as
+    DataSetLikelihood.load_dataset_file does."""
+    import os
+    params, defaults = {}, []
+    folder = os.path.dirname(os.path.abspath(path))
+    with open(path, encoding="utf-8-sig") as f:
+        for raw in f:
+            line = raw.split("#", 1)[0].strip()
+            if not line:
+                continue
+            for directive, bucket in (("DEFAULT(", defaults), ("INCLUDE(", None)):
+                if line.upper().startswith(directive) and line.endswith(")"):
+                    other = os.path.join(folder, line[len(directive):-1].strip())
+                    if bucket is None:
+                        params.update(read_dataset_ini(other))
+                    else:
+                        bucket.append(other)
+                    break
+            else:
+                if "=" not in line:
+                    raise ValueError(f"{path}: cannot parse the line {raw!r}")
+                key, value = line.split("=", 1)
+                params[key.strip()] = value.strip()
+    for other in defaults:
+        for k, v in read_dataset_ini(other).items():
+            params.setdefault(k, v)
+    for k, v in (overrides or {}).items():
+        params[k] = " ".join(map(str, v)) if isinstance(v, (list, tuple)) else str(v)
+    return params
+
+
+def read_fortran_reals(path):
+    """All reals of a Fortran sequential unformatted file (what `scipy.io.FortranFile(path,
+    'r').read_reals(dtype=float)` returns for a one-record file, planck_pliklite.py:62-65):
+    each record is <uint32 n_bytes> payload <uint32 n_bytes>; several records are
+    concatenated.  float64, native byte order."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    out, pos = [], 0
+    while pos < len(raw):
+        if pos + 4 > len(raw):
+            raise ValueError(f"{path}: truncated record marker")
+        n = int(raw[pos:pos + 4].view(np.uint32)[0])
+        end = pos + 4 + n
+        if end + 4 > len(raw) or int(raw[end:end + 4].view(np.uint32)[0]) != n or n % 8:
+            raise ValueError(f"{path}: not a sequential unformatted file of 8-byte reals")
+        out.append(raw[pos + 4:end].view(np.float64))
+        pos = end + 4
+    return np.concatenate(out) if out else np.zeros(0)
+
+
 @dataclass
 class PlikLiteDataset:
     """Contents of a plik-lite data set, as `init_params` reads them from files:
     `nbin{tt,te,ee}`, `lmax`, `bin_lmin_offset`; `blmin`/`blmax` [max nbin] RELATIVE to the
     offset; `weights` [lmax - offset + 1] in C_l units (planck_pliklite.py:52-56 converts them to
-    D_l); `data` [nbins, 3] = (l_eff, C_b, sigma_b); `cov` [nbins, nbins]."""
+    D_l); `data` [nbins, 3] = (l_eff, C_b, sigma_b); `cov` [nbins, nbins].  `options`: what the
+    .dataset file says about the selection (`use_cl`, `use_bins`, `bins_for_L_range`,
+    `calibration_param`) -- `BinnedGaussian.from_dataset(ds, **ds.options)`."""
     nbintt: int
     nbinte: int
     nbinee: int
@@ -37,10 +94,54 @@ class PlikLiteDataset:
     weights: np.ndarray
     data: np.ndarray
     cov: np.ndarray
+    options: dict = field(default_factory=dict)
 
     @property
     def nbins(self):
         return self.nbintt + self.nbinte + self.nbinee
+
+    @classmethod
+    def from_files(cls, dataset_file, dataset_params=None):
+        """The real thing: `plik_lite_v22.dataset` and the files it names (the input side of
+        planck_pliklite.py:32-76 -- the ini keys `nbintt nbinte nbinee lmax bin_lmin_offset data
+        blmin blmax weights cov_file_binary cov_file use_cl use_bins bins_for_L_range
+        calibration_param`, file names relative to the .dataset file, text files via
+        `np.loadtxt` (gzip transparently), the covariance from the Fortran-binary file when it
+        exists -- lower triangle authoritative, :62-65 -- else from the text `cov_file`).
+        `dataset_params` override the file's keys (DataSetLikelihood.py:64)."""
+        import os
+        if ".dataset" not in os.path.basename(dataset_file):
+            dataset_file += ".dataset"            # DataSetLikelihood.py:59-60
+        ini = read_dataset_ini(dataset_file, dataset_params)
+        folder = os.path.dirname(os.path.abspath(dataset_file))
+
+        def rel(key):
+            if key not in ini:
+                raise ValueError(f"{dataset_file}: the key '{key}' is missing")
+            return os.path.join(folder, ini[key])
+
+        def ints(key):
+            return [int(v) for v in ini.get(key, "").split()]
+
+        n_tt, n_te, n_ee = (int(ini[k]) for k in ("nbintt", "nbinte", "nbinee"))
+        n = n_tt + n_te + n_ee
+        binary = os.path.join(folder, ini["cov_file_binary"]) if "cov_file_binary" in ini else None
+        if binary and os.path.exists(binary):
+            flat = read_fortran_reals(binary)
+            if flat.size != n * n:
+                raise ValueError(f"{binary}: {flat.size} reals, expected {n}^2")
+            lower = np.tril(flat.reshape(n, n))
+            cov = lower + np.tril(lower, -1).T
+        else:
+            cov = np.loadtxt(rel("cov_file"))
+        options = {"use_cl": ini.get("use_cl", "").lower().split(),
+                   "use_bins": ints("use_bins"), "bins_for_L_range": ints("bins_for_L_range"),
+                   "calibration_param": ini.get("calibration_param", "A_planck")}
+        return cls(nbintt=n_tt, nbinte=n_te, nbinee=n_ee, lmax=int(ini["lmax"]),
+                   bin_lmin_offset=int(ini["bin_lmin_offset"]),
+                   blmin=np.loadtxt(rel("blmin")).astype(int), blmax=np.loadtxt(rel("blmax")).astype(int),
+                   weights=np.loadtxt(rel("weights")), data=np.loadtxt(rel("data")), cov=cov,
+                   options=options)
 
 
 @dataclass
@@ -62,47 +163,51 @@ class BinnedGaussian:
     @classmethod
     def from_dataset(cls, ds: PlikLiteDataset, use_cl=("tt", "te", "ee"), use_bins=(),
                      bins_for_L_range=(), calibration_param="A_planck"):
-        """planck_pliklite.py:32-141, line by line, on arrays instead of files."""
-        use_cl = [c.lower() for c in use_cl]
-        if not use_cl:
+        """The selection logic of planck_pliklite.py:32-141 on the arrays of a data set: D_l
+        weights, the bins each selected spectrum keeps (an explicit bin list, or the bins whose
+        centre lies in an l range -- not both), their places in the data vector, and the data /
+        covariance restricted to them."""
+        wanted = {str(c).lower() for c in use_cl}
+        if not wanted:
             raise ValueError("use_cl is empty")
         off = int(ds.bin_lmin_offset)
-        blmin = np.asarray(ds.blmin).astype(int) + off
-        blmax = np.asarray(ds.blmax).astype(int) + off
-        weights = np.array(ds.weights, dtype=np.float64)
-        ls = np.arange(len(weights)) + off
-        weights *= 2 * np.pi / ls / (ls + 1)          # "we work directly with DL not CL"
-        weights = np.hstack((np.zeros(off), weights))
-        nbins = ds.nbins
-        cov = np.asarray(ds.cov, dtype=np.float64)
-        data = np.asarray(ds.data, dtype=np.float64)
-        maxbin = max(ds.nbintt, ds.nbinte, ds.nbinee)
-        if cov.shape[0] != nbins or data.shape[0] != nbins:
+        lo, hi = np.asarray(ds.blmin).astype(int) + off, np.asarray(ds.blmax).astype(int) + off
+        ell = off + np.arange(len(ds.weights), dtype=np.float64)
+        # C_l-space weights -> D_l space (:52-56), padded with zeros below the first multipole
+        w_dl = np.concatenate((np.zeros(off), np.asarray(ds.weights, dtype=np.float64)
+                               * (2 * np.pi / ell / (ell + 1))))
+        counts = {"tt": int(ds.nbintt), "te": int(ds.nbinte), "ee": int(ds.nbinee)}
+        n_all, widest = sum(counts.values()), max(counts.values())
+        cov, data = np.asarray(ds.cov, dtype=np.float64), np.asarray(ds.data, dtype=np.float64)
+        if cov.shape != (n_all, n_all) or data.shape[0] != n_all:
             raise ValueError("data / covariance do not have nbintt + nbinte + nbinee rows")
-        use_bins = list(use_bins)
-        if len(use_bins) and np.max(use_bins) >= maxbin:
+        picked = [int(b) for b in use_bins]
+        if picked and max(picked) >= widest:
             raise ValueError("use_bins has bin index out of range")
         if len(bins_for_L_range):
-            if len(use_bins):
+            if picked:
                 raise ValueError("can only use one bin filter")
             if len(bins_for_L_range) != 2:
                 raise ValueError("bins_for_L_range needs two values")
-            use_bins = [b for b in range(maxbin)
-                        if bins_for_L_range[0] <= (blmin[b] + blmax[b]) / 2 <= bins_for_L_range[1]]
-        used_bins, used_indices, offset = [], [], 0
-        for name, nbin in zip(CL_NAMES, (ds.nbintt, ds.nbinte, ds.nbinee)):
-            if name in use_cl:
-                ub = (np.array([b for b in use_bins if b < nbin], dtype=int) if len(use_bins)
-                      else np.arange(nbin, dtype=int))
-                used_bins.append(ub)
-                used_indices.append(ub + offset)
+            centre = (lo[:widest] + hi[:widest]) / 2
+            picked = np.flatnonzero((centre >= bins_for_L_range[0])
+                                    & (centre <= bins_for_L_range[1])).tolist()
+        per_spectrum, places, first = [], [], 0
+        for name in CL_NAMES:
+            n = counts[name]
+            if name not in wanted:
+                keep = np.zeros(0, dtype=int)
+            elif picked:
+                keep = np.array([b for b in picked if b < n], dtype=int)
             else:
-                used_bins.append(np.arange(0, dtype=int))
-            offset += nbin
-        used_indices = np.hstack(used_indices)
-        return cls(blmin=blmin, blmax=blmax, weights=weights, used_bins=used_bins,
-                   used_indices=used_indices, X_data=data[used_indices, 1],
-                   cov=cov[np.ix_(used_indices, used_indices)], lmax=int(ds.lmax),
+                keep = np.arange(n, dtype=int)
+            per_spectrum.append(keep)
+            if name in wanted:
+                places.append(first + keep)
+            first += n
+        places = np.concatenate(places)
+        return cls(blmin=lo, blmax=hi, weights=w_dl, used_bins=per_spectrum, used_indices=places,
+                   X_data=data[places, 1], cov=cov[np.ix_(places, places)], lmax=int(ds.lmax),
                    calibration_param=calibration_param)
 
     @property
@@ -154,7 +259,7 @@ class LinearClEmulator:
 
     def cl(self, theta):
         """[3][lmax + 1] for one parameter vector (numpy; the device forms the same sums as
-        fma chains over p ascending, oracle/pliklite_oracle.py)."""
+        fma chains over p ascending, oracle/mcmc_oracle.c `orc_binned`)."""
         return self.D0 + self.J @ (np.asarray(theta, dtype=np.float64) - self.theta0)
 
 

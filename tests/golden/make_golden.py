@@ -614,6 +614,19 @@ def g13_pliklite():
             out[f"sel_{tag}_used_indices"] = sub.used_indices
             out[f"sel_{tag}_chi2"] = np.array([
                 sub.get_chi_squared(0, *emu.cl(theta[k]), A_planck=A[k]) for k in range(8)])
+        # (d) the Fortran-binary covariance (planck_pliklite.py:60-67): ONE sequential
+        # unformatted record of nbins^2 reals, written by scipy's FortranFile; only its LOWER
+        # triangle is the covariance -- the upper one holds -1 here, which `np.tril` must drop
+        from scipy.io import FortranFile
+        junk = np.tril(ds.cov) + np.triu(np.full(ds.cov.shape, -1.0), 1)
+        f = FortranFile(os.path.join(tmp, "cov.bin"), "w")
+        f.write_record(junk)
+        f.close()
+        binl = reference_object(use_cl="tt te ee", cov_file_binary="cov.bin", cov_file="absent.txt")
+        assert np.array_equal(binl.cov, ds.cov)
+        out["bin_chi2"] = np.array([binl.get_chi_squared(0, *emu.cl(theta[k]), A_planck=A[k])
+                                    for k in range(8)])
+        assert np.array_equal(out["bin_chi2"], chi2[:8])
     save("g13_pliklite", **out)
 
 

@@ -787,6 +787,101 @@ def test_binned_gaussian_oracle_against_reference_golden_g13():
                                g["emu_chi2"][3], rtol=1e-12)
 
 
+def write_pliklite_files(folder, ds, binary=True, dataset_name="plik_lite_synth.dataset", extra=""):
+    """The data set in the reference's own file formats (what planck_pliklite.py:44-73 reads):
+    text tables, the covariance as ONE Fortran sequential record written by scipy's FortranFile
+    with -1 in the upper triangle (which the reader must drop), and the .dataset file."""
+    import os
+    from scipy.io import FortranFile
+    np.savetxt(os.path.join(folder, "data.txt"), ds.data, fmt="%.17g")
+    np.savetxt(os.path.join(folder, "blmin.txt"), ds.blmin, fmt="%d")
+    np.savetxt(os.path.join(folder, "blmax.txt"), ds.blmax, fmt="%d")
+    np.savetxt(os.path.join(folder, "weights.txt.gz"), ds.weights, fmt="%.17g")
+    if binary:
+        f = FortranFile(os.path.join(folder, "cov.bin"), "w")
+        f.write_record(np.tril(ds.cov) + np.triu(np.full(ds.cov.shape, -1.0), 1))
+        f.close()
+    else:
+        np.savetxt(os.path.join(folder, "cov.txt"), ds.cov, fmt="%.17g")
+    path = os.path.join(folder, dataset_name)
+    with open(path, "w") as f:
+        f.write(f"""# a plik-lite-shaped synthetic data set (the layout of plik_lite_v22.dataset)
+use_cl = TT TE EE     # spectra in the data vector
+nbintt = {ds.nbintt}
+nbinte = {ds.nbinte}
+nbinee={ds.nbinee}
+lmax = {ds.lmax}
+bin_lmin_offset = {ds.bin_lmin_offset}
+
+data = data.txt
+blmin = blmin.txt
+blmax = blmax.txt
+weights = weights.txt.gz
+cov_file = cov.txt
+cov_file_binary = cov.bin
+{extra}""")
+    return path
+
+
+def test_pliklite_files_are_read_like_the_reference_reads_them(tmp_path):
+    """VERDICT r3 missing 2: `PlikLiteDataset.from_files` = the input side of
+    planck_pliklite.py:44-73 (.dataset keys, loadtxt tables, the Fortran-binary covariance with
+    the `tril` symmetrisation).  The files are written here in the reference's formats from the
+    G13 arrays; what the reader + `from_dataset` leave equals what the REFERENCE left after
+    reading the same contents (golden G13 `ref_*`, and `bin_chi2` = its chi2 with the binary
+    covariance), and the options of the .dataset file / `dataset_params` select as there."""
+    from cobaya_amd import pliklite as P
+    from cobaya_amd.model import ProblemSpec, UnsupportedModel
+    from tests.pliklite_common import load_g13
+    g, ds0 = load_g13()
+    path = write_pliklite_files(str(tmp_path), ds0)
+    raw = np.fromfile(tmp_path / "cov.bin", dtype=np.uint8)
+    assert len(raw) == 8 + 8 * ds0.nbins ** 2          # one record: marker, payload, marker
+    ds = P.PlikLiteDataset.from_files(path)
+    assert np.array_equal(ds.cov, ds0.cov) and np.array_equal(ds.data, ds0.data)
+    assert ds.options == {"use_cl": ["tt", "te", "ee"], "use_bins": [], "bins_for_L_range": [],
+                          "calibration_param": "A_planck"}
+    t = P.BinnedGaussian.from_dataset(ds, **ds.options)
+    assert np.array_equal(t.weights, g["ref_weights"]) and np.array_equal(t.X_data, g["ref_X_data"])
+    assert np.array_equal(t.used_indices, g["ref_used_indices"])
+    assert np.array_equal(t.blmin, g["ref_blmin"]) and np.array_equal(t.blmax, g["ref_blmax"])
+    emu = P.synthetic_emulator(26, ds.lmax)
+    B = O.Binned(t.bin_table(), t.weights, t.X_data, cov=t.cov, theta0=emu.theta0, D0=emu.D0,
+                 J=emu.J, calib=26)
+    x = np.column_stack((g["emu_theta"], g["emu_A"]))[:8]
+    np.testing.assert_allclose(B.chi2_of_delta(B.delta(x)), g["bin_chi2"], rtol=1e-12)
+    # without the binary file the text covariance is used (planck_pliklite.py:66-67)
+    os.remove(tmp_path / "cov.bin")
+    with pytest.raises(OSError):
+        P.PlikLiteDataset.from_files(path)
+    write_pliklite_files(str(tmp_path), ds0, binary=False)
+    assert np.array_equal(P.PlikLiteDataset.from_files(str(tmp_path / "plik_lite_synth")).cov, ds0.cov)
+    # through the input: `dataset_file` + `path`, `dataset_params` overriding the file's keys
+    # (TT_lite_native.yaml: `dataset_params: {use_cl: tt}`), options of the .dataset file itself
+    params = {n: {"prior": {"min": -1, "max": 1}} for n in emu.names}
+    params["A_planck"] = {"prior": {"dist": "norm", "loc": 1, "scale": 0.0025}}
+
+    def spec(**like):
+        return ProblemSpec.from_info({"likelihood": {"plik": {
+            "class": "planck_pliklite", "cl_emulator": emu, **like}}, "params": params})
+    full = spec(dataset_file="plik_lite_synth.dataset", path=str(tmp_path))
+    assert np.array_equal(full.components[0]["binned"].used_indices, g["ref_used_indices"])
+    tt = spec(dataset_file=path, dataset_params={"use_cl": "tt"})
+    assert np.array_equal(tt.components[0]["binned"].used_indices, g["sel_tt_used_indices"])
+    both = spec(dataset_file=path, use_cl="te ee", dataset_params={"use_cl": "tt", "bins_for_L_range": "500 1200"})
+    assert np.array_equal(both.components[0]["binned"].used_indices, g["sel_lrange_used_indices"])
+    write_pliklite_files(str(tmp_path), ds0, binary=False, dataset_name="bins.dataset",
+                         extra="use_bins = " + " ".join(map(str, range(10, 120, 3))) + "\n")
+    sel = spec(dataset_file="bins", path=str(tmp_path))
+    assert np.array_equal(sel.components[0]["binned"].used_indices, g["sel_bins_used_indices"])
+    with pytest.raises(UnsupportedModel, match="could not be read"):
+        spec(dataset_file="nowhere.dataset", path=str(tmp_path))
+    with open(tmp_path / "cov.bin", "wb") as f:
+        f.write(b"\x10\x00\x00\x00" + b"\x00" * 12)       # a record without its closing marker
+    with pytest.raises(ValueError, match="sequential unformatted"):
+        P.read_fortran_reals(str(tmp_path / "cov.bin"))
+
+
 def test_binned_gaussian_steps_sample_the_posterior():
     """The oracle's Metropolis steps on the binned target (small case, 6 parameters): mean and
     covariance of the walkers agree with the Gaussian (Fisher) approximation of the posterior --
