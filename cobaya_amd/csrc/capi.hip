@@ -299,6 +299,7 @@ extern "C" hipError_t mcmc_hip_launch_pl_prior(const double* t, int n, int d, co
                                                hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_residual(const mcmc::PlResidualArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_bin(const mcmc::PlBinArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_residual_mfma(const mcmc::PlResidualMfmaArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_chi2(const mcmc::PlChi2Args* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_combine(const double* psum, double* chi2, int n, hipStream_t st);
 
@@ -419,7 +420,7 @@ struct mcmc_hip_ctx {
         int n_bins = 0, KT = 0, ntw = 0, n_lin = 0, nlp = 0, calib = 0, lmax = 0;
         std::vector<int32_t> bins;                       // [n_bins][3]
         std::vector<double> Linv, Bc0, BJ;               // host copies (tests hand them to the oracle)
-        DevBuf<double> resp, theta0, Astream, weights, X;
+        DevBuf<double> resp, theta0, Astream, weights, X, bjs, es;   // bjs, es: pl_residual_mfma_kernel
         DevBuf<int> dbins;
         DevBuf<double> delta, trial, lp_t, Ea, psum;     // step scratch, W walkers
         DevBuf<double> edelta, etrial, elp, echi2, epsum, ecl, eA;   // evaluate scratch
@@ -693,6 +694,16 @@ int binned_chi2(mcmc_hip_ctx* h, const double* delta, double* psum, double* chi2
 int binned_residual(mcmc_hip_ctx* h, const double* trial, double* delta, int n)
 {
     auto& B = h->bg;
+    // MCMC_HIP_PL_SCALAR_RESIDUAL (developer switch): the lane-per-walker kernel of round 3
+    static const bool scalar = getenv("MCMC_HIP_PL_SCALAR_RESIDUAL") != nullptr;
+    if (!scalar) {
+        mcmc::PlResidualMfmaArgs m{};
+        m.trial = trial; m.theta0 = B.theta0.p; m.bjs = B.bjs.p; m.es = B.es.p; m.delta = delta;
+        m.W = n; m.KT = B.KT; m.n_lin = B.n_lin; m.np = (B.n_lin + 7) / 8; m.calib = B.calib;
+        m.n_tiles = (B.KT + 3) / 4;
+        HIP_TRY(h, mcmc_hip_launch_pl_residual_mfma(&m, h->stream));
+        return MCMC_HIP_OK;
+    }
     mcmc::PlResidualArgs r{};
     r.trial = trial; r.theta0 = B.theta0.p; r.resp = B.resp.p; r.delta = delta;
     r.W = n; r.n_bins = B.n_bins; r.KT = B.KT; r.n_lin = B.n_lin; r.nlp = B.nlp; r.calib = B.calib;
@@ -1022,6 +1033,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->inc_mean.release();
     {
         auto& B = h->bg;
+        B.bjs.release(); B.es.release();
         B.resp.release(); B.theta0.release(); B.Astream.release(); B.weights.release();
         B.X.release(); B.dbins.release(); B.delta.release(); B.trial.release(); B.lp_t.release();
         B.Ea.release(); B.psum.release(); B.epsum.release(); B.edelta.release(); B.etrial.release(); B.elp.release();
@@ -1174,7 +1186,32 @@ int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const i
         for (int p = 0; p < n_lin; ++p) r[1 + p] = B.BJ[b * n_lin + p];
         r[1 + B.nlp] = X[b];
     }
+    th.resize(32, 0.0);    // (pl_residual_mfma_kernel reads 8 np <= 32 entries)
     std::copy(theta0, theta0 + n_lin, th.begin());
+    // the same response as matrix-core operands (PlResidualMfmaArgs)
+    const int n_tiles = (B.KT + 3) / 4, npairs = (n_lin + 7) / 8;
+    std::vector<double> bjs((size_t)n_tiles * npairs * 128, 0.0), es((size_t)n_tiles * 4 * 128, 0.0);
+    for (int T = 0; T < n_tiles; ++T) {
+        for (int jp = 0; jp < npairs; ++jp)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 2; ++e) {
+                    const size_t b = 16 * (size_t)T + (l & 15);
+                    const int p = 4 * (2 * jp + e) + (l >> 4);
+                    if (b < n && p < n_lin)
+                        bjs[(((size_t)T * npairs + jp) * 64 + l) * 2 + e] = B.BJ[b * n_lin + p];
+                }
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r) {
+                const size_t b = 16 * (size_t)T + 4 * r + (l >> 4);
+                if (b >= n) continue;
+                es[(((size_t)T * 4 + r / 2) * 64 + l) * 2 + (r & 1)] = B.Bc0[b];
+                es[(((size_t)T * 4 + 2 + r / 2) * 64 + l) * 2 + (r & 1)] = X[b];
+            }
+    }
+    HIP_TRY(h, B.bjs.resize(bjs.size()));
+    HIP_TRY(h, B.es.resize(es.size()));
+    HIP_TRY(h, hipMemcpy(B.bjs.p, bjs.data(), sizeof(double) * bjs.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(B.es.p, es.data(), sizeof(double) * es.size(), hipMemcpyHostToDevice));
     // tiles of L^-1 per wave of pl_chi2_kernel: wave q owns the 16-row tiles of class q in
     // ascending order, absent tiles first; tile R has min(4 R + 4, KT) k-steps
     std::vector<double> As;

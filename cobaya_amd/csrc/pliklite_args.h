@@ -24,6 +24,18 @@ struct PlResidualArgs {
     double* delta;         // [W / 64][KT / 2][4][64][2]: B-operand order of pl_chi2_kernel, k-steps in pairs
     int W, n_bins, KT, n_lin, nlp, calib;
 };
+// pl_residual_mfma_kernel: the same residuals as a [bins x (n_lin padded)] . [params x walkers]
+// product on the matrix cores
+struct PlResidualMfmaArgs {
+    const double* trial;   // [d][W]
+    const double* theta0;  // [>= 8 np] fiducial parameters (zero beyond n_lin)
+    const double* bjs;     // [tiles][np][64][2]: A operands of bin tile T, k-step pair jp: lane l holds
+                           // BJ[16 T + (l & 15)][4 (2 jp + e) + (l >> 4)], e = 0, 1 (zero outside)
+    const double* es;      // [tiles][4][64][2]: per lane 16 c + n the rows 16 T + 4 r + c: (Bc0 r = 0, 1),
+                           // (Bc0 r = 2, 3), (X r = 0, 1), (X r = 2, 3)
+    double* delta;         // as PlResidualArgs
+    int W, KT, n_lin, np, calib, n_tiles;
+};
 struct PlBinArgs {
     const double* cl;      // [n_pts][3][stride], element l - L0 of a row is D_l
     const double* A;       // [n_pts] calibration

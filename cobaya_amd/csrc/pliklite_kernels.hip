@@ -192,6 +192,67 @@ __global__ void __launch_bounds__(256) pl_residual_kernel(const PlResidualArgs a
     }
 }
 
+// The same residuals on the matrix cores (the step path): cl = Bc0 + BJ . dtheta is a
+// [bins x params] . [params x walkers] product, and v_mfma_f64_16x16x4_f64 accumulates k ascending
+// with one rounding per product-sum -- started from Bc0_b, the accumulator IS the fma chain over p
+// ascending of the specification (padding parameters contribute fma(0, 0, cl) = cl).  Its layout
+// -- register r of lane 16 c + n = bin 16 T + 4 r + c of walker n -- is the B-operand layout of
+// k-step 4 T + r of pl_chi2_kernel, so a lane stores its four residuals as the two 16-byte pairs
+// (k-steps 4 T, 4 T + 1), (4 T + 2, 4 T + 3).  A workgroup of 4 waves owns 64 walkers; wave q takes
+// the bin tiles T = q (mod 4) for all four walker tiles (operands of a tile loaded once, used for
+// 4 x 2 NP MFMAs); the scalar-cache walk of pl_residual_kernel (one record per bin, 30 dependent
+// s_loads) is gone: 151 -> [measured in profiles/r04_pl_*] us per launch at 613 bins.
+template <int NP>   // pairs of k-steps over the emulator parameters: ceil(n_lin / 8)
+__global__ void __launch_bounds__(256) pl_residual_mfma_kernel(const PlResidualMfmaArgs a)
+{
+    const int lane = threadIdx.x & 63, c = lane >> 4, n = lane & 15;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x, W = a.W, calib = a.calib;
+    double dth[4][2 * NP], iA2[4];
+#pragma unroll
+    for (int wt = 0; wt < 4; ++wt) {
+        const size_t w = (size_t)wg * 64 + wt * 16 + n;
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) {
+            const int p = 4 * j + c, i = p + (p >= calib ? 1 : 0);
+            dth[wt][j] = p < a.n_lin ? a.trial[(size_t)i * W + w] - a.theta0[p] : 0.0;
+        }
+        const double A = a.trial[(size_t)calib * W + w];
+        iA2[wt] = 1.0 / (A * A);
+    }
+    const int KT2 = a.KT / 2;
+    const double2* __restrict__ bj = (const double2*)a.bjs + lane;
+    const double2* __restrict__ es = (const double2*)a.es + lane;
+    double2* __restrict__ out = (double2*)a.delta + (size_t)wg * KT2 * 256 + lane;
+    for (int T = q; T < a.n_tiles; T += 4) {
+        double2 av[NP], e[4];
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) av[jp] = bj[((size_t)T * NP + jp) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = es[((size_t)T * 4 + i) * 64];
+        d4 acc[4];
+#pragma unroll
+        for (int wt = 0; wt < 4; ++wt) acc[wt] = d4{e[0].x, e[0].y, e[1].x, e[1].y};
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+#pragma unroll
+            for (int wt = 0; wt < 4; ++wt)
+                acc[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jp].x, dth[wt][2 * jp], acc[wt], 0, 0, 0);
+#pragma unroll
+            for (int wt = 0; wt < 4; ++wt)
+                acc[wt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jp].y, dth[wt][2 * jp + 1], acc[wt], 0, 0, 0);
+        }
+        const bool second = 2 * T + 1 < KT2;     // (KT is even, not a multiple of 4: the last tile may end early)
+#pragma unroll
+        for (int wt = 0; wt < 4; ++wt) {
+            const double d0 = fma(-acc[wt][0], iA2[wt], e[2].x), d1 = fma(-acc[wt][1], iA2[wt], e[2].y);
+            const double d2 = fma(-acc[wt][2], iA2[wt], e[3].x), d3 = fma(-acc[wt][3], iA2[wt], e[3].y);
+            out[((size_t)(2 * T) * 4 + wt) * 64] = make_double2(d0, d1);
+            if (second) out[((size_t)(2 * T + 1) * 4 + wt) * 64] = make_double2(d2, d3);
+        }
+    }
+}
+
 // explicit spectra (mcmc_hip_evaluate_binned = get_chi_squared's own arguments): cl_b = fma chain
 // over l ascending of D_l weights_l (np.dot, planck_pliklite.py:148-151).  One thread per
 // (point, bin); n_pts is small (tests, checks).
@@ -358,6 +419,19 @@ extern "C" hipError_t mcmc_hip_launch_pl_residual(const PlResidualArgs* a, hipSt
     case 24: hipLaunchKernelGGL(pl_residual_kernel<24>, g, b, 0, st, *a); break;
     case 28: hipLaunchKernelGGL(pl_residual_kernel<28>, g, b, 0, st, *a); break;
     case 32: hipLaunchKernelGGL(pl_residual_kernel<32>, g, b, 0, st, *a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_residual_mfma(const PlResidualMfmaArgs* a, hipStream_t st)
+{
+    const dim3 g(a->W / 64), b(256);
+    switch (a->np) {
+    case 1: hipLaunchKernelGGL(pl_residual_mfma_kernel<1>, g, b, 0, st, *a); break;
+    case 2: hipLaunchKernelGGL(pl_residual_mfma_kernel<2>, g, b, 0, st, *a); break;
+    case 3: hipLaunchKernelGGL(pl_residual_mfma_kernel<3>, g, b, 0, st, *a); break;
+    case 4: hipLaunchKernelGGL(pl_residual_mfma_kernel<4>, g, b, 0, st, *a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
