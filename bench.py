@@ -93,6 +93,9 @@ def parse():
     ap.add_argument("--device-checkpoint", dest="device_checkpoint", action="store_const",
                     const="device", help="= --checkpoint-on device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cross-check-seconds", type=float, default=1.0,
+                    help="after the K timed steps, time the same loop again for at least this long "
+                         "and report it as `cross_check` (0 = skip)")
     ap.add_argument("--workload", choices=("gaussian_mixture", "pliklite"), default="gaussian_mixture",
                     help="pliklite: ONLY the planck_pliklite variant (613 bins, d = 27), as its "
                          "own line -- the command the profiles of pl_chi2_kernel are taken with")
@@ -274,7 +277,7 @@ def measured_traffic(d, walkers, spl, kernel):
     return None, None
 
 
-def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
+def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, cross_check_s=0.0):
     """W untimed + K timed bench steps of one sampler; returns the raw measurements.  `info`:
     an explicit input (variants); default: the d-dim gaussian_mixture workload."""
     from cobaya_amd import dist
@@ -346,13 +349,35 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None):
     kt = eng.kernel_times()
     if sampler.spec.like_kind == "planck_pliklite":
         kt["binned"] = eng.binned_kernel_times()
+    cross = None
+    if cross_check_s > 0:
+        # a second, LONG timed region of the same loop (>= cross_check_s seconds): the K-step
+        # region above lasts tens of milliseconds -- too short for a sampling monitor (the
+        # driver's smi samples saw an idle device in round 3); same bracketing, same clock
+        n_x = int(max(steps, math.ceil(cross_check_s / max(dt / steps, 1e-6))))
+        n_x = int(round(float(dist.all_reduce_max(np.array([float(n_x)]))[0])))
+        dist.barrier()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(n_x):
+            one_step()
+        if sampler._ckpt_pending:
+            sampler._finish_checkpoint()
+        eng.sync()
+        dist.barrier()
+        dx = time.perf_counter() - t0
+        if size > 1:
+            dx = float(dist.all_reduce_max(np.array([dx]))[0])
+        cross = {"steps": n_x, "seconds": dx, "ms_per_step": 1e3 * dx / n_x,
+                 "value": float(a.walkers) * size * spl * n_x / dx}
     res = {"dt": dt, "spl": spl, "kt": kt, "kernel": eng.last_step_kernel(),
            "evaluation": "incremental" if sampler.incremental else "full",
            "group_size": int(sampler.group_size),
            "basis_group_size": int(sampler.basis_group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
            "checkpoint_lag": int(sampler.checkpoint_lag),
            "checkpoint_on": "device" if sampler._device_ckpt else "host",
-           "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps}
+           "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps,
+           "cross_check": cross}
     sampler.close()
     return res
 
@@ -407,6 +432,17 @@ def gaussian_roofline(m, d, walkers, steps):
             "bound": "valu_issue", "achieved": ach / 1e9 if ach else None,
             "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
             "frac": ach / VALU_ISSUE_PEAK if ach else None,
+            # beside `frac`: the two other roofs, so that nobody has to derive them -- executed
+            # FP64 arithmetic over the dense FP64 peak, and the bytes that really crossed HBM
+            # (PMC FETCH_SIZE + WRITE_SIZE of one launch) over the kernel's duration and 8 TB/s
+            "fp64_frac": tf / FP64_PEAK_TFLOPS,
+            "hbm": {"bytes_per_launch": traffic,
+                    "GBps": traffic / (step_ms * 1e-3) / 1e9 if traffic and step_ms > 0 else None,
+                    "peak_GBps": HBM_PEAK_GBS,
+                    "frac": traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    if traffic and step_ms > 0 else None,
+                    "note": "the state lives in registers for the fused launch: HBM does not bind "
+                            "(north_star's >= 60 % of the HBM roofline is unmeetable by design)"},
             "fp64": {"flops_per_eval_executed": algo_flops_incremental(d),
                      "achieved_tflops": tf, "frac_of_peak": tf / FP64_PEAK_TFLOPS,
                      "flops_per_eval_from_scratch": algo_flops_per_eval(d),
@@ -520,7 +556,7 @@ def main():
         return main_pliklite(a, rank, size)
     d = a.dim
     mean, cov = target(d)
-    m = run_timed(a, d, mean, cov, a.emit, a.steps, a.warmup)
+    m = run_timed(a, d, mean, cov, a.emit, a.steps, a.warmup, cross_check_s=a.cross_check_seconds)
     collective = dist.describe()
     variants = []
     if size == 1 and not a.no_variants and m["evaluation"] == "incremental":
@@ -538,18 +574,55 @@ def main():
             / (v_ms * 1e-3) / 1e12,
             "fp64_frac_of_peak": algo_flops_per_eval(d) * a.walkers * v["spl"] / max(v_launches, 1)
             / (v_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS})
+    if size == 1 and not a.no_variants and (d, a.walkers, a.emit) == (30, 65536, "snapshots"):
+        # the price of fidelity: the reference-faithful control -- every walker draws its OWN
+        # Haar basis per cycle (proposal.py:59-69 to the letter: `shared_basis: False`) and every
+        # trial is evaluated from scratch, on the un-paired variate stream (0.33 threshold at 24
+        # bits, 52-bit uniforms).  Same workload, same walkers.
+        info_c = make_info(d, mean, cov, a.walkers, a.group_size, 4 * d, evaluation="full")
+        info_c["sampler"]["mcmc_hip"]["shared_basis"] = False
+        n_v = 3
+        v = run_timed(a, d, mean, cov, "snapshots", n_v, 1, info=info_c)
+        variants.append({
+            "variant": "to-the-letter control: shared_basis: False (a Haar basis per walker per "
+                       "cycle) + evaluation: full",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 1, "metropolis_steps_per_launch": v["spl"],
+            "kernel": v["kernel"],
+            "kernel_ms_per_launch": v["kt"]["step_ms"] / max(v["kt"]["step_launches"], 1),
+            "basis_kernel_ms_per_launch": v["kt"]["basis_ms"] / n_v,
+            "headline_over_this": (m["evals"] / m["dt"]) / (v["evals"] / v["dt"])})
     if a.emit == "snapshots" and size == 1 and not a.no_variants and (d, a.walkers) == (30, 65536):
         # the reference stores EVERY accepted row (mcmc.py:691-707, collection.py:402-427);
         # same workload with those semantics: rows cross PCIe and are kept on the host
         v = run_timed(a, d, mean, cov, "chains", 40, 4)
         variants.append({
-            "variant": "emit: chains (every accepted row drained to the host, PCIe-inclusive)",
+            "variant": "emit: chains (every accepted row drained to a pinned host ring at PCIe "
+                       "speed; a launch's 4.7 M rows exceed max_rows, so the host does NOT retain "
+                       "them here -- see the retained variant below)",
             "value": v["evals"] / v["dt"], "unit": "evals/s",
             "ms_per_step": 1e3 * v["dt"] / 40, "steps": 40, "warmup": 4,
             "metropolis_steps_per_launch": v["spl"], "kernel": v["kernel"],
             "kernel_ms_per_launch": v["kt"]["step_ms"] / 40,
             "accepted_rows_per_s": v["rows"] / v["dt"],
-            "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"]})
+            "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"],
+            "rows_retained_on_host": False})
+        # ... and with the rows RETAINED: a store large enough for the region, every drained
+        # block copied out of its pinned slot into the sampler's own memory (what products()
+        # hands out) -- the host-side copy is then part of the step
+        info_r = make_info(d, mean, cov, a.walkers, a.group_size, 40 * d, "chains")
+        info_r["sampler"]["mcmc_hip"]["max_rows"] = 1 << 24   # (4.7 GB of rows: ~3 launches, then
+        #                                                       the oldest half is dropped)
+        info_r["sampler"]["mcmc_hip"]["drain_copy"] = True
+        n_v = 4
+        v = run_timed(a, d, mean, cov, "chains", n_v, 1, info=info_r)
+        variants.append({
+            "variant": "emit: chains, rows retained on the host (copied out of the pinned ring "
+                       "into the sample store every launch)",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 1, "metropolis_steps_per_launch": v["spl"],
+            "accepted_rows_per_s": v["rows"] / v["dt"],
+            "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"], "rows_retained_on_host": True})
     headline = (d, a.walkers, a.emit) == (30, 65536, "snapshots")
     if size == 1 and not a.no_variants and headline:
         # BASELINE configs[3]: the 100-dim gaussian_mixture, same walkers (default path)
@@ -662,6 +735,7 @@ def main():
                 "checkpoint_on": m["checkpoint_on"],
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
+            "cross_check": m["cross_check"],
             "collective": collective,
             "roofline": roofline,
             "variants": variants,

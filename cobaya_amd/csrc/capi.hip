@@ -257,6 +257,7 @@ struct DevBuf {
 }  // namespace
 
 extern "C" hipError_t mcmc_hip_launch_general_step(const mcmc::GeneralStepArgs* b, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_general_drag(const mcmc::GeneralDragArgs* g, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pack_rows(const double* rows, const int* n_rows,
                                                 const long long* offset, double* out, int W,
                                                 int cap, int d, uint32_t walker0, hipStream_t st);
@@ -327,6 +328,7 @@ struct mcmc_hip_ctx {
     int drag_last_slow = -1, drag_steps = 0;
     DevBuf<int> dblk, vflag, vflag_f;               // dblk: size | oversample | i_of_j
     DevBuf<double> Vf;                              // dragging: directions of the fast blocks
+    DevBuf<double> drag_cs;                         // drag_general_kernel: start points [d][W]
     std::vector<double> shift;                      // moment shift
     // device
     DevBuf<double> x, logpost, logprior, loglike, cblock, dT, V, rows, gsum, Sg, pooled, dshift;
@@ -1016,7 +1018,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->dLcol.release(); h->weight_i.release(); h->prej.release();
     h->burn.release(); h->stuck.release(); h->nrows.release(); h->nacc.release();
     h->acc_total.p = nullptr;   // (a view into gsum)
-    h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release();
+    h->dblk.release(); h->vflag.release(); h->vflag_f.release(); h->Vf.release(); h->drag_cs.release();
     for (auto& sl : h->slots)
         if (sl.p) (void)hipHostFree(sl.p);
     h->ck.ring.release(); h->ck.wsum.release(); h->ck.payload.release(); h->ck.ws.release();
@@ -1321,10 +1323,7 @@ int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* bloc
     if (!h) return MCMC_HIP_ERR_ARG;
     if (!block_size || !oversampling || !i_of_j) return fail(h, MCMC_HIP_ERR_ARG, "null argument");
     const int d = h->d;
-    if (h->kb && !h->incremental)
-        return fail(h, MCMC_HIP_ERR_ARG,
-                    "parameter blocks and dragging at d > 32 need incremental evaluation (with "
-                    "evaluation: full they are supported for d <= 32; d=%d)", d);
+    // (d > 32 from scratch: the general kernels -- step_general_kernel, drag_general_kernel)
     if (n_blocks < 1 || n_blocks > 32)
         return fail(h, MCMC_HIP_ERR_ARG, "n_blocks must be in 1..32, got %d", n_blocks);
     int total = 0;
@@ -1353,8 +1352,8 @@ int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* bloc
                         "only %d blocks.", drag_last_slow, n_blocks);
         if (drag_steps < 1 || drag_steps > 256)
             return fail(h, MCMC_HIP_ERR_ARG, "drag_steps must be in 1..256, got %d", drag_steps);
-        if (h->cfg.emit_capacity > 0)
-            return fail(h, MCMC_HIP_ERR_ARG, "dragging does not emit rows (emit_capacity > 0)");
+        // (emitted rows, emit_capacity > 0: the from-scratch drag_kernel -- d <= 32 --; the
+        // incremental dragging kernel does not emit and refuses at mcmc_hip_step)
         trivial = false;
     } else {
         drag_last_slow = -1;
@@ -1908,8 +1907,11 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     // steps (= direction columns) per cycle, doubles per (group, cycle) slab of directions
     const int Lc = block_slots(h, drag ? 1 : 0);
     const unsigned long long d = (unsigned long long)Lc;
-    const size_t dd = h->kb ? (size_t)mcmc::v_slab_big(h->d)
-                            : (size_t)mcmc::v_slab_cols(Lc, h->d);
+    // (parameter blocks and dragging at d > 32: blocked directions in the d <= 32 layout --
+    // column stride d -- read by the general kernels)
+    const bool big_blocked = h->kb && (h->blocked || drag);
+    const size_t dd = (h->kb && !big_blocked) ? (size_t)mcmc::v_slab_big(h->d)
+                                              : (size_t)mcmc::v_slab_cols(Lc, h->d);
     const bool big_norm = h->norm_mask4[0] || h->norm_mask4[1] || h->norm_mask4[2] || h->norm_mask4[3];
     // d > 32: what the matrix-core / two-wave / column-sweep kernels leave out (mixtures, `one`,
     // periodic parameters, emitted rows; odd ensemble sizes with normal priors or d > 112) runs
@@ -1918,7 +1920,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
         return fail(h, MCMC_HIP_ERR_ARG,
                     "shared_basis: False serves a single parameter block without dragging");
     const bool general_big =
-        h->own_basis ||
+        h->own_basis || big_blocked ||
         (h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0 ||
                    (h->W % 256 != 0 && (big_norm || h->d > 112))));
     // basis "groups": the walker groups, or every walker on its own
@@ -2009,13 +2011,27 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
                 if (rc != MCMC_HIP_OK) return rc;
                 g.Vf = h->Vf.p;
                 g.vflag_f = any_1d_f ? h->vflag_f.p : nullptr;
-                HIP_TRY(h, h->k->drag(g, h->stream));
+                if (h->kb) {   // 32 < d <= 128: the general dragging kernel
+                    mcmc::GeneralDragArgs q{};
+                    q.g.s = a;
+                    q.g.Lrow = h->dLrow.p; q.g.d = h->d; q.g.ld = h->d; q.g.own_basis = 0;
+                    for (int m = 0; m < 4; ++m) q.g.norm_mask4[m] = h->norm_mask4[m];
+                    for (int i = 0; i < h->d; ++i)
+                        if (h->periodic[i]) q.g.periodic_mask4[i >> 5] |= 1u << (i & 31);
+                    HIP_TRY(h, h->drag_cs.resize((size_t)h->d * h->W));
+                    q.Vf = g.Vf; q.vflag_f = g.vflag_f; q.cs = h->drag_cs.p;
+                    q.cyc0 = g.cyc0; q.cyc0_f = g.cyc0_f; q.cps_f = g.cps_f; q.slab_f = g.slab_f;
+                    q.ncyc_f = g.ncyc_f; q.n_drag = g.n_drag;
+                    HIP_TRY(h, mcmc_hip_launch_general_drag(&q, h->stream));
+                } else {
+                    HIP_TRY(h, h->k->drag(g, h->stream));
+                }
             } else if (general_big) {
                 mcmc::GeneralStepArgs g{};
                 g.s = a;
                 g.Lrow = h->dLrow.p;
                 g.d = h->d;
-                g.ld = h->kb ? mcmc::v_ld(h->d) : h->d;
+                g.ld = (h->kb && !big_blocked) ? mcmc::v_ld(h->d) : h->d;
                 g.own_basis = h->own_basis ? 1 : 0;
                 for (int q = 0; q < 4; ++q) g.norm_mask4[q] = h->norm_mask4[q];
                 for (int i = 0; i < h->d; ++i)

@@ -197,6 +197,17 @@ struct GeneralStepArgs {
     int own_basis;                // every walker has its own (group, cycle) slabs of V
 };
 
+// The general dragging step (general_kernels.hip: drag_general_kernel)
+struct GeneralDragArgs {
+    GeneralStepArgs g;     // g.s: state, V = the slow blocks' directions (cps, slab, vflag), ...
+    const double* Vf;      // [G][ncyc_f][slab_f] directions of the fast blocks
+    const int* vflag_f;    // [G][ncyc_f][cps_f] or null
+    double* cs;            // [d][W] scratch: the start points of the dragging step
+    unsigned long long cyc0, cyc0_f;   // first slow / fast cycle held in V / Vf
+    int cps_f, slab_f, ncyc_f;
+    int n_drag;
+};
+
 // Incremental evaluation (incremental_kernels.hip): one Gaussian mode, non-periodic priors,
 // one block; 2 <= d <= 128 with dq = ceil(d / 4) dimensions per lane, four lanes per walker.
 struct IncStepArgs {

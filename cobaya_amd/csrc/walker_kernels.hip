@@ -1025,6 +1025,7 @@ __global__ void __launch_bounds__(256) drag_kernel(const DragArgs da)
     int wt = a.weight[w], prej = a.prior_rej[w], burn = a.burn_left[w];
     long long nacc = a.n_accept[w];
     const long long nacc0 = nacc;
+    int nrow = a.rows ? a.n_rows[w] : 0;
     const uint32_t gid = a.walker0 + (uint32_t)w;
     const int n = da.n_drag;
     auto evaluate = [&](double& lp, double& ll) -> double {
@@ -1107,7 +1108,19 @@ __global__ void __launch_bounds__(256) drag_kernel(const DragArgs da)
         const bool accept = !dead & metropolis(end_acc / navg, start_acc / navg, a.temperature, Ea0);
         // bookkeeping (mcmc.py:685-748); a dead slow proposal only adds weight
         if (accept) {
-            if (burn > 0) --burn;
+            // the point that is left enters the collection with its weight
+            // (mcmc.py:660-668 -> process_accept_or_reject, 691-707); sX still holds it
+            if (burn > 0) {
+                --burn;
+            } else if (a.rows) {
+                if (nrow < a.row_cap) {
+                    double* row = a.rows + ((size_t)w * a.row_cap + nrow) * (D + 4);
+                    row[0] = (double)wt; row[1] = lpost; row[2] = lpri; row[3] = llik;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) row[4 + i] = sX[i * bs];
+                }
+                ++nrow;  // rows beyond the capacity are counted as dropped
+            }
             lpri = ce_lp; llik = ce_ll; lpost = ce_lt;
             wt = 1; prej = 0; ++nacc;
         } else {
@@ -1125,6 +1138,7 @@ __global__ void __launch_bounds__(256) drag_kernel(const DragArgs da)
     a.logpost[w] = lpost; a.logprior[w] = lpri; a.loglike[w] = llik;
     a.weight[w] = wt; a.prior_rej[w] = prej; a.burn_left[w] = burn;
     a.n_accept[w] = nacc;
+    if (a.rows) a.n_rows[w] = nrow;
     wave_add_accepts(a.accept_total, nacc - nacc0);
 }
 

@@ -90,6 +90,10 @@ HIP_DEFAULTS = {
                               # record of the later half of the run) the per-chain bounds are
                               # selected from -- in every emit mode; at most 16384 / group_size.
                               # 0: no ring, convergence is judged on the means only
+    "drain_copy": False,      # emit: chains -- True: every drained block is copied out of the
+                              # engine's pinned slot at once (the store owns its rows from the
+                              # start); False: blocks are read in place and copied only when their
+                              # slot is about to be reused
     "row_buffer_bytes": 1 << 32,  # emit: chains -- device buffer of accepted rows between two
                               # drains (bounds steps_per_launch: every step may accept)
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
@@ -481,8 +485,7 @@ class EnsembleMCMC:
         if self.drag:
             self.log.info("Dragging with number of interpolating steps: %d", self.drag_interp_steps)
             self.cycle_length = sum(len(b) for b in blocks[:1 + self.i_last_slow_block])
-            if self.emit == "chains":
-                self._fail("emit: chains is not available with dragging")
+            # (emit: chains: rows leave the from-scratch dragging kernel, d <= 32 -- `initialize`)
         else:
             if any(f > 1 for f in factors):
                 self.log.info("Oversampling with factors: %r", list(zip(factors, blocks)))
@@ -679,7 +682,11 @@ class EnsembleMCMC:
             if hasattr(eng, "drain_samples_view"):
                 # rows land in a pinned host slot of the engine at PCIe speed and are read there
                 self._expire_row_views()
-                self._store_rows(eng.drain_samples_view(), view=True)
+                rows = eng.drain_samples_view()
+                if self.drain_copy:
+                    self._store_rows(np.array(rows))
+                else:
+                    self._store_rows(rows, view=True)
             else:
                 self._store_rows(eng.drain_samples())
         elif snap_every and self._since_snapshot >= snap_every:

@@ -143,8 +143,10 @@ MCMC_HIP_API int mcmc_hip_get_binned_constants(const mcmc_hip_ctx* h, double* Li
  * entries of i_of_j[d] (sampler indices in sorted order) and visited oversampling[b] *
  * block_size[b] times per cycle.  drag_last_slow >= 0 switches mcmc_hip_step to the dragging
  * step (mcmc.py:564-668) with blocks 0..drag_last_slow slow and drag_steps interpolation
- * steps; -1 keeps Metropolis steps.  d <= 32 only.  Must precede set_proposal_cov (a previous
- * covariance is forgotten).  One block with factor 1 and the identity order is the default. */
+ * steps; -1 keeps Metropolis steps.  From scratch: the tuned kernels for d <= 32, the general
+ * ones (step_general_kernel, drag_general_kernel) for 32 < d <= 128; with emit_capacity > 0 a
+ * dragging step emits the point it leaves (mcmc.py:656-668) from the from-scratch kernels.  Must
+ * precede set_proposal_cov (a previous covariance is forgotten).  One block with factor 1 and the identity order is the default. */
 MCMC_HIP_API int mcmc_hip_set_blocking(mcmc_hip_ctx* h, int32_t n_blocks, const int32_t* block_size,
                           const int32_t* oversampling, const int32_t* i_of_j,
                           int32_t drag_last_slow, int32_t drag_steps);

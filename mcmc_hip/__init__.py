@@ -47,6 +47,7 @@ else:
         snapshot_every: int | None = HIP_DEFAULTS["snapshot_every"]
         max_rows: int = HIP_DEFAULTS["max_rows"]
         bounds_snapshots: int = HIP_DEFAULTS["bounds_snapshots"]
+        drain_copy: bool = HIP_DEFAULTS["drain_copy"]
         row_buffer_bytes: int = HIP_DEFAULTS["row_buffer_bytes"]
         device_checkpoint: bool | None = HIP_DEFAULTS["device_checkpoint"]
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]

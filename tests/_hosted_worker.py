@@ -267,7 +267,7 @@ def reference_test_mcmc(tmp):
     return out
 
 
-def two_speeds_drag(tmp):
+def two_speeds_drag(tmp, chains=False):
     """The same two-speed model with `drag: True` (tests/test_mcmc.py:129-143 of the reference):
     the slow block is proposed, the fast one dragged along -- through Cobaya's live model, on
     the incremental dragging path."""
@@ -291,6 +291,8 @@ def two_speeds_drag(tmp):
                                  "oversample_power": 0.5, "steps_per_launch": "10d",
                                  "measure_speeds": False, "Rminus1_stop": 0.0,
                                  "max_samples": 60000, "snapshot_every": 10}}}
+    if chains:   # every accepted dragging step closes a weighted row (mcmc.py:656-668, 691-707)
+        info["sampler"]["mcmc_hip"].update(emit="chains", snapshot_every=None, burn_in=5)
     updated, sampler = run(info)
     coll = sampler.products(skip_samples=0.3)["sample"]
     tm = np.array([0.2, 0.0, 0.5, 0.4, 0.6])
@@ -300,7 +302,14 @@ def two_speeds_drag(tmp):
     return {"drag": bool(sampler.drag), "interp": int(sampler.drag_interp_steps),
             "incremental": bool(sampler.incremental), "cycle_length": int(sampler.cycle_length),
             "blocking": updated["sampler"]["mcmc_hip"]["blocking"],
-            "kl": kl_norm(tm, tc, coll.mean(), coll.cov()), "n_rows": len(coll)}
+            "kl": kl_norm(tm, tc, coll.mean(), coll.cov()), "n_rows": len(coll),
+            "max_weight": float(np.max(coll["weight"])), "accepted": int(sampler.n())}
+
+
+def two_speeds_drag_chains(tmp):
+    """tests/test_mcmc.py:132-171 (`test_mcmc_drag_results`) in the reference's own output mode:
+    the dragging sampler's product is a weighted chain."""
+    return two_speeds_drag(tmp, chains=True)
 
 
 def resume(tmp):

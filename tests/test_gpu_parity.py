@@ -361,15 +361,93 @@ def test_dragging_steps_bit_exact(d, W, gs, K, blocks, last_slow, n_drag, steps,
     assert c["accepted"] > 0.05 * W * steps
 
 
+@pytest.mark.parametrize("d,W,gs,K,blocks,last_slow,n_drag,extra", [
+    (5, 256, 64, 1, [[0, 1], [2, 3, 4]], 0, 6, dict(burn_in=2)),
+    (7, 256, 128, 2, [[5], [0, 3], [1], [6, 2, 4]], 1, 3, {}),
+    (6, 128, 64, 1, [[0, 1, 2], [3, 4, 5]], 0, 5,
+     dict(kinds=[0, 1, 0, 1, 0, 0], a=[0.0, 0.5, 0.0, 0.5, 0.0, 0.0],
+          b=[1.0, 0.2, 1.0, 0.3, 1.0, 1.0], periodic=[0, 0, 1, 0, 0, 1], T=1.7))])
+def test_dragging_steps_emit_rows_bit_exact(d, W, gs, K, blocks, last_slow, n_drag, extra):
+    """VERDICT r3 missing 3: every dragging step ends in process_accept_or_reject
+    (mcmc.py:656-668), so with `emit_capacity > 0` the point a walker leaves goes out with its
+    weight -- the rows of drag_kernel equal the oracle's (drag_core -> commit) bit for bit,
+    burn-in included, and per walker the weights of the emitted rows plus the open weight add
+    up to the steps taken."""
+    eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.4, 0.6] if K == 2 else None,
+                              blocks=blocks, over=[1] * (last_slow + 1) + [2] * (len(blocks) - last_slow - 1),
+                              drag_last_slow=last_slow, drag_steps=n_drag, cap=48, **extra)
+    total = np.zeros(W)
+    for n in (1, 30, 17):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+        rows, ref = eng.drain_samples(), st.drain()
+        assert rows.shape == ref.shape
+        assert_bit_equal(rows, ref, "rows")
+        np.add.at(total, rows[:, 0].astype(int), rows[:, 1])
+    assert len(rows) > W // 4 and eng.counters()["dropped_rows"] == 0
+    # a walker's emitted weights + the weight of its open point = the initial 1 + the 48 steps
+    # (points left during the burn-in are dropped, not emitted)
+    spent = total + eng.get_full_state()["weight"]
+    assert np.all(spent <= 49)
+    if not extra.get("burn_in"):
+        assert np.array_equal(spent, np.full(W, 49.0))
+
+
+@pytest.mark.parametrize("d,W,gs,K,blocks,over,extra", [
+    (40, 128, 64, 1, [list(range(25)), list(range(25, 40))], [1, 3], {}),
+    # a one-parameter block, a mixture, a periodic parameter, normal priors, emitted rows
+    (36, 128, 64, 2, [list(range(5, 36)), [2], [0, 1, 3, 4]], [1, 2, 4],
+     dict(kinds=[0] * 30 + [1] * 6, a=[0.0] * 30 + [0.5] * 6, b=[1.0] * 30 + [0.3] * 6,
+          periodic=[0, 0, 0, 1] + [0] * 32, cap=40, burn_in=2)),
+    (100, 64, 64, 1, [list(range(60)), list(range(60, 100))], [1, 2], {})])
+def test_blocked_steps_above_d32_from_scratch_bit_exact(d, W, gs, K, blocks, over, extra):
+    """VERDICT r3 missing 4: parameter blocks / oversampling from scratch above d = 32
+    (step_general_kernel reading the blocked directions): bit for bit the oracle's."""
+    eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.3, 0.7] if K == 2 else None,
+                              blocks=blocks, over=over, **extra)
+    for n in (1, 21, 18):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+        if extra.get("cap"):
+            assert_bit_equal(eng.drain_samples(), st.drain(), "rows")
+    assert eng.last_step_kernel().startswith("mcmc::step_general_kernel")
+    assert eng.counters()["accepted"] == int(st.n_accept.sum()) > 0
+
+
+@pytest.mark.parametrize("d,W,gs,K,blocks,last_slow,n_drag,extra", [
+    (40, 128, 64, 1, [list(range(12)), list(range(12, 40))], 0, 4, {}),
+    (36, 128, 64, 2, [[35], list(range(5, 35)), [2], [0, 1, 3, 4]], 1, 3,
+     dict(kinds=[0] * 30 + [1] * 6, a=[0.0] * 30 + [0.5] * 6, b=[1.0] * 30 + [0.3] * 6,
+          periodic=[0, 0, 0, 1] + [0] * 16 + [1] + [0] * 15, cap=24, burn_in=1, T=1.3)),
+    (72, 64, 64, 1, [list(range(30)), list(range(30, 72))], 0, 2, dict(cap=12))])
+def test_dragging_above_d32_from_scratch_bit_exact(d, W, gs, K, blocks, last_slow, n_drag, extra):
+    """VERDICT r3 missing 4: the dragging step from scratch above d = 32 (drag_general_kernel):
+    mixtures, periodic parameters (the DELTA of an interpolation step is wrapped, mcmc.py:606),
+    one-parameter blocks, emitted rows -- the oracle's drag_core bit for bit."""
+    eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.4, 0.6] if K == 2 else None,
+                              blocks=blocks, over=[1] * (last_slow + 1) + [2] * (len(blocks) - last_slow - 1),
+                              drag_last_slow=last_slow, drag_steps=n_drag, **extra)
+    for n in (1, 11, 9):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+        if extra.get("cap"):
+            assert_bit_equal(eng.drain_samples(), st.drain(), "rows")
+    assert eng.last_step_kernel().startswith("mcmc::drag_general_kernel")
+    assert eng.counters()["accepted"] == int(st.n_accept.sum()) > 0
+
+
 def test_blocking_errors_are_loud():
     eng = E.Engine(4, 64, group_size=64, seed=1)
     with pytest.raises(E.EngineError, match="do not contain all"):
         eng.set_blocking([[0, 1], [1, 3]], [1, 2])
     with pytest.raises(E.EngineError, match="Oversampling factors"):
         eng.set_blocking([[0, 1], [2, 3]], [1, 0])
-    big = E.Engine(40, 64, group_size=64, seed=1)
-    with pytest.raises(E.EngineError, match="d <= 32"):
-        big.set_blocking([list(range(20)), list(range(20, 40))], [1, 2])
 
 
 def test_paired_kernel_with_temperature_bit_exact():

