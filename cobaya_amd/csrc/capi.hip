@@ -301,6 +301,7 @@ extern "C" hipError_t mcmc_hip_launch_pl_prior(const double* t, int n, int d, co
 extern "C" hipError_t mcmc_hip_launch_pl_residual(const mcmc::PlResidualArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_bin(const mcmc::PlBinArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_residual_mfma(const mcmc::PlResidualMfmaArgs* a, hipStream_t st);
+extern "C" hipError_t mcmc_hip_launch_pl_fused(const mcmc::PlFusedArgs* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_chi2(const mcmc::PlChi2Args* a, hipStream_t st);
 extern "C" hipError_t mcmc_hip_launch_pl_combine(const double* psum, double* chi2, int n, hipStream_t st);
 
@@ -423,6 +424,10 @@ struct mcmc_hip_ctx {
         std::vector<int32_t> bins;                       // [n_bins][3]
         std::vector<double> Linv, Bc0, BJ;               // host copies (tests hand them to the oracle)
         DevBuf<double> resp, theta0, Astream, weights, X, bjs, es;   // bjs, es: pl_residual_mfma_kernel
+        DevBuf<double> Afused;                           // pl_fused_kernel: half-tile streams of L^-1
+        unsigned long long f_off[8][5][2];
+        int f_pairs[8][5][2];
+        int f_shift = 0, f_ng = 0;
         DevBuf<int> dbins;
         DevBuf<double> delta, trial, lp_t, Ea, psum;     // step scratch, W walkers
         DevBuf<double> edelta, etrial, elp, echi2, epsum, ecl, eA;   // evaluate scratch
@@ -674,9 +679,12 @@ int set_target_common(mcmc_hip_ctx* h, int K, const double* means, const double*
 
 
 // ------------------------------------------------------------------ binned Gaussian target
-// wave of pl_chi2_kernel that owns row tile R of NT (oracle: binned_class): a snake deal from
-// the last -- the most expensive -- tile down
-inline int binned_class(int R, int NT) { const int m = (NT - 1 - R) & 15; return m < 8 ? m : 15 - m; }
+// chain of the chi2 sum that row tile R of NT joins (oracle: binned_class): its position in its
+// group of eight tiles, the groups counted down from the last tile.  pl_fused_kernel gives the
+// tile at a position to one wave per pair of walker tiles; pl_chi2_kernel (explicit points) gives
+// wave q the tiles of class q.
+inline int binned_shift(int NT) { return (8 - NT % 8) % 8; }
+inline int binned_class(int R, int NT) { return (R + binned_shift(NT)) & 7; }
 
 // the 32 partial sums of chi2 per walker of the residuals held in `delta` (n walkers, a multiple
 // of 64) -> psum[32][n]; chi2 (may be null): their combination, one value per walker
@@ -761,7 +769,10 @@ int step_binned(mcmc_hip_ctx* h, int n_steps)
     HIP_TRY(h, B.lp_t.resize(W));
     HIP_TRY(h, B.Ea.resize(W));
     HIP_TRY(h, B.psum.resize((size_t)32 * W));
-    HIP_TRY(h, B.delta.resize(((size_t)W / 64) * (size_t)B.KT * 256 + (size_t)mcmc::kPlPad * 256));
+    // MCMC_HIP_PL_UNFUSED (developer switch): residuals and chi2 as two launches (round 3)
+    static const bool unfused = getenv("MCMC_HIP_PL_UNFUSED") != nullptr;
+    if (unfused)    // (fused: delta lives in LDS, 323 MB of HBM less at 65 536 walkers)
+        HIP_TRY(h, B.delta.resize(((size_t)W / 64) * (size_t)B.KT * 256 + (size_t)mcmc::kPlPad * 256));
     const size_t dd = (size_t)mcmc::v_slab(d);
     const int max_cyc = (int)std::max<size_t>(1, (64u << 20) / (sizeof(double) * dd * (size_t)h->G));
     mcmc::PlWalkerArgs a{};
@@ -802,17 +813,27 @@ int step_binned(mcmc_hip_ctx* h, int n_steps)
                 Timed t(h, 3);
                 HIP_TRY(h, mcmc_hip_launch_pl_walker(&a, pending ? 1 : 0, 1, h->stream));
             }
-            {
-                Timed t(h, 4);
-                const int rc = binned_residual(h, B.trial.p, B.delta.p, W);
-                if (rc) return rc;
-            }
-            {
+            if (unfused) {
+                {
+                    Timed t(h, 4);
+                    const int rc = binned_residual(h, B.trial.p, B.delta.p, W);
+                    if (rc) return rc;
+                }
                 Timed t(h, 5);
                 const int rc = binned_chi2(h, B.delta.p, B.psum.p, nullptr, W);
                 if (rc) return rc;
-                h->n_step_launches += 1;
+            } else {
+                Timed t(h, 5);
+                mcmc::PlFusedArgs f{};
+                f.trial = B.trial.p; f.theta0 = B.theta0.p; f.bjs = B.bjs.p; f.es = B.es.p;
+                f.Astream = B.Afused.p; f.psum = B.psum.p;
+                std::memcpy(f.a_off, B.f_off, sizeof f.a_off);
+                std::memcpy(f.a_pairs, B.f_pairs, sizeof f.a_pairs);
+                f.W = W; f.KT = B.KT; f.n_lin = B.n_lin; f.np = (B.n_lin + 7) / 8; f.calib = B.calib;
+                f.n_tiles = (B.KT + 3) / 4; f.shift = B.f_shift; f.ng = B.f_ng; f.n_sets = W / 64;
+                HIP_TRY(h, mcmc_hip_launch_pl_fused(&f, h->stream));
             }
+            h->n_step_launches += 1;
             pending = true;
             h->step += 1;
         }
@@ -1035,7 +1056,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     h->inc_mean.release();
     {
         auto& B = h->bg;
-        B.bjs.release(); B.es.release();
+        B.bjs.release(); B.es.release(); B.Afused.release();
         B.resp.release(); B.theta0.release(); B.Astream.release(); B.weights.release();
         B.X.release(); B.dbins.release(); B.delta.release(); B.trial.release(); B.lp_t.release();
         B.Ea.release(); B.psum.release(); B.epsum.release(); B.edelta.release(); B.etrial.release(); B.elp.release();
@@ -1237,6 +1258,35 @@ int mcmc_hip_set_target_binned_gaussian(mcmc_hip_ctx* h, int32_t n_bins, const i
         }
     }
     As.resize(As.size() + (size_t)mcmc::kPlPad * 64, 0.0);   // (operands are fetched ahead)
+    // pl_fused_kernel: per wave q and group G of eight virtual tiles (virtual = real + shift) the
+    // tile at position s = min(q, 7 - q) (half 0) and at 7 - s (half 1), each as a stream of its
+    // k-step pairs from pair 0, in A-operand lane order; absent tiles point at a block of zeros
+    {
+        const int sh = binned_shift(NT), NG = (NT + sh) / 8;
+        B.f_shift = sh; B.f_ng = NG;
+        std::vector<double> Af(128, 0.0);       // [0, 128): the zero block
+        for (int q = 0; q < 8; ++q) {
+            const int s_pos = q < 4 ? q : 7 - q;
+            for (int G = 0; G < 5; ++G)
+                for (int hf = 0; hf < 2; ++hf) {
+                    B.f_off[q][G][hf] = 0; B.f_pairs[q][G][hf] = 0;
+                    const int R = 8 * G + (hf ? 7 - s_pos : s_pos) - sh;
+                    if (G >= NG || R < 0 || R >= NT) continue;
+                    const int np2 = std::min(2 * R + 2, B.KT / 2);
+                    B.f_off[q][G][hf] = Af.size();
+                    B.f_pairs[q][G][hf] = np2 + 2 * sh;
+                    for (int P = 0; P < np2; ++P)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 2; ++e) {
+                                const size_t j = 16 * (size_t)R + (l & 15), i = 4 * (size_t)(2 * P + e) + (l >> 4);
+                                Af.push_back((j < n && i <= j) ? B.Linv[j * n + i] : 0.0);
+                            }
+                }
+        }
+        Af.resize(Af.size() + 256, 0.0);
+        HIP_TRY(h, B.Afused.resize(Af.size()));
+        HIP_TRY(h, hipMemcpy(B.Afused.p, Af.data(), sizeof(double) * Af.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY(h, B.resp.resize(resp.size()));
     HIP_TRY(h, B.theta0.resize(th.size()));
     HIP_TRY(h, B.Astream.resize(As.size()));

@@ -36,6 +36,23 @@ struct PlResidualMfmaArgs {
     double* delta;         // as PlResidualArgs
     int W, KT, n_lin, np, calib, n_tiles;
 };
+// pl_fused_kernel: residuals AND the triangular product in one launch; delta never leaves the CU
+constexpr int kPlChunkPairs = 16;   // k-step pairs (= 8 bin tiles = 128 bins) per LDS chunk
+struct PlFusedArgs {
+    const double* trial;   // [d][W]
+    const double* theta0;  // [32]
+    const double* bjs;     // as PlResidualMfmaArgs
+    const double* es;
+    const double* Astream; // half-tile (wave q, group G, half h) at a_off[q][G][h]: [pairs][64][2] doubles in
+                           // A-operand lane order from the tile's FIRST k-step pair, + padding
+    double* psum;          // [8][4][n_walkers]: p[pos][c] of every walker
+    unsigned long long a_off[8][5][2];
+    int a_pairs[8][5][2];  // VIRTUAL pair count of the half-tile (0: absent): pairs [2 shift, a_pairs)
+    int W, KT, n_lin, np, calib, n_tiles;   // n_tiles: real bin tiles (ceil(KT / 4))
+    int shift;             // virtual tile index = real + shift (the tile groups end at the LAST tile)
+    int ng;                // groups of 8 virtual tiles (= chunks)
+    int n_sets, batches;
+};
 struct PlBinArgs {
     const double* cl;      // [n_pts][3][stride], element l - L0 of a row is D_l
     const double* A;       // [n_pts] calibration

@@ -36,6 +36,8 @@
 // per 64 walkers (1.5 MB from L2), delta once per wave; nothing passes through LDS and there is NO
 // barrier: a workgroup takes several sets of 64 walkers in turn (one workgroup per CU for the whole
 // launch), its waves run free and leave their partial sums p[q][c] per walker in memory.
+#include <type_traits>
+
 #include "det_math.h"
 #include "pliklite_args.h"
 
@@ -365,6 +367,303 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
     }   // batches
 }
 
+// ------------------------------------------------------------------------------ fused
+// pl_fused_kernel: pl_residual_mfma_kernel and pl_chi2_kernel in one launch -- delta is produced
+// chunk by chunk into LDS (128 bins x 64 walkers = 64 KB, double-buffered) in the B-operand order
+// and consumed from there; it never crosses HBM (round 3: 643 MB of round trip per launch and a
+// kernel of its own), and every wave reads it from LDS instead of fetching it from L2 on its own.
+//
+// The barrier per chunk this needs would expose the imbalance of the snake deal (a wave's tiles
+// are not equally far along at a given k), so the rows are dealt differently: the 16-row tiles
+// are grouped in eights FROM THE LAST TILE DOWN (virtual tile index = real + shift, shift =
+// (8 - NT mod 8) mod 8, so that every group is complete but possibly the first, cheapest one),
+// group G's diagonal block falls into chunk G, and wave q owns in every group the tile at
+// position s = min(q, 7 - q) for two of the four walker tiles and the tile at position 7 - s for
+// the other two (q < 4: walker tiles {0, 1} | {2, 3}; q >= 4: {2, 3} | {0, 1}): in every chunk
+// every wave has the same work -- 2 (s + 1) + 2 (8 - s) = 18 pair-iterations of two walker tiles in
+// the diagonal group, 16 of four walker tiles in each group above --, so the barrier costs
+// nothing but its latency.  The partial sums are the chains p[pos][c] over the groups ascending
+// (oracle: binned_class(R) = (R + shift) mod 8).  The tiles of L^-1 stream from L2 as before,
+// one 16-byte load per half-tile and pair, re-issued right after their use (one pair ahead).
+// a 16-byte load at (wave-uniform base) + (per-lane 32-bit byte offset): global_load_dwordx4 with an
+// SGPR base -- the address costs one VGPR for all the streams of the kernel
+__device__ __forceinline__ double2 ld16(const void* ubase, unsigned voff)
+{
+    return *(const double2*)((const char*)ubase + voff);
+}
+
+#ifndef PL_PRODUCE_TILES
+#define PL_PRODUCE_TILES 2
+#endif
+#ifndef PL_ORDER_XY
+#define PL_ORDER_XY 1
+#endif
+#ifndef PL_EARLY_PRODUCERS
+#define PL_EARLY_PRODUCERS 1
+#endif
+#ifdef PL_DEBUG_NO_BARRIER
+#define PL_BARRIER() do {} while (0)   // (timing experiment: races)
+#else
+#define PL_BARRIER() __syncthreads()
+#endif
+template <int NG, int NP>
+__global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 lds[];   // [2][16][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, c = lane >> 4, n = lane & 15;
+    const unsigned l16 = (unsigned)lane * 16u;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s_pos = q < 4 ? q : 7 - q;
+    const int ws = q < 4 ? 0 : 2, wl = 2 - ws;          // walker tiles of the short / long half
+    const int wt_p = q & 3, th_p = q >> 2;              // producer: walker tile, half of the chunk's tiles
+    const int sh = a.shift, W = a.W, calib = a.calib;
+    constexpr int CP = kPlChunkPairs;
+    int nS[NG], nL[NG];                                  // real pairs of the half-tiles (0: absent)
+    const char* pS[NG];                                  // their streams (wave-uniform)
+    const char* pL[NG];
+#pragma unroll
+    for (int G = 0; G < NG; ++G) {
+        nS[G] = max(a.a_pairs[q][G][0] - 2 * sh, 0); nL[G] = max(a.a_pairs[q][G][1] - 2 * sh, 0);
+        pS[G] = (const char*)(a.Astream + a.a_off[q][G][0]);
+        pL[G] = (const char*)(a.Astream + a.a_off[q][G][1]);
+    }
+    for (int bt = 0; bt < a.batches; ++bt) {
+        const int wg = blockIdx.x * a.batches + bt;
+        if (wg >= a.n_sets) break;                       // (uniform over the workgroup)
+        // ---- producer: the residuals of chunk m (virtual bin tiles 8 m .. 8 m + 7) for the wave's
+        // walker tile and its half of the tiles -> LDS in B-operand order (pl_residual_mfma_kernel)
+        auto produce = [&](int m) {
+#ifdef PL_DEBUG_SKIP_PRODUCE
+            return;       // (timing experiment: the residuals are garbage)
+#endif
+            // (the lane index goes through an empty asm: everything derived from it below --
+            // eight gather addresses and more -- is then recomputed here instead of being hoisted
+            // out of the chunk loop, where it would sit in registers through the MFMA loops)
+            unsigned lw = l16;
+            asm volatile("; producer lane" : "+v"(lw));
+            const int cc = (int)(lw >> 8), nn = (int)((lw >> 4) & 15u);
+            const unsigned w8 = ((unsigned)wg * 64u + (unsigned)wt_p * 16u + (unsigned)nn) * 8u;
+            double dth[2 * NP];
+#pragma unroll
+            for (int j = 0; j < 2 * NP; ++j) {
+                const int p = 4 * j + cc, i = p + (p >= calib ? 1 : 0);
+#ifdef PL_DEBUG_NO_DTH
+                const double t = (double)(i + (int)w8);
+#else
+                const double t = *(const double*)((const char*)a.trial + ((unsigned)i * (unsigned)W * 8u + w8));
+#endif
+                dth[j] = p < a.n_lin ? t - a.theta0[min(p, 31)] : 0.0;
+            }
+            const double A = *(const double*)((const char*)a.trial + ((unsigned)calib * (unsigned)W * 8u + w8));
+            const double iA2 = 1.0 / (A * A);
+            double2* dst = (double2*)((char*)lds + ((size_t)(m & 1) * CP * 256 + wt_p * 64) * 16 + lw);
+            // PL_PRODUCE_TILES tiles at a time, ALL their operands requested before the first is
+            // used (beside the gathers of dtheta above): one memory latency per group of tiles
+            // instead of one per operand class, and independent accumulator chains for the matrix
+            // pipe (measured: the producer alone 99 us per launch with the loads issued where they
+            // are used -- seven dependent round trips per call)
+#pragma unroll 1
+            for (int j = 0; j < 4; j += PL_PRODUCE_TILES) {
+                bool on[PL_PRODUCE_TILES];
+                double2 av[PL_PRODUCE_TILES][NP], e[PL_PRODUCE_TILES][4];
+#pragma unroll
+                for (int u = 0; u < PL_PRODUCE_TILES; ++u) {
+                    const int T = 8 * m + 4 * th_p + j + u - sh;   // real bin tile
+                    on[u] = T >= 0 && T < a.n_tiles;              // (uniform; off: never read)
+                    const int Tc = on[u] ? T : 0;
+                    const char* bjT = (const char*)(a.bjs + (size_t)Tc * NP * 128);
+                    const char* esT = (const char*)(a.es + (size_t)Tc * 4 * 128);
+#ifdef PL_DEBUG_NO_PLOADS
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[u][k] = make_double2((double)lw, (double)k);
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) av[u][jp] = make_double2((double)jp, (double)lw);
+                    (void)bjT; (void)esT;
+#else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e[u][k] = ld16(esT + k * 1024, lw);
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) av[u][jp] = ld16(bjT + jp * 1024, lw);
+#endif
+                }
+                d4 y[PL_PRODUCE_TILES];
+#pragma unroll
+                for (int u = 0; u < PL_PRODUCE_TILES; ++u) y[u] = d4{e[u][0].x, e[u][0].y, e[u][1].x, e[u][1].y};
+#pragma unroll
+                for (int jp = 0; jp < NP; ++jp) {
+#pragma unroll
+                    for (int u = 0; u < PL_PRODUCE_TILES; ++u)
+                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jp].x, dth[2 * jp], y[u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < PL_PRODUCE_TILES; ++u)
+                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jp].y, dth[2 * jp + 1], y[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < PL_PRODUCE_TILES; ++u) {
+                    if (!on[u]) continue;
+                    const int tl = 4 * th_p + j + u;          // tile of the chunk: pairs 2 tl, 2 tl + 1
+                    dst[(size_t)(2 * tl) * 256] = make_double2(fma(-y[u][0], iA2, e[u][2].x), fma(-y[u][1], iA2, e[u][2].y));
+                    dst[(size_t)(2 * tl + 1) * 256] = make_double2(fma(-y[u][2], iA2, e[u][3].x), fma(-y[u][3], iA2, e[u][3].y));
+                }
+            }
+        };
+        // ---- consumer state
+        d4 acc[NG][4];
+        double2 aS[NG], aL[NG];      // operands of the next pair of every half-tile
+#pragma unroll
+        for (int G = 0; G < NG; ++G) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[G][j] = d4{0.0, 0.0, 0.0, 0.0};
+            aS[G] = ld16(pS[G], l16);     // real pair 0 (absent half-tiles point at zeros)
+            aL[G] = ld16(pL[G], l16);
+        }
+        double pch[4] = {0.0, 0.0, 0.0, 0.0};   // the chains p[pos][c] of the wave's four columns
+        produce(0);
+        PL_BARRIER();
+#pragma unroll
+        for (int m = 0; m < NG; ++m) {
+#if PL_EARLY_PRODUCERS
+            // the two waves of a SIMD (q and q + 4) take turns: the first produces the next chunk
+            // BEFORE it consumes this one, the second after -- a producer (a latency-bound chain)
+            // then always runs beside a consumer (MFMA-bound) on its SIMD
+            if (m + 1 < NG && q < 4) produce(m + 1);
+#endif
+            // (as in the producer: the lane offset is laundered per chunk, so that the LDS and
+            // stream addresses of the five unrolled chunks are not all computed up front and
+            // kept in registers for the whole set)
+            unsigned lm = l16;
+            asm volatile("; chunk lane" : "+v"(lm));
+            const char* const buf = (const char*)lds + (size_t)(m & 1) * CP * 4096 + lm;
+            // pairs of this chunk: virtual [16 m, 16 m + 16); real = virtual - 2 shift
+            const int base = CP * m - 2 * sh;            // real pair of i = 0
+            const int i0 = m == 0 ? 2 * sh : 0;
+            const int cS = min(max(nS[m] - base, 0), CP), cL = min(max(nL[m] - base, 0), CP);
+            // one pair-iteration: B operands from LDS, for every active half-tile two MFMAs per
+            // walker tile, then the operands of its next pair
+            // B operands of pair i0; from then on each pair's operands are re-read for the NEXT pair
+            // right behind their last use (the short half-tiles' behind the short MFMAs, ...), so
+            // that the LDS latency hides behind the other half's MFMAs
+            double2 b0 = *(const double2*)(buf + (size_t)i0 * 4096 + ws * 1024);
+            double2 b1 = *(const double2*)(buf + (size_t)i0 * 4096 + ws * 1024 + 1024);
+            double2 b2 = *(const double2*)(buf + (size_t)i0 * 4096 + wl * 1024);
+            double2 b3 = *(const double2*)(buf + (size_t)i0 * 4096 + wl * 1024 + 1024);
+            auto step = [&](int i, auto DS, auto DL) {
+                const int Pn = base + i + 1;             // the real pair that comes next
+                const char* const bn = buf + (size_t)min(i + 1, CP - 1) * 4096;
+#if PL_ORDER_XY
+                // first k-step of every active short half-tile, then the second (a dependent MFMA is
+                // then 2 x groups apart from its predecessor, as in pl_chi2_kernel), each followed by
+                // the reload of its operands
+#pragma unroll
+                for (int G = m; G < NG; ++G)
+                    if (G > m || decltype(DS)::value) {
+                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b0.x, acc[G][0], 0, 0, 0);
+                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b1.x, acc[G][1], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int G = m; G < NG; ++G)
+                    if (G > m || decltype(DS)::value) {
+                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b0.y, acc[G][0], 0, 0, 0);
+                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b1.y, acc[G][1], 0, 0, 0);
+                        aS[G] = ld16(pS[G] + (size_t)min(Pn, max(nS[G] - 1, 0)) * 1024, lm);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                b0 = *(const double2*)(bn + ws * 1024);
+                b1 = *(const double2*)(bn + ws * 1024 + 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int G = m; G < NG; ++G)
+                    if (G > m || decltype(DL)::value) {
+                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b2.x, acc[G][2], 0, 0, 0);
+                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b3.x, acc[G][3], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int G = m; G < NG; ++G)
+                    if (G > m || decltype(DL)::value) {
+                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b2.y, acc[G][2], 0, 0, 0);
+                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b3.y, acc[G][3], 0, 0, 0);
+                        aL[G] = ld16(pL[G] + (size_t)min(Pn, max(nL[G] - 1, 0)) * 1024, lm);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
+#pragma unroll
+                for (int G = m; G < NG; ++G) {
+                    const bool useS = G > m || decltype(DS)::value;
+                    if (useS) {
+                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b0.x, acc[G][0], 0, 0, 0);
+                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b1.x, acc[G][1], 0, 0, 0);
+                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b0.y, acc[G][0], 0, 0, 0);
+                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b1.y, acc[G][1], 0, 0, 0);
+                        aS[G] = ld16(pS[G] + (size_t)min(Pn, max(nS[G] - 1, 0)) * 1024, lm);
+                        // (the reload stays BEHIND the MFMAs that read the old pair: hoisted, the
+                        // ten loads of an iteration would double the operand registers)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                b0 = *(const double2*)(bn + ws * 1024);
+                b1 = *(const double2*)(bn + ws * 1024 + 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int G = m; G < NG; ++G) {
+                    const bool useL = G > m || decltype(DL)::value;
+                    if (useL) {
+                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b2.x, acc[G][2], 0, 0, 0);
+                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b3.x, acc[G][3], 0, 0, 0);
+                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b2.y, acc[G][2], 0, 0, 0);
+                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b3.y, acc[G][3], 0, 0, 0);
+                        aL[G] = ld16(pL[G] + (size_t)min(Pn, max(nL[G] - 1, 0)) * 1024, lm);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#endif
+                b2 = *(const double2*)(bn + wl * 1024);
+                b3 = *(const double2*)(bn + wl * 1024 + 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using T1 = std::integral_constant<bool, true>;
+            using T0 = std::integral_constant<bool, false>;
+            // (cS <= cL always: the long half-tile sits at the higher position of its group, and
+            // the absent virtual tiles are the lowest positions of group 0)
+            int i = i0;
+#ifdef PL_DEBUG_SKIP_CONSUME
+            i = CP;       // (timing experiment: no triangular product)
+#endif
+#pragma unroll 1
+            for (; i < cS; ++i) step(i, T1{}, T1{});
+#pragma unroll 1
+            for (; i < cL; ++i) step(i, T0{}, T1{});
+            if (m + 1 < NG) {
+#pragma unroll 1
+                for (; i < CP; ++i) step(i, T0{}, T0{});
+            }
+            // group m is complete (its diagonal block lies in this chunk): its rows join the
+            // chains -- groups ascending, r = 0..3 -- and its 32 accumulator registers are free
+            // for the producer of the next chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pch[j] = fma(acc[m][j][r], acc[m][j][r], pch[j]);
+#if PL_EARLY_PRODUCERS
+            if (m + 1 < NG && q >= 4) produce(m + 1);
+#else
+            if (m + 1 < NG) produce(m + 1);
+#endif
+            PL_BARRIER();
+        }
+        unsigned le = l16;
+        asm volatile("; epilogue lane" : "+v"(le));
+        const unsigned ce = le >> 8, ne = (le >> 4) & 15u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pos = j < 2 ? s_pos : 7 - s_pos;
+            const int wt = (j < 2 ? ws : wl) + (j & 1);
+            a.psum[(size_t)(pos * 4 + ce) * a.W + (size_t)wg * 64 + wt * 16 + ne] = pch[j];
+        }
+    }
+}
+
 // chi2 of a walker from the 32 partial sums pl_chi2_kernel left (oracle: orc_binned_chi2_of_delta)
 __device__ __forceinline__ double pl_combine(const double* __restrict__ psum, size_t W, size_t w)
 {
@@ -463,6 +762,51 @@ extern "C" hipError_t mcmc_hip_launch_pl_chi2(const PlChi2Args* a, hipStream_t s
                                          "mcmc::pl_chi2_kernel<5>"};
     mcmc_hip_note_step_kernel(names[a->ntw - 1]);
     return hipGetLastError();
+}
+
+template <int NG>
+static hipError_t launch_pl_fused_ng(const PlFusedArgs& b, dim3 g, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(double2) * 2 * kPlChunkPairs * 256;   // 128 KB
+    auto go = [&](auto kern) -> hipError_t {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, g, dim3(512), lds, st, b);
+        return hipGetLastError();
+    };
+    switch (b.np) {
+    case 1: return go(pl_fused_kernel<NG, 1>);
+    case 2: return go(pl_fused_kernel<NG, 2>);
+    case 3: return go(pl_fused_kernel<NG, 3>);
+    case 4: return go(pl_fused_kernel<NG, 4>);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+extern "C" hipError_t mcmc_hip_launch_pl_fused(const PlFusedArgs* a, hipStream_t st)
+{
+    PlFusedArgs b = *a;
+    b.batches = (a->n_sets + 255) / 256;     // one workgroup per CU for the whole launch
+    const dim3 g((a->n_sets + b.batches - 1) / b.batches);
+    static const char* const names[5] = {"mcmc::pl_fused_kernel<1>", "mcmc::pl_fused_kernel<2>",
+                                         "mcmc::pl_fused_kernel<3>", "mcmc::pl_fused_kernel<4>",
+                                         "mcmc::pl_fused_kernel<5>"};
+    hipError_t e;
+    switch (a->ng) {
+    case 1: e = launch_pl_fused_ng<1>(b, g, st); break;
+    case 2: e = launch_pl_fused_ng<2>(b, g, st); break;
+    case 3: e = launch_pl_fused_ng<3>(b, g, st); break;
+    case 4: e = launch_pl_fused_ng<4>(b, g, st); break;
+    case 5: e = launch_pl_fused_ng<5>(b, g, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    if (e == hipSuccess) mcmc_hip_note_step_kernel(names[a->ng - 1]);
+    return e;
 }
 
 extern "C" hipError_t mcmc_hip_launch_pl_combine(const double* psum, double* chi2, int n, hipStream_t st)

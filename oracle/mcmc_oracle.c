@@ -233,10 +233,10 @@ typedef struct {
  *   chi2      y_j = fma chain over i = 0..j ascending of Linv[j][i] delta_i from +0, with
  *             cov = L L^T (the same quadratic form as invcov.dot(diff).dot(diff));  the squares
  *             are summed in 32 interleaved chains p[q][c] over the rows with j mod 4 = c and
- *             class(j div 16) = q; with NT = ceil(n_bins / 16) tiles and m = (NT - 1 - R) mod 16,
- *             class(R) = m < 8 ? m : 15 - m (wave q of the chi2 kernel owns the 16-row tiles of
- *             class q -- a snake deal from the last, most expensive, tile down -- and lane
- *             class c their rows 4r + c),
+ *             class(j div 16) = q; with NT = ceil(n_bins / 16) tiles, class(R) = (R + shift) mod 8,
+ *             shift = (8 - NT mod 8) mod 8: the position of tile R in its group of eight, the
+ *             groups counted down from the last tile (the fused kernel gives the tile at a
+ *             position to one wave per pair of walker tiles, and lane class c its rows 4r + c),
  *             s_q = (p[q][0] + p[q][1]) + (p[q][2] + p[q][3]),
  *             chi2 = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
  *   loglike   -chi2 / 2. */
@@ -475,7 +475,8 @@ static inline double wrap_periodic(double t, double lo, double hi)
 }
 
 /* ------------------------------------------------------------------ binned Gaussian (plik-lite) */
-static inline int binned_class(int R, int NT) { int m = (NT - 1 - R) & 15; return m < 8 ? m : 15 - m; }
+/* position of 16-row tile R in its group of eight, the groups counted down from the LAST tile */
+static inline int binned_class(int R, int NT) { return (R + ((8 - NT % 8) % 8)) & 7; }
 
 /* chi2 of a residual vector (order: see orc_binned) */
 double orc_binned_chi2_of_delta(const orc_binned* b, const double* delta)

@@ -114,7 +114,7 @@ def test_binned_steps_bit_exact(case, W, gs, steps, T):
     c = eng.counters()
     assert c["steps"] == steps and c["accepted"] == int(st.n_accept.sum())
     assert 0.05 < c["accepted"] / (W * steps) < 0.9
-    assert "pl_chi2_kernel" in eng.last_step_kernel()
+    assert "pl_fused_kernel" in eng.last_step_kernel()
 
 
 def test_binned_target_refuses_what_it_does_not_cover():
