@@ -137,3 +137,52 @@ def test_binned_target_refuses_what_it_does_not_cover():
         eng.set_target_binned_gaussian(target, P.synthetic_emulator(4, ds.lmax), calib_index=4)
     with pytest.raises(E.EngineError, match="calibration"):
         eng.set_target_binned_gaussian(target, emu, calib_index=9)
+
+
+def test_binned_target_posterior_on_the_device_at_the_baseline_size():
+    """VERDICT r3 item 9 (Tier C for the plik-lite target, so far on the CPU oracle only): 65 536
+    walkers on the 613-bin target through the sampler; the posterior of (theta, A_planck) is
+    Gaussian to a very good approximation (Cl linear in theta, the calibration pinned by its
+    0.25 % prior), so the pooled ensemble must reproduce the Fisher covariance and the mean the
+    Gaussian approximation predicts -- to 2 % of sigma / 3 % (the approximation, not the sampler,
+    sets that bar)."""
+    from cobaya_amd import pliklite as Pk
+    from cobaya_amd.model import ProblemSpec
+    from cobaya_amd.sampler import MCMCHip
+    ds = Pk.synthetic_dataset(0)
+    target = Pk.BinnedGaussian.from_dataset(ds)
+    emu = Pk.synthetic_emulator(26, ds.lmax)
+    C = Pk.fisher_covariance(target, emu)
+    sig = np.sqrt(np.diag(C))
+    params = {n: {"prior": {"min": float(emu.theta0[i] - 8 * sig[i]), "max": float(emu.theta0[i] + 8 * sig[i])},
+                  "ref": {"dist": "norm", "loc": float(emu.theta0[i]), "scale": float(sig[i])}}
+              for i, n in enumerate(emu.names)}
+    params["A_planck"] = {"prior": {"dist": "norm", "loc": 1.0, "scale": 0.0025},
+                          "ref": {"dist": "norm", "loc": 1.0, "scale": 0.002}}
+    info = {"likelihood": {"plik": {"class": "planck_pliklite", "dataset": ds, "cl_emulator": emu}},
+            "params": params}
+    s = MCMCHip({"seed": 12, "n_walkers": 65536, "steps_per_launch": 54, "covmat": C,
+                 "covmat_params": list(params), "learn_proposal": False, "Rminus1_stop": 0.0,
+                 "snapshot_every": 540, "max_samples": 65536 * 540 * 10 * 0.4, "max_rows": 1 << 20},
+                ProblemSpec.from_info(info))
+    s.run()
+    assert "pl_fused_kernel<5>" in s.engine.last_step_kernel()
+    coll = s.products(skip_samples=0.45)["sample"]
+    assert len(coll) >= 4 * 65536
+    # the Gaussian approximation's mean: theta0 + C B^T Sigma^-1 (X - cl(theta0)) -- Newton step from the fiducial
+    n = emu.n
+    tab = target.bin_table()
+    Bm = np.zeros((target.n_bins, n + 1))
+    cl0 = np.zeros(target.n_bins)
+    for ib, (tp, a_, b_) in enumerate(tab):
+        wv = target.weights[a_:b_ + 1]
+        Bm[ib, :n] = wv @ emu.J[tp, a_:b_ + 1, :]
+        cl0[ib] = wv @ emu.D0[tp, a_:b_ + 1]
+        Bm[ib, n] = -2.0 * cl0[ib]
+    grad = Bm.T @ np.linalg.solve(target.cov, target.X_data - cl0)
+    mean = np.concatenate((emu.theta0, [1.0])) + C @ grad
+    acc = s.engine.counters()
+    assert 0.1 < acc["accepted"] / (acc["steps"] * 65536) < 0.5
+    assert np.max(np.abs(coll.mean() - mean) / sig) < 0.02
+    assert np.max(np.abs(coll.cov() - C) / np.outer(sig, sig)) < 0.03
+    s.close()
