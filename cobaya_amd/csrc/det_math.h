@@ -319,6 +319,21 @@ __device__ __forceinline__ double sqrt_midrange(double a)
     return g;
 }
 
+// The far tail of a short uniform (oracle: pair_tail): a variate whose 24- / 28-bit uniform fell
+// into the LOWEST bin stands for u in (0, 2^-b); it is redrawn there at full width -- u = 2^-b u',
+// u' = u52 of a Philox block of its own (walker, kStreamStep | 0x8000 | which << 13, step) --, so
+// -log u = b ln 2 - log u': the exponential laws of |r| and of the accept variate have their exact
+// tails instead of ending at 17.3 / 20.1.  Rare (2^-24 / 2^-28 per step and
+// walker): kept out of line, behind a wave-uniform branch.
+__device__ __attribute__((noinline)) double pair_tail(uint32_t key0, uint32_t key1, uint32_t gid,
+                                                       unsigned long long step, uint32_t which, double bits)
+{
+    constexpr double LN2 = 6.93147180559945286227e-01;
+    const u32x4 q = philox4x32_10(key0, key1, gid, kStreamStep | 0x8000u | (which << 13),
+                                  (uint32_t)step, (uint32_t)(step >> 32));
+    return fma(bits, LN2, -dlog(u52(((uint64_t)q.w0 << 20) | (q.w1 >> 12))));
+}
+
 struct PairRng {
     double r[2], Ea[2];
     __device__ __forceinline__ void run(uint32_t key0, uint32_t key1, uint32_t gid,
@@ -335,13 +350,21 @@ struct PairRng {
             const uint32_t a = w[2 * h], b = w[2 * h + 1];
             const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28);
             const uint32_t ka = b & 0x0FFFFFFFu;
-            const double Er = neg_log_short(2u * kr + 1u, 25, tab);
-            // (2 E_r lies in [2^-24, 35])
+            double Er = neg_log_short(2u * kr + 1u, 25, tab);
+            double Eah = neg_log_short(2u * ka + 1u, 29, tab);
+            if (lanes((kr == 0u) | (ka == 0u)) != 0ull) {   // wave-uniform, rare: the lowest bins
+                const unsigned long long step = 2ull * pair + (unsigned long long)h;
+                const double tr = pair_tail(key0, key1, gid, step, 0u, 24.0);
+                const double ta = pair_tail(key0, key1, gid, step, 1u, 28.0);
+                Er = kr == 0u ? tr : Er;
+                Eah = ka == 0u ? ta : Eah;
+            }
+            // (2 E_r lies in [2^-24, 35], or up to ~110 after a redraw of the tail)
             const double rr = sel(lanes(((a >> 20) & 0x7FFu) < 676u), Er, sqrt_midrange(2.0 * Er));
             // sign: bit 31 of a set = positive
             r[h] = __longlong_as_double(__double_as_longlong(rr) ^
                                         ((long long)(~a & 0x80000000u) << 32));
-            Ea[h] = neg_log_short(2u * ka + 1u, 29, tab);
+            Ea[h] = Eah;
         }
     }
 };

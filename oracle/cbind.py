@@ -95,6 +95,9 @@ def lib():
         L.orc_neg_log_short.restype = C.c_double
         L.orc_neg_log_short.argtypes = [C.c_uint32, C.c_int32]
         L.orc_pair_variates.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, c_double_p, c_double_p]
+        L.orc_find_short_tail.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                          C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.orc_find_short_tail.restype = C.c_int
         L.orc_sincos2pi.argtypes = [C.c_uint64, c_double_p, c_double_p]
         L.orc_haar_from_normals.argtypes = [C.c_int, c_double_p, c_double_p]
         L.orc_basis.argtypes = [C.POINTER(_Problem), C.c_uint32, C.c_uint32, c_double_p]
@@ -167,6 +170,16 @@ def pair_variates(seed, gid, step):
     r, e = C.c_double(), C.c_double()
     lib().orc_pair_variates(int(seed), int(gid), int(step), C.byref(r), C.byref(e))
     return r.value, e.value
+
+
+def find_short_tail(seed, gid0, n_walkers, step0, n_steps, which):
+    """First (walker, step) in the given ranges whose short radial (which = 0) / accept (which = 1)
+    uniform fell into the lowest bin, or None."""
+    g, st = C.c_uint32(), C.c_uint64()
+    if lib().orc_find_short_tail(int(seed), int(gid0), int(n_walkers), int(step0), int(n_steps),
+                                 int(which), C.byref(g), C.byref(st)):
+        return g.value, st.value
+    return None
 
 
 def sincos2pi(k):

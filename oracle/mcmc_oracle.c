@@ -862,6 +862,19 @@ static inline void walker_variates(uint32_t k0, uint32_t k1, uint32_t gid, uint6
  * u_r = (2 k_r + 1) 2^-25; k_a = b & 0xFFFFFFF (28 bits), u_a = (2 k_a + 1) 2^-29.  The two
  * logarithms are short-argument ones (orc_neg_log_short). */
 void orc_pair_variates(uint64_t seed, uint32_t gid, uint64_t step, double* r_out, double* Ea_out);
+/* The far tail of a short uniform: a variate whose 24- / 28-bit uniform fell into the LOWEST bin
+ * stands for u in (0, 2^-b) and is redrawn there at full width, u = 2^-b u', u' = u52 of the block
+ * (walker, STREAM_STEP | 0x8000 | which << 13, step): -log u = fma(b, ln 2, -log u'). */
+static inline double pair_tail(uint32_t k0, uint32_t k1, uint32_t gid, uint64_t step, uint32_t which,
+                               double bits)
+{
+    static const double LN2 = 6.93147180559945286227e-01;
+    uint32_t wd[4];
+    philox4x32_10(k0, k1, gid, STREAM_STEP | 0x8000u | (which << 13), (uint32_t)step,
+                  (uint32_t)(step >> 32), wd);
+    return fma(bits, LN2, -orc_dlog(u52(((uint64_t)wd[0] << 20) | (wd[1] >> 12))));
+}
+
 static inline void walker_variates_pair(uint32_t k0, uint32_t k1, uint32_t gid, uint64_t step,
                                         double* r_out, double* Ea_out)
 {
@@ -871,15 +884,40 @@ static inline void walker_variates_pair(uint32_t k0, uint32_t k1, uint32_t gid, 
     const uint32_t a = wd[2 * (step & 1)], b = wd[2 * (step & 1) + 1];
     const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28);
     const uint32_t ka = b & 0x0FFFFFFFu;
-    const double Er = orc_neg_log_short(2 * kr + 1, 25);
+    const double Er = kr ? orc_neg_log_short(2 * kr + 1, 25) : pair_tail(k0, k1, gid, step, 0, 24.0);
     const double rr = (((a >> 20) & 0x7FFu) < 676u) ? Er : sqrt(2.0 * Er);
     *r_out = (a & 0x80000000u) ? rr : -rr;
-    *Ea_out = orc_neg_log_short(2 * ka + 1, 29);
+    *Ea_out = ka ? orc_neg_log_short(2 * ka + 1, 29) : pair_tail(k0, k1, gid, step, 1, 28.0);
 }
 
 void orc_pair_variates(uint64_t seed, uint32_t gid, uint64_t step, double* r_out, double* Ea_out)
 {
     walker_variates_pair((uint32_t)seed, (uint32_t)(seed >> 32), gid, step, r_out, Ea_out);
+}
+
+/* Test helper: the first (walker, step) with walker in [gid0, gid0 + n_walkers) and step in
+ * [step0, step0 + n_steps) whose short radial (which = 0: 24 bits) or accept (which = 1: 28 bits)
+ * uniform fell into the lowest bin -- the draws pair_tail serves.  Returns 1 if found. */
+int orc_find_short_tail(uint64_t seed, uint32_t gid0, uint32_t n_walkers, uint64_t step0,
+                        uint64_t n_steps, int32_t which, uint32_t* gid_out, uint64_t* step_out)
+{
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (uint64_t P = step0 >> 1; 2 * P < step0 + n_steps; ++P)
+        for (uint32_t w = 0; w < n_walkers; ++w) {
+            uint32_t wd[4];
+            philox4x32_10(k0, k1, gid0 + w, STREAM_STEP | 0x4000u, (uint32_t)P, (uint32_t)(P >> 32), wd);
+            for (int h = 0; h < 2; ++h) {
+                const uint64_t step = 2 * P + (uint64_t)h;
+                if (step < step0 || step >= step0 + n_steps) continue;
+                const uint32_t a = wd[2 * h], b = wd[2 * h + 1];
+                const uint32_t kr = ((a & 0xFFFFFu) << 4) | (b >> 28), ka = b & 0x0FFFFFFFu;
+                if ((which == 0 && kr == 0) || (which == 1 && ka == 0)) {
+                    *gid_out = gid0 + w; *step_out = step;
+                    return 1;
+                }
+            }
+        }
+    return 0;
 }
 
 /* mcmc.py:670-683 with the Exp(1) variate supplied */

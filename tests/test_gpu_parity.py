@@ -848,6 +848,29 @@ def test_directions_computed_ahead_never_change_the_results(d, W, gs, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("which,bound", [(0, 24), (1, 28)])
+def test_short_variates_are_redrawn_in_their_lowest_bin(which, bound):
+    """VERDICT r3 item 9 (law hardening): a paired variate whose 24-bit (radial) / 28-bit (accept)
+    uniform falls into the lowest bin is redrawn there at full width (det_math.h `pair_tail`,
+    oracle `pair_tail`): the exponential laws keep their exact tails beyond 24 ln 2 / 28 ln 2.
+    The oracle finds such a draw (2^-24 / 2^-28 per step and walker); an ensemble that contains
+    that walker runs through that step on the device, bit for bit the oracle's."""
+    seed = 7
+    hit = O.find_short_tail(seed, 0, 1 << 17, 0, 4096, which)
+    assert hit is not None
+    gid, step = hit
+    r, Ea = O.pair_variates(seed, gid, step)
+    assert (abs(r) if which == 0 else Ea) > bound * np.log(2.0)
+    off = gid - gid % 64
+    eng, prob, st = make_pair(4, 64, 64, seed=seed, incremental=True, walker_offset=off)
+    for n in (step - 3, 8):          # the second launch crosses the redrawn step
+        eng.step(n)
+        eng.sync()
+        st.run(n, walker0=off, n_threads=4)
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residual")
+
+
 def test_incremental_mode_refuses_what_it_does_not_cover():
     with pytest.raises(E.EngineError, match="incremental"):
         E.Engine(1, 256, group_size=64, incremental=True)

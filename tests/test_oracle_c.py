@@ -573,6 +573,31 @@ def test_short_argument_logarithm_and_its_table():
             assert abs(v - t) <= 4e-16 * max(1.0, t), (n, nb, v, t)
 
 
+def test_short_variates_lowest_bin_is_redrawn_at_full_width():
+    """the 24-bit radial and the 28-bit accept uniform of the paired stream stand,
+    in their lowest bin, for u in (0, 2^-b): that bin is redrawn at full width from a Philox
+    block of its own, -log u = b ln 2 - log u' -- the variates there exceed the old cut-offs
+    (17.3 / 20.1) and are b ln 2 + an Exp(1) variate."""
+    import math
+    for which, b in ((0, 24), (1, 28)):
+        hits = []
+        g0 = 0
+        while len(hits) < (6 if which == 0 else 2):
+            h = O.find_short_tail(11, g0, 1 << 16, 0, 2048, which)
+            assert h is not None
+            hits.append(h)
+            g0 = h[0] + 1 if h[0] + 1 < (1 << 30) else 0
+            if g0 % (1 << 16):      # continue behind the hit, then the next block of walkers
+                g0 = ((h[0] >> 16) + 1) << 16
+        for gid, step in hits:
+            r, Ea = O.pair_variates(11, gid, step)
+            v = abs(r) if which == 0 else Ea
+            if which == 0 and v * v / 2.0 > b * math.log(2.0) - 1e-9 and v < b * math.log(2.0):
+                v = v * v / 2.0          # the chi(2) branch: |r| = sqrt(2 E)
+            assert v > b * math.log(2.0), (which, gid, step, v)
+            assert v - b * math.log(2.0) < 40.0
+
+
 def test_paired_variates_follow_the_reference_laws():
     """r and E_a of the paired stream, drawn directly: E_a is Exp(1); |r| is Exp(1) with
     probability 676/2048 and chi(2) otherwise (proposal.py:71-82 for n >= 2); the sign is fair
