@@ -745,7 +745,9 @@ def main():
                                                m["evaluation"] == "incremental")
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.shutdown()     # (the communicator is destroyed while every rank is still there)
     return out
 
 

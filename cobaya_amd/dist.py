@@ -20,6 +20,7 @@ import os
 import numpy as np
 
 _comm = None        # cobaya_amd.engine.Communicator: the library's RCCL communicator
+_rccl_error = None  # why the communicator could not be created (then: the gloo stand-in)
 _own_group = False  # the torch.distributed group was created here (shutdown destroys it)
 
 
@@ -99,7 +100,7 @@ def init_from_env(backend=None):
     WORLD_SIZE > 1; a no-op for single-process runs.  `backend` (or $MCMC_HIP_BACKEND):
     "rccl" (default wherever a GPU per rank is visible; "nccl" is accepted as its alias): the
     library's communicator; "gloo": the CPU stand-in."""
-    global _own_group
+    global _own_group, _comm, _rccl_error
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 or _comm is not None:
         return
@@ -117,7 +118,27 @@ def init_from_env(backend=None):
         _td().init_process_group(backend="gloo")   # bootstrap + host-side row gather only
         _own_group = True
     if backend == "rccl":
-        init_native_comm()
+        # Creation is collective; a rank that fails (no RCCL, a refused device, ...) must not
+        # leave the others inside ncclCommInitRank with a different idea of the backend: every
+        # rank reports, and unless ALL succeeded the job falls back -- loudly -- to the gloo
+        # stand-in for the collective (the kernels are unaffected; `describe()` says what runs).
+        err = None
+        try:
+            init_native_comm()
+        except Exception as e:      # EngineError with RCCL's message
+            err = f"{type(e).__name__}: {e}"
+        import torch
+        flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+        _td().all_reduce(flag, op=_td().ReduceOp.MIN)
+        if float(flag[0]) < 0.5:
+            if _comm is not None:
+                _comm.close()
+                _comm = None
+            _rccl_error = err or "another rank could not create its RCCL communicator"
+            import sys
+            print(f"[mcmc_hip] WARNING: the RCCL communicator could not be created on every rank "
+                  f"({_rccl_error}); the checkpoint's all-reduce uses the gloo stand-in",
+                  file=sys.stderr)
 
 
 def shutdown():
@@ -197,6 +218,8 @@ def describe():
     if _comm is not None:
         out["library"] = f"libmcmc_hip.so ({_comm.version}, in-stream ncclAllReduce)"
         out["bootstrap"] = "torch.distributed gloo" if is_initialized() else None
+    if _rccl_error:
+        out["rccl_error"] = _rccl_error
     return out
 
 

@@ -136,3 +136,21 @@ def test_bench_line_through_the_launcher_matches_the_direct_one():
     res = bench("--gpus", "1", "--steps", "8", "--warmup", "4", "--no-variants", "--no-cpu-baseline")
     assert res["n_gpus"] == 1 and res["collective"]["backend"] is None
     assert res["config"]["checkpoint_on"] == "host" and res["value"] > 3e10
+
+
+def test_a_refused_rccl_communicator_falls_back_to_gloo_on_every_rank():
+    """Robustness of the N > 1 start-up: two ranks forced onto RCCL on ONE device -- RCCL refuses
+    (duplicate GPU) --; every rank learns of it through the bootstrap group, the job continues on
+    the gloo stand-in and the bench line says so (`collective.rccl_error`).  With two GPUs this
+    scenario cannot be staged: skipped."""
+    if n_gpus() >= 2:
+        pytest.skip("needs ranks that share a device")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MCMC_HIP_BACKEND"] = "rccl"
+    res = bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--walkers", "16384",
+                "--steps-per-launch", "600", "--cross-check-seconds", "0", env=env)
+    c = res["collective"]
+    assert res["n_gpus"] == 2 and c["backend"] == "gloo" and c["nranks_seen"] == 2
+    assert "rccl_error" in c and "ncclCommInitRank" in c["rccl_error"]
+    assert res["config"]["checkpoint_on"] == "host" and res["value"] > 1e8

@@ -860,7 +860,8 @@ def test_short_variates_are_redrawn_in_their_lowest_bin(which, bound):
     assert hit is not None
     gid, step = hit
     r, Ea = O.pair_variates(seed, gid, step)
-    assert (abs(r) if which == 0 else Ea) > bound * np.log(2.0)
+    # |r| = E on the exponential branch, sqrt(2 E) on the chi(2) branch (proposal.py:79-82)
+    assert (max(abs(r), r * r / 2.0) if which == 0 else Ea) > bound * np.log(2.0)
     off = gid - gid % 64
     eng, prob, st = make_pair(4, 64, 64, seed=seed, incremental=True, walker_offset=off)
     for n in (step - 3, 8):          # the second launch crosses the redrawn step

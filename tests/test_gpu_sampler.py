@@ -591,7 +591,7 @@ def test_three_mode_mixture_at_the_baseline_ensemble_size():
             "sampler": {"mcmc_hip": {"seed": 9, "n_walkers": 65536, "covmat": cov, "covmat_params": names,
                                      "learn_proposal": False, "Rminus1_stop": 0.0, "snapshot_every": 600,
                                      "steps_per_launch": 600, "max_samples": 65536 * 600 * 22 * 0.45,
-                                     "max_rows": 1 << 20}}}
+                                     "max_rows": 1 << 21}}}
     updated, sampler = run(info)
     assert sampler.incremental and "step_inc" in sampler.engine.last_step_kernel()
     coll = sampler.products(skip_samples=0.4)["sample"]
