@@ -274,3 +274,65 @@ def test_random_general_incremental_shapes_bit_exact(seed):
     assert general or tuned, name
     assert ("emit" in name) == bool(cap), name
     eng.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_GENERAL_CASES", "24")))))
+def test_random_blocked_and_dragging_shapes_above_d32_bit_exact(seed):
+    """Round 4: from-scratch parameter blocks / oversampling / dragging at 32 < d <= 128
+    (step_general_kernel with blocks, drag_general_kernel) -- random block structures incl.
+    one-parameter blocks, 0..3 modes, normal priors, periodic parameters, temperature, burn-in,
+    emitted rows -- and rows out of the d <= 32 dragging kernel; uneven launches; state AND
+    drained rows bit for bit the oracle's."""
+    from tests.test_gpu_parity import assert_bit_equal
+    rng = np.random.default_rng(9000 + seed)
+    small = rng.random() < 0.25                     # d <= 32: drag_kernel's rows
+    d = int(rng.integers(4, 33)) if small else int(rng.integers(33, 129))
+    gs = int(rng.choice([64, 128]))
+    W = gs * int(rng.integers(1, 3))
+    K = int(rng.choice([1, 1, 2, 3, 0])) if d <= 64 else int(rng.choice([1, 1, 2]))
+    kw = {}
+    kinds = [0] * d
+    if rng.random() < 0.4:
+        kinds = (rng.random(d) < 0.4).astype(int).tolist()
+        kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.3)) if k else 1.0 for k in kinds])
+    if rng.random() < 0.35:
+        kw["periodic"] = [int(k == 0 and rng.random() < 0.08) for k in kinds]
+    if rng.random() < 0.3:
+        kw["T"] = float(rng.choice([1.5, 2.0]))
+    if rng.random() < 0.3:
+        kw["burn_in"] = int(rng.integers(1, 4))
+    if K > 1:
+        w = rng.uniform(0.2, 1.0, K)
+        kw["weights"] = (w / w.sum()).tolist()
+    perm = rng.permutation(d).tolist()
+    nb = int(rng.integers(2, 5))
+    cuts = sorted(rng.choice(np.arange(1, d), size=nb - 1, replace=False).tolist())
+    if rng.random() < 0.4:                          # force a one-parameter block
+        cuts[0] = 1
+        cuts = sorted(set(cuts))
+        nb = len(cuts) + 1
+    blocks = [perm[a:b] for a, b in zip([0] + cuts, cuts + [d])]
+    drag = small or rng.random() < 0.5
+    if drag:
+        kw.update(blocks=blocks, over=[1] * nb, drag_last_slow=int(rng.integers(0, nb - 1)),
+                  drag_steps=int(rng.integers(2, 5)))
+    else:
+        kw.update(blocks=blocks, over=sorted(int(v) for v in rng.integers(1, 4, size=nb)))
+    cap = int(rng.choice([0, 40]))
+    if small:
+        cap = 40
+    steps = [int(v) for v in rng.integers(1, 14, size=3)]
+    eng, prob, st = make_pair(d, W, gs, K=K, cap=cap, **kw)
+    for n in steps:
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        compare_state(eng, st)
+        if cap:
+            assert_bit_equal(eng.drain_samples(), st.drain(), "rows")
+    kern = eng.last_step_kernel()
+    if not small:
+        assert ("drag_general_kernel" if drag else "step_general_kernel") in kern, kern
+    c = eng.counters()
+    assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
