@@ -84,12 +84,17 @@ def parse():
                     help="untimed launches before the W warmup steps until the device has been "
                          "under load this long (a cold MI355X runs the same kernel 18 %% slower "
                          "for its first ~35 ms: tools/ramp_probe.py); 0 = none")
-    ap.add_argument("--checkpoint-on", dest="device_checkpoint", choices=("device", "host"),
+    ap.add_argument("--checkpoint-on", dest="device_checkpoint", choices=("device", "reduce", "host"),
                     default=None,
-                    help="device: R-1 and the proposal refresh on the device, the all-reduce in "
-                         "place on the engine's stream (`device_checkpoint: True`); host: from "
-                         "the pinned read-back beside the next launch.  Default: the sampler's "
-                         "(host on one GPU, device for N > 1)")
+                    help="device: window sums, the all-reduce (in place on the engine's stream), "
+                         "R-1 and the proposal refresh on the device (`device_checkpoint: True`); "
+                         "reduce: window sums + all-reduce on the device, the solve on the host "
+                         "beside the next launch (`device_checkpoint: reduce`); host: all of it "
+                         "from the pinned read-back beside the next launch.  Default: the "
+                         "sampler's (host on one GPU, reduce for N > 1)")
+    ap.add_argument("--attach-comm", action="store_true",
+                    help="single process: attach a ONE-rank RCCL communicator, so that the "
+                         "checkpoint queues the same ncclAllReduce an N-GPU job does")
     ap.add_argument("--device-checkpoint", dest="device_checkpoint", action="store_const",
                     const="device", help="= --checkpoint-on device")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -290,8 +295,9 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
                          evaluation or a.evaluation)
         if a.basis_group_size and (evaluation or a.evaluation) != "full":
             info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
-    if a.device_checkpoint is not None:   # (default: the sampler's -- device for N > 1)
-        info["sampler"]["mcmc_hip"]["device_checkpoint"] = a.device_checkpoint == "device"
+    if a.device_checkpoint is not None:   # (default: the sampler's -- reduce for N > 1)
+        info["sampler"]["mcmc_hip"]["device_checkpoint"] = {"device": True, "reduce": "reduce",
+                                                            "host": False}[a.device_checkpoint]
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -375,7 +381,9 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
            "group_size": int(sampler.group_size),
            "basis_group_size": int(sampler.basis_group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
            "checkpoint_lag": int(sampler.checkpoint_lag),
-           "checkpoint_on": "device" if sampler._device_ckpt else "host",
+           "checkpoint_on": ("host" if not sampler._device_ckpt else
+                             "device" if sampler._ckpt_solve_on_device else
+                             "device (window sums + all-reduce), host (solve)"),
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps,
            "cross_check": cross}
     sampler.close()
@@ -549,6 +557,8 @@ def main():
     from cobaya_amd import dist
 
     dist.init_from_env()
+    if a.attach_comm and dist.native() is None and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        dist.init_native_comm(0, 1, dist.default_device())
     rank, size = dist.rank(), dist.size()
     if size != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={size}", file=sys.stderr)

@@ -404,9 +404,10 @@ struct mcmc_hip_ctx {
         DevBuf<unsigned long long> acc_prev;
         int cap = 0;               // ring slots
         long long n_done = 0;      // checkpoints taken so far (the next one goes to slot n_done % cap)
-        double* pin_out = nullptr; // [8 + 2 d^2]
+        double* pin_out = nullptr; // [8 + 2 d^2 + d]: the solve's outcome, or the reduced payload
         hipEvent_t ev = nullptr;
         bool begun = false, pending = false;
+        bool payload_only = false; // the pending read-out is the payload (checkpoint_request_payload)
     } ck;
     // R-1 of the confidence bounds (mcmc.py:918-1002): ring of ensemble snapshots [slot][d][W]
     struct Bounds {
@@ -2408,7 +2409,7 @@ int mcmc_hip_checkpoint_set_ring(mcmc_hip_ctx* h, int32_t n_intervals, const dou
         HIP_TRY(h, hipMemset(K.acc_prev.p, 0, sizeof(unsigned long long)));
     }
     if (!K.pin_out)
-        HIP_TRY(h, hipHostMalloc((void**)&K.pin_out, sizeof(double) * (8 + 2 * d * d), hipHostMallocDefault));
+        HIP_TRY(h, hipHostMalloc((void**)&K.pin_out, sizeof(double) * (8 + 2 * d * d + d), hipHostMallocDefault));
     if (!K.ev) HIP_TRY(h, hipEventCreateWithFlags(&K.ev, hipEventDisableTiming));
     return MCMC_HIP_OK;
 }
@@ -2485,6 +2486,44 @@ int mcmc_hip_checkpoint_solve(mcmc_hip_ctx* h, double learn_lo, double learn_hi)
     ++h->dir_epoch;     // the transform may have changed: directions computed ahead are stale
     K.begun = false;
     K.pending = true;
+    K.payload_only = false;
+    return MCMC_HIP_OK;
+}
+
+// The other way to finish a checkpoint begun on the device: only the (all-reduced) payload comes
+// back -- 15 KB behind the launch, one event -- and the host solves it (mcmc_hip_gelman_rubin,
+// mcmc_hip_set_proposal_cov) while the next launch runs: the window sums and the collective stay
+// in stream order on the device, the d^3 work of ONE workgroup leaves the stream.
+int mcmc_hip_checkpoint_request_payload(mcmc_hip_ctx* h)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    auto& K = h->ck;
+    if (!K.begun) return fail(h, MCMC_HIP_ERR_STATE, "checkpoint_begin must precede checkpoint_request_payload");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    const size_t d = h->d;
+    HIP_TRY(h, hipMemcpyAsync(K.pin_out, K.payload.p, sizeof(double) * (5 + 2 * d * d + d),
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(K.ev, h->stream));
+    K.begun = false;
+    K.pending = true;
+    K.payload_only = true;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_checkpoint_fetch_payload(mcmc_hip_ctx* h, double* payload, int32_t n)
+{
+    if (!h || !payload) return MCMC_HIP_ERR_ARG;
+    auto& K = h->ck;
+    if (!K.pending || !K.payload_only)
+        return fail(h, MCMC_HIP_ERR_STATE, "no payload read-out is pending (checkpoint_request_payload)");
+    const size_t d = h->d;
+    if ((size_t)n != 5 + 2 * d * d + d)
+        return fail(h, MCMC_HIP_ERR_ARG, "the payload holds %zu doubles, not %d", 5 + 2 * d * d + d, n);
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipEventSynchronize(K.ev));
+    K.pending = false;
+    K.payload_only = false;
+    std::copy(K.pin_out, K.pin_out + n, payload);
     return MCMC_HIP_OK;
 }
 
@@ -2492,7 +2531,7 @@ int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_
 {
     if (!h || !stats) return MCMC_HIP_ERR_ARG;
     auto& K = h->ck;
-    if (!K.pending) return fail(h, MCMC_HIP_ERR_STATE, "no device checkpoint is pending");
+    if (!K.pending || K.payload_only) return fail(h, MCMC_HIP_ERR_STATE, "no device checkpoint is pending");
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     HIP_TRY(h, hipEventSynchronize(K.ev));
     K.pending = false;

@@ -44,8 +44,14 @@ __global__ void __launch_bounds__(256) ckpt_window_kernel(const CkptWindowArgs a
 // per rank: [G, N_c G, accepted since the last checkpoint, steps since x W, accepted |
 //            sum_g N_c cov_g = S - N_c sum_mm (d x d) | sum_g m_g (d) | sum_g m_g m_g^T (d x d)]
 // (mcmc.py:791-793 gathers N, mean, cov per chain; here a chain is a group of walkers)
+// The chain means are staged through LDS a tile of groups at a time (read straight from L2 the
+// dependent chain over the groups waits for memory at every batch: 41 us at G = 256, d = 30); the
+// terms are still added group by group in ascending order.
+constexpr int kPayloadTileDoubles = 6144;     // 48 KB of LDS
+
 __global__ void __launch_bounds__(256) ckpt_payload_kernel(const CkptPayloadArgs a)
 {
+    __shared__ double tile[kPayloadTileDoubles];
     const int d = a.d, G = a.G;
     const double Nc = a.n_per_chain;
     const double* __restrict__ ms = a.means;             // [G][d] chain means of the window
@@ -62,28 +68,33 @@ __global__ void __launch_bounds__(256) ckpt_payload_kernel(const CkptPayloadArgs
         *a.accept_prev = acc;
     }
     const int npair = d * (d + 1) / 2;
+    int i = 0, j = 0;
     if (tid < npair) {           // (i, j), i >= j
-        int i = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
+        i = (int)((sqrt(8.0 * tid + 1.0) - 1.0) * 0.5);
         while (i * (i + 1) / 2 > tid) --i;
         while ((i + 1) * (i + 2) / 2 <= tid) ++i;
-        const int j = tid - i * (i + 1) / 2;
-        double mm = 0.0;
-        int g = 0;
-        for (; g + 8 <= G; g += 8) {       // (eight pairs of loads in flight; the chain in order)
-            double a8[8], b8[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { a8[q] = ms[(size_t)(g + q) * d + i]; b8[q] = ms[(size_t)(g + q) * d + j]; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) mm = fma(a8[q], b8[q], mm);
+        j = tid - i * (i + 1) / 2;
+    } else if (tid < npair + d) {
+        i = tid - npair;
+    }
+    double mm = 0.0, sm = 0.0;
+    const int gt = kPayloadTileDoubles / d;               // groups per tile
+    for (int g0 = 0; g0 < G; g0 += gt) {
+        const int ng = G - g0 < gt ? G - g0 : gt;
+        __syncthreads();
+        for (int e = threadIdx.x; e < ng * d; e += 256) tile[e] = ms[(size_t)g0 * d + e];
+        __syncthreads();
+        if (tid < npair) {
+            for (int g = 0; g < ng; ++g) mm = fma(tile[g * d + i], tile[g * d + j], mm);
+        } else if (tid < npair + d) {
+            for (int g = 0; g < ng; ++g) sm = sm + tile[g * d + i];
         }
-        for (; g < G; ++g) mm = fma(ms[(size_t)g * d + i], ms[(size_t)g * d + j], mm);
+    }
+    if (tid < npair) {
         const double ncov = S[tid] - Nc * mm;
         P[5 + i * d + j] = P[5 + j * d + i] = ncov;
         P[5 + d * d + d + i * d + j] = P[5 + d * d + d + j * d + i] = mm;
     } else if (tid < npair + d) {
-        const int i = tid - npair;
-        double sm = 0.0;
-        for (int g = 0; g < G; ++g) sm = sm + ms[(size_t)g * d + i];
         P[5 + d * d + i] = sm;
     }
 }
@@ -230,7 +241,12 @@ __device__ double wg_lambda_max(int n, PT A, PT dg, PT eg, PT v, PT p, double* r
         if (q < 0.0) ++cnt;
         for (int i = 1; i < n; ++i) {
             const double den = fabs(q) < 1e-300 ? (q < 0.0 ? -1e-300 : 1e-300) : q;
-            q = dg[i] - x - eg[i - 1] * eg[i - 1] / den;
+            // (hardware reciprocal + one Newton step instead of an IEEE division: the COUNT only
+            // depends on the sign of q, which a relative error of 1e-15 flips only within that
+            // distance of an eigenvalue -- below the resolution of the statistic)
+            double r = __builtin_amdgcn_rcp(den);
+            r = fma(fma(-den, r, 1.0), r, r);
+            q = dg[i] - x - eg[i - 1] * eg[i - 1] * r;
             if (q < 0.0) ++cnt;
         }
         // the first point with all n eigenvalues below it bounds the largest from above

@@ -65,6 +65,8 @@ SYMBOLS = [
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("mcmc_hip_checkpoint_solve", C.c_int, [_H, C.c_double, C.c_double]),
     ("mcmc_hip_checkpoint_fetch", C.c_int, [_H, c_double_p, c_double_p]),
+    ("mcmc_hip_checkpoint_request_payload", C.c_int, [_H]),
+    ("mcmc_hip_checkpoint_fetch_payload", C.c_int, [_H, c_double_p, C.c_int32]),
     ("mcmc_hip_stream_handle", C.c_uint64, [_H]),
     ("mcmc_hip_drain_samples_pinned", C.c_int, [_H, C.POINTER(c_double_p), c_int64_p]),
     ("mcmc_hip_set_drain_slots", C.c_int, [_H, C.c_int32]),
@@ -601,6 +603,19 @@ class Engine:
         return {"Rminus1_groups": st[0], "status": int(st[1]), "refreshed": bool(st[2]),
                 "n_chains": st[3], "sum_N": st[4], "d_accepted": st[5], "d_steps": st[6],
                 "accepted": st[7], "mean_of_covs": cov}
+
+    def checkpoint_request_payload(self):
+        """Instead of `checkpoint_solve`: queue the read-out of the (all-reduced) payload; the
+        caller solves it on the host while the next launch runs."""
+        self._check(self._lib.mcmc_hip_checkpoint_request_payload(self._h))
+
+    def checkpoint_fetch_payload(self):
+        """The payload of the pending request: [chains, sum N, accepted since, steps x walkers
+        since, accepted | sum N cov | sum of chain means | sum of m m^T]."""
+        n = 5 + 2 * self.d * self.d + self.d
+        out = np.empty(n)
+        self._check(self._lib.mcmc_hip_checkpoint_fetch_payload(self._h, _dp(out), n))
+        return out
 
     # -- R-1 of the confidence bounds on the device
     BOUNDS_MAX_SLOTS = 64

@@ -75,16 +75,20 @@ HIP_DEFAULTS = {
                               # "chains": every accepted row with its integer weight
     "snapshot_every": None,   # steps; default = one checkpoint interval
     "max_rows": 1 << 21,      # cap on stored rows per process
-    "device_checkpoint": None,  # True: R-1 and the proposal refresh ON THE DEVICE, in stream order
-                              # (checkpoint_kernels.hip): the refreshed proposal is in force for
-                              # the very next launch and, with several processes, the all-reduce
-                              # runs in place on device memory, queued by the library on the
-                              # engine's stream (RCCL, no host bounce, no host synchronisation).
-                              # False: on the host from the pinned read-back while the next
-                              # launch runs -- measured faster on one GPU (the
-                              # device's single-workgroup linear algebra sits ON the critical
-                              # path, the host's beside it).  None (default): True for several
-                              # processes joined by the library's RCCL communicator, else False
+    "device_checkpoint": None,  # Where the learn / convergence checkpoint runs:
+                              # False: on the host, from the pinned read-back of the moments while
+                              # the next launch runs (the host all-reduces: fastest on one GPU).
+                              # "reduce": window sums, the payload and the all-reduce ON THE DEVICE
+                              # in stream order (RCCL in place, queued by the library on the
+                              # engine's stream: no host bounce, no RCCL kernel beside a step
+                              # kernel); only the reduced 15 KB come back and the host solves them
+                              # (R-1, Cholesky, upload) while the next launch runs.
+                              # True (= "solve"): the solve on the device as well (one workgroup,
+                              # checkpoint_kernels.hip): the refreshed proposal is in force for
+                              # the very next launch and no host is in the loop, at ~0.15 ms of
+                              # single-workgroup linear algebra IN the stream per checkpoint.
+                              # None (default): "reduce" for several processes joined by the
+                              # library's RCCL communicator, else False
     "bounds_snapshots": 16,   # R-1 of the confidence bounds (mcmc.py:918-1002) on the device: ring of
                               # this many ensemble snapshots (d * n_walkers doubles each, a thinned
                               # record of the later half of the run) the per-chain bounds are
@@ -225,6 +229,7 @@ class EnsembleMCMC:
             self._fail("emit must be 'snapshots' or 'chains', got %r", self.emit)
         dist.init_from_env()
         self.rank, self.size = dist.rank(), dist.size()
+        self._ckpt_lag_default = self.checkpoint_lag is None
         if self.checkpoint_lag is None:
             self.checkpoint_lag = 1 if self.size == 1 else 2
         if int(self.checkpoint_lag) != self.checkpoint_lag or int(self.checkpoint_lag) < 1:
@@ -414,20 +419,32 @@ class EnsembleMCMC:
         self.engine.bounds_snapshot(k)
 
     def _init_device_checkpoint(self):
-        """`device_checkpoint: True`: R-1 and the proposal refresh on the device (an option, not the
-        default: on one GPU the host path hides the same work behind the next launch)."""
+        """`device_checkpoint`: which part of the checkpoint runs on the device -- nothing (False),
+        window sums + payload + all-reduce ("reduce"), or the solve as well (True / "solve")."""
         can = hasattr(self.engine, "checkpoint_begin") and dist.device_collective()
-        if self.device_checkpoint and not can:
-            self._fail("device_checkpoint: True needs the HIP engine and, with several processes, "
-                       "the library's RCCL communicator (not the gloo stand-in)")
+        mode = self.device_checkpoint
+        if mode not in (None, False, True, "reduce", "solve"):
+            self._fail("device_checkpoint must be one of False, 'reduce', True (= 'solve') or None, "
+                       "got %r", mode)
+        if mode and not can:
+            self._fail("device_checkpoint: %r needs the HIP engine and, with several processes, "
+                       "the library's RCCL communicator (not the gloo stand-in)", mode)
         # the communicator goes to the engine: its checkpoint reduces in place, in stream order
         attached = can and dist.attach(self.engine)
-        if self.device_checkpoint is None:
-            self.device_checkpoint = bool(attached and self.size > 1)
-        self._device_ckpt = bool(self.device_checkpoint)
+        if mode is None:
+            mode = "reduce" if (attached and self.size > 1) else False
+        if mode in (True, "solve") and not hasattr(self.engine, "checkpoint_solve"):
+            self._fail("device_checkpoint: %r: this engine has no device-side solve", mode)
+        self.device_checkpoint = mode
+        self._device_ckpt = bool(mode)
+        self._ckpt_solve_on_device = mode in (True, "solve")
         if self._device_ckpt:
             self.engine.checkpoint_set_ring(self._intervals)
             self.engine.checkpoint_set_accepted(self._acc_last)
+            if attached and self._ckpt_lag_default:
+                # the collective is IN the stream: nothing of it runs beside a step kernel, so the
+                # host need not stay a launch further behind (`advance`)
+                self._ckpt_lag = 1
 
     def set_proposer_blocking(self):
         """mcmc.py:320-410: parameter blocks and oversampling factors (manual `blocking` or
@@ -739,18 +756,25 @@ class EnsembleMCMC:
         if self.size > 1 and not getattr(eng, "comm_attached", False):
             # (an engine the communicator is attached to has queued the all-reduce itself)
             dist.all_reduce_sum_device(ptr, n, eng.stream_handle())
-        learn = bool(self.learn_proposal)
-        eng.checkpoint_solve(self.learn_proposal_Rminus1_min if learn else np.inf,
-                             self.learn_proposal_Rminus1_max if learn else -np.inf)
+        if self._ckpt_solve_on_device:
+            learn = bool(self.learn_proposal)
+            eng.checkpoint_solve(self.learn_proposal_Rminus1_min if learn else np.inf,
+                                 self.learn_proposal_Rminus1_max if learn else -np.inf)
+        else:   # only the reduced payload comes back; the host solves it beside the next launch
+            eng.checkpoint_request_payload()
         self._ckpt_on_device = True
 
     def _finish_checkpoint(self):
         self._ckpt_pending = False
         moments = (self.engine.fetch_moments() if hasattr(self.engine, "fetch_moments")
                    else None)
-        dev = self.engine.checkpoint_fetch() if self._ckpt_on_device else None
+        dev = payload = None
+        if self._ckpt_on_device and self._ckpt_solve_on_device:
+            dev = self.engine.checkpoint_fetch()
+        elif self._ckpt_on_device:
+            payload = self.engine.checkpoint_fetch_payload()
         self._ckpt_on_device = False
-        self.check_convergence_and_learn_proposal(moments, dev)
+        self.check_convergence_and_learn_proposal(moments, dev, payload)
         self.i_learn += 1
         if self.emit == "snapshots" and not self.snapshot_every:
             self._snapshot()
@@ -1037,13 +1061,14 @@ class EnsembleMCMC:
         self._intervals = ivs = ivs[k:]
         return (sum(iv[0] for iv in ivs), sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs))
 
-    def check_convergence_and_learn_proposal(self, moments=None, dev=None):
+    def check_convergence_and_learn_proposal(self, moments=None, dev=None, payload=None):
         """mcmc.py:773-1032 on pooled sufficient statistics; one all-reduce.
         `moments`: what `engine.fetch_moments()` returned for the checkpoint (None: read them
         out now, synchronously).  `dev`: the outcome of the same checkpoint solved ON THE DEVICE
         (`engine.checkpoint_fetch()`): R-1, the mean of covariances and whether the proposal was
         refreshed there -- the host then only keeps the books (window, progress table, stop
-        criteria) and logs."""
+        criteria) and logs.  `payload`: the statistics of the same checkpoint formed AND
+        all-reduced on the device (`engine.checkpoint_fetch_payload()`): the host solves them."""
         d, eng = self.spec.d, self.engine
         if moments is None:
             n_snap, gs, S = eng.read_moments(reset=True)  # synchronises the stream
@@ -1056,16 +1081,20 @@ class EnsembleMCMC:
         if not self._intervals:
             return
         gsz = eng.group_size
+        from_device = payload is not None
         if dev is None:
-            n, gsum, Ssum = self._window()
-            N_c = float(n * gsz)                       # samples per chain (= group)
-            means = gsum / N_c                         # [G, d], relative to the shift
-            sum_mm = means.T @ means
-            payload = np.concatenate((
-                [float(eng.G), N_c * eng.G, float(c["accepted"] - self._acc_last),
-                 float((c["steps"] - self._steps_last) * eng.W), float(c["accepted"])],
-                (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
-            dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
+            if payload is None:
+                n, gsum, Ssum = self._window()
+                N_c = float(n * gsz)                       # samples per chain (= group)
+                means = gsum / N_c                         # [G, d], relative to the shift
+                sum_mm = means.T @ means
+                payload = np.concatenate((
+                    [float(eng.G), N_c * eng.G, float(c["accepted"] - self._acc_last),
+                     float((c["steps"] - self._steps_last) * eng.W), float(c["accepted"])],
+                    (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
+                dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
+            else:
+                self._window()  # (the books only; the device summed the same window, in stream order)
             n_chains, sum_N, d_acc, d_steps, n_acc_all = payload[:5]
             sum_Ncov = payload[5:5 + d * d].reshape(d, d)
             sum_mean = payload[5 + d * d:5 + d * d + d]
@@ -1074,7 +1103,7 @@ class EnsembleMCMC:
             self._window()      # (the books only: which intervals the window holds from now on)
             d_acc, d_steps, n_acc_all = dev["d_accepted"], dev["d_steps"], dev["accepted"]
         self._acc_last, self._steps_last = c["accepted"], c["steps"]
-        if dev is None and getattr(self, "_device_ckpt", False):
+        if dev is None and not from_device and getattr(self, "_device_ckpt", False):
             # a checkpoint without new snapshots took the host path: the device's own copy of
             # "accepted at the last checkpoint" must follow, or the next device checkpoint
             # would report the accepted steps of two intervals over the steps of one

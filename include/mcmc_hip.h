@@ -277,6 +277,14 @@ MCMC_HIP_API int mcmc_hip_checkpoint_begin(mcmc_hip_ctx* h, int32_t n_window_int
                               double steps_since, uint64_t* payload_device_ptr, int32_t* payload_len);
 MCMC_HIP_API int mcmc_hip_checkpoint_solve(mcmc_hip_ctx* h, double learn_lo, double learn_hi);
 MCMC_HIP_API int mcmc_hip_checkpoint_fetch(mcmc_hip_ctx* h, double stats[8], double* mean_of_covs);
+/* Instead of checkpoint_solve: only the (all-reduced) payload is read out behind the launch --
+ * checkpoint_begin -> checkpoint_request_payload -> [the next launch] -> checkpoint_fetch_payload
+ * (waits for the copy; n = the payload_len of checkpoint_begin) -- and the caller solves it on the
+ * host (mcmc_hip_gelman_rubin, mcmc_hip_set_proposal_cov) while that launch runs.  The window sums
+ * and the collective stay on the device in stream order; the single-workgroup d^3 solve leaves
+ * the stream (replaces the gather + host arithmetic of mcmc.py:791-793, 856-889). */
+MCMC_HIP_API int mcmc_hip_checkpoint_request_payload(mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_checkpoint_fetch_payload(mcmc_hip_ctx* h, double* payload, int32_t n);
 /* R-1 of the confidence-interval bounds ON THE DEVICE (mcmc.py:918-1002), in every emit mode: a ring
  * of n_slots ensemble snapshots [slot][d][n_walkers] (bounds_configure; 0 frees it);
  * bounds_snapshot(slot) copies the current points into a slot in stream order (the caller decides

@@ -1,8 +1,9 @@
 """Worker of tests/test_gpu_multirank.py: one rank of an N-GPU job (RANK / WORLD_SIZE / MASTER_*
 in the environment, one process per GPU).  `dist.init_from_env()` forms the library's RCCL
 communicator (mcmc_hip_comm_*, bootstrapped over a gloo group); the sampler shards the walkers by
-rank and runs with the device checkpoint (the default for N > 1: ncclAllReduce queued in place on
-the engine's stream by mcmc_hip_checkpoint_begin).  Writes one JSON + one npz per rank."""
+rank and runs with the device checkpoint (the default for N > 1, `reduce`: window sums, payload and
+ncclAllReduce queued in place on the engine's stream by mcmc_hip_checkpoint_begin; the host solves
+the reduced payload beside the next launch).  Writes one JSON + one npz per rank."""
 import json
 import os
 import sys
@@ -39,6 +40,7 @@ def main():
     s.run()
     st = s.engine.get_full_state()
     res = {"rank": dist.rank(), "collective": dist.describe(), "device_checkpoint": bool(s._device_ckpt),
+           "checkpoint_mode": s.device_checkpoint, "checkpoint_lag": int(s._ckpt_lag),
            "comm_attached": bool(s.engine.comm_attached), "device": int(s.engine.cfg.device),
            "walker_offset": int(s.engine.walker_offset), "steps": int(s.n_steps_raw),
            "progress": s.progress[["N", "acceptance_rate", "Rminus1"]].to_numpy().tolist(),

@@ -29,7 +29,7 @@ def run_checkpoints(use_group, device_checkpoint=False):
                        for i, n in enumerate(names)}}
     s = MCMCHip({"seed": 9, "n_walkers": 2048, "group_size": 64, "steps_per_launch": "10d",
                  "learn_every": "10d", "max_samples": 6e6, "Rminus1_stop": 0.0,
-                 "proposal_scale": 2.4, "device_checkpoint": bool(device_checkpoint)},
+                 "proposal_scale": 2.4, "device_checkpoint": device_checkpoint},
                 ProblemSpec.from_info(info))
     s.run()
     out = {"collective": dist.describe(), "progress": s.progress[["N", "acceptance_rate",
@@ -47,5 +47,6 @@ def run_checkpoints(use_group, device_checkpoint=False):
 
 
 if __name__ == "__main__":
-    print("RESULT " + json.dumps(run_checkpoints(sys.argv[1] == "nccl",
-                                                 len(sys.argv) > 3 and sys.argv[3] == "device")))
+    where = sys.argv[3] if len(sys.argv) > 3 else "host"
+    print("RESULT " + json.dumps(run_checkpoints(
+        sys.argv[1] == "nccl", {"device": True, "reduce": "reduce", "host": False}[where])))

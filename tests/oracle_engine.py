@@ -296,5 +296,56 @@ class OracleEngine:
             self._raise_if_stuck()
         return out
 
+    # -- the device side of `device_checkpoint: reduce` (mcmc_hip_checkpoint_set_ring / _begin /
+    # _request_payload / _fetch_payload): the ring of intervals, the window sums and the payload an
+    # all-reduce carries, with the arithmetic of the sampler's host path
+    def checkpoint_set_ring(self, intervals=(), min_capacity=16):
+        self._ck_ring = [(int(n), np.array(gs, float), np.array(S, float)) for n, gs, S in intervals]
+        self.ckpt_capacity = 16
+        while self.ckpt_capacity < max(len(self._ck_ring) + 2, int(min_capacity)):
+            self.ckpt_capacity *= 2
+        self._ck_payload = self._ck_out = None
+        if not hasattr(self, "_ck_acc_prev"):
+            self._ck_acc_prev = 0
+
+    def checkpoint_set_accepted(self, accepted):
+        self._ck_acc_prev = int(accepted)
+
+    def checkpoint_begin(self, n_window_intervals, n_window_snapshots, steps_since):
+        if self._requested is None:
+            raise RuntimeError("request_moments must precede checkpoint_begin")
+        if self._ck_payload is not None or self._ck_out is not None:
+            raise RuntimeError("a device checkpoint is already in flight")
+        n, gs, S, c = self._requested
+        self._ck_ring.append((n, gs.copy(), S.copy()))
+        if not 1 <= n_window_intervals <= self.ckpt_capacity:
+            raise RuntimeError("the window outgrew the ring")
+        ivs = self._ck_ring[-int(n_window_intervals):]
+        if sum(iv[0] for iv in ivs) != n_window_snapshots:
+            raise RuntimeError("the window's snapshot count disagrees with the ring's intervals")
+        self._ck_ring = self._ck_ring[-self.ckpt_capacity:]
+        gsum, Ssum = sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs)
+        G, W = self.G, self.W
+        N_c = float(n_window_snapshots * self.group_size)
+        means = gsum / N_c
+        mm = means.T @ means
+        acc = int(c["accepted"])
+        self._ck_payload = np.concatenate((
+            [float(G), N_c * G, float(acc - self._ck_acc_prev), float(steps_since * W), float(acc)],
+            (Ssum - N_c * mm).ravel(), means.sum(0), mm.ravel()))
+        self._ck_acc_prev = acc
+        return 0, len(self._ck_payload)
+
+    def checkpoint_request_payload(self):
+        if self._ck_payload is None:
+            raise RuntimeError("checkpoint_begin must precede checkpoint_request_payload")
+        self._ck_out, self._ck_payload = self._ck_payload, None
+
+    def checkpoint_fetch_payload(self):
+        if self._ck_out is None:
+            raise RuntimeError("no payload read-out is pending")
+        out, self._ck_out = self._ck_out, None
+        return out
+
     def close(self):
         self.closed = True

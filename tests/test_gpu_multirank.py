@@ -86,7 +86,9 @@ def test_shards_on_several_gpus_equal_the_slices_of_one_ensemble(tmp_path, world
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
     res = run_ranks(tmp_path, world, "nolearn")
-    opts = dict(w.options(world, False, walkers=2048 * world), checkpoint_lag=2, device_checkpoint=True)
+    assert res[0]["checkpoint_mode"] == "reduce" and res[0]["checkpoint_lag"] == 1   # the defaults for N > 1
+    opts = dict(w.options(world, False, walkers=2048 * world), checkpoint_lag=res[0]["checkpoint_lag"],
+                device_checkpoint=res[0]["checkpoint_mode"])
     one = MCMCHip(opts, ProblemSpec.from_info(w.problem()))
     one.run()
     st = one.engine.get_full_state()
@@ -124,7 +126,7 @@ def test_bench_launches_its_own_ranks():
     assert c["backend"] == ("nccl" if n_gpus() >= 2 else "gloo")
     assert len(c["per_rank_step_kernel_ms"]) == 2 and min(c["per_rank_step_kernel_ms"]) > 0
     assert res["config"]["evals_per_step"] == 2 * 16384 * 900
-    assert res["config"]["checkpoint_on"] == ("device" if n_gpus() >= 2 else "host")
+    assert res["config"]["checkpoint_on"].startswith("device (window sums" if n_gpus() >= 2 else "host")
     assert res["config"]["learn_checkpoints_in_timed_region"] >= 1
     assert res["value"] > 1e8 and res["cpu_baseline"] is None
     if n_gpus() >= 2:

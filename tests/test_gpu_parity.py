@@ -1331,3 +1331,56 @@ def test_device_checkpoint_matches_the_host_arithmetic(d, W, gs, blocks):
         acc_last, steps_last = c["accepted"], steps + d
         steps_last = steps
     eng.close()
+
+
+def test_device_checkpoint_payload_read_out():
+    """`device_checkpoint: reduce`: checkpoint_begin -> checkpoint_request_payload -> [a launch] ->
+    checkpoint_fetch_payload hands the host the statistics the all-reduce carries (window sums over
+    the device ring, group means, sum of outer products: mcmc.py:791-793's gather) --
+    equal to the host path's payload from the same moments (counts exactly, sums to rounding: the
+    device adds the groups one by one, numpy in BLAS order)."""
+    d, W, gs = 12, 1024, 64
+    eng, prob, st = make_pair(d, W, gs, incremental=True)
+    eng.set_moment_shift(np.full(d, 0.5))
+    eng.checkpoint_set_ring()
+    intervals, acc_last, steps_last = [], 0, 0
+    with pytest.raises(E.EngineError, match="checkpoint_begin must precede"):
+        eng.checkpoint_request_payload()
+    for n_launch, window in [(3, 1), (2, 2), (4, 2), (1, 3)]:
+        for _ in range(n_launch):
+            eng.step(2 * d)
+            eng.accumulate_moments()
+        eng.request_moments()
+        n_win = sum(iv[0] for iv in intervals[len(intervals) + 1 - window:]) + n_launch
+        steps = eng.counters()["steps"]
+        ptr, n = eng.checkpoint_begin(window, n_win, steps - steps_last)
+        assert n == 5 + 2 * d * d + d
+        eng.checkpoint_request_payload()
+        with pytest.raises(E.EngineError, match="no device checkpoint is pending"):
+            eng.checkpoint_fetch()
+        eng.step(d)                                   # (work queued behind the read-out)
+        n_snap, gsum, S, c = eng.fetch_moments()
+        intervals.append((n_snap, gsum, S))
+        got = eng.checkpoint_fetch_payload()
+        with pytest.raises(E.EngineError, match="no payload read-out is pending"):
+            eng.checkpoint_fetch_payload()
+        ivs = intervals[-window:]
+        g_sum, S_sum = sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs)
+        N_c = float(sum(iv[0] for iv in ivs) * gs)
+        means = g_sum / N_c
+        mm = means.T @ means
+        G = W // gs
+        assert got[0] == G and got[1] == N_c * G and got[2] == c["accepted"] - acc_last
+        assert got[3] == (steps - steps_last) * W and got[4] == c["accepted"]
+        scale = np.abs(S_sum).max()
+        np.testing.assert_allclose(got[5:5 + d * d].reshape(d, d), S_sum - N_c * mm, rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(got[5 + d * d:5 + d * d + d], means.sum(0), rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(got[5 + d * d + d:].reshape(d, d), mm, rtol=1e-12, atol=1e-16)
+        # the host's solve of the device's payload = the host path's, to rounding
+        R_dev, cov_dev = E.gelman_rubin(got[0], got[1], got[5:5 + d * d].reshape(d, d),
+                                        got[5 + d * d:5 + d * d + d], got[5 + d * d + d:].reshape(d, d))
+        R_host, cov_host = E.gelman_rubin(float(G), N_c * G, S_sum - N_c * mm, means.sum(0), mm)
+        np.testing.assert_allclose(R_dev, R_host, rtol=1e-8)
+        np.testing.assert_allclose(cov_dev, cov_host, rtol=1e-9, atol=1e-18)
+        acc_last, steps_last = c["accepted"], steps
+    eng.close()

@@ -655,7 +655,8 @@ def test_device_checkpoint_through_the_sampler_and_rccl():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     res = {}
-    for mode, dev in (("nccl", "device"), ("none", "device"), ("none", "host")):
+    for mode, dev in (("nccl", "device"), ("none", "device"), ("none", "host"), ("nccl", "reduce"),
+                      ("none", "reduce")):
         out = subprocess.run([sys.executable, os.path.join(here, "_rccl_worker.py"), mode,
                               str(port), dev], capture_output=True, text=True, timeout=600)
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")]
@@ -672,6 +673,19 @@ def test_device_checkpoint_through_the_sampler_and_rccl():
     ca, ch = np.array(b["proposal_cov"]), np.array(h["proposal_cov"])
     sa = np.sqrt(np.diag(ch))
     assert np.max(np.abs(ca - ch) / np.outer(sa, sa)) < 0.15
+    # (iii) `device_checkpoint: reduce` (round 4: the default for N > 1): window sums, payload and
+    # ncclAllReduce on the device, in stream order; the reduced payload alone comes back and the
+    # HOST solves it beside the next launch
+    ra, rb = res["nccl", "reduce"], res["none", "reduce"]
+    assert ra["collective"]["backend"] == "nccl" and len(ra["progress"]) >= 3
+    assert ra["progress"] == rb["progress"] and ra["proposal_cov"] == rb["proposal_cov"]
+    assert ra["x_sum"] == rb["x_sum"]
+    pr = np.array(rb["progress"])
+    assert pr[0, 0] == ph[0, 0] and pr[0, 1] == ph[0, 1]
+    np.testing.assert_allclose(pr[0, 2], ph[0, 2], rtol=1e-7)
+    cr = np.array(rb["proposal_cov"])
+    assert np.max(np.abs(cr - ch) / np.outer(sa, sa)) < 0.15
+    assert 0 < ra["Rminus1_cl"] == rb["Rminus1_cl"] < 1
 
 
 def test_shared_and_own_basis_sample_the_same_posterior():

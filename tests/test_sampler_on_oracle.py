@@ -473,3 +473,31 @@ def test_dragging_emits_chains():
     acc = s.engine.counters()["accepted"]
     assert acc - 128 * 11 <= len(coll) <= acc and w.max() > 1 and w.min() >= 1
     assert kl_norm(tm, tc, coll.mean(), coll.cov()) < 0.07     # the reference's own bar
+
+
+def test_device_reduce_checkpoint_retraces_the_host_checkpoint(tmp_path):
+    """`device_checkpoint: reduce` (round 4: the default for N > 1): the ring of intervals, the
+    window sums and the payload are the device's, only the reduced payload comes back and the
+    host solves it.  On the oracle-backed engine (whose payload uses the host path's arithmetic)
+    the whole run -- progress table, learned proposal, final ensemble -- retraces the host
+    checkpoint bit for bit, also across a resume (the ring is reloaded from the state file)."""
+    runs = {}
+    for mode in (False, "reduce"):
+        s = make(None, 60000, device_checkpoint=mode, learn_every="10d")
+        s.run()
+        assert s._device_ckpt == bool(mode) and not s._ckpt_solve_on_device
+        runs[mode] = (s.progress[["N", "acceptance_rate", "Rminus1"]].to_numpy(float),
+                      s.proposer.get_covariance(), s.engine.get_full_state()["x"])
+    assert len(runs[False][0]) >= 4 and np.isfinite(runs[False][0][:, 2]).any()
+    for a, b in zip(runs[False], runs["reduce"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    p = str(tmp_path / "r")
+    b1 = make(p, 30000, device_checkpoint="reduce", learn_every="10d")
+    b1.run()
+    b2 = make(p, 60000, resume=True, device_checkpoint="reduce", learn_every="10d")
+    b2.run()
+    assert np.array_equal(b2.engine.get_full_state()["x"], runs[False][2])
+    with pytest.raises(LoggedError, match="no device-side solve"):
+        make(None, 1000, device_checkpoint=True)
+    with pytest.raises(LoggedError, match="device_checkpoint must be one of"):
+        make(None, 1000, device_checkpoint="gpu")
