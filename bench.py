@@ -385,6 +385,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
                              "device" if sampler._ckpt_solve_on_device else
                              "device (window sums + all-reduce), host (solve)"),
            "rows": rows_kept[0], "evals": float(a.walkers) * size * spl * steps,
+           "rows_in_store": int(sampler._n_rows), "drain_slots": int(getattr(eng, "drain_slots", 0)),
+           "rows_copied_on_host": int(sum(len(r) for r in sampler._rows if not sampler._is_slot_view(r))),
            "cross_check": cross}
     sampler.close()
     return res
@@ -617,22 +619,29 @@ def main():
             "accepted_rows_per_s": v["rows"] / v["dt"],
             "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"],
             "rows_retained_on_host": False})
-        # ... and with the rows RETAINED: a store large enough for the region, every drained
-        # block copied out of its pinned slot into the sampler's own memory (what products()
-        # hands out) -- the host-side copy is then part of the step
-        info_r = make_info(d, mean, cov, a.walkers, a.group_size, 40 * d, "chains")
-        info_r["sampler"]["mcmc_hip"]["max_rows"] = 1 << 24   # (4.7 GB of rows: ~3 launches, then
-        #                                                       the oldest half is dropped)
-        info_r["sampler"]["mcmc_hip"]["drain_copy"] = True
-        n_v = 4
-        v = run_timed(a, d, mean, cov, "chains", n_v, 1, info=info_r)
-        variants.append({
-            "variant": "emit: chains, rows retained on the host (copied out of the pinned ring "
-                       "into the sample store every launch)",
-            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
-            "steps": n_v, "warmup": 1, "metropolis_steps_per_launch": v["spl"],
-            "accepted_rows_per_s": v["rows"] / v["dt"],
-            "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"], "rows_retained_on_host": True})
+        # ... and with the rows RETAINED: a store large enough for the region (max_rows = 16.7 M
+        # rows: the last ~3 launches, then the oldest half is dropped).  (a) the engine's ring of
+        # pinned drain slots sized to outlive that window (`drain_ring_bytes`): the store reads
+        # its rows in place, nothing is copied a second time on the host; (b) `drain_copy`: every
+        # drained block copied into the sampler's own memory at once (round 3's retained figure)
+        for label, extra in (
+                ("read in place in the engine's pinned drain ring, sized to outlive the max_rows "
+                 "window: no second host copy", {"drain_ring_bytes": 1 << 34}),
+                ("copied out of the pinned ring into the sampler's own memory every launch "
+                 "(drain_copy: True)", {"drain_copy": True})):
+            info_r = make_info(d, mean, cov, a.walkers, a.group_size, 40 * d, "chains")
+            info_r["sampler"]["mcmc_hip"]["max_rows"] = 1 << 24
+            info_r["sampler"]["mcmc_hip"].update(extra)
+            n_v, w_v = (12, 8) if "drain_ring_bytes" in extra else (4, 1)   # (warm-up: every slot pinned once)
+            v = run_timed(a, d, mean, cov, "chains", n_v, w_v, info=info_r)
+            variants.append({
+                "variant": "emit: chains, rows retained on the host (" + label + ")",
+                "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+                "steps": n_v, "warmup": w_v, "metropolis_steps_per_launch": v["spl"],
+                "accepted_rows_per_s": v["rows"] / v["dt"],
+                "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"], "rows_retained_on_host": True,
+                "rows_in_store_at_end": v.get("rows_in_store"), "drain_slots": v.get("drain_slots"),
+                "stored_rows_copied_on_host": v.get("rows_copied_on_host")})
     headline = (d, a.walkers, a.emit) == (30, 65536, "snapshots")
     if size == 1 and not a.no_variants and headline:
         # BASELINE configs[3]: the 100-dim gaussian_mixture, same walkers (default path)

@@ -98,6 +98,10 @@ HIP_DEFAULTS = {
                               # engine's pinned slot at once (the store owns its rows from the
                               # start); False: blocks are read in place and copied only when their
                               # slot is about to be reused
+    "drain_ring_bytes": 1 << 33,  # emit: chains, zero-copy drain -- pinned host memory the engine's
+                              # ring of drain slots may take (the ring is sized to outlive the
+                              # `max_rows` retention window, so that stored rows are read in place
+                              # and never copied again; 4 .. 64 slots)
     "row_buffer_bytes": 1 << 32,  # emit: chains -- device buffer of accepted rows between two
                               # drains (bounds steps_per_launch: every step may accept)
     "basis_group_size": None,  # walkers sharing one Haar basis per cycle (group_size times a
@@ -328,6 +332,7 @@ class EnsembleMCMC:
                                  incremental=self.incremental,
                                  basis_group_size=int(self.basis_group_size))
             spec.configure(self.engine)
+            self._size_drain_ring(d, W)
             if len(self.blocks) > 1 or self.oversampling_factors[0] != 1:
                 self.engine.set_blocking(
                     [[spec.sampled.index(p) for p in b] for b in self.blocks],
@@ -967,6 +972,27 @@ class EnsembleMCMC:
         out = rows[keep].copy()
         out[:, 1] = (q - q_prev)[keep]
         return out
+
+    def _size_drain_ring(self, d, W):
+        """emit: chains, zero-copy drain: the engine's ring of pinned host slots IS the sample
+        store as long as it outlives the retention window -- a stored block is dropped (oldest
+        half when `max_rows` is reached, `_store_rows`) before its slot comes round again, so no
+        row is ever copied a second time on the host.  Slots for the window's launches + 2 at a
+        LOW acceptance rate (8 %), within `drain_ring_bytes` of pinned memory at a high one (35 %);
+        a run outside that range simply has its oldest views copied out in time
+        (`_expire_row_views`)."""
+        eng = self.engine
+        if (self.emit != "chains" or self.drain_copy or self.max_rows <= 0
+                or not hasattr(eng, "set_drain_slots")):
+            return
+        # (the window holds max_rows / rows-per-launch blocks: MANY when few steps are accepted,
+        # while every slot grows to one launch's rows: LARGE when many are)
+        steps = W * float(self.steps_per_launch)
+        want = int(np.ceil(self.max_rows / max(1.0, 0.08 * steps))) + 2
+        fit = int(float(self.drain_ring_bytes) // (1.25 * max(1.0, 0.35 * steps) * 8 * (d + 5)))
+        n = int(min(64, max(4, min(want, fit))))
+        if n != getattr(eng, "drain_slots", 4):
+            eng.set_drain_slots(n)
 
     def _expire_row_views(self):
         """Before a drain: blocks of `_rows` that are views of the engine's pinned slots stay

@@ -49,6 +49,7 @@ else:
         bounds_snapshots: int = HIP_DEFAULTS["bounds_snapshots"]
         drain_copy: bool = HIP_DEFAULTS["drain_copy"]
         row_buffer_bytes: int = HIP_DEFAULTS["row_buffer_bytes"]
+        drain_ring_bytes: int = HIP_DEFAULTS["drain_ring_bytes"]
         device_checkpoint: bool | str | None = HIP_DEFAULTS["device_checkpoint"]
         shared_basis: bool = HIP_DEFAULTS["shared_basis"]
         evaluation: str = HIP_DEFAULTS["evaluation"]

@@ -402,8 +402,9 @@ def test_chains_mode_keeps_every_accepted_row_without_output():
     """with `emit: chains` and no `output`, rows read in place from the
     engine's drain slots must be copied out before their slot is reused -- the product holds
     every accepted row (up to `max_rows`), not the last three launches."""
-    s = make(None, 20000, emit="chains", steps_per_launch=20)
+    s = make(None, 20000, emit="chains", steps_per_launch=20, drain_ring_bytes=0)   # (4 slots)
     s.run()
+    assert s.engine.drain_slots == 4 and s._launches > 12
     coll = s.products()["sample"]
     acc = s.engine.counters()["accepted"]
     # every accepted step closes one row; the current points (one per walker) are still open
@@ -414,6 +415,36 @@ def test_chains_mode_keeps_every_accepted_row_without_output():
     # the store outlives the engine (its pinned slots die with it)
     s.close()
     assert np.all(np.isfinite(np.vstack(s._rows))) and len(np.vstack(s._rows)) == len(coll)
+
+
+def test_the_drain_ring_is_the_row_store():
+    """Round 4 (host side): the engine's ring of pinned drain slots is sized to
+    outlive the `max_rows` retention window, so stored rows are read in place for as long as
+    the store keeps them -- no block is ever copied a second time on the host (the oracle-backed
+    engine poisons a slot when it is reused: a view kept too long would read NaN)."""
+    s = make(None, 40000, emit="chains", steps_per_launch=20, max_rows=6000)
+    assert s.engine.drain_slots == int(np.ceil(6000 / (0.08 * 128 * 20))) + 2
+    copied = []
+    orig = s._expire_row_views
+
+    def spy():
+        before = [id(r) for r in s._rows]
+        orig()
+        copied.extend(1 for a, b in zip(before, s._rows) if a != id(b))
+    s._expire_row_views = spy
+    s.run()
+    assert s._launches >= 2 * s.engine.drain_slots and s._rows_capped   # the ring went round twice
+    assert not copied and all(s._is_slot_view(r) for r in s._rows)
+    rows = np.vstack(s._rows)
+    assert 3000 <= len(rows) <= 6000 and np.all(np.isfinite(rows))
+    # the same run with every block copied at once holds the same rows
+    c = make(None, 40000, emit="chains", steps_per_launch=20, max_rows=6000, drain_copy=True)
+    c.run()
+    assert c.engine.drain_slots == 4 and np.array_equal(np.vstack(c._rows), rows)
+    # a budget too small for the window: four slots, views copied out in time (still all rows)
+    b = make(None, 40000, emit="chains", steps_per_launch=20, max_rows=6000, drain_ring_bytes=1)
+    b.run()
+    assert b.engine.drain_slots == 4 and np.array_equal(np.vstack(b._rows), rows)
 
 
 @pytest.mark.parametrize("emit,max_rows", [("snapshots", 0), ("snapshots", 1 << 20), ("chains", 1 << 20)])
