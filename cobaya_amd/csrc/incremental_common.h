@@ -121,12 +121,14 @@ __device__ __forceinline__ lds_doubles relaunder(const double* p)
     return (lds_doubles)(unsigned long long)off;
 }
 
-// columns of one LDS chunk: a multiple of 4 (the variates come in fours); 16 KiB of pairs, 32 KiB
+// columns of one LDS chunk: a multiple of 4 (the variates come in fours); 14 KiB of pairs, 32 KiB
 // from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
 // workgroup barrier between chunks comes half as often)
 __host__ __device__ constexpr int inc_chunk(int dq)
 {
-    int c = ((dq >= 14 ? 2048 : 1024) / (4 * dq)) & ~3;
+    // (kernels at four waves per SIMD -- four workgroups per CU -- have 40 KB of LDS each: 28 KB
+    // of pairs beside the 8 KB of staged variates and the 2 KB logarithm table)
+    int c = ((dq >= 14 ? 2048 : 896) / (4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }
 

@@ -172,48 +172,58 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     __syncthreads();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
-    PairRng pr;
-    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+    // the (r, Ea) pairs of the current octet: [wave][step of the octet][walker of the wave]
+    __shared__ pair_t sRE[4 * 8 * 16];
+    const unsigned re_base = lds_offset(sRE + (wave * 8 * 16 + (lane >> 2)));
+    unsigned re_off = re_base;
     const int hw_slot = hw_wave_slot();
 
     for (int base = 0, k = 0; base < ncols; base += C, ++k) {
         const double2* __restrict__ cur = sVU + (k & 1) * CHUNK;
         stage(k + 1);     // travels while this chunk is consumed
-        const int cols = ncols - base < C ? ncols - base : C;
+        const int cols = __builtin_amdgcn_readfirstlane(ncols - base < C ? ncols - base : C);
         unsigned long long oned_cols = 0;   // bit sl: column sl of the chunk is a 1-D one
         if (ONED)
             oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
         // (the step loop is rolled: an unrolled body lets the scheduler hoist the LDS reads of
         // several steps and costs the registers that decide the occupancy)
+        // (the LDS address of the step's column is CARRIED and passes through the empty asms in
+        // place: a laundered copy of a pointer that stays live costs a v_mov per step)
+        unsigned coff = lds_offset(cur + c);
 #pragma unroll 1
-        for (int sl = 0; sl < cols; ++sl) {
+        for (int sl = 0; sl < cols; ++sl, coff += COLB * 16) {
             {
                 {
                     // Variates: EIGHT consecutive steps (an aligned octet of the global step index)
                     // at once -- lane class c draws the Philox block of the step pair 4 * octet + c
-                    // (PairRng: both halves, four logarithms, two square roots), and a step
-                    // fetches its pair from the class that drew it by a quad broadcast.
+                    // (PairRng: both halves, four logarithms, two square roots) and leaves its two
+                    // (r, Ea) pairs in the wave's corner of LDS, [step of the octet][walker]; a
+                    // step then reads its pair with ONE ds_read_b128, the same 16 bytes in the
+                    // four lanes of a walker.  (Until round 4 the pair came by a quad broadcast
+                    // behind an eight-way switch on the step index: 4 DPP moves and ~12 scalar
+                    // instructions per step -- and the scalar ones are not free: the kernel's time
+                    // follows VALU + SALU instructions, profiles/r04_instruction_diet.txt.)
                     const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                     if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
                         cur_oct = S >> 3;
                         rotate_priority<inc_min_waves(DQ, MODE)>(hw_slot);
+                        PairRng pr;
                         pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+                        pair_t* const mine = sRE + ((wave * 8 + 2 * c) * 16 + (lane >> 2));
+                        mine[0] = pair_t{pr.r[0], pr.Ea[0]};
+                        mine[16] = pair_t{pr.r[1], pr.Ea[1]};
+                        re_off = re_base + (unsigned)(S & 7ull) * 256u;
                     }
                     double r, Ea;
                     if (ONED && ((oned_cols >> sl) & 1ull)) {   // wave-uniform
                         step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
-                    } else
-                    switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
-                    case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
-                    case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
-                    case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
-                    case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
-                    case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
-                    case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
-                    case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
-                    default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+                    } else {
+                        const pair_t re = *(lds_pairs)(unsigned long long)re_off;
+                        r = re.x;
+                        Ea = re.y;
                     }
-                    const double2* __restrict__ col = cur + sl * COLB + c;
+                    re_off += 256u;
+                    const lds_pairs col = (lds_pairs)(unsigned long long)coff;
                     double pc = 0.0, sc = 0.0;
                     // (the support test is kept as the wave's lane mask: every comparison lands
                     // in a scalar register pair and the ANDs run on the scalar unit)
@@ -225,7 +235,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // beyond it, negative, -0) is decided by the exact comparisons below, a
                     // wave-uniform branch that a posterior away from the walls never takes
                     unsigned hmx = 0u;
-                    auto trial = [&](int kk, const double2 p) {
+                    auto trial = [&](int kk, const pair_t p) {
                         const double t = fma(r, p.x, x[kk]);
                         if (MODE == 0) {
                             const unsigned h = (unsigned)__double2hiint(t);
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             sc = sc + fma(-0.5 * qq, qq, mls);
                         }
                     };
-                    double2 pk[KEEP ? DQ : 1];
+                    pair_t pk[KEEP ? DQ : 1];
                     if constexpr (KEEP) {
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) pk[kk] = col[4 * kk];
@@ -261,7 +271,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         // and little else to cover the LDS latency: the pairs are fetched PIPE
                         // at a time, one batch ahead of the arithmetic)
                         constexpr int NB = (DQ + PIPE - 1) / PIPE;
-                        double2 buf[2][PIPE];
+                        pair_t buf[2][PIPE];
 #pragma unroll
                         for (int j = 0; j < PIPE; ++j)
                             if (j < DQ) buf[0][j] = col[4 * j];
@@ -278,11 +288,14 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     }
                     // inside the prior support = all four lanes of the walker are: the AND over
                     // the quad is taken on the wave's lane mask (scalar unit, no vector work)
-                    bool inside;
+                    unsigned long long inside_m;   // lane mask: the walker's four lanes are all inside
                     if (MODE == 0) {
-                        inside = quad_max_u32(hmx) < bhi_word;
-                        if (lanes(!inside) != 0ull) {   // (wave-uniform, rare) the exact test
-                            lds_pairs colx = relaunder(col);
+                        // (ONE vector compare: "some lane is not certainly inside" is read off
+                        // the mask on the scalar unit)
+                        inside_m = lanes(quad_max_u32(hmx) < bhi_word);
+                        if (inside_m != lanes(true)) {   // (wave-uniform, rare) the exact test
+                            asm volatile("" : "+v"(coff));
+                            const lds_pairs colx = (lds_pairs)(unsigned long long)coff;
                             // (fully unrolled: a rolled loop would index x[] at run time and
                             // move the walker's state from registers to scratch memory)
 #pragma unroll
@@ -290,10 +303,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                                 const double t = fma(r, colx[4 * kk].x, x[kk]);
                                 inb &= lanes(t <= bhi) & lanes(t >= blo);
                             }
-                            inside = quad_all(inb);
+                            inside_m = quad_all_mask(inb);
                         }
                     } else {
-                        inside = quad_all(inb);
+                        inside_m = quad_all_mask(inb);
                     }
                     const double chi2 = quad_sum(pc);
                     const double lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
@@ -303,7 +316,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // explicit lt != -inf)
                     const double lt = lp + ll;
                     const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
-                    const bool accept = inside & ((lt > lpost) | (Ea > delta));
+                    const unsigned long long acc_m = inside_m & (lanes(lt > lpost) | lanes(Ea > delta));
+                    const bool accept = __builtin_amdgcn_inverse_ballot_w64(acc_m);
                     if (EMIT) {
                         // the point the walker leaves, with its weight (mcmc.py:691-707); each of
                         // the walker's four lanes stores its quarter: header word c, then the
@@ -325,16 +339,19 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     }
                     // (burn-in, mcmc.py:685-690, ends early in a run: its bookkeeping sits
                     // behind a wave-uniform test of "some lane is still burning in")
-                    int lim = lim1;
+                    const bool was_burning = burning;   // (wave-uniform)
+                    int lim_b;
+                    asm("" : "=v"(lim_b));   // (set and used while burning in only)
                     if (burning) {
-                        lim = burn > 0 ? lim10 : lim1;
+                        lim_b = burn > 0 ? lim10 : lim1;
                         burn -= (accept & (burn > 0)) ? 1 : 0;
                         burning = lanes(burn > 0) != 0ull;
                     }
                     const double ra = accept ? r : 0.0;
                     // (the pairs are read AGAIN from LDS: the pointer passes through an empty
                     // asm so that the compiler cannot keep the first reads alive in 4 DQ registers)
-                    lds_pairs col2 = relaunder(col);
+                    asm volatile("" : "+v"(coff));
+                    lds_pairs col2 = (lds_pairs)(unsigned long long)coff;
                     if constexpr (KEEP) {
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
@@ -347,7 +364,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             // (four pairs at a time: the pointer of the next four depends, through
                             // an empty asm, on the last result of these four -- else all DQ reads
                             // are issued up front into 4 DQ registers)
-                            if (kk % 4 == 0 && kk) col2 = relaunder_after(col2, y[kk - 1]);
+                            if (kk % 4 == 0 && kk) {
+                                asm volatile("" : "+v"(coff) : "v"(y[kk - 1]));
+                                col2 = (lds_pairs)(unsigned long long)coff;
+                            }
                             const pair_t p = col2[4 * kk];
                             x[kk] = fma(ra, p.x, x[kk]);
                             y[kk] = fma(ra, p.y, y[kk]);
@@ -361,7 +381,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 #pragma unroll
                         for (int b = 0; b < NB; ++b) {
                             // (the batch after next must not start before this one is used)
-                            if (b + 1 < NB && b > 0) col2 = relaunder_after(col2, y[b * PIPE - 1]);
+                            if (b + 1 < NB && b > 0) {
+                                asm volatile("" : "+v"(coff) : "v"(y[b * PIPE - 1]));
+                                col2 = (lds_pairs)(unsigned long long)coff;
+                            }
 #pragma unroll
                             for (int j = 0; j < PIPE; ++j)
                                 if (b + 1 < NB && (b + 1) * PIPE + j < DQ)
@@ -379,10 +402,18 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // (logprior and loglike of the current point are formed once, after the
                     // loop, from the committed x and y: the same chains on the same values)
                     lpost = accept ? lt : lpost;
-                    prej = accept ? 0 : (prej + (inside ? 0 : 1));
-                    wt = accept ? 1 : wt + 1;
-                    nacc += accept ? 1 : 0;
-                    if (wt - prej > lim && c == 0) atomicCAS(s.stuck, 0, 1 + (int)gid);
+                    {
+                        const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
+                        prej = accept ? 0 : (prej + (inside ? 0 : 1));
+                        wt = accept ? 1 : wt + 1;
+                        nacc += accept ? 1 : 0;
+                    }
+                    // (after the burn-in the limit is the wave-uniform lim1)
+                    unsigned long long over_m;
+                    if (was_burning) over_m = lanes(wt - prej > lim_b);
+                    else over_m = lanes(wt - prej > lim1);
+                    if (__builtin_amdgcn_inverse_ballot_w64(over_m) && c == 0)
+                        atomicCAS(s.stuck, 0, 1 + (int)gid);
                 }
             }
         }
