@@ -50,7 +50,8 @@ struct AnyGeom {
     int lcols;   // the columns of L_k^-1 of the periodic dimensions sit in LDS (else: read from HBM)
     size_t dynamic;
 };
-constexpr size_t kAnyStatic = 16 * 128 * 2 + 8 * 128 + 4 * 128 + 16 * SHORT_LOG_TABLE_SIZE + 16 * kMaxModes + 256;
+constexpr size_t kAnyStatic = 16 * 128 * 2 + 8 * 128 + 4 * 128 + 16 * SHORT_LOG_TABLE_SIZE + 16 * kMaxModes + 256 +
+                              16 * 4 * 8 * 16;   // (+ the staged variates, StagedVariates)
 constexpr size_t kLdsPerCu = 160u << 10;
 constexpr size_t kLdsPerWg = 160u << 10;   // (a single workgroup may hold all of it)
 
@@ -201,8 +202,9 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned long long cur_oct = ~0ull;
-    PairRng pr;
-    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
+    StagedVariates sv;
+    sv.init(sRE, wave, lane);
 
     for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
         const double* __restrict__ cur = sCol + (kc & 1) * CHUNK;
@@ -216,22 +218,18 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
             const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
             if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                 cur_oct = S >> 3;
+                PairRng pr;
                 pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+                sv.fill(sRE, wave, lane, c, pr, S);
             }
             double r, Ea;
             if ((oned_cols >> sl) & 1ull) {   // wave-uniform: the un-paired 1-D variates
                 step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
             } else
-            switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
-            case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
-            case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
-            case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
-            case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
-            case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
-            case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
-            case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
-            default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+            {
+                sv.fetch(r, Ea);
             }
+            sv.next();
             const double* __restrict__ col = cur + sl * COL + c;
             // ---- the trial point: support, normal priors, wraps
             unsigned long long inb = ~0ull, wound = 0ull;
@@ -422,7 +420,7 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
 // ---------------------------------------------------------------- mixtures in registers
 __host__ __device__ constexpr int regs_chunk(int dq, int km)
 {
-    int c = (2048 / ((1 + km) * 4 * dq)) & ~3;
+    int c = (1792 / ((1 + km) * 4 * dq)) & ~3;   // (as inc_chunk_mix: 8 KB go to the staged variates)
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }
 __host__ __device__ constexpr int regs_min_waves(int dq, int km)
@@ -571,8 +569,9 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
     const int hw_slot = hw_wave_slot();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
-    PairRng pr;
-    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
+    StagedVariates sv;
+    sv.init(sRE, wave, lane);
 
     for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
         const double* __restrict__ cur = smem + (kc & 1) * CHUNK;
@@ -587,22 +586,18 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
             if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                 cur_oct = S >> 3;
                 rotate_priority<regs_min_waves(DQ, KM)>(hw_slot);
+                PairRng pr;
                 pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+                sv.fill(sRE, wave, lane, c, pr, S);
             }
             double r, Ea;
             if ((oned_cols >> sl) & 1ull) {   // wave-uniform: the un-paired 1-D variates
                 step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
             } else
-            switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
-            case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
-            case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
-            case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
-            case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
-            case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
-            case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
-            case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
-            default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+            {
+                sv.fetch(r, Ea);
             }
+            sv.next();
             const double* __restrict__ col = cur + sl * COL + c;
             unsigned long long inb = ~0ull;   // the support test as a lane mask
             unsigned long long wound = 0ull;  // PER: lanes whose periodic coordinate changed its winding

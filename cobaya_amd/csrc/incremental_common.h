@@ -121,6 +121,40 @@ __device__ __forceinline__ lds_doubles relaunder(const double* p)
     return (lds_doubles)(unsigned long long)off;
 }
 
+// The (r, Ea) variates of an OCTET of steps, staged in LDS (round 4).  Lane class c of a walker draws
+// the Philox block of the step pair 4 * octet + c (PairRng) and leaves its two pairs in the wave's
+// corner of a workgroup array sRE[kStagedPairs] = [wave][step of the octet][walker of the wave];
+// a step then reads its pair with ONE ds_read_b128 -- the same 16 bytes in the four lanes of a
+// walker.  (Until round 4 the pair came by a quad broadcast behind an eight-way switch on the step
+// index: 4 DPP moves and ~12 scalar instructions per step, and 8 VGPRs alive across the octet;
+// profiles/r04_instruction_diet.txt.)  A wave reads what it wrote itself: LDS operations of one
+// wave complete in order, no barrier.
+constexpr int kStagedPairs = 4 * 8 * 16;   // 8 KB per workgroup of four waves
+struct StagedVariates {
+    unsigned base, off;
+    __device__ __forceinline__ void init(const pair_t* sRE, int wave, int lane)
+    {
+        base = lds_offset(sRE + (wave * 8 * 16 + (lane >> 2)));
+        off = base;
+    }
+    // after PairRng::run for the octet that holds step S (the step about to be taken)
+    __device__ __forceinline__ void fill(pair_t* sRE, int wave, int lane, int c, const PairRng& pr,
+                                         unsigned long long S)
+    {
+        pair_t* const mine = sRE + ((wave * 8 + 2 * c) * 16 + (lane >> 2));
+        mine[0] = pair_t{pr.r[0], pr.Ea[0]};
+        mine[16] = pair_t{pr.r[1], pr.Ea[1]};
+        off = base + (unsigned)(S & 7ull) * 256u;
+    }
+    __device__ __forceinline__ void fetch(double& r, double& Ea) const
+    {
+        const pair_t re = *(lds_pairs)(unsigned long long)off;
+        r = re.x;
+        Ea = re.y;
+    }
+    __device__ __forceinline__ void next() { off += 256u; }
+};
+
 // columns of one LDS chunk: a multiple of 4 (the variates come in fours); 14 KiB of pairs, 32 KiB
 // from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
 // workgroup barrier between chunks comes half as often)

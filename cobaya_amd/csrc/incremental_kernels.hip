@@ -172,10 +172,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     __syncthreads();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
-    // the (r, Ea) pairs of the current octet: [wave][step of the octet][walker of the wave]
-    __shared__ pair_t sRE[4 * 8 * 16];
-    const unsigned re_base = lds_offset(sRE + (wave * 8 * 16 + (lane >> 2)));
-    unsigned re_off = re_base;
+    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
+    StagedVariates sv;
+    sv.init(sRE, wave, lane);
     const int hw_slot = hw_wave_slot();
 
     for (int base = 0, k = 0; base < ncols; base += C, ++k) {
@@ -196,33 +195,23 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                 {
                     // Variates: EIGHT consecutive steps (an aligned octet of the global step index)
                     // at once -- lane class c draws the Philox block of the step pair 4 * octet + c
-                    // (PairRng: both halves, four logarithms, two square roots) and leaves its two
-                    // (r, Ea) pairs in the wave's corner of LDS, [step of the octet][walker]; a
-                    // step then reads its pair with ONE ds_read_b128, the same 16 bytes in the
-                    // four lanes of a walker.  (Until round 4 the pair came by a quad broadcast
-                    // behind an eight-way switch on the step index: 4 DPP moves and ~12 scalar
-                    // instructions per step -- and the scalar ones are not free: the kernel's time
-                    // follows VALU + SALU instructions, profiles/r04_instruction_diet.txt.)
+                    // (PairRng: both halves, four logarithms, two square roots) and stages its two
+                    // (r, Ea) pairs in LDS; a step reads its pair there (StagedVariates).
                     const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                     if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
                         cur_oct = S >> 3;
                         rotate_priority<inc_min_waves(DQ, MODE)>(hw_slot);
                         PairRng pr;
                         pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
-                        pair_t* const mine = sRE + ((wave * 8 + 2 * c) * 16 + (lane >> 2));
-                        mine[0] = pair_t{pr.r[0], pr.Ea[0]};
-                        mine[16] = pair_t{pr.r[1], pr.Ea[1]};
-                        re_off = re_base + (unsigned)(S & 7ull) * 256u;
+                        sv.fill(sRE, wave, lane, c, pr, S);
                     }
                     double r, Ea;
                     if (ONED && ((oned_cols >> sl) & 1ull)) {   // wave-uniform
                         step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
                     } else {
-                        const pair_t re = *(lds_pairs)(unsigned long long)re_off;
-                        r = re.x;
-                        Ea = re.y;
+                        sv.fetch(r, Ea);
                     }
-                    re_off += 256u;
+                    sv.next();
                     const lds_pairs col = (lds_pairs)(unsigned long long)coff;
                     double pc = 0.0, sc = 0.0;
                     // (the support test is kept as the wave's lane mask: every comparison lands
@@ -908,7 +897,9 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
 // lane class k, the logarithm by every lane.
 __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 {
-    int c = (2048 / ((1 + km) * 4 * dq)) & ~3;
+    // (14 KB of planes per chunk: beside the 8 KB of staged variates and the logarithm table a
+    // workgroup at four waves per SIMD stays within its 40 KB of LDS)
+    int c = (1792 / ((1 + km) * 4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }
 
@@ -989,8 +980,9 @@ step_inc_mix_kernel(const IncStepArgs a)
     const int hw_slot = hw_wave_slot();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
-    PairRng pr;
-    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
+    StagedVariates sv;
+    sv.init(sRE, wave, lane);
 
     for (int base = 0, kc = 0; base < ncols; base += C, ++kc) {
         const double* __restrict__ cur = smem + (kc & 1) * CHUNK;
@@ -1008,22 +1000,18 @@ step_inc_mix_kernel(const IncStepArgs a)
                 if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                     cur_oct = S >> 3;
                     rotate_priority<inc_mix_min_waves(DQ, KM)>(hw_slot);
+                    PairRng pr;
                     pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+                    sv.fill(sRE, wave, lane, c, pr, S);
                 }
                 double r, Ea;
                 if (ONED && ((oned_cols >> sl) & 1ull)) {   // wave-uniform: the un-paired 1-D variates
                     step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
                 } else
-                switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
-                case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
-                case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
-                case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
-                case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
-                case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
-                case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
-                case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
-                default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+                {
+                    sv.fetch(r, Ea);
                 }
+                sv.next();
                 const double* __restrict__ col = cur + sl * COL + c;
                 unsigned long long inb = ~0ull;   // the support test as a lane mask
                 double sc = 0.0;

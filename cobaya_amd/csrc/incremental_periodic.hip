@@ -150,8 +150,9 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
     __syncthreads();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
-    PairRng pr;
-    pr.r[0] = pr.r[1] = pr.Ea[0] = pr.Ea[1] = 0.0;
+    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
+    StagedVariates sv;
+    sv.init(sRE, wave, lane);
     const int hw_slot = hw_wave_slot();
     double* const myShift = sShift + (tid >> 2) * np;
 
@@ -168,22 +169,18 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
             if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step (see step_inc_kernel)
                 cur_oct = S >> 3;
                 rotate_priority<inc_periodic_min_waves(DQ)>(hw_slot);
+                PairRng pr;
                 pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
+                sv.fill(sRE, wave, lane, c, pr, S);
             }
             double r, Ea;
             if (ONED && ((oned_cols >> sl) & 1ull)) {   // wave-uniform
                 step_variates(s.key0, s.key1, gid, S, 0, true, r, Ea);
             } else
-            switch ((int)(S & 7)) {   // wave-uniform: (lane class, half) that drew step S
-            case 0: r = quad_perm<0x00>(pr.r[0]); Ea = quad_perm<0x00>(pr.Ea[0]); break;
-            case 1: r = quad_perm<0x00>(pr.r[1]); Ea = quad_perm<0x00>(pr.Ea[1]); break;
-            case 2: r = quad_perm<0x55>(pr.r[0]); Ea = quad_perm<0x55>(pr.Ea[0]); break;
-            case 3: r = quad_perm<0x55>(pr.r[1]); Ea = quad_perm<0x55>(pr.Ea[1]); break;
-            case 4: r = quad_perm<0xAA>(pr.r[0]); Ea = quad_perm<0xAA>(pr.Ea[0]); break;
-            case 5: r = quad_perm<0xAA>(pr.r[1]); Ea = quad_perm<0xAA>(pr.Ea[1]); break;
-            case 6: r = quad_perm<0xFF>(pr.r[0]); Ea = quad_perm<0xFF>(pr.Ea[0]); break;
-            default: r = quad_perm<0xFF>(pr.r[1]); Ea = quad_perm<0xFF>(pr.Ea[1]); break;
+            {
+                sv.fetch(r, Ea);
             }
+            sv.next();
             const double2* __restrict__ col = cur + sl * COLB + c;
             unsigned long long inb = ~0ull, wound = 0ull;
             double pc = 0.0, sc = 0.0;
@@ -363,6 +360,7 @@ hipError_t launch_periodic_dq(const IncStepArgs& a, hipStream_t st)
     // by the occupancy the registers are held to: one workgroup less per CU is a second round
     // of workgroups at 65 536 walkers)
     const size_t fixed = (size_t)4 * DQ * (16 + 32 + (a.has_norm ? 24 : 0)) + 16 * SHORT_LOG_TABLE_SIZE + 64 +
+                         sizeof(pair_t) * kStagedPairs +
                          sizeof(double) * (size_t)np * (64 + 4 * DQ);
     const size_t share = ((size_t)160 << 10) / inc_periodic_min_waves(DQ);
     int C = inc_chunk(DQ);
