@@ -46,6 +46,18 @@ if [ "$1" != "quick" ]; then
   cp $EVIDENCE_DST/traffic.json profiles/traffic.json
   timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 fi
+# ... and the four per-configuration lines again, for the same reason (the ones taken inside prof()
+# preceded their own counter passes and quote the previous traffic entry)
+requote() {  # requote <tag> <bench args...>
+  TAG=$1; shift
+  timeout 600 python bench.py --no-cpu-baseline --no-variants --steps 20 --warmup 4 --cross-check-seconds 0.25 $* > $EVIDENCE_DST/${TAG}_bench.json 2>/dev/null
+}
+if [ "$1" != "quick" ]; then
+  requote r04
+  requote r04_full --evaluation full
+  requote r04_d100 --dim 100 --steps 10 --warmup 2
+  requote r04_pl --workload pliklite --steps 8 --warmup 2
+fi
 [ -f gpurun_out/final_bench.json ] && cp gpurun_out/final_bench.json $EVIDENCE_DST/r04_bench_full_line.json
 cp gpurun_out/final_smoke.log $EVIDENCE_DST/r04_smoke.log 2>/dev/null
 rm -rf gpurun_out/final gpurun_out/final_full gpurun_out/final_d100 gpurun_out/final_pl
