@@ -347,6 +347,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
         one_step()
     if sampler._ckpt_pending:      # a checkpoint requested by the last launch belongs to it
         sampler._finish_checkpoint()
+        sampler._after_checkpoint()
     eng.sync()
     dist.barrier()
     dt = time.perf_counter() - t0
@@ -369,6 +370,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
             one_step()
         if sampler._ckpt_pending:
             sampler._finish_checkpoint()
+            sampler._after_checkpoint()
         eng.sync()
         dist.barrier()
         dx = time.perf_counter() - t0

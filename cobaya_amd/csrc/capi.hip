@@ -362,7 +362,13 @@ struct mcmc_hip_ctx {
     unsigned long long dir_epoch = 0;
     hipStream_t stream2 = nullptr;
     hipEvent_t mark = nullptr;               // main stream: behind the last step kernel
+    bool mark_valid = false;
     bool prefetch = true;
+    // the directions of the launch a call BEGINS with are formed at that call, not at the end of
+    // the previous one (step_incremental): a proposal refreshed in between is then in them at once
+    bool lazy_dirs = true;
+    hipEvent_t T_event = nullptr;            // main stream: behind the last write of dT
+    bool T_fresh = false;                    // ... which no direction set has been ordered behind yet
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
     // stream-ordered proposal refresh: pinned host staging
     double* pin_mom = nullptr;                      // [G*d + d(d+1)/2 + 2]
@@ -999,6 +1005,8 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         acc(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
         acc(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_least));
         acc(hipEventCreateWithFlags(&h->mark, hipEventDisableTiming));
+        acc(hipEventCreateWithFlags(&h->T_event, hipEventDisableTiming));
+        if (const char* e = getenv("MCMC_HIP_EAGER_DIRECTIONS")) h->lazy_dirs = !(e[0] && e[0] != '0');
         for (auto& D : h->dirs) acc(hipEventCreateWithFlags(&D.ready, hipEventDisableTiming));
         // MCMC_HIP_NO_PREFETCH (developer switch): directions on the main stream, in line
         h->prefetch = !getenv("MCMC_HIP_NO_PREFETCH");
@@ -1032,6 +1040,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
         if (D.ready) (void)hipEventDestroy(D.ready);
     }
     if (h->mark) (void)hipEventDestroy(h->mark);
+    if (h->T_event) (void)hipEventDestroy(h->T_event);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     h->x.release(); h->logpost.release(); h->logprior.release(); h->loglike.release();
     h->cblock.release(); h->dT.release(); h->V.release(); h->rows.release(); h->gsum.release();
@@ -1487,6 +1496,10 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
         if (D.ahead && D.ready) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
     HIP_TRY(h, hipMemcpyAsync(h->dT.p, slot, sizeof(double) * d * d, hipMemcpyHostToDevice,
                               h->stream));
+    if (h->T_event) {
+        HIP_TRY(h, hipEventRecord(h->T_event, h->stream));
+        h->T_fresh = true;
+    }
     h->have_cov = true;
     ++h->dir_epoch;
     return MCMC_HIP_OK;
@@ -1875,8 +1888,22 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         if (D.ahead) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
         D.ahead = false;
         if (!hit) {
-            const int rc = make_directions(h, P, seg, D, h->stream);
-            if (rc != MCMC_HIP_OK) return rc;
+            // Not prepared (the first launch of a call, see below): formed on the SECOND stream
+            // behind the previous step kernel (`mark`) -- beside the moment snapshot and the y
+            // refresh the main stream still holds, like a set prepared ahead -- and behind the
+            // last write of the transform: a proposal refreshed since the previous call is in
+            // them at once, nothing stale is computed and thrown away.
+            if (h->prefetch && h->lazy_dirs && h->mark_valid && h->stream2) {
+                HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
+                if (h->T_fresh) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->T_event, 0));
+                const int rc = make_directions(h, P, seg, D, h->stream2);
+                if (rc != MCMC_HIP_OK) return rc;
+                HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
+            } else {
+                const int rc = make_directions(h, P, seg, D, h->stream);
+                if (rc != MCMC_HIP_OK) return rc;
+            }
+            h->T_fresh = false;
         }
         {
             Timed t(h, 0);
@@ -1931,10 +1958,20 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             const IncSeg nxt = plan_segment(P, h->step + (unsigned long long)n,
                                             left > n ? left - n : n_steps);
             HIP_TRY(h, hipEventRecord(h->mark, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
-            const int rc = make_directions(h, P, nxt, N, h->stream2);
-            if (rc != MCMC_HIP_OK) return rc;
-            N.ahead = true;
+            h->mark_valid = true;
+            // (round 4) the launch a LATER call begins with is left to that call (above): the
+            // host is a launch ahead of the device, so its directions still run in the same
+            // place -- behind this step kernel, beside the main stream's work -- but see a
+            // transform that set_proposal_cov / the device checkpoint writes in between.
+            // Before, a refreshed proposal made the set prepared here stale and the next call
+            // recomputed it on the MAIN stream: 141 us instead of 72 between two step kernels
+            // after every learn checkpoint (tools/gpu_r4_timeline.sh).
+            if (left > n || !h->lazy_dirs) {
+                HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
+                const int rc = make_directions(h, P, nxt, N, h->stream2);
+                if (rc != MCMC_HIP_OK) return rc;
+                N.ahead = true;
+            }
         }
         h->dir_cur ^= 1;
         h->step += (unsigned long long)n;
@@ -2480,6 +2517,10 @@ int mcmc_hip_checkpoint_solve(mcmc_hip_ctx* h, double learn_lo, double learn_hi)
     s.d = (int)d; s.group_size = (double)h->gs; s.learn_lo = learn_lo; s.learn_hi = learn_hi;
     s.proposal_scale = h->cfg.proposal_scale;
     HIP_TRY(h, mcmc_hip_launch_ckpt_solve(&s, h->stream));
+    if (h->T_event) {   // (the kernel may have refreshed dT)
+        HIP_TRY(h, hipEventRecord(h->T_event, h->stream));
+        h->T_fresh = true;
+    }
     HIP_TRY(h, hipMemcpyAsync(K.pin_out, K.out.p, sizeof(double) * (8 + 2 * d * d),
                               hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipEventRecord(K.ev, h->stream));

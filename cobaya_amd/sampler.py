@@ -549,6 +549,7 @@ class EnsembleMCMC:
         self._next_ckpt = None   # steps per walker at which the next learn checkpoint is due
         self._ckpt_pending = False  # moments requested, checkpoint not processed yet
         self._ckpt_age = 0       # launches queued since the request
+        self._ckpt_post = False  # a checkpoint was processed in this pass: its snapshot / callback / files follow
         self._ckpt_on_device = False   # the pending checkpoint was solved on the device
         self._snaps_in_interval = 0    # moment snapshots since the last checkpoint request
         self._ckpt_steps_last = 0      # steps per walker at the last request
@@ -660,6 +661,8 @@ class EnsembleMCMC:
                 self.advance()
             if self._ckpt_pending:
                 self._finish_checkpoint()
+            if self._ckpt_post:
+                self._after_checkpoint()
             self.engine.sync()
             self._update_counters()
         except ChainStuck as e:
@@ -695,6 +698,15 @@ class EnsembleMCMC:
         self.n_steps_raw += spl
         self._launches += 1
         self._since_snapshot += spl
+        # A pending checkpoint is processed FIRST, right behind the launch just queued: its
+        # statistics came back long ago, and a refreshed proposal is then uploaded ahead of the
+        # moment snapshot -- the directions of the next launch, formed on the second stream
+        # behind that upload, start at once when this launch ends (tools/gpu_r4_timeline.sh:
+        # 127 -> 85 us between two step kernels after a learn checkpoint)
+        if self._ckpt_pending:
+            self._ckpt_age += 1
+            if self._ckpt_age >= self._ckpt_lag:
+                self._finish_checkpoint()
         if self._launches % max(1, int(self.moments_every)) == 0:
             eng.accumulate_moments()
             self._snaps_in_interval += 1
@@ -713,10 +725,8 @@ class EnsembleMCMC:
                 self._store_rows(eng.drain_samples())
         elif snap_every and self._since_snapshot >= snap_every:
             self._snapshot()
-        if self._ckpt_pending:
-            self._ckpt_age += 1
-            if self._ckpt_age >= self._ckpt_lag:
-                self._finish_checkpoint()
+        if self._ckpt_post:
+            self._after_checkpoint()
         # (a run that has just converged or reached max_samples leaves the loop: a request
         # queued now would be processed after convergence -- an extra progress row, possibly
         # `converged` flipped back under a "Sampling complete" log, mcmc.py:470)
@@ -781,6 +791,12 @@ class EnsembleMCMC:
         self._ckpt_on_device = False
         self.check_convergence_and_learn_proposal(moments, dev, payload)
         self.i_learn += 1
+        self._ckpt_post = True
+
+    def _after_checkpoint(self):
+        """What follows a processed checkpoint once the launch's own bookkeeping (moment
+        snapshot, emission) is done: the checkpoint's sample snapshot, the callback, the files."""
+        self._ckpt_post = False
         if self.emit == "snapshots" and not self.snapshot_every:
             self._snapshot()
         if self.callback_function:
