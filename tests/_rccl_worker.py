@@ -14,7 +14,17 @@ def run_checkpoints(use_group, device_checkpoint=False):
     from cobaya_amd import dist
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
-    if use_group:
+    if use_group == "torch":
+        # the loading order of a multi-rank job (dist.init_from_env): PyTorch first -- its gloo
+        # group is the bootstrap, and importing it maps the RCCL build that ships with it --, then
+        # the library binds RCCL at run time and creates its communicator
+        import torch
+        import torch.distributed as td
+        td.init_process_group("gloo", rank=0, world_size=1,
+                              init_method=f"tcp://127.0.0.1:{int(sys.argv[2])}")
+        assert torch.cuda.device_count() >= 1
+        dist.init_native_comm(0, 1, 0)
+    elif use_group:
         # the library's own RCCL communicator, a world of one on cuda:0 -- no PyTorch involved
         dist.init_native_comm(0, 1, 0)
         assert "torch" not in sys.modules
@@ -48,5 +58,6 @@ def run_checkpoints(use_group, device_checkpoint=False):
 
 if __name__ == "__main__":
     where = sys.argv[3] if len(sys.argv) > 3 else "host"
+    group = "torch" if sys.argv[1] == "nccl+torch" else sys.argv[1] == "nccl"
     print("RESULT " + json.dumps(run_checkpoints(
-        sys.argv[1] == "nccl", {"device": True, "reduce": "reduce", "host": False}[where])))
+        group, {"device": True, "reduce": "reduce", "host": False}[where])))

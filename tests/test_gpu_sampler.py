@@ -637,6 +637,36 @@ def test_rccl_path_with_one_rank():
     assert 0 < res["nccl"]["Rminus1_cl"] == res["none"]["Rminus1_cl"] < 1
 
 
+def test_rccl_communicator_after_pytorch_has_been_imported():
+    """The library-loading order of a real multi-rank job (`dist.init_from_env`): PyTorch is
+    imported and its gloo group formed FIRST (mapping whatever RCCL ships with it), then
+    libmcmc_hip.so binds RCCL at run time and creates its communicator (one rank here).  The
+    in-stream all-reduce of `device_checkpoint: reduce` runs through it, and the run equals the
+    one without PyTorch in the process, bit for bit."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for mode in ("nccl+torch", "nccl"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = subprocess.run([sys.executable, os.path.join(here, "_rccl_worker.py"), mode,
+                              str(port), "reduce"], capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")]
+        assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-3000:]
+        res[mode] = json.loads(lines[-1][7:])
+    a, b = res["nccl+torch"], res["nccl"]
+    assert a["collective"]["backend"] == "nccl" and a["collective"]["nranks_seen"] == 1
+    assert a["collective"]["bootstrap"] == "torch.distributed gloo" and b["collective"]["bootstrap"] is None
+    assert a["allreduce_identity"] and len(a["progress"]) >= 3
+    assert a["progress"] == b["progress"] and a["proposal_cov"] == b["proposal_cov"]
+    assert a["x_sum"] == b["x_sum"] and a["Rminus1_cl"] == b["Rminus1_cl"]
+
+
 def test_device_checkpoint_through_the_sampler_and_rccl():
     """Row N2 / VERDICT r2 item 7: `device_checkpoint: True` -- window sums, R-1 and the proposal
     refresh on the device, in stream order.  (i) With the library's communicator attached (RCCL,
