@@ -1182,6 +1182,28 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
 
     const double* __restrict__ z = sz[half];
     double* __restrict__ xs = sx[half];
+    // The scalars of the D - 1 reflections -- norm, sign, pivot, denominator -- depend on the
+    // normals alone, not on each other: lane n forms those of reflection n (its own ascending fma
+    // chain over the m = D - n normals of that reflection, two square roots), all reflections at
+    // once, instead of every lane repeating them one reflection after the other inside the
+    // sequential loop below (round 4: two dependent square roots per reflection were half of
+    // the kernel's 25 us -- it is one wave per SIMD of pure latency).  Same operations in the same
+    // order as before (orc_haar_from_normals): the results are bit-identical.
+    __shared__ double sPivot[2][D], sDen[2][D], sSign[2][D];
+    if (l < D - 1) {
+        const int n = l, m = D - n, ix = n * D - n * (n - 1) / 2;
+        double norm2 = 0.0;
+        for (int k = 0; k < m; ++k) norm2 = fma(z[ix + k], z[ix + k], norm2);
+        const double x0 = z[ix];
+        const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
+        const double x0n = x0 + Dn * sqrt(norm2);
+        double tt = norm2 - x0 * x0;
+        tt = tt + x0n * x0n;
+        sPivot[half][n] = x0n;
+        sDen[half][n] = sqrt(0.5 * tt);
+        sSign[half][n] = Dn;
+    }
+    __syncthreads();
     double H[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) H[k] = (k == l) ? 1.0 : 0.0;
@@ -1190,18 +1212,11 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
 #pragma unroll
     for (int n = 0; n < D - 1; ++n) {
         const int m = D - n;
-        double norm2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < m; ++k) norm2 = fma(z[ix + k], z[ix + k], norm2);
-        const double x0 = z[ix];
-        const double Dn = (x0 < 0.0) ? -1.0 : 1.0;
+        const double Dn = sSign[half][n];
         dprod *= Dn;
         if (l == n) Dmine = Dn;
-        const double x0n = x0 + Dn * sqrt(norm2);
-        double tt = norm2 - x0 * x0;
-        tt = tt + x0n * x0n;
-        const double den = sqrt(0.5 * tt);
-        __syncthreads();
+        const double x0n = sPivot[half][n], den = sDen[half][n];
+        if (n) __syncthreads();   // (the previous reflection's xs has been used)
         if (l < m) xs[l] = ((l == 0) ? x0n : z[ix + l]) / den;
         __syncthreads();
         double tmp = 0.0;
@@ -1268,20 +1283,55 @@ __global__ void __launch_bounds__(256) group_moments_kernel(const MomentArgs a)
 #pragma unroll
     for (int i = 0; i < D; ++i) sX[tid * LDX + i] = a.x[(size_t)i * a.W + w] - a.shift[i];
     __syncthreads();
-    if (tid < D) {
+    // Every sum is ONE chain over the group's walkers in ascending order (the specification); a
+    // chain's operands are read from LDS eight walkers at a time, so that the reads of a batch
+    // travel together instead of one LDS round trip per term (round 4: the kernel has one wave
+    // per SIMD and nothing else to cover them: 14.6 -> ~6 us at group_size 256, d = 30).  A thread
+    // runs two chains side by side: the pairs p and p + gs, or -- the last D threads, whose
+    // second pair does not exist when NPAIR <= 2 gs - D -- a pair and a group sum.
+    auto pair_of = [](int p, int& i, int& j) {   // p = i(i+1)/2 + j, i >= j
+        i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+        while ((i + 1) * (i + 2) / 2 <= p) ++i;
+        while (i * (i + 1) / 2 > p) --i;
+        j = p - i * (i + 1) / 2;
+    };
+    const bool sums_ride = NPAIR + D <= 2 * gs;   // the group sums fit beside the second pairs
+    for (int p0 = tid; p0 < NPAIR || (sums_ride && p0 < gs); p0 += 2 * gs) {
+        const int p1 = p0 + gs;
+        const bool has0 = p0 < NPAIR, has1 = p1 < NPAIR;
+        const int sidx = tid - (gs - D);                       // the group sum this thread carries
+        const bool sum1 = sums_ride && !has1 && p0 < gs && sidx >= 0 && sidx < D;
+        int i0 = 0, j0 = 0, i1 = 0, j1 = 0;
+        if (has0) pair_of(p0, i0, j0);
+        if (has1) pair_of(p1, i1, j1);
+        if (sum1) i1 = sidx;
+        double s0 = 0.0, s1 = 0.0;
+        int l = 0;
+        for (; l + 8 <= gs; l += 8) {
+            double a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                a0[q] = sX[(l + q) * LDX + i0]; b0[q] = sX[(l + q) * LDX + j0];
+                a1[q] = sX[(l + q) * LDX + i1]; b1[q] = sX[(l + q) * LDX + j1];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                s0 = fma(a0[q], b0[q], s0);
+                s1 = sum1 ? s1 + a1[q] : fma(a1[q], b1[q], s1);
+            }
+        }
+        for (; l < gs; ++l) {
+            s0 = fma(sX[l * LDX + i0], sX[l * LDX + j0], s0);
+            s1 = sum1 ? s1 + sX[l * LDX + i1] : fma(sX[l * LDX + i1], sX[l * LDX + j1], s1);
+        }
+        if (has0) a.Sg[(size_t)g * NPAIR + p0] = s0;
+        if (has1) a.Sg[(size_t)g * NPAIR + p1] = s1;
+        if (sum1) a.group_sum[(size_t)g * D + sidx] += s1;
+    }
+    if (!sums_ride && tid < D) {   // (small groups: the sums on their own)
         double s = 0.0;
         for (int l = 0; l < gs; ++l) s = s + sX[l * LDX + tid];
         a.group_sum[(size_t)g * D + tid] += s;
-    }
-    for (int p = tid; p < NPAIR; p += gs) {
-        // p -> (i, j), i >= j, p = i(i+1)/2 + j
-        int i = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-        while ((i + 1) * (i + 2) / 2 <= p) ++i;
-        while (i * (i + 1) / 2 > p) --i;
-        const int j = p - i * (i + 1) / 2;
-        double s = 0.0;
-        for (int l = 0; l < gs; ++l) s = fma(sX[l * LDX + i], sX[l * LDX + j], s);
-        a.Sg[(size_t)g * NPAIR + p] = s;
     }
 }
 
@@ -1290,8 +1340,16 @@ __global__ void __launch_bounds__(64) pool_moments_kernel(const MomentArgs a)
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= NPAIR) return;
     double acc = a.pooled[p];
-    // loads batched 16 deep (latency), additions strictly in ascending group order (spec)
+    // loads batched 64 deep (a batch is one L2 round trip: 16 deep the 256 groups of config 2 took
+    // 11 us), additions strictly in ascending group order (spec)
     int g = 0;
+    for (; g + 64 <= a.G; g += 64) {
+        double v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = a.Sg[(size_t)(g + u) * NPAIR + p];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc += v[u];
+    }
     for (; g + 16 <= a.G; g += 16) {
         double v[16];
 #pragma unroll
