@@ -95,6 +95,29 @@ def init_native_comm(rank_=None, size_=None, device=None):
     return _comm
 
 
+def _create_comm_guarded(timeout_s):
+    """`init_native_comm()` with a deadline: ncclCommInitRank blocks until every rank has joined
+    and cannot be cancelled -- a rank whose peers never arrive (a bootstrap interface RCCL cannot
+    use, a rank that died) would hang the job.  The call runs in a helper thread (ctypes releases
+    the GIL); past the deadline this rank reports failure, and the agreement that follows sends
+    every rank to the gloo stand-in.  Returns None or the reason."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            init_native_comm()
+        except Exception as e:      # EngineError with RCCL's message
+            box["err"] = f"{type(e).__name__}: {e}"
+    t = threading.Thread(target=work, name="mcmc_hip-rccl-init", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        return (f"timed out after {timeout_s:g} s in ncclCommInitRank (MCMC_HIP_RCCL_TIMEOUT; "
+                f"NCCL_SOCKET_IFNAME selects the bootstrap interface)")
+    return box.get("err")
+
+
 def init_from_env(backend=None):
     """From RANK/WORLD_SIZE/MASTER_* (torch.distributed.run or bench.py's own launcher) when
     WORLD_SIZE > 1; a no-op for single-process runs.  `backend` (or $MCMC_HIP_BACKEND):
@@ -122,18 +145,14 @@ def init_from_env(backend=None):
         # leave the others inside ncclCommInitRank with a different idea of the backend: every
         # rank reports, and unless ALL succeeded the job falls back -- loudly -- to the gloo
         # stand-in for the collective (the kernels are unaffected; `describe()` says what runs).
-        err = None
-        try:
-            init_native_comm()
-        except Exception as e:      # EngineError with RCCL's message
-            err = f"{type(e).__name__}: {e}"
+        err = _create_comm_guarded(float(os.environ.get("MCMC_HIP_RCCL_TIMEOUT", "300")))
         import torch
         flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
         _td().all_reduce(flag, op=_td().ReduceOp.MIN)
         if float(flag[0]) < 0.5:
-            if _comm is not None:
+            if _comm is not None and not (err or "").startswith("timed out"):
                 _comm.close()
-                _comm = None
+            _comm = None
             _rccl_error = err or "another rank could not create its RCCL communicator"
             import sys
             print(f"[mcmc_hip] WARNING: the RCCL communicator could not be created on every rank "
