@@ -353,6 +353,7 @@ struct mcmc_hip_ctx {
         DevBuf<double> V, Vf, VU;
         DevBuf<int> vflag, vflag_f, colflag;   // colflag: 1-D columns of the launch, in VU order
         bool has_flags = false;
+        DevBuf<double> UU;                   // |u|^2 of the columns (step_inc_kernel: one mode, no periodic parameter)
         hipEvent_t ready = nullptr;          // recorded on the stream that filled the set
         bool ahead = false;                  // filled ahead of its launch (on stream2)
         unsigned long long step0 = ~0ull, epoch = 0;
@@ -1035,7 +1036,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     resolve_timing(h);
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto& D : h->dirs) {
-        D.V.release(); D.Vf.release(); D.VU.release(); D.vflag.release(); D.vflag_f.release();
+        D.V.release(); D.Vf.release(); D.VU.release(); D.vflag.release(); D.vflag_f.release(); D.UU.release();
         D.colflag.release();
         if (D.ready) (void)hipEventDestroy(D.ready);
     }
@@ -1723,6 +1724,7 @@ struct IncPlan {   // what the cutting of launches depends on besides the step c
     unsigned long long R;
     bool drag;
     bool any;   // the general kernel (incremental_any.hip): columns as planes (v, u_1 .. u_K)
+    bool carry; // step_inc_kernel (one mode, no periodic parameter, Metropolis steps): the log-likelihood is carried
 };
 struct IncSeg {    // one launch: steps [step0, step0 + n)
     unsigned long long step0, c0, cyc0_f;
@@ -1789,6 +1791,10 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
     w.out_total = s.n * (1 + nd);
     w.colflag = D.has_flags ? D.colflag.p : nullptr;
     w.vflag = any_1d ? D.vflag.p : nullptr;
+    if (P.carry) {
+        HIP_TRY(h, D.UU.resize((size_t)h->BG * s.n));
+        w.UU = D.UU.p;
+    }
     if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
     if (P.any) HIP_TRY(h, mcmc_hip_launch_whiten_directions_planes(&w, h->BG, st));
     else HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
@@ -1822,6 +1828,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     // four modes, mixtures above d = 64, periodic parameters with a mixture, more than eight of
     // them -- Metropolis steps only
     P.any = !P.drag && (K > 4 || (K > 1 && dq > 16) || (n_periodic > 0 && (K > 1 || n_periodic > 8)));
+    P.carry = false;   // (set below, once the kernel is chosen)
     if (K < 1 || K > mcmc::kMaxModes || (P.drag && (K > 1 || n_periodic > 0)) ||
         (P.drag && drag_lds > (128u << 10)))
         return fail(h, MCMC_HIP_ERR_ARG,
@@ -1849,6 +1856,9 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                         "incremental evaluation: %d modes at d=%d with %d periodic parameters do "
                         "not fit the LDS of a CU; use evaluation: full for this model", K, d, n_periodic);
     }
+    // one mode, no periodic parameter, Metropolis steps: step_inc_kernel, which carries the
+    // log-likelihood along the whitened direction and needs |u|^2 of every column
+    P.carry = !P.any && !P.drag && K == 1 && n_periodic == 0;
     auto launch = P.any ? mcmc_hip_launch_inc_any
                   : emit ? (dq <= 8 ? mcmc_hip_launch_inc_emit_1 : dq <= 16 ? mcmc_hip_launch_inc_emit_9
                           : dq <= 24 ? mcmc_hip_launch_inc_emit_17 : mcmc_hip_launch_inc_emit_25)
@@ -1874,10 +1884,12 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         P.drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * P.ddf * (size_t)h->BG)) : 0;
     int left = n_steps;
     while (left > 0) {
+        bool anchor = false;   // y is refreshed from x before this launch
         if (!h->y_valid || h->step % P.R == 0) {
             HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
                                                     d, h->W, K, h->stream));
             h->y_valid = true;
+            anchor = true;
         }
         const IncSeg seg = plan_segment(P, h->step, left);
         const int n = seg.n;
@@ -1935,6 +1947,8 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.n_drag = nd; a.chunk_steps = P.chunk_steps;
             a.colflag = D.has_flags ? D.colflag.p : nullptr;
             a.Lrow = h->inc_Lrow.p;
+            a.UU = P.carry ? D.UU.p : nullptr;
+            a.anchor = anchor ? 1 : 0;
             for (int i = 0; i < d; ++i)
                 if (h->periodic[i]) a.periodic_mask4[i >> 5] |= 1u << (i & 31);
             HIP_TRY(h, launch(&a, h->stream));

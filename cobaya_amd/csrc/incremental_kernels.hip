@@ -161,10 +161,18 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
             sNM[i] = a.prior[4 * dpad + i];
         }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    if (a.anchor) {   // (wave-uniform) y has just been refreshed from x: the carried log-likelihood
+        double pa = 0.0;   // is re-anchored on it (orc_anchor_loglike)
+#pragma unroll
+        for (int kk = 0; kk < DQ; ++kk) pa = fma(y[kk], y[kk], pa);
+        llik = -0.5 * (s.cnorm0 + quad_sum(pa));
+        lpost = lpri + llik;
+    }
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;     // accepted steps of this launch (< 2^31)
     int nrow = EMIT ? s.n_rows[w] : 0;
+    const double* __restrict__ gUU = a.UU + (size_t)g * ncols;   // |u|^2 of the launch's columns
     const uint32_t gid = s.walker0 + (uint32_t)w;
     // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
     const double mt10 = s.max_tries * 10.0;
@@ -217,6 +225,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         sv.fetch(r, Ea);
                     }
                     sv.next();
+                    const double uu = gUU[base + sl];   // (wave-uniform address: a scalar load)
                     const lds_pairs col = (lds_pairs)(unsigned long long)coff;
                     double pc = 0.0, sc = 0.0;
                     // (the support test is kept as the wave's lane mask: every comparison lands
@@ -240,8 +249,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             const double2 lh = sLH[4 * kk + c];
                             inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
                         }
-                        const double yt = fma(r, p.y, y[kk]);
-                        pc = fma(yt, yt, pc);
+                        pc = fma(y[kk], p.y, pc);   // (y . u: the log-likelihood is carried)
                         if (NORMP) {
                             const int i = 4 * kk + c;
                             const double loc = kNormInRegs ? nloc[kk] : sNA[i].x;
@@ -305,12 +313,13 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     } else {
                         inside_m = quad_all_mask(inb);
                     }
-                    const double chi2 = quad_sum(pc);
+                    // chi2(y + r u) - chi2(y) = r (2 y.u + r |u|^2): the trial's log-likelihood from
+                    // the carried one (step_core_inc, `carry`)
+                    const double yu = quad_sum(pc);
                     const double lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
-                    const double ll = -0.5 * (s.cnorm0 + chi2);
-                    // (outside the support lt is not used; a chi2 that overflowed gives
-                    // lt = -inf, which fails both comparisons like the specification's
-                    // explicit lt != -inf)
+                    const double ll = fma(-0.5 * r, fma(r, uu, yu + yu), llik);
+                    // (outside the support lt is not used; an overflow gives lt = -inf or NaN,
+                    // which fail both comparisons like the specification's explicit lt != -inf)
                     const double lt = lp + ll;
                     const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
                     const unsigned long long acc_m = inside_m & (lanes(lt > lpost) | lanes(Ea > delta));
@@ -331,9 +340,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             }
                             nrow += em ? 1 : 0;   // rows beyond the capacity are counted as dropped
                         }
-                        lpri = accept ? lp : lpri;
-                        llik = accept ? ll : llik;
                     }
+                    llik = accept ? ll : llik;
+                    if (NORMP) lpri = accept ? lp : lpri;   // (else: uniform_logp, always)
                     // (burn-in, mcmc.py:685-690, ends early in a run: its bookkeeping sits
                     // behind a wave-uniform test of "some lane is still burning in")
                     const bool was_burning = burning;   // (wave-uniform)
@@ -396,8 +405,6 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             }
                         }
                     }
-                    // (logprior and loglike of the current point are formed once, after the
-                    // loop, from the committed x and y: the same chains on the same values)
                     lpost = accept ? lt : lpost;
                     {
                         const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
@@ -416,23 +423,6 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk has landed
         __syncthreads();
-    }
-    if (!EMIT && nacc != 0) {   // (the same in the four lanes of a walker: the quad sums are safe)
-        double pc = 0.0, sc = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < DQ; ++kk) {
-            pc = fma(y[kk], y[kk], pc);
-            if (NORMP) {
-                const int i = 4 * kk + c;
-                const double loc = kNormInRegs ? nloc[kk] : sNA[i].x;
-                const double inv = kNormInRegs ? ninv[kk] : sNA[i].y;
-                const double mls = kNormInRegs ? nmls[kk] : sNM[i];
-                const double qq = (x[kk] - loc) * inv;
-                sc = sc + fma(-0.5 * qq, qq, mls);
-            }
-        }
-        llik = -0.5 * (s.cnorm0 + quad_sum(pc));
-        lpri = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
     }
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
@@ -859,6 +849,22 @@ __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs
     }
     if (part == 3)
         for (int j = d; j < 4 * a.dq; ++j) out[j] = make_double2(0.0, 0.0);
+    if (a.UU) {
+        // |u|^2 in the pattern of every chi2 here (orc_direction_norms): chain p over the rows
+        // j = p (mod 4) ascending -- one wave each, the u's read back from the column this
+        // workgroup has just written --, then (s0 + s1) + (s2 + s3)
+        __shared__ double sq[4][64];
+        __syncthreads();   // (only reached when every thread of the workgroup is live, see below)
+        double sp = 0.0;
+        for (int j = part; j < d; j += 4) {
+            const double u = out[j].y;
+            sp = fma(u, u, sp);
+        }
+        sq[part][l] = sp;
+        __syncthreads();
+        if (part == 0)
+            a.UU[(size_t)g * a.out_total + ocol] = (sq[0][l] + sq[1][l]) + (sq[2][l] + sq[3][l]);
+    }
 }
 
 // Mixtures: the same per mode, written as PLANES -- VU[g][step][0] = v, [1 + k] = u_k = L_k^-1 v,

@@ -233,6 +233,11 @@ struct IncStepArgs {
     // dimension i; Lrow = L^-1 row-major [d][d] (a wrap moves the residual by a column of it)
     unsigned periodic_mask4[4];
     const double* Lrow;
+    // step_inc_kernel (one mode, no periodic parameter): |u|^2 of the launch's columns
+    // [G][n_steps], and whether this launch starts where y has just been refreshed from x -- the
+    // carried log-likelihood is then re-anchored on y (oracle: orc_anchor_loglike)
+    const double* UU;
+    int anchor;
 };
 
 struct IncDirArgs {
@@ -250,6 +255,9 @@ struct IncDirArgs {
     // are copied to colflag[G][out_total] (null: nothing to write) at the columns' places in VU
     const int* vflag;
     int* colflag;
+    // |u|^2 of every column, [G][out_total], in the four-chain pattern of chi2 (null: not wanted):
+    // step_inc_kernel carries the log-likelihood along the direction (oracle: orc_direction_norms)
+    double* UU;
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

@@ -728,15 +728,57 @@ void orc_whiten_directions(const orc_problem* p, int ncol, const double* V, doub
     }
 }
 
+/* sum of squares in the pattern of every chi2 here: four interleaved chains over i & 3, combined
+ * (s0 + s1) + (s2 + s3) */
+static inline double four_chain_squares(const double* a, int d)
+{
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < d; ++i) s[i & 3] = fma(a[i], a[i], s[i & 3]);
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+/* |u_c|^2 of the whitened directions of a cycle (one mode), in that pattern */
+void orc_direction_norms(const orc_problem* p, int ncol, const double* U, double* UU)
+{
+    for (int c = 0; c < ncol; ++c) UU[c] = four_chain_squares(U + (size_t)c * p->d, p->d);
+}
+
+/* ONE Gaussian mode, no periodic parameter (step_inc_kernel; round 4): the log-likelihood itself
+ * is carried.  chi2(y + r u) - chi2(y) = r (2 y.u + r |u|^2), so the trial's
+ *     ll_t = fma(-0.5 r, fma(r, |u|^2, y.u + y.u), ll)
+ * with y.u in the four-chain pattern and |u|^2 formed once per direction (orc_direction_norms) --
+ * one chain over the dimensions per trial instead of two (d fewer FP64 instructions of the ~ 60
+ * a step issues per lane), and a difference that is formed directly instead of as the difference
+ * of two sums.  Like y, ll follows the rounding of its own updates and is re-anchored where y is
+ * refreshed: orc_anchor_loglike. */
+static inline int carries_loglike(const orc_problem* p, const orc_state* st)
+{
+    if (!(p->incremental && p->n_modes == 1 && !p->has_periodic)) return 0;
+    /* (emitted rows with a one-parameter block run on the general kernel, incremental_any.hip,
+     * which forms every chi2 from the trial's residual) */
+    if (st->rows && p->blocking)
+        for (int b = 0; b < p->blocking->n_blocks; ++b)
+            if (p->blocking->size[b] == 1) return 0;
+    return 1;
+}
+
+void orc_anchor_loglike(const orc_problem* p, orc_state* st, int w)
+{
+    const double* y = st->y + (size_t)w * p->d;
+    st->loglike[w] = -0.5 * (p->cnorm[0] + four_chain_squares(y, p->d));
+    st->logpost[w] = st->logprior[w] + st->loglike[w];
+}
+
 /* One step in incremental mode.  Trial t = x + r v and, per mode, its whitened residual
  * yt_k = y_k + r u_k; prior terms and every chi2_k are summed as FOUR interleaved chains over the
  * dimensions i = c (mod 4) (the kernel keeps dimension i in lane i mod 4 of the walker's quad),
  * combined (s0 + s1) + (s2 + s3) -- for every d in this mode.  u: [K] pointers to the mode's
  * whitened direction of this step.  K > 1: log-sum-exp as in eval_point. */
 static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, const double* v,
-                                const double* const* u, double r, double exp_draw)
+                                const double* const* u, double uu, double r, double exp_draw)
 {
     int d = p->d, K = p->n_modes;
+    const int carry = carries_loglike(p, st);
     double t[128], yt[16 * 128], sh[128];
     const double* x = st->x + (size_t)w * d;
     double* y = st->y + (size_t)w * K * d;
@@ -771,7 +813,14 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
             }
         lp = p->uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
         double a[16], amax = -INFINITY;
-        for (int k = 0; k < K; ++k) {
+        if (carry) {
+            double q[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < d; ++i) q[i & 3] = fma(y[i], u[0][i], q[i & 3]);
+            const double yu = (q[0] + q[1]) + (q[2] + q[3]);
+            a[0] = fma(-0.5 * r, fma(r, uu, yu + yu), st->loglike[w]);
+            for (int i = 0; i < d; ++i) yt[i] = fma(r, u[0][i], y[i]);
+        }
+        for (int k = 0; k < K && !carry; ++k) {
             double pc[4] = {0.0, 0.0, 0.0, 0.0};
             for (int i = 0; i < d; ++i) yt[k * d + i] = fma(r, u[k][i], y[k * d + i]);
             if (wound) {   /* a wrap by sh_i moves the residual by sh_i (column i of L^-1) */
@@ -1098,17 +1147,21 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
             if (p->incremental && !drag) {
                 const int K = p->n_modes;
                 if (cycle != have_u) {
-                    if (!U) U = (double*)malloc(sizeof(double) * (size_t)K * L0 * d);
+                    if (!U) U = (double*)malloc(sizeof(double) * ((size_t)K * L0 * d + (size_t)L0));
                     orc_whiten_directions(p, L0, V, U);
+                    if (carries_loglike(p, st)) orc_direction_norms(p, L0, U, U + (size_t)K * L0 * d);
                     have_u = cycle;
                 }
+                const double uu = carries_loglike(p, st) ? U[(size_t)K * L0 * d + col] : 0.0;
                 const double* uk[16];
                 for (int k = 0; k < K; ++k) uk[k] = U + ((size_t)k * L0 + col) * d;
                 for (int l = 0; l < gs; ++l) {
                     int w = g * gs + l;
                     double r, Ea;
-                    if (step % (uint64_t)p->refresh_every == 0)
+                    if (step % (uint64_t)p->refresh_every == 0) {
                         orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * K * d);
+                        if (carries_loglike(p, st)) orc_anchor_loglike(p, st, w);
+                    }
                     /* a column of a one-parameter block draws the RandProposer1D variates of
                      * the un-paired stream, as in full evaluation (its half of the pair block
                      * stays unused) */
@@ -1118,7 +1171,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                         walker_variates_pair(k0, k1, walker0 + (uint32_t)w, step, &r, &Ea);
                     else
                         walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
-                    total += step_core_inc(p, st, w, v, uk, r, Ea);
+                    total += step_core_inc(p, st, w, v, uk, uu, r, Ea);
                 }
                 continue;
             }
