@@ -238,9 +238,10 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 1024 SIMDs, one p
 
 
 def algo_flops_incremental(d):
-    """FP64 arithmetic one INCREMENTAL evaluation executes: trial x, trial y, chi2, and the
-    commits of x and y -- five fused multiply-adds per dimension."""
-    return 10 * d
+    """FP64 arithmetic one INCREMENTAL evaluation executes on step_inc_kernel since round 4 (the
+    log-likelihood is carried): trial x, the chain y.u, and the commits of x and y -- four fused
+    multiply-adds per dimension (rounds 2-3: five -- trial y and its square instead of y.u)."""
+    return 8 * d
 
 
 def csrc_sha16():
