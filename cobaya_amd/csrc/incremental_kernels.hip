@@ -172,7 +172,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;     // accepted steps of this launch (< 2^31)
     int nrow = EMIT ? s.n_rows[w] : 0;
-    const double* __restrict__ gUU = a.UU + (size_t)g * ncols;   // |u|^2 of the launch's columns
+    // |u|^2 of the launch's columns, through the constant address space: the address is
+    // wave-uniform, the load a scalar one (s_load_dwordx2 on the scalar cache's counter -- a vector
+    // load would queue behind the DMA of the next chunk on vmcnt)
+    const cdoubles gUU = (cdoubles)(unsigned long long)(a.UU + (size_t)g * ncols);
     const uint32_t gid = s.walker0 + (uint32_t)w;
     // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
     const double mt10 = s.max_tries * 10.0;
