@@ -92,6 +92,9 @@ def parse():
                          "beside the next launch (`device_checkpoint: reduce`); host: all of it "
                          "from the pinned read-back beside the next launch.  Default: the "
                          "sampler's (host on one GPU, reduce for N > 1)")
+    ap.add_argument("--checkpoint-lag", type=int, default=None,
+                    help="launches between the request of a checkpoint and its processing on the "
+                         "host (`checkpoint_lag`; default: the sampler's)")
     ap.add_argument("--attach-comm", action="store_true",
                     help="single process: attach a ONE-rank RCCL communicator, so that the "
                          "checkpoint queues the same ncclAllReduce an N-GPU job does")
@@ -296,6 +299,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
                          evaluation or a.evaluation)
         if a.basis_group_size and (evaluation or a.evaluation) != "full":
             info["sampler"]["mcmc_hip"]["basis_group_size"] = a.basis_group_size
+    if getattr(a, "checkpoint_lag", None):
+        info["sampler"]["mcmc_hip"]["checkpoint_lag"] = int(a.checkpoint_lag)
     if a.device_checkpoint is not None:   # (default: the sampler's -- reduce for N > 1)
         info["sampler"]["mcmc_hip"]["device_checkpoint"] = {"device": True, "reduce": "reduce",
                                                             "host": False}[a.device_checkpoint]

@@ -117,9 +117,12 @@ HIP_DEFAULTS = {
                               # dragging, snapshots); "auto": incremental where it applies
     "checkpoint_lag": None,   # launches between the request of a learn / convergence checkpoint
                               # and its processing on the host (the refreshed proposal takes
-                              # effect with the launch queued after that).  Default: 1 for a
-                              # single process, 2 when the checkpoint holds a collective -- see
-                              # `advance`
+                              # effect with the launch queued after that).  Default: 2 -- the
+                              # host's pass over a checkpoint (~ 1 ms of Python, R-1, Cholesky,
+                              # upload) then has two launches of cover; with one (round 3's
+                              # single-process default) a launch of 0.9 ms no longer covers it
+                              # on a slow host, and with several processes the collective's
+                              # kernel needs the room as well -- see `advance`
     "shared_basis": True,     # True: the walkers of a group share one Haar basis per cycle;
                               # False: every walker draws its own (proposal.py:59-69 to the
                               # letter: the reference-faithful control, much slower)
@@ -233,9 +236,8 @@ class EnsembleMCMC:
             self._fail("emit must be 'snapshots' or 'chains', got %r", self.emit)
         dist.init_from_env()
         self.rank, self.size = dist.rank(), dist.size()
-        self._ckpt_lag_default = self.checkpoint_lag is None
         if self.checkpoint_lag is None:
-            self.checkpoint_lag = 1 if self.size == 1 else 2
+            self.checkpoint_lag = 2
         if int(self.checkpoint_lag) != self.checkpoint_lag or int(self.checkpoint_lag) < 1:
             self._fail("checkpoint_lag must be an integer >= 1, got %r", self.checkpoint_lag)
         self._ckpt_lag = int(self.checkpoint_lag)
@@ -446,10 +448,6 @@ class EnsembleMCMC:
         if self._device_ckpt:
             self.engine.checkpoint_set_ring(self._intervals)
             self.engine.checkpoint_set_accepted(self._acc_last)
-            if attached and self._ckpt_lag_default:
-                # the collective is IN the stream: nothing of it runs beside a step kernel, so the
-                # host need not stay a launch further behind (`advance`)
-                self._ckpt_lag = 1
 
     def set_proposer_blocking(self):
         """mcmc.py:320-410: parameter blocks and oversampling factors (manual `blocking` or
@@ -682,17 +680,19 @@ class EnsembleMCMC:
         checkpoint falls due, the read-out of the sufficient statistics is only QUEUED behind
         the launch (`request_moments`); the next launch is queued right after it, and while
         that one runs the host fetches the statistics, all-reduces them, forms R-1 and uploads
-        the refreshed proposal in stream order.  The new proposal therefore takes effect one
-        launch after the checkpoint (deterministically, also across a resume).
+        the refreshed proposal in stream order.  The new proposal therefore takes effect
+        `checkpoint_lag` launches after the checkpoint (deterministically, also across a
+        resume).
 
-        With several processes the checkpoint holds a collective, and the step kernel leaves
-        no room on the device beside it (its workgroups are exactly what the chip
-        holds): the RCCL kernel only runs when the first workgroups of the launch in flight
-        retire, i.e. the host gets the reduced statistics at the END of that launch and would
-        queue the next one late.  `checkpoint_lag: 2` (the default for more than one process)
-        therefore processes a checkpoint one launch later: a launch is always queued behind
-        the one whose tail the collective waits for, and the new proposal takes effect two
-        launches after the checkpoint -- as deterministically as before."""
+        `checkpoint_lag: 2` (the default): the host's pass over a checkpoint -- about a
+        millisecond of Python, R-1, a Cholesky factor, the upload -- has two launches of cover.
+        With one, a launch that has become shorter than that pass (0.9 ms at BASELINE config 2
+        since round 4) leaves the device waiting on a slow host; and with several processes
+        on the host path the step kernel leaves no room on the device beside it (DESIGN.md 4:
+        its workgroups are exactly what the chip holds), so the RCCL kernel of the all-reduce
+        only runs when the first workgroups of the launch in flight retire: the host gets the
+        reduced statistics at the END of that launch.  A launch is therefore always queued
+        behind the one the checkpoint's processing overlaps."""
         eng, spl = self.engine, self.steps_per_launch
         eng.step(spl)
         self.n_steps_raw += spl

@@ -86,7 +86,7 @@ def test_shards_on_several_gpus_equal_the_slices_of_one_ensemble(tmp_path, world
     from cobaya_amd.model import ProblemSpec
     from cobaya_amd.sampler import MCMCHip
     res = run_ranks(tmp_path, world, "nolearn")
-    assert res[0]["checkpoint_mode"] == "reduce" and res[0]["checkpoint_lag"] == 1   # the defaults for N > 1
+    assert res[0]["checkpoint_mode"] == "reduce" and res[0]["checkpoint_lag"] == 2   # the defaults for N > 1
     opts = dict(w.options(world, False, walkers=2048 * world), checkpoint_lag=res[0]["checkpoint_lag"],
                 device_checkpoint=res[0]["checkpoint_mode"])
     one = MCMCHip(opts, ProblemSpec.from_info(w.problem()))

@@ -457,7 +457,7 @@ def test_bounds_criterion_in_every_emit_mode(emit, max_rows):
              learn_every="5d", steps_per_launch=20, snapshot_every=None)
     s.run()
     prog = s.progress
-    assert s.converged and len(prog) >= 3
+    assert s.converged and len(prog) >= 2   # (the means criterion has to hold twice in a row)
     cl = prog["Rminus1_cl"].to_numpy(float)
     r = prog["Rminus1"].to_numpy(float)
     assert np.isfinite(cl[-1]) and cl[-1] < 0.3
