@@ -570,9 +570,10 @@ class Engine:
         return n.value, gs, S, {"steps": int(c[0]), "accepted": int(c[1])}
 
     # -- the checkpoint on the device
-    def checkpoint_set_ring(self, intervals=(), min_capacity=16):
+    def checkpoint_set_ring(self, intervals=(), min_capacity=16, first_index=0):
         """`intervals`: the (n_snapshots, group_sum[G][d], pooled_S[d][d]) the caller still
-        holds, oldest first (none at the start of a run)."""
+        holds, oldest first (none at the start of a run).  (`first_index`, the run's index of the
+        first of them, is of no use to the device, which sums a window slot by slot.)"""
         n = len(intervals)
         gs = _f64(np.array([iv[1] for iv in intervals]).reshape(n, self.G * self.d)) if n else None
         S = _f64(np.array([iv[2] for iv in intervals]).reshape(n, self.d * self.d)) if n else None

@@ -141,6 +141,48 @@ def _number_with_units(value, unit, scale):
     return value
 
 
+class WindowSums:
+    """Sums of the statistics of CONSECUTIVE checkpoint intervals [lo, hi) -- absolute indices:
+    interval i is the i-th one the run has closed -- as a fixed function of those intervals: the
+    canonical decomposition of [lo, hi) into aligned dyadic blocks, added in ascending order, a
+    block's sum being left half + right half.  Block sums of four intervals and more are cached,
+    so that a checkpoint costs O(log n) array additions instead of the n of a running `sum()` over
+    the window (the window is the later half of the run: it grows with it, and at a thousand
+    checkpoints the host spent milliseconds per checkpoint adding 60 KB arrays).  Nothing of the
+    cache is state: a resumed run rebuilds it and forms the same sums, bit for bit."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def _block(self, level, k, get):
+        if level == 0:
+            return get(k)
+        key = (level, k)
+        v = self._cache.get(key)
+        if v is None:
+            a, b = self._block(level - 1, 2 * k, get), self._block(level - 1, 2 * k + 1, get)
+            v = tuple(x + y for x, y in zip(a, b))
+            if level >= 2:
+                self._cache[key] = v
+        return v
+
+    def total(self, lo, hi, get):
+        """Sum over the intervals lo <= i < hi (hi > lo); `get(i)` -> tuple of arrays."""
+        i, acc = lo, None
+        while i < hi:
+            level = 0
+            while i % (2 << level) == 0 and i + (2 << level) <= hi:
+                level += 1
+            part = self._block(level, i >> level, get)
+            acc = part if acc is None else tuple(x + y for x, y in zip(acc, part))
+            i += 1 << level
+        return acc
+
+    def forget_below(self, lo):
+        for key in [k for k in self._cache if ((k[1] + 1) << k[0]) <= lo]:
+            del self._cache[key]
+
+
 class EnsembleMCMC:
     """The engine-backed sampler logic, host-agnostic.  Two hosts give it a constructor:
 
@@ -446,7 +488,7 @@ class EnsembleMCMC:
         self._device_ckpt = bool(mode)
         self._ckpt_solve_on_device = mode in (True, "solve")
         if self._device_ckpt:
-            self.engine.checkpoint_set_ring(self._intervals)
+            self.engine.checkpoint_set_ring(self._intervals, first_index=self._iv0)
             self.engine.checkpoint_set_accepted(self._acc_last)
 
     def set_proposer_blocking(self):
@@ -534,6 +576,8 @@ class EnsembleMCMC:
         self._txt_rows = 0       # data rows of this process' chain file
         self._carried = None     # table rows of earlier legs, read back at resume
         self._intervals = []     # per checkpoint: (n_snapshots, group_sum[G,d], pooled_S[d,d])
+        self._iv0 = 0            # absolute index of _intervals[0] (intervals dropped so far)
+        self._wsums = WindowSums()
         self._dropped_snapshots = 0
         self._progress_rows = {}  # i_learn -> row dict (DataFrame built on demand: `progress`)
         self.i_learn = 1
@@ -766,7 +810,7 @@ class EnsembleMCMC:
         counts = [iv[0] for iv in self._intervals] + [self._snaps_in_interval]
         k = self._window_len(counts, self._dropped_snapshots)
         if k + 1 > eng.ckpt_capacity:     # the window outgrew the ring: reload it, larger
-            eng.checkpoint_set_ring(self._intervals, min_capacity=2 * (k + 1))
+            eng.checkpoint_set_ring(self._intervals, min_capacity=2 * (k + 1), first_index=self._iv0)
         ptr, n = eng.checkpoint_begin(k, sum(counts[-k:]), self.n_steps_raw - self._ckpt_steps_last)
         if self.size > 1 and not getattr(eng, "comm_attached", False):
             # (an engine the communicator is attached to has queued the all-reduce itself)
@@ -870,6 +914,7 @@ class EnsembleMCMC:
                      proposal_cov=self.engine.get_proposal_cov(), shift=self._shift,
                      iv_n=np.array([iv[0] for iv in ivs], dtype=np.int64),
                      iv_gs=np.array([iv[1] for iv in ivs]), iv_S=np.array([iv[2] for iv in ivs]),
+                     iv0=np.int64(self._iv0),
                      book=np.array([self.n_steps_raw, self.i_learn, self._acc_last,
                                     self._steps_last, self._launches, self._dropped_snapshots,
                                     self._accepted_total, self.seed, self.size,
@@ -914,6 +959,8 @@ class EnsembleMCMC:
                 self.log.info("The snapshots behind R-1 of the bounds were not kept in the state "
                               "file (too large, or bounds_snapshots changed): that ring restarts empty.")
         self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]
+        self._iv0 = int(z["iv0"]) if "iv0" in z else 0
+        self._wsums = WindowSums()
         (self.n_steps_raw, self.i_learn, self._acc_last, self._steps_last, self._launches,
          self._dropped_snapshots, self._accepted_total) = (int(v) for v in book[:7])
         self._next_ckpt = int(book[10]) or None
@@ -1089,19 +1136,31 @@ class EnsembleMCMC:
         return c
 
     # ------------------------------------------------------------------ a15 + a16
-    def _window(self):
+    def _window(self, sums=True):
         """Statistics over the later half of the run ([n/2:], mcmc.py:787-790) at interval
         granularity: the shortest suffix of checkpoint intervals holding >= half of all
         snapshots taken so far.  The window start only moves forward, so earlier intervals
-        are dropped (their snapshot count is remembered)."""
+        are dropped (their snapshot count is remembered).  `sums=False`: the books only (the
+        device summed the same window)."""
+        if getattr(self, "_wsums", None) is None:   # (bookkeeping set up by hand: tests)
+            self._iv0, self._wsums = 0, WindowSums()
         ivs = self._intervals
-        total = self._dropped_snapshots + sum(iv[0] for iv in ivs)
-        k = 0
-        while k + 1 < len(ivs) and sum(iv[0] for iv in ivs[k + 1:]) >= total / 2:
+        counts = [iv[0] for iv in ivs]
+        total = self._dropped_snapshots + sum(counts)
+        k, rest = 0, sum(counts)
+        while k + 1 < len(ivs) and rest - counts[k] >= total / 2:
+            rest -= counts[k]
             k += 1
-        self._dropped_snapshots += sum(iv[0] for iv in ivs[:k])
+        self._dropped_snapshots += sum(counts[:k])
         self._intervals = ivs = ivs[k:]
-        return (sum(iv[0] for iv in ivs), sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs))
+        self._iv0 += k
+        if k:
+            self._wsums.forget_below(self._iv0)
+        if not sums:
+            return rest, None, None
+        i0 = self._iv0
+        gsum, Ssum = self._wsums.total(i0, i0 + len(ivs), lambda i: ivs[i - i0][1:])
+        return rest, gsum, Ssum
 
     def check_convergence_and_learn_proposal(self, moments=None, dev=None, payload=None):
         """mcmc.py:773-1032 on pooled sufficient statistics; one all-reduce.
@@ -1136,13 +1195,13 @@ class EnsembleMCMC:
                     (Ssum - N_c * sum_mm).ravel(), means.sum(0), sum_mm.ravel()))
                 dist.all_reduce_sum(payload)               # RCCL over xGMI when size > 1
             else:
-                self._window()  # (the books only; the device summed the same window, in stream order)
+                self._window(sums=False)  # (the books only; the device summed the same window, in stream order)
             n_chains, sum_N, d_acc, d_steps, n_acc_all = payload[:5]
             sum_Ncov = payload[5:5 + d * d].reshape(d, d)
             sum_mean = payload[5 + d * d:5 + d * d + d]
             sum_mm = payload[5 + d * d + d:].reshape(d, d)
         else:
-            self._window()      # (the books only: which intervals the window holds from now on)
+            self._window(sums=False)      # (the books only: which intervals the window holds from now on)
             d_acc, d_steps, n_acc_all = dev["d_accepted"], dev["d_steps"], dev["accepted"]
         self._acc_last, self._steps_last = c["accepted"], c["steps"]
         if dev is None and not from_device and getattr(self, "_device_ckpt", False):

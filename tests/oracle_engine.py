@@ -299,8 +299,11 @@ class OracleEngine:
     # -- the device side of `device_checkpoint: reduce` (mcmc_hip_checkpoint_set_ring / _begin /
     # _request_payload / _fetch_payload): the ring of intervals, the window sums and the payload an
     # all-reduce carries, with the arithmetic of the sampler's host path
-    def checkpoint_set_ring(self, intervals=(), min_capacity=16):
+    def checkpoint_set_ring(self, intervals=(), min_capacity=16, first_index=0):
+        from cobaya_amd.sampler import WindowSums
         self._ck_ring = [(int(n), np.array(gs, float), np.array(S, float)) for n, gs, S in intervals]
+        self._ck_base = int(first_index)     # the run's index of _ck_ring[0]
+        self._ck_sums = WindowSums()
         self.ckpt_capacity = 16
         while self.ckpt_capacity < max(len(self._ck_ring) + 2, int(min_capacity)):
             self.ckpt_capacity *= 2
@@ -323,8 +326,14 @@ class OracleEngine:
         ivs = self._ck_ring[-int(n_window_intervals):]
         if sum(iv[0] for iv in ivs) != n_window_snapshots:
             raise RuntimeError("the window's snapshot count disagrees with the ring's intervals")
-        self._ck_ring = self._ck_ring[-self.ckpt_capacity:]
-        gsum, Ssum = sum(iv[1] for iv in ivs), sum(iv[2] for iv in ivs)
+        hi = self._ck_base + len(self._ck_ring)
+        ring, base = self._ck_ring, self._ck_base
+        # (the host path's arithmetic: WindowSums over the run's interval indices)
+        gsum, Ssum = self._ck_sums.total(hi - len(ivs), hi, lambda i: ring[i - base][1:])
+        drop = max(0, len(self._ck_ring) - self.ckpt_capacity)
+        self._ck_ring = self._ck_ring[drop:]
+        self._ck_base += drop
+        self._ck_sums.forget_below(self._ck_base)
         G, W = self.G, self.W
         N_c = float(n_window_snapshots * self.group_size)
         means = gsum / N_c

@@ -708,3 +708,36 @@ def test_incremental_supported_is_a_pure_function_of_the_shape():
     assert not ok(30, 17, 0, 0, W, gs) and not ok(30, 0, 0, 0, W, gs)
     assert not ok(128, 16, 0, 0, W, gs)                            # 0.5 MB of residuals per wave
     assert not ok(30, 1, 0, 0, W, 100) and not ok(30, 1, 0, 0, 1000, 256)
+
+
+def test_window_sums_are_a_fixed_function_of_the_intervals_and_cost_log_n():
+    """Round 4: the host-path checkpoint sums the window (the later half of the run) in
+    O(log n) array additions -- `WindowSums`: aligned dyadic blocks over the run's interval
+    indices, cached -- instead of n.  The sum is a fixed function of the intervals in [lo, hi):
+    a fresh object (a resumed run) forms the same bits as one that has followed the whole run."""
+    from cobaya_amd.sampler import WindowSums
+    rng = np.random.default_rng(8)
+    ivs = [(rng.normal(size=(7, 3)), rng.normal(size=(3, 3))) for _ in range(700)]
+    adds = [0]
+
+    class Counted(np.ndarray):
+        def __add__(self, other):
+            adds[0] += 1
+            return np.ndarray.__add__(self, other)
+    ivc = [tuple(a.view(Counted) for a in iv) for iv in ivs]
+    ws, cost = WindowSums(), []
+    for hi in range(1, 701):          # the run: one more interval per checkpoint, window = later half
+        lo = hi // 2
+        ws.forget_below(lo)
+        adds[0] = 0
+        got = ws.total(lo, hi, lambda i: ivc[i])
+        cost.append(adds[0] / 2)      # (two arrays per interval)
+        if hi in (1, 2, 3, 17, 100, 333, 700):
+            fresh = WindowSums().total(lo, hi, lambda i: ivs[i])
+            for a, b in zip(got, fresh):
+                assert np.array_equal(np.asarray(a), b)
+            ref = [sum(iv[q] for iv in ivs[lo:hi]) for q in (0, 1)]
+            for a, b in zip(got, ref):
+                np.testing.assert_allclose(np.asarray(a), b, rtol=1e-12, atol=1e-12)
+    assert max(cost[400:]) <= 4 * np.log2(700) and np.mean(cost[400:]) < 20   # (a plain sum: 200 ... 350)
+    assert len(ws._cache) < 700
