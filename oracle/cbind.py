@@ -127,6 +127,7 @@ def lib():
                                         c_double_p, c_int32_p]
         L.orc_whiten.argtypes = [C.POINTER(_Problem), c_double_p, c_double_p]
         L.orc_whiten_directions.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p]
+        L.orc_direction_norms.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p]
         L.orc_max_threads.restype = C.c_int
         L.orc_binned_chi2_of_delta.restype = C.c_double
         L.orc_binned_chi2_of_delta.argtypes = [C.POINTER(_Binned), c_double_p]
@@ -408,6 +409,14 @@ class Problem:
         U = np.empty((max(self.K, 1),) + V.shape)
         lib().orc_whiten_directions(C.byref(self.c), len(V), _dp(V), _dp(U))
         return U[0] if self.K <= 1 else U
+
+    def direction_norms(self, U):
+        """|u_c|^2 of whitened directions U[ncol][d] (one mode) in the four-chain pattern of every
+        chi2 (orc_direction_norms): what step_inc_kernel's carried log-likelihood moves by."""
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        UU = np.empty(len(U))
+        lib().orc_direction_norms(C.byref(self.c), len(U), _dp(U), _dp(UU))
+        return UU
 
     def basis(self, group, cycle):
         V = np.empty((self.d, self.d))

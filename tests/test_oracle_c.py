@@ -936,3 +936,61 @@ def test_binned_gaussian_steps_sample_the_posterior():
     assert np.all(np.abs(mean - best) < 5 * sig / np.sqrt(W / 8)), (mean - best) / sig
     ratio = st.x.std(axis=0) / sig
     assert np.all((ratio > 0.8) & (ratio < 1.25)), ratio
+
+
+def test_carried_loglikelihood_follows_the_evaluated_one_and_is_re_anchored():
+    """Round 4 (step_inc_kernel, oracle step_core_inc `carry`): with ONE mode and no periodic
+    parameter the log-likelihood is carried, ll_t = fma(-r/2, fma(r, |u|^2, 2 y.u), ll), instead of
+    being formed from the trial's residual.  (i) |u|^2 is the four-chain sum of squares of the
+    whitened direction; (ii) between two refreshes the carried value stays within rounding of the
+    log-likelihood evaluated from scratch at the same point; (iii) where y is refreshed from x
+    (every 40 cycles) it is re-anchored: -chi2(y)/2 in the four-chain pattern, logpost = logprior +
+    loglike, exactly; (iv) a mixture keeps the two-chain form (no anchor: its state is untouched
+    by a refresh)."""
+    from oracle import cbind as O
+    d = 11
+    rng = np.random.default_rng(17)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.002
+    mean = np.full(d, 0.5)
+    T = O.proposal_transform(cov, 2.4)
+    p = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov, T=T, group_size=64,
+                  seed=6, incremental=True)
+    assert p.refresh_every == 40 * d
+    # (i)
+    V = p.basis(3, 5)
+    U = p.whiten_directions(V)
+    ref = np.array([(u[0::4] ** 2).sum() + (u[1::4] ** 2).sum() + (u[2::4] ** 2).sum()
+                    + (u[3::4] ** 2).sum() for u in U])
+    np.testing.assert_allclose(p.direction_norms(U), ref, rtol=1e-14)
+    x0 = np.clip(mean + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
+    st = O.State(p, x0)
+    # (ii) just before the first refresh after the start: 40 d - 1 carried steps
+    st.run(40 * d - 1, n_threads=4)
+    lp, ll = p.evaluate(st.x)
+    assert st.n_accept.sum() > 128 * 40         # (the walkers did move)
+    assert np.max(np.abs(st.loglike - ll)) < 1e-10 and np.max(np.abs(st.loglike - ll)) > 0
+    np.testing.assert_allclose(st.logpost, lp + ll, rtol=0, atol=1e-10)
+    # (iii) step 40 d is a refresh: take ONE step and undo nothing -- instead predict the anchor
+    # for the walkers that reject it (their point is the refreshed one)
+    before = st.n_accept.copy()
+    st.run(1, n_threads=1)
+    stay = st.n_accept == before
+    assert stay.sum() > 20
+    y = p.whiten(st.x)
+    anchored = np.empty(len(y))
+    for w in range(len(y)):
+        s4 = [0.0, 0.0, 0.0, 0.0]
+        for i in range(d):
+            s4[i & 3] = float(np.float64(y[w, i]) * np.float64(y[w, i]) + s4[i & 3])   # (no fma: to rounding)
+        anchored[w] = -0.5 * (p.cnorm[0] + ((s4[0] + s4[1]) + (s4[2] + s4[3])))
+    np.testing.assert_allclose(st.loglike[stay], anchored[stay], rtol=1e-14)
+    assert np.array_equal(st.logpost[stay], st.logprior[stay] + st.loglike[stay])
+    # (iv)
+    pm = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=[mean, mean + 0.03], covs=[cov, cov],
+                   weights=[0.5, 0.5], T=T, group_size=64, seed=6, incremental=True)
+    sm = O.State(pm, x0)
+    ll0 = sm.loglike.copy()
+    sm.run(1, n_threads=1)                      # (step 0 is a refresh)
+    keep = sm.n_accept == 0
+    assert keep.sum() > 20 and np.array_equal(sm.loglike[keep], ll0[keep])
