@@ -67,7 +67,9 @@ typedef struct mcmc_hip_config {
  * every walker carries y_k = L_k^-1 (x - mu_k) and a trial moves it along the whitened shared
  * direction, y_k' = y_k + r L_k^-1 v -- the same log-posterior (gaussian_mixture.py:158-163) in
  * O(d) per step and mode; y is recomputed from x every 40 cycle lengths (40 d steps for one
- * block).  What the mode does not serve is refused by mcmc_hip_step with MCMC_HIP_ERR_ARG.
+ * block).  With ONE mode and no periodic parameter the log-likelihood is carried as well:
+ * loglike' = loglike - r/2 (2 y.u + r |u|^2), u = L^-1 v, re-anchored on y wherever y is
+ * recomputed.  What the mode does not serve is refused by mcmc_hip_step with MCMC_HIP_ERR_ARG.
  * Specified in oracle/mcmc_oracle.c. */
 #define MCMC_HIP_FLAG_INCREMENTAL 2
 /* incremental mode: the walkers that share one Haar basis = group_size << ((flags >> 8) & 15)
