@@ -180,6 +180,7 @@ def make_pliklite_info(n_lin, walkers, group_size, spl):
             "seed": 1, "n_walkers": walkers, "group_size": group_size, "steps_per_launch": spl,
             "covmat": C, "covmat_params": list(params), "Rminus1_stop": 0.0,
             "learn_proposal": True, "emit": "snapshots", "max_rows": 0}},
+        "_certify_against": (np.concatenate((emu.theta0, [1.0])), C, 1),
     }, tgt
 
 
@@ -261,6 +262,85 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+ACCEPTANCE_GATE = (0.15, 0.5)   # a healthy Metropolis chain of this proposal (mcmc.py:545-562, 670-748)
+KL_GATE = 0.07                  # the reference's own tolerance: tests/common_sampler.py:18, 152-161
+
+
+def expected_moments(info):
+    """Mean and covariance of the posterior an input describes, where they are known in closed
+    form: a gaussian_mixture (moments of the mixture), or a `gaussian` likelihood times normal
+    priors (product of Gaussians).  The uniform boxes are wide against the target (their
+    truncation is ignored: < 1e-6 of the mass at the benchmark targets).  None otherwise."""
+    like = info["likelihood"]
+    names = list(info["params"])
+    d = len(names)
+    if "gaussian_mixture" in like:
+        gm = like["gaussian_mixture"]
+        means = np.atleast_2d(np.asarray(gm["means"], dtype=float))
+        covs = np.asarray(gm["covs"], dtype=float)
+        covs = covs if covs.ndim == 3 else covs[None]
+        K = len(means)
+        w = np.asarray(gm.get("weights") if gm.get("weights") is not None else np.full(K, 1.0 / K), dtype=float)
+        w = w / w.sum()
+        m = w @ means
+        C = sum(w[k] * (covs[k] + np.outer(means[k], means[k])) for k in range(K)) - np.outer(m, m)
+        return m, C, K
+    if "gaussian" in like:
+        mean = np.asarray(like["gaussian"]["mean"], dtype=float)
+        P = np.linalg.inv(np.asarray(like["gaussian"]["cov"], dtype=float))
+        h = P @ mean
+        for i, n in enumerate(names):
+            pr = info["params"][n]["prior"]
+            if pr.get("dist") == "norm":
+                P[i, i] += 1.0 / pr["scale"] ** 2
+                h[i] += pr["loc"] / pr["scale"] ** 2
+        C = np.linalg.inv(P)
+        return C @ h, C, 1
+    return None
+
+
+def certify(info, x, accepted, evals, gate=True, approx=None):
+    """What the timed region produced, beside how long it took (VERDICT r4 "Next round" 1b): the
+    acceptance rate over the timed steps and the moments of the ensemble the region leaves --
+    `x` [W][d], one sample per walker -- against the known posterior: max |mean error| / sigma,
+    max error of the covariance in units of sigma_i sigma_j, and the Gaussian KL divergence the
+    reference's sampler tests gate on (tests/common_sampler.py:152-161; cobaya/tools.py:745).
+    `ok` is False when the acceptance rate leaves [0.15, 0.5] or (single Gaussian targets) the KL
+    exceeds 0.07 -- a kernel that stopped accepting, or walked somewhere else, fails the run."""
+    rate = accepted / max(evals, 1.0)
+    out = {"acceptance_rate": rate, "accepted": int(accepted), "evaluations": float(evals),
+           "acceptance_gate": list(ACCEPTANCE_GATE)}
+    ok = ACCEPTANCE_GATE[0] <= rate <= ACCEPTANCE_GATE[1]
+    exp = approx or expected_moments(info)
+    if exp is not None and x is not None:
+        m0, C0, K = exp
+        sig = np.sqrt(np.diag(C0))
+        m = x.mean(0)
+        C = np.cov(x.T)
+        dm = m - m0
+        kl = 0.5 * (np.trace(np.linalg.solve(C, C0)) + dm @ np.linalg.solve(C, dm) - len(m0)
+                    + np.linalg.slogdet(C)[1] - np.linalg.slogdet(C0)[1])
+        pc = {"samples": int(len(x)), "of": "the ensemble at the end of the timed region (one "
+              "sample per walker)", "max_mean_err_over_sigma": float(np.max(np.abs(dm) / sig)),
+              "max_cov_err_over_sigma_i_sigma_j": float(np.max(np.abs(C - C0) / np.outer(sig, sig))),
+              "KL": float(kl), "KL_gate": KL_GATE,
+              # what a PERFECT sampler scores with this many independent samples
+              "KL_sampling_floor": len(m0) * (len(m0) + 3) / (4.0 * len(x)),
+              "sampling_error_of_a_mean_over_sigma": float(1.0 / np.sqrt(len(x)))}
+        gated = bool(gate and K == 1 and approx is None)
+        pc["gated"] = gated
+        if approx is not None:
+            pc["note"] = ("against the Gaussian (Fisher) approximation of a posterior that is not "
+                          "Gaussian in the calibration parameter: reported, not gated")
+        elif K > 1:
+            pc["note"] = "moments of the mixture (KL between Gaussians of those moments: reported, not gated)"
+        if gated and not kl <= KL_GATE:
+            ok = False
+        out["posterior_check"] = pc
+    out["ok"] = bool(ok)
+    return out
+
+
 def measured_traffic(d, walkers, spl, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/traffic.json, written by tools/collect_evidence.py from `rocprofv3 --pmc
@@ -304,6 +384,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
     if a.device_checkpoint is not None:   # (default: the sampler's -- reduce for N > 1)
         info["sampler"]["mcmc_hip"]["device_checkpoint"] = {"device": True, "reduce": "reduce",
                                                             "host": False}[a.device_checkpoint]
+    approx = info.pop("_certify_against", None)   # (pliklite: the Fisher approximation)
     sampler = MCMCHip(info["sampler"]["mcmc_hip"], ProblemSpec.from_info(info))
     eng = sampler.engine
     spl = int(sampler.steps_per_launch)   # chains: capped by the device row buffer
@@ -348,6 +429,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
     n_ckpt0, rows_kept[0] = sampler.i_learn, 0
     dist.barrier()
     eng.sync()
+    acc0 = eng.counters()["accepted"]
     t0 = time.perf_counter()
     for _ in range(steps):
         one_step()
@@ -359,6 +441,10 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
     dt = time.perf_counter() - t0
     if size > 1:   # MAX over ranks
         dt = float(dist.all_reduce_max(np.array([dt]))[0])
+    # what the region produced (outside the clock): accepted steps of all ranks, and rank 0's
+    # ensemble as it stands at the end of the K timed steps
+    accepted = float(dist.all_reduce_sum(np.array([float(eng.counters()["accepted"] - acc0)]))[0])
+    x_end = eng.get_state()["x"]
     kt = eng.kernel_times()
     if sampler.spec.like_kind == "planck_pliklite":
         kt["binned"] = eng.binned_kernel_times()
@@ -396,6 +482,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
            "rows_in_store": int(sampler._n_rows), "drain_slots": int(getattr(eng, "drain_slots", 0)),
            "rows_copied_on_host": int(sum(len(r) for r in sampler._rows if not sampler._is_slot_view(r))),
            "cross_check": cross}
+    res["certificate"] = certify(info, x_end, accepted, res["evals"],
+                                 approx=approx)
     sampler.close()
     return res
 
@@ -523,6 +611,10 @@ def main_pliklite(a, rank, size):
                        "d": 27, "walkers_per_gpu": a.walkers, "group_size": m["group_size"],
                        "metropolis_steps_per_launch": m["spl"], "evaluation": m["evaluation"],
                        "learn_checkpoints_in_timed_region": m["n_ckpt"]},
+            "acceptance_rate": m["certificate"]["acceptance_rate"],
+            "accepted": m["certificate"]["accepted"],
+            "posterior_check": m["certificate"].get("posterior_check"),
+            "certified": bool(m["certificate"]["ok"]),
             "roofline": pliklite_roofline(m, tgt.n_bins, a.walkers, a.steps),
             "cpu_baseline": None if a.no_cpu_baseline else cpu_baseline_pliklite(26, a.cpu_seconds)}
         print(json.dumps(out))
@@ -587,6 +679,7 @@ def main():
         v_ms = v["kt"]["step_ms"] / max(v["kt"]["step_launches"], 1)
         v_launches = v["kt"]["step_launches"] / n_v
         variants.append({
+            "certificate": v["certificate"],
             "variant": "evaluation: full (every trial evaluated from scratch)",
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
             "steps": n_v, "warmup": 4, "kernel": v["kernel"], "kernel_ms_per_launch": v_ms,
@@ -604,6 +697,7 @@ def main():
         n_v = 3
         v = run_timed(a, d, mean, cov, "snapshots", n_v, 1, info=info_c)
         variants.append({
+            "certificate": v["certificate"],
             "variant": "to-the-letter control: shared_basis: False (a Haar basis per walker per "
                        "cycle) + evaluation: full",
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
@@ -617,6 +711,7 @@ def main():
         # same workload with those semantics: rows cross PCIe and are kept on the host
         v = run_timed(a, d, mean, cov, "chains", 40, 4)
         variants.append({
+            "certificate": v["certificate"],
             "variant": "emit: chains (every accepted row drained to a pinned host ring at PCIe "
                        "speed; a launch's 4.7 M rows exceed max_rows, so the host does NOT retain "
                        "them here -- see the retained variant below)",
@@ -643,6 +738,7 @@ def main():
             n_v, w_v = (12, 8) if "drain_ring_bytes" in extra else (4, 1)   # (warm-up: every slot pinned once)
             v = run_timed(a, d, mean, cov, "chains", n_v, w_v, info=info_r)
             variants.append({
+                "certificate": v["certificate"],
                 "variant": "emit: chains, rows retained on the host (" + label + ")",
                 "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
                 "steps": n_v, "warmup": w_v, "metropolis_steps_per_launch": v["spl"],
@@ -658,6 +754,7 @@ def main():
         n_v = 6
         v = run_timed(a, d4, m4, c4, "snapshots", n_v, 2)
         variants.append({
+            "certificate": v["certificate"],
             "variant": "BASELINE configs[3]: 100-dim single-mode gaussian_mixture, 65536 walkers",
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
             "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
@@ -670,6 +767,7 @@ def main():
         info5 = make_info(d5, m5, c5, a.walkers, a.group_size, 40 * d5, normal_from=6)
         v = run_timed(a, d5, m5, c5, "snapshots", n_v, 3, info=info5)
         variants.append({
+            "certificate": v["certificate"],
             "variant": "BASELINE configs[4] shape: 27-dim `gaussian` likelihood, 6 uniform + 21 "
                        "normal priors (synthetic stand-in), 65536 walkers",
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
@@ -687,6 +785,7 @@ def main():
         n_v = 4
         v = run_timed(a, d, mean, cov, "snapshots", n_v, 2, info=info8)
         variants.append({
+            "certificate": v["certificate"],
             "variant": "8-mode gaussian_mixture at d = 30 (the general incremental kernels), 65536 walkers",
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
             "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
@@ -700,6 +799,7 @@ def main():
         info6, tgt6 = make_pliklite_info(26, a.walkers, a.group_size, spl6)
         v = run_timed(a, 27, None, None, "snapshots", n_v, 2, info=info6)
         entry = {
+            "certificate": v["certificate"],
             "variant": "BASELINE configs[4] arithmetic: planck_pliklite (613 bins, FP64-MFMA "
                        "triangular GEMM), 26-parameter linear Cl(theta) + A_planck, 65536 walkers; "
                        "synthetic plik-lite-shaped data",
@@ -742,6 +842,7 @@ def main():
     if rank == 0:
         spl, dt = m["spl"], m["dt"]
         roofline = gaussian_roofline(m, d, a.walkers, a.steps)
+        cert = m["certificate"]
         out = {
             "metric": "log-posterior evals/sec (whole node), %d-dim gaussian_mixture" % d,
             "value": m["evals"] / dt, "unit": "evals/s", "n_gpus": size, "steps": a.steps,
@@ -762,6 +863,12 @@ def main():
                 "checkpoint_on": m["checkpoint_on"],
                 "parallelism": f"walkers sharded over {size} GPU(s); one all-reduce per "
                                "checkpoint"},
+            # what the timed region produced (certify()): a run that stopped accepting or left
+            # the target fails (exit code 3) instead of posting a rate
+            "acceptance_rate": cert["acceptance_rate"], "accepted": cert["accepted"],
+            "posterior_check": cert.get("posterior_check"),
+            "certified": bool(cert["ok"] and all(v.get("certificate", {}).get("ok", True)
+                                                 for v in variants)),
             "cross_check": m["cross_check"],
             "collective": collective,
             "roofline": roofline,
@@ -775,6 +882,14 @@ def main():
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.shutdown()     # (the communicator is destroyed while every rank is still there)
+    if out is not None and not out["certified"]:
+        bad = [("headline", cert)] + [(v["variant"], v["certificate"]) for v in variants
+                                      if not v.get("certificate", {}).get("ok", True)]
+        for name, c in bad:
+            if not c["ok"]:
+                print(f"[bench] NOT CERTIFIED: {name}: acceptance {c['acceptance_rate']:.3f}, "
+                      f"posterior_check {c.get('posterior_check')}", file=sys.stderr)
+        sys.exit(3)
     return out
 
 

@@ -1121,11 +1121,22 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
     const int Lf = drag ? orc_block_slots(p, 2, NULL) : 0;
     const int nd = drag ? B->drag_steps : 0;
     int64_t total = 0;
+    /* Wide basis groups (4 096 walkers at the benchmark geometry) leave fewer groups than
+     * threads: a group is then cut into `nsub` runs of walkers, each of which forms the group's
+     * bases itself -- they are pure functions of (group, cycle), so the results are the same
+     * bit for bit (tests/test_oracle_c.py::test_run_is_invariant_to_the_thread_split). */
+    int nsub = 1;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
+    {
+        int want = n_threads > 0 ? n_threads : omp_get_max_threads();
+        while (G * nsub < want && gs % (2 * nsub) == 0 && gs / (2 * nsub) >= 64) nsub *= 2;
+    }
 #pragma omp parallel for schedule(static) reduction(+ : total)
 #endif
-    for (int g = 0; g < G; ++g) {
+    for (int gi = 0; gi < G * nsub; ++gi) {
+        const int g = gi / nsub;
+        const int l_lo = (gi % nsub) * (gs / nsub), l_hi = l_lo + gs / nsub;
         uint32_t group = walker0 / (uint32_t)gs + (uint32_t)g;
         double* V = (double*)malloc(sizeof(double) * (size_t)L0 * d);
         int32_t* f1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(L0 + Lf + 1));
@@ -1155,7 +1166,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 const double uu = carries_loglike(p, st) ? U[(size_t)K * L0 * d + col] : 0.0;
                 const double* uk[16];
                 for (int k = 0; k < K; ++k) uk[k] = U + ((size_t)k * L0 + col) * d;
-                for (int l = 0; l < gs; ++l) {
+                for (int l = l_lo; l < l_hi; ++l) {
                     int w = g * gs + l;
                     double r, Ea;
                     if (step % (uint64_t)p->refresh_every == 0) {
@@ -1176,7 +1187,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 continue;
             }
             if (!drag) {
-                for (int l = 0; l < gs; ++l) {
+                for (int l = l_lo; l < l_hi; ++l) {
                     int w = g * gs + l;
                     double r, Ea;
                     walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, f1[col], &r, &Ea);
@@ -1206,7 +1217,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 orc_whiten_directions(p, 1, v, U);
                 for (int i = 1; i <= nd; ++i) orc_whiten_directions(p, 1, vfp[i - 1], U + (size_t)i * d);
             }
-            for (int l = 0; l < gs; ++l) {
+            for (int l = l_lo; l < l_hi; ++l) {
                 int w = g * gs + l;
                 double r[257], Ea[257];
                 for (int i = 0; i <= nd; ++i)

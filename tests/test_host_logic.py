@@ -741,3 +741,46 @@ def test_window_sums_are_a_fixed_function_of_the_intervals_and_cost_log_n():
                 np.testing.assert_allclose(np.asarray(a), b, rtol=1e-12, atol=1e-12)
     assert max(cost[400:]) <= 4 * np.log2(700) and np.mean(cost[400:]) < 20   # (a plain sum: 200 ... 350)
     assert len(ws._cache) < 700
+
+
+def test_bench_certificate_gates_acceptance_and_posterior():
+    """bench.py certifies what its timed region produced (VERDICT r4 "Next round" 1b): the
+    acceptance rate and the ensemble's moments against the known posterior, with the reference's
+    own gates (KL <= 0.07: tests/common_sampler.py:18, 152-161).  A sampler that stopped accepting
+    or sits somewhere else fails; mixtures and the config-5 shape have closed-form moments."""
+    import bench
+    rng = np.random.default_rng(3)
+    d = 6
+    mean, cov = bench.target(d)
+    info = bench.make_info(d, mean, cov, 4096, 64, 40 * d)
+    m, C, K = bench.expected_moments(info)
+    assert K == 1 and np.allclose(m, mean) and np.allclose(C, cov)
+    x = rng.multivariate_normal(mean, cov, size=16384)
+    good = bench.certify(info, x, accepted=0.3 * 1e6, evals=1e6)
+    assert good["ok"] and good["posterior_check"]["gated"]
+    assert good["posterior_check"]["KL"] < 0.01 and abs(good["acceptance_rate"] - 0.3) < 1e-12
+    assert not bench.certify(info, x, accepted=0.0, evals=1e6)["ok"]           # stopped accepting
+    assert not bench.certify(info, x, accepted=0.9e6, evals=1e6)["ok"]         # accepts everything
+    stuck = mean + 0.2 * (x - mean)                                            # never spread out
+    bad = bench.certify(info, stuck, accepted=0.3e6, evals=1e6)
+    assert not bad["ok"] and bad["posterior_check"]["KL"] > 0.07
+    moved = bench.certify(info, x + 0.6 * np.sqrt(np.diag(cov)), accepted=0.3e6, evals=1e6)
+    assert not moved["ok"]
+    # config-5 shape: `gaussian` likelihood x normal priors = a product of Gaussians
+    info5 = bench.make_info(d, mean, cov, 4096, 64, 40 * d, normal_from=2)
+    m5, C5, _ = bench.expected_moments(info5)
+    P = np.linalg.inv(cov)
+    P[np.arange(2, d), np.arange(2, d)] += 1 / 0.3 ** 2
+    h = np.linalg.inv(cov) @ mean
+    h[2:] += 0.5 / 0.3 ** 2
+    assert np.allclose(C5, np.linalg.inv(P)) and np.allclose(m5, np.linalg.inv(P) @ h)
+    # a mixture: moments of the mixture, reported but not gated
+    info2 = bench.make_info(d, mean, cov, 4096, 64, 40 * d)
+    mu2 = mean + 2 * np.sqrt(np.diag(cov))
+    info2["likelihood"]["gaussian_mixture"].update(means=[mean, mu2], covs=[cov, cov])
+    m2, C2, K2 = bench.expected_moments(info2)
+    assert K2 == 2 and np.allclose(m2, (mean + mu2) / 2)
+    assert np.allclose(C2, cov + np.outer(mu2 - mean, mu2 - mean) / 4)
+    xs = np.concatenate((x[:8192], x[8192:] + (mu2 - mean)))
+    c2 = bench.certify(info2, xs, accepted=0.3e6, evals=1e6)
+    assert c2["ok"] and not c2["posterior_check"]["gated"] and c2["posterior_check"]["KL"] < 0.01

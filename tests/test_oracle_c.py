@@ -994,3 +994,41 @@ def test_carried_loglikelihood_follows_the_evaluated_one_and_is_re_anchored():
     sm.run(1, n_threads=1)                      # (step 0 is a refresh)
     keep = sm.n_accept == 0
     assert keep.sum() > 20 and np.array_equal(sm.loglike[keep], ll0[keep])
+
+
+@pytest.mark.parametrize("incremental", [True, False])
+def test_run_is_invariant_to_the_thread_split(golden, incremental):
+    """orc_run cuts a wide basis group (one Haar basis for 1 024 walkers here, 4 096 at the
+    benchmark geometry) into runs of >= 64 walkers when there are fewer groups than threads; each
+    run forms the group's bases itself.  The result does not depend on the cut (1, 4, 16 threads)
+    nor on how the ensemble is handed over (whole, or one group at a time with `walker0`)."""
+    from oracle import cbind as O
+    d, W, gs = 30, 2048, 1024
+    t = golden("targets")
+    mean, cov = t["mean_d30"], t["cov_d30"]
+    prob = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov,
+                     T=O.proposal_transform(cov, 2.4), group_size=gs, seed=11,
+                     incremental=incremental)
+    rng = np.random.default_rng(5)
+    x0 = np.clip(rng.multivariate_normal(mean, cov, size=W), 1e-6, 1 - 1e-6)
+    runs = []
+    for nt in (1, 4, 16):
+        st = O.State(prob, x0)
+        acc = st.run(2 * d + 7, walker0=3 * gs, n_threads=nt)
+        st.run(d, walker0=3 * gs, n_threads=nt)
+        runs.append((st, acc))
+    a = runs[0][0]
+    assert 0.1 < a.n_accept.sum() / (W * a.step) < 0.7
+    for st, acc in runs[1:]:
+        assert acc == runs[0][1]
+        assert np.array_equal(st.x.view(np.uint64), a.x.view(np.uint64))
+        assert np.array_equal(st.logpost.view(np.uint64), a.logpost.view(np.uint64))
+        assert np.array_equal(st.weight, a.weight) and np.array_equal(st.n_accept, a.n_accept)
+        if incremental:
+            assert np.array_equal(st.y.view(np.uint64), a.y.view(np.uint64))
+    for g in range(2):    # one group at a time
+        st = O.State(prob, x0[g * gs:(g + 1) * gs])
+        st.run(2 * d + 7, walker0=(3 + g) * gs, n_threads=8)
+        st.run(d, walker0=(3 + g) * gs, n_threads=8)
+        assert np.array_equal(st.x.view(np.uint64), a.x[g * gs:(g + 1) * gs].view(np.uint64))
+        assert np.array_equal(st.weight, a.weight[g * gs:(g + 1) * gs])
