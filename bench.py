@@ -629,26 +629,40 @@ def self_launch(n):
     device) -- the line says so in `collective.backend`."""
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    # the port stays RESERVED (bound, SO_REUSEADDR) until the ranks are spawned: another
+    # process cannot take it in between; rank 0's store binds it with SO_REUSEADDR as well
+    sock = socket.socket()
+    sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if r == 0:
+            sock.close()
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    # all ranks are watched TOGETHER: a rank that dies while the others sit in a collective
+    # (ncclCommInitRank waits 300 s, gloo 30 min) ends the job at once
     rc = 0
     try:
-        for p in procs:
-            rc = p.wait() or rc
-            if rc:
-                break
+        live = list(procs)
+        while live and not rc:
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    rc = rc or code
+            if live and not rc:
+                time.sleep(0.05)
     finally:
         for p in procs:        # a rank that failed must not leave the others in a collective
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
     return rc
 
 

@@ -523,12 +523,12 @@ extern "C" hipError_t mcmc_hip_launch_ckpt_bounds(const mcmc::CkptBoundsArgs* a,
 {
     using namespace mcmc;
     const size_t lds = sizeof(unsigned long long) * (size_t)a->n_slots * a->gs;
-    static bool raised = false;
-    if (!raised) {
+    // the attribute belongs to the CURRENT device's copy of the kernel: set it before every
+    // launch that needs it (cheap, and right for engines on several devices and threads)
+    if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ckpt_bounds_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kBoundsLdsBytes);
         if (e != hipSuccess) return e;
-        raised = true;
     }
     ckpt_bounds_kernel<<<dim3(G, a->d), 256, lds, st>>>(*a);
     return hipGetLastError();

@@ -51,7 +51,7 @@ struct AnyGeom {
     size_t dynamic;
 };
 constexpr size_t kAnyStatic = 16 * 128 * 2 + 8 * 128 + 4 * 128 + 16 * SHORT_LOG_TABLE_SIZE + 16 * kMaxModes + 256 +
-                              16 * 4 * 8 * 16;   // (+ the staged variates, StagedVariates)
+                              16 * kStagedPairs;   // (+ the staged variates, StagedVariates)
 constexpr size_t kLdsPerCu = 160u << 10;
 constexpr size_t kLdsPerWg = 160u << 10;   // (a single workgroup may hold all of it)
 

@@ -129,22 +129,31 @@ __device__ __forceinline__ lds_doubles relaunder(const double* p)
 // index: 4 DPP moves and ~12 scalar instructions per step, and 8 VGPRs alive across the octet;
 // profiles/r04_instruction_diet.txt.)  A wave reads what it wrote itself: LDS operations of one
 // wave complete in order, no barrier.
-constexpr int kStagedPairs = 4 * 8 * 16;   // 8 KB per workgroup of four waves
+// Row stride: 17 pairs = 272 bytes (round 5).  With 16 (256 B) the four lane classes of a walker
+// wrote rows 2c, 2c + 1 at the same 16 bytes of the 128-byte bank window of ds_write_b128 (served
+// in groups of 8 contiguous lanes = two walkers x four classes, bank = (a / 4) mod 32): a 4-way
+// conflict on every fill, 24 extra LDS cycles per store -- SQ_LDS_BANK_CONFLICT 1.73e7 -> 4.68e7
+// per launch at d = 30 when the staging arrived.  With 272 the rows 2c start
+// 32 c bytes apart modulo 128, so the eight lanes of a group cover the window exactly once.  The
+// reads (one ds_read_b128 per step, the same 16 bytes in the four lanes of a walker, 16
+// consecutive pairs per wave) are conflict-free with either stride.
+constexpr int kStagedRow = 17;                     // pairs per row (16 walkers + 1 of padding)
+constexpr int kStagedPairs = 4 * 8 * kStagedRow;   // 8.5 KB per workgroup of four waves
 struct StagedVariates {
     unsigned base, off;
     __device__ __forceinline__ void init(const pair_t* sRE, int wave, int lane)
     {
-        base = lds_offset(sRE + (wave * 8 * 16 + (lane >> 2)));
+        base = lds_offset(sRE + (wave * 8 * kStagedRow + (lane >> 2)));
         off = base;
     }
     // after PairRng::run for the octet that holds step S (the step about to be taken)
     __device__ __forceinline__ void fill(pair_t* sRE, int wave, int lane, int c, const PairRng& pr,
                                          unsigned long long S)
     {
-        pair_t* const mine = sRE + ((wave * 8 + 2 * c) * 16 + (lane >> 2));
+        pair_t* const mine = sRE + ((wave * 8 + 2 * c) * kStagedRow + (lane >> 2));
         mine[0] = pair_t{pr.r[0], pr.Ea[0]};
-        mine[16] = pair_t{pr.r[1], pr.Ea[1]};
-        off = base + (unsigned)(S & 7ull) * 256u;
+        mine[kStagedRow] = pair_t{pr.r[1], pr.Ea[1]};
+        off = base + (unsigned)(S & 7ull) * (16u * kStagedRow);
     }
     __device__ __forceinline__ void fetch(double& r, double& Ea) const
     {
@@ -152,7 +161,7 @@ struct StagedVariates {
         r = re.x;
         Ea = re.y;
     }
-    __device__ __forceinline__ void next() { off += 256u; }
+    __device__ __forceinline__ void next() { off += 16u * kStagedRow; }
 };
 
 // columns of one LDS chunk: a multiple of 4 (the variates come in fours); 14 KiB of pairs, 32 KiB
@@ -161,7 +170,7 @@ struct StagedVariates {
 __host__ __device__ constexpr int inc_chunk(int dq)
 {
     // (kernels at four waves per SIMD -- four workgroups per CU -- have 40 KB of LDS each: 28 KB
-    // of pairs beside the 8 KB of staged variates and the 2 KB logarithm table)
+    // of pairs beside the 8.5 KB of staged variates and the 2 KB logarithm table)
     int c = ((dq >= 14 ? 2048 : 896) / (4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }

@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
 // lane class k, the logarithm by every lane.
 __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 {
-    // (14 KB of planes per chunk: beside the 8 KB of staged variates and the logarithm table a
+    // (14 KB of planes per chunk: beside the 8.5 KB of staged variates and the logarithm table a
     // workgroup at four waves per SIMD stays within its 40 KB of LDS)
     int c = (1792 / ((1 + km) * 4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);

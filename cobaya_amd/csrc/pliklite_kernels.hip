@@ -769,12 +769,10 @@ static hipError_t launch_pl_fused_ng(const PlFusedArgs& b, dim3 g, hipStream_t s
 {
     constexpr size_t lds = sizeof(double2) * 2 * kPlChunkPairs * 256;   // 128 KB
     auto go = [&](auto kern) -> hipError_t {
-        static bool raised = false;
-        if (!raised) {
+        {   // per device and per call: the attribute is the current device's
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            raised = true;
         }
         hipLaunchKernelGGL(kern, g, dim3(512), lds, st, b);
         return hipGetLastError();

@@ -78,6 +78,26 @@ def default_device() -> int:
     return local_rank() % n if n else local_rank()
 
 
+def _exchange_id(r, n):
+    """The 128-byte RCCL id from rank 0 to every rank through the bootstrap group.  Rank 0 ALWAYS
+    broadcasts -- the id, or the reason it has none (librccl not loadable, ncclGetUniqueId
+    failed) -- so that no rank is left waiting in the broadcast; every rank then raises the same
+    error (a rank 0 that raised before the broadcast hung the whole job)."""
+    from .engine import Communicator
+    msg = [None]
+    if r == 0:
+        try:
+            msg = [(Communicator.unique_id(), None)]
+        except Exception as e:
+            msg = [(None, f"{type(e).__name__}: {e}")]
+    if n > 1:
+        _td().broadcast_object_list(msg, src=0)
+    ident, err = msg[0]
+    if err is not None:
+        raise RuntimeError(f"rank 0 could not create the RCCL id ({err})")
+    return ident
+
+
 def init_native_comm(rank_=None, size_=None, device=None):
     """Create the library's RCCL communicator (collective over all ranks).  The 128-byte id
     travels from rank 0 through the bootstrap group; a world of one needs no group at all."""
@@ -88,34 +108,52 @@ def init_native_comm(rank_=None, size_=None, device=None):
     r = rank() if rank_ is None else int(rank_)
     n = size() if size_ is None else int(size_)
     dev = default_device() if device is None else int(device)
-    ident = [Communicator.unique_id() if r == 0 else None]
-    if n > 1:
-        _td().broadcast_object_list(ident, src=0)
-    _comm = Communicator(ident[0], r, n, dev)
+    _comm = Communicator(_exchange_id(r, n), r, n, dev)
     return _comm
 
 
 def _create_comm_guarded(timeout_s):
-    """`init_native_comm()` with a deadline: ncclCommInitRank blocks until every rank has joined
+    """The communicator with a deadline: ncclCommInitRank blocks until every rank has joined
     and cannot be cancelled -- a rank whose peers never arrive (a bootstrap interface RCCL cannot
-    use, a rank that died) would hang the job.  The call runs in a helper thread (ctypes releases
-    the GIL); past the deadline this rank reports failure, and the agreement that follows sends
-    every rank to the gloo stand-in.  Returns None or the reason."""
+    use, a rank that died) would hang the job.  The id is exchanged HERE, on the calling thread
+    (so no bootstrap collective is ever pending on another thread when the agreement that follows
+    runs on the same group); only ncclCommInitRank runs in a helper thread (ctypes releases the
+    GIL).  Past the deadline this rank reports failure, and the agreement sends every rank to the
+    gloo stand-in.  The communicator is PUBLISHED by the calling thread only: a helper that
+    finishes after it was abandoned destroys what it made.  Returns (communicator or None, None
+    or the reason)."""
     import threading
-    box = {}
+    from .engine import Communicator
+    r, n, dev = rank(), size(), default_device()
+    try:
+        ident = _exchange_id(r, n)
+    except Exception as e:
+        return None, str(e)
+    box, lock = {}, threading.Lock()
 
     def work():
         try:
-            init_native_comm()
+            c = Communicator(ident, r, n, dev)
         except Exception as e:      # EngineError with RCCL's message
-            box["err"] = f"{type(e).__name__}: {e}"
+            with lock:
+                box["err"] = f"{type(e).__name__}: {e}"
+            return
+        with lock:
+            if box.get("abandoned"):
+                c.close()           # nobody will ever use it: the job runs on gloo
+            else:
+                box["comm"] = c
     t = threading.Thread(target=work, name="mcmc_hip-rccl-init", daemon=True)
     t.start()
     t.join(timeout_s)
-    if t.is_alive():
-        return (f"timed out after {timeout_s:g} s in ncclCommInitRank (MCMC_HIP_RCCL_TIMEOUT; "
-                f"NCCL_SOCKET_IFNAME selects the bootstrap interface)")
-    return box.get("err")
+    with lock:
+        if "comm" in box:
+            return box["comm"], None
+        if "err" in box:
+            return None, box["err"]
+        box["abandoned"] = True
+    return None, (f"timed out after {timeout_s:g} s in ncclCommInitRank (MCMC_HIP_RCCL_TIMEOUT; "
+                  f"NCCL_SOCKET_IFNAME selects the bootstrap interface)")
 
 
 def init_from_env(backend=None):
@@ -145,13 +183,15 @@ def init_from_env(backend=None):
         # leave the others inside ncclCommInitRank with a different idea of the backend: every
         # rank reports, and unless ALL succeeded the job falls back -- loudly -- to the gloo
         # stand-in for the collective (the kernels are unaffected; `describe()` says what runs).
-        err = _create_comm_guarded(float(os.environ.get("MCMC_HIP_RCCL_TIMEOUT", "300")))
+        comm, err = _create_comm_guarded(float(os.environ.get("MCMC_HIP_RCCL_TIMEOUT", "300")))
         import torch
         flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
         _td().all_reduce(flag, op=_td().ReduceOp.MIN)
-        if float(flag[0]) < 0.5:
-            if _comm is not None and not (err or "").startswith("timed out"):
-                _comm.close()
+        if float(flag[0]) >= 0.5:
+            _comm = comm        # published here, by the thread that agreed on it
+        else:
+            if comm is not None:
+                comm.close()
             _comm = None
             _rccl_error = err or "another rank could not create its RCCL communicator"
             import sys

@@ -907,6 +907,8 @@ class EnsembleMCMC:
             ring_bytes = 8 * len(held) * int(self.n_walkers) * self.spec.d
             if held and ring_bytes <= self.BOUNDS_RING_SAVE_BYTES:
                 st["bring"] = np.array([self.engine.bounds_get_slot(k) for k in held])
+            elif held:
+                self._save_bounds_sidecar()
             st["bslots"] = np.array(self._bslots, dtype=np.int64)
             st["bbook"] = np.array([self._bstride, self._bsnap_idx], dtype=np.int64)
             tmp = self._state_file() + ".tmp.npz"
@@ -926,6 +928,68 @@ class EnsembleMCMC:
                                     + [float(getattr(self, k)) for k in self.CONVERGE_OPTIONS]),
                      progress=self.progress.to_numpy(dtype=object).astype(str))
             os.replace(tmp, self._state_file())   # never leave a half-written state behind
+
+    def _bounds_sidecar(self):
+        return self._chain_file("bounds.npy"), self._chain_file("bounds_tags.npy")
+
+    def _save_bounds_sidecar(self):
+        """A bounds ring too large for the state file (251 MB at BASELINE config 2: 16 slots of
+        65 536 x 30 doubles) lives in a sidecar `prefix.<n>.bounds.npy` of fixed shape
+        [slots][W][d], written IN PLACE and only where a slot's snapshot changed since the last
+        dump; `prefix.<n>.bounds_tags.npy` (replaced atomically, after the data) says which
+        snapshot each slot of the file holds.  A resumed run restores exactly the slots whose tag
+        equals the state file's book -- after a crash between the two writes a slot is dropped,
+        never mixed up -- so Rminus1_cl after a resume is the uninterrupted run's."""
+        data_f, tags_f = self._bounds_sidecar()
+        n, shape = len(self._bslots), (len(self._bslots), int(self.n_walkers), self.spec.d)
+        tags = np.full(n, -1, dtype=np.int64)
+        mm = None
+        if os.path.exists(data_f) and os.path.exists(tags_f):
+            try:
+                mm = np.load(data_f, mmap_mode="r+")
+                old = np.load(tags_f)
+                if mm.shape == shape and old.shape == tags.shape:
+                    tags = old
+                else:
+                    mm = None
+            except Exception:
+                mm = None
+        if mm is None:
+            mm = np.lib.format.open_memmap(data_f, mode="w+", dtype=np.float64, shape=shape)
+            tags[:] = -1
+        dirty = [k for k, j in enumerate(self._bslots) if j >= 0 and tags[k] != j]
+        if dirty:   # (the tags of the slots being rewritten are invalid until the data is down)
+            tags[dirty] = -1
+            np.save(tags_f + ".tmp.npy", tags)
+            os.replace(tags_f + ".tmp.npy", tags_f)
+            for k in dirty:
+                mm[k] = self.engine.bounds_get_slot(k)
+            mm.flush()
+        for k, j in enumerate(self._bslots):
+            tags[k] = j if j >= 0 else -1
+        del mm
+        np.save(tags_f + ".tmp.npy", tags)
+        os.replace(tags_f + ".tmp.npy", tags_f)
+
+    def _load_bounds_sidecar(self, saved):
+        """-> the slot books after restoring what the sidecar vouches for (see above)."""
+        data_f, tags_f = self._bounds_sidecar()
+        out = [-1] * len(saved)
+        if not (os.path.exists(data_f) and os.path.exists(tags_f)):
+            return out, 0
+        try:
+            mm, tags = np.load(data_f, mmap_mode="r"), np.load(tags_f)
+        except Exception:
+            return out, 0
+        if mm.shape != (len(saved), int(self.n_walkers), self.spec.d) or len(tags) != len(saved):
+            return out, 0
+        n = 0
+        for k, j in enumerate(saved):
+            if j >= 0 and int(tags[k]) == j:
+                self.engine.bounds_set_slot(k, np.array(mm[k]))
+                out[k] = j
+                n += 1
+        return out, n
 
     def _load_checkpoint(self):
         """Resume (sampler.py:291-310, mcmc.py:131-139, 189-214): same number of processes and
@@ -955,9 +1019,15 @@ class EnsembleMCMC:
                 self._bslots = saved
                 for k, x in zip(held, z["bring"]):
                     self.engine.bounds_set_slot(k, x)
+            elif held and len(saved) == len(self._bslots):
+                self._bslots, n_back = self._load_bounds_sidecar(saved)
+                if n_back < len(held):
+                    self.log.info("%d of the %d snapshots behind R-1 of the bounds were not found "
+                                  "beside the state file: those slots restart empty.",
+                                  len(held) - n_back, len(held))
             elif held:
-                self.log.info("The snapshots behind R-1 of the bounds were not kept in the state "
-                              "file (too large, or bounds_snapshots changed): that ring restarts empty.")
+                self.log.info("bounds_snapshots changed since the checkpoint: the ring behind R-1 "
+                              "of the bounds restarts empty.")
         self._intervals = [(int(n), gs, S) for n, gs, S in zip(z["iv_n"], z["iv_gs"], z["iv_S"])]
         self._iv0 = int(z["iv0"]) if "iv0" in z else 0
         self._wsums = WindowSums()
@@ -1497,7 +1567,7 @@ class MCMCHip(EnsembleMCMC):
             return [], []
         head = re.escape(prefix) + (r"[\._]" if prefix else "")
         chain = re.compile(head + r"\d+\.txt$")
-        rest = re.compile(head + r"(checkpoint|progress|covmat|\d+\.state\.npz)$")
+        rest = re.compile(head + r"(checkpoint|progress|covmat|\d+\.(state\.npz|bounds\.npy|bounds_tags\.npy))$")
         names = sorted(os.listdir(folder))
         return ([os.path.join(folder, n) for n in names if chain.match(n)],
                 [os.path.join(folder, n) for n in names if rest.match(n)])

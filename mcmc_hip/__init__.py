@@ -77,7 +77,8 @@ else:
             cleans them and a stale state never survives a fresh start."""
             regexps = _CobayaMCMC.output_files_regexps(output, info=info, minimal=minimal)
             if not minimal:
-                regexps.append((re.compile(output.prefix_regexp_str + r"\d+\.state\.npz$"),
+                regexps.append((re.compile(output.prefix_regexp_str
+                                           + r"\d+\.(state\.npz|bounds\.npy|bounds_tags\.npy)$"),
                                 None))
             return regexps
 

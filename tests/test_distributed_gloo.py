@@ -124,3 +124,30 @@ def test_shards_equal_the_slices_of_one_ensemble(tmp_path, world):
     assert [int(v) for v in prog["N"]] == res[0]["N"]
     np.testing.assert_allclose(prog["Rminus1"].to_numpy(float), res[0]["Rminus1"], rtol=1e-9)
     np.testing.assert_allclose(prog["acceptance_rate"].to_numpy(float), res[0]["acc"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("mode", ["id", "init"])
+def test_rccl_fallback_does_not_hang(mode):
+    """ADVICE r4 (medium + low): asked for RCCL where it cannot be had, every rank must come out
+    of `dist.init_from_env` on the gloo stand-in -- (id) rank 0 fails BEFORE the id broadcast
+    (it now always broadcasts: the id or the reason); (init) one rank sits in ncclCommInitRank
+    past the deadline and joins late: its communicator is destroyed by the helper thread, never
+    published behind the main thread's back.  Both used to leave the ranks in mismatched
+    collectives."""
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCMC_HIP_RCCL_TIMEOUT="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_rccl_fallback_worker.py"),
+                                       mode], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=120)
+            assert p.returncode == 0, out.decode()[-3000:]
+            assert b" ok after " in out
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()

@@ -472,9 +472,15 @@ def test_bounds_criterion_in_every_emit_mode(emit, max_rows):
     assert not t.converged and np.isfinite(t.progress["Rminus1_cl"].to_numpy(float)).sum() >= 2
 
 
-def test_resume_restores_the_bounds_ring(tmp_path):
+@pytest.mark.parametrize("sidecar", [False, True])
+def test_resume_restores_the_bounds_ring(tmp_path, sidecar, monkeypatch):
     """The ring behind R-1 of the bounds is part of the state: a resumed run reports the same
-    Rminus1_cl at the same checkpoints as the uninterrupted one."""
+    Rminus1_cl at the same checkpoints as the uninterrupted one -- with the snapshots inside the
+    state file (small rings) and in the sidecar `prefix.<n>.bounds.npy` a ring above
+    BOUNDS_RING_SAVE_BYTES goes to (251 MB at BASELINE config 2)."""
+    if sidecar:
+        from cobaya_amd.sampler import EnsembleMCMC
+        monkeypatch.setattr(EnsembleMCMC, "BOUNDS_RING_SAVE_BYTES", 0)
     opts = dict(Rminus1_stop=0.3, Rminus1_cl_stop=1e-9, learn_every="5d", steps_per_launch=20)
     one = make(str(tmp_path / "a"), 40000, **opts)
     one.run()
@@ -485,6 +491,16 @@ def test_resume_restores_the_bounds_ring(tmp_path):
     cl1, cl2 = (x.progress["Rminus1_cl"].to_numpy(float) for x in (one, b))
     assert np.isfinite(cl1).sum() >= 2 and np.array_equal(cl1, cl2, equal_nan=True)
     assert b._bslots == one._bslots and b._bstride == one._bstride
+    import glob
+    assert bool(glob.glob(p + "*.bounds.npy")) == sidecar
+    if sidecar:   # a slot the tags do not vouch for is dropped, never mixed up
+        tags_f = glob.glob(p + "*.bounds_tags.npy")[0]
+        tags = np.load(tags_f)
+        k = int(np.argmax(tags >= 0))
+        tags[k] += 1
+        np.save(tags_f, tags)
+        c = make(p, 40000, resume=True, **opts)
+        assert c._bslots[k] == -1 and sum(j >= 0 for j in c._bslots) == sum(j >= 0 for j in b._bslots) - 1
 
 
 def test_dragging_emits_chains():
