@@ -41,12 +41,39 @@ def main():
     class S(MCMCHip):
         _engine_factory = staticmethod(Spy)
 
-    learn = len(sys.argv) < 3 or sys.argv[2] != "nolearn"
-    s = S({"seed": 5, "n_walkers": 128, "group_size": 64, "steps_per_launch": 40,
-           "max_samples": 30000 * dist.size(), "Rminus1_stop": 0.0, "learn_every": "40d",
-           "learn_proposal": learn},
-          ProblemSpec.from_info(QUICK), output=os.path.join(out_dir, "run"))
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    learn = mode != "nolearn"
+    covs = []
+    if mode == "config2":
+        # BASELINE configs[2] at FULL size: 8 x 65 536 walkers of the d = 30 target, R-1 groups of
+        # 256, one Haar basis per 4 096 walkers (the sampler's own choice at this size), learn
+        # checkpoints with the all-reduce -- shortened in TIME only (launches of 40 steps, a
+        # checkpoint every d accepted steps per chain) so that the CPU oracle finishes in seconds
+        import bench
+        mean, cov = bench.target(30)
+        info = bench.make_info(30, mean, cov, 65536, 256, 40)
+        opts = dict(info["sampler"]["mcmc_hip"], seed=1, learn_every="1d", max_samples=int(sys.argv[3]),
+                    learn_proposal_Rminus1_max=1e9, max_rows=0)
+        spec = ProblemSpec.from_info(info)
+        set_cov = Spy.set_proposal_cov
+
+        def logged_set_cov(self, c):
+            covs.append((self.launches, np.array(c)))
+            return set_cov(self, c)
+        Spy.set_proposal_cov = logged_set_cov
+        s = S(opts, spec)
+        assert (s.group_size, s.basis_group_size, s.incremental) == (256, 4096, True)
+        if dist.rank() == dist.size() - 1:
+            np.save(os.path.join(out_dir, "x0_last_rank.npy"), s.engine.get_full_state()["x"])
+    else:
+        s = S({"seed": 5, "n_walkers": 128, "group_size": 64, "steps_per_launch": 40,
+               "max_samples": 30000 * dist.size(), "Rminus1_stop": 0.0, "learn_every": "40d",
+               "learn_proposal": learn},
+              ProblemSpec.from_info(QUICK), output=os.path.join(out_dir, "run"))
     s.run()
+    if covs and dist.rank() == dist.size() - 1:
+        np.savez(os.path.join(out_dir, "refreshes_last_rank.npz"),
+                 launches=np.array([k for k, _ in covs]), covs=np.array([c for _, c in covs]))
     st = s.engine.get_full_state()
     np.savez(os.path.join(out_dir, f"state_rank{dist.rank()}.npz"), x=st["x"], logpost=st["logpost"],
              weight=st["weight"], n_accept=st["n_accept"])

@@ -151,3 +151,49 @@ def test_rccl_fallback_does_not_hang(mode):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+
+
+def test_config2_full_size_on_eight_ranks(tmp_path):
+    """BASELINE configs[2] at its FULL size -- 8 ranks x 65 536 walkers of the d = 30 target,
+    R-1 groups of 256, one Haar basis per 4 096 walkers -- through the whole run loop on the
+    oracle-backed engine, with learn checkpoints and their all-reduce (mcmc.py:791-793, 1005-1007,
+    1021).  Shortened in TIME only (40-step launches, a checkpoint per d accepted steps): >= 2
+    checkpoints are processed, every rank forms the same R-1 / acceptance / learned covariance
+    from the reduced statistics, the shards start at 65 536 k, and rank 7's shard after the run
+    IS walkers [458 752, 524 288) of the ensemble: an independent replay of those walkers on the
+    oracle, fed the logged proposal refreshes, gives the same state bit for bit."""
+    from oracle import cbind as O
+    import bench
+    W, world = 65536, 8
+    res = _run_ranks(tmp_path, world, "config2", str(int(0.3 * 8 * W * 330)))
+    a = res[0]
+    assert [r["walker_offset"] for r in res] == [W * k for k in range(world)]
+    assert all(r["size"] == world and r["lag"] == 2 for r in res)
+    assert len(a["Rminus1"]) >= 2 and all(np.isfinite(a["Rminus1"]))
+    for b in res[1:]:
+        assert a["steps"] == b["steps"]
+        for k in ("Rminus1", "N", "acc", "cov"):
+            assert a[k] == b[k], k
+    assert all(0.15 < x < 0.5 for x in a["acc"])
+    # the accepted total of the last checkpoint is the sum over all 524 288 walkers
+    assert a["N"][-1] > 0.15 * world * W * 200
+    # independent replay of the last rank's shard
+    ref = np.load(tmp_path / "refreshes_last_rank.npz")
+    assert len(ref["launches"]) >= 3          # the initial covmat + >= 2 learned proposals
+    mean, cov = bench.target(30)
+    d = 30
+    x0 = np.load(tmp_path / "x0_last_rank.npy")
+    prob = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov,
+                     T=O.proposal_transform(ref["covs"][0], 2.4), group_size=4096, seed=1,
+                     incremental=True)
+    st = O.State(prob, x0)
+    n_launch = a["steps"] // 40
+    for k in range(n_launch):
+        for j in np.nonzero(ref["launches"] == k)[0]:
+            if k or j:
+                prob.set_T(O.proposal_transform(ref["covs"][j], 2.4))
+        st.run(40, walker0=7 * W, n_threads=O.max_threads())
+    z = np.load(tmp_path / "state_rank7.npz")
+    assert np.array_equal(z["x"].view(np.uint64), st.x.view(np.uint64))
+    assert np.array_equal(z["logpost"].view(np.uint64), st.logpost.view(np.uint64))
+    assert np.array_equal(z["weight"], st.weight) and np.array_equal(z["n_accept"], st.n_accept)
