@@ -773,6 +773,18 @@ def main():
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
             "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
             "evaluation": v["evaluation"], "roofline": gaussian_roofline(v, d4, a.walkers, n_v)})
+        # ... and the path north_star names for it: every trial from scratch,
+        # the dense L^-1 (t - mu) contraction on the FP64 matrix cores (step_mfma_kernel,
+        # walker_kernels_big.hip: 91 v_mfma_f64_16x16x4 per 16 walkers and step)
+        n_v = 3
+        v = run_timed(a, d4, m4, c4, "snapshots", n_v, 1, evaluation="full")
+        variants.append({
+            "certificate": v["certificate"],
+            "variant": "BASELINE configs[3] on the matrix cores: 100-dim gaussian_mixture, evaluation: "
+                       "full (dense Sigma^-1 x contraction via FP64 MFMA, LDS-staged L^-1 tiles), 65536 walkers",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 1, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"], "roofline": gaussian_roofline(v, d4, a.walkers, n_v)})
         # configs[4]'s SHAPE (SURVEY 8d "Config 5"): d = 27, 6 uniform + 21 normal priors, a
         # `gaussian` likelihood with a seeded SPD covariance -- synthetic, no Planck data
         d5 = 27

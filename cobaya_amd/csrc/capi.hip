@@ -343,6 +343,10 @@ struct mcmc_hip_ctx {
     // 8..11 = log2 of the multiple); the R-1 groups (moments) stay group_size wide
     int bgs = 0, BG = 0;
     DevBuf<double> y, inc_prior, inc_Lrow, inc_mean;
+    // mixtures on the kernels that carry the log-density of every mode (inc_carries_modes):
+    // amode[K][W]; valid = written by a launch (or set) since y was; else re-anchored on y
+    DevBuf<double> amode;
+    bool amode_valid = false;
     // The directions of a launch -- Haar columns V (Vf: the fast blocks' when dragging) and their
     // whitened pairs VU -- do not depend on the walkers' state, so the set of the NEXT launch is
     // computed on a second stream while the step kernel of this one runs (two sets, used in
@@ -603,6 +607,8 @@ int upload_constants(mcmc_hip_ctx* h)
     if (h->incremental && K >= 1 && K <= mcmc::kMaxModes) {
         const int dq = (d + 3) / 4, dpad = 4 * dq;
         HIP_TRY(h, h->y.resize((size_t)K * d * h->W));
+        if (K > 1) HIP_TRY(h, h->amode.resize((size_t)K * h->W));
+        h->amode_valid = false;
         std::vector<double> pr((size_t)5 * dpad, 0.0);
         for (int i = 0; i < dpad; ++i) {
             pr[i] = i < d ? h->lo[i] : -INFINITY;
@@ -622,7 +628,7 @@ int upload_constants(mcmc_hip_ctx* h)
         HIP_TRY(h, h->inc_mean.resize((size_t)K * d));
         HIP_TRY(h, hipMemcpyAsync(h->inc_mean.p, h->mean.data(), sizeof(double) * K * d,
                                   hipMemcpyHostToDevice, h->stream));
-        h->y_valid = false;
+        h->y_valid = false; h->amode_valid = false;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MCMC_HIP_OK;
@@ -1063,7 +1069,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->mom_event) (void)hipEventDestroy(h->mom_event);
     h->pack_out.release(); h->pack_off.release();
-    h->y.release(); h->inc_prior.release(); h->inc_Lrow.release();
+    h->y.release(); h->amode.release(); h->inc_prior.release(); h->inc_Lrow.release();
     h->inc_mean.release();
     {
         auto& B = h->bg;
@@ -1597,7 +1603,7 @@ int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad)
     HIP_TRY(h, hipStreamSynchronize(s));
     h->step = 0;
     h->have_state = true;
-    h->y_valid = false;   // incremental mode: y = L^-1 (x - mu) is formed before the next step
+    h->y_valid = false; h->amode_valid = false;   // incremental mode: y = L^-1 (x - mu) is formed before the next step
     return MCMC_HIP_OK;
 }
 
@@ -1679,7 +1685,7 @@ int mcmc_hip_set_full_state(mcmc_hip_ctx* h, const double* x, const double* logp
     }
     h->step = step;
     h->have_state = true;
-    h->y_valid = false;   // incremental mode: mcmc_hip_set_whitened must follow (bit-exact resume)
+    h->y_valid = false; h->amode_valid = false;   // incremental mode: mcmc_hip_set_whitened must follow (bit-exact resume)
     return MCMC_HIP_OK;
 }
 
@@ -1715,6 +1721,23 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
 }
 
 
+// Does the kernel that serves this engine's incremental steps carry the log-density of every mode
+// (round 5)?  step_inc_mix_kernel: 2..4 modes, d <= 64, no periodic parameter, Metropolis steps,
+// no emitted rows.
+bool inc_carries_modes(const mcmc_hip_ctx* h)
+{
+    if (!h->incremental || h->K < 2 || h->drag_last_slow >= 0) return false;
+    for (int i = 0; i < h->d; ++i)
+        if (h->periodic[i]) return false;
+    // step_inc_mix_kernel: 2..4 modes at d <= 64 without emitted rows.  Everything else goes to
+    // the general kernels (incremental_any.hip), which sum every chi2_k from the trial's residual:
+    // the carried form was built for the register-plane kernel as well and measured SLOWER there
+    // (K = 5 / 8 / 16 at d = 30: 9.66 -> 8.26, 7.37 -> 6.46, 2.09 -> 1.85e9 evals/s,
+    // profiles/r05_carried_modes.txt) -- those kernels wait on latency at one or two waves per
+    // SIMD, and the extra K registers cost more than the d / 4 fewer FMAs per mode bought
+    return h->K <= 4 && (h->d + 3) / 4 <= 16 && h->cfg.emit_capacity == 0;
+}
+
 // mcmc_hip_step in incremental mode (MCMC_HIP_FLAG_INCREMENTAL; incremental_kernels.hip).
 // Launches are cut at the multiples of refresh_every = 40 cycle lengths, where y = L^-1 (x - mu)
 // is recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
@@ -1725,6 +1748,7 @@ struct IncPlan {   // what the cutting of launches depends on besides the step c
     bool drag;
     bool any;   // the general kernel (incremental_any.hip): columns as planes (v, u_1 .. u_K)
     bool carry; // step_inc_kernel (one mode, no periodic parameter, Metropolis steps): the log-likelihood is carried
+    bool carry_modes;   // step_inc_mix_kernel: the log-density of every mode is carried
 };
 struct IncSeg {    // one launch: steps [step0, step0 + n)
     unsigned long long step0, c0, cyc0_f;
@@ -1791,8 +1815,8 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
     w.out_total = s.n * (1 + nd);
     w.colflag = D.has_flags ? D.colflag.p : nullptr;
     w.vflag = any_1d ? D.vflag.p : nullptr;
-    if (P.carry) {
-        HIP_TRY(h, D.UU.resize((size_t)h->BG * s.n));
+    if (P.carry || P.carry_modes) {
+        HIP_TRY(h, D.UU.resize((size_t)h->BG * s.n * (P.carry_modes ? (size_t)P.K : 1)));
         w.UU = D.UU.p;
     }
     if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
@@ -1859,6 +1883,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     // one mode, no periodic parameter, Metropolis steps: step_inc_kernel, which carries the
     // log-likelihood along the whitened direction and needs |u|^2 of every column
     P.carry = !P.any && !P.drag && K == 1 && n_periodic == 0;
+    // mixtures on step_inc_mix_kernel (2..4 modes, d <= 64, no periodic parameter): the log-density
+    // of every mode is carried; |u_k|^2 of every column and mode (inc_carries_modes says the same
+    // to the caller: the oracle takes the rule from there)
+    P.carry_modes = inc_carries_modes(h);
     auto launch = P.any ? mcmc_hip_launch_inc_any
                   : emit ? (dq <= 8 ? mcmc_hip_launch_inc_emit_1 : dq <= 16 ? mcmc_hip_launch_inc_emit_9
                           : dq <= 24 ? mcmc_hip_launch_inc_emit_17 : mcmc_hip_launch_inc_emit_25)
@@ -1891,6 +1919,9 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             h->y_valid = true;
             anchor = true;
         }
+        // (carried mode log-densities that no launch has written since y was set are re-anchored
+        // on y: after set_state always; after a resume only if the state file did not hold them)
+        if (P.carry_modes && !h->amode_valid) anchor = true;
         const IncSeg seg = plan_segment(P, h->step, left);
         const int n = seg.n;
         auto& D = h->dirs[h->dir_cur];
@@ -1947,8 +1978,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.n_drag = nd; a.chunk_steps = P.chunk_steps;
             a.colflag = D.has_flags ? D.colflag.p : nullptr;
             a.Lrow = h->inc_Lrow.p;
-            a.UU = P.carry ? D.UU.p : nullptr;
+            a.UU = (P.carry || P.carry_modes) ? D.UU.p : nullptr;
             a.anchor = anchor ? 1 : 0;
+            a.amode = P.carry_modes ? h->amode.p : nullptr;
+            if (P.carry_modes) h->amode_valid = true;
             for (int i = 0; i < d; ++i)
                 if (h->periodic[i]) a.periodic_mask4[i >> 5] |= 1u << (i & 31);
             HIP_TRY(h, launch(&a, h->stream));
@@ -2802,6 +2835,46 @@ int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y)
         for (size_t i = 0; i < d; ++i) yt[i * W + w] = y[w * d + i];
     HIP_TRY(h, hipMemcpy(h->y.p, yt.data(), sizeof(double) * W * d, hipMemcpyHostToDevice));
     h->y_valid = true;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_incremental_carries_modes(const mcmc_hip_ctx* h)
+{
+    return h && inc_carries_modes(h) ? 1 : 0;
+}
+
+int mcmc_hip_get_mode_logdensities(mcmc_hip_ctx* h, double* a)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!a || !inc_carries_modes(h))
+        return fail(h, MCMC_HIP_ERR_ARG, "this engine does not carry mode log-densities, or null");
+    if (!h->have_state || !h->amode_valid)
+        return fail(h, MCMC_HIP_ERR_STATE, "no carried mode log-densities yet (a step forms them)");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t W = h->W, K = (size_t)h->K;
+    std::vector<double> t(W * K);
+    HIP_TRY(h, hipMemcpy(t.data(), h->amode.p, sizeof(double) * W * K, hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < W; ++w)
+        for (size_t k = 0; k < K; ++k) a[w * K + k] = t[k * W + w];
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_mode_logdensities(mcmc_hip_ctx* h, const double* a)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (!a || !inc_carries_modes(h))
+        return fail(h, MCMC_HIP_ERR_ARG, "this engine does not carry mode log-densities, or null");
+    if (!h->have_state || !h->y_valid)
+        return fail(h, MCMC_HIP_ERR_STATE, "set_full_state and set_whitened must precede set_mode_logdensities");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t W = h->W, K = (size_t)h->K;
+    std::vector<double> t(W * K);
+    for (size_t w = 0; w < W; ++w)
+        for (size_t k = 0; k < K; ++k) t[k * W + w] = a[w * K + k];
+    HIP_TRY(h, hipMemcpy(h->amode.p, t.data(), sizeof(double) * W * K, hipMemcpyHostToDevice));
+    h->amode_valid = true;
     return MCMC_HIP_OK;
 }
 

@@ -903,15 +903,30 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
             uk[j] = acc;
         }
         for (int j = d; j < dpad; ++j) uk[j] = 0.0;
+        if (a.UU) {   // |u_k|^2 in the four-chain pattern (orc_direction_norms), rows ascending
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (int j = 0; j < d; j += 4) {
+                s0 = fma(uk[j], uk[j], s0);
+                if (j + 1 < d) s1 = fma(uk[j + 1], uk[j + 1], s1);
+                if (j + 2 < d) s2 = fma(uk[j + 2], uk[j + 2], s2);
+                if (j + 3 < d) s3 = fma(uk[j + 3], uk[j + 3], s3);
+            }
+            a.UU[((size_t)g * a.n_steps + sr) * K + k] = (s0 + s1) + (s2 + s3);
+        }
     }
 }
 
 #if MCMC_DQ_LO <= 16
 // ---------------------------------------------------------------- the step kernel, mixtures
 // KM = 2..4 modes, DQ <= 16 (d <= 64): one carried residual y_k per mode, the direction planes
-// (v, u_1 .. u_KM) of a step read with ds_read_b64, chi2_k per mode through the quad, then the
-// log-sum-exp of eval_point (gaussian_mixture.py:158-163) -- the exponential of mode k evaluated by
-// lane class k, the logarithm by every lane.
+// (v, u_1 .. u_KM) of a step read with ds_read_b64, then the log-sum-exp of eval_point
+// (gaussian_mixture.py:158-163) -- the exponential of mode k evaluated by lane class k, the
+// logarithm by every lane.  Round 5: the log-density a_k = -(c_k + chi2_k) / 2 of every mode is
+// CARRIED like step_inc_kernel's log-likelihood (oracle: carries_modes, step_core_inc):
+// a_k' = fma(-r / 2, fma(r, |u_k|^2, y_k.u_k + y_k.u_k), a_k) -- one chain over the dimensions per
+// mode and trial (y_k.u_k) instead of two (the trial residual and its square), |u_k|^2 formed once
+// per (group, step, mode) by whiten_directions_mix_kernel and read with a scalar load; the a_k live
+// in a.amode between launches and are re-anchored on y where it is refreshed (a.anchor).
 __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 {
     // (14 KB of planes per chunk: beside the 8.5 KB of staged variates and the logarithm table a
@@ -922,12 +937,19 @@ __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 
 __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
 {
-    // (measured like inc_min_waves, tools/mix_bench.py d:K over builds held to 1..4 waves; the
-    // state is dq (km + 1) doubles per lane)
-    return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 18 ? 4 : dq * (km + 1) <= 24 ? 3
-                                                     : dq * (km + 1) <= 50 ? 2 : 1);
+    // measured (round 5, tools/mix_bench.py d:K over builds held to 2..4 waves, 65 536 walkers; ms per
+    // 40 d steps at 2 / 3 / 4 waves): d = 30, K = 2: 3.33 / 3.66 / 5.32; K = 3: 3.93 / 7.36 / 17.3;
+    // K = 4: 5.07 / 24.3 / 31.3; d = 16, K = 4: 1.87 / 1.91 / 2.00.  The walker's state is
+    // dq (km + 1) + km doubles per lane and the step body (Philox block, two logarithms, the
+    // log-sum-exp) wants ~100 registers beside it: above two waves per SIMD it spills, and the
+    // kernel is bound by its instruction count (~270 VALU per wave-step at K = 2), not by latency,
+    // so occupancy buys nothing once two waves overlap.
+    return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 12 ? 4 : dq * (km + 1) <= 50 ? 2 : 1);
 }
 
+#ifndef MCMC_MIX_ORDERED_READS
+#define MCMC_MIX_ORDERED_READS 0   // 1: the reads of a step are issued plane by plane (fewer registers)
+#endif
 template <int DQ, int KM, bool UNIT_T, bool ONED>
 __global__ void __launch_bounds__(256, inc_mix_min_waves(DQ, KM))
 step_inc_mix_kernel(const IncStepArgs a)
@@ -994,6 +1016,40 @@ step_inc_mix_kernel(const IncStepArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long class1 = lanes(c == 1), class2 = lanes(c == 2), class3 = lanes(c == 3);
+    // log-sum-exp of the mode log-densities (mixture_lse of the oracle): one exponential per lane
+    // -- lane class k (< KM) takes the one of mode k -- and the weighted sum gathers them by quad
+    // broadcasts in the order of the specification
+    auto lse = [&](const double (&ak)[KM]) {
+        double amax = ak[0];
+#pragma unroll
+        for (int k = 1; k < KM; ++k) amax = fmax(ak[k], amax);
+        double mine = ak[0];
+        if (KM > 1) mine = sel(class1, ak[1], mine);
+        if (KM > 2) mine = sel(class2, ak[2 < KM ? 2 : 0], mine);
+        if (KM > 3) mine = sel(class3, ak[3 < KM ? 3 : 0], mine);
+        const double e_mine = dexp(mine - amax);
+        double Ssum = fma(wk[0], quad_perm<0x00>(e_mine), 0.0);
+        if (KM > 1) Ssum = fma(wk[1], quad_perm<0x55>(e_mine), Ssum);
+        if (KM > 2) Ssum = fma(wk[2 < KM ? 2 : 0], quad_perm<0xAA>(e_mine), Ssum);
+        if (KM > 3) Ssum = fma(wk[3 < KM ? 3 : 0], quad_perm<0xFF>(e_mine), Ssum);
+        return dlog(Ssum) + amax;
+    };
+    // the carried log-density of every mode (the same value in the four lanes of a walker)
+    double am[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) am[k] = a.amode[(size_t)k * W + w];
+    if (a.anchor) {   // (wave-uniform) y has just been refreshed from x: orc_anchor_modes
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            double pa = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) pa = fma(y[k][kk], y[k][kk], pa);
+            am[k] = -0.5 * (cn[k] + quad_sum(pa));
+        }
+        llik = lse(am);
+        lpost = lpri + llik;
+    }
+    const cdoubles gUU = (cdoubles)(unsigned long long)(a.UU + (size_t)g * ncols * KM);
     const int hw_slot = hw_wave_slot();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
@@ -1029,9 +1085,17 @@ step_inc_mix_kernel(const IncStepArgs a)
                     sv.fetch(r, Ea);
                 }
                 sv.next();
-                const double* __restrict__ col = cur + sl * COL + c;
+                // (round 5: the LDS address of the step's column is carried as a 32-bit offset
+                // and passes through empty asms -- every group of reads below then starts where the
+                // previous group's results exist, instead of all (1 + KM) DQ operands of a step
+                // being fetched up front: the old body wanted 213 registers at KM = 2 and more
+                // than 256 at KM = 4, and spilled at the occupancy it was held to)
+                unsigned coff = lds_offset(cur + sl * COL + c);
+                asm volatile("" : "+v"(coff));
+                const lds_doubles col = (lds_doubles)(unsigned long long)coff;
                 unsigned long long inb = ~0ull;   // the support test as a lane mask
                 double sc = 0.0;
+                double dep;                       // what the next group of reads is ordered behind
                 if (a.box) {   // wave-uniform: one box for every dimension, no normal priors --
                     // the test is taken on the extremes of the trial (no bounds read from LDS,
                     // no mask arithmetic per dimension; a trial coordinate is never NaN)
@@ -1043,6 +1107,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                         tmn = __builtin_fmin(tmn, t);
                     }
                     inb = lanes(tmx <= a.box_hi) & lanes(tmn >= a.box_lo);
+                    dep = tmx;
                 } else {
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
@@ -1055,39 +1120,30 @@ step_inc_mix_kernel(const IncStepArgs a)
                             const double qq = (t - li.x) * li.y;
                             sc = sc + fma(-0.5 * qq, qq, sNM[i]);
                         }
+                        dep = t;
                     }
                 }
-                double ak[KM], amax = -INFINITY;
+                double ak[KM];
 #pragma unroll
                 for (int k = 0; k < KM; ++k) {
-                    const double* __restrict__ uk = col + (1 + k) * dpad;
+                    unsigned uoff = coff + (unsigned)((1 + k) * dpad * 8);
+#if MCMC_MIX_ORDERED_READS
+                    asm volatile("" : "+v"(uoff) : "v"(dep));
+#endif
+                    const lds_doubles uk = (lds_doubles)(unsigned long long)uoff;
                     double pc = 0.0;
 #pragma unroll
-                    for (int kk = 0; kk < DQ; ++kk) {
-                        const double yt = fma(r, uk[4 * kk], y[k][kk]);
-                        pc = fma(yt, yt, pc);
-                    }
-                    const double chi2 = quad_sum(pc);
-                    ak[k] = -0.5 * (cn[k] + chi2);
-                    amax = fmax(ak[k], amax);
+                    for (int kk = 0; kk < DQ; ++kk) pc = fma(y[k][kk], uk[4 * kk], pc);   // y_k . u_k
+                    dep = pc;
+                    const double yu = quad_sum(pc);
+                    const double uu = gUU[(size_t)(base + sl) * KM + k];   // (a scalar load)
+                    ak[k] = fma(-0.5 * r, fma(r, uu, yu + yu), am[k]);
                 }
                 // inside the support = all four lanes of the walker are (outside, what follows is
                 // computed and not used)
                 const unsigned long long inside_m = quad_all_mask(inb);
-                const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
                 const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
-                // one exponential per lane: lane class k (< KM) takes the one of mode k, and the
-                // weighted sum gathers them by quad broadcasts in the order of the specification
-                double mine = ak[0];
-                if (KM > 1) mine = sel(class1, ak[1], mine);
-                if (KM > 2) mine = sel(class2, ak[2 < KM ? 2 : 0], mine);
-                if (KM > 3) mine = sel(class3, ak[3 < KM ? 3 : 0], mine);
-                const double e_mine = dexp(mine - amax);
-                double Ssum = fma(wk[0], quad_perm<0x00>(e_mine), 0.0);
-                if (KM > 1) Ssum = fma(wk[1], quad_perm<0x55>(e_mine), Ssum);
-                if (KM > 2) Ssum = fma(wk[2 < KM ? 2 : 0], quad_perm<0xAA>(e_mine), Ssum);
-                if (KM > 3) Ssum = fma(wk[3 < KM ? 3 : 0], quad_perm<0xFF>(e_mine), Ssum);
-                const double ll = dlog(Ssum) + amax;
+                const double ll = lse(ak);
                 const double lt = lp + ll;   // (finite: the sum of the weights' terms is >= w_max)
                 const double delta = UNIT_T ? (lpost - lt) : (lpost - lt) / s.temperature;
                 const unsigned long long acc_m = inside_m & (lanes(lt > lpost) | lanes(Ea > delta));
@@ -1099,14 +1155,28 @@ step_inc_mix_kernel(const IncStepArgs a)
                     burning = lanes(burn > 0) != 0ull;
                 }
                 const double ra = sel(acc_m, r, 0.0);
-                const lds_doubles col2 = relaunder(col);
+                // the commit reads the planes AGAIN, one plane at a time (x, then y_1 .. y_KM)
+                {
+                    unsigned poff = coff;
+                    asm volatile("" : "+v"(poff) : "v"(ra));   // (re-read: not kept from the trial)
+                    const lds_doubles pv = (lds_doubles)(unsigned long long)poff;
 #pragma unroll
-                for (int kk = 0; kk < DQ; ++kk) {
-                    x[kk] = fma(ra, col2[4 * kk], x[kk]);
-#pragma unroll
-                    for (int k = 0; k < KM; ++k)
-                        y[k][kk] = fma(ra, col2[(1 + k) * dpad + 4 * kk], y[k][kk]);
+                    for (int kk = 0; kk < DQ; ++kk) x[kk] = fma(ra, pv[4 * kk], x[kk]);
                 }
+#pragma unroll
+                for (int k = 0; k < KM; ++k) {
+                    unsigned poff = coff + (unsigned)((1 + k) * dpad * 8);
+#if MCMC_MIX_ORDERED_READS
+                    asm volatile("" : "+v"(poff) : "v"(k == 0 ? x[DQ - 1] : y[k > 0 ? k - 1 : 0][DQ - 1]));
+#else
+                    asm volatile("" : "+v"(poff) : "v"(ra));
+#endif
+                    const lds_doubles pu = (lds_doubles)(unsigned long long)poff;
+#pragma unroll
+                    for (int kk = 0; kk < DQ; ++kk) y[k][kk] = fma(ra, pu[4 * kk], y[k][kk]);
+                }
+#pragma unroll
+                for (int k = 0; k < KM; ++k) am[k] = sel(acc_m, ak[k], am[k]);
                 lpri = sel(acc_m, lp, lpri);
                 llik = sel(acc_m, ll, llik);
                 lpost = sel(acc_m, lt, lpost);
@@ -1129,6 +1199,8 @@ step_inc_mix_kernel(const IncStepArgs a)
         }
     }
     if (c == 0) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k) a.amode[(size_t)k * W + w] = am[k];
         s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;

@@ -238,6 +238,10 @@ struct IncStepArgs {
     // carried log-likelihood is then re-anchored on y (oracle: orc_anchor_loglike)
     const double* UU;
     int anchor;
+    // mixtures with carried mode log-densities (round 5: step_inc_mix_kernel, step_inc_regs_kernel
+    // without periodic parameters; oracle: carries_modes): amode[K][W] = -(c_k + chi2_k) / 2 of the
+    // current point per mode, UU then holds |u_k|^2 as [G][n_steps][K]; re-anchored with `anchor`
+    double* amode;
 };
 
 struct IncDirArgs {
@@ -256,7 +260,8 @@ struct IncDirArgs {
     const int* vflag;
     int* colflag;
     // |u|^2 of every column, [G][out_total], in the four-chain pattern of chi2 (null: not wanted):
-    // step_inc_kernel carries the log-likelihood along the direction (oracle: orc_direction_norms)
+    // step_inc_kernel carries the log-likelihood along the direction (oracle: orc_direction_norms);
+    // mixtures (the plane kernels): [G][out_total][K], |u_k|^2 of every mode
     double* UU;
 };
 

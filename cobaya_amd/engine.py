@@ -112,6 +112,9 @@ SYMBOLS = [
     ("mcmc_hip_last_step_kernel", C.c_char_p, [_H]),
     ("mcmc_hip_get_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_set_whitened", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_incremental_carries_modes", C.c_int, [_H]),
+    ("mcmc_hip_get_mode_logdensities", C.c_int, [_H, c_double_p]),
+    ("mcmc_hip_set_mode_logdensities", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
     ("mcmc_hip_bounds_configure", C.c_int, [_H, C.c_int32]),
     ("mcmc_hip_bounds_snapshot", C.c_int, [_H, C.c_int32]),
@@ -474,6 +477,12 @@ class Engine:
         if self.incremental:   # the carried whitened residual is part of the state
             out["y"] = np.empty((W, max(self.K or 1, 1) * self.d))
             self._check(self._lib.mcmc_hip_get_whitened(self._h, _dp(out["y"])))
+            if self.carries_modes():
+                # the carried log-density of every mode (mixtures on step_inc_mix_kernel); absent
+                # until a step has formed them (they are then re-anchored on y by the next one)
+                am = np.empty((W, self.K))
+                if self._lib.mcmc_hip_get_mode_logdensities(self._h, _dp(am)) == 0:
+                    out["amode"] = am
         return out
 
     def set_full_state(self, st):
@@ -490,6 +499,15 @@ class Engine:
         if self.incremental and "y" in st:
             y = _f64(st["y"], (W, max(self.K or 1, 1) * self.d))
             self._check(self._lib.mcmc_hip_set_whitened(self._h, _dp(y)))
+            if "amode" in st and self.carries_modes():
+                am = _f64(st["amode"], (W, self.K))
+                self._check(self._lib.mcmc_hip_set_mode_logdensities(self._h, _dp(am)))
+
+    def carries_modes(self):
+        """Mixtures in incremental mode: does the step kernel this configuration selects carry the
+        log-density of every mode (mcmc_hip_incremental_carries_modes)?  The oracle takes the rule
+        from here (`oracle.cbind.Problem(carry_modes=...)`)."""
+        return bool(self.incremental and self._lib.mcmc_hip_incremental_carries_modes(self._h))
 
     # -- sampling
     def step(self, n_steps):

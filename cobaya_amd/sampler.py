@@ -1005,7 +1005,7 @@ class EnsembleMCMC:
         self.engine.set_proposal_cov(z["proposal_cov"])
         self.engine.set_full_state({k: z[k] for k in ("x", "logpost", "logprior", "loglike",
                                                       "weight", "prior_rej", "burn_left",
-                                                      "n_accept", "step", "y") if k in z})
+                                                      "n_accept", "step", "y", "amode") if k in z})
         self._shift = z["shift"]
         self.engine.set_moment_shift(self._shift)
         if "acc_n" in z:   # snapshots accumulated on the device since the last read-out

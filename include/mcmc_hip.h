@@ -370,6 +370,19 @@ MCMC_HIP_API int mcmc_hip_enable_timing(mcmc_hip_ctx* h, int32_t on);
  * needs (call mcmc_hip_set_whitened after mcmc_hip_set_full_state) */
 MCMC_HIP_API int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y);
 MCMC_HIP_API int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
+/* incremental mode, Gaussian mixtures (gaussian_mixture.py:138-163): 1 if the step kernel this
+ * engine's configuration selects CARRIES the log-density a_k = -(c_k + chi2_k) / 2 of every mode
+ * with the walker (round 5: step_inc_mix_kernel -- 2..4 modes, d <= 64, no periodic parameter,
+ * Metropolis steps, emit_capacity 0), moved along the whitened direction like the carried
+ * log-likelihood of a single mode; 0 if every chi2_k is summed from the trial's residual (the
+ * general kernels: more modes, periodic parameters, emitted rows).  The
+ * specification (oracle/mcmc_oracle.c: carries_modes) takes the rule from here.  The carried
+ * a[n_walkers][n_modes] are part of the state a bit-identical resume needs (call
+ * mcmc_hip_set_mode_logdensities after mcmc_hip_set_whitened; without it they are re-anchored on y
+ * at the next step). */
+MCMC_HIP_API int mcmc_hip_incremental_carries_modes(const mcmc_hip_ctx* h);
+MCMC_HIP_API int mcmc_hip_get_mode_logdensities(mcmc_hip_ctx* h, double* a);
+MCMC_HIP_API int mcmc_hip_set_mode_logdensities(mcmc_hip_ctx* h, const double* a);
 
 /* name of the step kernel the last mcmc_hip_step launched, e.g.
  * "mcmc::step_pair_kernel<true, false> (d=30)" -- reported by the launcher itself, so that

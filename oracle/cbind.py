@@ -45,7 +45,7 @@ class _Problem(C.Structure):
         ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
         ("weight", c_double_p), ("T", c_double_p), ("blocking", C.c_void_p),
         ("incremental", C.c_int32), ("refresh_every", C.c_int32),
-        ("paired_variates", C.c_int32), ("binned", C.c_void_p),
+        ("paired_variates", C.c_int32), ("carry_modes", C.c_int32), ("binned", C.c_void_p),
     ]
 
 
@@ -71,7 +71,7 @@ class _State(C.Structure):
         ("logpost", c_double_p), ("weight", c_int32_p), ("prior_rej", c_int32_p),
         ("burn_left", c_int32_p), ("n_accept", c_int64_p), ("stuck", c_int32_p),
         ("rows", c_double_p), ("n_rows", c_int32_p), ("row_cap", C.c_int32),
-        ("y", c_double_p),
+        ("y", c_double_p), ("amode", c_double_p),
     ]
 
 
@@ -128,6 +128,8 @@ def lib():
         L.orc_whiten.argtypes = [C.POINTER(_Problem), c_double_p, c_double_p]
         L.orc_whiten_directions.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p]
         L.orc_direction_norms.argtypes = [C.POINTER(_Problem), C.c_int, c_double_p, c_double_p]
+        L.orc_anchor_modes.argtypes = [C.POINTER(_Problem), C.POINTER(_State), C.c_int]
+        L.orc_anchor_modes.restype = None
         L.orc_max_threads.restype = C.c_int
         L.orc_binned_chi2_of_delta.restype = C.c_double
         L.orc_binned_chi2_of_delta.argtypes = [C.POINTER(_Binned), c_double_p]
@@ -282,8 +284,11 @@ class Problem:
                  normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
                  max_tries=None, derived=None, blocks=None, oversampling=None,
                  drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None,
-                 paired_variates=None, binned=None):
+                 paired_variates=None, binned=None, carry_modes=False):
         self.d = d
+        # mixtures: the log-density of every mode is carried (step_inc_mix_kernel, the register-plane
+        # kernel without periodic parameters); the engine says which: Engine.carries_modes()
+        self.carry_modes = bool(carry_modes)
         self.binned = binned    # a `Binned` target instead of the mixture (means must be None)
         assert binned is None or (means is None and binned.n_lin == d - 1 and not incremental)
         # incremental evaluation (one Gaussian mode, non-periodic, one block): the whitened
@@ -380,6 +385,8 @@ class Problem:
                                        if self.blocking is not None else self.d))
         p.incremental, p.refresh_every = int(self.incremental), self.refresh_every
         p.paired_variates = int(self.paired_variates)
+        p.carry_modes = int(self.carry_modes and self.incremental and self.K > 1
+                            and not self.periodic.any())
         self.c = p
 
     def set_T(self, T):
@@ -462,6 +469,8 @@ class State:
         self.n_rows = np.zeros(self.W, np.int32)
         self.step = 0
         self.y = problem.whiten(self.x) if problem.incremental else np.zeros((1, 1))
+        # carried mode log-densities (anchored at the first step, like the carried log-likelihood)
+        self.amode = np.zeros((self.W, max(problem.K, 1)))
         s = _State()
         s.x, s.logprior, s.loglike = _dp(self.x), _dp(self.logprior), _dp(self.loglike)
         s.logpost, s.weight, s.prior_rej = _dp(self.logpost), _ip(self.weight), _ip(self.prior_rej)
@@ -472,6 +481,7 @@ class State:
         s.n_rows = _ip(self.n_rows)
         s.row_cap = row_cap
         s.y = _dp(self.y)
+        s.amode = _dp(self.amode)
         self.c = s
 
     def run(self, n_steps, walker0=0, n_threads=1):
@@ -479,6 +489,12 @@ class State:
                             n_steps, n_threads)
         self.step += n_steps
         return acc
+
+    def anchor_modes(self):
+        """carry_modes: a_k, loglike and logpost of every walker from its carried y (what a launch
+        that finds no carried values does: orc_anchor_modes)."""
+        for w in range(self.W):
+            lib().orc_anchor_modes(C.byref(self.p.c), C.byref(self.c), w)
 
     def step_injected(self, vec, exp_draw):
         vec = np.ascontiguousarray(vec, dtype=np.float64)

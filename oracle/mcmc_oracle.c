@@ -212,6 +212,12 @@ typedef struct {
      * block (walker_variates_pair) -- what the incremental kernels do; 0 = one block per step as
      * everywhere else (kept so that tests can run both modes on the same proposal stream) */
     int32_t paired_variates;
+    /* incremental mode, mixtures (round 5): 1 = the log-density a_k of every MODE is carried with
+     * the walker like the log-likelihood of a single mode (step_core_inc, `carry_modes`) -- what
+     * step_inc_mix_kernel and the register-plane kernel without periodic parameters do; 0 = every
+     * chi2_k is summed from the trial's residual (the general LDS kernel, periodic parameters).
+     * The engine says which (mcmc_hip_incremental_carries_modes). */
+    int32_t carry_modes;
     /* binned-bandpower Gaussian likelihood (planck_pliklite.py:143-155) instead of the mixture
      * (n_modes must be 0): see orc_binned below */
     const struct orc_binned* binned;
@@ -637,6 +643,7 @@ typedef struct {
      * (weight, logpost, logprior, loglike, x...), n_rows[W] */
     double* rows; int32_t* n_rows; int32_t row_cap;
     double* y;         /* [W][K][d] incremental mode: L_k^-1 (x - mu_k) of the current point */
+    double* amode;     /* [W][K] carry_modes: the log-density -(c_k + chi2_k) / 2 of every mode */
 } orc_state;
 
 /* the Metropolis bookkeeping shared by the Philox and the injected drivers */
@@ -769,16 +776,51 @@ void orc_anchor_loglike(const orc_problem* p, orc_state* st, int w)
     st->logpost[w] = st->logprior[w] + st->loglike[w];
 }
 
+/* MIXTURES with carried mode log-densities (round 5; step_inc_mix_kernel, step_inc_regs_kernel
+ * without periodic parameters).  Per mode chi2_k(y_k + r u_k) - chi2_k(y_k) =
+ * r (2 y_k.u_k + r |u_k|^2), so
+ *     a_k' = fma(-0.5 r, fma(r, |u_k|^2, y_k.u_k + y_k.u_k), a_k),   a_k = -(c_k + chi2_k) / 2
+ * with y_k.u_k in the four-chain pattern and |u_k|^2 formed once per (direction, mode)
+ * (orc_direction_norms) -- one chain over the dimensions per mode and trial instead of two --, then
+ * the log-sum-exp of eval_point on the a_k'.  The a_k follow the rounding of their own updates like
+ * y_k and are re-anchored, with loglike and logpost, wherever y is refreshed (orc_anchor_modes). */
+static inline int carries_modes(const orc_problem* p)
+{
+    return p->incremental && p->n_modes > 1 && p->carry_modes && !p->has_periodic;
+}
+
+static inline double mixture_lse(const orc_problem* p, const double* a)
+{
+    const int K = p->n_modes;
+    double amax = -INFINITY, S = 0.0;
+    for (int k = 0; k < K; ++k)
+        if (a[k] > amax) amax = a[k];
+    for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp(a[k] - amax), S);
+    return orc_dlog(S) + amax;
+}
+
+void orc_anchor_modes(const orc_problem* p, orc_state* st, int w)
+{
+    const int K = p->n_modes, d = p->d;
+    double* a = st->amode + (size_t)w * K;
+    for (int k = 0; k < K; ++k)
+        a[k] = -0.5 * (p->cnorm[k] + four_chain_squares(st->y + ((size_t)w * K + k) * d, d));
+    st->loglike[w] = mixture_lse(p, a);
+    st->logpost[w] = st->logprior[w] + st->loglike[w];
+}
+
 /* One step in incremental mode.  Trial t = x + r v and, per mode, its whitened residual
  * yt_k = y_k + r u_k; prior terms and every chi2_k are summed as FOUR interleaved chains over the
  * dimensions i = c (mod 4) (the kernel keeps dimension i in lane i mod 4 of the walker's quad),
  * combined (s0 + s1) + (s2 + s3) -- for every d in this mode.  u: [K] pointers to the mode's
  * whitened direction of this step.  K > 1: log-sum-exp as in eval_point. */
 static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, const double* v,
-                                const double* const* u, double uu, double r, double exp_draw)
+                                const double* const* u, double uu, const double* uu_k, double r,
+                                double exp_draw)
 {
     int d = p->d, K = p->n_modes;
     const int carry = carries_loglike(p, st);
+    const int carry_k = carries_modes(p);
     double t[128], yt[16 * 128], sh[128];
     const double* x = st->x + (size_t)w * d;
     double* y = st->y + (size_t)w * K * d;
@@ -802,6 +844,7 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
         inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
     }
     double lp = -INFINITY, ll = -INFINITY, lt = -INFINITY;
+    double a_new[16];   /* carry_modes: the trial's mode log-densities */
     if (inb) {
         double sc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = 0; i < d; ++i)
@@ -820,7 +863,19 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
             a[0] = fma(-0.5 * r, fma(r, uu, yu + yu), st->loglike[w]);
             for (int i = 0; i < d; ++i) yt[i] = fma(r, u[0][i], y[i]);
         }
-        for (int k = 0; k < K && !carry; ++k) {
+        if (carry_k) {   /* (uu: |u_k|^2 of this step's direction, mode k at uu_k[k]) */
+            const double* am = st->amode + (size_t)w * K;
+            for (int k = 0; k < K; ++k) {
+                double q[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int i = 0; i < d; ++i) q[i & 3] = fma(y[k * d + i], u[k][i], q[i & 3]);
+                const double yu = (q[0] + q[1]) + (q[2] + q[3]);
+                a[k] = fma(-0.5 * r, fma(r, uu_k[k], yu + yu), am[k]);
+                for (int i = 0; i < d; ++i) yt[k * d + i] = fma(r, u[k][i], y[k * d + i]);
+            }
+            ll = mixture_lse(p, a);
+            for (int k = 0; k < K; ++k) a_new[k] = a[k];
+        }
+        for (int k = 0; k < K && !carry && !carry_k; ++k) {
             double pc[4] = {0.0, 0.0, 0.0, 0.0};
             for (int i = 0; i < d; ++i) yt[k * d + i] = fma(r, u[k][i], y[k * d + i]);
             if (wound) {   /* a wrap by sh_i moves the residual by sh_i (column i of L^-1) */
@@ -835,7 +890,8 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
             a[k] = -0.5 * (p->cnorm[k] + ((pc[0] + pc[1]) + (pc[2] + pc[3])));
             if (a[k] > amax) amax = a[k];
         }
-        if (K == 1) ll = a[0];
+        if (carry_k) { /* (formed above) */ }
+        else if (K == 1) ll = a[0];
         else {
             double S = 0.0;
             for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp(a[k] - amax), S);
@@ -847,8 +903,11 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
     if (!inb || lt == -INFINITY) accept = 0;
     else if (lt > st->logpost[w]) accept = 1;
     else accept = exp_draw > (st->logpost[w] - lt) / p->temperature;
-    if (accept)
+    if (accept) {
         for (int i = 0; i < K * d; ++i) y[i] = yt[i];
+        if (carry_k)
+            for (int k = 0; k < K; ++k) st->amode[(size_t)w * K + k] = a_new[k];
+    }
     commit(p, st, w, t, inb, lp, ll, lt, accept);
     return accept;
 }
@@ -1158,20 +1217,28 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
             if (p->incremental && !drag) {
                 const int K = p->n_modes;
                 if (cycle != have_u) {
-                    if (!U) U = (double*)malloc(sizeof(double) * ((size_t)K * L0 * d + (size_t)L0));
+                    if (!U) U = (double*)malloc(sizeof(double) * ((size_t)K * L0 * d + (size_t)K * L0));
                     orc_whiten_directions(p, L0, V, U);
                     if (carries_loglike(p, st)) orc_direction_norms(p, L0, U, U + (size_t)K * L0 * d);
+                    if (carries_modes(p))   /* |u_k|^2 of column c at [k * L0 + c] */
+                        for (int k = 0; k < K; ++k)
+                            orc_direction_norms(p, L0, U + (size_t)k * L0 * d,
+                                                U + (size_t)K * L0 * d + (size_t)k * L0);
                     have_u = cycle;
                 }
                 const double uu = carries_loglike(p, st) ? U[(size_t)K * L0 * d + col] : 0.0;
                 const double* uk[16];
+                double uuk[16];
                 for (int k = 0; k < K; ++k) uk[k] = U + ((size_t)k * L0 + col) * d;
+                if (carries_modes(p))
+                    for (int k = 0; k < K; ++k) uuk[k] = U[(size_t)K * L0 * d + (size_t)k * L0 + col];
                 for (int l = l_lo; l < l_hi; ++l) {
                     int w = g * gs + l;
                     double r, Ea;
                     if (step % (uint64_t)p->refresh_every == 0) {
                         orc_whiten(p, st->x + (size_t)w * d, st->y + (size_t)w * K * d);
                         if (carries_loglike(p, st)) orc_anchor_loglike(p, st, w);
+                        if (carries_modes(p)) orc_anchor_modes(p, st, w);
                     }
                     /* a column of a one-parameter block draws the RandProposer1D variates of
                      * the un-paired stream, as in full evaluation (its half of the pair block
@@ -1182,7 +1249,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                         walker_variates_pair(k0, k1, walker0 + (uint32_t)w, step, &r, &Ea);
                     else
                         walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
-                    total += step_core_inc(p, st, w, v, uk, uu, r, Ea);
+                    total += step_core_inc(p, st, w, v, uk, uu, uuk, r, Ea);
                 }
                 continue;
             }

@@ -114,7 +114,7 @@ class OracleEngine:
                 self.d, kinds, a, b, per, **self._target,
                 group_size=1 if self.own_basis else self.basis_group_size,
                 seed=self.seed, temperature=self.temperature, max_tries=self.max_tries,
-                incremental=self.incremental, **bl)
+                incremental=self.incremental, carry_modes=self.carries_modes(), **bl)
             if self._cov is not None:
                 self._problem.set_T(self._transform(self._cov))
             if self._state is not None:      # re-point the state at the new problem
@@ -166,7 +166,17 @@ class OracleEngine:
                    n_accept=s.n_accept.copy(), step=np.uint64(s.step))
         if self.incremental:
             out["y"] = s.y.copy()
+            if self.carries_modes() and s.step > 0:
+                out["amode"] = s.amode.copy()
         return out
+
+    def carries_modes(self):
+        """The engine's rule (mcmc_hip_incremental_carries_modes): step_inc_mix_kernel serves 2..4
+        modes at d <= 64 without periodic parameters, dragging or emitted rows."""
+        drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
+        periodic = self._prior is not None and self._prior[3] is not None and self._prior[3].any()
+        return bool(self.incremental and self.K is not None and 2 <= self.K <= 4 and self.d <= 64
+                    and not drag and not periodic and self.cap == 0)
 
     def set_full_state(self, st):
         self.set_state(st["x"])
@@ -177,6 +187,11 @@ class OracleEngine:
         s.step = self._steps = int(st["step"])
         if self.incremental and "y" in st:
             s.y[...] = st["y"]
+            if self.carries_modes():
+                if "amode" in st:
+                    s.amode[...] = st["amode"]
+                else:   # (the engine re-anchors them on y at the next launch)
+                    s.anchor_modes()
 
     # -- sampling -----------------------------------------------------------------------
     def step(self, n_steps):

@@ -82,7 +82,9 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
                      seed=seed,
                      temperature=T, max_tries=max_tries,
                      derived=None if own_constants else eng.derived_constants(),
-                     incremental=incremental)
+                     incremental=incremental,
+                     # (which mixtures carry the log-density of every mode is the engine's rule)
+                     carry_modes=eng.carries_modes())
     m0 = means[0] if K else np.full(d, 0.5)
     s0 = np.sqrt(np.diag(covs[0])) if K else np.full(d, 0.1)
     x0 = np.clip(m0 + rng.normal(size=(W, d)) * s0, 1e-3, 1 - 1e-3)
@@ -106,6 +108,9 @@ def compare_state(eng, st):
     assert_bit_equal(s["logprior"], st.logprior, "logprior")
     assert_bit_equal(s["loglike"], st.loglike, "loglike")
     assert np.array_equal(s["weight"], st.weight)
+    if eng.incremental and eng.carries_modes() and st.step > 0:
+        assert st.p.c.carry_modes == 1
+        assert_bit_equal(eng.get_full_state()["amode"], st.amode, "carried mode log-densities")
 
 
 def test_library_reports_gfx950():
@@ -1041,6 +1046,26 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
     assert st.step > R and "step_inc_mix_kernel" in eng.last_step_kernel()
     assert eng.counters()["accepted"] == int(st.n_accept.sum())
+    assert eng.carries_modes()
+    # the carried a_k are part of the state (mcmc_hip_set_mode_logdensities): handed back with the
+    # full state the run continues bit for bit; without them they are re-anchored on y at the next
+    # launch -- the same values to rounding
+    full = eng.get_full_state()
+    assert full["amode"].shape == (W, K)
+    eng.set_full_state(full)
+    eng.step(d + 5)
+    eng.sync()
+    st.run(d + 5, n_threads=8)
+    compare_state(eng, st)
+    full = eng.get_full_state()
+    del full["amode"]
+    eng.set_full_state(full)
+    eng.step(3)
+    eng.sync()
+    st.run(3, n_threads=8)
+    s2 = eng.get_full_state()
+    np.testing.assert_allclose(s2["logpost"], st.logpost, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(s2["amode"], st.amode, rtol=1e-12, atol=1e-10)
     eng.close()
 
 

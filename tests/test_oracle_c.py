@@ -387,10 +387,13 @@ def test_whitened_directions_are_linv_times_v(golden):
     np.testing.assert_allclose(U, V @ Linv.T, rtol=1e-11, atol=1e-12 * np.abs(U).max())
 
 
-@pytest.mark.parametrize("d,K", [(4, 3), (30, 2), (9, 4)])
-def test_incremental_mixture_is_the_same_posterior(d, K):
+@pytest.mark.parametrize("carry", [False, True])
+@pytest.mark.parametrize("d,K", [(4, 3), (30, 2), (9, 4), (30, 8)])
+def test_incremental_mixture_is_the_same_posterior(d, K, carry):
     """K > 1 in incremental mode: one carried residual y_k and one whitened direction u_k per
-    mode, log-sum-exp as in eval_point (gaussian_mixture.py:158-163)."""
+    mode, log-sum-exp as in eval_point (gaussian_mixture.py:158-163).  carry (round 5): the
+    log-density a_k of every mode is carried as well (step_inc_mix_kernel): it stays within
+    rounding of the evaluated one between refreshes and is re-anchored where y is."""
     from oracle import cbind as O
     rng = np.random.default_rng(40 + d)
     means = rng.uniform(0.4, 0.6, size=(K, d))
@@ -404,8 +407,9 @@ def test_incremental_mixture_is_the_same_posterior(d, K):
     T = O.proposal_transform(covs[0], 2.4)
     mk = lambda inc: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=means, covs=covs,
                                weights=w, T=T, group_size=64, seed=9, incremental=inc,
-                               paired_variates=False)
+                               paired_variates=False, carry_modes=carry and inc)
     full, inc = mk(False), mk(True)
+    assert inc.c.carry_modes == int(carry)
     x0 = np.clip(means[0] + rng.normal(size=(128, d)) * 0.03, 1e-6, 1 - 1e-6)
     a, b = O.State(full, x0), O.State(inc, x0)
     assert b.y.shape == (128, K * d)
@@ -414,6 +418,27 @@ def test_incremental_mixture_is_the_same_posterior(d, K):
         lp, ll = full.evaluate(b.x)
         np.testing.assert_allclose(b.loglike, ll, rtol=2e-13, atol=1e-11)
         np.testing.assert_allclose(b.y, full.whiten(b.x), rtol=0, atol=1e-11)
+        if carry:   # the carried a_k against -(c_k + |y_k|^2) / 2 of the carried residuals
+            yk = b.y.reshape(128, K, d)
+            np.testing.assert_allclose(b.amode, -0.5 * (inc.cnorm + (yk ** 2).sum(2)),
+                                       rtol=2e-13, atol=1e-11)
+    if carry:
+        # exactly re-anchored where y is refreshed: one step past a refresh the carried values
+        # of the walkers that did not move are the anchored ones
+        b2 = O.State(inc, x0)
+        b2.run(inc.refresh_every, n_threads=4)
+        before = b2.n_accept.copy()
+        b2.run(1, n_threads=4)
+        still = b2.n_accept == before
+        yk = b2.y.reshape(128, K, d)[still]
+        q = np.zeros((still.sum(), K, 4))
+        for i in range(d):
+            q[:, :, i & 3] = np.fma(yk[:, :, i], yk[:, :, i], q[:, :, i & 3]) if hasattr(np, "fma") \
+                else q[:, :, i & 3] + yk[:, :, i] ** 2
+        if hasattr(np, "fma"):
+            chi2 = (q[..., 0] + q[..., 1]) + (q[..., 2] + q[..., 3])
+            assert np.array_equal(b2.amode[still], -0.5 * (inc.cnorm + chi2))
+        assert still.sum() > 40
     a.run(300, n_threads=4)
     c = O.State(inc, x0)
     c.run(300, n_threads=4)

@@ -62,7 +62,8 @@ prof() {  # prof <outdir> <bench args...>: bench line, kernel trace, PMC passes 
 sub=$1; shift
 case "$sub" in
 tests)
-  timeout ${TEST_TIMEOUT:-2400} python -m pytest ${*:-tests} -m gpu -q -x 2>&1 | tail -${TAIL:-15} | tee gpurun_out/tests.log ;;
+  [ $# -eq 0 ] && set -- tests
+  timeout ${TEST_TIMEOUT:-2400} python -m pytest "$@" -m gpu -q -x 2>&1 | tail -${TAIL:-15} | tee gpurun_out/tests.log ;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tee gpurun_out/smoke.log ;;
 bench)
