@@ -9,9 +9,11 @@ tests/golden/targets.npz), U(0,1) priors, 65 536 walkers per GPU initialised fro
 pdf N(mu_i, sigma_i), proposal covariance = target covariance, proposal_scale 2.4, T = 1,
 seed 1.  Synthetic data; inputs are resident in HBM when the timed region starts.
 
-One bench "step" = one pass of the hot path over the whole ensemble = ONE fused launch of
-`steps_per_launch` Metropolis steps for every walker (Haar-basis generation + step kernel)
-plus one moment snapshot; learn/convergence checkpoints (read-back of the sufficient
+One bench "step" = one pass of the hot path over the whole ensemble = one call of the engine:
+`steps_per_launch` Metropolis steps for every walker (Haar-basis generation + the fused step
+kernel; since round 5 the sampler's default at this size is 160 d = 4 800 steps, run as four
+launches of 40 d steps -- the refresh interval of the carried residual -- whose directions are
+formed together) plus one moment snapshot; learn/convergence checkpoints (read-back of the sufficient
 statistics, the all-reduce across ranks, R-1, proposal refresh) run inside the timed region
 at the reference cadence `learn_every = 40d` accepted steps per chain (mcmc.yaml:22).
 One evaluation = one Metropolis step of one walker = one Model.logposterior call of the
@@ -70,7 +72,8 @@ def parse():
     ap.add_argument("--basis-group-size", type=int, default=None,
                     help="walkers sharing one Haar basis (default: the sampler's choice)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
-                    help="default 40*d (the sampler's default)")
+                    help="default: the sampler's (40 d; 160 d for incremental runs of >= 65536 "
+                         "walkers with emit: snapshots)")
     ap.add_argument("--emit", choices=("snapshots", "chains"), default="snapshots",
                     help="chains: every accepted row is stored with its weight (the reference's "
                          "own semantics, mcmc.py:691-707) and drained to the host every launch")
@@ -238,6 +241,18 @@ def cpu_baseline_pliklite(n_lin, seconds):
                       f"{dt:.1f} s on {threads} OpenMP threads (oracle/mcmc_oracle.c, orc_binned)"}
 
 
+PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16, one direction (what a drained row crosses once)
+
+
+def pcie_roofline(rows, d, dt, kernel):
+    """`emit: chains`: every accepted row (8 (d + 5) bytes) crosses PCIe once -- the roof that
+    binds the reference's own product above ~1e9 evals/s (0.3 rows per evaluation at d = 30)."""
+    gbs = rows * 8.0 * (d + 5) / dt / 1e9
+    return {"bound": "pcie", "achieved": gbs, "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / PCIE_PEAK_GBS, "kernel": kernel,
+            "note": "device-to-host row traffic of the drain over the PCIe Gen5 x16 rate"}
+
+
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # wave-instructions/s: 1024 SIMDs, one per 4 clocks, 2.4 GHz
 
 
@@ -374,7 +389,8 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
     from cobaya_amd.sampler import MCMCHip
     size = dist.size()
     if info is None:
-        spl_req = a.steps_per_launch or 40 * d
+        # (None: the sampler's own default -- 40 d; 160 d for large incremental ensembles)
+        spl_req = a.steps_per_launch or (40 * d if emit == "chains" else None)
         info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit,
                          evaluation or a.evaluation)
         if a.basis_group_size and (evaluation or a.evaluation) != "full":
@@ -471,6 +487,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
         cross = {"steps": n_x, "seconds": dx, "ms_per_step": 1e3 * dx / n_x,
                  "value": float(a.walkers) * size * spl * n_x / dx}
     res = {"dt": dt, "spl": spl, "kt": kt, "kernel": eng.last_step_kernel(),
+           "n_modes": int(getattr(sampler.spec, "n_modes", 1) or 1),
            "evaluation": "incremental" if sampler.incremental else "full",
            "group_size": int(sampler.group_size),
            "basis_group_size": int(sampler.basis_group_size), "n_ckpt": sampler.i_learn - n_ckpt0,
@@ -503,7 +520,9 @@ def gaussian_roofline(m, d, walkers, steps):
     algo_gbs = algo_bytes / (step_ms * 1e-3) / 1e9 if step_ms > 0 else None
     kernel = m["kernel"]
     on_matrix_cores = "mfma" in kernel
-    traffic, traffic_source = measured_traffic(d, walkers, spl, kernel)
+    # (the counter passes are per KERNEL launch: 40 d steps each, however many a call holds)
+    traffic, traffic_source = measured_traffic(
+        d, walkers, int(round(spl / max(launches_per_step, 1))), kernel)
     overlapped = m["evaluation"] == "incremental" and not os.environ.get("MCMC_HIP_NO_PREFETCH")
     common = {
         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel,
@@ -533,7 +552,19 @@ def gaussian_roofline(m, d, walkers, steps):
         # see traffic_source) / HIP-event duration of the kernel in THIS run.
         insts = (traffic_source or {}).get("sq_insts_valu_per_launch")
         ach = insts / (step_ms * 1e-3) if insts and step_ms > 0 else None
-        tf = algo_flops_incremental(d) * evals_per_launch / (step_ms * 1e-3) / 1e12
+        n_modes = max(1, int(m.get("n_modes", 1)))
+        fl = algo_flops_incremental(d) if n_modes == 1 else (4 + 6 * n_modes) * d
+        tf = fl * evals_per_launch / (step_ms * 1e-3) / 1e12
+        if ach is None:
+            # no counter pass of this kernel is committed (profiles/traffic.json): the fraction is
+            # the executed FP64 arithmetic over the dense FP64 peak, measured live
+            return {
+                "bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / FP64_PEAK_TFLOPS, "flops_per_eval_executed": fl,
+                "note": "executed FP64 flops of the incremental step (trial x, the chains over the "
+                        "dimensions per mode, the commits of x and the residuals) over the dense FP64 "
+                        "peak; no PMC pass of this kernel is committed, so no issue-slot fraction",
+                **common}
         return {
             "bound": "valu_issue", "achieved": ach / 1e9 if ach else None,
             "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
@@ -700,7 +731,8 @@ def main():
             "fp64_tflops": algo_flops_per_eval(d) * a.walkers * v["spl"] / max(v_launches, 1)
             / (v_ms * 1e-3) / 1e12,
             "fp64_frac_of_peak": algo_flops_per_eval(d) * a.walkers * v["spl"] / max(v_launches, 1)
-            / (v_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS})
+            / (v_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "roofline": gaussian_roofline(v, d, a.walkers, n_v)})
     if size == 1 and not a.no_variants and (d, a.walkers, a.emit) == (30, 65536, "snapshots"):
         # the price of fidelity: the reference-faithful control -- every walker draws its OWN
         # Haar basis per cycle (proposal.py:59-69 to the letter: `shared_basis: False`) and every
@@ -719,7 +751,18 @@ def main():
             "kernel": v["kernel"],
             "kernel_ms_per_launch": v["kt"]["step_ms"] / max(v["kt"]["step_launches"], 1),
             "basis_kernel_ms_per_launch": v["kt"]["basis_ms"] / n_v,
-            "headline_over_this": (m["evals"] / m["dt"]) / (v["evals"] / v["dt"])})
+            "headline_over_this": (m["evals"] / m["dt"]) / (v["evals"] / v["dt"]),
+            # what this path computes per evaluation: the from-scratch log-posterior
+            # (d (d + 1) + 4 d flops) plus its share of a private Haar basis per cycle of d steps
+            # (Householder construction ~ 2 d^3, V = T R: d^3 -> 3 d^2 per step)
+            "roofline": (lambda fl, ms: {
+                "bound": "fp64_valu", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                "achieved": fl * a.walkers * v["spl"] / (ms * 1e-3) / 1e12,
+                "frac": fl * a.walkers * v["spl"] / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "flops_per_eval": fl, "kernel": v["kernel"],
+                "kernel_ms_per_launch_step_plus_basis": ms})(
+                    algo_flops_per_eval(d) + 3 * d * d,
+                    (v["kt"]["step_ms"] + v["kt"]["basis_ms"]) / n_v)})
     if a.emit == "snapshots" and size == 1 and not a.no_variants and (d, a.walkers) == (30, 65536):
         # the reference stores EVERY accepted row (mcmc.py:691-707, collection.py:402-427);
         # same workload with those semantics: rows cross PCIe and are kept on the host
@@ -735,7 +778,8 @@ def main():
             "kernel_ms_per_launch": v["kt"]["step_ms"] / 40,
             "accepted_rows_per_s": v["rows"] / v["dt"],
             "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"],
-            "rows_retained_on_host": False})
+            "rows_retained_on_host": False,
+            "roofline": pcie_roofline(v["rows"], d, v["dt"], v["kernel"])})
         # ... and with the rows RETAINED: a store large enough for the region (max_rows = 16.7 M
         # rows: the last ~3 launches, then the oldest half is dropped).  (a) the engine's ring of
         # pinned drain slots sized to outlive that window (`drain_ring_bytes`): the store reads
@@ -758,6 +802,7 @@ def main():
                 "steps": n_v, "warmup": w_v, "metropolis_steps_per_launch": v["spl"],
                 "accepted_rows_per_s": v["rows"] / v["dt"],
                 "row_bytes_per_s": v["rows"] * 8 * (d + 5) / v["dt"], "rows_retained_on_host": True,
+                "roofline": pcie_roofline(v["rows"], d, v["dt"], v["kernel"]),
                 "rows_in_store_at_end": v.get("rows_in_store"), "drain_slots": v.get("drain_slots"),
                 "stored_rows_copied_on_host": v.get("rows_copied_on_host")})
     headline = (d, a.walkers, a.emit) == (30, 65536, "snapshots")
@@ -790,7 +835,7 @@ def main():
         d5 = 27
         m5, c5 = target(d5)
         n_v = 10
-        info5 = make_info(d5, m5, c5, a.walkers, a.group_size, 40 * d5, normal_from=6)
+        info5 = make_info(d5, m5, c5, a.walkers, a.group_size, None, normal_from=6)
         v = run_timed(a, d5, m5, c5, "snapshots", n_v, 3, info=info5)
         variants.append({
             "certificate": v["certificate"],
@@ -804,7 +849,7 @@ def main():
         # from-scratch kernels, 6e9 at four modes)
         rng8 = np.random.default_rng(8)
         sig8 = np.sqrt(np.diag(cov))
-        info8 = make_info(d, mean, cov, a.walkers, a.group_size, 40 * d)
+        info8 = make_info(d, mean, cov, a.walkers, a.group_size, None)
         info8["likelihood"] = {"gaussian_mixture": {
             "means": [mean] + [np.clip(mean + rng8.normal(size=d) * sig8, 0.05, 0.95) for _ in range(7)],
             "covs": [cov] * 8, "input_params_prefix": "a_"}}
@@ -816,7 +861,8 @@ def main():
             "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
             "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
             "evaluation": v["evaluation"], "kernel": v.get("kernel"),
-            "kernel_ms_per_launch": v["kt"]["step_ms"] / max(1, v["kt"]["step_launches"])})
+            "kernel_ms_per_launch": v["kt"]["step_ms"] / max(1, v["kt"]["step_launches"]),
+            "roofline": gaussian_roofline(v, d, a.walkers, n_v)})
         # configs[4]'s ARITHMETIC: the plik-lite likelihood (planck_pliklite.py:143-155) -- 613
         # bins, chi2 = delta^T Sigma^-1 delta on the matrix cores -- with a 26-parameter linear
         # Cl(theta) + A_planck (d = 27); synthetic plik-lite-shaped data (the Planck files and a

@@ -1779,6 +1779,23 @@ IncSeg plan_segment(const IncPlan& P, unsigned long long step, int left)
     return s;
 }
 
+// step_inc_kernel (P.carry): the steps whose directions are formed TOGETHER -- a call's steps as
+// far as the direction buffers hold them, NOT cut at the refresh of y: the launches inside (cut
+// there by plan_segment) read their columns out of one set and follow each other directly
+IncSeg plan_span(const IncPlan& P, unsigned long long step, int left)
+{
+    if (!P.carry) return plan_segment(P, step, left);
+    IncSeg s{};
+    const unsigned long long Lc = (unsigned long long)P.Lc;
+    s.step0 = step;
+    s.c0 = step / Lc;
+    unsigned long long room = (s.c0 + (unsigned long long)P.max_cyc) * Lc - step;
+    room = std::min<unsigned long long>(room, (unsigned long long)P.max_steps_vu);
+    s.n = (int)std::min<unsigned long long>((unsigned long long)left, room);
+    s.ncyc = (int)((step + (unsigned long long)s.n - 1) / Lc - s.c0 + 1);
+    return s;
+}
+
 // fills the set D with the directions of launch `s`, on stream `st`
 int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip_ctx::DirSet& D,
                     hipStream_t st)
@@ -1912,20 +1929,11 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         P.drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * P.ddf * (size_t)h->BG)) : 0;
     int left = n_steps;
     while (left > 0) {
-        bool anchor = false;   // y is refreshed from x before this launch
-        if (!h->y_valid || h->step % P.R == 0) {
-            HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
-                                                    d, h->W, K, h->stream));
-            h->y_valid = true;
-            anchor = true;
-        }
-        // (carried mode log-densities that no launch has written since y was set are re-anchored
-        // on y: after set_state always; after a resume only if the state file did not hold them)
-        if (P.carry_modes && !h->amode_valid) anchor = true;
-        const IncSeg seg = plan_segment(P, h->step, left);
-        const int n = seg.n;
+        // the steps whose directions form one set: one launch (cut at the refresh of y), or --
+        // step_inc_kernel, round 5 -- as much of the call as the buffers hold
+        const IncSeg span = plan_span(P, h->step, left);
         auto& D = h->dirs[h->dir_cur];
-        const bool hit = D.ahead && D.step0 == seg.step0 && D.n == n && D.epoch == h->dir_epoch;
+        const bool hit = D.ahead && D.step0 == span.step0 && D.n == span.n && D.epoch == h->dir_epoch;
         // (a set filled ahead on stream2 -- hit or not -- must have been written before it is
         // read or overwritten here)
         if (D.ahead) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
@@ -1939,15 +1947,33 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             if (h->prefetch && h->lazy_dirs && h->mark_valid && h->stream2) {
                 HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
                 if (h->T_fresh) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->T_event, 0));
-                const int rc = make_directions(h, P, seg, D, h->stream2);
+                const int rc = make_directions(h, P, span, D, h->stream2);
                 if (rc != MCMC_HIP_OK) return rc;
                 HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
             } else {
-                const int rc = make_directions(h, P, seg, D, h->stream);
+                const int rc = make_directions(h, P, span, D, h->stream);
                 if (rc != MCMC_HIP_OK) return rc;
             }
             h->T_fresh = false;
         }
+        for (int done = 0; done < span.n;) {
+        bool anchor = false;   // y is refreshed from x before (or, step_inc_kernel: in) this launch
+        bool refresh_in_kernel = false;
+        if (!h->y_valid || h->step % P.R == 0) {
+            if (P.carry) {
+                refresh_in_kernel = true;   // (round 5: whiten_state_kernel folded into the launch)
+            } else {
+                HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
+                                                        d, h->W, K, h->stream));
+            }
+            h->y_valid = true;
+            anchor = true;
+        }
+        // (carried mode log-densities that no launch has written since y was set are re-anchored
+        // on y: after set_state always; after a resume only if the state file did not hold them)
+        if (P.carry_modes && !h->amode_valid) anchor = true;
+        const IncSeg seg = plan_segment(P, h->step, span.n - done);
+        const int n = seg.n;
         {
             Timed t(h, 0);
             mcmc::IncStepArgs a{};
@@ -1979,9 +2005,13 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.colflag = D.has_flags ? D.colflag.p : nullptr;
             a.Lrow = h->inc_Lrow.p;
             a.UU = (P.carry || P.carry_modes) ? D.UU.p : nullptr;
-            a.anchor = anchor ? 1 : 0;
+            a.anchor = (anchor ? 1 : 0) | (refresh_in_kernel ? 2 : 0);
             a.amode = P.carry_modes ? h->amode.p : nullptr;
             if (P.carry_modes) h->amode_valid = true;
+            // (the launch's columns inside the set; 0 / 0: the set is this launch's own)
+            a.vu_cols = P.carry ? span.n : 0;
+            a.col0 = P.carry ? done : 0;
+            a.mean = h->inc_mean.p;
             for (int i = 0; i < d; ++i)
                 if (h->periodic[i]) a.periodic_mask4[i >> 5] |= 1u << (i & 31);
             HIP_TRY(h, launch(&a, h->stream));
@@ -1991,6 +2021,9 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                 g_noted_kernel = nullptr;
             }
         }
+        h->step += (unsigned long long)n;
+        done += n;
+        }   // launches of the span
         if (h->prefetch) {
             // the launch expected next: the rest of this call, or a call like this one.  Its
             // directions are computed on the second stream BEHIND this step kernel (the event
@@ -2002,8 +2035,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             // round (1.78 ms instead of 1.04; with the event recorded BEFORE the step kernel
             // d = 64 ran 6.13 ms per launch instead of 4.24, d = 48 and d = 100 unchanged).
             auto& N = h->dirs[h->dir_cur ^ 1];
-            const IncSeg nxt = plan_segment(P, h->step + (unsigned long long)n,
-                                            left > n ? left - n : n_steps);
+            const IncSeg nxt = plan_span(P, h->step, left > span.n ? left - span.n : n_steps);
             HIP_TRY(h, hipEventRecord(h->mark, h->stream));
             h->mark_valid = true;
             // (round 4) the launch a LATER call begins with is left to that call (above): the
@@ -2013,7 +2045,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             // Before, a refreshed proposal made the set prepared here stale and the next call
             // recomputed it on the MAIN stream: 141 us instead of 72 between two step kernels
             // after every learn checkpoint (tools/gpu_r4_timeline.sh).
-            if (left > n || !h->lazy_dirs) {
+            if (left > span.n || !h->lazy_dirs) {
                 HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
                 const int rc = make_directions(h, P, nxt, N, h->stream2);
                 if (rc != MCMC_HIP_OK) return rc;
@@ -2021,8 +2053,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             }
         }
         h->dir_cur ^= 1;
-        h->step += (unsigned long long)n;
-        left -= n;
+        left -= span.n;
     }
     return MCMC_HIP_OK;
 }

@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     const int w = blockIdx.x * 64 + (tid >> 2);
     const int g = __builtin_amdgcn_readfirstlane(w / s.group_size);
     const int ncols = s.n_steps;
-    const double2* __restrict__ gVU = (const double2*)a.VU + (size_t)g * ncols * COLB;
+    // (the launch's columns inside its direction set: see IncStepArgs::vu_cols)
+    const int set_cols = a.vu_cols > 0 ? a.vu_cols : ncols;
+    const double2* __restrict__ gVU =
+        (const double2*)a.VU + ((size_t)g * set_cols + (size_t)a.col0) * COLB;
     constexpr int dpad = 4 * DQ;
     double2* const sVU = smem2;                          // [2][CHUNK]
     double2* const sLH = smem2 + 2 * CHUNK;              // [dpad] (lo, hi), kBoundsInLds only
@@ -127,7 +130,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
         }
     };
-    stage(0);
+    // (a launch that refreshes y itself uses the chunk buffers as scratch first: its first
+    // chunk is staged behind that, below)
+    const bool refresh_y = (a.anchor & 2) != 0;   // wave-uniform
+    if (!refresh_y) stage(0);
     MCMC_EXP_BLOCK_BEGIN();
 
     const double blo = a.box_lo, bhi = a.box_hi;
@@ -161,6 +167,45 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
             sNM[i] = a.prior[4 * dpad + i];
         }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    if (refresh_y) {
+        // y = L^-1 (x - mu) from the walker's x (round 5: whiten_state_kernel folded into the
+        // launch that needs it -- one kernel and ~17 us less on the main stream between two step
+        // kernels).  The deviations of the wave's 16 walkers go to LDS ([walker][dimension], in the
+        // chunk buffers, which nothing has been staged into yet: every wave its own 16 x 4 DQ
+        // doubles, no barrier), then ONE rolled loop over the dimensions i ascending: every row
+        // j = 4 kk + c of the lane takes fma(L^-1[j][i], dev_i, y_j) -- for i > j the factor is
+        // the exact +0.0 above the diagonal (tri_inverse_lower), which leaves the chain where it
+        // ended at i = j: bit for bit orc_whiten's ascending chain over i <= j.
+        static_assert(C >= 16, "the chunk buffers hold the deviations of the workgroup's 64 walkers");
+        double* const sdev = (double*)sVU + (size_t)(tid >> 2) * dpad;   // this walker's deviations
+#pragma unroll
+        for (int kk = 0; kk < DQ; ++kk) {
+            const int i = 4 * kk + c;
+            sdev[i] = i < d ? x[kk] - a.mean[i] : 0.0;
+            y[kk] = 0.0;
+        }
+        asm volatile("" ::: "memory");
+        // (the lane's rows of L^-1 as 32-bit element offsets: a padded row reads row d - 1 and
+        // is zeroed below)
+        const int row0 = (4 * 0 + c < d ? c : d - 1) * d;
+        const lds_doubles pdev = relaunder(sdev);
+#pragma unroll 1
+        for (int i = 0; i < d; ++i) {
+            const double dv = pdev[i];
+            const double* __restrict__ li = a.Lrow + i;
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) {
+                const int j = 4 * kk + c;
+                const int off = kk == 0 ? row0 : (j < d ? j : d - 1) * d;
+                y[kk] = fma(li[off], dv, y[kk]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < DQ; ++kk)
+            if (4 * kk + c >= d) y[kk] = 0.0;
+        __syncthreads();   // every wave is done with its scratch: the first chunk may land
+        stage(0);
+    }
     if (a.anchor) {   // (wave-uniform) y has just been refreshed from x: the carried log-likelihood
         double pa = 0.0;   // is re-anchored on it (orc_anchor_loglike)
 #pragma unroll
@@ -175,7 +220,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     // |u|^2 of the launch's columns, through the constant address space: the address is
     // wave-uniform, the load a scalar one (s_load_dwordx2 on the scalar cache's counter -- a vector
     // load would queue behind the DMA of the next chunk on vmcnt)
-    const cdoubles gUU = (cdoubles)(unsigned long long)(a.UU + (size_t)g * ncols);
+    const cdoubles gUU = (cdoubles)(unsigned long long)(a.UU + (size_t)g * set_cols + (size_t)a.col0);
     const uint32_t gid = s.walker0 + (uint32_t)w;
     // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
     const double mt10 = s.max_tries * 10.0;
@@ -199,7 +244,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         const int cols = __builtin_amdgcn_readfirstlane(ncols - base < C ? ncols - base : C);
         unsigned long long oned_cols = 0;   // bit sl: column sl of the chunk is a 1-D one
         if (ONED)
-            oned_cols = lanes(lane < cols && a.colflag[(size_t)g * ncols + base + lane] != 0);
+            oned_cols = lanes(lane < cols &&
+                              a.colflag[(size_t)g * set_cols + (size_t)a.col0 + base + lane] != 0);
         // (the step loop is rolled: an unrolled body lets the scheduler hoist the LDS reads of
         // several steps and costs the registers that decide the occupancy)
         // (the LDS address of the step's column is CARRIED and passes through the empty asms in

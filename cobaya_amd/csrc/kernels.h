@@ -242,6 +242,15 @@ struct IncStepArgs {
     // without periodic parameters; oracle: carries_modes): amode[K][W] = -(c_k + chi2_k) / 2 of the
     // current point per mode, UU then holds |u_k|^2 as [G][n_steps][K]; re-anchored with `anchor`
     double* amode;
+    // step_inc_kernel (round 5): a direction set may cover SEVERAL launches of one call (the steps
+    // of a call are cut at the refresh of y; their directions are formed together, so that the
+    // launches follow each other without the direction kernels in between): the launch reads
+    // the columns [col0, col0 + s.n_steps) of a set of vu_cols columns per group (0: the set is
+    // this launch's own, vu_cols = s.n_steps).  anchor & 2: y is refreshed from x IN the kernel
+    // (whiten_state_kernel's arithmetic: one ascending fma chain per row from +0.0, orc_whiten)
+    // before the carried log-likelihood is re-anchored on it; mean = the mode's mean [d]
+    int vu_cols, col0;
+    const double* mean;
 };
 
 struct IncDirArgs {

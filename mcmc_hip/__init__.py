@@ -41,7 +41,7 @@ else:
         n_walkers: int = HIP_DEFAULTS["n_walkers"]
         group_size: int | None = HIP_DEFAULTS["group_size"]
         device: int | None = HIP_DEFAULTS["device"]
-        steps_per_launch: int | str = HIP_DEFAULTS["steps_per_launch"]
+        steps_per_launch: int | str | None = HIP_DEFAULTS["steps_per_launch"]
         moments_every: int = HIP_DEFAULTS["moments_every"]
         emit: str = HIP_DEFAULTS["emit"]
         snapshot_every: int | None = HIP_DEFAULTS["snapshot_every"]

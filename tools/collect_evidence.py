@@ -91,12 +91,14 @@ def main():
         f.write(f"# rocprofv3 --pmc <counters> (one pass per line group) -- {CMD}\n")
         f.write(f"# per-dispatch averages for {bench['roofline']['kernel']}, "
                 f"{wl['walkers_per_gpu']} walkers, {wl['metropolis_steps_per_launch']} steps "
-                "per launch\n# pass, counter, avg value, dispatches, avg dispatch ns\n")
+                "per call of the engine\n# pass, counter, avg value, dispatches, avg dispatch ns\n")
         f.write("\n".join(lines) + "\n")
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         traffic = {
             "d": wl["d"], "walkers": wl["walkers_per_gpu"],
-            "steps_per_launch": wl["metropolis_steps_per_launch"],
+            # (steps per KERNEL launch: a call of the engine may hold several launches)
+            "steps_per_launch": int(round(wl["metropolis_steps_per_launch"]
+                                          / max(1.0, bench["roofline"].get("kernel_launches_per_step", 1)))),
             "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
             "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
             "sq_insts_valu": vals.get("SQ_INSTS_VALU"),
@@ -117,7 +119,7 @@ def main():
         if os.path.exists(tj):
             with open(tj) as f:
                 table = json.load(f)
-        table[f"{rnd}_d{wl['d']}_w{wl['walkers_per_gpu']}_spl{wl['metropolis_steps_per_launch']}"] = traffic
+        table[f"{rnd}_d{wl['d']}_w{wl['walkers_per_gpu']}_spl{traffic['steps_per_launch']}"] = traffic
         with open(tj, "w") as f:
             json.dump(table, f, indent=1)
     print(open(os.path.join(DST, f"{rnd}_kernel_stats.txt")).read())
