@@ -10,10 +10,10 @@ pdf N(mu_i, sigma_i), proposal covariance = target covariance, proposal_scale 2.
 seed 1.  Synthetic data; inputs are resident in HBM when the timed region starts.
 
 One bench "step" = one pass of the hot path over the whole ensemble = one call of the engine:
-`steps_per_launch` Metropolis steps for every walker (Haar-basis generation + the fused step
-kernel; since round 5 the sampler's default at this size is 160 d = 4 800 steps, run as four
-launches of 40 d steps -- the refresh interval of the carried residual -- whose directions are
-formed together) plus one moment snapshot; learn/convergence checkpoints (read-back of the sufficient
+ONE fused launch of `steps_per_launch` = 40 d Metropolis steps for every walker (Haar-basis
+generation + step kernel; `--steps-per-launch 4800` runs four such launches per call off one
+set of directions: +3.8 % whole job, not the default -- R-1 is estimated from the per-call moment
+snapshots) plus one moment snapshot; learn/convergence checkpoints (read-back of the sufficient
 statistics, the all-reduce across ranks, R-1, proposal refresh) run inside the timed region
 at the reference cadence `learn_every = 40d` accepted steps per chain (mcmc.yaml:22).
 One evaluation = one Metropolis step of one walker = one Model.logposterior call of the
@@ -72,8 +72,7 @@ def parse():
     ap.add_argument("--basis-group-size", type=int, default=None,
                     help="walkers sharing one Haar basis (default: the sampler's choice)")
     ap.add_argument("--steps-per-launch", type=int, default=None,
-                    help="default: the sampler's (40 d; 160 d for incremental runs of >= 65536 "
-                         "walkers with emit: snapshots)")
+                    help="default: the sampler's, 40 d")
     ap.add_argument("--emit", choices=("snapshots", "chains"), default="snapshots",
                     help="chains: every accepted row is stored with its weight (the reference's "
                          "own semantics, mcmc.py:691-707) and drained to the host every launch")
@@ -389,7 +388,7 @@ def run_timed(a, d, mean, cov, emit, steps, warmup, evaluation=None, info=None, 
     from cobaya_amd.sampler import MCMCHip
     size = dist.size()
     if info is None:
-        # (None: the sampler's own default -- 40 d; 160 d for large incremental ensembles)
+        # (None: the sampler's own default, 40 d)
         spl_req = a.steps_per_launch or (40 * d if emit == "chains" else None)
         info = make_info(d, mean, cov, a.walkers, a.group_size, spl_req, emit,
                          evaluation or a.evaluation)

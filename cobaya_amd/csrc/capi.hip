@@ -1749,6 +1749,7 @@ struct IncPlan {   // what the cutting of launches depends on besides the step c
     bool any;   // the general kernel (incremental_any.hip): columns as planes (v, u_1 .. u_K)
     bool carry; // step_inc_kernel (one mode, no periodic parameter, Metropolis steps): the log-likelihood is carried
     bool carry_modes;   // step_inc_mix_kernel: the log-density of every mode is carried
+    bool fold;          // step_inc_kernel: the refresh of y is the kernel's, a direction set spans a call
 };
 struct IncSeg {    // one launch: steps [step0, step0 + n)
     unsigned long long step0, c0, cyc0_f;
@@ -1784,7 +1785,7 @@ IncSeg plan_segment(const IncPlan& P, unsigned long long step, int left)
 // there by plan_segment) read their columns out of one set and follow each other directly
 IncSeg plan_span(const IncPlan& P, unsigned long long step, int left)
 {
-    if (!P.carry) return plan_segment(P, step, left);
+    if (!P.fold) return plan_segment(P, step, left);
     IncSeg s{};
     const unsigned long long Lc = (unsigned long long)P.Lc;
     s.step0 = step;
@@ -1897,9 +1898,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                         "incremental evaluation: %d modes at d=%d with %d periodic parameters do "
                         "not fit the LDS of a CU; use evaluation: full for this model", K, d, n_periodic);
     }
-    // one mode, no periodic parameter, Metropolis steps: step_inc_kernel, which carries the
-    // log-likelihood along the whitened direction and needs |u|^2 of every column
-    P.carry = !P.any && !P.drag && K == 1 && n_periodic == 0;
+    // one mode, Metropolis steps: step_inc_kernel / step_inc_periodic_kernel, which carry the
+    // log-likelihood along the whitened direction and need |u|^2 of every column
+    P.carry = !P.any && !P.drag && K == 1;   // (round 5: with up to eight periodic parameters too)
+    P.fold = P.carry && n_periodic == 0;     // step_inc_kernel: y refreshed in the kernel, sets of several launches
     // mixtures on step_inc_mix_kernel (2..4 modes, d <= 64, no periodic parameter): the log-density
     // of every mode is carried; |u_k|^2 of every column and mode (inc_carries_modes says the same
     // to the caller: the oracle takes the rule from there)
@@ -1960,7 +1962,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         bool anchor = false;   // y is refreshed from x before (or, step_inc_kernel: in) this launch
         bool refresh_in_kernel = false;
         if (!h->y_valid || h->step % P.R == 0) {
-            if (P.carry) {
+            if (P.fold) {
                 refresh_in_kernel = true;   // (round 5: whiten_state_kernel folded into the launch)
             } else {
                 HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
@@ -2009,8 +2011,8 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.amode = P.carry_modes ? h->amode.p : nullptr;
             if (P.carry_modes) h->amode_valid = true;
             // (the launch's columns inside the set; 0 / 0: the set is this launch's own)
-            a.vu_cols = P.carry ? span.n : 0;
-            a.col0 = P.carry ? done : 0;
+            a.vu_cols = P.fold ? span.n : 0;
+            a.col0 = P.fold ? done : 0;
             a.mean = h->inc_mean.p;
             for (int i = 0; i < d; ++i)
                 if (h->periodic[i]) a.periodic_mask4[i >> 5] |= 1u << (i & 31);
@@ -2867,6 +2869,15 @@ int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y)
     HIP_TRY(h, hipMemcpy(h->y.p, yt.data(), sizeof(double) * W * d, hipMemcpyHostToDevice));
     h->y_valid = true;
     return MCMC_HIP_OK;
+}
+
+int mcmc_hip_incremental_carries_periodic(const mcmc_hip_ctx* h)
+{
+    if (!h || !h->incremental || h->K != 1 || h->drag_last_slow >= 0 || h->cfg.emit_capacity > 0)
+        return 0;
+    int n = 0;
+    for (int i = 0; i < h->d; ++i) n += h->periodic[i] ? 1 : 0;
+    return n >= 1 && n <= 8 ? 1 : 0;
 }
 
 int mcmc_hip_incremental_carries_modes(const mcmc_hip_ctx* h)

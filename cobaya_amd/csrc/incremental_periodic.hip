@@ -1,27 +1,25 @@
 // mcmc_hip -- incremental step kernel for ONE Gaussian mode with PERIODIC parameters (gfx950).
 //
 // prior.py:658-676 (Prior.reduce_periodic) in incremental mode; specification: oracle/mcmc_oracle.c,
-// step_core_inc.  The trial coordinate of a periodic dimension is the wrapped one,
-// t' = ((t - lo) / w - floor(.)) w + lo, at every step; when the winding number changes
-// (floor != 0) the move sh = t' - t is carried into the whitened residual,
-// y'_j += sh L^-1[j][i] for j >= i (ascending i), before chi2 is summed.
-//
-// The design is step_inc_kernel's (incremental_kernels.hip): x and y in registers, four lanes per
-// walker, the (v, u) pairs of a step read from LDS twice -- for the trial and, re-read, for the
-// commit (x += ra v, y += ra u with ra = r where the walker accepts, 0 elsewhere) --, logprior
-// and loglike of the current point formed once after the loop.  What a periodic dimension adds:
-//   * the trial and the commit loops stay branch-free (a periodic dimension has the bounds
-//     (-inf, +inf) there); behind each, the rows that hold a periodic dimension (a scalar test
-//     per row) wrap the coordinate -- for the support test and the move of a wrap, and again on
-//     the committed value (nothing is kept between the two);
+// step_core_inc with `carry_periodic`.  Round 5: the kernel is step_inc_kernel's body -- x and y
+// in registers, four lanes per walker, the (v, u) pairs of a step read from LDS for the trial
+// and, re-read, for the commit, the log-likelihood CARRIED along the whitened direction -- with
+// the bounds of a periodic dimension set to [lo, pred(hi)]: a step on which every lane of the
+// wave is inside all its bounds (most steps) is step_inc_kernel's step.  Only when some lane is
+// outside (wave-uniform branch) the rows are looked at again, branch-free:
+//   * a periodic coordinate that LEFT [lo, hi) is wrapped, t' = ((t - lo) / w - floor(.)) w + lo
+//     (inside the interval the reference's expression returns t up to its own rounding; here it
+//     returns t), and when the winding number changes (floor != 0) the move sh = t' - t is
+//     carried into the whitened residual, y'_j += sh L^-1[j][i] for j >= i (ascending i), and
+//     the walker's chi2 is summed from that residual instead of moved;
 //   * the division by the period without a division: with R = RN(1 / w) from the prologue,
 //     q0 = a R, q1 = fma(fma(-q0, w, a), R, q0), q2 = fma(fma(-q1, w, a), R, q1) is the correctly
 //     rounded a / w (q1 is faithful -- its exact argument is within 2^-52 ulp of a / w -- and a
 //     faithful quotient corrected once with the correctly rounded reciprocal is the IEEE quotient:
-//     Markstein 1990) -- bit for bit the oracle's `/`, 5 instructions instead of 30;
-//   * a wrap somewhere in the wave (wave-uniform, a few per cent of the steps even on a target
-//     that straddles the seam): the trial residual of every row goes to registers, takes the
-//     wrap moves in ascending dimension, is summed again and, where the walker accepts, selected.
+//     Markstein 1990) -- bit for bit the oracle's `/`, 5 instructions instead of 30.
+// Rounds 2-4 wrapped every periodic coordinate at every step behind a scalar test per row (25
+// branches per step at d = 30) and summed chi2 from the trial residual: 2.5 ms per 1200 steps with
+// one periodic parameter against 1.37 for the same bounds without the flag.
 // Up to kMaxPeriodic periodic parameters; more run on the general kernel (incremental_any.hip).
 #include <string>
 
@@ -36,6 +34,15 @@ __host__ __device__ constexpr int inc_periodic_min_waves(int dq)
     // (measured, 65 536 walkers: d = 30 at four waves 2.6 ms per 1200 steps, at two 4.4; d = 100 at
     // two waves -- with some spilled registers -- 34 ms per 4000 steps, at one 59)
     return MCMC_EXP_WAVES(PERIODIC, dq <= 8 ? 4 : 2);
+}
+
+// the largest double below a finite x
+__device__ __forceinline__ double pred_double(double x)
+{
+    const long long b = __double_as_longlong(x);
+    if (x > 0.0) return __longlong_as_double(b - 1);
+    if (x < 0.0) return __longlong_as_double(b + 1);
+    return -4.9406564584124654e-324;
 }
 
 // a / w given R = RN(1 / w): the correctly rounded quotient (see the header)
@@ -54,7 +61,7 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
     constexpr int COLB = 4 * DQ;
     const int CHUNK = C * COLB;   // (C: columns per chunk, inc_chunk(DQ) or what the LDS leaves)
     constexpr int dpad = 4 * DQ;
-    __shared__ double2 sLH[dpad];       // (lo, hi); beyond d and for a periodic dimension: (-inf, +inf)
+    __shared__ double2 sLH[dpad];       // (lo, hi); beyond d: (-inf, +inf); a periodic dimension: [lo, pred(hi)]
     __shared__ double4 sPer[dpad];      // periodic dimensions: (lo, hi, w, RN(1 / w)), w = hi - lo
     __shared__ double2 sNA[NORMP ? dpad : 1];   // normal priors: (loc, 1/scale); 1/scale = 0: none here
     __shared__ double sNM[NORMP ? dpad : 1];    //                -log(scale sqrt(2 pi))
@@ -95,7 +102,9 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
     for (int i = tid; i < dpad; i += 256) {
         const double lo = a.prior[i], hi = a.prior[dpad + i];
         const bool per = i < d && is_periodic(i);
-        sLH[i] = per ? make_double2(-INFINITY, INFINITY) : make_double2(lo, hi);
+        // (a periodic dimension: [lo, pred(hi)] -- "t <= pred(hi)" is "t < hi": inside means
+        // that nothing has to be wrapped)
+        sLH[i] = per ? make_double2(lo, pred_double(hi)) : make_double2(lo, hi);
         sPer[i] = per ? make_double4(lo, hi, hi - lo, 1.0 / (hi - lo)) : make_double4(0.0, 1.0, 1.0, 1.0);
         if (NORMP) {
             sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
@@ -114,7 +123,6 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
     }
     double x[DQ], y[DQ];
     unsigned mine = 0;     // bit kk: dimension 4 kk + c of this lane is periodic
-    unsigned anyp = 0;     // bit kk: one of the dimensions 4 kk .. 4 kk + 3 is (wave-uniform)
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
@@ -122,9 +130,7 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
         x[kk] = in ? s.x[(size_t)i * W + w] : 0.0;     // (beyond d: bounds -inf / +inf)
         y[kk] = in ? a.y[(size_t)i * W + w] : 0.0;
         if (in && is_periodic(i)) mine |= 1u << kk;
-        if ((a.periodic_mask4[(4 * kk) >> 5] >> ((4 * kk) & 31)) & 0xFu) anyp |= 1u << kk;
     }
-    anyp = (unsigned)__builtin_amdgcn_readfirstlane((int)anyp);
     // the slot of the periodic dimension 4 kk + c in sPdim: the periodic dimensions of the rows
     // below (scalar) plus those of this row in the lane classes below c
     const unsigned below_c = (1u << c) - 1u;
@@ -136,6 +142,13 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
         return n + __builtin_popcount((word >> ((4 * kk) & 31)) & below_c);
     };
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    if (a.anchor) {   // (wave-uniform) y has just been refreshed from x: the carried log-likelihood
+        double pa = 0.0;   // is re-anchored on it (orc_anchor_loglike)
+#pragma unroll
+        for (int kk = 0; kk < DQ; ++kk) pa = fma(y[kk], y[kk], pa);
+        llik = -0.5 * (s.cnorm0 + quad_sum(pa));
+        lpost = lpri + llik;
+    }
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;
@@ -144,6 +157,8 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
     const bool unit_t = s.temperature == 1.0;
+    // |u|^2 of the launch's columns by scalar loads (see step_inc_kernel)
+    const cdoubles gUU = (cdoubles)(unsigned long long)(a.UU + (size_t)g * ncols);
     __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
     const short_log_tab slog = short_log_load(short_log_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -181,13 +196,16 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
                 sv.fetch(r, Ea);
             }
             sv.next();
+            const double uu = gUU[base + sl];   // (wave-uniform address: a scalar load)
             const double2* __restrict__ col = cur + sl * COLB + c;
-            unsigned long long inb = ~0ull, wound = 0ull;
+            unsigned long long inb = ~0ull;
             double pc = 0.0, sc = 0.0;
-            // The trial as in step_inc_kernel, branch-free over the rows: the bounds this loop
-            // tests are (-inf, +inf) for a periodic dimension, whose coordinate is dealt with below.
+            // ---- the trial as in step_inc_kernel: the bounds of a periodic dimension are
+            // [lo, pred(hi)] here, so "every lane inside" also says that no coordinate has to be
+            // wrapped (round 5: a periodic coordinate is wrapped only where it LEAVES [lo, hi)),
+            // and the log-likelihood moves by r (2 y.u + r |u|^2) / 2 (carried)
             // (four rows at a time: the pointers of the next rows depend, through an empty
-            // asm, on the chi2 chain of these -- else the pairs and the bounds of all DQ rows are
+            // asm, on the chain of these -- else the pairs and the bounds of all DQ rows are
             // fetched up front into 8 DQ registers)
             lds_pairs colt = relaunder(col), lht = relaunder(&sLH[c]);
 #pragma unroll
@@ -200,8 +218,7 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
                 const pair_t lh = lht[4 * kk];
                 const double tk = fma(r, p.x, x[kk]);
                 inb &= lanes(tk <= lh.y) & lanes(tk >= lh.x);
-                const double yt = fma(r, p.y, y[kk]);
-                pc = fma(yt, yt, pc);
+                pc = fma(y[kk], p.y, pc);   // y . u
                 if (NORMP) {   // branch-free inside (1/scale = 0: no term -- a periodic dimension)
                     const int i = 4 * kk + c;
                     const double2 li = sNA[i];
@@ -209,61 +226,72 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
                     sc = sc + fma(-0.5 * qq, qq, sNM[i]);
                 }
             }
-            // the rows that hold a periodic dimension (a scalar test per row): the wrapped
-            // coordinate against the bounds of the prior, and the move of a wrap
-            auto wrapped = [&](int kk, double tk, double& fl) {
-                const double4 pw = sPer[4 * kk + c];   // (lo, hi, w, RN(1 / w))
-                const double yv = div_by(tk - pw.x, pw.z, pw.w);
-                fl = floor(yv);
-                return (yv - fl) * pw.z + pw.x;
-            };
+            const double yu = quad_sum(pc);
+            double ll = fma(-0.5 * r, fma(r, uu, yu + yu), llik);
+            // ---- some lane of the wave is outside some bound (wave-uniform; rare away from the
+            // walls except for walkers at the seam of a periodic parameter): row by row,
+            // branch-free -- a periodic coordinate that left [lo, hi) is wrapped (prior.py:675,
+            // the division by the period as div_by), its move goes to the walker's slot in LDS;
+            // the support test is taken on the wrapped coordinates
+            unsigned long long wound = 0ull;
+            const bool slow = inb != ~0ull;
+            if (slow) {
+                inb = ~0ull;
+                lds_pairs colw = relaunder(col), lhw = relaunder(&sLH[c]);
 #pragma unroll
-            for (int kk = 0; kk < DQ; ++kk)
-                if ((anyp >> kk) & 1u) {   // wave-uniform
+                for (int kk = 0; kk < DQ; ++kk) {
                     const bool per = (mine >> kk) & 1u;
-                    const double tk = fma(r, colt[4 * kk].x, x[kk]);
-                    double fl;
-                    const double tw = wrapped(kk, tk, fl);
-                    const double4 pw = sPer[4 * kk + c];
-                    inb &= lanes(!per | ((tw <= pw.y) & (tw >= pw.x)));
-                    const double shk = (per & (fl != 0.0)) ? tw - tk : 0.0;
+                    const double tk = fma(r, colw[4 * kk].x, x[kk]);
+                    const pair_t lh = lhw[4 * kk];
+                    const bool out = !((tk <= lh.y) & (tk >= lh.x));
+                    const double4 pw = sPer[4 * kk + c];   // (lo, hi, w, RN(1 / w)); no period: (0, 1, 1, 1)
+                    const double yv = div_by(tk - pw.x, pw.z, pw.w);
+                    const double fl = floor(yv);
+                    const double tw = (yv - fl) * pw.z + pw.x;
+                    const bool wr = per & out;
+                    const double shk = (wr & (fl != 0.0)) ? tw - tk : 0.0;
                     wound |= lanes(shk != 0.0);
                     if (per) myShift[slot_of(kk)] = shk;
+                    const bool ins = wr ? ((tw <= pw.y) & (tw >= pw.x)) : !out;
+                    inb &= lanes(ins);
                 }
+            }
             // the trial residual with the wrap moves (a wrap in the wave only): every row's
             // fma(r, u, y), then the moves in ascending dimension -- the columns of L^-1 of the
-            // periodic dimensions sit in LDS (sLc).  Formed here for chi2 and AGAIN in the commit:
-            // kept in registers across the decision it would cost the hot path its registers
-            auto shifted = [&](double (&ytw)[DQ]) {
-                lds_pairs colw = relaunder(col);
-#pragma unroll
-                for (int kk = 0; kk < DQ; ++kk) ytw[kk] = fma(r, colw[4 * kk].y, y[kk]);
+            // periodic dimensions sit in LDS (sLc) -- for the lanes `on`
+            auto shift_rows = [&](double (&yr)[DQ], unsigned long long on_m) {
+                const bool on_l = __builtin_amdgcn_inverse_ballot_w64(on_m);
 #pragma unroll 1
                 for (int q = 0; q < np; ++q) {
-                    const double sv = myShift[q];                // the same in the walker's quad
-                    if (lanes(sv != 0.0) == 0ull) continue;      // wave-uniform
+                    const double sv_ = myShift[q];               // the same in the walker's quad
+                    if (lanes(sv_ != 0.0) == 0ull) continue;     // wave-uniform
                     const int i = sPdim[q];                      // the dimension that wrapped
                     const double* __restrict__ lc = sLc + q * dpad + c;
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
                         const int j = 4 * kk + c;
-                        const bool on = (sv != 0.0) & (j >= i) & (j < d);
-                        ytw[kk] = on ? fma(sv, lc[4 * kk], ytw[kk]) : ytw[kk];
+                        const bool on = on_l & (sv_ != 0.0) & (j >= i) & (j < d);
+                        yr[kk] = on ? fma(sv_, lc[4 * kk], yr[kk]) : yr[kk];
                     }
                 }
             };
-            if (wound != 0ull) {   // wave-uniform
+            // (the walkers whose residual took a move: any lane of the quad wrote a non-zero one)
+            const unsigned long long wq = ~quad_all_mask(~wound);
+            if (wound != 0ull) {   // wave-uniform, rarer still: chi2 of those walkers is summed anew
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes
                 double ytw[DQ];
-                shifted(ytw);
-                pc = 0.0;
+                lds_pairs colw = relaunder(col);
 #pragma unroll
-                for (int kk = 0; kk < DQ; ++kk) pc = fma(ytw[kk], ytw[kk], pc);
+                for (int kk = 0; kk < DQ; ++kk) ytw[kk] = fma(r, colw[4 * kk].y, y[kk]);
+                shift_rows(ytw, ~0ull);
+                double ps = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) ps = fma(ytw[kk], ytw[kk], ps);
+                const double ll_w = -0.5 * (s.cnorm0 + quad_sum(ps));
+                ll = sel(wq, ll_w, ll);
             }
             const bool inside = quad_all(inb);
-            const double chi2 = quad_sum(pc);
             const double lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
-            const double ll = -0.5 * (s.cnorm0 + chi2);
             // (outside the support lt is not used; lt = -inf fails both comparisons like the
             // specification's explicit lt != -inf)
             const double lt = lp + ll;
@@ -282,32 +310,33 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
             // ---- commit: the pairs are read again (see step_inc_kernel)
             const double ra = accept ? r : 0.0;
             lds_pairs col2 = relaunder(col);
-            if (wound != 0ull) {   // wave-uniform, rare: the residual that took the wrap moves
-                double ytw[DQ];
-                shifted(ytw);
 #pragma unroll
-                for (int kk = 0; kk < DQ; ++kk) {
-                    x[kk] = fma(ra, col2[4 * kk].x, x[kk]);
-                    y[kk] = accept ? ytw[kk] : y[kk];
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < DQ; ++kk) {
-                    if (kk % 4 == 0 && kk) col2 = relaunder_after(col2, y[kk - 1]);
-                    const pair_t p = col2[4 * kk];
-                    x[kk] = fma(ra, p.x, x[kk]);
-                    y[kk] = fma(ra, p.y, y[kk]);
-                }
+            for (int kk = 0; kk < DQ; ++kk) {
+                if (kk % 4 == 0 && kk) col2 = relaunder_after(col2, y[kk - 1]);
+                const pair_t p = col2[4 * kk];
+                x[kk] = fma(ra, p.x, x[kk]);
+                y[kk] = fma(ra, p.y, y[kk]);
             }
-            // (a periodic coordinate that was accepted holds the moved value: wrapped now, from
-            // the same value as in the trial)
+            if (slow) {   // wave-uniform: an accepted coordinate that left [lo, hi) is the wrapped one
+                lds_pairs lhw = relaunder(&sLH[c]);
 #pragma unroll
-            for (int kk = 0; kk < DQ; ++kk)
-                if ((anyp >> kk) & 1u) {   // wave-uniform
-                    double fl;
-                    const double tw = wrapped(kk, x[kk], fl);
-                    x[kk] = (accept & (bool)((mine >> kk) & 1u)) ? tw : x[kk];
+                for (int kk = 0; kk < DQ; ++kk) {
+                    const bool per = (mine >> kk) & 1u;
+                    const pair_t lh = lhw[4 * kk];
+                    const bool out = !((x[kk] <= lh.y) & (x[kk] >= lh.x));
+                    const double4 pw = sPer[4 * kk + c];
+                    const double yv = div_by(x[kk] - pw.x, pw.z, pw.w);
+                    const double fl = floor(yv);
+                    const double tw = (yv - fl) * pw.z + pw.x;
+                    x[kk] = (per & out & accept) ? tw : x[kk];   // (a walker that stays keeps its x)
                 }
+                // ... and the residual of a walker that accepted a wrapping trial takes the moves
+                // (on top of fma(r, u, y): the same operations in the same order as for the trial)
+                if (wound != 0ull)
+                    shift_rows(y, lanes(accept));
+            }
+            llik = accept ? ll : llik;
+            if (NORMP) lpri = accept ? lp : lpri;
             lpost = accept ? lt : lpost;
             prej = accept ? 0 : (prej + (inside ? 0 : 1));
             wt = accept ? 1 : wt + 1;
@@ -316,23 +345,6 @@ step_inc_periodic_kernel(const IncStepArgs a, const int C)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-    if (nacc != 0) {   // (the same in the four lanes of a walker: the quad sums are safe)
-        // logprior and loglike of the current point, from the committed x and y: the chains of
-        // the trial that was accepted last, on the same values
-        double pc = 0.0, sc = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < DQ; ++kk) {
-            pc = fma(y[kk], y[kk], pc);
-            if (NORMP) {
-                const int i = 4 * kk + c;
-                const double2 li = sNA[i];
-                const double qq = (x[kk] - li.x) * li.y;
-                sc = sc + fma(-0.5 * qq, qq, sNM[i]);
-            }
-        }
-        llik = -0.5 * (s.cnorm0 + quad_sum(pc));
-        lpri = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
     }
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {

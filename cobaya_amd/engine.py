@@ -113,6 +113,7 @@ SYMBOLS = [
     ("mcmc_hip_get_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_set_whitened", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_incremental_carries_modes", C.c_int, [_H]),
+    ("mcmc_hip_incremental_carries_periodic", C.c_int, [_H]),
     ("mcmc_hip_get_mode_logdensities", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_set_mode_logdensities", C.c_int, [_H, c_double_p]),
     ("mcmc_hip_kernel_times", C.c_int, [_H, c_double_p, c_int64_p, C.c_int32]),
@@ -508,6 +509,12 @@ class Engine:
         log-density of every mode (mcmc_hip_incremental_carries_modes)?  The oracle takes the rule
         from here (`oracle.cbind.Problem(carry_modes=...)`)."""
         return bool(self.incremental and self._lib.mcmc_hip_incremental_carries_modes(self._h))
+
+    def carries_periodic(self):
+        """One mode with periodic parameters in incremental mode: step_inc_periodic_kernel's rule
+        (wrap only what leaves [lo, hi), carried log-likelihood) applies
+        (mcmc_hip_incremental_carries_periodic); the oracle takes it from here."""
+        return bool(self.incremental and self._lib.mcmc_hip_incremental_carries_periodic(self._h))
 
     # -- sampling
     def step(self, n_steps):

@@ -70,9 +70,7 @@ HIP_DEFAULTS = {
                               # default: 256 from 16384 walkers per process up, else 64
     "device": None,           # HIP ordinal; default LOCAL_RANK
     "steps_per_launch": None,  # Metropolis steps fused per call of the engine (between two moment
-                               # snapshots); default "40d" -- "160d" for incremental Metropolis runs of
-                               # >= 65536 walkers per process with emit: snapshots, where the ~70 us
-                               # between two launches are 7 % of a 40d launch (round 5)
+                               # snapshots); default "40d"
     "moments_every": 1,       # launches between moment snapshots
     "emit": "snapshots",      # "snapshots": ensemble state every snapshot_every steps,
                               # "chains": every accepted row with its integer weight
@@ -353,17 +351,13 @@ class EnsembleMCMC:
                        "group_size that is a multiple of 64; emit: chains with Metropolis steps; use "
                        "'full' (or 'auto')")
         self.incremental = can_inc and self.evaluation != "full"
-        if (self._spl_default and self.incremental and W >= 65536 and self.emit == "snapshots"
-                and not self.drag):
-            # Large ensembles: four refresh intervals of y per call.  The engine forms the
-            # directions of the whole call at once and its launches (cut at the refresh, which the
-            # step kernel does itself) follow each other directly; the moment snapshot, the Haar
-            # bases and the launch latencies around them (~70 us at config 2) are then paid once
-            # per 160d steps (measured: whole job / step kernel 1.077 -> 1.036).  A snapshot of such
-            # an ensemble holds >= 65536 samples, and the learn checkpoints keep their cadence:
-            # learn_every = 40d ACCEPTED steps is four 40d launches or one 160d call at the usual
-            # acceptance rate (mcmc.py:757-760).
-            self.steps_per_launch *= 4
+        # (Longer calls were tried as the default for large ensembles in round 5 -- "160d": the
+        # engine forms the directions of a whole call at once and its launches follow each other
+        # directly, whole job / step kernel 1.077 -> 1.036 at config 2 -- and NOT kept: the moment
+        # snapshot is taken once per call, R-1 is estimated from the snapshots, and with a quarter
+        # of them the default stopping rule needed four times the steps
+        # (test_config2_full_size_run_converges).  `steps_per_launch: 160d` remains a choice for
+        # runs that are not waiting for R-1.)
         if self.basis_group_size is None:
             self.basis_group_size = int(self.group_size)
             if self.incremental and W >= 16384 and W % 1024 == 0 and 1024 % int(self.group_size) == 0:

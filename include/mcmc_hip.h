@@ -381,6 +381,13 @@ MCMC_HIP_API int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
  * mcmc_hip_set_mode_logdensities after mcmc_hip_set_whitened; without it they are re-anchored on y
  * at the next step). */
 MCMC_HIP_API int mcmc_hip_incremental_carries_modes(const mcmc_hip_ctx* h);
+/* incremental mode, ONE mode with periodic parameters (prior.py:658-676): 1 if this configuration
+ * runs on step_inc_periodic_kernel (1..8 periodic parameters, Metropolis steps, emit_capacity 0),
+ * whose rule since round 5 is: a periodic coordinate is wrapped only where the trial leaves
+ * [lo, hi), and the log-likelihood is carried along the whitened direction, re-summed from the
+ * moved residual at a step that wraps; 0: the coordinate passes through the wrap at every step
+ * (the general kernels).  The specification (oracle: carry_periodic) takes the rule from here. */
+MCMC_HIP_API int mcmc_hip_incremental_carries_periodic(const mcmc_hip_ctx* h);
 MCMC_HIP_API int mcmc_hip_get_mode_logdensities(mcmc_hip_ctx* h, double* a);
 MCMC_HIP_API int mcmc_hip_set_mode_logdensities(mcmc_hip_ctx* h, const double* a);
 

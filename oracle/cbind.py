@@ -45,7 +45,8 @@ class _Problem(C.Structure):
         ("mean", c_double_p), ("Linv", c_double_p), ("cnorm", c_double_p),
         ("weight", c_double_p), ("T", c_double_p), ("blocking", C.c_void_p),
         ("incremental", C.c_int32), ("refresh_every", C.c_int32),
-        ("paired_variates", C.c_int32), ("carry_modes", C.c_int32), ("binned", C.c_void_p),
+        ("paired_variates", C.c_int32), ("carry_modes", C.c_int32), ("carry_periodic", C.c_int32),
+        ("binned", C.c_void_p),
     ]
 
 
@@ -284,8 +285,11 @@ class Problem:
                  normalized=True, T=None, group_size=64, seed=1, temperature=1.0,
                  max_tries=None, derived=None, blocks=None, oversampling=None,
                  drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None,
-                 paired_variates=None, binned=None, carry_modes=False):
+                 paired_variates=None, binned=None, carry_modes=False, carry_periodic=False):
         self.d = d
+        # one mode with periodic parameters on step_inc_periodic_kernel: wrap only what leaves
+        # [lo, hi), carry the log-likelihood (Engine.carries_periodic())
+        self.carry_periodic = bool(carry_periodic)
         # mixtures: the log-density of every mode is carried (step_inc_mix_kernel, the register-plane
         # kernel without periodic parameters); the engine says which: Engine.carries_modes()
         self.carry_modes = bool(carry_modes)
@@ -387,6 +391,8 @@ class Problem:
         p.paired_variates = int(self.paired_variates)
         p.carry_modes = int(self.carry_modes and self.incremental and self.K > 1
                             and not self.periodic.any())
+        p.carry_periodic = int(self.carry_periodic and self.incremental and self.K == 1
+                               and bool(self.periodic.any()))
         self.c = p
 
     def set_T(self, T):

@@ -218,6 +218,14 @@ typedef struct {
      * chi2_k is summed from the trial's residual (the general LDS kernel, periodic parameters).
      * The engine says which (mcmc_hip_incremental_carries_modes). */
     int32_t carry_modes;
+    /* incremental mode, ONE mode with periodic parameters (round 5): 1 = step_inc_periodic_kernel's
+     * rule -- a periodic coordinate is wrapped only where the trial LEAVES [lo, hi) (inside, the
+     * reference's ((x - a) / (b - a)) % 1 * (b - a) + a, prior.py:675, returns x up to its own
+     * rounding; here it returns x), and the log-likelihood is carried as without periodic
+     * parameters, re-summed from the moved residual only at a step that wraps; 0 = the coordinate
+     * passes through the wrap at every step and chi2 is summed from the trial's residual (the
+     * general kernels).  The engine says which (mcmc_hip_incremental_carries_periodic). */
+    int32_t carry_periodic;
     /* binned-bandpower Gaussian likelihood (planck_pliklite.py:143-155) instead of the mixture
      * (n_modes must be 0): see orc_binned below */
     const struct orc_binned* binned;
@@ -760,7 +768,7 @@ void orc_direction_norms(const orc_problem* p, int ncol, const double* U, double
  * refreshed: orc_anchor_loglike. */
 static inline int carries_loglike(const orc_problem* p, const orc_state* st)
 {
-    if (!(p->incremental && p->n_modes == 1 && !p->has_periodic)) return 0;
+    if (!(p->incremental && p->n_modes == 1 && (!p->has_periodic || p->carry_periodic))) return 0;
     /* (emitted rows with a one-parameter block run on the general kernel, incremental_any.hip,
      * which forms every chi2 from the trial's residual) */
     if (st->rows && p->blocking)
@@ -828,8 +836,10 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
     for (int i = 0; i < d; ++i) {
         t[i] = fma(r, v[i], x[i]);
         sh[i] = 0.0;
-        if (p->has_periodic && p->periodic[i]) {
-            /* prior.py:675 (wrap_periodic, spelled out): the coordinate is the wrapped one; when
+        if (p->has_periodic && p->periodic[i] &&
+            !(carry && t[i] >= p->lo[i] && t[i] < p->hi[i])) {
+            /* (carry_periodic: only a coordinate that left [lo, hi) is wrapped)
+             * prior.py:675 (wrap_periodic, spelled out): the coordinate is the wrapped one; when
              * the winding number changes (floor != 0) the move of the coordinate, sh = t' - t, is
              * carried into the whitened residual below -- otherwise t' differs from t by the
              * rounding of the wrap alone, which y does not follow (as it does not follow the
@@ -862,6 +872,13 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
             const double yu = (q[0] + q[1]) + (q[2] + q[3]);
             a[0] = fma(-0.5 * r, fma(r, uu, yu + yu), st->loglike[w]);
             for (int i = 0; i < d; ++i) yt[i] = fma(r, u[0][i], y[i]);
+            if (wound) {   /* a wrap: the residual takes the moves, chi2 is summed from it */
+                const double* Li = p->Linv;
+                for (int i = 0; i < d; ++i)
+                    if (sh[i] != 0.0)
+                        for (int j = i; j < d; ++j) yt[j] = fma(sh[i], Li[j * d + i], yt[j]);
+                a[0] = -0.5 * (p->cnorm[0] + four_chain_squares(yt, d));
+            }
         }
         if (carry_k) {   /* (uu: |u_k|^2 of this step's direction, mode k at uu_k[k]) */
             const double* am = st->amode + (size_t)w * K;

@@ -114,7 +114,8 @@ class OracleEngine:
                 self.d, kinds, a, b, per, **self._target,
                 group_size=1 if self.own_basis else self.basis_group_size,
                 seed=self.seed, temperature=self.temperature, max_tries=self.max_tries,
-                incremental=self.incremental, carry_modes=self.carries_modes(), **bl)
+                incremental=self.incremental, carry_modes=self.carries_modes(),
+                carry_periodic=self.carries_periodic(), **bl)
             if self._cov is not None:
                 self._problem.set_T(self._transform(self._cov))
             if self._state is not None:      # re-point the state at the new problem
@@ -169,6 +170,13 @@ class OracleEngine:
             if self.carries_modes() and s.step > 0:
                 out["amode"] = s.amode.copy()
         return out
+
+    def carries_periodic(self):
+        """The engine's rule (mcmc_hip_incremental_carries_periodic): one mode with 1..8 periodic
+        parameters on Metropolis steps without emitted rows runs on step_inc_periodic_kernel."""
+        drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
+        n_per = 0 if self._prior is None or self._prior[3] is None else int(self._prior[3].sum())
+        return bool(self.incremental and self.K == 1 and 1 <= n_per <= 8 and not drag and self.cap == 0)
 
     def carries_modes(self):
         """The engine's rule (mcmc_hip_incremental_carries_modes): step_inc_mix_kernel serves 2..4

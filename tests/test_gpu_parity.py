@@ -84,7 +84,7 @@ def make_pair(d, W, gs, K=1, kinds=None, a=None, b=None, periodic=None, seed=7, 
                      derived=None if own_constants else eng.derived_constants(),
                      incremental=incremental,
                      # (which mixtures carry the log-density of every mode is the engine's rule)
-                     carry_modes=eng.carries_modes())
+                     carry_modes=eng.carries_modes(), carry_periodic=eng.carries_periodic())
     m0 = means[0] if K else np.full(d, 0.5)
     s0 = np.sqrt(np.diag(covs[0])) if K else np.full(d, 0.1)
     x0 = np.clip(m0 + rng.normal(size=(W, d)) * s0, 1e-3, 1 - 1e-3)

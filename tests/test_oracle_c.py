@@ -643,7 +643,7 @@ def test_paired_variates_follow_the_reference_laws():
 
 
 @pytest.mark.parametrize("blocked", [False, True])
-def test_incremental_with_periodic_parameters_is_the_same_sampler(blocked):
+def test_incremental_with_periodic_parameters_is_the_same_sampler(blocked, carry=False):
     """Periodic parameters (prior.py:675) in incremental mode: the coordinate is the wrapped one,
     and a wrap that changes the winding number moves the carried residual by the wrap times a
     column of L^-1.  With un-paired variates the incremental and the from-scratch run take the
@@ -664,8 +664,10 @@ def test_incremental_with_periodic_parameters_is_the_same_sampler(blocked):
         kw = dict(T=O.proposal_transform(cov, 2.4))
     mk = lambda inc, paired: O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, periodic=periodic,
                                        means=mean, covs=cov, group_size=64, seed=9,
-                                       incremental=inc, paired_variates=paired, **kw)
+                                       incremental=inc, paired_variates=paired,
+                                       carry_periodic=carry and inc, **kw)
     full, inc = mk(False, False), mk(True, False)
+    assert inc.c.carry_periodic == int(carry)
     x0 = (mean + rng.normal(size=(128, d)) * 0.05) % 1.0
     a, b = O.State(full, x0), O.State(inc, x0)
     wraps = 0
@@ -685,6 +687,16 @@ def test_incremental_with_periodic_parameters_is_the_same_sampler(blocked):
     c.run(900, n_threads=4)
     lp, ll = full.evaluate(c.x)
     np.testing.assert_allclose(c.logpost, lp + ll, rtol=2e-13, atol=1e-9)
+
+
+@pytest.mark.parametrize("blocked", [False, True])
+def test_incremental_periodic_with_the_carried_loglikelihood(blocked):
+    """Round 5 (step_inc_periodic_kernel): a periodic coordinate is wrapped only where the trial
+    leaves [lo, hi) and the log-likelihood is carried, re-summed from the moved residual at a step
+    that wraps -- still the same sampler as the from-scratch run on a target at the seam (same
+    decisions, coordinates to rounding: inside the interval the from-scratch run passes x through
+    ((x - a) / (b - a)) % 1 * (b - a) + a, prior.py:675, which returns x up to its own rounding)."""
+    test_incremental_with_periodic_parameters_is_the_same_sampler(blocked, carry=True)
 
 
 @pytest.mark.parametrize("seed", list(range(8)))
