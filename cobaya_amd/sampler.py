@@ -202,6 +202,7 @@ class EnsembleMCMC:
     fallback_covmat_scale = 4.0  # sampler.py:474
     _LoggedError = LoggedError   # the hosted class raises cobaya.log.LoggedError instead
     _engine_factory = staticmethod(Engine)  # the seam to libmcmc_hip.so (tests swap it)
+    MAX_DIM = 128    # capi.hip: kMaxDimBig (mixtures: at most 16 modes, model.py)
 
     # ------------------------------------------------------------------ host seams
     def _fail(self, msg, *args, cause=None):
@@ -259,6 +260,13 @@ class EnsembleMCMC:
             self.Rminus1_last = np.inf
         spec = self.spec
         d = spec.d
+        if d > self.MAX_DIM:
+            # (fails here, with the reason, instead of at mcmc_hip_create's "no kernels compiled":
+            # the reference has no cap, proposal.py:96-201)
+            self._fail("mcmc_hip samples at most %d parameters (this model has %d): a walker group's "
+                       "Haar basis of d x d doubles is built in the 160 KiB of LDS of one compute "
+                       "unit.  Fix or marginalise parameters, or use the reference sampler `mcmc` "
+                       "for this model.", self.MAX_DIM, d)
         if self.temperature is None:
             self.temperature = 1
         if self.temperature < 1:

@@ -784,3 +784,24 @@ def test_bench_certificate_gates_acceptance_and_posterior():
     xs = np.concatenate((x[:8192], x[8192:] + (mu2 - mean)))
     c2 = bench.certify(info2, xs, accepted=0.3e6, evals=1e6)
     assert c2["ok"] and not c2["posterior_check"]["gated"] and c2["posterior_check"]["KL"] < 0.01
+
+
+def test_caps_fail_early_and_say_why():
+    """VERDICT r4 "Next round" 9: what the engine cannot serve is refused at initialisation with the
+    reason -- more than 128 parameters (the reference has no cap, proposal.py:96-201), more than 16
+    modes (gaussian_mixture.py:45-136) -- not at the first launch."""
+    from cobaya_amd.model import ProblemSpec, UnsupportedModel
+    from cobaya_amd.sampler import LoggedError, MCMCHip
+    d = 130
+    info = {"likelihood": {"gaussian_mixture": {"means": [np.full(d, 0.5)], "covs": [np.eye(d) * 0.01],
+                                                "input_params_prefix": "a_"}},
+            "params": {f"a__{i}": {"prior": {"min": 0, "max": 1}} for i in range(d)}}
+    with pytest.raises(LoggedError, match="at most 128 parameters"):
+        MCMCHip({"n_walkers": 128, "group_size": 64}, ProblemSpec.from_info(info))
+    d = 3
+    info = {"likelihood": {"gaussian_mixture": {"means": [np.full(d, 0.1 + 0.04 * k) for k in range(17)],
+                                                "covs": [np.eye(d) * 0.01] * 17,
+                                                "input_params_prefix": "a_"}},
+            "params": {f"a__{i}": {"prior": {"min": 0, "max": 1}} for i in range(d)}}
+    with pytest.raises(UnsupportedModel, match="17 modes"):
+        ProblemSpec.from_info(info)

@@ -16,8 +16,8 @@
 #                              ("cur" = the built libmcmc_hip.so), alternated REPS (3) times
 #   abpmc "<v1 ..>" <kernel-like> [bench args]   SQ + LDS counters of one kernel for those builds
 #   pmc <kernel-like> "<counters>" -- <command>  one PMC pass of any command, per-kernel averages
-#   timeline [bench args]      start / duration / gap of every kernel and copy around the middle
-#                              step kernel of a bench run
+#   timeline [bench args | -- <command>]   start / duration / gap of every kernel and copy around
+#                              the middle step kernel of a bench run (or of any command)
 #   py <script> [args]         python <script> (tools/*.py benches) -> stdout
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -150,7 +150,12 @@ pmc)
   find $O -name "*.db" -delete ;;
 timeline)
   O=gpurun_out/timeline; rm -rf $O; mkdir -p $O
-  timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $O/prof -o t -- python bench.py --no-variants --no-cpu-baseline --cross-check-seconds 0 "$@" > $O/bench.json 2> $O/bench.err
+  if [ "$1" = "--" ]; then   # timeline -- <any command>
+    shift
+    timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $O/prof -o t -- "$@" > $O/cmd.log 2>&1
+  else
+    timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $O/prof -o t -- python bench.py --no-variants --no-cpu-baseline --cross-check-seconds 0 "$@" > $O/bench.json 2> $O/bench.err
+  fi
   python - "$O" <<'PY'
 import glob, sqlite3, sys
 O = sys.argv[1]
@@ -162,7 +167,7 @@ except Exception as e:
     print("no memory_copies view:", e); mc = []
 ev = sorted(rows + mc)
 idx = [i for i, r in enumerate(ev) if "step_" in r[2] or "pl_fused" in r[2]]
-i0, i1 = idx[len(idx) // 2], idx[min(len(idx) // 2 + 5, len(idx) - 1)]
+i0, i1 = idx[len(idx) // 2], idx[min(len(idx) // 2 + int(__import__("os").environ.get("TL_STEPS", "5")), len(idx) - 1)]
 t0 = ev[i0][0]
 with open(f"{O}/timeline.txt", "w") as f:
     for r in ev[i0:i1 + 1]:

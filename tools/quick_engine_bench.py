@@ -15,7 +15,8 @@ if d in (30, 100):
     mean, cov = g[f"mean_d{d}"], g[f"cov_d{d}"]
 else:
     rng = np.random.default_rng(d); A = rng.normal(size=(d, d)); cov = (A @ A.T / d + np.eye(d)) * 1e-3; mean = np.full(d, 0.5)
-eng = E.Engine(d, W, group_size=gs, seed=1)
+# QB_OWN=1: shared_basis False (a Haar basis per walker: the to-the-letter control)
+eng = E.Engine(d, W, group_size=gs, seed=1, shared_basis=not os.environ.get("QB_OWN"))
 n_norm = int(os.environ.get("QB_NORM", "0"))  # the last n_norm priors normal (config-5 shape)
 sd = np.sqrt(np.diag(cov))
 kinds = [0] * (d - n_norm) + [1] * n_norm
