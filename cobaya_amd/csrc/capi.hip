@@ -1962,8 +1962,14 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         bool anchor = false;   // y is refreshed from x before (or, step_inc_kernel: in) this launch
         bool refresh_in_kernel = false;
         if (!h->y_valid || h->step % P.R == 0) {
-            if (P.fold) {
-                refresh_in_kernel = true;   // (round 5: whiten_state_kernel folded into the launch)
+            if (P.fold && done > 0) {
+                // (round 5) a launch INSIDE a call's set of directions refreshes y itself: nothing
+                // stands between it and the launch before.  The first launch of a call keeps the
+                // separate kernel: there the main stream waits for the second one (Haar bases,
+                // whitened columns) anyway, and the refresh inside the step kernel -- two barriers
+                // and a memory round trip per eight dimensions before the first chunk can be
+                // staged -- cost it 7 us (same-box A/B: whole job -0.5 %)
+                refresh_in_kernel = true;
             } else {
                 HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
                                                         d, h->W, K, h->stream));

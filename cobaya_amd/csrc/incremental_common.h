@@ -137,7 +137,10 @@ __device__ __forceinline__ lds_doubles relaunder(const double* p)
 // 32 c bytes apart modulo 128, so the eight lanes of a group cover the window exactly once.  The
 // reads (one ds_read_b128 per step, the same 16 bytes in the four lanes of a walker, 16
 // consecutive pairs per wave) are conflict-free with either stride.
-constexpr int kStagedRow = 17;                     // pairs per row (16 walkers + 1 of padding)
+#ifndef MCMC_STAGED_ROW
+#define MCMC_STAGED_ROW 17
+#endif
+constexpr int kStagedRow = MCMC_STAGED_ROW;        // pairs per row (16 walkers + 1 of padding)
 constexpr int kStagedPairs = 4 * 8 * kStagedRow;   // 8.5 KB per workgroup of four waves
 struct StagedVariates {
     unsigned base, off;

@@ -132,7 +132,11 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     };
     // (a launch that refreshes y itself uses the chunk buffers as scratch first: its first
     // chunk is staged behind that, below)
+#ifdef MCMC_EXP_NO_FOLD
+    const bool refresh_y = false;   // (timing experiment: the in-kernel refresh compiled out)
+#else
     const bool refresh_y = (a.anchor & 2) != 0;   // wave-uniform
+#endif
     if (!refresh_y) stage(0);
     MCMC_EXP_BLOCK_BEGIN();
 
@@ -167,6 +171,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
             sNM[i] = a.prior[4 * dpad + i];
         }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
+    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
     if (refresh_y) {
         // y = L^-1 (x - mu) from the walker's x (round 5: whiten_state_kernel folded into the
         // launch that needs it -- one kernel and ~17 us less on the main stream between two step
@@ -176,33 +181,36 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         // j = 4 kk + c of the lane takes fma(L^-1[j][i], dev_i, y_j) -- for i > j the factor is
         // the exact +0.0 above the diagonal (tri_inverse_lower), which leaves the chain where it
         // ended at i = j: bit for bit orc_whiten's ascending chain over i <= j.
+        // L^-1 comes through LDS eight columns at a time (all 256 threads fill a [4 DQ][8] tile,
+        // every lane then reads its rows there): read per lane straight from memory, the rolled
+        // loop waited for one memory round trip per dimension -- +40 us per launch at d = 30, +260
+        // at d = 100, more than the kernel it replaced (same-box A/B, profiles/r05_launch_gap.txt).
         static_assert(C >= 16, "the chunk buffers hold the deviations of the workgroup's 64 walkers");
+        constexpr int TW = 8;
+        static_assert(sizeof(pair_t) * kStagedPairs >= sizeof(double) * dpad * TW, "the tile fits sRE");
         double* const sdev = (double*)sVU + (size_t)(tid >> 2) * dpad;   // this walker's deviations
+        double* const tile = (double*)sRE;   // [dpad][TW] (the staged variates are not in use yet)
 #pragma unroll
         for (int kk = 0; kk < DQ; ++kk) {
             const int i = 4 * kk + c;
             sdev[i] = i < d ? x[kk] - a.mean[i] : 0.0;
             y[kk] = 0.0;
         }
-        asm volatile("" ::: "memory");
-        // (the lane's rows of L^-1 as 32-bit element offsets: a padded row reads row d - 1 and
-        // is zeroed below)
-        const int row0 = (4 * 0 + c < d ? c : d - 1) * d;
-        const lds_doubles pdev = relaunder(sdev);
-#pragma unroll 1
-        for (int i = 0; i < d; ++i) {
-            const double dv = pdev[i];
-            const double* __restrict__ li = a.Lrow + i;
+        for (int i0 = 0; i0 < d; i0 += TW) {
+            __syncthreads();   // (the previous tile has been used; the first: sdev is written)
+            for (int e = tid; e < dpad * TW; e += 256) {
+                const int j = e / TW, i = i0 + e % TW;
+                tile[e] = (j < d && i < d) ? a.Lrow[(size_t)j * d + i] : 0.0;
+            }
+            __syncthreads();
+            const lds_doubles pt = relaunder(tile + c * TW), pd = relaunder(sdev + i0);
 #pragma unroll
-            for (int kk = 0; kk < DQ; ++kk) {
-                const int j = 4 * kk + c;
-                const int off = kk == 0 ? row0 : (j < d ? j : d - 1) * d;
-                y[kk] = fma(li[off], dv, y[kk]);
+            for (int ii = 0; ii < TW; ++ii) {
+                const double dv = pd[ii];   // (beyond d: 0, and the tile's column is 0)
+#pragma unroll
+                for (int kk = 0; kk < DQ; ++kk) y[kk] = fma(pt[4 * kk * TW + ii], dv, y[kk]);
             }
         }
-#pragma unroll
-        for (int kk = 0; kk < DQ; ++kk)
-            if (4 * kk + c >= d) y[kk] = 0.0;
         __syncthreads();   // every wave is done with its scratch: the first chunk may land
         stage(0);
     }
@@ -233,7 +241,6 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     __syncthreads();
     bool burning = lanes(burn > 0) != 0ull;   // wave-uniform
     unsigned long long cur_oct = ~0ull;
-    __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
     StagedVariates sv;
     sv.init(sRE, wave, lane);
     const int hw_slot = hw_wave_slot();

@@ -153,7 +153,15 @@ def load_library(path: str | None = None):
                           "(hipcc, gfx950). mcmc_hip has no CPU fallback.")
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
-        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        try:
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+        except AttributeError:
+            # developer A/B runs against an OLDER build of the library (MCMC_HIP_LIB=... with
+            # MCMC_HIP_LIB_COMPAT=1, tools/gpu.sh ab): an entry point it predates answers 0 / "no"
+            if not (os.environ.get("MCMC_HIP_LIB_COMPAT") and os.environ.get("MCMC_HIP_LIB")):
+                raise
+            setattr(lib, name, C.CFUNCTYPE(restype, *argtypes)(lambda *a: 0))
+            continue
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib

@@ -93,10 +93,13 @@ def test_config2_bench_launches_bit_exact(offset):
     assert prob.refresh_every == spl           # a bench launch = one re-anchoring interval
     _compare(eng, st, "initial evaluation")
     for launch in range(3):
-        eng.step(spl)
+        # (the last call holds TWO launches: their directions are formed as one set and the
+        # second launch refreshes y = L^-1 (x - mu) itself, inside step_inc_kernel)
+        n = spl if launch < 2 else 2 * spl
+        eng.step(n)
         eng.accumulate_moments()               # (the snapshot kernels between two launches)
         eng.sync()
-        st.run(spl, walker0=offset, n_threads=threads)
+        st.run(n, walker0=offset, n_threads=threads)
         s = _compare(eng, st, f"launch {launch}")
         kernel = eng.last_step_kernel()
         assert "step_inc_kernel" in kernel, kernel
