@@ -2052,7 +2052,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             // transform that set_proposal_cov / the device checkpoint writes in between.
             // Before, a refreshed proposal made the set prepared here stale and the next call
             // recomputed it on the MAIN stream: 141 us instead of 72 between two step kernels
-            // after every learn checkpoint (tools/gpu_r4_timeline.sh).
+            // after every learn checkpoint (tools/gpu.sh timeline, round 4).
             if (left > span.n || !h->lazy_dirs) {
                 HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
                 const int rc = make_directions(h, P, nxt, N, h->stream2);

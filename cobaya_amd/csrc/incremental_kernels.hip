@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     constexpr bool KEEP = MCMC_EXP_KEEP(inc_keep_pairs(DQ, MODE));
     // pairs fetched ahead of the trial arithmetic, PIPE at a time.  The kernels at three / four waves
     // per SIMD got it in round 4, once the staged variates had freed 8 registers: measured over
-    // d = 4 ... 52 (tools/gpu_r4_k.sh, same box): dq 5 ... 12 gain 0.2 - 2 % (MODE 1 at d = 30: 3.9 %),
+    // d = 4 ... 52 (round-4 sweep, same box): dq 5 ... 12 gain 0.2 - 2 % (MODE 1 at d = 30: 3.9 %),
     // dq <= 4 nothing, dq = 13 at four waves (MODE 1 / 2) LOSES 5 % to spills
     constexpr int PIPE = KEEP ? 0
         : MCMC_EXP_PIPE(inc_min_waves(DQ, MODE) <= 2 ? 4 : (DQ >= 5 && DQ <= 12) ? 4 : 0);

@@ -763,7 +763,7 @@ class EnsembleMCMC:
         # A pending checkpoint is processed FIRST, right behind the launch just queued: its
         # statistics came back long ago, and a refreshed proposal is then uploaded ahead of the
         # moment snapshot -- the directions of the next launch, formed on the second stream
-        # behind that upload, start at once when this launch ends (tools/gpu_r4_timeline.sh:
+        # behind that upload, start at once when this launch ends (tools/gpu.sh timeline, round 4:
         # 127 -> 85 us between two step kernels after a learn checkpoint)
         if self._ckpt_pending:
             self._ckpt_age += 1

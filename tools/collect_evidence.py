@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/final (written by tools/gpu_final.sh on the GPU box) into the committed
+"""Turns gpurun_out/final (written by `tools/gpu.sh evidence` on the GPU box) into the committed
 evidence under profiles/: <rnd>_bench.json, <rnd>_gpu_tests.log, <rnd>_kernel_stats.txt,
 <rnd>_pmc.txt and an entry of traffic.json (per-launch HBM bytes and VALU instructions of the
 dominant kernel, which bench.py quotes in its roofline block).
 
     python tools/collect_evidence.py [round-prefix, default r01] [source dir under gpurun_out,
-                                      default final; e.g. `r01_d100 d100` after tools/gpu_d100.sh]
+                                      default final; e.g. `r01_d100 d100` after a run into that directory]
 """
 import json
 import os
