@@ -298,6 +298,47 @@ __device__ __forceinline__ double neg_log_short(uint32_t n, int b, short_log_tab
     return fma((double)(b - e), LN2, t.y) - p;
 }
 
+// Table-driven log and exp of the incremental mixtures' log-sum-exp (round 5; oracle: orc_dlog_tab,
+// orc_dexp_tab, where the error bounds are stated).  No division; the logarithm shares the table of
+// the short-argument one, the exponential has 2^(j / 64) in 512 bytes of LDS (exp_tab_load).
+typedef const double __attribute__((address_space(3))) * exp_tab;
+static __device__ const double kExp64[64] = EXP64_TABLE;
+
+__device__ __forceinline__ exp_tab exp_tab_load(double* lds_table)
+{
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) lds_table[i] = kExp64[i];
+    return (exp_tab)(unsigned long long)(unsigned)(unsigned long long)lds_table;
+}
+
+__device__ __forceinline__ double dlog_tab(double x, short_log_tab tab)
+{
+    constexpr double LN2 = 6.93147180559945286227e-01, C2 = -0.5, C3 = 3.33333333333333314830e-01,
+                     C4 = -0.25, C5 = 2.00000000000000011102e-01, C6 = -1.66666666666666657415e-01;
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const unsigned j = ((unsigned)__double2hiint(m) >> 13) & 0x7Fu;
+    const dpair_t t = tab[j];
+    const double f = fma(m, t.x, -1.0);
+    const double p = f * fma(f, fma(f, fma(f, fma(f, fma(f, C6, C5), C4), C3), C2), 1.0);
+    return p - fma((double)(-e), LN2, t.y);
+}
+
+__device__ __forceinline__ double dexp_tab(double x, exp_tab tab)
+{
+    constexpr double C2 = 0.5, C3 = 1.66666666666666657415e-01, C4 = 4.16666666666666643537e-02,
+                     C5 = 8.33333333333333321769e-03;
+    const unsigned long long in_range = lanes(x >= -708.0);   // else 0 (also for NaN)
+    const double kf = rint(x * EXP64_INV_LN2);
+    double r = fma(-kf, EXP64_LN2_HI, x);
+    r = fma(-kf, EXP64_LN2_LO, r);
+    const double p = r * fma(r, fma(r, fma(r, fma(r, C5, C4), C3), C2), 1.0);
+    // (outside the range kf is not an int: the index is masked, the result discarded)
+    const int k = (int)kf;
+    const double T = tab[k & 63];
+    const double y = fma(T, p, T);
+    return sel(in_range, __longlong_as_double(__double_as_longlong(y) + ((long long)(k >> 6) << 52)), 0.0);
+}
+
 // The variates of TWO consecutive steps from one Philox block (incremental kernels, plain steps;
 // oracle: walker_variates_pair): block (walker, kStreamStep | 0x4000, P), P = step >> 1; half
 // h = step & 1 uses the words a = w[2h], b = w[2h+1]: sign = bit 31 of a (set = positive),

@@ -50,7 +50,7 @@ struct AnyGeom {
     int lcols;   // the columns of L_k^-1 of the periodic dimensions sit in LDS (else: read from HBM)
     size_t dynamic;
 };
-constexpr size_t kAnyStatic = 16 * 128 * 2 + 8 * 128 + 4 * 128 + 16 * SHORT_LOG_TABLE_SIZE + 16 * kMaxModes + 256 +
+constexpr size_t kAnyStatic = 16 * 128 * 2 + 8 * 128 + 4 * 128 + 16 * SHORT_LOG_TABLE_SIZE + 16 * kMaxModes + 256 + 512 +
                               16 * kStagedPairs;   // (+ the staged variates, StagedVariates)
 constexpr size_t kLdsPerCu = 160u << 10;
 constexpr size_t kLdsPerWg = 160u << 10;   // (a single workgroup may hold all of it)
@@ -199,6 +199,8 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
     const short_log_tab slog = short_log_load(short_log_lds);
+    __shared__ double exp64_lds[64];   // 2^(j / 64): the log-sum-exp's table-driven exponential
+    const exp_tab etab = exp_tab_load(exp64_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned long long cur_oct = ~0ull;
@@ -326,11 +328,11 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
             if (K > 1) {
                 // one exponential per (walker, mode): lane class c takes the modes k = c mod 4
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (int k = c; k < K; k += 4) sA[k * 64 + lane] = dexp(sA[k * 64 + lane] - amax);
+                for (int k = c; k < K; k += 4) sA[k * 64 + lane] = dexp_tab(sA[k * 64 + lane] - amax, etab);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 double Ssum = 0.0;
                 for (int k = 0; k < K; ++k) Ssum = fma(sMode[k].y, sA[k * 64 + (lane & ~3) + (k & 3)], Ssum);
-                ll = dlog(Ssum) + amax;
+                ll = dlog_tab(Ssum, slog) + amax;
             }
             const unsigned long long inside_m = quad_all_mask(inb);
             const double lp = s.uniform_logp + (a.has_norm ? quad_sum(sc) : 0.0);
@@ -563,6 +565,8 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
     __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
     const short_log_tab slog = short_log_load(short_log_lds);
+    __shared__ double exp64_lds[64];   // 2^(j / 64): the log-sum-exp's table-driven exponential
+    const exp_tab etab = exp_tab_load(exp64_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long class1 = lanes(c == 1), class2 = lanes(c == 2), class3 = lanes(c == 3);
@@ -706,7 +710,7 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
                         if (4 * j + 1 < KM) mine = sel(class1, ak[4 * j + 1 < KM ? 4 * j + 1 : 0], mine);
                         if (4 * j + 2 < KM) mine = sel(class2, ak[4 * j + 2 < KM ? 4 * j + 2 : 0], mine);
                         if (4 * j + 3 < KM) mine = sel(class3, ak[4 * j + 3 < KM ? 4 * j + 3 : 0], mine);
-                        e[j] = dexp(mine - amax);
+                        e[j] = dexp_tab(mine - amax, etab);
                     }
                 double Ssum = 0.0;
 #pragma unroll
@@ -716,7 +720,7 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
                     if (4 * j + 2 < K) Ssum = fma(sMode[4 * j + 2].y, quad_perm<0xAA>(e[j]), Ssum);
                     if (4 * j + 3 < K) Ssum = fma(sMode[4 * j + 3].y, quad_perm<0xFF>(e[j]), Ssum);
                 }
-                ll = dlog(Ssum) + amax;
+                ll = dlog_tab(Ssum, slog) + amax;
             }
             const double lt = lp + ll;
             const double delta = (lpost - lt) / s.temperature;   // (T = 1: x / 1.0 == x)

@@ -1066,6 +1066,8 @@ step_inc_mix_kernel(const IncStepArgs a)
     const int lim10 = mt10 < 2.0e9 ? (int)floor(mt10) : 0x7fffffff;
     __shared__ dpair_t short_log_lds[SHORT_LOG_TABLE_SIZE];
     const short_log_tab slog = short_log_load(short_log_lds);
+    __shared__ double exp64_lds[64];   // 2^(j / 64): the log-sum-exp's table-driven exponential
+    const exp_tab etab = exp_tab_load(exp64_lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long class1 = lanes(c == 1), class2 = lanes(c == 2), class3 = lanes(c == 3);
@@ -1080,12 +1082,12 @@ step_inc_mix_kernel(const IncStepArgs a)
         if (KM > 1) mine = sel(class1, ak[1], mine);
         if (KM > 2) mine = sel(class2, ak[2 < KM ? 2 : 0], mine);
         if (KM > 3) mine = sel(class3, ak[3 < KM ? 3 : 0], mine);
-        const double e_mine = dexp(mine - amax);
+        const double e_mine = dexp_tab(mine - amax, etab);
         double Ssum = fma(wk[0], quad_perm<0x00>(e_mine), 0.0);
         if (KM > 1) Ssum = fma(wk[1], quad_perm<0x55>(e_mine), Ssum);
         if (KM > 2) Ssum = fma(wk[2 < KM ? 2 : 0], quad_perm<0xAA>(e_mine), Ssum);
         if (KM > 3) Ssum = fma(wk[3 < KM ? 3 : 0], quad_perm<0xFF>(e_mine), Ssum);
-        return dlog(Ssum) + amax;
+        return dlog_tab(Ssum, slog) + amax;
     };
     // the carried log-density of every mode (the same value in the four lanes of a walker)
     double am[KM];

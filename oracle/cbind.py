@@ -93,6 +93,10 @@ def lib():
         L.orc_dlog.argtypes = [C.c_double]
         L.orc_dexp.restype = C.c_double
         L.orc_dexp.argtypes = [C.c_double]
+        L.orc_dlog_tab.restype = C.c_double
+        L.orc_dlog_tab.argtypes = [C.c_double]
+        L.orc_dexp_tab.restype = C.c_double
+        L.orc_dexp_tab.argtypes = [C.c_double]
         L.orc_neg_log_short.restype = C.c_double
         L.orc_neg_log_short.argtypes = [C.c_uint32, C.c_int32]
         L.orc_pair_variates.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, c_double_p, c_double_p]
@@ -162,6 +166,15 @@ def dlog(x):
 
 def dexp(x):
     return lib().orc_dexp(float(x))
+
+
+def dlog_tab(x):
+    """The table-driven log of the incremental mixtures' log-sum-exp (orc_dlog_tab)."""
+    return lib().orc_dlog_tab(float(x))
+
+
+def dexp_tab(x):
+    return lib().orc_dexp_tab(float(x))
 
 
 def neg_log_short(n, b):

@@ -114,6 +114,45 @@ double orc_neg_log_short(uint32_t n, int32_t b)
     return fma((double)(b - e), LN2, short_log_table[j][1]) - p;
 }
 
+/* Table-driven log and exp of the INCREMENTAL mixtures' log-sum-exp (round 5: dlog_tab / dexp_tab in
+ * det_math.h; the from-scratch evaluator keeps orc_dlog / orc_dexp, pinned by golden G5).  No
+ * division: a K = 2 step spent ~75 of its ~370 issue slots in the two fdlibm routines.
+ *   log x, x > 0 normal: x = m 2^e, m in [1/2, 1); j = top seven fraction bits of m;
+ *     f = fma(m, RC_j, -1), |f| <= 2^-8 (one rounding: 2^-61 absolute); log x =
+ *     log1p(f) - fma(-e, ln 2, LRC_j), log1p by its Taylor polynomial to f^6 (as orc_neg_log_short).
+ *     Absolute error < 3e-16 + 1 ulp: what a log-sum-exp of terms in [w_max, 1] needs.
+ *   exp x, x >= -708 (else 0): k = rint(x 64 / ln 2), r = x - k ln 2 / 64 (two fmas, |r| <= 0.0055),
+ *     exp r - 1 = r (1 + r (1/2 + r (1/6 + r (1/24 + r / 120)))) (next term 3e-17), T_j = 2^(j / 64)
+ *     with j = k mod 64 from the table, result fma(T_j, p, T_j) 2^(k div 64).  Within 2 ulp. */
+static const double exp64_table[64] = EXP64_TABLE;
+double orc_dlog_tab(double x)
+{
+    static const double LN2 = 6.93147180559945286227e-01, C2 = -0.5,
+        C3 = 3.33333333333333314830e-01, C4 = -0.25, C5 = 2.00000000000000011102e-01,
+        C6 = -1.66666666666666657415e-01;
+    int e;
+    const double m = frexp(x, &e);
+    const unsigned j = (unsigned)(d2bits(m) >> 45) & 0x7Fu;
+    const double f = fma(m, short_log_table[j][0], -1.0);
+    const double p = f * fma(f, fma(f, fma(f, fma(f, fma(f, C6, C5), C4), C3), C2), 1.0);
+    return p - fma((double)(-e), LN2, short_log_table[j][1]);
+}
+
+double orc_dexp_tab(double x)
+{
+    static const double C2 = 0.5, C3 = 1.66666666666666657415e-01, C4 = 4.16666666666666643537e-02,
+        C5 = 8.33333333333333321769e-03;
+    if (!(x >= -708.0)) return 0.0;
+    const double kf = rint(x * EXP64_INV_LN2);
+    double r = fma(-kf, EXP64_LN2_HI, x);
+    r = fma(-kf, EXP64_LN2_LO, r);
+    const double p = r * fma(r, fma(r, fma(r, fma(r, C5, C4), C3), C2), 1.0);
+    const int k = (int)kf;
+    const double T = exp64_table[k & 63];
+    const double y = fma(T, p, T);
+    return bits2d(d2bits(y) + ((uint64_t)(int64_t)(k >> 6) << 52));
+}
+
 /* exp(x) for x <= 0 (mixture log-sum-exp terms); fdlibm e_exp.c reduction/polynomial.
  * x < -708 returns 0 (the term is below 1e-307 of the leading one). */
 double orc_dexp(double x)
@@ -803,8 +842,8 @@ static inline double mixture_lse(const orc_problem* p, const double* a)
     double amax = -INFINITY, S = 0.0;
     for (int k = 0; k < K; ++k)
         if (a[k] > amax) amax = a[k];
-    for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp(a[k] - amax), S);
-    return orc_dlog(S) + amax;
+    for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp_tab(a[k] - amax), S);
+    return orc_dlog_tab(S) + amax;
 }
 
 void orc_anchor_modes(const orc_problem* p, orc_state* st, int w)
@@ -910,9 +949,10 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
         if (carry_k) { /* (formed above) */ }
         else if (K == 1) ll = a[0];
         else {
+            /* (incremental mode: the table-driven exp / log, as in mixture_lse) */
             double S = 0.0;
-            for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp(a[k] - amax), S);
-            ll = orc_dlog(S) + amax;
+            for (int k = 0; k < K; ++k) S = fma(p->weight[k], orc_dexp_tab(a[k] - amax), S);
+            ll = orc_dlog_tab(S) + amax;
         }
         lt = lp + ll;
     }

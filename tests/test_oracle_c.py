@@ -1069,3 +1069,27 @@ def test_run_is_invariant_to_the_thread_split(golden, incremental):
         st.run(d, walker0=(3 + g) * gs, n_threads=8)
         assert np.array_equal(st.x.view(np.uint64), a.x[g * gs:(g + 1) * gs].view(np.uint64))
         assert np.array_equal(st.weight, a.weight[g * gs:(g + 1) * gs])
+
+
+def test_table_driven_exp_and_log_of_the_log_sum_exp():
+    """Round 5: the incremental mixtures take their log-sum-exp with a table-driven exp and log
+    without divisions (orc_dexp_tab / orc_dlog_tab = dexp_tab / dlog_tab of det_math.h; the tables are
+    generated with 60-digit decimal arithmetic into the ONE header both sides compile).  Against libm:
+    exp within 2 ulp on [-708, 0] (0 below); log within 1 ulp + 3e-16 absolute -- what a sum of
+    weighted terms in [w_max, 1] needs (the logarithm of a number next to 1 is tiny and the bar is
+    absolute there)."""
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([-rng.uniform(0, 40, 6000), -(10 ** rng.uniform(-12, 2.85, 4000)),
+                         [0.0, -1e-300, -707.9, -0.010830424696249145 / 2, -0.0108304246962491]])
+    worst = 0.0
+    for x in xs:
+        got, ref = O.dexp_tab(x), math.exp(x)
+        worst = max(worst, abs(got - ref) / math.ulp(ref))
+    assert worst <= 2.0, worst
+    assert O.dexp_tab(-709.0) == 0.0 and O.dexp_tab(-np.inf) == 0.0 and O.dexp_tab(0.0) == 1.0
+    ys = np.concatenate([rng.uniform(0.01, 1.0, 6000), 10 ** rng.uniform(-300, 300, 3000),
+                         1 - 10 ** rng.uniform(-16, -1, 1000), [1.0, 0.5, 0.25, 2.0, 1e-300]])
+    for y in ys:
+        got, ref = O.dlog_tab(y), math.log(y)
+        assert abs(got - ref) <= 3e-16 + math.ulp(ref), (y, got, ref)
+    assert abs(O.dlog_tab(1.0)) < 1e-16     # (not exactly 0: the bar near 1 is absolute)
