@@ -950,9 +950,23 @@ __global__ void __launch_bounds__(64) whiten_directions_mix_kernel(const IncDirA
     for (int k = 0; k < K; ++k) {
         double* __restrict__ uk = out + (size_t)(1 + k) * dpad;
         for (int j = 0; j < d; ++j) {
-            const double* __restrict__ row = a.Lrow + ((size_t)k * d + j) * d;
             double acc = 0.0;
-            for (int i = 0; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
+            if (d <= 32) {   // (wave-uniform)
+                // the row through the constant address space, eight terms per batch: wide scalar
+                // loads instead of a vector load per element and lane (round 5: 0.150 -> 0.116 ms
+                // per launch at d = 30, K = 2).  Small d only: at d = 128 the rows of four modes
+                // (0.5 MB) thrash the scalar cache and the same change cost 4x (measured)
+                const cdoubles row = (cdoubles)(unsigned long long)(a.Lrow + ((size_t)k * d + j) * d);
+                int i = 0;
+                for (; i + 8 <= j + 1; i += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = fma(row[i + u], sv[(i + u) * 64 + l], acc);
+                }
+                for (; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
+            } else {
+                const double* __restrict__ row = a.Lrow + ((size_t)k * d + j) * d;
+                for (int i = 0; i <= j; ++i) acc = fma(row[i], sv[i * 64 + l], acc);
+            }
             uk[j] = acc;
         }
         for (int j = d; j < dpad; ++j) uk[j] = 0.0;
