@@ -1409,3 +1409,38 @@ def test_device_checkpoint_payload_read_out():
         np.testing.assert_allclose(cov_dev, cov_host, rtol=1e-9, atol=1e-18)
         acc_last, steps_last = c["accepted"], steps
     eng.close()
+
+
+@pytest.mark.parametrize("d,W,gs,kw", [
+    (2, 256, 64, {}), (7, 256, 64, {}), (30, 512, 256, {"basis_group_size": 512}),
+    (48, 256, 64, {}), (52, 256, 64, {}), (56, 256, 128, {}), (100, 256, 64, {}),
+    (104, 128, 64, {}), (128, 128, 64, {}),
+    # normal priors (MODE 2), bounds that differ (MODE 1), a temperature
+    (27, 256, 64, dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.25] * 21)),
+    (13, 256, 64, dict(a=[-0.25 * (i % 3) for i in range(13)], b=[1.0 + 0.5 * (i % 2) for i in range(13)],
+                       T=1.4)),
+    # parameter blocks with a one-parameter block; emitted rows
+    (12, 256, 64, {"blocks": [[0, 1, 2], [3], list(range(4, 12))], "over": [1, 2, 3]}),
+    (30, 256, 64, {"cap": 400})])
+def test_calls_of_several_launches_refresh_y_inside_the_step_kernel(d, W, gs, kw):
+    """Round 5 (capi.hip plan_span, step_inc_kernel `anchor & 2`): a call that spans several refresh
+    intervals forms its directions as ONE set and every launch after the first refreshes
+    y = L^-1 (x - mu) itself -- deviations and eight-column tiles of L^-1 through LDS, the same
+    ascending chains as whiten_state_kernel -- before it re-anchors the carried log-likelihood.
+    Every padded dimension dq = 1 ... 32 class, every prior mode, blocks and emitted rows: bit for
+    bit the oracle's, the carried residual included."""
+    kw = dict(kw)
+    cap = kw.pop("cap", 0)
+    eng, prob, st = make_pair(d, W, gs, incremental=True, cap=cap, max_tries=1e9, **kw)
+    R = prob.refresh_every
+    for n in (3, 3 * R + 5, 2 * R):      # launches cut inside the call at the multiples of R
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        if cap:
+            assert_bit_equal(eng.drain_samples(), st.drain(), "rows")
+        compare_state(eng, st)
+        assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residual")
+    assert "step_inc_kernel" in eng.last_step_kernel()
+    assert eng.counters()["accepted"] == int(st.n_accept.sum())
+    eng.close()
