@@ -72,27 +72,38 @@ class SampleCollection:
     def is_tempered(self):
         return self.temperature != 1
 
+    @staticmethod
+    def _unit_temperature_factors(logposts, T):
+        """exp(logp (T - 1) - max over the batch) per sample, for tempered log-posteriors `logposts`
+        (a list of arrays, one per collection): what multiplies a tempered weight to give the
+        weight under the unit-temperature posterior (collection.py:688-731; p**(1/T) was sampled,
+        so the missing factor is p**(1 - 1/T) = exp(T logp_T - logp_T) with logp_T = logp / T).
+        The largest factor of the batch is 1."""
+        if not logposts or all(len(lp) == 0 for lp in logposts):
+            return [np.ones(len(lp)) for lp in logposts]
+        gain = [lp * T - lp for lp in logposts]          # log of the missing factor
+        top = np.max(np.concatenate(logposts))
+        ref = top * T - top
+        return [np.exp(g - ref) for g in gain]
+
     def _detempered_weights(self, with_batch=None):
-        """collection.py:688-731: weights of the unit-temperature posterior, one vector per
-        collection of the batch: w * exp(logp (1 - 1/T)) with logp the untempered
-        log-posterior, normalised by the largest log-posterior of the whole batch."""
-        batch = [self] + list(with_batch or [])
-        temps = [c.temperature for c in batch]
-        if not np.allclose(temps, temps[0]):
-            raise ValueError(f"Temperature inconsistent across the batch: {temps}.")
-        weights = [c.data["weight"].to_numpy(dtype=np.float64) for c in batch]
-        if self.temperature == 1:
-            return weights
-        T = self.temperature
-        tlp = [-c.data["minuslogpost"].to_numpy(dtype=np.float64) for c in batch]
-        mx = np.max(np.concatenate(tlp))
-        max_log_ratio = mx / (1 / T) - mx          # remove_temperature(x, T) = x / (1 / T)
-        return [w * np.exp((lp / (1 / T) - lp) - max_log_ratio) for w, lp in zip(weights, tlp)]
+        """One weight vector per collection of the batch (this one first), as under the
+        unit-temperature posterior; the batch must share one temperature."""
+        colls = [self, *(with_batch or [])]
+        T = float(self.temperature)
+        others = [c.temperature for c in colls]
+        if not np.allclose(others, T):
+            raise ValueError(f"Temperature inconsistent across the batch: {others}.")
+        w = [c.data["weight"].to_numpy(dtype=np.float64) for c in colls]
+        if T == 1:
+            return w
+        lp_T = [-c.data["minuslogpost"].to_numpy(dtype=np.float64) for c in colls]
+        return [wi * f for wi, f in zip(w, self._unit_temperature_factors(lp_T, T))]
 
     def _detempered_minuslogpost(self):
-        """collection.py:733-739."""
-        mlp = self.data["minuslogpost"].to_numpy(dtype=np.float64)
-        return mlp if self.temperature == 1 else -((-mlp) / (1 / self.temperature))
+        """-log-posterior at unit temperature: the stored column is that of p**(1/T)."""
+        col = self.data["minuslogpost"].to_numpy(dtype=np.float64)
+        return col if self.temperature == 1 else col * float(self.temperature)
 
     def _set_data(self, arr):
         self._blocks, self._data = ([arr] if len(arr) else []), None
