@@ -78,7 +78,7 @@ def build(dims=None, jobs=None, verbose=True):
     if extra:
         FLAGS.extend(f for f in extra if f not in FLAGS)
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, h) for h in ("det_math.h", "kernels.h")]
+    hdrs = [os.path.join(CSRC, h) for h in ("det_math.h", "kernels.h", "short_log_table.h")]
     root_hdr = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "mcmc_hip.h")
     wk = os.path.join(CSRC, "walker_kernels.hip")
     capi = os.path.join(CSRC, "capi.hip")
