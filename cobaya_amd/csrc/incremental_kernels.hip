@@ -1014,6 +1014,9 @@ __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
     return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 12 ? 4 : dq * (km + 1) <= 50 ? 2 : 1);
 }
 
+#ifndef MCMC_MIX_FRESH_EPILOGUE
+#define MCMC_MIX_FRESH_EPILOGUE 1
+#endif
 #ifndef MCMC_MIX_ORDERED_READS
 #define MCMC_MIX_ORDERED_READS 0   // 1: the reads of a step are issued plane by plane (fewer registers)
 #endif
@@ -1258,21 +1261,30 @@ step_inc_mix_kernel(const IncStepArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    // (the walker index passes through an empty asm: the addresses of the stores below are then
+    // formed HERE -- else the compiler keeps the (1 + KM) DQ + KM + 7 addresses of the prologue's
+    // loads alive through the whole step loop, ~60 registers at KM = 2, to reuse them)
+#if MCMC_MIX_FRESH_EPILOGUE
+    int we = w;
+    asm volatile("" : "+v"(we));
+#else
+    const int we = w;
+#endif
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
         if (i < d) {
-            s.x[(size_t)i * W + w] = x[kk];
+            s.x[(size_t)i * W + we] = x[kk];
 #pragma unroll
-            for (int k = 0; k < KM; ++k) a.y[((size_t)k * d + i) * W + w] = y[k][kk];
+            for (int k = 0; k < KM; ++k) a.y[((size_t)k * d + i) * W + we] = y[k][kk];
         }
     }
     if (c == 0) {
 #pragma unroll
-        for (int k = 0; k < KM; ++k) a.amode[(size_t)k * W + w] = am[k];
-        s.logpost[w] = lpost; s.logprior[w] = lpri; s.loglike[w] = llik;
-        s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
-        s.n_accept[w] = nacc0 + nacc;
+        for (int k = 0; k < KM; ++k) a.amode[(size_t)k * W + we] = am[k];
+        s.logpost[we] = lpost; s.logprior[we] = lpri; s.loglike[we] = llik;
+        s.weight[we] = wt; s.prior_rej[we] = prej; s.burn_left[we] = burn;
+        s.n_accept[we] = nacc0 + nacc;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
