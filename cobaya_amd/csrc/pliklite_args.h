@@ -38,6 +38,10 @@ struct PlResidualMfmaArgs {
 };
 // pl_fused_kernel: residuals AND the triangular product in one launch; delta never leaves the CU
 constexpr int kPlChunkPairs = 16;   // k-step pairs (= 8 bin tiles = 128 bins) per LDS chunk
+// LDS of a workgroup: two chunks of residuals [pairs][4 walker tiles][64 lanes] x 16 B, then the
+// producers' (dtheta, 1 / A^2) of the set: [4 waves][np + 1][64 lanes] x 16 B (np <= 4)
+constexpr size_t kPlFusedChunkBytes = 2 * (size_t)kPlChunkPairs * 256 * 16;
+constexpr size_t kPlFusedLdsBytes = kPlFusedChunkBytes + 4 * 5 * 1024;
 struct PlFusedArgs {
     const double* trial;   // [d][W]
     const double* theta0;  // [32]

@@ -384,7 +384,36 @@ __global__ void __launch_bounds__(512, 2) pl_chi2_kernel(const PlChi2Args a)
 // the diagonal group, 16 of four walker tiles in each group above --, so the barrier costs
 // nothing but its latency.  The partial sums are the chains p[pos][c] over the groups ascending
 // (oracle: binned_class(R) = (R + shift) mod 8).  The tiles of L^-1 stream from L2 as before,
-// one 16-byte load per half-tile and pair, re-issued right after their use (one pair ahead).
+// one 16-byte load per half-tile and pair, re-issued right after their use (one pair ahead; two
+// from the second chunk on, in the registers of the finished group).
+//
+// Round 5 (tools/pl_clocks.py: the shader clock of every wave at the phase boundaries of a set;
+// profiles/r05_pl_fused_experiments.txt): the kernel lost 22 % of its cycles beside the MFMAs --
+// 0.497 ms per launch -- and most of that in the producers:
+//   * the gathers of dtheta sat in the arm of a conditional: eight branches, eight round trips to
+//     memory in a row per producer call.  Now requested together, ONCE per set (with its first
+//     chunk), and kept in the producing wave's corner of LDS (20 KB beside the 128 KB of residuals);
+//   * (X_b) was requested behind the MFMAs (the compiler had sunk the loads into the conditional
+//     store), one more round trip per pair of tiles; (Bc0, X) are read as 4 x 64 B per tile;
+//   * the older wave of a SIMD produced BEFORE its consumption and the younger behind: the older
+//     is through a chunk first anyway, so the younger produced beside nothing.  Now the other way
+//     round (see the kernel);
+//   * the first chunk of a set was produced with every SIMD idle: it is now produced beside the
+//     last chunk of the set before (the two LDS buffers alternate across sets);
+//   * the operand streams were addressed as (stream base + lane offset) kept in 20 VGPRs; the lane
+//     offset is now laundered per pair-iteration, the position goes into the scalar base.
+// What the register allocator makes of all this decides as much as the design: tools/check_pl_spills.py
+// (and tests/test_host_logic.py) hold the build to MFMA loops without scratch traffic.
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 // a 16-byte load at (wave-uniform base) + (per-lane 32-bit byte offset): global_load_dwordx4 with an
 // SGPR base -- the address costs one VGPR for all the streams of the kernel
 __device__ __forceinline__ double2 ld16(const void* ubase, unsigned voff)
@@ -392,14 +421,35 @@ __device__ __forceinline__ double2 ld16(const void* ubase, unsigned voff)
     return *(const double2*)((const char*)ubase + voff);
 }
 
-#ifndef PL_PRODUCE_TILES
-#define PL_PRODUCE_TILES 2
+// Experiment hooks (tools/exp_pl_variants.sh); the shipped values are the defaults.
+#ifndef PL_DEEP_FROM
+#define PL_DEEP_FROM 1         // operands of L^-1 two pairs ahead of their MFMAs from this chunk on (one before)
 #endif
-#ifndef PL_ORDER_XY
-#define PL_ORDER_XY 1
+#ifndef PL_PRODUCER_PRIO
+#define PL_PRODUCER_PRIO 1     // producers at a raised priority
 #endif
-#ifndef PL_EARLY_PRODUCERS
-#define PL_EARLY_PRODUCERS 1
+#ifndef PL_OLDER_FIRST
+#define PL_OLDER_FIRST 1       // the waves q < 4 at a higher priority than the waves q >= 4 throughout
+#endif
+#ifndef PL_ES_COMPACT
+#define PL_ES_COMPACT 1        // (Bc0, X): the 16 lanes of a class read the same 16 bytes
+#endif
+#ifndef PL_CROSS_SET
+#define PL_CROSS_SET 1         // the first chunk of the NEXT set is produced beside the last chunk of this one
+#endif
+// (timing experiment, tools/pl_clocks.py: the shader clock of every wave at the phase boundaries of
+// its SECOND set of walkers; not compiled into libmcmc_hip.so)
+#ifdef PL_DEBUG_CLOCKS
+__device__ unsigned long long pl_clock_log[256 * 8 * 64];
+#define PL_STAMP(i)                                                                         \
+    do {                                                                                    \
+        if (bt == 1 && blockIdx.x < 256) {                                                  \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+            if (lane == 0) pl_clock_log[((size_t)blockIdx.x * 8 + q) * 64 + (i)] = t_;      \
+        }                                                                                   \
+    } while (0)
+#else
+#define PL_STAMP(i) ((void)0)
 #endif
 #ifdef PL_DEBUG_NO_BARRIER
 #define PL_BARRIER() do {} while (0)   // (timing experiment: races)
@@ -409,13 +459,12 @@ __device__ __forceinline__ double2 ld16(const void* ubase, unsigned voff)
 template <int NG, int NP>
 __global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 lds[];   // [2][16][4][64]
+    extern __shared__ __attribute__((aligned(16))) double2 lds[];   // [2][16][4][64] + [4][NP + 1][64]
     const int tid = threadIdx.x, lane = tid & 63, c = lane >> 4, n = lane & 15;
     const unsigned l16 = (unsigned)lane * 16u;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s_pos = q < 4 ? q : 7 - q;
     const int ws = q < 4 ? 0 : 2, wl = 2 - ws;          // walker tiles of the short / long half
-    const int wt_p = q & 3, th_p = q >> 2;              // producer: walker tile, half of the chunk's tiles
     const int sh = a.shift, W = a.W, calib = a.calib;
     constexpr int CP = kPlChunkPairs;
     int nS[NG], nL[NG];                                  // real pairs of the half-tiles (0: absent)
@@ -427,117 +476,191 @@ __global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
         pS[G] = (const char*)(a.Astream + a.a_off[q][G][0]);
         pL[G] = (const char*)(a.Astream + a.a_off[q][G][1]);
     }
+    // The two waves of a SIMD are q and q + 4.  Each produces half of the next chunk's residuals
+    // for the walker tile q & 3: the wave q >= 4 BEFORE it consumes the current chunk, the wave
+    // q < 4 behind its consumption -- a producer (a chain of latencies with 32 MFMAs in it) then
+    // runs beside a consumer (MFMA-bound) on its SIMD, and the wave that starts a chunk late is the
+    // one that ends it late.  The waves q < 4 are served first throughout, by priority and not
+    // only by age.  (Round 4 had it the other way round -- q < 4 before, q >= 4 behind: the older
+    // wave, through its consumption first anyway, left the younger one to produce beside nothing,
+    // 8 k clocks per chunk; tools/pl_clocks.py.)
+    if (PL_OLDER_FIRST && q < 4) __builtin_amdgcn_s_setprio(1);
+    int par = 0;                                         // LDS buffer of this set's first chunk
     for (int bt = 0; bt < a.batches; ++bt) {
         const int wg = blockIdx.x * a.batches + bt;
         if (wg >= a.n_sets) break;                       // (uniform over the workgroup)
-        // ---- producer: the residuals of chunk m (virtual bin tiles 8 m .. 8 m + 7) for the wave's
-        // walker tile and its half of the tiles -> LDS in B-operand order (pl_residual_mfma_kernel)
-        auto produce = [&](int m) {
+        // ---- producer: the residuals of four bin tiles of chunk M (virtual tiles 8 M + 4 (q / 4) .. + 3)
+        // of set `wg` for walker tile q & 3 -> LDS buffer `slot` in B-operand order (pl_residual_mfma_kernel)
+        auto produce = [&](int wg, auto M, int slot) {
 #ifdef PL_DEBUG_SKIP_PRODUCE
             return;       // (timing experiment: the residuals are garbage)
 #endif
-            // (the lane index goes through an empty asm: everything derived from it below --
-            // eight gather addresses and more -- is then recomputed here instead of being hoisted
-            // out of the chunk loop, where it would sit in registers through the MFMA loops)
+            constexpr int m = decltype(M)::value, NT = 2, NTL = 4;   // NT of the wave's NTL tiles in flight together
+            const int t0 = q < 4 ? 0 : 4;
+            // a producer is a chain of latencies with a few MFMAs in it; at a raised priority those
+            // do not queue behind the 8-40 MFMAs per iteration of the consumer it runs beside
+            if (PL_PRODUCER_PRIO) __builtin_amdgcn_s_setprio(3);
+            // (the lane index goes through an empty asm: everything derived from it below is then
+            // recomputed here instead of being hoisted out of the chunk loop, where it would sit in
+            // registers through the MFMA loops)
             unsigned lw = l16;
             asm volatile("; producer lane" : "+v"(lw));
-            const int cc = (int)(lw >> 8), nn = (int)((lw >> 4) & 15u);
-            const unsigned w8 = ((unsigned)wg * 64u + (unsigned)wt_p * 16u + (unsigned)nn) * 8u;
+            const int wq = q & 3;    // the walker tile
+            double2* dst = (double2*)((char*)lds + ((size_t)slot * CP * 256 + wq * 64) * 16 + lw);
+            // dtheta_p = theta_p - theta0_p of the lane's walker (p = 4 j + c) and 1 / A^2: gathered
+            // with the set's first chunk -- ALL the requests in flight together (round 4 had them
+            // inside the `p < n_lin` arm of a conditional: eight branches, eight round trips in a
+            // row, most of a producer's time) -- and left in the wave's own corner of LDS for the
+            // other chunks of the set (a wave reads what it wrote itself: no barrier)
+            double2* const keep = (double2*)((char*)lds + kPlFusedChunkBytes + (size_t)wq * (NP + 1) * 1024 + lw);
             double dth[2 * NP];
+            double A = 1.0, iA2 = 0.0;
+            double traw[2 * NP], th0[2 * NP];
+            if (m == 0) {
+                const int cc = (int)(lw >> 8), nn = (int)((lw >> 4) & 15u);
+                const unsigned w8 = ((unsigned)wg * 64u + (unsigned)wq * 16u + (unsigned)nn) * 8u;
 #pragma unroll
-            for (int j = 0; j < 2 * NP; ++j) {
-                const int p = 4 * j + cc, i = p + (p >= calib ? 1 : 0);
+                for (int j = 0; j < 2 * NP; ++j) {
+                    const int p = min(4 * j + cc, a.n_lin - 1), i = p + (p >= calib ? 1 : 0);
 #ifdef PL_DEBUG_NO_DTH
-                const double t = (double)(i + (int)w8);
+                    traw[j] = (double)(i + (int)w8);
 #else
-                const double t = *(const double*)((const char*)a.trial + ((unsigned)i * (unsigned)W * 8u + w8));
+                    traw[j] = *(const double*)((const char*)a.trial + ((unsigned)i * (unsigned)W * 8u + w8));
 #endif
-                dth[j] = p < a.n_lin ? t - a.theta0[min(p, 31)] : 0.0;
-            }
-            const double A = *(const double*)((const char*)a.trial + ((unsigned)calib * (unsigned)W * 8u + w8));
-            const double iA2 = 1.0 / (A * A);
-            double2* dst = (double2*)((char*)lds + ((size_t)(m & 1) * CP * 256 + wt_p * 64) * 16 + lw);
-            // PL_PRODUCE_TILES tiles at a time, ALL their operands requested before the first is
-            // used (beside the gathers of dtheta above): one memory latency per group of tiles
-            // instead of one per operand class, and independent accumulator chains for the matrix
-            // pipe (measured: the producer alone 99 us per launch with the loads issued where they
-            // are used -- seven dependent round trips per call)
-#pragma unroll 1
-            for (int j = 0; j < 4; j += PL_PRODUCE_TILES) {
-                bool on[PL_PRODUCE_TILES];
-                double2 av[PL_PRODUCE_TILES][NP], e[PL_PRODUCE_TILES][4];
-#pragma unroll
-                for (int u = 0; u < PL_PRODUCE_TILES; ++u) {
-                    const int T = 8 * m + 4 * th_p + j + u - sh;   // real bin tile
-                    on[u] = T >= 0 && T < a.n_tiles;              // (uniform; off: never read)
-                    const int Tc = on[u] ? T : 0;
-                    const char* bjT = (const char*)(a.bjs + (size_t)Tc * NP * 128);
-                    const char* esT = (const char*)(a.es + (size_t)Tc * 4 * 128);
-#ifdef PL_DEBUG_NO_PLOADS
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e[u][k] = make_double2((double)lw, (double)k);
-#pragma unroll
-                    for (int jp = 0; jp < NP; ++jp) av[u][jp] = make_double2((double)jp, (double)lw);
-                    (void)bjT; (void)esT;
-#else
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) e[u][k] = ld16(esT + k * 1024, lw);
-#pragma unroll
-                    for (int jp = 0; jp < NP; ++jp) av[u][jp] = ld16(bjT + jp * 1024, lw);
-#endif
+                    th0[j] = a.theta0[p];
                 }
-                d4 y[PL_PRODUCE_TILES];
+                A = *(const double*)((const char*)a.trial + ((unsigned)calib * (unsigned)W * 8u + w8));
+            } else {
 #pragma unroll
-                for (int u = 0; u < PL_PRODUCE_TILES; ++u) y[u] = d4{e[u][0].x, e[u][0].y, e[u][1].x, e[u][1].y};
+                for (int jp = 0; jp < NP; ++jp) {
+                    const double2 v = keep[jp * 64];
+                    dth[2 * jp] = v.x;
+                    dth[2 * jp + 1] = v.y;
+                }
+                iA2 = keep[NP * 64].x;
+            }
+            // (Bc0, X) of a bin tile do not depend on the walker: the 16 lanes of a class read the same
+            // 16 bytes (the n = 0 entries) -- 4 x 64 B per tile through the L1 instead of 4 KB
+            const unsigned le = PL_ES_COMPACT ? (lw & ~255u) : lw;
+            // NT tiles at a time.  Registers are what a producer is short of (it runs between the
+            // MFMA loops, with the accumulators of the unfinished groups alive): Bc0 is requested
+            // straight into the accumulators, the operands of BJ two k-step pairs ahead of their
+            // MFMAs into the registers those just released, X behind the last but one pair --
+            // 16 + 24 NT registers instead of 16 + (16 + 4 NP) NT
+#pragma unroll
+            for (int j = 0; j < NTL; j += NT) {
+                const char* bjT[NT];
+                const char* esT[NT];
+                double2 av[NT][2], X[NT][2];
+                d4 y[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int T = 8 * m + t0 + j + u - sh;        // real bin tile
+                    const int Tc = T >= 0 && T < a.n_tiles ? T : 0;   // (uniform; an absent tile's rows are never read)
+                    bjT[u] = (const char*)(a.bjs + (size_t)Tc * NP * 128);
+                    esT[u] = (const char*)(a.es + (size_t)Tc * 4 * 128);
+                    const double2 e0 = ld16(esT[u], le), e1 = ld16(esT[u] + 1024, le);
+                    y[u] = d4{e0.x, e0.y, e1.x, e1.y};
+                    av[u][0] = ld16(bjT[u], lw);
+                    if (NP > 1) av[u][1] = ld16(bjT[u] + 1024, lw);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (m == 0 && j == 0) {     // (behind the first tiles' requests: one round trip for both)
+#pragma unroll
+                    for (int jj = 0; jj < 2 * NP; ++jj) {
+                        const int cc = (int)(lw >> 8);
+                        dth[jj] = 4 * jj + cc < a.n_lin ? traw[jj] - th0[jj] : 0.0;
+                    }
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp)
+                        if (q < 4) keep[jp * 64] = make_double2(dth[2 * jp], dth[2 * jp + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int jp = 0; jp < NP; ++jp) {
 #pragma unroll
-                    for (int u = 0; u < PL_PRODUCE_TILES; ++u)
-                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jp].x, dth[2 * jp], y[u], 0, 0, 0);
+                    for (int u = 0; u < NT; ++u)
+                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jp & 1].x, dth[2 * jp], y[u], 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < PL_PRODUCE_TILES; ++u)
-                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jp].y, dth[2 * jp + 1], y[u], 0, 0, 0);
-                }
+                    for (int u = 0; u < NT; ++u)
+                        y[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jp & 1].y, dth[2 * jp + 1], y[u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jp + 2 < NP) {
 #pragma unroll
-                for (int u = 0; u < PL_PRODUCE_TILES; ++u) {
-                    if (!on[u]) continue;
-                    const int tl = 4 * th_p + j + u;          // tile of the chunk: pairs 2 tl, 2 tl + 1
-                    dst[(size_t)(2 * tl) * 256] = make_double2(fma(-y[u][0], iA2, e[u][2].x), fma(-y[u][1], iA2, e[u][2].y));
-                    dst[(size_t)(2 * tl + 1) * 256] = make_double2(fma(-y[u][2], iA2, e[u][3].x), fma(-y[u][3], iA2, e[u][3].y));
+                        for (int u = 0; u < NT; ++u) av[u][jp & 1] = ld16(bjT[u] + (jp + 2) * 1024, lw);
+                    }
+                    if (jp == (NP >= 2 ? NP - 2 : 0)) {
+#pragma unroll
+                        for (int u = 0; u < NT; ++u) {
+                            X[u][0] = ld16(esT[u] + 2048, le);
+                            X[u][1] = ld16(esT[u] + 3072, le);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                if (m == 0 && j == 0) {     // (1 / A^2 behind the first MFMAs: its division waits for A there, not in front of the requests)
+                    double A2 = A * A;
+                    asm volatile("; calibration" : "+v"(A2));
+                    iA2 = 1.0 / A2;
+                    if (q < 4) keep[NP * 64] = make_double2(iA2, 0.0);
+                }
+                // (the rows of an absent tile -- below the first or beyond the last bin -- are written
+                // too: nobody reads them, and a conditional store would have the compiler sink the
+                // requests of X behind the MFMAs, a round trip of their own)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int tl = t0 + j + u;                // tile of the chunk: pairs 2 tl, 2 tl + 1
+                    dst[(size_t)(2 * tl) * 256] = make_double2(fma(-y[u][0], iA2, X[u][0].x), fma(-y[u][1], iA2, X[u][0].y));
+                    dst[(size_t)(2 * tl + 1) * 256] = make_double2(fma(-y[u][2], iA2, X[u][1].x), fma(-y[u][3], iA2, X[u][1].y));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (PL_PRODUCER_PRIO) {
+                if (PL_OLDER_FIRST && q < 4) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
             }
         };
         // ---- consumer state
         d4 acc[NG][4];
-        double2 aS[NG], aL[NG];      // operands of the next pair of every half-tile
+        double2 aS[2][NG], aL[2][NG];   // operands of the next pair(s) of every half-tile ([1]: from chunk PL_DEEP_FROM on)
 #pragma unroll
         for (int G = 0; G < NG; ++G) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[G][j] = d4{0.0, 0.0, 0.0, 0.0};
-            aS[G] = ld16(pS[G], l16);     // real pair 0 (absent half-tiles point at zeros)
-            aL[G] = ld16(pL[G], l16);
+            aS[0][G] = ld16(pS[G], l16);  // real pair 0 (absent half-tiles point at zeros)
+            aL[0][G] = ld16(pL[G], l16);
         }
         double pch[4] = {0.0, 0.0, 0.0, 0.0};   // the chains p[pos][c] of the wave's four columns
-        produce(0);
-        PL_BARRIER();
-#pragma unroll
-        for (int m = 0; m < NG; ++m) {
-#if PL_EARLY_PRODUCERS
-            // the two waves of a SIMD (q and q + 4) take turns: the first produces the next chunk
-            // BEFORE it consumes this one, the second after -- a producer (a latency-bound chain)
-            // then always runs beside a consumer (MFMA-bound) on its SIMD
-            if (m + 1 < NG && q < 4) produce(m + 1);
-#endif
+        PL_STAMP(0);
+        if (!PL_CROSS_SET || bt == 0) {
+            produce(wg, std::integral_constant<int, 0>{}, par);
+            PL_STAMP(1);
+            PL_BARRIER();
+        }
+        PL_STAMP(2);
+        static_for<NG>([&](auto M_) {
+            constexpr int m = decltype(M_)::value;
+            // what is produced beside chunk m: the next chunk of this set, or (PL_CROSS_SET) the
+            // first chunk of the next set -- into the buffer chunk m does not read
+            const bool nxt_set = m + 1 == NG;
+            const bool prod = !nxt_set || (PL_CROSS_SET && bt + 1 < a.batches && wg + 1 < a.n_sets);   // (uniform)
+            const int p_wg = nxt_set ? wg + 1 : wg, p_slot = (par + m + 1) & 1;
+            using PM = std::integral_constant<int, (m + 1 == NG ? 0 : m + 1)>;
+            if (prod && q >= 4) produce(p_wg, PM{}, p_slot);
+            PL_STAMP(3 + 6 * m);
             // (as in the producer: the lane offset is laundered per chunk, so that the LDS and
             // stream addresses of the five unrolled chunks are not all computed up front and
             // kept in registers for the whole set)
             unsigned lm = l16;
             asm volatile("; chunk lane" : "+v"(lm));
-            const char* const buf = (const char*)lds + (size_t)(m & 1) * CP * 4096 + lm;
+            const char* const buf = (const char*)lds + (size_t)((par + m) & 1) * CP * 4096 + lm;
             // pairs of this chunk: virtual [16 m, 16 m + 16); real = virtual - 2 shift
             const int base = CP * m - 2 * sh;            // real pair of i = 0
             const int i0 = m == 0 ? 2 * sh : 0;
-            const int cS = min(max(nS[m] - base, 0), CP), cL = min(max(nL[m] - base, 0), CP);
+            // (wave-uniform, and said so: as a lane value a loop bound was spilled and re-read per
+            // iteration behind a full s_waitcnt -- every request drained before the next iteration)
+            const int cS = __builtin_amdgcn_readfirstlane(min(max(nS[m] - base, 0), CP));
+            const int cL = __builtin_amdgcn_readfirstlane(min(max(nL[m] - base, 0), CP));
             // one pair-iteration: B operands from LDS, for every active half-tile two MFMAs per
             // walker tile, then the operands of its next pair
             // B operands of pair i0; from then on each pair's operands are re-read for the NEXT pair
@@ -547,26 +670,43 @@ __global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
             double2 b1 = *(const double2*)(buf + (size_t)i0 * 4096 + ws * 1024 + 1024);
             double2 b2 = *(const double2*)(buf + (size_t)i0 * 4096 + wl * 1024);
             double2 b3 = *(const double2*)(buf + (size_t)i0 * 4096 + wl * 1024 + 1024);
-            auto step = [&](int i, auto DS, auto DL) {
-                const int Pn = base + i + 1;             // the real pair that comes next
+            // From chunk PL_DEEP_FROM on a finished group's registers hold a SECOND pair of operands:
+            // pair i's are re-requested for pair i + 2 (slot i & 1; all the loop bounds are even).  A
+            // wave that has its SIMD to itself -- the other producing, or through with the chunk --
+            // has only its own MFMAs to cover a request: 4 to 16 of them one pair ahead.
+            constexpr int DEPTH = m >= PL_DEEP_FROM ? 2 : 1;
+            if (m == PL_DEEP_FROM) {
+#pragma unroll
+                for (int G = m; G < NG; ++G) {
+                    aS[1][G] = ld16(pS[G] + (size_t)min(base + i0 + 1, max(nS[G] - 1, 0)) * 1024, lm);
+                    aL[1][G] = ld16(pL[G] + (size_t)min(base + i0 + 1, max(nL[G] - 1, 0)) * 1024, lm);
+                }
+            }
+            auto step = [&](int i, auto DS, auto DL, auto K) {
+                constexpr int k = decltype(K)::value;
+                // (the lane offset is taken anew in every pair-iteration: were it loop-invariant, the
+                // compiler would keep (stream base + lane offset) of all ten streams in registers --
+                // 20 VGPRs -- instead of adding the stream's position to the base in scalar registers)
+                unsigned li = lm;
+                asm volatile("; pair lane" : "+v"(li));
+                const int Pn = base + i + DEPTH;         // the real pair requested behind this one's MFMAs
                 const char* const bn = buf + (size_t)min(i + 1, CP - 1) * 4096;
-#if PL_ORDER_XY
                 // first k-step of every active short half-tile, then the second (a dependent MFMA is
                 // then 2 x groups apart from its predecessor, as in pl_chi2_kernel), each followed by
                 // the reload of its operands
 #pragma unroll
                 for (int G = m; G < NG; ++G)
                     if (G > m || decltype(DS)::value) {
-                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b0.x, acc[G][0], 0, 0, 0);
-                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b1.x, acc[G][1], 0, 0, 0);
+                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[k][G].x, b0.x, acc[G][0], 0, 0, 0);
+                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[k][G].x, b1.x, acc[G][1], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int G = m; G < NG; ++G)
                     if (G > m || decltype(DS)::value) {
-                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b0.y, acc[G][0], 0, 0, 0);
-                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b1.y, acc[G][1], 0, 0, 0);
-                        aS[G] = ld16(pS[G] + (size_t)min(Pn, max(nS[G] - 1, 0)) * 1024, lm);
+                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[k][G].y, b0.y, acc[G][0], 0, 0, 0);
+                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[k][G].y, b1.y, acc[G][1], 0, 0, 0);
+                        aS[k][G] = ld16(pS[G] + (size_t)min(Pn, max(nS[G] - 1, 0)) * 1024, li);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 b0 = *(const double2*)(bn + ws * 1024);
@@ -575,49 +715,18 @@ __global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
 #pragma unroll
                 for (int G = m; G < NG; ++G)
                     if (G > m || decltype(DL)::value) {
-                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b2.x, acc[G][2], 0, 0, 0);
-                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b3.x, acc[G][3], 0, 0, 0);
+                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[k][G].x, b2.x, acc[G][2], 0, 0, 0);
+                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[k][G].x, b3.x, acc[G][3], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int G = m; G < NG; ++G)
                     if (G > m || decltype(DL)::value) {
-                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b2.y, acc[G][2], 0, 0, 0);
-                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b3.y, acc[G][3], 0, 0, 0);
-                        aL[G] = ld16(pL[G] + (size_t)min(Pn, max(nL[G] - 1, 0)) * 1024, lm);
+                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[k][G].y, b2.y, acc[G][2], 0, 0, 0);
+                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[k][G].y, b3.y, acc[G][3], 0, 0, 0);
+                        aL[k][G] = ld16(pL[G] + (size_t)min(Pn, max(nL[G] - 1, 0)) * 1024, li);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#else
-#pragma unroll
-                for (int G = m; G < NG; ++G) {
-                    const bool useS = G > m || decltype(DS)::value;
-                    if (useS) {
-                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b0.x, acc[G][0], 0, 0, 0);
-                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].x, b1.x, acc[G][1], 0, 0, 0);
-                        acc[G][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b0.y, acc[G][0], 0, 0, 0);
-                        acc[G][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[G].y, b1.y, acc[G][1], 0, 0, 0);
-                        aS[G] = ld16(pS[G] + (size_t)min(Pn, max(nS[G] - 1, 0)) * 1024, lm);
-                        // (the reload stays BEHIND the MFMAs that read the old pair: hoisted, the
-                        // ten loads of an iteration would double the operand registers)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                b0 = *(const double2*)(bn + ws * 1024);
-                b1 = *(const double2*)(bn + ws * 1024 + 1024);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int G = m; G < NG; ++G) {
-                    const bool useL = G > m || decltype(DL)::value;
-                    if (useL) {
-                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b2.x, acc[G][2], 0, 0, 0);
-                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].x, b3.x, acc[G][3], 0, 0, 0);
-                        acc[G][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b2.y, acc[G][2], 0, 0, 0);
-                        acc[G][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[G].y, b3.y, acc[G][3], 0, 0, 0);
-                        aL[G] = ld16(pL[G] + (size_t)min(Pn, max(nL[G] - 1, 0)) * 1024, lm);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-#endif
                 b2 = *(const double2*)(bn + wl * 1024);
                 b3 = *(const double2*)(bn + wl * 1024 + 1024);
                 __builtin_amdgcn_sched_barrier(0);
@@ -630,14 +739,26 @@ __global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
 #ifdef PL_DEBUG_SKIP_CONSUME
             i = CP;       // (timing experiment: no triangular product)
 #endif
+            using K0 = std::integral_constant<int, 0>;
+            using K1 = std::integral_constant<int, 1>;
+            auto run = [&](int upto, auto DS, auto DL) {
+                if constexpr (DEPTH == 1) {
 #pragma unroll 1
-            for (; i < cS; ++i) step(i, T1{}, T1{});
+                    for (; i < upto; ++i) step(i, DS, DL, K0{});
+                } else {
 #pragma unroll 1
-            for (; i < cL; ++i) step(i, T0{}, T1{});
-            if (m + 1 < NG) {
-#pragma unroll 1
-                for (; i < CP; ++i) step(i, T0{}, T0{});
-            }
+                    for (; i < upto; i += 2) {
+                        step(i, DS, DL, K0{});
+                        step(i + 1, DS, DL, K1{});
+                    }
+                }
+            };
+            run(cS, T1{}, T1{});
+            PL_STAMP(4 + 6 * m);
+            run(cL, T0{}, T1{});
+            PL_STAMP(5 + 6 * m);
+            if (m + 1 < NG) run(CP, T0{}, T0{});
+            PL_STAMP(6 + 6 * m);
             // group m is complete (its diagonal block lies in this chunk): its rows join the
             // chains -- groups ascending, r = 0..3 -- and its 32 accumulator registers are free
             // for the producer of the next chunk
@@ -645,13 +766,12 @@ __global__ void __launch_bounds__(512, 2) pl_fused_kernel(const PlFusedArgs a)
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pch[j] = fma(acc[m][j][r], acc[m][j][r], pch[j]);
-#if PL_EARLY_PRODUCERS
-            if (m + 1 < NG && q >= 4) produce(m + 1);
-#else
-            if (m + 1 < NG) produce(m + 1);
-#endif
+            if (prod && q < 4) produce(p_wg, PM{}, p_slot);
+            PL_STAMP(7 + 6 * m);
             PL_BARRIER();
-        }
+            PL_STAMP(8 + 6 * m);
+        });
+        par = (par + NG) & 1;
         unsigned le = l16;
         asm volatile("; epilogue lane" : "+v"(le));
         const unsigned ce = le >> 8, ne = (le >> 4) & 15u;
@@ -767,7 +887,7 @@ extern "C" hipError_t mcmc_hip_launch_pl_chi2(const PlChi2Args* a, hipStream_t s
 template <int NG>
 static hipError_t launch_pl_fused_ng(const PlFusedArgs& b, dim3 g, hipStream_t st)
 {
-    constexpr size_t lds = sizeof(double2) * 2 * kPlChunkPairs * 256;   // 128 KB
+    constexpr size_t lds = kPlFusedLdsBytes;   // 128 KB of residuals + 20 KB
     auto go = [&](auto kern) -> hipError_t {
         {   // per device and per call: the attribute is the current device's
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -806,6 +926,13 @@ extern "C" hipError_t mcmc_hip_launch_pl_fused(const PlFusedArgs* a, hipStream_t
     if (e == hipSuccess) mcmc_hip_note_step_kernel(names[a->ng - 1]);
     return e;
 }
+
+#ifdef PL_DEBUG_CLOCKS
+extern "C" __attribute__((visibility("default"))) int mcmc_hip_debug_pl_clocks(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcmc::pl_clock_log), sizeof(unsigned long long) * 256 * 8 * 64);
+}
+#endif
 
 extern "C" hipError_t mcmc_hip_launch_pl_combine(const double* psum, double* chi2, int n, hipStream_t st)
 {

@@ -4,6 +4,7 @@ reference-pinned oracle, and the Python mirror of the reference interface (model
 initial covmat, collection, option handling) behaves like the reference."""
 import math
 import os
+import sys
 import shutil
 import subprocess
 import re
@@ -18,6 +19,20 @@ from cobaya_amd.sampler import MCMCHip, LoggedError, _number_with_units
 from oracle import ref_numpy as R
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pl_fused_kernel_does_not_spill_where_it_hurts():
+    """pl_fused_kernel<5, 4> runs at 256 VGPRs, 160 of them accumulators: a few registers more in a
+    producer and the compiler spills inside an MFMA loop, or spills a producer's requested operands
+    one by one behind a full s_waitcnt (both seen in round 5, 5-30 % of the kernel each).  The
+    shipped source must compile to loops without scratch traffic (tools/check_pl_spills.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_pl_spills as C
+    loops, producers = C.report(C.kernel_lines(C.compile_to_asm()))
+    assert len(loops) >= 13 and len(producers) >= 9          # five chunks of three loops; early and late producers
+    assert [lp for lp in loops if lp["scratch"]] == []
+    assert [p for p in producers if p["spilled_on_arrival"]] == []
+    assert max(p["scratch"] for p in producers) <= 8
 
 
 def test_capi_exports_every_declared_symbol():
