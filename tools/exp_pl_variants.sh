@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer experiments on pl_fused_kernel / pl_chi2_kernel: builds cobaya_amd/csrc/_exp/lib_<name>.so
-# with extra -D flags for pliklite_kernels.hip (e.g. -DPL_PRODUCE_TILES=4).
-#   tools/exp_pl_variants.sh p4 "-DPL_PRODUCE_TILES=4" early "-DPL_EARLY_PRODUCERS=1"
+# with extra -D flags for pliklite_kernels.hip (e.g. -DPL_DEEP_FROM=9).
+#   tools/exp_pl_variants.sh nodeep "-DPL_DEEP_FROM=9" clk "-DPL_DEBUG_CLOCKS"
 # Run on the GPU with MCMC_HIP_LIB=<that .so> python bench.py --workload pliklite ...
 set -e
 cd "$(dirname "$0")/.."

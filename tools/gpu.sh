@@ -15,6 +15,7 @@
 #   ab "<v1 v2 ..>" [bench args]     same-box A/B of library builds cobaya_amd/csrc/_exp/lib_<v>.so
 #                              ("cur" = the built libmcmc_hip.so), alternated REPS (3) times
 #   abpmc "<v1 ..>" <kernel-like> [bench args]   SQ + LDS counters of one kernel for those builds
+#   plab "<v..>" "<v..>" "<v..>"   plik-lite kernels of those builds: GPU tests / kernel times / per-phase clocks
 #   pmc <kernel-like> "<counters>" -- <command>  one PMC pass of any command, per-kernel averages
 #   timeline [bench args | -- <command>]   start / duration / gap of every kernel and copy around
 #                              the middle step kernel of a bench run (or of any command)
@@ -131,6 +132,20 @@ except Exception as e:
     print(sys.argv[2], sys.argv[3], "FAILED", e)
 PY
     done
+  done ;;
+plab)
+  # plab "<variants to test>" "<variants to time>" "<variants to clock>": the plik-lite kernels of
+  # cobaya_amd/csrc/_exp/lib_<v>.so (tools/exp_pl_variants.sh; "cur" = the built library): the GPU
+  # tests of the likelihood, tools/pliklite_bench.py twice alternated, tools/pl_clocks.py
+  export MCMC_HIP_LIB_COMPAT=1
+  for v in $1; do
+    echo "== tests $v"; MCMC_HIP_LIB=$(libof $v) timeout 600 python -m pytest tests/test_gpu_pliklite.py -m gpu -q -x 2>&1 | tail -2
+  done
+  for rep in 1 2; do for v in $2; do
+    echo "== $v $(MCMC_HIP_LIB=$(libof $v) timeout 300 python tools/pliklite_bench.py 26 65536 24 2>&1 | grep 'per step')"
+  done; done
+  for v in $3; do
+    echo "== clocks $v"; MCMC_HIP_LIB=$(libof $v) timeout 200 python tools/pl_clocks.py 2>&1 | tail -42
   done ;;
 abpmc)
   VARIANTS=$1; KLIKE=$2; shift 2
