@@ -358,6 +358,7 @@ struct mcmc_hip_ctx {
         DevBuf<int> vflag, vflag_f, colflag;   // colflag: 1-D columns of the launch, in VU order
         bool has_flags = false;
         DevBuf<double> UU;                   // |u|^2 of the columns (step_inc_kernel: one mode, no periodic parameter)
+        DevBuf<double> VW, NL;               // the carried log-prior's stream and (v.w, loc.w) of the columns
         hipEvent_t ready = nullptr;          // recorded on the stream that filled the set
         bool ahead = false;                  // filled ahead of its launch (on stream2)
         unsigned long long step0 = ~0ull, epoch = 0;
@@ -1738,6 +1739,21 @@ bool inc_carries_modes(const mcmc_hip_ctx* h)
     return h->K <= 4 && (h->d + 3) / 4 <= 16 && h->cfg.emit_capacity == 0;
 }
 
+// Does the kernel that serves this engine's incremental steps carry the log-prior (round 5)?
+// step_inc_kernel (one mode, no periodic parameter, Metropolis steps; with emitted rows: no block
+// of one parameter) with some normal prior.  The oracle's rule is the same (carries_prior).
+bool inc_carries_prior(const mcmc_hip_ctx* h)
+{
+    if (!h->incremental || h->K != 1 || h->drag_last_slow >= 0) return false;
+    if (!(h->norm_mask4[0] | h->norm_mask4[1] | h->norm_mask4[2] | h->norm_mask4[3])) return false;
+    for (int i = 0; i < h->d; ++i)
+        if (h->periodic[i]) return false;
+    if (h->cfg.emit_capacity > 0)
+        for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b)
+            if (h->blk_size[b] == 1) return false;
+    return true;
+}
+
 // mcmc_hip_step in incremental mode (MCMC_HIP_FLAG_INCREMENTAL; incremental_kernels.hip).
 // Launches are cut at the multiples of refresh_every = 40 cycle lengths, where y = L^-1 (x - mu)
 // is recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
@@ -1750,6 +1766,7 @@ struct IncPlan {   // what the cutting of launches depends on besides the step c
     bool carry; // step_inc_kernel (one mode, no periodic parameter, Metropolis steps): the log-likelihood is carried
     bool carry_modes;   // step_inc_mix_kernel: the log-density of every mode is carried
     bool fold;          // step_inc_kernel: the refresh of y is the kernel's, a direction set spans a call
+    bool carry_prior;   // step_inc_kernel with normal priors: the log-prior is carried (inc_carries_prior)
 };
 struct IncSeg {    // one launch: steps [step0, step0 + n)
     unsigned long long step0, c0, cyc0_f;
@@ -1837,6 +1854,11 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
         HIP_TRY(h, D.UU.resize((size_t)h->BG * s.n * (P.carry_modes ? (size_t)P.K : 1)));
         w.UU = D.UU.p;
     }
+    if (P.carry_prior) {
+        HIP_TRY(h, D.VW.resize((size_t)h->BG * s.n * 4 * (size_t)P.dq));
+        HIP_TRY(h, D.NL.resize((size_t)h->BG * s.n * 2));
+        w.prior = h->inc_prior.p; w.VW = D.VW.p; w.NL = D.NL.p;
+    }
     if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
     if (P.any) HIP_TRY(h, mcmc_hip_launch_whiten_directions_planes(&w, h->BG, st));
     else HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));
@@ -1902,6 +1924,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     // log-likelihood along the whitened direction and need |u|^2 of every column
     P.carry = !P.any && !P.drag && K == 1;   // (round 5: with up to eight periodic parameters too)
     P.fold = P.carry && n_periodic == 0;     // step_inc_kernel: y refreshed in the kernel, sets of several launches
+    // ... with normal priors: the log-prior is carried as well (inc_carries_prior says the same to
+    // the caller); from d = 113 on its chunks leave no room for the refresh inside the kernel
+    P.carry_prior = inc_carries_prior(h);
+    if (P.carry_prior && dq >= 29) P.fold = false;
     // mixtures on step_inc_mix_kernel (2..4 modes, d <= 64, no periodic parameter): the log-density
     // of every mode is carried; |u_k|^2 of every column and mode (inc_carries_modes says the same
     // to the caller: the oracle takes the rule from there)
@@ -2020,6 +2046,8 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.vu_cols = P.fold ? span.n : 0;
             a.col0 = P.fold ? done : 0;
             a.mean = h->inc_mean.p;
+            a.VW = P.carry_prior ? D.VW.p : nullptr;
+            a.NL = P.carry_prior ? D.NL.p : nullptr;
             for (int i = 0; i < d; ++i)
                 if (h->periodic[i]) a.periodic_mask4[i >> 5] |= 1u << (i & 31);
             HIP_TRY(h, launch(&a, h->stream));

@@ -170,8 +170,14 @@ struct StagedVariates {
 // columns of one LDS chunk: a multiple of 4 (the variates come in fours); 14 KiB of pairs, 32 KiB
 // from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
 // workgroup barrier between chunks comes half as often)
-__host__ __device__ constexpr int inc_chunk(int dq)
+// with_w: the chunk also holds the doubles of the carried log-prior's stream (24 bytes per
+// dimension and column instead of 16: MODE 2 of step_inc_kernel)
+__host__ __device__ constexpr int inc_chunk(int dq, bool with_w = false)
 {
+    if (with_w) {
+        int c = ((dq >= 9 ? 1364 : 600) / (4 * dq)) & ~3;
+        return c < 8 ? 8 : (c > 64 ? 64 : c);
+    }
     // (kernels at four waves per SIMD -- four workgroups per CU -- have 40 KB of LDS each: 28 KB
     // of pairs beside the 8.5 KB of staged variates and the 2 KB logarithm table)
     int c = ((dq >= 14 ? 2048 : 896) / (4 * dq)) & ~3;

@@ -36,7 +36,9 @@ namespace {
 //   MODE 0 "box":    every prior uniform on the SAME interval [lo, hi] (kernel arguments; the
 //                    padded dimensions sit at its midpoint) -- BASELINE configs 2-4
 //   MODE 1 general bounds: per-dimension [lo_i, hi_i] in registers (DQ <= 12) or LDS
-//   MODE 2 ... and normal priors
+//   MODE 2 ... and normal priors, whose log-density is CARRIED along the direction like the
+//          log-likelihood (round 5; oracle: carries_prior): a third stream w_i = (v_i / s_i) / s_i
+//          of the columns beside the (v, u) pairs, one more fma per dimension and trial
 // Registers: x and y only (+ the bounds for MODE > 0, DQ <= 12); the (v_i, u_i) pairs of a step
 // are read from LDS twice (trial, commit) -- ds_read_b128 costs 4 LDS cycles per wave, far below
 // what the step's VALU work takes.  The columns of the launch reach LDS by global->LDS DMA,
@@ -54,7 +56,9 @@ __host__ __device__ constexpr int inc_min_waves(int dq, int mode)
     return MCMC_EXP_WAVES(STEP,
         mode == 0 ? (dq <= 12 ? 4 : dq <= 30 ? 2 : 1)
         : mode == 1 ? ((dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1)
-        : (dq <= 5 ? 4 : dq == 6 ? 3 : dq == 13 ? 4 : dq == 15 ? 3 : dq <= 31 ? 2 : 1));
+        // (MODE 2, round 5: MODE 1's registers + the stream of the carried log-prior in LDS --
+        // 24 bytes per dimension and column --, which four workgroups per CU hold up to dq = 8)
+        : (dq <= 8 ? 4 : dq <= 31 ? 2 : 1));
 }
 
 // The step's (v, u) pairs kept in registers from the trial to the commit (no second LDS read):
@@ -78,15 +82,11 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem2[];
     constexpr int COLB = 4 * DQ;                 // (v, u) pairs per column
-    constexpr int C = inc_chunk(DQ);
+    constexpr bool NORMP = MODE == 2;
+    constexpr int C = inc_chunk(DQ, NORMP);
     constexpr int CHUNK = C * COLB;              // pairs per chunk
     constexpr bool kBoundsInRegs = MODE > 0 && DQ <= 12;
     constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;
-    constexpr bool NORMP = MODE == 2;
-    constexpr bool kNormInRegs = NORMP && DQ <= 8;
-    constexpr bool kNormInLds = NORMP && DQ > 8;   // (loc, 1/scale) pairs and mls in LDS
-    __shared__ double2 sNA[kNormInLds ? 4 * DQ : 1];
-    __shared__ double sNM[kNormInLds ? 4 * DQ : 1];
     // (MODE 0 = ONE box [0, hi] for every dimension, BASELINE configs 2-4: its support test works
     // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
     // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step
@@ -113,7 +113,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         (const double2*)a.VU + ((size_t)g * set_cols + (size_t)a.col0) * COLB;
     constexpr int dpad = 4 * DQ;
     double2* const sVU = smem2;                          // [2][CHUNK]
-    double2* const sLH = smem2 + 2 * CHUNK;              // [dpad] (lo, hi), kBoundsInLds only
+    double* const sW = (double*)(smem2 + 2 * CHUNK);     // [2][CHUNK] doubles, NORMP only
+    double2* const sLH = smem2 + 2 * CHUNK + (NORMP ? CHUNK : 0);   // [dpad] (lo, hi), kBoundsInLds only
+    const double* __restrict__ gW =
+        NORMP ? a.VW + ((size_t)g * set_cols + (size_t)a.col0) * COLB : nullptr;
 
     // chunk k of the launch -> buffer k & 1, by DMA: every wave moves every fourth KiB
     auto stage = [&](int k) {
@@ -129,13 +132,24 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     (const __attribute__((address_space(1))) void*)(src + kb * 1024 + lane * 16),
                     (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
         }
+        if (NORMP) {   // the chunk's w (8 bytes per dimension and column), dealt from the last wave down
+            const int wbytes = cols * COLB * 8;
+            const char* wsrc = (const char*)(gW + (size_t)first * COLB);
+            char* wdst = (char*)(sW + (k & 1) * CHUNK);
+            for (int kb = 3 - wave; kb * 1024 < wbytes; kb += 4) {
+                if (kb * 1024 + lane * 16 < wbytes)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(wsrc + kb * 1024 + lane * 16),
+                        (__attribute__((address_space(3))) void*)(wdst + kb * 1024), 16, 0, 0);
+            }
+        }
     };
     // (a launch that refreshes y itself uses the chunk buffers as scratch first: its first
     // chunk is staged behind that, below)
 #ifdef MCMC_EXP_NO_FOLD
     const bool refresh_y = false;   // (timing experiment: the in-kernel refresh compiled out)
 #else
-    const bool refresh_y = (a.anchor & 2) != 0;   // wave-uniform
+    const bool refresh_y = !(NORMP && DQ >= 29) && (a.anchor & 2) != 0;   // wave-uniform
 #endif
     if (!refresh_y) stage(0);
     MCMC_EXP_BLOCK_BEGIN();
@@ -143,9 +157,6 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     const double blo = a.box_lo, bhi = a.box_hi;
     const unsigned bhi_word = (unsigned)__double2hiint(bhi);   // (MODE 0: blo == +0, 0 < bhi < inf)
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
-    // normal priors, branch-free: a dimension without one has 1/scale = 0 and mls = 0, so its
-    // term is fma(-0, 0, 0) = +0 and leaves the chain untouched
-    double nloc[kNormInRegs ? DQ : 1], ninv[kNormInRegs ? DQ : 1], nmls[kNormInRegs ? DQ : 1];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
@@ -157,19 +168,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
             lo[kk] = a.prior[i];               // padded: -inf / +inf beyond d
             hi[kk] = a.prior[dpad + i];
         }
-        if (kNormInRegs) {
-            nloc[kk] = a.prior[2 * dpad + i];
-            ninv[kk] = a.prior[3 * dpad + i];
-            nmls[kk] = a.prior[4 * dpad + i];
-        }
     }
     if (kBoundsInLds)
         for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
-    if (kNormInLds)
-        for (int i = tid; i < dpad; i += 256) {
-            sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
-            sNM[i] = a.prior[4 * dpad + i];
-        }
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
     if (refresh_y) {
@@ -185,7 +186,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         // every lane then reads its rows there): read per lane straight from memory, the rolled
         // loop waited for one memory round trip per dimension -- +40 us per launch at d = 30, +260
         // at d = 100, more than the kernel it replaced (same-box A/B, profiles/r05_launch_gap.txt).
-        static_assert(C >= 16, "the chunk buffers hold the deviations of the workgroup's 64 walkers");
+        static_assert((NORMP ? 3 : 2) * C >= 32 || (NORMP && DQ >= 29),
+                      "the chunk buffers hold the deviations of the workgroup's 64 walkers");
+        // (MODE 2 from d = 113 on: the chunks are too small; the host refreshes y with
+        // whiten_state_kernel before every such launch -- capi.hip: IncPlan::fold)
         constexpr int TW = 8;
         static_assert(sizeof(pair_t) * kStagedPairs >= sizeof(double) * dpad * TW, "the tile fits sRE");
         double* const sdev = (double*)sVU + (size_t)(tid >> 2) * dpad;   // this walker's deviations
@@ -219,6 +223,19 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 #pragma unroll
         for (int kk = 0; kk < DQ; ++kk) pa = fma(y[kk], y[kk], pa);
         llik = -0.5 * (s.cnorm0 + quad_sum(pa));
+        if (NORMP) {
+            // ... and the carried log-prior on x: the normal terms, branch-free -- a dimension
+            // without one has 1/scale = 0 and mls = 0, so its term is fma(-0, 0, 0) = +0 and
+            // leaves the chain untouched (four chains over i mod 4, as every sum here)
+            double sc = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < DQ; ++kk) {
+                const int i = 4 * kk + c;
+                const double qq = (x[kk] - a.prior[2 * dpad + i]) * a.prior[3 * dpad + i];
+                sc = sc + fma(-0.5 * qq, qq, a.prior[4 * dpad + i]);
+            }
+            lpri = s.uniform_logp + quad_sum(sc);
+        }
         lpost = lpri + llik;
     }
     int wt = s.weight[w], prej = s.prior_rej[w], burn = s.burn_left[w];
@@ -229,6 +246,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     // wave-uniform, the load a scalar one (s_load_dwordx2 on the scalar cache's counter -- a vector
     // load would queue behind the DMA of the next chunk on vmcnt)
     const cdoubles gUU = (cdoubles)(unsigned long long)(a.UU + (size_t)g * set_cols + (size_t)a.col0);
+    // (v.w, loc.w) of the columns (carried log-prior), the same way
+    const cdoubles gNL =
+        (cdoubles)(unsigned long long)(NORMP ? a.NL + 2 * ((size_t)g * set_cols + (size_t)a.col0) : a.UU);
     const uint32_t gid = s.walker0 + (uint32_t)w;
     // stuck test (mcmc.py:717-743) on integers: (double)n > m  <=>  n > floor(m) for n integer
     const double mt10 = s.max_tries * 10.0;
@@ -258,8 +278,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         // (the LDS address of the step's column is CARRIED and passes through the empty asms in
         // place: a laundered copy of a pointer that stays live costs a v_mov per step)
         unsigned coff = lds_offset(cur + c);
+        unsigned woff = NORMP ? lds_offset(sW + (k & 1) * CHUNK + c) : 0u;
 #pragma unroll 1
-        for (int sl = 0; sl < cols; ++sl, coff += COLB * 16) {
+        for (int sl = 0; sl < cols; ++sl, coff += COLB * 16, woff += NORMP ? COLB * 8 : 0) {
             {
                 {
                     // Variates: EIGHT consecutive steps (an aligned octet of the global step index)
@@ -283,6 +304,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     sv.next();
                     const double uu = gUU[base + sl];   // (wave-uniform address: a scalar load)
                     const lds_pairs col = (lds_pairs)(unsigned long long)coff;
+                    const lds_doubles wcol = (lds_doubles)(unsigned long long)woff;
                     double pc = 0.0, sc = 0.0;
                     // (the support test is kept as the wave's lane mask: every comparison lands
                     // in a scalar register pair and the ANDs run on the scalar unit)
@@ -306,14 +328,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
                         }
                         pc = fma(y[kk], p.y, pc);   // (y . u: the log-likelihood is carried)
-                        if (NORMP) {
-                            const int i = 4 * kk + c;
-                            const double loc = kNormInRegs ? nloc[kk] : sNA[i].x;
-                            const double inv = kNormInRegs ? ninv[kk] : sNA[i].y;
-                            const double mls = kNormInRegs ? nmls[kk] : sNM[i];
-                            const double qq = (t - loc) * inv;
-                            sc = sc + fma(-0.5 * qq, qq, mls);
-                        }
+                        if (NORMP) sc = fma(x[kk], wcol[4 * kk], sc);   // (x . w: the log-prior is carried)
                     };
                     pair_t pk[KEEP ? DQ : 1];
                     if constexpr (KEEP) {
@@ -372,8 +387,14 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // chi2(y + r u) - chi2(y) = r (2 y.u + r |u|^2): the trial's log-likelihood from
                     // the carried one (step_core_inc, `carry`)
                     const double yu = quad_sum(pc);
-                    const double lp = s.uniform_logp + (NORMP ? quad_sum(sc) : 0.0);
-                    const double ll = fma(-0.5 * r, fma(r, uu, yu + yu), llik);
+                    const double mhr = -0.5 * r;
+                    double lp = s.uniform_logp;
+                    if (NORMP) {
+                        // lp(x + r v) - lp(x) = -r/2 (r v.w + 2 (x.w - loc.w)) (step_core_inc, `carry_p`)
+                        const double xw = quad_sum(sc) - gNL[2 * (base + sl) + 1];
+                        lp = fma(mhr, fma(r, gNL[2 * (base + sl)], xw + xw), lpri);
+                    }
+                    const double ll = fma(mhr, fma(r, uu, yu + yu), llik);
                     // (outside the support lt is not used; an overflow gives lt = -inf or NaN,
                     // which fail both comparisons like the specification's explicit lt != -inf)
                     const double lt = lp + ll;
@@ -921,6 +942,34 @@ __global__ void __launch_bounds__(256) whiten_directions_kernel(const IncDirArgs
         if (part == 0)
             a.UU[(size_t)g * a.out_total + ocol] = (sq[0][l] + sq[1][l]) + (sq[2][l] + sq[3][l]);
     }
+    if (a.VW) {
+        // the carried log-prior's stream (step_inc_kernel MODE 2; orc_direction_prior):
+        // w_j = (v_j / s_j) / s_j -- 1/s_j = 0 where no normal prior is --, and v.w, loc.w as chain
+        // p over the rows j = p (mod 4) ascending, one wave each, then (s0 + s1) + (s2 + s3)
+        __shared__ double sn[2][4][64];
+        const int dpad = 4 * a.dq;
+        const cdoubles pr = (cdoubles)(unsigned long long)a.prior;
+        double* __restrict__ wout = a.VW + ((size_t)g * a.out_total + ocol) * dpad;
+        double nn = 0.0, lw = 0.0;
+        for (int j = part; j < dpad; j += 4) {
+            double w = 0.0;
+            if (j < d) {
+                const double inv = pr[3 * dpad + j], v = sv[j * 64 + l];
+                w = (v * inv) * inv;
+                nn = fma(v, w, nn);
+                lw = fma(pr[2 * dpad + j], w, lw);
+            }
+            wout[j] = w;
+        }
+        sn[0][part][l] = nn;
+        sn[1][part][l] = lw;
+        __syncthreads();
+        if (part == 0) {
+            double2* __restrict__ nl = (double2*)a.NL + ((size_t)g * a.out_total + ocol);
+            *nl = make_double2((sn[0][0][l] + sn[0][1][l]) + (sn[0][2][l] + sn[0][3][l]),
+                               (sn[1][0][l] + sn[1][1][l]) + (sn[1][2][l] + sn[1][3][l]));
+        }
+    }
 }
 
 // Mixtures: the same per mode, written as PLANES -- VU[g][step][0] = v, [1 + k] = u_k = L_k^-1 v,
@@ -1328,9 +1377,12 @@ hipError_t dispatch_inc_mix(const IncStepArgs& a, hipStream_t st)
 template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
-    constexpr int C = inc_chunk(DQ);
     const int mode = a.has_norm ? 2 : ((a.box && a.box_lo == 0.0) ? 0 : 1);   // MODE 0: [0, hi]
-    const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    // (MODE 2: the chunks hold the carried log-prior's stream as well, 24 bytes per dimension)
+    const int C = mode == 2 ? inc_chunk(DQ, true) : inc_chunk(DQ);
+    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    if (mode == 2 && (!a.VW || !a.NL)) return hipErrorInvalidValue;
+    if (mode == 2 && DQ >= 29 && (a.anchor & 2)) return hipErrorInvalidValue;   // (no room for the refresh)
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);
     static const kern_t kerns[6] = {
@@ -1359,9 +1411,12 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
-    constexpr int C = inc_chunk(DQ);
     const int mode = a.has_norm ? 2 : ((a.box && a.box_lo == 0.0) ? 0 : 1);   // MODE 0: [0, hi]
-    const size_t lds = sizeof(double2) * (2 * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    // (MODE 2: the chunks hold the carried log-prior's stream as well, 24 bytes per dimension)
+    const int C = mode == 2 ? inc_chunk(DQ, true) : inc_chunk(DQ);
+    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    if (mode == 2 && (!a.VW || !a.NL)) return hipErrorInvalidValue;
+    if (mode == 2 && DQ >= 29 && (a.anchor & 2)) return hipErrorInvalidValue;   // (no room for the refresh)
     const bool unit_t = a.s.temperature == 1.0;
     typedef void (*kern_t)(const IncStepArgs);
     static const kern_t kerns[12] = {

@@ -251,6 +251,13 @@ struct IncStepArgs {
     // before the carried log-likelihood is re-anchored on it; mean = the mode's mean [d]
     int vu_cols, col0;
     const double* mean;
+    // step_inc_kernel with normal priors (round 5, `carried log-prior`; oracle: carries_prior): the
+    // log-prior moves along the direction like the log-likelihood,
+    //     lp(x + r v) = fma(-r / 2, fma(r, v.w, 2 (x.w - loc.w)), lp(x)),   w_i = (v_i / s_i) / s_i,
+    // with VW[G][n_steps][4 dq] = w of every column (zero beyond d and where no normal prior is)
+    // and NL[G][n_steps][2] = (v.w, loc.w) in the four-chain pattern; re-anchored with `anchor`
+    const double* VW;
+    const double* NL;
 };
 
 struct IncDirArgs {
@@ -272,6 +279,11 @@ struct IncDirArgs {
     // step_inc_kernel carries the log-likelihood along the direction (oracle: orc_direction_norms);
     // mixtures (the plane kernels): [G][out_total][K], |u_k|^2 of every mode
     double* UU;
+    // carried log-prior (IncStepArgs::VW, NL; null: not wanted): prior = the engine's table
+    // [5][4 dq] (lo, hi, loc, 1/scale, mls)
+    const double* prior;
+    double* VW;
+    double* NL;
 };
 
 // Launchers of the d > 32 kernels (walker_kernels_big.hip, one TU per accumulator count).

@@ -816,10 +816,60 @@ static inline int carries_loglike(const orc_problem* p, const orc_state* st)
     return 1;
 }
 
+/* ... and with NORMAL PRIORS the log-prior as well (step_inc_kernel MODE 2; round 5):
+ *     lp(x + r v) - lp(x) = -1/2 sum_i ((t_i - loc_i)^2 - (x_i - loc_i)^2) / s_i^2
+ *                         = -r/2 (r v.w + 2 (x.w - loc.w)),      w_i = (v_i / s_i) / s_i,
+ * so the trial's lp_t = fma(-0.5 r, fma(r, v.w, xw + xw), lp), xw = x.w - loc.w, with w, v.w and
+ * loc.w formed once per direction (orc_direction_prior) and x.w in the four-chain pattern: one fma
+ * per dimension and trial instead of a subtraction, two products, an fma and an addition.  Like
+ * the log-likelihood it is re-anchored (on x) wherever y is refreshed: orc_anchor_loglike.
+ * The rule is the engine's (capi.hip: inc_carries_prior). */
+static inline int carries_prior(const orc_problem* p, const orc_state* st)
+{
+    if (!carries_loglike(p, st) || p->has_periodic) return 0;
+    if (p->blocking && p->blocking->drag_last_slow >= 0) return 0;
+    for (int i = 0; i < p->d; ++i)
+        if (p->kind[i] == 1) return 1;
+    return 0;
+}
+
+/* the normal terms of the log-prior in incremental mode: four chains over i mod 4 */
+static inline double inc_logprior(const orc_problem* p, const double* t)
+{
+    double sc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < p->d; ++i)
+        if (p->kind[i] == 1) {
+            /* (multiplication by the reciprocal of the scale, formed once: 1 ulp from the
+             * division of eval_point, a fifth of its instructions) */
+            double q = (t[i] - p->loc[i]) * (1.0 / p->scale[i]);
+            sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, p->mls[i]);
+        }
+    return p->uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
+}
+
+/* Wd[c*d + i] = w_i of column c, NL[2c] = v.w, NL[2c + 1] = loc.w (four chains over i mod 4) */
+void orc_direction_prior(const orc_problem* p, int ncol, const double* V, double* Wd, double* NL)
+{
+    const int d = p->d;
+    for (int c = 0; c < ncol; ++c) {
+        double nn[4] = {0.0, 0.0, 0.0, 0.0}, lw[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < d; ++i) {
+            const double inv = p->kind[i] == 1 ? 1.0 / p->scale[i] : 0.0;
+            const double v = V[(size_t)c * d + i], w = (v * inv) * inv;
+            Wd[(size_t)c * d + i] = w;
+            nn[i & 3] = fma(v, w, nn[i & 3]);
+            if (p->kind[i] == 1) lw[i & 3] = fma(p->loc[i], w, lw[i & 3]);
+        }
+        NL[2 * c] = (nn[0] + nn[1]) + (nn[2] + nn[3]);
+        NL[2 * c + 1] = (lw[0] + lw[1]) + (lw[2] + lw[3]);
+    }
+}
+
 void orc_anchor_loglike(const orc_problem* p, orc_state* st, int w)
 {
     const double* y = st->y + (size_t)w * p->d;
     st->loglike[w] = -0.5 * (p->cnorm[0] + four_chain_squares(y, p->d));
+    if (carries_prior(p, st)) st->logprior[w] = inc_logprior(p, st->x + (size_t)w * p->d);
     st->logpost[w] = st->logprior[w] + st->loglike[w];
 }
 
@@ -862,11 +912,12 @@ void orc_anchor_modes(const orc_problem* p, orc_state* st, int w)
  * combined (s0 + s1) + (s2 + s3) -- for every d in this mode.  u: [K] pointers to the mode's
  * whitened direction of this step.  K > 1: log-sum-exp as in eval_point. */
 static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, const double* v,
-                                const double* const* u, double uu, const double* uu_k, double r,
-                                double exp_draw)
+                                const double* const* u, double uu, const double* uu_k,
+                                const double* wp, const double* nl, double r, double exp_draw)
 {
     int d = p->d, K = p->n_modes;
     const int carry = carries_loglike(p, st);
+    const int carry_p = wp != NULL;   /* (carries_prior: the caller formed w, v.w and loc.w) */
     const int carry_k = carries_modes(p);
     double t[128], yt[16 * 128], sh[128];
     const double* x = st->x + (size_t)w * d;
@@ -895,15 +946,14 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
     double lp = -INFINITY, ll = -INFINITY, lt = -INFINITY;
     double a_new[16];   /* carry_modes: the trial's mode log-densities */
     if (inb) {
-        double sc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < d; ++i)
-            if (p->kind[i] == 1) {
-                /* (multiplication by the reciprocal of the scale, formed once: 1 ulp from the
-                 * division of eval_point, a fifth of its instructions) */
-                double q = (t[i] - p->loc[i]) * (1.0 / p->scale[i]);
-                sc[i & 3] = sc[i & 3] + fma(-0.5 * q, q, p->mls[i]);
-            }
-        lp = p->uniform_logp + ((sc[0] + sc[1]) + (sc[2] + sc[3]));
+        if (carry_p) {   /* the carried log-prior moves along the direction */
+            double sc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < d; ++i) sc[i & 3] = fma(x[i], wp[i], sc[i & 3]);
+            const double xw = ((sc[0] + sc[1]) + (sc[2] + sc[3])) - nl[1];
+            lp = fma(-0.5 * r, fma(r, nl[0], xw + xw), st->logprior[w]);
+        } else {
+            lp = inc_logprior(p, t);
+        }
         double a[16], amax = -INFINITY;
         if (carry) {
             double q[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1262,6 +1312,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
         uint64_t have_cycle = UINT64_MAX, have_f[2] = {UINT64_MAX, UINT64_MAX};
         uint64_t have_u = UINT64_MAX;
         double* U = NULL;
+        double* Wd = NULL;   /* carries_prior: w of the cycle's columns, then (v.w, loc.w) */
         for (int s = 0; s < n_steps; ++s) {
             uint64_t step = step0 + (uint64_t)s;
             uint64_t cycle = step / (uint64_t)L0;
@@ -1281,8 +1332,14 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                         for (int k = 0; k < K; ++k)
                             orc_direction_norms(p, L0, U + (size_t)k * L0 * d,
                                                 U + (size_t)K * L0 * d + (size_t)k * L0);
+                    if (carries_prior(p, st)) {
+                        if (!Wd) Wd = (double*)malloc(sizeof(double) * ((size_t)L0 * d + 2 * (size_t)L0));
+                        orc_direction_prior(p, L0, V, Wd, Wd + (size_t)L0 * d);
+                    }
                     have_u = cycle;
                 }
+                const double* wp = carries_prior(p, st) ? Wd + (size_t)col * d : NULL;
+                const double* nl = carries_prior(p, st) ? Wd + (size_t)L0 * d + 2 * col : NULL;
                 const double uu = carries_loglike(p, st) ? U[(size_t)K * L0 * d + col] : 0.0;
                 const double* uk[16];
                 double uuk[16];
@@ -1306,7 +1363,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                         walker_variates_pair(k0, k1, walker0 + (uint32_t)w, step, &r, &Ea);
                     else
                         walker_variates(k0, k1, walker0 + (uint32_t)w, step, 0, 0, &r, &Ea);
-                    total += step_core_inc(p, st, w, v, uk, uu, uuk, r, Ea);
+                    total += step_core_inc(p, st, w, v, uk, uu, uuk, wp, nl, r, Ea);
                 }
                 continue;
             }
@@ -1356,7 +1413,7 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 }
             }
         }
-        free(V); free(f1); free(Vf); free(Vstep); free(U);
+        free(V); free(f1); free(Vf); free(Vstep); free(U); free(Wd);
     }
     return total;
 }

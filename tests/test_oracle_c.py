@@ -1033,6 +1033,58 @@ def test_carried_loglikelihood_follows_the_evaluated_one_and_is_re_anchored():
     assert keep.sum() > 20 and np.array_equal(sm.loglike[keep], ll0[keep])
 
 
+def test_carried_logprior_follows_the_evaluated_one_and_is_re_anchored():
+    """Round 5 (step_inc_kernel MODE 2, oracle step_core_inc `carry_p`): with ONE mode, no periodic
+    parameter and some NORMAL priors the log-prior is carried along the direction,
+    lp_t = fma(-r/2, fma(r, v.w, 2 (x.w - loc.w)), lp) with w_i = (v_i / s_i) / s_i, instead of
+    being summed from the trial (prior.py:733-763 is what both evaluate).  (i) between two
+    refreshes the carried value stays within rounding of the log-prior evaluated from scratch at
+    the same point, also with a location four orders of magnitude above its scale; (ii) at a
+    refresh it is re-anchored on x."""
+    from oracle import cbind as O
+    d = 11
+    rng = np.random.default_rng(23)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.002
+    mean = np.full(d, 0.5)
+    mean[7] = 1000.5
+    T = O.proposal_transform(cov, 2.4)
+    kinds = [0, 1, 1, 0, 1, 0, 1, 1, 0, 1, 1]
+    a = [0.0 if k == 0 else 0.5 for k in kinds]
+    b = [1.0 if k == 0 else 0.07 + 0.01 * i for i, k in enumerate(kinds)]
+    a[7] = 1000.5
+    p = O.Problem(d, kinds, a, b, means=mean, covs=cov, T=T, group_size=64, seed=6,
+                  incremental=True)
+    x0 = mean + rng.normal(size=(128, d)) * 0.03
+    x0[:, [0, 3, 5, 8]] = np.clip(x0[:, [0, 3, 5, 8]], 1e-6, 1 - 1e-6)
+    st = O.State(p, x0)
+    st.run(40 * d - 1, n_threads=4)
+    lp, ll = p.evaluate(st.x)
+    assert st.n_accept.sum() > 128 * 40
+    err = np.max(np.abs(st.logprior - lp))
+    assert 0 < err < 1e-9, err
+    np.testing.assert_allclose(st.logpost, lp + ll, rtol=0, atol=2e-9)
+    pf = O.Problem(d, kinds, a, b, means=mean, covs=cov, T=T, group_size=64, seed=6,
+                   incremental=False)
+    st.run(1, n_threads=1)                      # (step 40 d - 1, the last one before the refresh)
+    before = st.n_accept.copy()
+    st.run(1, n_threads=1)                      # step 40 d: a refresh, then one step
+    stay = st.n_accept == before
+    assert stay.sum() > 20
+    # (ii) re-anchored: the incremental form of the normal terms (reciprocal of the scale), four
+    # chains over i mod 4 -- within rounding of eval_point's division form, and logpost exact
+    lp1, _ = pf.evaluate(st.x)
+    np.testing.assert_allclose(st.logprior[stay], lp1[stay], rtol=1e-14)
+    assert np.array_equal(st.logpost[stay], st.logprior[stay] + st.loglike[stay])
+    sc = np.zeros((128, 4))
+    for i in range(d):
+        if kinds[i]:
+            q = (st.x[:, i] - a[i]) * (1.0 / b[i])
+            sc[:, i & 3] += -0.5 * q * q + p.mls[i]
+    anchored = p.uniform_logp + ((sc[:, 0] + sc[:, 1]) + (sc[:, 2] + sc[:, 3]))
+    np.testing.assert_allclose(st.logprior[stay], anchored[stay], rtol=1e-15)
+
+
 @pytest.mark.parametrize("incremental", [True, False])
 def test_run_is_invariant_to_the_thread_split(golden, incremental):
     """orc_run cuts a wide basis group (one Haar basis for 1 024 walkers here, 4 096 at the
