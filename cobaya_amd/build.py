@@ -122,9 +122,6 @@ def build(dims=None, jobs=None, verbose=True):
         tasks.append((inc, os.path.join(OBJ, f"incremental_emit_{lo_}.o"),
                       ["-DMCMC_INC_EMIT_TU", f"-DMCMC_DQ_LO={lo_}", f"-DMCMC_DQ_HI={hi_}"],
                       _digest([inc, inc_hdr] + hdrs, extra=f"incemit{lo_}-{hi_}|{' '.join(FLAGS)}")))
-    perk = os.path.join(CSRC, "incremental_periodic.hip")   # one mode with periodic parameters
-    tasks.append((perk, os.path.join(OBJ, "incremental_periodic.o"), [],
-                  _digest([perk, inc_hdr] + hdrs, extra=" ".join(FLAGS))))
     anyk = os.path.join(CSRC, "incremental_any.hip")   # the general incremental kernel
     for part in (0, 1, 2):   # the LDS kernel + KM = 4 | KM = 8 | KM = 16 register planes
         tasks.append((anyk, os.path.join(OBJ, f"incremental_any_{part}.o"), [f"-DANY_PART={part}"],

@@ -894,7 +894,7 @@ int mcmc_hip_incremental_supported(int32_t d, int32_t n_modes, int32_t n_periodi
         const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)chunk_steps * (1 + n_drag) * 4 * dq;
         return K == 1 && n_periodic == 0 && drag_lds <= (128u << 10);
     }
-    if ((K == 1 || (K <= 4 && dq <= 16)) && (n_periodic == 0 || (K == 1 && n_periodic <= 8)))
+    if ((K == 1 || (K <= 4 && dq <= 16)) && (n_periodic == 0 || (K == 1 && n_periodic <= mcmc::kIncMaxPeriodic)))
         return 1;
     return mcmc_hip_inc_any_fits &&
            mcmc_hip_inc_any_fits(d, K, n_periodic, n_walkers, basis_group_size) ? 1 : 0;
@@ -1740,17 +1740,21 @@ bool inc_carries_modes(const mcmc_hip_ctx* h)
 }
 
 // Does the kernel that serves this engine's incremental steps carry the log-prior (round 5)?
-// step_inc_kernel (one mode, no periodic parameter, Metropolis steps; with emitted rows: no block
-// of one parameter) with some normal prior.  The oracle's rule is the same (carries_prior).
+// step_inc_kernel (one mode, Metropolis steps; up to 16 periodic parameters without emitted
+// rows; with emitted rows: no periodic parameter, no block of one parameter) with some normal
+// prior.  The oracle's rule is the same (carries_prior: where the log-likelihood is carried).
 bool inc_carries_prior(const mcmc_hip_ctx* h)
 {
     if (!h->incremental || h->K != 1 || h->drag_last_slow >= 0) return false;
     if (!(h->norm_mask4[0] | h->norm_mask4[1] | h->norm_mask4[2] | h->norm_mask4[3])) return false;
-    for (int i = 0; i < h->d; ++i)
-        if (h->periodic[i]) return false;
-    if (h->cfg.emit_capacity > 0)
+    int n_periodic = 0;
+    for (int i = 0; i < h->d; ++i) n_periodic += h->periodic[i] ? 1 : 0;
+    if (n_periodic > mcmc::kIncMaxPeriodic) return false;
+    if (h->cfg.emit_capacity > 0) {
+        if (n_periodic > 0) return false;
         for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b)
             if (h->blk_size[b] == 1) return false;
+    }
     return true;
 }
 
@@ -1889,9 +1893,9 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     int n_periodic = 0;
     for (int i = 0; i < d; ++i) n_periodic += h->periodic[i] ? 1 : 0;
     // what the tuned kernels leave out runs on the general one (incremental_any.hip): more than
-    // four modes, mixtures above d = 64, periodic parameters with a mixture, more than eight of
+    // four modes, mixtures above d = 64, periodic parameters with a mixture, more than 16 of
     // them -- Metropolis steps only
-    P.any = !P.drag && (K > 4 || (K > 1 && dq > 16) || (n_periodic > 0 && (K > 1 || n_periodic > 8)));
+    P.any = !P.drag && (K > 4 || (K > 1 && dq > 16) || (n_periodic > 0 && (K > 1 || n_periodic > mcmc::kIncMaxPeriodic)));
     P.carry = false;   // (set below, once the kernel is chosen)
     if (K < 1 || K > mcmc::kMaxModes || (P.drag && (K > 1 || n_periodic > 0)) ||
         (P.drag && drag_lds > (128u << 10)))
@@ -1922,7 +1926,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     }
     // one mode, Metropolis steps: step_inc_kernel / step_inc_periodic_kernel, which carry the
     // log-likelihood along the whitened direction and need |u|^2 of every column
-    P.carry = !P.any && !P.drag && K == 1;   // (round 5: with up to eight periodic parameters too)
+    P.carry = !P.any && !P.drag && K == 1;   // (round 5: with up to 16 periodic parameters too)
     P.fold = P.carry && n_periodic == 0;     // step_inc_kernel: y refreshed in the kernel, sets of several launches
     // ... with normal priors: the log-prior is carried as well (inc_carries_prior says the same to
     // the caller); from d = 113 on its chunks leave no room for the refresh inside the kernel
@@ -2911,7 +2915,7 @@ int mcmc_hip_incremental_carries_periodic(const mcmc_hip_ctx* h)
         return 0;
     int n = 0;
     for (int i = 0; i < h->d; ++i) n += h->periodic[i] ? 1 : 0;
-    return n >= 1 && n <= 8 ? 1 : 0;
+    return n >= 1 && n <= mcmc::kIncMaxPeriodic ? 1 : 0;
 }
 
 int mcmc_hip_incremental_carries_modes(const mcmc_hip_ctx* h)

@@ -167,13 +167,57 @@ struct StagedVariates {
     __device__ __forceinline__ void next() { off += 16u * kStagedRow; }
 };
 
+// ---------------------------------------------------------------- periodic parameters
+// (step_inc_kernel<.., PER>; prior.py:658-676 in incremental mode, oracle: step_core_inc with
+// `carry_periodic`)
+constexpr int kMaxPeriodic = kIncMaxPeriodic;   // periodic parameters step_inc_kernel serves (kernels.h)
+
+// the largest double below a finite x
+__device__ __forceinline__ double pred_double(double x)
+{
+    const long long b = __double_as_longlong(x);
+    if (x > 0.0) return __longlong_as_double(b - 1);
+    if (x < 0.0) return __longlong_as_double(b + 1);
+    return -4.9406564584124654e-324;
+}
+
+// a / w given R = RN(1 / w): the correctly rounded quotient without a division: q0 = a R,
+// q1 = fma(fma(-q0, w, a), R, q0), q2 = fma(fma(-q1, w, a), R, q1) (q1 is faithful -- its exact
+// argument is within 2^-52 ulp of a / w -- and a faithful quotient corrected once with the
+// correctly rounded reciprocal is the IEEE quotient: Markstein 1990) -- bit for bit the oracle's
+// `/`, 5 instructions instead of 30
+__device__ __forceinline__ double div_by(double a, double w, double R)
+{
+    double q = a * R;
+    q = fma(fma(-q, w, a), R, q);
+    return fma(fma(-q, w, a), R, q);
+}
+
+// LDS behind the column chunks of a launch with np periodic parameters: the wrap moves
+// [64 walkers][np] and the columns of L^-1 of the periodic dimensions [np][4 dq]
+__host__ __device__ constexpr size_t inc_periodic_lds(int dq, int np)
+{
+    return sizeof(double) * (size_t)np * (64 + 4 * (size_t)dq);
+}
+
 // columns of one LDS chunk: a multiple of 4 (the variates come in fours); 14 KiB of pairs, 32 KiB
 // from dq = 14 on (kernels of at most two waves per SIMD, i.e. two workgroups per CU: the
 // workgroup barrier between chunks comes half as often)
 // with_w: the chunk also holds the doubles of the carried log-prior's stream (24 bytes per
 // dimension and column instead of 16: MODE 2 of step_inc_kernel)
-__host__ __device__ constexpr int inc_chunk(int dq, bool with_w = false)
+// per: room for kMaxPeriodic periodic parameters (sPer, the wrap moves, the columns of L^-1)
+__host__ __device__ constexpr int inc_chunk(int dq, bool with_w = false, bool per = false)
 {
+    if (per) {
+        // four waves per SIMD (40 KB per workgroup) up to dq = 8, two (80 KB) above: what the
+        // staged variates (8.5 KB), the logarithm table (2 KB), the bounds in LDS (64 dq bytes from
+        // dq = 13 on), sPer (128 dq bytes) and inc_periodic_lds(dq, 8) leave, in bytes per
+        // dimension and column: 16, or 24 with the carried log-prior's stream
+        const int left = (dq <= 8 ? 40 : 80) * 1024 - 10752 - 64 * dq - 128 * dq -
+                         (int)inc_periodic_lds(dq, kMaxPeriodic);
+        int c = (left / (2 * (with_w ? 24 : 16)) / (4 * dq)) & ~3;
+        return c < 4 ? 4 : (c > 64 ? 64 : c);
+    }
     if (with_w) {
         int c = ((dq >= 9 ? 1364 : 600) / (4 * dq)) & ~3;
         return c < 8 ? 8 : (c > 64 ? 64 : c);

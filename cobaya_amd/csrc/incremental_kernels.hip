@@ -26,8 +26,6 @@
 
 #include "incremental_common.h"
 
-extern "C" hipError_t mcmc_hip_launch_inc_periodic(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
-
 namespace mcmc {
 namespace {
 
@@ -51,14 +49,26 @@ namespace {
 // the LDS pairs (PIPE) -- beat one even where they spill (d = 128, MODE 0: +12 % in round 2;
 // round 3, with the pairs kept in registers, one wave wins from dq = 31: see inc_keep_pairs).
 // The odd entries (13, 15) are where the per-dimension constants move from registers to LDS.
-__host__ __device__ constexpr int inc_min_waves(int dq, int mode)
+__host__ __device__ constexpr int inc_min_waves(int dq, int mode, bool per = false)
 {
+    // (periodic parameters: the LDS of a workgroup is laid out for four waves per SIMD up to
+    // dq = 8 and for two above, inc_chunk)
+    if (per) return MCMC_EXP_WAVES(STEP, dq <= 8 ? 4 : dq <= 31 ? 2 : 1);
     return MCMC_EXP_WAVES(STEP,
         mode == 0 ? (dq <= 12 ? 4 : dq <= 30 ? 2 : 1)
         : mode == 1 ? ((dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1)
         // (MODE 2, round 5: MODE 1's registers + the stream of the carried log-prior in LDS --
         // 24 bytes per dimension and column --, which four workgroups per CU hold up to dq = 8)
         : (dq <= 8 ? 4 : dq <= 31 ? 2 : 1));
+}
+
+// per-dimension bounds [lo_i, hi_i] (MODE 1, 2): in registers up to dq = 12, in LDS above.  With
+// periodic parameters the kernels at four waves per SIMD keep them in registers up to dq = 5 only:
+// at dq = 7, 8 the compiler spilled two of them INSIDE the step loop (two scratch loads and their
+// s_waitcnt vmcnt(0) per step: 2.47 ms per 1200 steps at d = 30 against 1.15 without the flag)
+__host__ __device__ constexpr bool inc_bounds_in_lds(int dq, int mode, bool per)
+{
+    return mode > 0 && (dq > 12 || (per && dq >= 6 && dq <= 8));
 }
 
 // The step's (v, u) pairs kept in registers from the trial to the commit (no second LDS read):
@@ -77,16 +87,30 @@ __host__ __device__ constexpr bool inc_keep_pairs(int dq, int mode)
 //   EMIT: every accepted step past the burn-in stores the point it LEAVES with its weight
 //   (mcmc.py:691-707: rows[w][n_rows[w]++] = (weight, logpost, logprior, loglike, x), a.s.rows /
 //   n_rows / row_cap as in the from-scratch kernels) -- the reference's own product, `emit: chains`
-template <int DQ, int MODE, bool UNIT_T, bool ONED, bool EMIT = false>
-__global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(const IncStepArgs a)
+//   PER: some parameter is PERIODIC (prior.py:658-676, Prior.reduce_periodic; up to kMaxPeriodic of
+//   them, MODE 1 or 2; specification: step_core_inc with `carry_periodic`).  The bounds of a
+//   periodic dimension are [lo, pred(hi)]: a step on which every lane of the wave is inside all
+//   its bounds (most steps) is the plain step.  Only when some lane is outside (wave-uniform
+//   branch) the rows are looked at again, branch-free: a periodic coordinate that LEFT [lo, hi)
+//   is wrapped, t' = ((t - lo) / w - floor(.)) w + lo (inside the interval the reference's
+//   expression returns t up to its own rounding; here it returns t), and when the winding number
+//   changes (floor != 0) the move sh = t' - t is carried into the whitened residual,
+//   y'_j += sh L^-1[j][i] for j >= i (ascending i), and the walker's chi2 is summed from that
+//   residual instead of moved.  (Rounds 2-4 wrapped every periodic coordinate at every step;
+//   round 5 first had a kernel of its own for this, incremental_periodic.hip, whose fast path
+//   read the bounds from LDS four rows at a time and waited for them: 1.78 ms per 1200 steps at
+//   d = 30 against 1.15 for the same bounds without the flag -- now it IS the plain step.)
+template <int DQ, int MODE, bool UNIT_T, bool ONED, bool EMIT = false, bool PER = false>
+__global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_kernel(const IncStepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem2[];
     constexpr int COLB = 4 * DQ;                 // (v, u) pairs per column
     constexpr bool NORMP = MODE == 2;
-    constexpr int C = inc_chunk(DQ, NORMP);
+    static_assert(!PER || (MODE >= 1 && !EMIT), "periodic parameters: general bounds, no emitted rows");
+    constexpr int C = inc_chunk(DQ, NORMP, PER);
     constexpr int CHUNK = C * COLB;              // pairs per chunk
-    constexpr bool kBoundsInRegs = MODE > 0 && DQ <= 12;
-    constexpr bool kBoundsInLds = MODE > 0 && DQ > 12;
+    constexpr bool kBoundsInLds = inc_bounds_in_lds(DQ, MODE, PER);
+    constexpr bool kBoundsInRegs = MODE > 0 && !kBoundsInLds;
     // (MODE 0 = ONE box [0, hi] for every dimension, BASELINE configs 2-4: its support test works
     // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
     // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step
@@ -100,7 +124,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     // d = 4 ... 52 (round-4 sweep, same box): dq 5 ... 12 gain 0.2 - 2 % (MODE 1 at d = 30: 3.9 %),
     // dq <= 4 nothing, dq = 13 at four waves (MODE 1 / 2) LOSES 5 % to spills
     constexpr int PIPE = KEEP ? 0
-        : MCMC_EXP_PIPE(inc_min_waves(DQ, MODE) <= 2 ? 4 : (DQ >= 5 && DQ <= 12) ? 4 : 0);
+        : MCMC_EXP_PIPE(inc_min_waves(DQ, MODE, PER) <= 2 ? 4 : (DQ >= 5 && DQ <= 12) ? 4 : 0);
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, c = tid & 3, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
@@ -115,6 +139,17 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     double2* const sVU = smem2;                          // [2][CHUNK]
     double* const sW = (double*)(smem2 + 2 * CHUNK);     // [2][CHUNK] doubles, NORMP only
     double2* const sLH = smem2 + 2 * CHUNK + (NORMP ? CHUNK : 0);   // [dpad] (lo, hi), kBoundsInLds only
+    // periodic parameters, behind that: the wrap moves of a step [walker of the workgroup][periodic
+    // parameter], written by the lane that owns the dimension and read by its quad, and
+    // L^-1[j][i_q] for j >= i_q, the q-th periodic dimension -- what a wrap moves y by
+    int np = 0;
+    if (PER)
+        for (int q = 0; q < 4; ++q) np += __builtin_popcount(a.periodic_mask4[q]);
+    double* const sShift = (double*)(sLH + (kBoundsInLds ? dpad : 0));   // [64][np]
+    double* const sLc = sShift + 64 * np;                                // [np][dpad]
+    __shared__ double4 sPer[PER ? dpad : 1];     // periodic dimensions: (lo, hi, w, RN(1 / w)), w = hi - lo
+    __shared__ int sPdim[PER ? kMaxPeriodic : 1];   // the periodic dimensions, ascending
+    auto is_periodic = [&](int i) { return PER && ((a.periodic_mask4[i >> 5] >> (i & 31)) & 1u); };
     const double* __restrict__ gW =
         NORMP ? a.VW + ((size_t)g * set_cols + (size_t)a.col0) * COLB : nullptr;
 
@@ -149,7 +184,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
 #ifdef MCMC_EXP_NO_FOLD
     const bool refresh_y = false;   // (timing experiment: the in-kernel refresh compiled out)
 #else
-    const bool refresh_y = !(NORMP && DQ >= 29) && (a.anchor & 2) != 0;   // wave-uniform
+    const bool refresh_y = !PER && !(NORMP && DQ >= 29) && (a.anchor & 2) != 0;   // wave-uniform
 #endif
     if (!refresh_y) stage(0);
     MCMC_EXP_BLOCK_BEGIN();
@@ -157,6 +192,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
     const double blo = a.box_lo, bhi = a.box_hi;
     const unsigned bhi_word = (unsigned)__double2hiint(bhi);   // (MODE 0: blo == +0, 0 < bhi < inf)
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
+    unsigned mine = 0;     // (PER) bit kk: dimension 4 kk + c of this lane is periodic
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
@@ -167,10 +203,49 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         if (kBoundsInRegs) {
             lo[kk] = a.prior[i];               // padded: -inf / +inf beyond d
             hi[kk] = a.prior[dpad + i];
+            // (a periodic dimension: [lo, pred(hi)] -- "t <= pred(hi)" is "t < hi": inside means
+            // that nothing has to be wrapped)
+            if (PER && in && is_periodic(i)) hi[kk] = pred_double(hi[kk]);
         }
+        if (PER && in && is_periodic(i)) mine |= 1u << kk;
     }
     if (kBoundsInLds)
-        for (int i = tid; i < dpad; i += 256) sLH[i] = make_double2(a.prior[i], a.prior[dpad + i]);
+        for (int i = tid; i < dpad; i += 256) {
+            const double bh = a.prior[dpad + i];
+            sLH[i] = make_double2(a.prior[i], (i < d && is_periodic(i)) ? pred_double(bh) : bh);
+        }
+    if (PER) {
+        for (int i = tid; i < dpad; i += 256) {
+            const double plo = a.prior[i], phi = a.prior[dpad + i];
+            sPer[i] = (i < d && is_periodic(i)) ? make_double4(plo, phi, phi - plo, 1.0 / (phi - plo))
+                                                : make_double4(0.0, 1.0, 1.0, 1.0);
+        }
+        if (tid == 0) {
+            int n = 0;
+            for (int i = 0; i < d; ++i)
+                if (is_periodic(i) && n < kMaxPeriodic) sPdim[n++] = i;
+        }
+        __syncthreads();   // (sPdim)
+        for (int e = tid; e < np * dpad; e += 256) {
+            const int j = e % dpad, q = e / dpad, i = sPdim[q];
+            sLc[e] = (j >= i && j < d) ? a.Lrow[(size_t)j * d + i] : 0.0;
+        }
+    }
+    // the slot of the periodic dimension 4 kk + c in sPdim: the periodic dimensions of the rows
+    // below (scalar) plus those of this row in the lane classes below c
+    const unsigned below_c = (1u << c) - 1u;
+    auto slot_of = [&](int kk) {
+        int n = 0;
+        for (int q = 0; q < ((4 * kk) >> 5); ++q) n += __builtin_popcount(a.periodic_mask4[q]);
+        const unsigned word = a.periodic_mask4[(4 * kk) >> 5];
+        n += __builtin_popcount(word & ((1u << ((4 * kk) & 31)) - 1u));
+        return n + __builtin_popcount((word >> ((4 * kk) & 31)) & below_c);
+    };
+    double* const myShift = sShift + (tid >> 2) * np;
+    // (wave-uniform) some lane class of row kk holds a periodic dimension
+    auto row_periodic = [&](int kk) {
+        return PER && ((a.periodic_mask4[(4 * kk) >> 5] >> ((4 * kk) & 31)) & 15u) != 0u;
+    };
     double lpost = s.logpost[w], lpri = s.logprior[w], llik = s.loglike[w];
     __shared__ pair_t sRE[kStagedPairs];   // the (r, Ea) pairs of the current octet (StagedVariates)
     if (refresh_y) {
@@ -186,7 +261,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
         // every lane then reads its rows there): read per lane straight from memory, the rolled
         // loop waited for one memory round trip per dimension -- +40 us per launch at d = 30, +260
         // at d = 100, more than the kernel it replaced (same-box A/B, profiles/r05_launch_gap.txt).
-        static_assert((NORMP ? 3 : 2) * C >= 32 || (NORMP && DQ >= 29),
+        static_assert((NORMP ? 3 : 2) * C >= 32 || (NORMP && DQ >= 29) || PER,
                       "the chunk buffers hold the deviations of the workgroup's 64 walkers");
         // (MODE 2 from d = 113 on: the chunks are too small; the host refreshes y with
         // whiten_state_kernel before every such launch -- capi.hip: IncPlan::fold)
@@ -290,7 +365,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     const unsigned long long S = s.step0 + (unsigned long long)(base + sl);
                     if ((S >> 3) != cur_oct) {   // wave-uniform: every eighth step
                         cur_oct = S >> 3;
-                        rotate_priority<inc_min_waves(DQ, MODE)>(hw_slot);
+                        rotate_priority<inc_min_waves(DQ, MODE, PER)>(hw_slot);
                         PairRng pr;
                         pr.run(s.key0, s.key1, gid, (cur_oct << 2) + (unsigned long long)c, slog);
                         sv.fill(sRE, wave, lane, c, pr, S);
@@ -365,6 +440,27 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                     // inside the prior support = all four lanes of the walker are: the AND over
                     // the quad is taken on the wave's lane mask (scalar unit, no vector work)
                     unsigned long long inside_m;   // lane mask: the walker's four lanes are all inside
+                    unsigned long long wound = 0ull;   // (PER) lanes whose coordinate wrapped with a move
+                    bool slow = false;                 // (PER, wave-uniform) some lane left some bound
+                    // (PER) the residual with the wrap moves of this step (a wrap in the wave only):
+                    // on top of every row's fma(r, u, y), the moves in ascending dimension -- the
+                    // columns of L^-1 of the periodic dimensions sit in LDS (sLc) -- for the lanes `on`
+                    auto shift_rows = [&](double (&yr)[DQ], unsigned long long on_m) {
+                        const bool on_l = __builtin_amdgcn_inverse_ballot_w64(on_m);
+#pragma unroll 1
+                        for (int q = 0; q < np; ++q) {
+                            const double sv_ = myShift[q];               // the same in the walker's quad
+                            if (lanes(sv_ != 0.0) == 0ull) continue;     // wave-uniform
+                            const int i = sPdim[q];                      // the dimension that wrapped
+                            const double* __restrict__ lc = sLc + q * dpad + c;
+#pragma unroll
+                            for (int kk = 0; kk < DQ; ++kk) {
+                                const int j = 4 * kk + c;
+                                const bool on = on_l & (sv_ != 0.0) & (j >= i) & (j < d);
+                                yr[kk] = on ? fma(sv_, lc[4 * kk], yr[kk]) : yr[kk];
+                            }
+                        }
+                    };
                     if (MODE == 0) {
                         // (ONE vector compare: "some lane is not certainly inside" is read off
                         // the mask on the scalar unit)
@@ -382,6 +478,45 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                             inside_m = quad_all_mask(inb);
                         }
                     } else {
+                        if constexpr (PER) {
+                            // ---- some lane of the wave is outside some bound (wave-uniform; rare
+                            // away from the walls except for walkers at the seam of a periodic
+                            // parameter): row by row, branch-free -- a periodic coordinate that
+                            // left [lo, hi) is wrapped (prior.py:675, the division by the period
+                            // as div_by), its move goes to the walker's slot in LDS; the support
+                            // test is taken on the wrapped coordinates
+                            slow = __builtin_expect(inb != ~0ull, 0);
+                            if (slow) {
+                                inb = ~0ull;
+                                asm volatile("" : "+v"(coff));
+                                const lds_pairs colw = (lds_pairs)(unsigned long long)coff;
+#pragma unroll
+                                for (int kk = 0; kk < DQ; ++kk) {
+                                    const bool per = (mine >> kk) & 1u;
+                                    const double tk = fma(r, colw[4 * kk].x, x[kk]);
+                                    double blo_k, bhi_k;
+                                    if (kBoundsInRegs) { blo_k = lo[kk]; bhi_k = hi[kk]; }
+                                    else { const double2 lh = sLH[4 * kk + c]; blo_k = lh.x; bhi_k = lh.y; }
+                                    const bool out = !((tk <= bhi_k) & (tk >= blo_k));
+                                    // (wave-uniform: a row without a periodic dimension has
+                                    // nothing to wrap -- its part of the support test is all)
+                                    if (!row_periodic(kk)) {
+                                        inb &= lanes(!out);
+                                        continue;
+                                    }
+                                    const double4 pw = sPer[4 * kk + c];   // (lo, hi, w, RN(1 / w)); no period: (0, 1, 1, 1)
+                                    const double yv = div_by(tk - pw.x, pw.z, pw.w);
+                                    const double fl = floor(yv);
+                                    const double tw = (yv - fl) * pw.z + pw.x;
+                                    const bool wr = per & out;
+                                    const double shk = (wr & (fl != 0.0)) ? tw - tk : 0.0;
+                                    wound |= lanes(shk != 0.0);
+                                    if (per) myShift[slot_of(kk)] = shk;
+                                    const bool ins = wr ? ((tw <= pw.y) & (tw >= pw.x)) : !out;
+                                    inb &= lanes(ins);
+                                }
+                            }
+                        }
                         inside_m = quad_all_mask(inb);
                     }
                     // chi2(y + r u) - chi2(y) = r (2 y.u + r |u|^2): the trial's log-likelihood from
@@ -394,7 +529,25 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                         const double xw = quad_sum(sc) - gNL[2 * (base + sl) + 1];
                         lp = fma(mhr, fma(r, gNL[2 * (base + sl)], xw + xw), lpri);
                     }
-                    const double ll = fma(mhr, fma(r, uu, yu + yu), llik);
+                    double ll = fma(mhr, fma(r, uu, yu + yu), llik);
+                    if constexpr (PER) {
+                        if (__builtin_expect(wound != 0ull, 0)) {   // wave-uniform, rarer still: chi2 of the walkers whose
+                            // residual took a move (any lane of the quad wrote a non-zero one) is summed anew
+                            const unsigned long long wq = ~quad_all_mask(~wound);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes
+                            double ytw[DQ];
+                            asm volatile("" : "+v"(coff));
+                            const lds_pairs colw = (lds_pairs)(unsigned long long)coff;
+#pragma unroll
+                            for (int kk = 0; kk < DQ; ++kk) ytw[kk] = fma(r, colw[4 * kk].y, y[kk]);
+                            shift_rows(ytw, ~0ull);
+                            double ps = 0.0;
+#pragma unroll
+                            for (int kk = 0; kk < DQ; ++kk) ps = fma(ytw[kk], ytw[kk], ps);
+                            const double ll_w = -0.5 * (s.cnorm0 + quad_sum(ps));
+                            ll = sel(wq, ll_w, ll);
+                        }
+                    }
                     // (outside the support lt is not used; an overflow gives lt = -inf or NaN,
                     // which fail both comparisons like the specification's explicit lt != -inf)
                     const double lt = lp + ll;
@@ -480,6 +633,28 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE)) step_inc_kernel(
                                     y[kk] = fma(ra, buf[b & 1][j].y, y[kk]);
                                 }
                             }
+                        }
+                    }
+                    if constexpr (PER) {
+                        if (slow) {   // wave-uniform: an accepted coordinate that left [lo, hi) is the wrapped one
+#pragma unroll
+                            for (int kk = 0; kk < DQ; ++kk) {
+                                if (!row_periodic(kk)) continue;   // (wave-uniform)
+                                const bool per = (mine >> kk) & 1u;
+                                double blo_k, bhi_k;
+                                if (kBoundsInRegs) { blo_k = lo[kk]; bhi_k = hi[kk]; }
+                                else { const double2 lh = sLH[4 * kk + c]; blo_k = lh.x; bhi_k = lh.y; }
+                                const bool out = !((x[kk] <= bhi_k) & (x[kk] >= blo_k));
+                                const double4 pw = sPer[4 * kk + c];
+                                const double yv = div_by(x[kk] - pw.x, pw.z, pw.w);
+                                const double fl = floor(yv);
+                                const double tw = (yv - fl) * pw.z + pw.x;
+                                x[kk] = (per & out & accept) ? tw : x[kk];   // (a walker that stays keeps its x)
+                            }
+                            // ... and the residual of a walker that accepted a wrapping trial takes
+                            // the moves (on top of fma(r, u, y): the same operations in the same
+                            // order as for the trial)
+                            if (wound != 0ull) shift_rows(y, acc_m);
                         }
                     }
                     lpost = accept ? lt : lpost;
@@ -1445,6 +1620,44 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
     return hipGetLastError();
 }
 #else
+// periodic parameters (step_inc_kernel<.., PER>): MODE 1 or 2
+template <int DQ>
+hipError_t launch_inc_periodic_dq(const IncStepArgs& a, int np, hipStream_t st)
+{
+    const int mode = a.has_norm ? 2 : 1;
+    const int C = inc_chunk(DQ, mode == 2, true);
+    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ +
+                                          (inc_bounds_in_lds(DQ, mode, true) ? 4 * DQ : 0)) +
+                       inc_periodic_lds(DQ, np);
+    if (np < 1 || np > kMaxPeriodic || a.s.rows || (a.anchor & 2)) return hipErrorInvalidValue;
+    if (mode == 2 && (!a.VW || !a.NL)) return hipErrorInvalidValue;
+    const bool unit_t = a.s.temperature == 1.0;
+    typedef void (*kern_t)(const IncStepArgs);
+    static const kern_t kerns[8] = {
+        step_inc_kernel<DQ, 1, false, false, false, true>, step_inc_kernel<DQ, 1, true, false, false, true>,
+        step_inc_kernel<DQ, 2, false, false, false, true>, step_inc_kernel<DQ, 2, true, false, false, true>,
+        step_inc_kernel<DQ, 1, false, true, false, true>, step_inc_kernel<DQ, 1, true, true, false, true>,
+        step_inc_kernel<DQ, 2, false, true, false, true>, step_inc_kernel<DQ, 2, true, true, false, true>};
+    static const std::string names[8] = {
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, false, periodic>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, true, periodic>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false, periodic>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true, periodic>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, false, periodic, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 1, true, periodic, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, false, periodic, 1-D blocks>",
+        "mcmc::step_inc_kernel<" + std::to_string(DQ) + ", 2, true, periodic, 1-D blocks>"};
+    const int v = 2 * (mode - 1) + (unit_t ? 1 : 0) + (a.colflag ? 4 : 0);
+    if (lds > 40 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kerns[v],
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    mcmc_hip_note_step_kernel(names[v].c_str());
+    hipLaunchKernelGGL(kerns[v], dim3(a.s.W / 64), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int DQ>
 hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
 {
@@ -1545,11 +1758,10 @@ hipError_t dispatch_inc(const IncStepArgs& a, hipStream_t st)
     if constexpr (DQ > MCMC_DQ_HI) {
         return hipErrorInvalidValue;
     } else {
-        const bool periodic = (a.periodic_mask4[0] | a.periodic_mask4[1] | a.periodic_mask4[2] |
-                               a.periodic_mask4[3]) != 0u;
-        if (a.dq == DQ && periodic)   // (incremental_periodic.hip)
-            return (a.n_drag > 0 || !mcmc_hip_launch_inc_periodic) ? hipErrorInvalidValue
-                                                                   : mcmc_hip_launch_inc_periodic(&a, st);
+        int np = 0;
+        for (int q = 0; q < 4; ++q) np += __builtin_popcount(a.periodic_mask4[q]);
+        if (a.dq == DQ && np > 0)
+            return a.n_drag > 0 ? hipErrorInvalidValue : launch_inc_periodic_dq<DQ>(a, np, st);
         if (a.dq == DQ) return a.n_drag > 0 ? launch_drag_dq<DQ>(a, st) : launch_inc_dq<DQ>(a, st);
         return dispatch_inc<DQ + 1>(a, st);
     }

@@ -208,6 +208,10 @@ struct GeneralDragArgs {
     int n_drag;
 };
 
+// periodic parameters step_inc_kernel<.., PER> serves (one mode, Metropolis steps, no emitted rows);
+// more: the general incremental kernels (incremental_any.hip)
+constexpr int kIncMaxPeriodic = 16;
+
 // Incremental evaluation (incremental_kernels.hip): one Gaussian mode, non-periodic priors,
 // one block; 2 <= d <= 128 with dq = ceil(d / 4) dimensions per lane, four lanes per walker.
 struct IncStepArgs {

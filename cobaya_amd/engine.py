@@ -519,7 +519,7 @@ class Engine:
         return bool(self.incremental and self._lib.mcmc_hip_incremental_carries_modes(self._h))
 
     def carries_periodic(self):
-        """One mode with periodic parameters in incremental mode: step_inc_periodic_kernel's rule
+        """One mode with periodic parameters in incremental mode: the rule of step_inc_kernel<.., periodic>
         (wrap only what leaves [lo, hi), carried log-likelihood) applies
         (mcmc_hip_incremental_carries_periodic); the oracle takes it from here."""
         return bool(self.incremental and self._lib.mcmc_hip_incremental_carries_periodic(self._h))

@@ -85,7 +85,7 @@ MCMC_HIP_API int mcmc_hip_dim_supported(int d);
 /* 1 if MCMC_HIP_FLAG_INCREMENTAL serves a Gaussian mixture of n_modes (>= 1) modes in d dimensions
  * of which n_periodic are periodic (prior.py:658-676), with n_drag interpolation steps per dragging
  * step (0: Metropolis steps), for n_walkers walkers of which basis_group_size share a proposal
- * direction: the tuned kernels (one mode; up to four at d <= 64; up to eight periodic parameters
+ * direction: the tuned kernels (one mode; up to four at d <= 64; up to 16 periodic parameters
  * of one mode; dragging of one non-periodic mode) or the general one (anything else without
  * dragging whose per-walker state -- n_modes * d doubles -- fits the LDS of a CU).  0: such a model
  * is sampled from scratch (no flag).  A pure function: no device is touched. */
@@ -382,7 +382,7 @@ MCMC_HIP_API int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
  * at the next step). */
 MCMC_HIP_API int mcmc_hip_incremental_carries_modes(const mcmc_hip_ctx* h);
 /* incremental mode, ONE mode with periodic parameters (prior.py:658-676): 1 if this configuration
- * runs on step_inc_periodic_kernel (1..8 periodic parameters, Metropolis steps, emit_capacity 0),
+ * runs on step_inc_kernel<.., periodic> (1..16 periodic parameters, Metropolis steps, emit_capacity 0),
  * whose rule since round 5 is: a periodic coordinate is wrapped only where the trial leaves
  * [lo, hi), and the log-likelihood is carried along the whitened direction, re-summed from the
  * moved residual at a step that wraps; 0: the coordinate passes through the wrap at every step

@@ -823,10 +823,11 @@ static inline int carries_loglike(const orc_problem* p, const orc_state* st)
  * loc.w formed once per direction (orc_direction_prior) and x.w in the four-chain pattern: one fma
  * per dimension and trial instead of a subtraction, two products, an fma and an addition.  Like
  * the log-likelihood it is re-anchored (on x) wherever y is refreshed: orc_anchor_loglike.
+ * A periodic parameter has a uniform prior, w_i = 0: a wrap of its coordinate moves nothing here.
  * The rule is the engine's (capi.hip: inc_carries_prior). */
 static inline int carries_prior(const orc_problem* p, const orc_state* st)
 {
-    if (!carries_loglike(p, st) || p->has_periodic) return 0;
+    if (!carries_loglike(p, st)) return 0;   /* (with periodic parameters: carry_periodic) */
     if (p->blocking && p->blocking->drag_last_slow >= 0) return 0;
     for (int i = 0; i < p->d; ++i)
         if (p->kind[i] == 1) return 1;

@@ -172,11 +172,11 @@ class OracleEngine:
         return out
 
     def carries_periodic(self):
-        """The engine's rule (mcmc_hip_incremental_carries_periodic): one mode with 1..8 periodic
-        parameters on Metropolis steps without emitted rows runs on step_inc_periodic_kernel."""
+        """The engine's rule (mcmc_hip_incremental_carries_periodic): one mode with 1..16 periodic
+        parameters on Metropolis steps without emitted rows runs on step_inc_kernel<.., periodic>."""
         drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
         n_per = 0 if self._prior is None or self._prior[3] is None else int(self._prior[3].sum())
-        return bool(self.incremental and self.K == 1 and 1 <= n_per <= 8 and not drag and self.cap == 0)
+        return bool(self.incremental and self.K == 1 and 1 <= n_per <= 16 and not drag and self.cap == 0)
 
     def carries_modes(self):
         """The engine's rule (mcmc_hip_incremental_carries_modes): step_inc_mix_kernel serves 2..4

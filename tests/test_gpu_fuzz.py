@@ -186,7 +186,7 @@ def test_random_incremental_shapes_bit_exact(seed):
 
 def draw_general_case(seed):
     """A random shape only the general incremental kernels serve (incremental_any.hip): more than
-    four modes, a mixture above d = 64, periodic parameters beside a mixture, more than eight
+    four modes, a mixture above d = 64, periodic parameters beside a mixture, more than 16
     periodic parameters -- with normal priors, temperature, burn-in, blocks (one-parameter blocks
     too), and emitted rows on half of the cases."""
     rng = np.random.default_rng(seed)
@@ -266,11 +266,11 @@ def test_random_general_incremental_shapes_bit_exact(seed):
     c = eng.counters()
     assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
     name = eng.last_step_kernel()
-    # (a draw whose periodic parameters mostly fell on normal priors is left with at most eight:
+    # (a draw whose periodic parameters mostly fell on normal priors is left with at most 16:
     # the periodic kernel's, unless rows are emitted;
     # or none: the tuned mixture kernel's)
     general = "step_inc_regs_kernel" in name or "step_inc_any_kernel" in name
-    tuned = not cap and ("step_inc_periodic_kernel" in name or "step_inc_mix_kernel" in name)
+    tuned = not cap and (("step_inc_kernel" in name and "periodic" in name) or "step_inc_mix_kernel" in name)
     assert general or tuned, name
     assert ("emit" in name) == bool(cap), name
     eng.close()

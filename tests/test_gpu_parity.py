@@ -1077,7 +1077,7 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (100, 128, 64, 3, [], {"normal": True}),
     (30, 256, 128, 3, [0, 7, 29], {}),                         # periodic parameters and a mixture
     (27, 128, 64, 5, [3], {"normal": True}),
-    (40, 128, 64, 1, list(range(0, 40, 3)), {}),               # more than eight periodic parameters
+    (40, 128, 64, 1, list(range(0, 40, 2)), {}),               # more than 16 periodic parameters
     (128, 128, 64, 1, list(range(0, 128)), {}),                # ... every one of 128
     (9, 128, 64, 6, [4], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
     (30, 1024, 256, 8, [2], {"bgs": 1024}),
@@ -1086,7 +1086,7 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (90, 128, 64, 7, [], {"normal": True})])                   # 8 planes at dq = 23
 def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
     """What the tuned incremental kernels leave out -- more than four modes, mixtures above d = 64,
-    periodic parameters with a mixture, more than eight periodic parameters -- on the general
+    periodic parameters with a mixture, more than 16 periodic parameters -- on the general
     incremental kernel (step_inc_any_kernel, residuals in LDS): bit for bit against the oracle's
     step_core_inc, carried residuals included, across the refresh at 40 cycle lengths."""
     extra = dict(extra)
@@ -1138,9 +1138,11 @@ def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
     (27, 128, 64, [3], {"normal": True}),
     (9, 128, 64, [4], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
     (33, 128, 64, [32, 1], {}),
+    (40, 128, 64, list(range(0, 40, 3)), {}),                  # 14 periodic parameters
+    (100, 128, 64, list(range(3, 100, 7)), {"normal": True}),  # 14 at d = 100, carried log-prior
     (100, 128, 64, [5, 50, 99], {})])
 def test_incremental_periodic_steps_bit_exact(d, W, gs, per, extra):
-    """Periodic parameters in incremental mode (step_inc_periodic_kernel; oracle step_core_inc):
+    """Periodic parameters in incremental mode (step_inc_kernel<.., periodic>; oracle step_core_inc):
     the coordinate is the wrapped one at every step, and a wrap that changes the winding number
     moves the carried residual by the wrap times a column of L^-1.  The periodic intervals are
     a few sigma wide around the mode, so that walkers cross the seam all the time."""
@@ -1167,7 +1169,7 @@ def test_incremental_periodic_steps_bit_exact(d, W, gs, per, extra):
         compare_state(eng, st)
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
         wraps += int(np.sum(np.abs(st.x - before)[:, per] > 0.08))
-    assert st.step > 40 * L and "step_inc_periodic_kernel" in eng.last_step_kernel()
+    assert st.step > 40 * L and "step_inc_kernel" in eng.last_step_kernel() and "periodic" in eng.last_step_kernel()
     assert wraps > 20 and eng.counters()["accepted"] == int(st.n_accept.sum())
     x = eng.get_full_state()["x"]
     assert np.all((x[:, per] >= 0.42) & (x[:, per] <= 0.58))

@@ -691,7 +691,7 @@ def test_incremental_with_periodic_parameters_is_the_same_sampler(blocked, carry
 
 @pytest.mark.parametrize("blocked", [False, True])
 def test_incremental_periodic_with_the_carried_loglikelihood(blocked):
-    """Round 5 (step_inc_periodic_kernel): a periodic coordinate is wrapped only where the trial
+    """Round 5 (step_inc_kernel<.., periodic>): a periodic coordinate is wrapped only where the trial
     leaves [lo, hi) and the log-likelihood is carried, re-summed from the moved residual at a step
     that wraps -- still the same sampler as the from-scratch run on a target at the seam (same
     decisions, coordinates to rounding: inside the interval the from-scratch run passes x through
