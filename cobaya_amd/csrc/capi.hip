@@ -373,6 +373,8 @@ struct mcmc_hip_ctx {
     // the directions of the launch a call BEGINS with are formed at that call, not at the end of
     // the previous one (step_incremental): a proposal refreshed in between is then in them at once
     bool lazy_dirs = true;
+    // step_inc_kernel: calls whose directions are formed together (MCMC_HIP_LOOKAHEAD, default 4)
+    int lookahead = 4;
     hipEvent_t T_event = nullptr;            // main stream: behind the last write of dT
     bool T_fresh = false;                    // ... which no direction set has been ordered behind yet
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
@@ -1015,6 +1017,8 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         acc(hipEventCreateWithFlags(&h->mark, hipEventDisableTiming));
         acc(hipEventCreateWithFlags(&h->T_event, hipEventDisableTiming));
         if (const char* e = getenv("MCMC_HIP_EAGER_DIRECTIONS")) h->lazy_dirs = !(e[0] && e[0] != '0');
+        // MCMC_HIP_LOOKAHEAD (developer switch): calls per direction set of step_inc_kernel; 1: a set per call
+        if (const char* e = getenv("MCMC_HIP_LOOKAHEAD")) h->lookahead = std::max(1, atoi(e));
         for (auto& D : h->dirs) acc(hipEventCreateWithFlags(&D.ready, hipEventDisableTiming));
         // MCMC_HIP_NO_PREFETCH (developer switch): directions on the main stream, in line
         h->prefetch = !getenv("MCMC_HIP_NO_PREFETCH");
@@ -1961,15 +1965,30 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         P.drag ? (int)std::max<size_t>(2, (256u << 20) / (sizeof(double) * P.ddf * (size_t)h->BG)) : 0;
     int left = n_steps;
     while (left > 0) {
+        // step_inc_kernel (P.fold), round 5 late: a set of directions reaches over SEVERAL calls --
+        // `lookahead` calls like this one -- and the calls that find their columns in it start
+        // with nothing but the moment snapshot between them and the previous step kernel (the
+        // direction kernels are latency-bound: 80 us for one launch's columns at config 2, hardly
+        // more for four).  Directions are pure functions of (group, cycle, transform): a set
+        // formed under another transform (dir_epoch) is dropped, never used.
+        bool covers = false;
+        if (P.fold) {
+            const auto& C0 = h->dirs[h->dir_cur];
+            covers = C0.n > 0 && C0.epoch == h->dir_epoch && C0.step0 <= h->step &&
+                     h->step < C0.step0 + (unsigned long long)C0.n;
+        }
         // the steps whose directions form one set: one launch (cut at the refresh of y), or --
-        // step_inc_kernel, round 5 -- as much of the call as the buffers hold
-        const IncSeg span = plan_span(P, h->step, left);
+        // step_inc_kernel -- the calls ahead as far as the buffers hold them
+        IncSeg span = plan_span(P, h->step, P.fold ? std::max(left, std::min(h->lookahead, 16) * n_steps) : left);
         auto& D = h->dirs[h->dir_cur];
-        const bool hit = D.ahead && D.step0 == span.step0 && D.n == span.n && D.epoch == h->dir_epoch;
+        if (covers) { span.step0 = D.step0; span.n = D.n; }
+        const bool hit = covers ||
+            (D.ahead && D.step0 == span.step0 && D.n == span.n && D.epoch == h->dir_epoch);
         // (a set filled ahead on stream2 -- hit or not -- must have been written before it is
         // read or overwritten here)
         if (D.ahead) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
         D.ahead = false;
+        bool wait_ready = false;   // the set is being formed on the second stream
         if (!hit) {
             // Not prepared (the first launch of a call, see below): formed on the SECOND stream
             // behind the previous step kernel (`mark`) -- beside the moment snapshot and the y
@@ -1981,24 +2000,33 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                 if (h->T_fresh) HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->T_event, 0));
                 const int rc = make_directions(h, P, span, D, h->stream2);
                 if (rc != MCMC_HIP_OK) return rc;
-                HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
+                // (the main stream waits for the set where it needs it: in front of the step
+                // kernel, BEHIND the refresh of y -- which does not read the directions and ran
+                // 24 us late behind this wait: timeline of round 5, 101 -> 77 us between the
+                // step kernels of a call that forms its set)
+                wait_ready = true;
             } else {
                 const int rc = make_directions(h, P, span, D, h->stream);
                 if (rc != MCMC_HIP_OK) return rc;
             }
             h->T_fresh = false;
         }
-        for (int done = 0; done < span.n;) {
+        // the steps of THIS call the set holds
+        const int take = P.fold
+            ? (int)std::min<unsigned long long>((unsigned long long)left,
+                                                D.step0 + (unsigned long long)D.n - h->step)
+            : span.n;
+        for (int done = 0; done < take;) {
         bool anchor = false;   // y is refreshed from x before (or, step_inc_kernel: in) this launch
         bool refresh_in_kernel = false;
         if (!h->y_valid || h->step % P.R == 0) {
             if (P.fold && done > 0) {
-                // (round 5) a launch INSIDE a call's set of directions refreshes y itself: nothing
-                // stands between it and the launch before.  The first launch of a call keeps the
-                // separate kernel: there the main stream waits for the second one (Haar bases,
-                // whitened columns) anyway, and the refresh inside the step kernel -- two barriers
-                // and a memory round trip per eight dimensions before the first chunk can be
-                // staged -- cost it 7 us (same-box A/B: whole job -0.5 %)
+                // (round 5) a launch INSIDE a call refreshes y itself: nothing stands between it
+                // and the launch before.  The first launch of a call keeps the separate kernel:
+                // the refresh inside the step kernel -- two barriers and a memory round trip per
+                // eight dimensions before the first chunk can be staged -- costs that launch 22 us
+                // (timeline: 912 against 890 us), whiten_state_kernel 14 beside the moment
+                // snapshot's host gap
                 refresh_in_kernel = true;
             } else {
                 HIP_TRY(h, mcmc_hip_launch_whiten_state(h->x.p, h->y.p, h->inc_mean.p, h->inc_Lrow.p,
@@ -2010,8 +2038,12 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         // (carried mode log-densities that no launch has written since y was set are re-anchored
         // on y: after set_state always; after a resume only if the state file did not hold them)
         if (P.carry_modes && !h->amode_valid) anchor = true;
-        const IncSeg seg = plan_segment(P, h->step, span.n - done);
+        const IncSeg seg = plan_segment(P, h->step, take - done);
         const int n = seg.n;
+        if (wait_ready) {
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
+            wait_ready = false;
+        }
         {
             Timed t(h, 0);
             mcmc::IncStepArgs a{};
@@ -2047,8 +2079,8 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.amode = P.carry_modes ? h->amode.p : nullptr;
             if (P.carry_modes) h->amode_valid = true;
             // (the launch's columns inside the set; 0 / 0: the set is this launch's own)
-            a.vu_cols = P.fold ? span.n : 0;
-            a.col0 = P.fold ? done : 0;
+            a.vu_cols = P.fold ? D.n : 0;
+            a.col0 = P.fold ? (int)(h->step - D.step0) : 0;
             a.mean = h->inc_mean.p;
             a.VW = P.carry_prior ? D.VW.p : nullptr;
             a.NL = P.carry_prior ? D.NL.p : nullptr;
@@ -2064,6 +2096,26 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         h->step += (unsigned long long)n;
         done += n;
         }   // launches of the span
+        if (P.fold) {
+            // the set is kept while it has columns left; the next one is formed by the call that
+            // needs it (see lazy_dirs below), behind this step kernel
+            HIP_TRY(h, hipEventRecord(h->mark, h->stream));
+            h->mark_valid = true;
+            left -= take;
+            if (h->step >= D.step0 + (unsigned long long)D.n) {
+                if (h->prefetch && h->stream2 && (left > 0 || !h->lazy_dirs)) {
+                    auto& N = h->dirs[h->dir_cur ^ 1];
+                    const IncSeg nxt = plan_span(
+                        P, h->step, std::max(left, std::min(h->lookahead, 16) * n_steps));
+                    HIP_TRY(h, hipStreamWaitEvent(h->stream2, h->mark, 0));
+                    const int rc = make_directions(h, P, nxt, N, h->stream2);
+                    if (rc != MCMC_HIP_OK) return rc;
+                    N.ahead = true;
+                }
+                h->dir_cur ^= 1;
+            }
+            continue;
+        }
         if (h->prefetch) {
             // the launch expected next: the rest of this call, or a call like this one.  Its
             // directions are computed on the second stream BEHIND this step kernel (the event
