@@ -896,7 +896,7 @@ int mcmc_hip_incremental_supported(int32_t d, int32_t n_modes, int32_t n_periodi
         const size_t drag_lds = sizeof(double) * 2 * 2 * (size_t)chunk_steps * (1 + n_drag) * 4 * dq;
         return K == 1 && n_periodic == 0 && drag_lds <= (128u << 10);
     }
-    if ((K == 1 || (K <= 4 && dq <= 16)) && (n_periodic == 0 || (K == 1 && n_periodic <= mcmc::kIncMaxPeriodic)))
+    if ((K == 1 || mcmc::inc_mix_serves(K, dq)) && (n_periodic == 0 || (K == 1 && n_periodic <= mcmc::kIncMaxPeriodic)))
         return 1;
     return mcmc_hip_inc_any_fits &&
            mcmc_hip_inc_any_fits(d, K, n_periodic, n_walkers, basis_group_size) ? 1 : 0;
@@ -1727,20 +1727,20 @@ int blocked_basis(mcmc_hip_ctx* h, int which, unsigned long long c0, int ncyc, i
 
 
 // Does the kernel that serves this engine's incremental steps carry the log-density of every mode
-// (round 5)?  step_inc_mix_kernel: 2..4 modes, d <= 64, no periodic parameter, Metropolis steps,
-// no emitted rows.
+// (round 5)?  step_inc_mix_kernel: 2..4 modes at d <= 64, 5 and 6 at d <= 32 (kernels.h:
+// inc_mix_serves), no periodic parameter, Metropolis steps, no emitted rows.
 bool inc_carries_modes(const mcmc_hip_ctx* h)
 {
     if (!h->incremental || h->K < 2 || h->drag_last_slow >= 0) return false;
     for (int i = 0; i < h->d; ++i)
         if (h->periodic[i]) return false;
-    // step_inc_mix_kernel: 2..4 modes at d <= 64 without emitted rows.  Everything else goes to
+    // step_inc_mix_kernel without emitted rows.  Everything else goes to
     // the general kernels (incremental_any.hip), which sum every chi2_k from the trial's residual:
     // the carried form was built for the register-plane kernel as well and measured SLOWER there
     // (K = 5 / 8 / 16 at d = 30: 9.66 -> 8.26, 7.37 -> 6.46, 2.09 -> 1.85e9 evals/s,
     // profiles/r05_carried_modes.txt) -- those kernels wait on latency at one or two waves per
     // SIMD, and the extra K registers cost more than the d / 4 fewer FMAs per mode bought
-    return h->K <= 4 && (h->d + 3) / 4 <= 16 && h->cfg.emit_capacity == 0;
+    return mcmc::inc_mix_serves(h->K, (h->d + 3) / 4) && h->cfg.emit_capacity == 0;
 }
 
 // Does the kernel that serves this engine's incremental steps carry the log-prior (round 5)?
@@ -1899,7 +1899,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
     // what the tuned kernels leave out runs on the general one (incremental_any.hip): more than
     // four modes, mixtures above d = 64, periodic parameters with a mixture, more than 16 of
     // them -- Metropolis steps only
-    P.any = !P.drag && (K > 4 || (K > 1 && dq > 16) || (n_periodic > 0 && (K > 1 || n_periodic > mcmc::kIncMaxPeriodic)));
+    P.any = !P.drag && ((K > 1 && !mcmc::inc_mix_serves(K, dq)) || (n_periodic > 0 && (K > 1 || n_periodic > mcmc::kIncMaxPeriodic)));
     P.carry = false;   // (set below, once the kernel is chosen)
     if (K < 1 || K > mcmc::kMaxModes || (P.drag && (K > 1 || n_periodic > 0)) ||
         (P.drag && drag_lds > (128u << 10)))

@@ -1226,6 +1226,8 @@ __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
     return c < 4 ? 4 : (c > 64 ? 64 : c);
 }
 
+// five and six modes: up to dq = kIncMixWideDq (d <= 32) -- 7 dq doubles of state per lane
+constexpr int kMixWideDq = kIncMixWideDq;
 __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
 {
     // measured (round 5, tools/mix_bench.py d:K over builds held to 2..4 waves, 65 536 walkers; ms per
@@ -1331,6 +1333,17 @@ step_inc_mix_kernel(const IncStepArgs a)
         if (KM > 1) Ssum = fma(wk[1], quad_perm<0x55>(e_mine), Ssum);
         if (KM > 2) Ssum = fma(wk[2 < KM ? 2 : 0], quad_perm<0xAA>(e_mine), Ssum);
         if (KM > 3) Ssum = fma(wk[3 < KM ? 3 : 0], quad_perm<0xFF>(e_mine), Ssum);
+        if (KM > 4) {   // modes 4 .. 7: a second exponential per lane, lane class k - 4 takes mode k
+            double mine2 = ak[4 < KM ? 4 : 0];
+            if (KM > 5) mine2 = sel(class1, ak[5 < KM ? 5 : 0], mine2);
+            if (KM > 6) mine2 = sel(class2, ak[6 < KM ? 6 : 0], mine2);
+            if (KM > 7) mine2 = sel(class3, ak[7 < KM ? 7 : 0], mine2);
+            const double e2 = dexp_tab(mine2 - amax, etab);
+            Ssum = fma(wk[4 < KM ? 4 : 0], quad_perm<0x00>(e2), Ssum);
+            if (KM > 5) Ssum = fma(wk[5 < KM ? 5 : 0], quad_perm<0x55>(e2), Ssum);
+            if (KM > 6) Ssum = fma(wk[6 < KM ? 6 : 0], quad_perm<0xAA>(e2), Ssum);
+            if (KM > 7) Ssum = fma(wk[7 < KM ? 7 : 0], quad_perm<0xFF>(e2), Ssum);
+        }
         return dlog_tab(Ssum, slog) + amax;
     };
     // the carried log-density of every mode (the same value in the four lanes of a walker)
@@ -1575,10 +1588,15 @@ hipError_t dispatch_inc_mix(const IncStepArgs& a, hipStream_t st)
     if constexpr (DQ > MCMC_DQ_HI) {
         return hipErrorInvalidValue;
     } else {
-        if (a.dq == DQ)
+        if (a.dq == DQ) {
+            if constexpr (DQ <= kMixWideDq) {
+                if (a.n_modes == 5 || a.n_modes == 6)
+                    return a.n_modes == 5 ? launch_inc_mix<DQ, 5>(a, st) : launch_inc_mix<DQ, 6>(a, st);
+            }
             return a.n_modes == 2 ? launch_inc_mix<DQ, 2>(a, st)
                  : a.n_modes == 3 ? launch_inc_mix<DQ, 3>(a, st)
                  : a.n_modes == 4 ? launch_inc_mix<DQ, 4>(a, st) : hipErrorInvalidValue;
+        }
         return dispatch_inc_mix<DQ + 1>(a, st);
     }
 }

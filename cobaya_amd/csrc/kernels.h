@@ -208,6 +208,17 @@ struct GeneralDragArgs {
     int n_drag;
 };
 
+// step_inc_mix_kernel (carried mode log-densities): 2..4 modes up to d = 64, 5 and 6 as far as
+// the state -- dq (K + 1) doubles per lane -- leaves the body its registers at two waves per SIMD
+// (K = 5: d <= 32, K = 6: d <= 28; measured at d = 30, ms per 1200 steps of 65 536 walkers:
+// K = 5 7.71 on the register-plane kernel -> 5.84 here; K = 6 at dq = 8 spills: 13.3 against ~8.6);
+// everything else: the general incremental kernels
+constexpr int kIncMixWideDq = 8;
+__host__ __device__ constexpr bool inc_mix_serves(int K, int dq)
+{
+    return K >= 2 && ((K <= 4 && dq <= 16) || (K <= 6 && dq <= kIncMixWideDq && dq * (K + 1) <= 50));
+}
+
 // periodic parameters step_inc_kernel<.., PER> serves (one mode, Metropolis steps, no emitted rows);
 // more: the general incremental kernels (incremental_any.hip)
 constexpr int kIncMaxPeriodic = 16;

@@ -180,11 +180,11 @@ class OracleEngine:
 
     def carries_modes(self):
         """The engine's rule (mcmc_hip_incremental_carries_modes): step_inc_mix_kernel serves 2..4
-        modes at d <= 64 without periodic parameters, dragging or emitted rows."""
+        modes at d <= 64 (5 at d <= 32, 6 at d <= 28) without periodic parameters, dragging or emitted rows."""
         drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
         periodic = self._prior is not None and self._prior[3] is not None and self._prior[3].any()
-        return bool(self.incremental and self.K is not None and 2 <= self.K <= 4 and self.d <= 64
-                    and not drag and not periodic and self.cap == 0)
+        mix = self.K is not None and ((2 <= self.K <= 4 and self.d <= 64) or (5 <= self.K <= 6 and self.d <= 32 and ((self.d + 3) // 4) * (self.K + 1) <= 50))
+        return bool(self.incremental and mix and not drag and not periodic and self.cap == 0)
 
     def set_full_state(self, st):
         self.set_state(st["x"])

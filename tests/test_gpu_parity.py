@@ -1016,9 +1016,11 @@ def test_own_basis_periodic_rows_and_offsets_bit_exact():
 @pytest.mark.parametrize("d,W,gs,K,normal,T", [
     (4, 256, 64, 2, False, 1.0), (30, 256, 64, 2, False, 1.0), (30, 256, 256, 3, False, 1.0),
     (9, 128, 64, 4, True, 1.0), (64, 128, 64, 2, False, 2.0), (27, 256, 128, 2, True, 1.0),
-    (30, 256, 64, 2, "box off the origin", 1.0), (30, 256, 64, 4, "bounds differ", 1.0)])
+    (30, 256, 64, 2, "box off the origin", 1.0), (30, 256, 64, 4, "bounds differ", 1.0),
+    (30, 256, 64, 5, False, 1.0), (28, 128, 64, 6, True, 1.7), (32, 128, 64, 5, True, 1.0), (6, 256, 128, 6, False, 1.0),
+    (27, 128, 64, 5, "bounds differ", 1.0)])
 def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
-    """Mixtures of 2..4 modes in incremental mode (step_inc_mix_kernel): a carried residual and
+    """Mixtures of 2..4 modes (5 and 6 up to d = 32) in incremental mode (step_inc_mix_kernel): a carried residual and
     a whitened direction per mode, the log-sum-exp of eval_point -- bit for bit against the
     oracle, across the refresh at 40 d steps.  With one box for all dimensions the kernel takes
     the support test on the extremes of the trial (its padded dimensions rest at the middle of
@@ -1070,8 +1072,9 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
 
 
 @pytest.mark.parametrize("d,W,gs,K,per,extra", [
-    (4, 256, 64, 5, [], {}),                                   # more than four modes
-    (30, 256, 64, 6, [], {"T": 1.7, "burn_in": 2}),
+    (4, 256, 64, 7, [], {}),                                   # more than six modes
+    (30, 256, 64, 8, [], {"T": 1.7, "burn_in": 2}),
+    (36, 128, 64, 5, [], {}),                                  # five above d = 32
     (10, 128, 64, 16, [], {}),                                 # kMaxModes
     (80, 128, 64, 2, [], {}),                                  # a mixture above d = 64
     (100, 128, 64, 3, [], {"normal": True}),
@@ -1081,7 +1084,7 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (128, 128, 64, 1, list(range(0, 128)), {}),                # ... every one of 128
     (9, 128, 64, 6, [4], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
     (30, 1024, 256, 8, [2], {"bgs": 1024}),
-    (9, 128, 64, 6, [], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
+    (9, 128, 64, 7, [], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
     (40, 128, 64, 12, [], {}),                                 # 16 register planes, 12 live
     (90, 128, 64, 7, [], {"normal": True})])                   # 8 planes at dq = 23
 def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
