@@ -111,6 +111,13 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     constexpr int CHUNK = C * COLB;              // pairs per chunk
     constexpr bool kBoundsInLds = inc_bounds_in_lds(DQ, MODE, PER);
     constexpr bool kBoundsInRegs = MODE > 0 && !kBoundsInLds;
+    // (round 5 late) kernels at four waves per SIMD whose bounds sit in LDS -- periodic parameters
+    // at dq = 6..8 -- keep single-precision copies of them in registers, rounded inward and moved
+    // in by one more ulp (2 dq registers): the support test of a step is taken on those, and the
+    // double-precision bounds are read from LDS only when some coordinate is not inside for
+    // certain.  (Read from LDS at every step the compiler, short of registers, fetched them one
+    // row at a time -- eight dependent round trips per trial: SQ_WAIT_ANY 49 % of the wave-cycles.)
+    constexpr bool kFloatBounds = PER && kBoundsInLds && DQ <= 8;
     // (MODE 0 = ONE box [0, hi] for every dimension, BASELINE configs 2-4: its support test works
     // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
     // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step
@@ -138,14 +145,19 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     constexpr int dpad = 4 * DQ;
     double2* const sVU = smem2;                          // [2][CHUNK]
     double* const sW = (double*)(smem2 + 2 * CHUNK);     // [2][CHUNK] doubles, NORMP only
-    double2* const sLH = smem2 + 2 * CHUNK + (NORMP ? CHUNK : 0);   // [dpad] (lo, hi), kBoundsInLds only
+    // [dpad] (lo, hi), kBoundsInLds only.  A STATIC array (round 5 late): behind the chunks in the
+    // dynamic block the compiler could not tell its reads from the chunk DMA's writes and put an
+    // s_waitcnt vmcnt(0) in front of the first one of every step -- the next chunk's transfer
+    // was waited for at once instead of at the end of the chunk
+    __shared__ double2 sLHs[kBoundsInLds ? dpad : 1];
+    double2* const sLH = sLHs;
     // periodic parameters, behind that: the wrap moves of a step [walker of the workgroup][periodic
     // parameter], written by the lane that owns the dimension and read by its quad, and
     // L^-1[j][i_q] for j >= i_q, the q-th periodic dimension -- what a wrap moves y by
     int np = 0;
     if (PER)
         for (int q = 0; q < 4; ++q) np += __builtin_popcount(a.periodic_mask4[q]);
-    double* const sShift = (double*)(sLH + (kBoundsInLds ? dpad : 0));   // [64][np]
+    double* const sShift = (double*)(smem2 + 2 * CHUNK + (NORMP ? CHUNK : 0));   // [64][np]
     double* const sLc = sShift + 64 * np;                                // [np][dpad]
     __shared__ double4 sPer[PER ? dpad : 1];     // periodic dimensions: (lo, hi, w, RN(1 / w)), w = hi - lo
     __shared__ int sPdim[PER ? kMaxPeriodic : 1];   // the periodic dimensions, ascending
@@ -193,6 +205,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     const unsigned bhi_word = (unsigned)__double2hiint(bhi);   // (MODE 0: blo == +0, 0 < bhi < inf)
     double x[DQ], y[DQ], lo[kBoundsInRegs ? DQ : 1], hi[kBoundsInRegs ? DQ : 1];
     unsigned mine = 0;     // (PER) bit kk: dimension 4 kk + c of this lane is periodic
+    float flo[kFloatBounds ? DQ : 1], fhi[kFloatBounds ? DQ : 1];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
@@ -208,6 +221,18 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
             if (PER && in && is_periodic(i)) hi[kk] = pred_double(hi[kk]);
         }
         if (PER && in && is_periodic(i)) mine |= 1u << kk;
+        if (kFloatBounds) {
+            const double blo_d = a.prior[i];
+            double bhi_d = a.prior[dpad + i];
+            if (in && is_periodic(i)) bhi_d = pred_double(bhi_d);
+            // lo: rounded up, then one ulp further in; hi: rounded down, then one further in
+            // (infinite bounds -- the padding, a dimension without a bound -- stay infinite)
+            float fl = __double2float_ru(blo_d), fh = __double2float_rd(bhi_d);
+            if (fl > -INFINITY) fl = nextafterf(fl, INFINITY);
+            if (fh < INFINITY) fh = nextafterf(fh, -INFINITY);
+            flo[kk] = fl;
+            fhi[kk] = fh;
+        }
     }
     if (kBoundsInLds)
         for (int i = tid; i < dpad; i += 256) {
@@ -398,6 +423,12 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
                             hmx = hmx > h ? hmx : h;
                         }
                         else if (kBoundsInRegs) inb &= lanes(t <= hi[kk]) & lanes(t >= lo[kk]);
+                        else if (kFloatBounds) {
+                            // (inside for certain: the trial rounded to single precision lies
+                            // within bounds rounded INWARD and moved in by one more ulp)
+                            const float tf = __double2float_rn(t);
+                            inb &= lanes(tf <= fhi[kk]) & lanes(tf >= flo[kk]);
+                        }
                         else {
                             const double2 lh = sLH[4 * kk + c];
                             inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
@@ -478,6 +509,22 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
                             inside_m = quad_all_mask(inb);
                         }
                     } else {
+                        if constexpr (kFloatBounds && !PER) {
+                            // (wave-uniform, rare: some trial coordinate is not inside for certain
+                            // -- within 2^-23 of a bound, or outside: the exact comparisons, rows
+                            // from LDS; with periodic parameters the pass below does them)
+                            if (__builtin_expect(inb != ~0ull, 0)) {
+                                inb = ~0ull;
+                                asm volatile("" : "+v"(coff));
+                                const lds_pairs colx = (lds_pairs)(unsigned long long)coff;
+#pragma unroll
+                                for (int kk = 0; kk < DQ; ++kk) {
+                                    const double t = fma(r, colx[4 * kk].x, x[kk]);
+                                    const double2 lh = sLH[4 * kk + c];
+                                    inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
+                                }
+                            }
+                        }
                         if constexpr (PER) {
                             // ---- some lane of the wave is outside some bound (wave-uniform; rare
                             // away from the walls except for walkers at the seam of a periodic
@@ -1610,7 +1657,7 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
     const int mode = a.has_norm ? 2 : ((a.box && a.box_lo == 0.0) ? 0 : 1);   // MODE 0: [0, hi]
     // (MODE 2: the chunks hold the carried log-prior's stream as well, 24 bytes per dimension)
     const int C = mode == 2 ? inc_chunk(DQ, true) : inc_chunk(DQ);
-    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ);   // (the bounds: a static array)
     if (mode == 2 && (!a.VW || !a.NL)) return hipErrorInvalidValue;
     if (mode == 2 && DQ >= 29 && (a.anchor & 2)) return hipErrorInvalidValue;   // (no room for the refresh)
     const bool unit_t = a.s.temperature == 1.0;
@@ -1644,9 +1691,7 @@ hipError_t launch_inc_periodic_dq(const IncStepArgs& a, int np, hipStream_t st)
 {
     const int mode = a.has_norm ? 2 : 1;
     const int C = inc_chunk(DQ, mode == 2, true);
-    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ +
-                                          (inc_bounds_in_lds(DQ, mode, true) ? 4 * DQ : 0)) +
-                       inc_periodic_lds(DQ, np);
+    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ) + inc_periodic_lds(DQ, np);
     if (np < 1 || np > kMaxPeriodic || a.s.rows || (a.anchor & 2)) return hipErrorInvalidValue;
     if (mode == 2 && (!a.VW || !a.NL)) return hipErrorInvalidValue;
     const bool unit_t = a.s.temperature == 1.0;
@@ -1682,7 +1727,7 @@ hipError_t launch_inc_dq(const IncStepArgs& a, hipStream_t st)
     const int mode = a.has_norm ? 2 : ((a.box && a.box_lo == 0.0) ? 0 : 1);   // MODE 0: [0, hi]
     // (MODE 2: the chunks hold the carried log-prior's stream as well, 24 bytes per dimension)
     const int C = mode == 2 ? inc_chunk(DQ, true) : inc_chunk(DQ);
-    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ + ((mode > 0 && DQ > 12) ? 4 * DQ : 0));
+    const size_t lds = sizeof(double2) * ((mode == 2 ? 3 : 2) * C * 4 * DQ);   // (the bounds: a static array)
     if (mode == 2 && (!a.VW || !a.NL)) return hipErrorInvalidValue;
     if (mode == 2 && DQ >= 29 && (a.anchor & 2)) return hipErrorInvalidValue;   // (no room for the refresh)
     const bool unit_t = a.s.temperature == 1.0;

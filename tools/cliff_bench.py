@@ -31,8 +31,9 @@ def run(d, K, n_per, W=65536, gs=256, launches=2):
     differ = n_per < 0      # d:K:-1 -- no periodic parameter, but bounds that differ (MODE 1)
     n_per = max(n_per, 0)
     per = [int(i < n_per) for i in range(d)]
-    lo = [0.5 - 4 * sd[i] if per[i] else 0.0 for i in range(d)]
-    hi = [0.5 + 4 * sd[i] if per[i] else 1.0 for i in range(d)]
+    ns = float(os.environ.get("CLIFF_PER_SIGMAS", 4))   # (wide intervals: the seam is never reached)
+    lo = [0.5 - ns * sd[i] if per[i] else 0.0 for i in range(d)]
+    hi = [0.5 + ns * sd[i] if per[i] else 1.0 for i in range(d)]
     if differ:
         lo[0] = -0.125
     if not incremental_supported(d, K, n_per, 0, W, 4096):
