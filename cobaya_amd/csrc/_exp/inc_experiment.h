@@ -41,6 +41,9 @@
 #else
 #define MCMC_EXP_KEEP(tuned) (tuned)
 #endif
+#ifdef EXP_BOUNDS_REGS
+#define MCMC_EXP_BOUNDS_LDS(tuned) (false)
+#endif
 #ifdef EXP_NO_ROTATE
 #define MCMC_EXP_ROTATE(on) (false)
 #else

@@ -49,6 +49,16 @@ namespace {
 // the LDS pairs (PIPE) -- beat one even where they spill (d = 128, MODE 0: +12 % in round 2;
 // round 3, with the pairs kept in registers, one wave wins from dq = 31: see inc_keep_pairs).
 // The odd entries (13, 15) are where the per-dimension constants move from registers to LDS.
+// General bounds at the top of the dimension range (round 5 late): ONE wave per SIMD with
+// everything in its 512 registers -- x, y, the bounds AND the step's pairs (KEEP: one LDS read per
+// dimension and step instead of three).  Measured against the two-wave / LDS-bounds form (same box,
+// 65 536 walkers, ms per 40 d steps, MODE 1): d = 128: 36.6 -> 27.2; d = 124: 26.1 -> 25.0; below that
+// two waves win (d = 116: 18.4 against 21.0; d = 108: 16.0 / 18.8; d = 100: 14.0 / 16.4).
+__host__ __device__ constexpr bool inc_one_wave_regs(int dq, int mode, bool per)
+{
+    return !per && ((mode == 1 && dq >= 31) || (mode == 2 && dq >= 32));
+}
+
 __host__ __device__ constexpr int inc_min_waves(int dq, int mode, bool per = false)
 {
     // (periodic parameters: the LDS of a workgroup is laid out for four waves per SIMD up to
@@ -56,7 +66,7 @@ __host__ __device__ constexpr int inc_min_waves(int dq, int mode, bool per = fal
     if (per) return MCMC_EXP_WAVES(STEP, dq <= 8 ? 4 : dq <= 31 ? 2 : 1);
     return MCMC_EXP_WAVES(STEP,
         mode == 0 ? (dq <= 12 ? 4 : dq <= 30 ? 2 : 1)
-        : mode == 1 ? ((dq <= 8 || dq == 13) ? 4 : dq <= 31 ? 2 : 1)
+        : mode == 1 ? ((dq <= 8 || dq == 13) ? 4 : dq <= 30 ? 2 : 1)
         // (MODE 2, round 5: MODE 1's registers + the stream of the carried log-prior in LDS --
         // 24 bytes per dimension and column --, which four workgroups per CU hold up to dq = 8)
         : (dq <= 8 ? 4 : dq <= 31 ? 2 : 1));
@@ -68,7 +78,8 @@ __host__ __device__ constexpr int inc_min_waves(int dq, int mode, bool per = fal
 // s_waitcnt vmcnt(0) per step: 2.47 ms per 1200 steps at d = 30 against 1.15 without the flag)
 __host__ __device__ constexpr bool inc_bounds_in_lds(int dq, int mode, bool per)
 {
-    return mode > 0 && (dq > 12 || (per && dq >= 6 && dq <= 8));
+    return MCMC_EXP_BOUNDS_LDS(mode > 0 && ((dq > 12 && !inc_one_wave_regs(dq, mode, per)) ||
+                                            (per && dq >= 6 && dq <= 8)));
 }
 
 // The step's (v, u) pairs kept in registers from the trial to the commit (no second LDS read):
@@ -77,9 +88,9 @@ __host__ __device__ constexpr bool inc_bounds_in_lds(int dq, int mode, bool per)
 // 80: 5.98 -> 5.36, 96: 8.25 -> 7.28, 100: 9.83 -> 8.96, 112: 11.99 -> 11.42, 116: 14.5 -> 13.9;
 // d = 124 / 128 (one wave per SIMD now, inc_min_waves): 24.9 -> 17.7 / 35.4 -> 19.5.  The kernels
 // at four waves per SIMD (dq <= 12, 128 registers) cannot afford the 4 dq registers.
-__host__ __device__ constexpr bool inc_keep_pairs(int dq, int mode)
+__host__ __device__ constexpr bool inc_keep_pairs(int dq, int mode, bool per = false)
 {
-    return mode == 0 && dq >= 13;
+    return (mode == 0 && dq >= 13) || inc_one_wave_regs(dq, mode, per);
 }
 
 //   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     // KEEP: the step's DQ (v, u) pairs stay in registers from the trial to the commit instead of
     // being read from LDS twice (4 DQ VGPRs: only where the kernel runs two waves per SIMD on
     // 256 registers and the LDS pipe, not the register file, is what binds)
-    constexpr bool KEEP = MCMC_EXP_KEEP(inc_keep_pairs(DQ, MODE));
+    constexpr bool KEEP = MCMC_EXP_KEEP(inc_keep_pairs(DQ, MODE, PER));
     // pairs fetched ahead of the trial arithmetic, PIPE at a time.  The kernels at three / four waves
     // per SIMD got it in round 4, once the staged variates had freed 8 registers: measured over
     // d = 4 ... 52 (round-4 sweep, same box): dq 5 ... 12 gain 0.2 - 2 % (MODE 1 at d = 30: 3.9 %),

@@ -767,7 +767,10 @@ def test_walkers_of_a_group_are_independent_chains(incremental, bgs):
     (8, 256, 64, False, 1.0), (13, 192, 64, True, 1.0), (30, 512, 256, False, 1.0),
     (27, 256, 64, True, 1.0), (32, 256, 64, False, 1.0), (33, 256, 64, False, 1.0),
     (48, 256, 128, True, 1.5), (64, 256, 64, False, 1.0), (100, 256, 64, False, 1.0),
-    (100, 512, 256, True, 1.0), (112, 128, 64, False, 1.0), (128, 256, 128, False, 1.0)])
+    (100, 512, 256, True, 1.0), (112, 128, 64, False, 1.0), (128, 256, 128, False, 1.0),
+    # general bounds at the top of the range: one wave per SIMD, everything in registers
+    (128, 128, 64, True, 1.0), (124, 128, 64, "bounds differ", 1.0), (128, 128, 64, "bounds differ", 2.0),
+    (120, 128, 64, True, 1.0)])
 def test_incremental_steps_bit_exact(d, W, gs, normal, T):
     """MCMC_HIP_FLAG_INCREMENTAL (incremental_kernels.hip) against the oracle's incremental mode
     (oracle/mcmc_oracle.c: step_core_inc, orc_whiten, orc_whiten_directions): positions, the
@@ -775,7 +778,9 @@ def test_incremental_steps_bit_exact(d, W, gs, normal, T):
     over launches that end mid-cycle, off the four-step variate blocks, and across the refresh
     at 40 d steps."""
     kw = {}
-    if normal:
+    if normal == "bounds differ":
+        kw = dict(a=[-0.25 * (i % 3) for i in range(d)], b=[1.0 + 0.5 * (i % 2) for i in range(d)])
+    elif normal:
         rng = np.random.default_rng(7000 + d)
         kinds = (rng.random(d) < 0.5).astype(int).tolist()
         kinds[d - 1] = 1
