@@ -531,8 +531,9 @@ def test_two_mode_mixture_at_d40_chains_mode():
 @pytest.mark.parametrize("periodic", [False, True])
 def test_six_mode_mixture_runs_incrementally(periodic):
     """More than four modes (and, second case, a periodic parameter beside them) through
-    `run(info)` with `evaluation: auto`: the run is incremental -- the general kernels of
-    incremental_any.hip, not the from-scratch fallback -- and the pooled walkers recover the
+    `run(info)` with `evaluation: auto`: the run is incremental -- step_inc_mix_kernel, or with
+    the periodic parameter the general kernels of incremental_any.hip, not the from-scratch
+    fallback -- and the pooled walkers recover the
     mean and the covariance of the mixture (modes within 1.5 sigma of each other)."""
     d, K = 12, 6
     rng = np.random.default_rng(66)
@@ -555,7 +556,10 @@ def test_six_mode_mixture_runs_incrementally(periodic):
     updated, sampler = run(info)
     assert sampler.incremental
     kern = sampler.engine.last_step_kernel()
-    assert "step_inc_regs_kernel" in kern and ("periodic" in kern) == periodic, kern
+    # (six modes at d = 12: step_inc_mix_kernel since round 5; beside a periodic parameter the
+    # register-plane kernel of incremental_any.hip)
+    want = "step_inc_regs_kernel" if periodic else "step_inc_mix_kernel<3, 6"
+    assert want in kern and ("periodic" in kern) == periodic, kern
     x = sampler.engine.get_state()["x"]
     mean = w @ mus
     truth = cov + (mus - mean).T @ np.diag(w) @ (mus - mean)
