@@ -329,8 +329,8 @@ class EnsembleMCMC:
         if self.evaluation not in ("auto", "full", "incremental"):
             self._fail("evaluation must be 'auto', 'full' or 'incremental', got %r",
                        self.evaluation)
-        # (the engine's own answer: tuned kernels for one mode, up to four at d <= 64, up to
-        # eight periodic parameters, dragging of one non-periodic mode; the general kernel for
+        # (the engine's own answer: tuned kernels for one mode, up to four at d <= 64 (six at d <= 28), up to
+        # 16 periodic parameters, dragging of one non-periodic mode; the general kernel for
         # any other mixture / periodic set whose residuals fit the LDS)
         can_inc = (d >= 2 and int(self.group_size) % 64 == 0 and W % int(self.group_size) == 0
                    and incremental_supported(d, spec.n_modes, int(np.sum(spec.periodic)),

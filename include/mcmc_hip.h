@@ -85,7 +85,7 @@ MCMC_HIP_API int mcmc_hip_dim_supported(int d);
 /* 1 if MCMC_HIP_FLAG_INCREMENTAL serves a Gaussian mixture of n_modes (>= 1) modes in d dimensions
  * of which n_periodic are periodic (prior.py:658-676), with n_drag interpolation steps per dragging
  * step (0: Metropolis steps), for n_walkers walkers of which basis_group_size share a proposal
- * direction: the tuned kernels (one mode; up to four at d <= 64; up to 16 periodic parameters
+ * direction: the tuned kernels (one mode; up to four at d <= 64, five and six at d <= 32 / 28; up to 16 periodic parameters
  * of one mode; dragging of one non-periodic mode) or the general one (anything else without
  * dragging whose per-walker state -- n_modes * d doubles -- fits the LDS of a CU).  0: such a model
  * is sampled from scratch (no flag).  A pure function: no device is touched. */
@@ -372,7 +372,7 @@ MCMC_HIP_API int mcmc_hip_get_whitened(mcmc_hip_ctx* h, double* y);
 MCMC_HIP_API int mcmc_hip_set_whitened(mcmc_hip_ctx* h, const double* y);
 /* incremental mode, Gaussian mixtures (gaussian_mixture.py:138-163): 1 if the step kernel this
  * engine's configuration selects CARRIES the log-density a_k = -(c_k + chi2_k) / 2 of every mode
- * with the walker (round 5: step_inc_mix_kernel -- 2..4 modes, d <= 64, no periodic parameter,
+ * with the walker (round 5: step_inc_mix_kernel -- 2..4 modes at d <= 64, 5 at d <= 32, 6 at d <= 28, no periodic parameter,
  * Metropolis steps, emit_capacity 0), moved along the whitened direction like the carried
  * log-likelihood of a single mode; 0 if every chi2_k is summed from the trial's residual (the
  * general kernels: more modes, periodic parameters, emitted rows).  The
