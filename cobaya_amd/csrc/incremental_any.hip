@@ -944,7 +944,7 @@ namespace {
 // as far as the registers hold the residuals
 bool regs_serves(int K, int dq, int n_periodic)
 {
-    if (K < 1) return false;
+    if (K < 1 || K > 16) return false;   // (more than 16 modes: the LDS kernel, if its geometry fits)
     const int km = regs_bucket(K);
     if (!regs_fits(dq, km)) return false;
     // periodic parameters: their wrap moves and columns of L_k^-1 beside the column chunks in LDS

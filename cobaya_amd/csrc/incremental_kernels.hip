@@ -1295,7 +1295,10 @@ __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
     // log-sum-exp) wants ~100 registers beside it: above two waves per SIMD it spills, and the
     // kernel is bound by its instruction count (~270 VALU per wave-step at K = 2), not by latency,
     // so occupancy buys nothing once two waves overlap.
-    return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 12 ? 4 : dq * (km + 1) <= 50 ? 2 : 1);
+    // (round 5 late, after the box test moved to the high words: two modes at three waves 2.81 against
+    // 2.91 ms per 1200 steps at d = 30; three and more modes still spill there)
+    return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 12 ? 4 : (km == 2 && dq * (km + 1) <= 24) ? 3
+                                                      : dq * (km + 1) <= 50 ? 2 : 1);
 }
 
 #ifndef MCMC_MIX_FRESH_EPILOGUE

@@ -7,7 +7,7 @@ namespace mcmc {
 
 constexpr int kMaxDimLane = 32;   // lane-per-walker kernels: d <= 32 (state in VGPRs)
 constexpr int kMaxDimPair = 56;   // ... and the two-wave step kernel alone up to here
-constexpr int kMaxModes = 16;
+constexpr int kMaxModes = 64;   // (16 until round 5; the tuned incremental kernels: 16, incremental_any.hip)
 
 // Whitening factor L_k^-1 (lower triangular) packed in the order the kernels consume it, so
 // that the wave-uniform operand stream is read front to back with wide scalar loads:

@@ -265,11 +265,11 @@ class ProblemSpec:
             c = comps[0]
             spec.like_name, spec.like_kind = c["name"], c["kind"]
             spec.means, spec.covs, spec.weights = c["means"], c["covs"], c["weights"]
-            if c["means"] is not None and len(c["means"]) > 16:
+            if c["means"] is not None and len(c["means"]) > 64:
                 # (said here, not by the engine at its first launch: kernels.h kMaxModes; the
                 # reference has no cap, gaussian_mixture.py:45-136)
                 raise UnsupportedModel(f"likelihood '{c['name']}' has {len(c['means'])} modes: mcmc_hip "
-                                       "evaluates mixtures of at most 16 (one register / LDS plane of "
+                                       "evaluates mixtures of at most 64 (one register / LDS plane of "
                                        "whitened residuals per mode)")
             spec.normalized, spec.has_derived = c["normalized"], c["has_derived"]
             if c["kind"] == "planck_pliklite":

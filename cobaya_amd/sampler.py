@@ -202,7 +202,7 @@ class EnsembleMCMC:
     fallback_covmat_scale = 4.0  # sampler.py:474
     _LoggedError = LoggedError   # the hosted class raises cobaya.log.LoggedError instead
     _engine_factory = staticmethod(Engine)  # the seam to libmcmc_hip.so (tests swap it)
-    MAX_DIM = 128    # capi.hip: kMaxDimBig (mixtures: at most 16 modes, model.py)
+    MAX_DIM = 128    # capi.hip: kMaxDimBig (mixtures: at most 64 modes, model.py)
 
     # ------------------------------------------------------------------ host seams
     def _fail(self, msg, *args, cause=None):

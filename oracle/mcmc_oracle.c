@@ -920,7 +920,7 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
     const int carry = carries_loglike(p, st);
     const int carry_p = wp != NULL;   /* (carries_prior: the caller formed w, v.w and loc.w) */
     const int carry_k = carries_modes(p);
-    double t[128], yt[16 * 128], sh[128];
+    double t[128], yt[64 * 128], sh[128];   /* (64: the engine's kMaxModes) */
     const double* x = st->x + (size_t)w * d;
     double* y = st->y + (size_t)w * K * d;
     int inb = 1, wound = 0;
@@ -945,7 +945,7 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
         inb &= (t[i] <= p->hi[i]) & (t[i] >= p->lo[i]);
     }
     double lp = -INFINITY, ll = -INFINITY, lt = -INFINITY;
-    double a_new[16];   /* carry_modes: the trial's mode log-densities */
+    double a_new[64];   /* carry_modes: the trial's mode log-densities */
     if (inb) {
         if (carry_p) {   /* the carried log-prior moves along the direction */
             double sc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -955,7 +955,7 @@ static inline int step_core_inc(const orc_problem* p, orc_state* st, int w, cons
         } else {
             lp = inc_logprior(p, t);
         }
-        double a[16], amax = -INFINITY;
+        double a[64], amax = -INFINITY;
         if (carry) {
             double q[4] = {0.0, 0.0, 0.0, 0.0};
             for (int i = 0; i < d; ++i) q[i & 3] = fma(y[i], u[0][i], q[i & 3]);
@@ -1342,8 +1342,8 @@ int64_t orc_run(const orc_problem* p, orc_state* st, int W, uint32_t walker0, ui
                 const double* wp = carries_prior(p, st) ? Wd + (size_t)col * d : NULL;
                 const double* nl = carries_prior(p, st) ? Wd + (size_t)L0 * d + 2 * col : NULL;
                 const double uu = carries_loglike(p, st) ? U[(size_t)K * L0 * d + col] : 0.0;
-                const double* uk[16];
-                double uuk[16];
+                const double* uk[64];
+                double uuk[64];
                 for (int k = 0; k < K; ++k) uk[k] = U + ((size_t)k * L0 + col) * d;
                 if (carries_modes(p))
                     for (int k = 0; k < K; ++k) uuk[k] = U[(size_t)K * L0 * d + (size_t)k * L0 + col];

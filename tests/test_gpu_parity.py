@@ -131,7 +131,9 @@ def test_initial_evaluation_bit_exact():
     # smaller d and other widths run the one-wave kernel
     (8, 256, 64, 1, 50), (13, 256, 128, 1, 45), (14, 256, 64, 1, 45), (16, 512, 256, 1, 40),
     (17, 256, 128, 1, 40), (21, 256, 64, 1, 50),
-    (24, 256, 256, 1, 55), (30, 192, 64, 1, 70), (16, 64, 64, 1, 40)])
+    (24, 256, 256, 1, 55), (30, 192, 64, 1, 70), (16, 64, 64, 1, 40),
+    # more than 16 modes (kMaxModes 64 since round 5): the mode log-densities of a workgroup in LDS
+    (6, 128, 64, 24, 40), (12, 256, 128, 64, 30)])
 def test_steps_bit_exact(d, W, gs, K, steps):
     eng, prob, st = make_pair(d, W, gs, K=K, weights=[0.2, 0.8] if K == 2 else None)
     # several launches that start and stop mid-cycle
@@ -241,7 +243,7 @@ def test_two_wave_kernel_above_32_dimensions_bit_exact(d, W, gs, normal):
     (40, 256, 64, 2, "mixture"), (64, 128, 64, 3, "mixture"), (36, 128, 128, 0, "one"),
     (50, 128, 64, 1, "periodic+normal"), (100, 256, 128, 1, "periodic"),
     (40, 64, 64, 1, "normal, odd ensemble"), (120, 128, 64, 1, "d > 112, odd ensemble"),
-    (48, 256, 256, 2, "mixture+periodic+normal+T")])
+    (48, 256, 256, 2, "mixture+periodic+normal+T"), (40, 128, 64, 33, "mixture")])
 def test_big_dimension_general_kernel_bit_exact(d, W, gs, K, case):
     """d > 32 outside the specialised kernels -- mixtures, `one`, periodic parameters, normal
     priors or d > 112 on ensembles that are not whole 256-walker workgroups -- runs on the
@@ -1091,6 +1093,7 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (30, 1024, 256, 8, [2], {"bgs": 1024}),
     (9, 128, 64, 7, [], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
     (40, 128, 64, 12, [], {}),                                 # 16 register planes, 12 live
+    (6, 128, 64, 24, [], {}),                                  # more than 16 modes: residuals in LDS
     (90, 128, 64, 7, [], {"normal": True})])                   # 8 planes at dq = 23
 def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
     """What the tuned incremental kernels leave out -- more than four modes, mixtures above d = 64,
@@ -1130,7 +1133,7 @@ def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
             wraps += int(np.sum(np.abs(st.x - before)[:, per] > 0.08))
     # (what fits the register file, a few periodic parameters included: step_inc_regs_kernel;
     # 128 periodic parameters: their columns of L^-1 do not fit beside it -- residuals in LDS)
-    want = "step_inc_any_kernel" if len(per) > 100 else "step_inc_regs_kernel"
+    want = "step_inc_any_kernel" if (len(per) > 100 or K > 16) else "step_inc_regs_kernel"
     assert st.step > 40 * L and want in eng.last_step_kernel(), eng.last_step_kernel()
     assert eng.counters()["accepted"] == int(st.n_accept.sum()) > 0
     if per:
