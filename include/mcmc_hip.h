@@ -60,7 +60,7 @@ typedef struct mcmc_hip_config {
 /* every walker draws its OWN Haar basis per cycle (proposal.py:59-69 to the letter) instead
  * of sharing the group's: the reference-faithful control, much slower */
 #define MCMC_HIP_FLAG_OWN_BASIS 1
-/* incremental evaluation (Gaussian mixtures of up to 16 modes with uniform / normal priors and
+/* incremental evaluation (Gaussian mixtures of up to 64 modes with uniform / normal priors and
  * any number of periodic parameters, parameter blocks of any size and oversampling, Metropolis
  * steps -- mcmc_hip_incremental_supported says whether a shape fits; dragging for one mode with
  * non-periodic priors; 2 <= d <= 128; emitted rows, emit_capacity > 0, with Metropolis steps):
