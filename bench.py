@@ -867,6 +867,37 @@ def main():
             "evaluation": v["evaluation"], "kernel": v.get("kernel"),
             "kernel_ms_per_launch": v["kt"]["step_ms"] / max(1, v["kt"]["step_launches"]),
             "roofline": gaussian_roofline(v, d, a.walkers, n_v)})
+        # ... two modes (step_inc_mix_kernel: the log-density of every mode carried) ...
+        info2 = make_info(d, mean, cov, a.walkers, a.group_size, None)
+        info2["likelihood"] = {"gaussian_mixture": {
+            "means": [mean, np.clip(mean + rng8.normal(size=d) * sig8, 0.05, 0.95)],
+            "covs": [cov] * 2, "input_params_prefix": "a_"}}
+        n_v = 6
+        v = run_timed(a, d, mean, cov, "snapshots", n_v, 2, info=info2)
+        variants.append({
+            "certificate": v["certificate"],
+            "variant": "2-mode gaussian_mixture at d = 30 (step_inc_mix_kernel), 65536 walkers",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"], "kernel": v.get("kernel"),
+            "kernel_ms_per_launch": v["kt"]["step_ms"] / max(1, v["kt"]["step_launches"]),
+            "roofline": gaussian_roofline(v, d, a.walkers, n_v)})
+        # ... and a periodic parameter (prior.py:658-676; step_inc_kernel<.., periodic>): the first
+        # parameter on an interval of +-4 sigma around the mode, so that walkers do cross the seam
+        infop = make_info(d, mean, cov, a.walkers, a.group_size, None)
+        infop["params"]["a__0"]["prior"] = {"min": float(mean[0] - 4 * sig8[0]),
+                                            "max": float(mean[0] + 4 * sig8[0])}
+        infop["params"]["a__0"]["periodic"] = True
+        n_v = 8
+        v = run_timed(a, d, mean, cov, "snapshots", n_v, 2, info=infop)
+        variants.append({
+            "certificate": v["certificate"],
+            "variant": "d = 30 with one periodic parameter (interval of +-4 sigma), 65536 walkers",
+            "value": v["evals"] / v["dt"], "unit": "evals/s", "ms_per_step": 1e3 * v["dt"] / n_v,
+            "steps": n_v, "warmup": 2, "metropolis_steps_per_launch": v["spl"],
+            "evaluation": v["evaluation"], "kernel": v.get("kernel"),
+            "kernel_ms_per_launch": v["kt"]["step_ms"] / max(1, v["kt"]["step_launches"]),
+            "roofline": gaussian_roofline(v, d, a.walkers, n_v)})
         # configs[4]'s ARITHMETIC: the plik-lite likelihood (planck_pliklite.py:143-155) -- 613
         # bins, chi2 = delta^T Sigma^-1 delta on the matrix cores -- with a 26-parameter linear
         # Cl(theta) + A_planck (d = 27); synthetic plik-lite-shaped data (the Planck files and a
