@@ -119,7 +119,7 @@ def report(title, name, lines):
 def main():
     csrc = os.path.join(ROOT, "cobaya_amd", "csrc")
     inc = assembly(os.path.join(csrc, "incremental_kernels.hip"), ["-DMCMC_DQ_LO=1", "-DMCMC_DQ_HI=8"])
-    name, body = kernel_body(inc, r"_ZN4mcmc12_GLOBAL__N_115step_inc_kernelILi8ELi0ELb1ELb0EEEvNS_11IncStepArgsE")
+    name, body = kernel_body(inc, r"_ZN4mcmc12_GLOBAL__N_115step_inc_kernelILi8ELi0ELb1ELb0ELb0ELb0EEEvNS_11IncStepArgsE")
     report("step_inc_kernel<8, 0, true>  (d = 30, incremental evaluation; 16 walkers per wave: the "
            "step loop is the loop holding the ds_read_b128 / v_fma_f64 body; PairRng is the block "
            "with the v_mul_hi_u32 Philox rounds, entered every eighth step)", name, body)

@@ -27,8 +27,12 @@ def scan(rng):
                    check=True, stderr=subprocess.DEVNULL)
     rows = []
     text = open(out).read()
-    for m in re.finditer(r"\.set (\S+)\.num_vgpr, (\d+)", text):
+    # (ROCm 7.2 writes these as expressions over the callees: `max(128, .L…pair_tail….num_vgpr)`,
+    # `96+max(…)`: the leading number is the kernel's own)
+    for m in re.finditer(r"\.set (\S+)\.num_vgpr, (?:max\()?(\d+)", text):
         name = m.group(1)
+        if name.startswith(".L"):
+            continue
         seg = re.search(re.escape(name) + r"\.private_seg_size, (\d+)", text)
         dem = subprocess.run(["c++filt", name], capture_output=True,
                              text=True).stdout.strip()
