@@ -44,6 +44,9 @@
 #ifdef EXP_BOUNDS_REGS
 #define MCMC_EXP_BOUNDS_LDS(tuned) (false)
 #endif
+#ifdef EXP_FLOAT_BOUNDS
+#define MCMC_EXP_FLOAT_BOUNDS(tuned) (true)
+#endif
 #ifdef EXP_NO_ROTATE
 #define MCMC_EXP_ROTATE(on) (false)
 #else

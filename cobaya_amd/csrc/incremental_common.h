@@ -18,6 +18,9 @@
 #define MCMC_EXP_ROTATE(on) (on)                 // rotate the wave priorities at all
 #define MCMC_EXP_KEEP(tuned) (tuned)             // keep a step's (v, u) pairs in registers
 #endif
+#ifndef MCMC_EXP_FLOAT_BOUNDS
+#define MCMC_EXP_FLOAT_BOUNDS(tuned) (tuned)     // single-precision copies of LDS-resident bounds in registers
+#endif
 #ifndef MCMC_EXP_BOUNDS_LDS
 #define MCMC_EXP_BOUNDS_LDS(tuned) (tuned)       // per-dimension bounds in LDS (else in registers)
 #endif
