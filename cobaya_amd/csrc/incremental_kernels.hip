@@ -135,7 +135,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     // 16.2, 13.9 -> 25.1; dq = 13 runs at four waves (128 registers): 3.33 -> 12.9
     constexpr bool kFloatBounds =
         kBoundsInLds &&
-        MCMC_EXP_FLOAT_BOUNDS(PER ? DQ <= 8 : (DQ >= 14 && DQ <= (MODE == 1 ? 22 : 21)));
+        // (periodic parameters at dq = 14..20 as well: d = 56 with one 5.93 -> 5.07, d = 64 with two
+        // 8.25 -> 6.75, d = 80 with two 11.74 -> 9.72; dq = 23 without: no difference)
+        MCMC_EXP_FLOAT_BOUNDS(PER ? (DQ <= 8 || (DQ >= 14 && DQ <= 20))
+                                  : (DQ >= 14 && DQ <= (MODE == 1 ? 22 : 21)));
     // (MODE 0 = ONE box [0, hi] for every dimension, BASELINE configs 2-4: its support test works
     // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
     // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step

@@ -1168,6 +1168,8 @@ def test_incremental_general_kernel_steps_bit_exact(d, W, gs, K, per, extra):
     (27, 128, 64, [3], {"normal": True}),
     (9, 128, 64, [4], {"blocks": [[4], [0, 1, 2, 3], [5, 6, 7, 8]], "over": [1, 2, 2]}),
     (33, 128, 64, [32, 1], {}),
+    (56, 128, 64, [55], {}), (64, 128, 64, [3, 40], {}),       # dq = 14..20: single-precision bounds
+    (80, 128, 64, [0, 41, 79], {"normal": True}), (72, 256, 128, [5, 6, 7, 8], {}),
     (40, 128, 64, list(range(0, 40, 3)), {}),                  # 14 periodic parameters
     (100, 128, 64, list(range(3, 100, 7)), {"normal": True}),  # 14 at d = 100, carried log-prior
     (100, 128, 64, [5, 50, 99], {})])
