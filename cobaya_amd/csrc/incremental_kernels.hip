@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     // double-precision bounds are read from LDS only when some coordinate is not inside for
     // certain.  (Read from LDS at every step the compiler, short of registers, fetched them one
     // row at a time -- eight dependent round trips per trial: SQ_WAIT_ANY 49 % of the wave-cycles.)
-    // ... and the two-wave kernels of general bounds at dq = 14..22 (MODE 2: ..21), where 2 dq more
+    // ... and the two-wave kernels of general bounds at dq = 14..22 (MODE 2: ..18; at dq = 21 it
+    // spilled: 19.0 ms per 3360 steps at d = 84 against 11.9 per 3520 at d = 88), where 2 dq more
     // registers still fit: one LDS read per dimension and step less -- measured, same box, MODE 1,
     // ms per 40 d steps of 65 536 walkers: d = 56: 4.65 -> 4.18, 60: 5.37 -> 4.49, 64: 5.94 -> 5.15,
     // 68: 6.68 -> 5.66, 80: 8.34 -> 6.83, 88: 9.83 -> 8.22; d = 96 and 100 (dq = 24, 25) spill: 11.4 ->
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
         // (periodic parameters at dq = 14..20 as well: d = 56 with one 5.93 -> 5.07, d = 64 with two
         // 8.25 -> 6.75, d = 80 with two 11.74 -> 9.72; dq = 23 without: no difference)
         MCMC_EXP_FLOAT_BOUNDS(PER ? (DQ <= 8 || (DQ >= 14 && DQ <= 20))
-                                  : (DQ >= 14 && DQ <= (MODE == 1 ? 22 : 21)));
+                                  : (DQ >= 14 && DQ <= (MODE == 1 ? 22 : 18)));
     // (MODE 0 = ONE box [0, hi] for every dimension, BASELINE configs 2-4: its support test works
     // on the high words of the trial coordinates, see `trial` below.  Round 2 took it on lane masks
     // at four waves per SIMD and on v_max / v_min_f64 at two: 2 DQ FP64 instructions per step
