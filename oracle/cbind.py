@@ -300,7 +300,7 @@ class Problem:
                  drag_last_slow=-1, drag_steps=0, incremental=False, refresh_every=None,
                  paired_variates=None, binned=None, carry_modes=False, carry_periodic=False):
         self.d = d
-        # one mode with periodic parameters on step_inc_periodic_kernel: wrap only what leaves
+        # one mode with periodic parameters on step_inc_kernel<.., periodic>: wrap only what leaves
         # [lo, hi), carry the log-likelihood (Engine.carries_periodic())
         self.carry_periodic = bool(carry_periodic)
         # mixtures: the log-density of every mode is carried (step_inc_mix_kernel, the register-plane

@@ -655,7 +655,7 @@ def test_g8_chain_statistics_match_the_reference(golden):
 
 
 def test_division_by_the_period_without_a_division_is_the_ieee_quotient(tmp_path):
-    """incremental_periodic.hip divides by the period of a periodic parameter as
+    """step_inc_kernel<.., periodic> (incremental_common.h: div_by) divides by the period of a periodic parameter as
     q0 = a R, q1 = fma(fma(-q0, w, a), R, q0), q2 = fma(fma(-q1, w, a), R, q1) with R = RN(1 / w)
     and claims q2 == a / w bit for bit (the oracle divides; prior.py:675).  The same five
     operations in C (gcc, no contraction) against the division: 2 * 10^7 random operands over the
