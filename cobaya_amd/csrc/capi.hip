@@ -394,6 +394,8 @@ struct mcmc_hip_ctx {
     DevBuf<double> pack_out;                        // drain_samples: packed rows
     DevBuf<long long> pack_off;
     DevBuf<int> weight_i, prej, burn, stuck, nrows;
+    DevBuf<int> thin_acc;   // thinned emission (mcmc_hip_set_emit_thin): the weight a walker has added up
+    int emit_thin = 1;
     DevBuf<long long> nacc;
     DevBuf<unsigned long long> acc_total;
     unsigned long long step = 0;
@@ -1912,6 +1914,10 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                     "incremental evaluation: %d modes at d=%d with %d periodic parameters do not "
                     "fit the LDS of a CU; use evaluation: full for this model", K, d, n_periodic);
     const bool emit = h->cfg.emit_capacity > 0;
+    if (emit && h->emit_thin > 1 && (K != 1 || n_periodic > 0 || P.drag))
+        return fail(h, MCMC_HIP_ERR_ARG,
+                    "emit_thin: rows are thinned on the device by step_inc_kernel<.., emit> (one mode, "
+                    "non-periodic priors, blocks of at least two parameters); thin on the host");
     if (emit) {
         bool one_d = false;   // (a block of one parameter: its columns draw other variates)
         for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b) one_d = one_d || h->blk_size[b] == 1;
@@ -1922,6 +1928,9 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         // step_inc_kernel<.., EMIT> emits for one mode with non-periodic priors and blocks of at
         // least two parameters; every other shape on the general kernels, which emit at run time
         if (K != 1 || n_periodic > 0 || one_d) P.any = true;
+        if (P.any && h->emit_thin > 1)
+            return fail(h, MCMC_HIP_ERR_ARG,
+                        "emit_thin: a block of one parameter emits on the general kernels; thin on the host");
         if (P.any && (!mcmc_hip_launch_inc_any || !mcmc_hip_inc_any_fits ||
                       !mcmc_hip_inc_any_fits(d, K, n_periodic, h->W, h->bgs)))
             return fail(h, MCMC_HIP_ERR_ARG,
@@ -2052,6 +2061,7 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
             a.s.burn_left = h->burn.p; a.s.n_accept = h->nacc.p; a.s.stuck = h->stuck.p;
             a.s.accept_total = h->acc_total.p;
             a.s.rows = h->rows.p; a.s.n_rows = h->nrows.p; a.s.row_cap = h->cfg.emit_capacity;
+            a.s.thin = h->emit_thin; a.s.thin_acc = h->thin_acc.p;
             a.s.W = h->W; a.s.n_modes = K; a.s.group_size = h->bgs;   // the walkers that share a column of VU
             a.s.cblock = h->cblock.p;
             {
@@ -2161,6 +2171,8 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (h->bg.on) return step_binned(h, n_steps);
     if (h->incremental) return step_incremental(h, n_steps);
+    if (h->emit_thin > 1)
+        return fail(h, MCMC_HIP_ERR_ARG, "emit_thin needs incremental evaluation; thin on the host");
     const bool drag = h->drag_last_slow >= 0;
     // steps (= direction columns) per cycle, doubles per (group, cycle) slab of directions
     const int Lc = block_slots(h, drag ? 1 : 0);
@@ -2389,6 +2401,54 @@ int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int6
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     HIP_TRY(h, hipMemset(h->nrows.p, 0, sizeof(int) * W));
+    return MCMC_HIP_OK;
+}
+
+// Thinned emission on the device (round 5; collection.py:1373-1383, OneSamplePoint.add_to_collection
+// with output_thin > 1): step_inc_kernel<.., EMIT> only -- whatever else emits rows refuses at its
+// first step, and the caller thins on the host as before.
+int mcmc_hip_set_emit_thin(mcmc_hip_ctx* h, int32_t thin)
+{
+    if (!h) return MCMC_HIP_ERR_ARG;
+    if (thin < 1) return fail(h, MCMC_HIP_ERR_ARG, "thin must be >= 1");
+    if (thin > 1 && h->cfg.emit_capacity <= 0)
+        return fail(h, MCMC_HIP_ERR_ARG, "emit_thin needs emitted rows (emit_capacity > 0)");
+    if (thin > 1) {   // (the configuration as it stands now; mcmc_hip_step checks again)
+        bool ok = h->incremental && h->K == 1 && h->drag_last_slow < 0;
+        for (int i = 0; i < h->d && ok; ++i) ok = !h->periodic[i];
+        for (size_t b = 0; h->blocked && b < h->blk_size.size() && ok; ++b) ok = h->blk_size[b] != 1;
+        if (!ok)
+            return fail(h, MCMC_HIP_ERR_ARG,
+                        "emit_thin: rows are thinned on the device by step_inc_kernel<.., emit> (incremental "
+                        "evaluation of one mode, non-periodic priors, blocks of at least two parameters, "
+                        "Metropolis steps); thin on the host");
+    }
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (thin > 1 && !h->thin_acc.p) {
+        HIP_TRY(h, h->thin_acc.resize((size_t)h->W));
+        HIP_TRY(h, hipMemsetAsync(h->thin_acc.p, 0, sizeof(int) * (size_t)h->W, h->stream));
+    }
+    h->emit_thin = thin;
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_get_thin_carry(mcmc_hip_ctx* h, int32_t* carry)
+{
+    if (!h || !carry) return MCMC_HIP_ERR_ARG;
+    if (!h->thin_acc.p) return fail(h, MCMC_HIP_ERR_STATE, "emit_thin is not set");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(carry, h->thin_acc.p, sizeof(int) * (size_t)h->W, hipMemcpyDeviceToHost));
+    return MCMC_HIP_OK;
+}
+
+int mcmc_hip_set_thin_carry(mcmc_hip_ctx* h, const int32_t* carry)
+{
+    if (!h || !carry) return MCMC_HIP_ERR_ARG;
+    if (!h->thin_acc.p) return fail(h, MCMC_HIP_ERR_STATE, "emit_thin is not set");
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->thin_acc.p, carry, sizeof(int) * (size_t)h->W, hipMemcpyHostToDevice));
     return MCMC_HIP_OK;
 }
 

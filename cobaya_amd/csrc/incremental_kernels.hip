@@ -364,6 +364,9 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;     // accepted steps of this launch (< 2^31)
     int nrow = EMIT ? s.n_rows[w] : 0;
+    const bool thinning = EMIT && s.thin > 1;   // (wave-uniform)
+    int tacc = thinning ? s.thin_acc[w] : 0;
+    const double inv_thin = thinning ? 1.0 / (double)s.thin : 1.0;
     // |u|^2 of the launch's columns, through the constant address space: the address is
     // wave-uniform, the load a scalar one (s_load_dwordx2 on the scalar cache's counter -- a vector
     // load would queue behind the DMA of the next chunk on vmcnt)
@@ -627,12 +630,28 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
                         // the point the walker leaves, with its weight (mcmc.py:691-707); each of
                         // the walker's four lanes stores its quarter: header word c, then the
                         // dimensions 4 kk + c -- 32 contiguous bytes per walker and instruction
-                        const bool em = accept & (burn <= 0);
+                        bool em = accept & (burn <= 0);
                         if (lanes(em) != 0ull) {   // (wave-uniform: some walker emits)
+                            int ew = wt;   // the weight the row is written with
+                            if (thinning) {
+                                // thinned output (collection.py:1373-1383): the weights add up; a
+                                // row goes out when the sum reaches `thin`, with weight sum / thin
+                                // (the quotient by a reciprocal, set right by the remainder)
+                                const int tot = tacc + wt;
+                                int q = (int)((double)tot * inv_thin);
+                                int rem = tot - q * s.thin;
+                                q += rem >= s.thin ? 1 : 0;
+                                rem -= rem >= s.thin ? s.thin : 0;
+                                q -= rem < 0 ? 1 : 0;
+                                rem += rem < 0 ? s.thin : 0;
+                                tacc = em ? rem : tacc;
+                                ew = q;
+                                em = em & (q > 0);
+                            }
                             if (em & (nrow < s.row_cap)) {
                                 double* __restrict__ row =
                                     s.rows + ((size_t)w * s.row_cap + nrow) * (size_t)(d + 4);
-                                row[c] = c == 0 ? (double)wt : c == 1 ? lpost : c == 2 ? lpri : llik;
+                                row[c] = c == 0 ? (double)ew : c == 1 ? lpost : c == 2 ? lpri : llik;
 #pragma unroll
                                 for (int kk = 0; kk < DQ; ++kk)
                                     if (4 * kk + c < d) row[4 + 4 * kk + c] = x[kk];
@@ -758,6 +777,7 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;
         if (EMIT) s.n_rows[w] = nrow;
+        if (thinning) s.thin_acc[w] = tacc;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
     MCMC_EXP_BLOCK_END();

@@ -82,6 +82,12 @@ struct StepArgs {
     double* rows;
     int* n_rows;
     int row_cap;
+    // thinned emission (round 5; OneSamplePoint.add_to_collection with output_thin > 1,
+    // collection.py:1373-1383; step_inc_kernel<.., EMIT> only): thin <= 1: off; else the weights of
+    // a walker accumulate in thin_acc[W] and a row is written when the sum reaches `thin`, with
+    // weight sum / thin, the remainder carried
+    int thin;
+    int* thin_acc;
     // problem
     const double* cblock;
     const double* V;  // [G][ncyc][v_slab(d)] direction vectors of the cycles this launch spans

@@ -70,6 +70,9 @@ SYMBOLS = [
     ("mcmc_hip_stream_handle", C.c_uint64, [_H]),
     ("mcmc_hip_drain_samples_pinned", C.c_int, [_H, C.POINTER(c_double_p), c_int64_p]),
     ("mcmc_hip_set_drain_slots", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_set_emit_thin", C.c_int, [_H, C.c_int32]),
+    ("mcmc_hip_get_thin_carry", C.c_int, [_H, C.POINTER(C.c_int32)]),
+    ("mcmc_hip_set_thin_carry", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("mcmc_hip_set_target_binned_gaussian", C.c_int,
      [_H, C.c_int32, c_int32_p, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int32,
       c_double_p, c_double_p, c_double_p, C.c_int32]),
@@ -492,6 +495,8 @@ class Engine:
                 am = np.empty((W, self.K))
                 if self._lib.mcmc_hip_get_mode_logdensities(self._h, _dp(am)) == 0:
                     out["amode"] = am
+        if self.emit_thin > 1:   # thinned emission on the device: the per-walker remainders
+            out["thin_carry"] = self.get_thin_carry()
         return out
 
     def set_full_state(self, st):
@@ -511,6 +516,8 @@ class Engine:
             if "amode" in st and self.carries_modes():
                 am = _f64(st["amode"], (W, self.K))
                 self._check(self._lib.mcmc_hip_set_mode_logdensities(self._h, _dp(am)))
+        if self.emit_thin > 1 and "thin_carry" in st:
+            self.set_thin_carry(st["thin_carry"])
 
     def carries_modes(self):
         """Mixtures in incremental mode: does the step kernel this configuration selects carry the
@@ -545,6 +552,26 @@ class Engine:
             self._check(self._lib.mcmc_hip_drain_samples(self._h, _dp(rows), n.value,
                                                          C.byref(n)))
         return rows
+
+    emit_thin = 1
+
+    def set_emit_thin(self, thin):
+        """Thinned emission on the device (mcmc_hip_set_emit_thin; collection.py:1373-1383): a
+        walker's weights add up and a row is emitted when the sum reaches `thin`, with weight
+        sum // thin.  Served by step_inc_kernel<.., emit>; other configurations refuse at their
+        first step (EngineError): thin on the host then."""
+        self._check(self._lib.mcmc_hip_set_emit_thin(self._h, int(thin)))
+        self.emit_thin = int(thin)
+
+    def get_thin_carry(self):
+        out = np.empty(self.W, np.int32)
+        self._check(self._lib.mcmc_hip_get_thin_carry(self._h, _ip(out)))
+        return out
+
+    def set_thin_carry(self, carry):
+        c = np.ascontiguousarray(carry, dtype=np.int32)
+        assert c.shape == (self.W,)
+        self._check(self._lib.mcmc_hip_set_thin_carry(self._h, _ip(c)))
 
     def set_drain_slots(self, n_slots):
         self._check(self._lib.mcmc_hip_set_drain_slots(self._h, int(n_slots)))

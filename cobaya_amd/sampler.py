@@ -116,6 +116,13 @@ HIP_DEFAULTS = {
                               # posterior; one Gaussian mode or a mixture of <= 4 at d <= 64,
                               # non-periodic priors, parameter blocks / oversampling /
                               # dragging, snapshots); "auto": incremental where it applies
+    "emit_thin": None,        # emit: chains -- thin the emitted rows by this factor (the rule of
+                              # OneSamplePoint.add_to_collection, collection.py:1373-1383: weights
+                              # add up, a row of weight sum // thin is written when the sum reaches
+                              # thin).  None: the reference's rule -- 1, or with oversampling and
+                              # oversample_thin the oversampling ratio (mcmc.py:377-389).  Thinned
+                              # ON THE DEVICE where the incremental single-mode kernel emits
+                              # (PCIe carries thin times fewer rows), on the host otherwise
     "checkpoint_lag": None,   # launches between the request of a learn / convergence checkpoint
                               # and its processing on the host (the refreshed proposal takes
                               # effect with the launch queued after that).  Default: 2 -- the
@@ -404,6 +411,15 @@ class EnsembleMCMC:
                 assert self.engine.cycle_length() == self.cycle_length
         except EngineError as e:
             self._fail("%s", str(e), cause=e)
+        # thinned output: on the device where the engine's emitting kernel does it (PCIe then
+        # carries output_thin times fewer rows), else on the host (`_thin_rows`)
+        self._device_thin = False
+        if self.emit == "chains" and self.output_thin > 1 and hasattr(self.engine, "set_emit_thin"):
+            try:
+                self.engine.set_emit_thin(self.output_thin)
+                self._device_thin = True
+            except EngineError:
+                pass
         # initial proposal covariance (sampler.py:485-685), tempered (mcmc.py:438-440)
         self._initial_covmat, where_nan = self.initial_proposal_covmat()
         if np.any(where_nan) and self.learn_proposal:
@@ -573,6 +589,10 @@ class EnsembleMCMC:
                     self.output_thin = int(np.round(
                         sum(len(b) * o for b, o in zip(blocks, factors)) / spec.d))
             self.cycle_length = sum(len(b) * o for b, o in zip(blocks, factors))
+        if self.emit_thin:   # (mcmc_hip's own option: any run may thin its emitted rows)
+            if int(self.emit_thin) < 1:
+                self._fail("emit_thin must be a positive integer, got %r", self.emit_thin)
+            self.output_thin = int(self.emit_thin)
 
     @property
     def i_last_slow_block(self):
@@ -1023,7 +1043,8 @@ class EnsembleMCMC:
         self.engine.set_proposal_cov(z["proposal_cov"])
         self.engine.set_full_state({k: z[k] for k in ("x", "logpost", "logprior", "loglike",
                                                       "weight", "prior_rej", "burn_left",
-                                                      "n_accept", "step", "y", "amode") if k in z})
+                                                      "n_accept", "step", "y", "amode",
+                                                      "thin_carry") if k in z})
         self._shift = z["shift"]
         self.engine.set_moment_shift(self._shift)
         if "acc_n" in z:   # snapshots accumulated on the device since the last read-out
@@ -1173,7 +1194,7 @@ class EnsembleMCMC:
         `view`: the block is a read-only view of an engine-owned pinned slot (zero-copy drain);
         it is kept as such unless something has to outlive the slot (the chain file's pending
         rows, thinned rows)."""
-        if len(rows) and self.emit == "chains" and self.output_thin > 1:
+        if len(rows) and self.emit == "chains" and self.output_thin > 1 and not self._device_thin:
             rows = self._thin_rows(rows)
             view = False
         if not len(rows) or self.max_rows <= 0:

@@ -217,6 +217,16 @@ MCMC_HIP_API int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t c
  * stated here.) */
 MCMC_HIP_API int mcmc_hip_drain_samples_pinned(mcmc_hip_ctx* h, const double** rows, int64_t* n_rows);
 MCMC_HIP_API int mcmc_hip_set_drain_slots(mcmc_hip_ctx* h, int32_t n_slots);
+/* Thinned emission ON THE DEVICE (round 5): OneSamplePoint.add_to_collection with output_thin > 1
+ * (collection.py:1373-1383) -- the weights of a walker's accepted rows add up, a row is emitted when
+ * the sum reaches `thin`, with weight sum / thin, the remainder carried to its next rows.  `emit:
+ * chains` is bound by PCIe (54 GB/s of rows): thinned by T it moves T times fewer.  Served by the
+ * incremental kernel of one Gaussian mode with non-periodic priors and blocks of at least two
+ * parameters; anything else refuses at its first step (thin on the host as before).  thin = 1: off.
+ * get / set_thin_carry: the per-walker remainders [W] (part of the state of a resumed run). */
+MCMC_HIP_API int mcmc_hip_set_emit_thin(mcmc_hip_ctx* h, int32_t thin);
+MCMC_HIP_API int mcmc_hip_get_thin_carry(mcmc_hip_ctx* h, int32_t* carry);
+MCMC_HIP_API int mcmc_hip_set_thin_carry(mcmc_hip_ctx* h, const int32_t* carry);
 
 /* Constants the engine derived from set_prior / set_target_* (uniform_logp of prior.py:528-533,
  * mls[d] of tools.py:723, Linv[K*d*d] row-major of functions.py:81-89, cnorm[K] =

@@ -55,6 +55,7 @@ else:
         evaluation: str = HIP_DEFAULTS["evaluation"]
         basis_group_size: int | None = HIP_DEFAULTS["basis_group_size"]
         checkpoint_lag: int | None = HIP_DEFAULTS["checkpoint_lag"]
+        emit_thin: int | None = HIP_DEFAULTS["emit_thin"]
 
         def _export_collection(self, coll):
             """Our table -> `cobaya.collection.SampleCollection` (same columns,

@@ -73,6 +73,7 @@ class _State(C.Structure):
         ("burn_left", c_int32_p), ("n_accept", c_int64_p), ("stuck", c_int32_p),
         ("rows", c_double_p), ("n_rows", c_int32_p), ("row_cap", C.c_int32),
         ("y", c_double_p), ("amode", c_double_p),
+        ("thin", C.c_int32), ("thin_acc", c_int32_p),
     ]
 
 
@@ -470,7 +471,7 @@ class Problem:
 class State:
     """Walker state arrays of the oracle (walker-major x)."""
 
-    def __init__(self, problem, x0, burn_in=0, row_cap=0):
+    def __init__(self, problem, x0, burn_in=0, row_cap=0, thin=1):
         self.p = problem
         x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
         self.W, d = x0.shape
@@ -501,6 +502,11 @@ class State:
         s.row_cap = row_cap
         s.y = _dp(self.y)
         s.amode = _dp(self.amode)
+        # thinned emission (OneSamplePoint.add_to_collection with output_thin, collection.py:1373-1383)
+        self.thin = int(thin)
+        self.thin_acc = np.zeros(self.W, np.int32)
+        s.thin = self.thin
+        s.thin_acc = _ip(self.thin_acc)
         self.c = s
 
     def run(self, n_steps, walker0=0, n_threads=1):

@@ -691,6 +691,11 @@ typedef struct {
     double* rows; int32_t* n_rows; int32_t row_cap;
     double* y;         /* [W][K][d] incremental mode: L_k^-1 (x - mu_k) of the current point */
     double* amode;     /* [W][K] carry_modes: the log-density -(c_k + chi2_k) / 2 of every mode */
+    /* thinned emission (collection.py:1373-1383, OneSamplePoint.add_to_collection with
+     * output_thin > 1): thin <= 1: every accepted row is written with its weight; else the weights
+     * of a walker accumulate in thin_acc[W] and a row is written when the sum reaches `thin`, with
+     * weight sum / thin, the remainder carried */
+    int32_t thin; int32_t* thin_acc;
 } orc_state;
 
 /* the Metropolis bookkeeping shared by the Philox and the injected drivers */
@@ -702,13 +707,21 @@ static inline void commit(const orc_problem* p, orc_state* st, int w, const doub
     if (accept) {
         if (st->burn_left[w] <= 0) {
             if (st->rows) {
-                if (st->n_rows[w] < st->row_cap) {
-                    double* row = st->rows + ((size_t)w * st->row_cap + st->n_rows[w]) * (d + 4);
-                    row[0] = (double)st->weight[w]; row[1] = st->logpost[w];
-                    row[2] = st->logprior[w]; row[3] = st->loglike[w];
-                    for (int i = 0; i < d; ++i) row[4 + i] = x[i];
+                int32_t ew = st->weight[w];
+                if (st->thin > 1 && st->thin_acc) {
+                    const int32_t tot = st->thin_acc[w] + st->weight[w];
+                    ew = tot / st->thin;
+                    st->thin_acc[w] = tot % st->thin;
                 }
-                st->n_rows[w] += 1; /* rows beyond the capacity are counted as dropped */
+                if (ew > 0) {
+                    if (st->n_rows[w] < st->row_cap) {
+                        double* row = st->rows + ((size_t)w * st->row_cap + st->n_rows[w]) * (d + 4);
+                        row[0] = (double)ew; row[1] = st->logpost[w];
+                        row[2] = st->logprior[w]; row[3] = st->loglike[w];
+                        for (int i = 0; i < d; ++i) row[4 + i] = x[i];
+                    }
+                    st->n_rows[w] += 1; /* rows beyond the capacity are counted as dropped */
+                }
             }
         } else {
             st->burn_left[w] -= 1;

@@ -152,7 +152,8 @@ class OracleEngine:
 
     def set_state(self, x):
         x = np.array(x, float).reshape(self.W, self.d)
-        self._state = O.State(self._prob(), x, burn_in=self.burn_in, row_cap=self.cap)
+        self._state = O.State(self._prob(), x, burn_in=self.burn_in, row_cap=self.cap,
+                              thin=self.emit_thin)
         self._state.step = self._steps
 
     def get_state(self):
@@ -169,6 +170,8 @@ class OracleEngine:
             out["y"] = s.y.copy()
             if self.carries_modes() and s.step > 0:
                 out["amode"] = s.amode.copy()
+        if self.emit_thin > 1:
+            out["thin_carry"] = s.thin_acc.copy()
         return out
 
     def carries_periodic(self):
@@ -200,6 +203,8 @@ class OracleEngine:
                     s.amode[...] = st["amode"]
                 else:   # (the engine re-anchors them on y at the next launch)
                     s.anchor_modes()
+        if self.emit_thin > 1 and "thin_carry" in st:
+            s.thin_acc[...] = st["thin_carry"]
 
     # -- sampling -----------------------------------------------------------------------
     def step(self, n_steps):
@@ -240,6 +245,29 @@ class OracleEngine:
         return rows
 
     drain_slots = 4
+    emit_thin = 1
+
+    def set_emit_thin(self, thin):
+        """The engine's rule (mcmc_hip_set_emit_thin): thinned on the device by the incremental
+        kernel of one mode with non-periodic priors and blocks of at least two parameters."""
+        thin = int(thin)
+        if thin < 1 or (thin > 1 and not self.cap):
+            raise EngineError(ERR_ARG, "emit_thin needs emitted rows and thin >= 1")
+        periodic = self._prior is not None and self._prior[3] is not None and self._prior[3].any()
+        one_d = bool(self._blocking) and any(len(b) == 1 for b in self._blocking.get("blocks", []))
+        drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
+        if thin > 1 and (not self.incremental or self.K != 1 or periodic or one_d or drag):
+            raise EngineError(ERR_ARG, "emit_thin: thin on the host")
+        self.emit_thin = thin
+        if self._state is not None:
+            self._state.thin = thin
+            self._state.c.thin = thin
+
+    def get_thin_carry(self):
+        return self._state.thin_acc.copy()
+
+    def set_thin_carry(self, carry):
+        self._state.thin_acc[...] = carry
 
     def set_drain_slots(self, n):
         self.drain_slots = int(n)

@@ -964,6 +964,59 @@ def test_incremental_emitted_rows_bit_exact(d, W, gs, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("d,W,gs,thin,kw", [
+    (30, 256, 64, 3, {}), (8, 512, 128, 7, dict(burn_in=3, T=2.0)), (100, 128, 64, 2, {}),
+    (27, 256, 64, 5, dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.3] * 21)),
+    (12, 256, 64, 4, dict(blocks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]], over=[1, 3]))])
+def test_rows_thinned_on_the_device_bit_exact(d, W, gs, thin, kw):
+    """mcmc_hip_set_emit_thin (round 5): step_inc_kernel<.., emit> thins the rows where they are
+    produced -- OneSamplePoint.add_to_collection with output_thin (collection.py:1373-1383): the
+    weights of a walker add up, a row of weight sum // thin goes out when the sum reaches thin, the
+    remainder is carried (and is part of the full state).  Rows, remainders and state bit for bit
+    the oracle's; the chain itself is the unthinned one."""
+    cap = 80
+    eng, prob, st = make_pair(d, W, gs, incremental=True, cap=cap, **kw)
+    eng.set_emit_thin(thin)
+    st.thin = st.c.thin = thin
+    total = weight = 0
+    for i, n in enumerate((1, 40, 37, 25)):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=4)
+        ref = st.drain()
+        rows = eng.drain_samples() if i % 2 == 0 else np.array(eng.drain_samples_view())
+        assert rows.shape == ref.shape
+        assert_bit_equal(rows, ref, "rows")
+        total += len(rows)
+        weight += int(rows[:, 1].sum()) if len(rows) else 0
+        compare_state(eng, st)
+        assert np.array_equal(eng.get_thin_carry(), st.thin_acc)
+    assert total > W // 2 and eng.counters()["dropped_rows"] == 0
+    assert "emit" in eng.last_step_kernel()
+    # the carried remainders travel with the full state
+    full = eng.get_full_state()
+    assert np.array_equal(full["thin_carry"], st.thin_acc)
+    eng.set_thin_carry(np.zeros(W, np.int32))
+    eng.set_full_state(full)
+    assert np.array_equal(eng.get_thin_carry(), st.thin_acc)
+    eng.close()
+
+
+def test_device_thinning_is_refused_where_the_general_kernels_emit():
+    eng, prob, st = make_pair(9, 256, 64, incremental=True, cap=40, K=2, weights=[0.3, 0.7])
+    with pytest.raises(E.EngineError, match="thin on the host"):
+        eng.set_emit_thin(3)
+    eng.close()
+    eng, prob, st = make_pair(9, 256, 64, incremental=False, cap=40)
+    with pytest.raises(E.EngineError, match="thin on the host"):
+        eng.set_emit_thin(3)
+    eng.close()
+    eng, prob, st = make_pair(9, 256, 64, incremental=True)
+    with pytest.raises(E.EngineError, match="emit_capacity"):
+        eng.set_emit_thin(3)
+    eng.close()
+
+
 def test_pinned_drain_views_stay_valid_for_the_ring():
     """drain_samples_view hands out library-owned pinned memory: a view is valid until its slot
     comes round again (drain_slots - 1 further drains)."""

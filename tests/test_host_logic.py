@@ -529,6 +529,38 @@ def test_thinned_chain_rows_follow_the_reference_rule():
         assert [(int(a), b) for a, b in zip(got[:, 1], got[:, 2])] == expect[w]
 
 
+def test_rows_thinned_by_the_oracle_equal_rows_thinned_on_the_host():
+    """Round 5: thinned emission on the device (mcmc_hip_set_emit_thin; oracle: orc_state.thin) is
+    the rule of `_thin_rows` = OneSamplePoint.add_to_collection (collection.py:1373-1383) applied
+    where the rows are produced: the same chain emitted unthinned and thinned on the host gives
+    the rows the oracle emits thinned, drain by drain, with the remainders carried in the state."""
+    from oracle import cbind as O
+    d, W = 5, 128
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(d, d))
+    cov = (A @ A.T / d + np.eye(d)) * 0.002
+    mean = np.full(d, 0.5)
+    T = O.proposal_transform(cov, 2.4)
+    p = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov, T=T, group_size=64,
+                  seed=9, incremental=True)
+    x0 = np.clip(mean + rng.normal(size=(W, d)) * 0.03, 1e-6, 1 - 1e-6)
+    plain = O.State(p, x0, burn_in=2, row_cap=64)
+    thinned = O.State(p, x0, burn_in=2, row_cap=64, thin=4)
+    s = _bare_sampler(None, emit="chains")
+    s.output_thin, s._thin_carry = 4, {}
+    n_thin = 0
+    for n in (7, 30, 1, 44):
+        plain.run(n, n_threads=2)
+        thinned.run(n, n_threads=2)
+        want = s._thin_rows(plain.drain())
+        got = thinned.drain()
+        order = np.lexsort((np.arange(len(want)), want[:, 0]))   # (both: chain after chain)
+        assert np.array_equal(got, want[order])
+        n_thin += len(got)
+    assert n_thin > W and np.array_equal(plain.x, thinned.x)
+    assert np.array_equal(thinned.thin_acc, [s._thin_carry.get(w, 0) for w in range(W)])
+
+
 def test_row_store_keeps_following_the_run():
     """max_rows must not freeze the stored samples (the bounds criterion reads their later
     half): full snapshot stores are thinned by two and the stride doubles; chain stores drop

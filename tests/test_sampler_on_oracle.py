@@ -398,6 +398,29 @@ def test_chains_mode_runs_on_the_incremental_path(tmp_path):
     assert len(lines(p + ".1.txt")) - 1 == len(f.products()["sample"])
 
 
+def test_emit_thin_on_the_device_equals_thinning_on_the_host(monkeypatch):
+    """`emit_thin: T` (mcmc_hip's own option; the rule of OneSamplePoint.add_to_collection with
+    output_thin, collection.py:1373-1383): where the engine's emitting kernel thins the rows itself
+    (`set_emit_thin`) the sampler takes them as they come; where it refuses, `_thin_rows` thins
+    them on the host -- the same collection either way."""
+    from tests.oracle_engine import OracleEngine
+    dev = make(None, 12000, emit="chains", steps_per_launch=20, emit_thin=3)
+    assert dev._device_thin and dev.output_thin == 3 and dev.engine.emit_thin == 3
+    dev.run()
+    monkeypatch.delattr(OracleEngine, "set_emit_thin")
+    host = make(None, 12000, emit="chains", steps_per_launch=20, emit_thin=3)
+    assert not host._device_thin and host.output_thin == 3
+    host.run()
+    a, b = dev.products()["sample"], host.products()["sample"]
+    assert len(a) == len(b) > 500
+    assert np.array_equal(a.data.to_numpy(), b.data.to_numpy())
+    # thinned: a third of the weight (the open remainders aside), and fewer rows than accepted steps
+    steps = dev.engine.counters()["steps"] * 128
+    w = np.asarray(a["weight"]).sum()
+    assert steps // 3 - 128 * 25 <= w <= steps // 3
+    assert len(a) < dev.engine.counters()["accepted"]
+
+
 def test_chains_mode_keeps_every_accepted_row_without_output():
     """with `emit: chains` and no `output`, rows read in place from the
     engine's drain slots must be copied out before their slot is reused -- the product holds
