@@ -414,9 +414,9 @@ class EnsembleMCMC:
         # thinned output: on the device where the engine's emitting kernel does it (PCIe then
         # carries output_thin times fewer rows), else on the host (`_thin_rows`)
         self._device_thin = False
-        if self.emit == "chains" and self.output_thin > 1 and hasattr(self.engine, "set_emit_thin"):
+        if self.emit == "chains" and self.row_thin > 1 and hasattr(self.engine, "set_emit_thin"):
             try:
-                self.engine.set_emit_thin(self.output_thin)
+                self.engine.set_emit_thin(self.row_thin)
                 self._device_thin = True
             except EngineError:
                 pass
@@ -589,10 +589,13 @@ class EnsembleMCMC:
                     self.output_thin = int(np.round(
                         sum(len(b) * o for b, o in zip(blocks, factors)) / spec.d))
             self.cycle_length = sum(len(b) * o for b, o in zip(blocks, factors))
-        if self.emit_thin:   # (mcmc_hip's own option: any run may thin its emitted rows)
+        # the factor emitted rows are thinned by: the reference's output_thin, or mcmc_hip's own
+        # `emit_thin` (which leaves the 'd' units and the burn-in of output_thin alone)
+        self.row_thin = self.output_thin
+        if self.emit_thin:
             if int(self.emit_thin) < 1:
                 self._fail("emit_thin must be a positive integer, got %r", self.emit_thin)
-            self.output_thin = int(self.emit_thin)
+            self.row_thin = int(self.emit_thin)
 
     @property
     def i_last_slow_block(self):
@@ -1126,7 +1129,7 @@ class EnsembleMCMC:
         """OneSamplePoint.add_to_collection (collection.py:1362-1383) for emitted chain rows:
         a walker's weights accumulate; a row is written when the sum reaches `output_thin`,
         with weight sum // output_thin, the remainder carried to its next rows."""
-        thin = self.output_thin
+        thin = getattr(self, "row_thin", None) or self.output_thin
         order = np.argsort(rows[:, 0], kind="stable")
         rows = rows[order]
         ids = rows[:, 0].astype(np.int64)
@@ -1194,7 +1197,8 @@ class EnsembleMCMC:
         `view`: the block is a read-only view of an engine-owned pinned slot (zero-copy drain);
         it is kept as such unless something has to outlive the slot (the chain file's pending
         rows, thinned rows)."""
-        if len(rows) and self.emit == "chains" and self.output_thin > 1 and not self._device_thin:
+        row_thin = getattr(self, "row_thin", None) or self.output_thin
+        if len(rows) and self.emit == "chains" and row_thin > 1 and not getattr(self, "_device_thin", False):
             rows = self._thin_rows(rows)
             view = False
         if not len(rows) or self.max_rows <= 0:

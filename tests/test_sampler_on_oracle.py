@@ -405,11 +405,11 @@ def test_emit_thin_on_the_device_equals_thinning_on_the_host(monkeypatch):
     them on the host -- the same collection either way."""
     from tests.oracle_engine import OracleEngine
     dev = make(None, 12000, emit="chains", steps_per_launch=20, emit_thin=3)
-    assert dev._device_thin and dev.output_thin == 3 and dev.engine.emit_thin == 3
+    assert dev._device_thin and dev.row_thin == 3 and dev.output_thin == 1 and dev.engine.emit_thin == 3
     dev.run()
     monkeypatch.delattr(OracleEngine, "set_emit_thin")
     host = make(None, 12000, emit="chains", steps_per_launch=20, emit_thin=3)
-    assert not host._device_thin and host.output_thin == 3
+    assert not host._device_thin and host.row_thin == 3
     host.run()
     a, b = dev.products()["sample"], host.products()["sample"]
     assert len(a) == len(b) > 500
