@@ -12,6 +12,7 @@
 #                              box by tools/collect_evidence.py into gpurun_out/evidence/<rNN>_*
 #                              (copy those into profiles/), then the full bench line re-quoted on
 #                              the counter passes just taken
+#   evidence1 <rNN>            the headline's part of `evidence` alone (bench line, kernel trace, PMC passes)
 #   ab "<v1 v2 ..>" [bench args]     same-box A/B of library builds cobaya_amd/csrc/_exp/lib_<v>.so
 #                              ("cur" = the built libmcmc_hip.so), alternated REPS (3) times
 #   abpmc "<v1 ..>" <kernel-like> [bench args]   SQ + LDS counters of one kernel for those builds
@@ -115,6 +116,17 @@ evidence)
   cp gpurun_out/final_smoke.log $EVIDENCE_DST/${RND}_smoke.log 2>/dev/null
   rm -rf gpurun_out/final gpurun_out/final_full gpurun_out/final_d100 gpurun_out/final_pl
   du -sh gpurun_out; ls $EVIDENCE_DST ;;
+evidence1)
+  # the headline's kernel-trace stats and PMC passes alone (a late change of the kernel sources:
+  # traffic.json must follow, or the bench line says so)
+  RND=${1:-r05}
+  prof gpurun_out/final
+  export EVIDENCE_DST=$PWD/gpurun_out/evidence EVIDENCE_COMMIT=$(cat tools/.evidence_commit 2>/dev/null)
+  rm -rf $EVIDENCE_DST; mkdir -p $EVIDENCE_DST
+  cp profiles/traffic.json $EVIDENCE_DST/traffic.json
+  python tools/collect_evidence.py $RND final > /dev/null
+  rm -rf gpurun_out/final
+  ls $EVIDENCE_DST ;;
 ab)
   VARIANTS=$1; shift
   O=gpurun_out/ab; mkdir -p $O
