@@ -319,6 +319,16 @@ class EnsembleMCMC:
                 if W >= 16384 and W % gs == 0:
                     self.group_size = gs
                     break
+        if W == int(self.group_size) and self.size == 1:
+            # ONE group = the reference's single chain (mcmc.py:796-813), which it splits in time
+            # into Rminus1_single_split parts for the R-1 test.  Here the group is split into that
+            # many sub-groups of WALKERS (each a multiple of the 64-lane wavefront), which are
+            # the chains of the test from then on.
+            split = int(self.Rminus1_single_split)
+            if split >= 2 and W % (64 * split) == 0:
+                self.group_size = W // split
+                self.log.info("A single group of %d walkers: split into %d groups of %d for the "
+                              "R-1 test (Rminus1_single_split).", W, split, self.group_size)
         if W % int(self.group_size) or (W // int(self.group_size)) * self.size < 2:
             # R-1 needs at least two chains (= walker groups) over all processes
             # (mcmc.py:856-889; the reference splits a single chain instead, 796-813)

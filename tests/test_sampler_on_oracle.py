@@ -145,7 +145,15 @@ def test_rminus1_is_quoted_per_walker_and_a_shared_transient_does_not_pass(tmp_p
     np.testing.assert_allclose(s.proposer.get_covariance(), tc, rtol=0.2, atol=0.01)
 
 
-def test_a_single_group_is_refused():
+def test_a_single_group_is_split_or_refused():
+    """The reference's single chain is split in time for its R-1 (mcmc.py:796-813,
+    Rminus1_single_split); a single group of walkers is split into that many sub-groups where each
+    is still a multiple of a wavefront -- and refused where it is not."""
+    s = OnOracle({"n_walkers": 256, "group_size": 256, "seed": 3, "max_samples": 4000,
+                  "Rminus1_stop": 0.0, "learn_every": "20d"}, ProblemSpec.from_info(QUICK))
+    assert int(s.group_size) == 64 and s.engine.G == 4
+    s.run()
+    assert len(s.progress) >= 1 and np.isfinite(s.progress["Rminus1"].to_numpy(float)[-1])
     with pytest.raises(LoggedError, match="at least two groups"):
         OnOracle({"n_walkers": 64, "group_size": 64}, ProblemSpec.from_info(QUICK))
     with pytest.raises(LoggedError, match="multiple of group_size"):
