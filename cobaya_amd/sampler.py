@@ -428,8 +428,9 @@ class EnsembleMCMC:
             try:
                 self.engine.set_emit_thin(self.row_thin)
                 self._device_thin = True
-            except EngineError:
-                pass
+                self.log.info("Emitted rows are thinned by %d on the device.", self.row_thin)
+            except EngineError as e:
+                self.log.info("Emitted rows are thinned by %d on the host (%s).", self.row_thin, e)
         # initial proposal covariance (sampler.py:485-685), tempered (mcmc.py:438-440)
         self._initial_covmat, where_nan = self.initial_proposal_covmat()
         if np.any(where_nan) and self.learn_proposal:
