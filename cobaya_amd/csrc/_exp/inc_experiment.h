@@ -5,6 +5,8 @@
 //   -DEXP_PIPE=n              pairs fetched ahead in the trial loop of step_inc_kernel
 //   -DEXP_KEEP=1              the step's (v, u) pairs stay in registers (no second LDS read)
 //   -DEXP_NO_ROTATE           no wave-priority rotation;  -DEXP_ROTATE_SHIFT=k  its period
+//   -DEXP_BOUNDS_REGS         per-dimension bounds in registers at every dq (else: inc_bounds_in_lds)
+//   -DEXP_FLOAT_BOUNDS        single-precision copies of LDS-resident bounds in registers at every dq
 //   -DEXP_BLOCK_TIMES         start / end clock and hardware placement of every workgroup
 //                             (read back by tools/block_times.py)
 #pragma once
