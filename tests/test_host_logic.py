@@ -853,3 +853,59 @@ def test_caps_fail_early_and_say_why():
             "params": {f"a__{i}": {"prior": {"min": 0, "max": 1}} for i in range(d)}}
     with pytest.raises(UnsupportedModel, match="65 modes"):
         ProblemSpec.from_info(info)
+
+
+def test_bench_lines_are_compact_and_complete():
+    """VERDICT r5 "Next round" 1: the round-5 line was 25.6 KB (13 variants nested in it) and the
+    driver did not parse it.  Every line `bench.py` prints is now shorter than 4 KB: the headline
+    (before the variants and again as the last line) and one line per variant.  Canned
+    measurements: the round-5 record itself (`profiles/r05_bench_full_line.json`), an 8-rank
+    `collective` block, a variant that raised."""
+    import json
+
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05_bench_full_line.json")) as f:
+        full = json.loads(f.read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    variants = full.pop("variants")
+    for i, v in enumerate(variants):
+        v["tag"] = f"v{i}"
+    variants.append({"tag": "broken", "variant": "a variant that raised",
+                     "error": "EngineError: " + "x" * 5000})
+    full["collective"] = {"backend": "nccl", "world_size": 8, "nranks_seen": 8, "rccl_error": None,
+                          "per_rank_step_kernel_ms": [0.9049123456789] * 8,
+                          "per_rank_timed_region_s": [0.0212345678901] * 8,
+                          "checkpoint_allreduce_us": 123.456789, "checkpoint_allreduce_doubles": 1835,
+                          "checkpoint_allreduce_in_stream_us": 31.23456789}
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "acceptance_rate", "certified",
+            "roofline", "cpu_baseline", "variants_file", "collective", "stage"}
+    for stage, vs in (("headline", []), ("final", variants)):
+        s = bench.headline_line(full, vs, "gpurun_out/bench_variants.json", stage)
+        assert len(s) < 4096 and "\n" not in s
+        line = json.loads(s)
+        assert need <= set(line) and line["stage"] == stage
+        assert line["value"] == pytest.approx(full["value"], rel=1e-6)
+        assert line["config"]["workload"].startswith("BASELINE configs[1]")
+        r = line["roofline"]
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms_per_launch",
+                "issue_frac", "fp64_frac", "hbm_frac"} <= set(r)
+        assert r["frac"] == r["issue_frac"] and 0 < r["hbm_frac"] < r["fp64_frac"] < r["issue_frac"] < 1
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-5)
+        assert all(not isinstance(v, (dict, list)) or k == "counters" for k, v in r.items())
+        cb = line["cpu_baseline"]
+        assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port"
+        assert line["collective"]["nranks_seen"] == 8
+    assert line["variants"]["broken"] == "error" and line["variants"]["v0"] > 1e9
+    assert line["variants_certified"] is True        # (an error is reported, not a failed certificate)
+    for v in variants:
+        s = bench.variant_line(v)
+        assert len(s) < 4096 and "\n" not in s
+        e = json.loads(s)
+        assert list(e) == ["bench_variant"] and "metric" not in e["bench_variant"]
+        if "error" not in v:
+            assert e["bench_variant"]["value"] == pytest.approx(v["value"], rel=1e-6)
+            assert e["bench_variant"]["certificate"]["ok"] is True
+            assert e["bench_variant"]["roofline"]["frac"] > 0
+    # NaN / infinity never reach a line (strict JSON)
+    assert json.loads(bench.dumps({"a": float("nan"), "b": [float("inf"), 1.0]})) == {"a": None, "b": [None, 1.0]}

@@ -73,16 +73,20 @@ bench)
   echo "bench rc=$?"; tail -c 600 gpurun_out/bench_${TAG:-line}.err
   python - gpurun_out/bench_${TAG:-line}.json <<'PY'
 import json, sys
-b = json.loads([x for x in open(sys.argv[1]) if x.startswith("{")][-1])
+lines = [json.loads(x) for x in open(sys.argv[1]) if x.startswith("{")]
+b = lines[-1]
 r = b["roofline"]
-print("value %.4g  ms/step %.4f  kernel %s %.4f ms  frac %s  accept %.3f  certified %s  KL %s" % (
+print("value %.4g  ms/step %.4f  kernel %s %.4f ms  frac %s  accept %.3f  certified %s  KL %s  line %d B" % (
     b["value"], b["ms_per_step"], r["kernel"], r["kernel_ms_per_launch"], r.get("frac"),
-    b.get("acceptance_rate", -1), b.get("certified"), (b.get("posterior_check") or {}).get("KL")))
-for v in b.get("variants", []):
-    c = v.get("certificate", {})
-    print("  %-70s %.4g  ok=%s acc=%.3f KL=%s frac=%s" % (v["variant"][:70], v["value"], c.get("ok"),
-          c.get("acceptance_rate", -1), (c.get("posterior_check") or {}).get("KL"),
-          (v.get("roofline") or {}).get("frac", v.get("fp64_frac_of_peak"))))
+    b.get("acceptance_rate", -1), b.get("certified"), (b.get("posterior_check") or {}).get("KL"),
+    max(len(x) for x in open(sys.argv[1]))))
+for v in (x["bench_variant"] for x in lines if "bench_variant" in x):
+    c = v.get("certificate") or {}
+    if "error" in v:
+        print("  %-14s ERROR %s" % (v.get("tag"), v["error"][:150])); continue
+    print("  %-14s %.4g  kernel %.4f ms  ok=%s acc=%.3f KL=%s frac=%s  %s" % (v.get("tag"), v["value"],
+          v.get("kernel_ms_per_launch") or -1, c.get("ok"), c.get("acceptance_rate") or -1, c.get("KL"),
+          (v.get("roofline") or {}).get("frac"), (v.get("kernel") or "")[:60]))
 PY
   ;;
 evidence)
