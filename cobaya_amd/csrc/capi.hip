@@ -1607,6 +1607,9 @@ int mcmc_hip_set_state(mcmc_hip_ctx* h, const double* x, int32_t* n_bad)
         HIP_TRY(h, hipMemcpyAsync(h->nrows.p, zeros.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemsetAsync(h->stuck.p, 0, sizeof(int), s));
     HIP_TRY(h, hipMemsetAsync(h->acc_total.p, 0, sizeof(unsigned long long), s));
+    // a fresh start: no thinning remainders from an earlier run (the oracle's State starts at zero;
+    // mcmc_hip_set_full_state leaves them alone -- mcmc_hip_set_thin_carry follows it)
+    if (h->thin_acc.p) HIP_TRY(h, hipMemsetAsync(h->thin_acc.p, 0, sizeof(int) * W, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     h->step = 0;
     h->have_state = true;
@@ -2424,10 +2427,10 @@ int mcmc_hip_set_emit_thin(mcmc_hip_ctx* h, int32_t thin)
                         "Metropolis steps); thin on the host");
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    if (thin > 1 && !h->thin_acc.p) {
-        HIP_TRY(h, h->thin_acc.resize((size_t)h->W));
+    if (thin > 1 && !h->thin_acc.p) HIP_TRY(h, h->thin_acc.resize((size_t)h->W));
+    // remainders are in units of the factor they were added up under: a new factor starts from zero
+    if (thin > 1 && thin != h->emit_thin)
         HIP_TRY(h, hipMemsetAsync(h->thin_acc.p, 0, sizeof(int) * (size_t)h->W, h->stream));
-    }
     h->emit_thin = thin;
     return MCMC_HIP_OK;
 }

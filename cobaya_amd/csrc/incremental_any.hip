@@ -1,6 +1,6 @@
 // mcmc_hip -- the GENERAL incremental step kernel (gfx950 only), 2 <= d <= 128.
 //
-// What the tuned incremental kernels (incremental_kernels.hip, incremental_periodic.hip) leave
+// What the tuned incremental kernels (incremental_kernels.hip: step_inc_kernel<.., PER>, step_inc_mix_kernel) leave
 // out: mixtures of more than four modes (gaussian_mixture.py:138-163, up to kMaxModes), mixtures
 // above d = 64, periodic parameters (prior.py:658-676) together with a mixture, more than eight
 // periodic parameters, and emitted rows of anything but one non-periodic mode.  Same specification (oracle/mcmc_oracle.c, step_core_inc), same O(d) step: the trial
@@ -25,7 +25,7 @@
 // lane, i.e. 4 modes at d = 128, 8 at d <= 92, 16 at d <= 48, and periodic sets whose columns of
 // L^-1 take at most 24 KiB of LDS -- runs on step_inc_regs_kernel<DQ, KM, PER> instead:
 // step_inc_mix_kernel's design (everything in registers, KM = 2, 4, 8 or 16 register planes of
-// which the first n_modes are live; PER adds incremental_periodic.hip's scheme for periodic
+// which the first n_modes are live; PER adds the round-3 scheme for periodic
 // parameters), which does not pay the LDS round trips and is not held to one wave per SIMD by
 // the LDS the state takes.  One translation unit per group of KM (build.py: -DANY_PART=0 / 1 / 2).
 // Both kernels emit rows at run time (`emit: chains`, s.rows).
@@ -440,7 +440,7 @@ __host__ __device__ constexpr bool regs_fits(int dq, int km) { return dq * (km +
 __host__ __device__ constexpr int regs_bucket(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : 16; }
 
 // a / w given R = RN(1 / w): the correctly rounded quotient in five operations (see
-// incremental_periodic.hip: q1 is faithful, and a faithful quotient corrected once with the
+// DESIGN.md 2 "Periodic parameters": q1 is faithful, and a faithful quotient corrected once with the
 // correctly rounded reciprocal is the IEEE quotient)
 __device__ __forceinline__ double regs_div_by(double a, double w, double R)
 {
@@ -452,7 +452,8 @@ __device__ __forceinline__ double regs_div_by(double a, double w, double R)
 // KM register planes, the first a.n_modes of them live (a plane beyond that is never touched:
 // the tests on k < K are wave-uniform branches around fully unrolled code).  The columns are
 // planes of 4 DQ doubles, 1 + n_modes of them.  One-parameter blocks and the temperature are
-// run-time properties here.  PER: periodic parameters, as in incremental_periodic.hip -- the trial
+// run-time properties here.  PER: periodic parameters (the round-3 scheme; the tuned one-mode kernel folds them
+// into step_inc_kernel<.., PER> instead) -- the trial
 // and commit loops stay branch-free (a periodic dimension has the bounds (-inf, +inf) there);
 // behind each, the rows that hold a periodic dimension wrap their coordinate; a wrap in the
 // wave sends the trial residual of a mode to registers, which takes the wrap moves in ascending

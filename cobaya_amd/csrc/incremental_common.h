@@ -1,5 +1,4 @@
-// Shared device helpers of the incremental kernels (incremental_kernels.hip, incremental_any.hip,
-// incremental_periodic.hip): DPP quad permutes and sums, lane-mask helpers, the priority rotation,
+// Shared device helpers of the incremental kernels (incremental_kernels.hip, incremental_any.hip): DPP quad permutes and sums, lane-mask helpers, the priority rotation,
 // laundered LDS pointers, the size of a column chunk.  gfx950 only.
 #pragma once
 #include "det_math.h"

@@ -160,10 +160,15 @@ def load_library(path: str | None = None):
             fn = getattr(lib, name)  # AttributeError if the library does not export it
         except AttributeError:
             # developer A/B runs against an OLDER build of the library (MCMC_HIP_LIB=... with
-            # MCMC_HIP_LIB_COMPAT=1, tools/gpu.sh ab): an entry point it predates answers 0 / "no"
+            # MCMC_HIP_LIB_COMPAT=1, tools/gpu.sh ab): an entry point it predates answers "no" --
+            # 0 for the predicates (`*_supported`, `*carries_*`), MCMC_HIP_ERR_ARG for every
+            # setter and getter: a missing mcmc_hip_set_emit_thin must not look like success
+            # (the sampler then skipped host thinning and rows came out un-thinned)
             if not (os.environ.get("MCMC_HIP_LIB_COMPAT") and os.environ.get("MCMC_HIP_LIB")):
                 raise
-            setattr(lib, name, C.CFUNCTYPE(restype, *argtypes)(lambda *a: 0))
+            predicate = "carries_" in name or name.endswith("_supported")
+            answer = 0 if predicate or restype is not C.c_int else ERR_ARG
+            setattr(lib, name, C.CFUNCTYPE(restype, *argtypes)(lambda *a, _r=answer: _r))
             continue
         fn.restype = restype
         fn.argtypes = argtypes

@@ -285,9 +285,8 @@ class EnsembleMCMC:
         self.max_tries = _number_with_units(self.max_tries, "d", unit)
         self.learn_every = int(_number_with_units(self.learn_every, "d", unit))
         self.burn_in = int(_number_with_units(self.burn_in, "d", unit))
-        self._spl_default = self.steps_per_launch is None
         self.steps_per_launch = max(1, int(_number_with_units(
-            "40d" if self._spl_default else self.steps_per_launch, "d", unit)))
+            "40d" if self.steps_per_launch is None else self.steps_per_launch, "d", unit)))
         if self.drag:  # a dragging step costs 1 + 2 * drag_interp_steps evaluations
             self.steps_per_launch = max(1, self.steps_per_launch // (1 + self.drag_interp_steps))
         if self.callback_every is None:
@@ -319,16 +318,21 @@ class EnsembleMCMC:
                 if W >= 16384 and W % gs == 0:
                     self.group_size = gs
                     break
+        self._split_of = None
         if W == int(self.group_size) and self.size == 1:
             # ONE group = the reference's single chain (mcmc.py:796-813), which it splits in time
             # into Rminus1_single_split parts for the R-1 test.  Here the group is split into that
             # many sub-groups of WALKERS (each a multiple of the 64-lane wavefront), which are
-            # the chains of the test from then on.
-            split = int(self.Rminus1_single_split)
-            if split >= 2 and W % (64 * split) == 0:
+            # the chains of the test from then on -- or into the largest smaller number (>= 2)
+            # that divides the walkers so.  Only the R-1 bookkeeping changes: the walkers keep
+            # sharing ONE Haar basis where the engine can do that (`basis_group_size`, below).
+            want = int(self.Rminus1_single_split)
+            split = next((n for n in range(want, 1, -1) if W % (64 * n) == 0), None)
+            if split:
+                self._split_of = W
                 self.group_size = W // split
                 self.log.info("A single group of %d walkers: split into %d groups of %d for the "
-                              "R-1 test (Rminus1_single_split).", W, split, self.group_size)
+                              "R-1 test (Rminus1_single_split: %d).", W, split, self.group_size, want)
         if W % int(self.group_size) or (W // int(self.group_size)) * self.size < 2:
             # R-1 needs at least two chains (= walker groups) over all processes
             # (mcmc.py:856-889; the reference splits a single chain instead, 796-813)
@@ -385,7 +389,11 @@ class EnsembleMCMC:
         # runs that are not waiting for R-1.)
         if self.basis_group_size is None:
             self.basis_group_size = int(self.group_size)
-            if self.incremental and W >= 16384 and W % 1024 == 0 and 1024 % int(self.group_size) == 0:
+            n_split = (self._split_of or 0) // int(self.group_size)
+            if self.incremental and n_split >= 2 and n_split & (n_split - 1) == 0:
+                # a single group that was split for the R-1 test: one basis for all, as asked
+                self.basis_group_size = int(self._split_of)
+            elif self.incremental and W >= 16384 and W % 1024 == 0 and 1024 % int(self.group_size) == 0:
                 self.basis_group_size = 1024
                 # at the benchmark size the Haar bases and the whitened columns of a launch
                 # are 6 % of the step kernel with a basis per 1024 walkers (a tenth above
@@ -620,7 +628,9 @@ class EnsembleMCMC:
         self.collection = self._export_collection(
             SampleCollection(spec.sampled, spec.derived, self._like_names(),
                              self.temperature, name=str(1 + self.rank)))
-        self._thin_carry = {}    # chains mode with thinned output: added weight per walker
+        # chains mode with output thinned on the host: added weight per walker (dense, saved in
+        # the state file under the key the device-thinned path uses: `thin_carry`)
+        self._thin_carry = np.zeros(int(self.n_walkers), dtype=np.int64)
         self._snap_stride, self._snap_count, self._rows_capped = 1, 0, False
         self._rows = []          # (walker, weight, logpost, logprior, loglike, x...) blocks
         self._n_rows = 0
@@ -950,6 +960,9 @@ class EnsembleMCMC:
             self._last_state_dump = now
             self._flush_rows()
             st = self.engine.get_full_state()
+            if self.emit == "chains" and self.row_thin > 1 and not self._device_thin:
+                st["thin_carry"] = self._thin_carry.astype(np.int32)   # (host-thinned rows)
+            st["geometry"] = np.array([int(self.group_size), int(self.basis_group_size)], dtype=np.int64)
             acc_n, acc_gs, acc_S = self.engine.read_moments(reset=False)
             st.update(acc_n=np.int64(acc_n), acc_gs=acc_gs, acc_S=acc_S)
             ivs = self._intervals
@@ -1054,6 +1067,14 @@ class EnsembleMCMC:
             self._fail("Cannot resume a run with a different number of chains: was "
                        "%d processes x %d walkers and now is %d x %d.",
                        int(book[8]), int(book[9]), self.size, int(self.n_walkers))
+        if "geometry" in z and tuple(int(v) for v in z["geometry"]) != (
+                int(self.group_size), int(self.basis_group_size)):
+            self._fail("Cannot resume: the run was written with group_size %d / basis_group_size %d "
+                       "and now has %d / %d (the walkers' variate streams and the R-1 groups "
+                       "depend on them).", int(z["geometry"][0]), int(z["geometry"][1]),
+                       int(self.group_size), int(self.basis_group_size))
+        if "thin_carry" in z and not self._device_thin:
+            self._thin_carry = z["thin_carry"].astype(np.int64)
         self.engine.set_proposal_cov(z["proposal_cov"])
         self.engine.set_full_state({k: z[k] for k in ("x", "logpost", "logprior", "loglike",
                                                       "weight", "prior_rej", "burn_left",
@@ -1148,12 +1169,12 @@ class EnsembleMCMC:
         cum = np.cumsum(w)
         first = np.r_[0, np.flatnonzero(np.diff(ids)) + 1]
         base = np.repeat(cum[first] - w[first], np.diff(np.r_[first, len(ids)]))
-        carry = np.array([self._thin_carry.get(int(i), 0) for i in ids[first]], dtype=np.int64)
+        off = self.rank * int(self.n_walkers)     # rows carry GLOBAL walker ids
+        carry = self._thin_carry[ids[first] - off]
         total = cum - base + np.repeat(carry, np.diff(np.r_[first, len(ids)]))
         q, q_prev = total // thin, (total - w) // thin
         last = np.r_[first[1:] - 1, len(ids) - 1]
-        for i, t in zip(ids[last], total[last]):
-            self._thin_carry[int(i)] = int(t % thin)
+        self._thin_carry[ids[last] - off] = total[last] % thin
         keep = q > q_prev
         out = rows[keep].copy()
         out[:, 1] = (q - q_prev)[keep]

@@ -909,3 +909,30 @@ def test_bench_lines_are_compact_and_complete():
             assert e["bench_variant"]["roofline"]["frac"] > 0
     # NaN / infinity never reach a line (strict JSON)
     assert json.loads(bench.dumps({"a": float("nan"), "b": [float("inf"), 1.0]})) == {"a": None, "b": [None, 1.0]}
+
+
+def test_compat_stubs_of_an_older_library_answer_no(tmp_path, monkeypatch):
+    """with MCMC_HIP_LIB_COMPAT=1 (developer A/B runs against an older build) an entry
+    point the library predates must not look like success: setters and getters answer
+    MCMC_HIP_ERR_ARG, only the predicates answer 0 = "no"."""
+    src = tmp_path / "old.c"
+    src.write_text("int mcmc_hip_old_build_marker(void) { return 1; }\n")
+    so = tmp_path / "libold.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    monkeypatch.setenv("MCMC_HIP_LIB", str(so))
+    monkeypatch.setenv("MCMC_HIP_LIB_COMPAT", "1")
+    saved = E._lib
+    try:
+        old = E.load_library(str(so))
+        assert old.mcmc_hip_set_emit_thin(None, 3) == E.ERR_ARG
+        assert old.mcmc_hip_get_thin_carry(None, None) == E.ERR_ARG
+        assert old.mcmc_hip_incremental_supported(30, 1, 0, 0, 65536, 4096) == 0
+        assert old.mcmc_hip_incremental_carries_modes(None) == 0
+    finally:
+        E._lib = saved
+    monkeypatch.delenv("MCMC_HIP_LIB_COMPAT")
+    with pytest.raises(AttributeError):
+        try:
+            E.load_library(str(so))
+        finally:
+            E._lib = saved

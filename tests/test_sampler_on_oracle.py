@@ -579,3 +579,46 @@ def test_device_reduce_checkpoint_retraces_the_host_checkpoint(tmp_path):
         make(None, 1000, device_checkpoint=True)
     with pytest.raises(LoggedError, match="device_checkpoint must be one of"):
         make(None, 1000, device_checkpoint="gpu")
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_thinned_rows_resume_bit_identically(tmp_path, monkeypatch, where):
+    """the per-walker thinning remainders come back at a resume on BOTH paths -- the
+    device-thinned one (engine state) and the host fallback (`_thin_rows`; the state file's
+    `thin_carry`, the same key): the chain file of run + resume equals the uninterrupted run's."""
+    if where == "host":
+        monkeypatch.delattr(OracleEngine, "set_emit_thin")
+    kw = dict(emit="chains", steps_per_launch=20, emit_thin=7)
+    one = make(str(tmp_path / "a"), 30000, **kw)
+    assert one._device_thin == (where == "device")
+    one.run()
+    p = str(tmp_path / "b")
+    b1 = make(p, 14000, **kw)
+    b1.run()
+    z = np.load(p + ".1.state.npz")
+    assert "thin_carry" in z and z["thin_carry"].shape == (128,) and z["thin_carry"].max() > 0
+    assert tuple(z["geometry"]) == (64, 64)
+    b2 = make(p, 30000, resume=True, **kw)
+    b2.run()
+    assert lines(p + ".1.txt") == lines(str(tmp_path / "a") + ".1.txt")
+    # the geometry the streams depend on is checked at a resume
+    with pytest.raises(LoggedError, match="group_size 64"):
+        make(p, 30000, resume=True, n_walkers=128, group_size=128, **kw)
+
+
+def test_a_single_group_splits_as_far_as_the_wavefronts_allow():
+    """W = 128 with Rminus1_single_split = 4 cannot give four groups of whole
+    wavefronts -- two of 64 are taken instead of refusing; the walkers keep sharing ONE Haar
+    basis (the user's group) where the number of sub-groups is a power of two."""
+    s = OnOracle({"n_walkers": 128, "group_size": 128, "seed": 3, "max_samples": 2000,
+                  "Rminus1_stop": 0.0, "learn_every": "20d"}, ProblemSpec.from_info(QUICK))
+    assert int(s.group_size) == 64 and s.engine.G == 2 and s._split_of == 128
+    assert int(s.basis_group_size) == (128 if s.incremental else 64)
+    s.run()
+    assert np.isfinite(s.progress["Rminus1"].to_numpy(float)[-1])
+    s = OnOracle({"n_walkers": 256, "group_size": 256, "seed": 3}, ProblemSpec.from_info(QUICK))
+    assert int(s.group_size) == 64 and int(s.basis_group_size) == (256 if s.incremental else 64)
+    # three sub-groups (not a power of two): the basis follows the sub-groups
+    s = OnOracle({"n_walkers": 192, "group_size": 192, "seed": 3, "Rminus1_single_split": 3},
+                 ProblemSpec.from_info(QUICK))
+    assert int(s.group_size) == 64 and int(s.basis_group_size) == 64
