@@ -109,3 +109,18 @@ def test_sampler_stops_on_the_bounds_criterion_with_nothing_stored():
     # n = 64 walkers x snapshots per chain: the bound's sampling noise, sqrt(q(1-q)/n)/pdf, ~ 0.05-0.15
     assert cl[-1] > 0.01
     s.close()
+
+
+def test_getdist_pin_tool_on_the_device(capsys, monkeypatch):
+    """`tools/check_getdist_bounds.py --device`: the committed reference chains (golden G7) through
+    `mcmc_hip_bounds_statistics` against GetDist's `confidence` where GetDist is installed, against
+    its restatement otherwise -- exact either way."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_getdist_bounds as T
+    monkeypatch.setattr(sys, "argv", ["check_getdist_bounds.py", "--device"])
+    assert T.main() == 0
+    out = capsys.readouterr().out
+    assert out.count("device bounds") == len(T.LIMFRACS) and "DIFFERENT" not in out

@@ -936,3 +936,22 @@ def test_compat_stubs_of_an_older_library_answer_no(tmp_path, monkeypatch):
             E.load_library(str(so))
         finally:
             E._lib = saved
+
+
+def test_getdist_pin_tool_runs_dry_without_getdist(capsys, monkeypatch):
+    """VERDICT r5 "Next round" 9: `tools/check_getdist_bounds.py` is the one-command pin of
+    `Rminus1_cl` (mcmc.py:925-930 through GetDist's `confidence`) for a machine that has GetDist;
+    here -- GetDist absent -- it runs the restatement on the committed reference chains and says so."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_getdist_bounds as T
+    chains = T.committed_chains()
+    assert len(chains) == 12 and all(x.shape[0] == len(w) and w.min() >= 1 for _, x, w, _ in chains)
+    assert T.pieces(600) == [(0, 600), (150, 299), (300, 449), (450, 599)]
+    monkeypatch.setattr(sys, "argv", ["check_getdist_bounds.py"])
+    assert T.main() == 0
+    out = capsys.readouterr().out
+    try:
+        import getdist  # noqa: F401
+        assert "pinning" in out and "all equal" in out
+    except ImportError:
+        assert "DRY RUN" in out and "all equal (restatement only)" in out
