@@ -382,6 +382,7 @@ struct mcmc_hip_ctx {
     double* pin_mom = nullptr;                      // [G*d + d(d+1)/2 + 2]
     double* pin_T = nullptr;                        // ring of 4 transforms [4][d*d]
     int pin_T_slot = 0;
+    hipEvent_t pin_T_done[4] = {nullptr, nullptr, nullptr, nullptr};   // the copy out of slot k has run
     hipEvent_t mom_event = nullptr;
     bool mom_pending = false;
     int64_t mom_n = 0;
@@ -1006,6 +1007,7 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
     // (y is sized when the target is known: [K][d][W])
     acc(hipHostMalloc((void**)&h->pin_mom, sizeof(double) * (G * d + np + 2), hipHostMallocDefault));
     acc(hipHostMalloc((void**)&h->pin_T, sizeof(double) * 4 * d * d, hipHostMallocDefault));
+    for (auto& e : h->pin_T_done) acc(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     acc(hipEventCreateWithFlags(&h->mom_event, hipEventDisableTiming));
     if (h->incremental) {
         // (LOWEST priority: the step kernel's 1024 workgroups are exactly what the chip holds
@@ -1050,7 +1052,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto& D : h->dirs) {
         D.V.release(); D.Vf.release(); D.VU.release(); D.vflag.release(); D.vflag_f.release(); D.UU.release();
-        D.colflag.release();
+        D.colflag.release(); D.VW.release(); D.NL.release();
         if (D.ready) (void)hipEventDestroy(D.ready);
     }
     if (h->mark) (void)hipEventDestroy(h->mark);
@@ -1074,6 +1076,7 @@ void mcmc_hip_destroy(mcmc_hip_ctx* h)
     if (h->ck.ev) (void)hipEventDestroy(h->ck.ev);
     if (h->pin_mom) (void)hipHostFree(h->pin_mom);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
+    for (auto& e : h->pin_T_done) if (e) (void)hipEventDestroy(e);
     if (h->mom_event) (void)hipEventDestroy(h->mom_event);
     h->pack_out.release(); h->pack_off.release();
     h->y.release(); h->amode.release(); h->inc_prior.release(); h->inc_Lrow.release();
@@ -1498,11 +1501,17 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
         for (int j = 0; j <= i; ++j) h->T[i * d + j] = h->cfg.proposal_scale * (sd[i] * L[i * d + j]);
     // Stream-ordered, no host synchronisation: launches already queued keep the old transform
     // (their basis kernels precede this copy in the stream), later ones see the new one.  The
-    // source is a pinned ring slot that stays untouched for the next three refreshes.
+    // source is a pinned ring slot that stays untouched for the next three refreshes: before it
+    // is written again the host waits for the copy that last read it -- an event recorded four
+    // refreshes ago, long complete.  (Rounds 1-5 synchronised the whole stream whenever the ring
+    // wrapped: every fourth refresh the host lost its lead of several launches, and the device
+    // then idled through the host's pass over the checkpoint -- 275 instead of 96 us between
+    // two step kernels, tools/gpu.sh timeline, round 6.)
     HIP_TRY(h, hipSetDevice(h->cfg.device));
-    double* slot = h->pin_T + (size_t)h->pin_T_slot * d * d;
+    const int k_slot = h->pin_T_slot;
+    double* slot = h->pin_T + (size_t)k_slot * d * d;
     h->pin_T_slot = (h->pin_T_slot + 1) & 3;
-    if (h->pin_T_slot == 0) HIP_TRY(h, hipStreamSynchronize(h->stream));   // ring wrapped
+    HIP_TRY(h, hipEventSynchronize(h->pin_T_done[k_slot]));   // (never recorded: returns at once)
     std::copy(h->T.begin(), h->T.end(), slot);
     // a direction set being filled ahead on the second stream still reads dT: the copy waits for
     // it (that set is stale after ++dir_epoch and is recomputed, but it must not read a torn T)
@@ -1510,6 +1519,7 @@ int mcmc_hip_set_proposal_cov(mcmc_hip_ctx* h, const double* cov)
         if (D.ahead && D.ready) HIP_TRY(h, hipStreamWaitEvent(h->stream, D.ready, 0));
     HIP_TRY(h, hipMemcpyAsync(h->dT.p, slot, sizeof(double) * d * d, hipMemcpyHostToDevice,
                               h->stream));
+    HIP_TRY(h, hipEventRecord(h->pin_T_done[k_slot], h->stream));
     if (h->T_event) {
         HIP_TRY(h, hipEventRecord(h->T_event, h->stream));
         h->T_fresh = true;
@@ -1872,6 +1882,7 @@ int make_directions(mcmc_hip_ctx* h, const IncPlan& P, const IncSeg& s, mcmc_hip
         HIP_TRY(h, D.NL.resize((size_t)h->BG * s.n * 2));
         w.prior = h->inc_prior.p; w.VW = D.VW.p; w.NL = D.NL.p;
     }
+
     if (P.drag) { w.out_div = 1; w.out_cols = 1 + nd; w.out_slot0 = 0; }
     if (P.any) HIP_TRY(h, mcmc_hip_launch_whiten_directions_planes(&w, h->BG, st));
     else HIP_TRY(h, mcmc_hip_launch_whiten_directions(&w, h->BG, st));

@@ -192,10 +192,13 @@ import glob, sqlite3, sys
 O = sys.argv[1]
 db = sqlite3.connect(glob.glob(f"{O}/prof/**/*.db", recursive=True)[0])
 rows = db.execute("select start, end, name, queue_id from kernels order by start").fetchall()
-try:
-    mc = db.execute("select start, end, name, 0 from memory_copies order by start").fetchall()
-except Exception as e:
-    print("no memory_copies view:", e); mc = []
+try:   # (with the bytes moved where the view has them)
+    mc = db.execute("select start, end, name || ' ' || size || ' B', 0 from memory_copies order by start").fetchall()
+except Exception:
+    try:
+        mc = db.execute("select start, end, name, 0 from memory_copies order by start").fetchall()
+    except Exception as e:
+        print("no memory_copies view:", e); mc = []
 ev = sorted(rows + mc)
 idx = [i for i, r in enumerate(ev) if "step_" in r[2] or "pl_fused" in r[2]]
 i0, i1 = idx[len(idx) // 2], idx[min(len(idx) // 2 + int(__import__("os").environ.get("TL_STEPS", "5")), len(idx) - 1)]
