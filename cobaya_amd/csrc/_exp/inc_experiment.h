@@ -85,3 +85,13 @@ extern "C" __attribute__((visibility("default"))) int mcmc_hip_debug_wave_place(
 #define MCMC_EXP_BLOCK_BEGIN() ((void)0)
 #define MCMC_EXP_BLOCK_END() ((void)0)
 #endif
+//   -DEXP_FLOAT_LDS=0|1       (round 6) single-precision bounds from LDS + kept pairs in the two-wave kernels of MODE 1 / 2
+#ifdef EXP_FLOAT_LDS
+#define MCMC_EXP_FLOAT_LDS(tuned) (EXP_FLOAT_LDS != 0)
+#endif
+#ifdef EXP_FLOAT_LDS_KEEP
+#define MCMC_EXP_FLOAT_LDS_KEEP(tuned) (EXP_FLOAT_LDS_KEEP != 0)
+#endif
+#ifdef EXP_FLOAT_VEC
+#define MCMC_EXP_FLOAT_VEC(tuned) (EXP_FLOAT_VEC != 0)
+#endif

@@ -88,9 +88,45 @@ __host__ __device__ constexpr bool inc_bounds_in_lds(int dq, int mode, bool per)
 // 80: 5.98 -> 5.36, 96: 8.25 -> 7.28, 100: 9.83 -> 8.96, 112: 11.99 -> 11.42, 116: 14.5 -> 13.9;
 // d = 124 / 128 (one wave per SIMD now, inc_min_waves): 24.9 -> 17.7 / 35.4 -> 19.5.  The kernels
 // at four waves per SIMD (dq <= 12, 128 registers) cannot afford the 4 dq registers.
+#ifndef MCMC_EXP_FLOAT_LDS
+#define MCMC_EXP_FLOAT_LDS(tuned) (tuned)
+#endif
+#ifndef MCMC_EXP_FLOAT_VEC
+#define MCMC_EXP_FLOAT_VEC(tuned) (tuned)
+#endif
+#ifndef MCMC_EXP_FLOAT_LDS_KEEP
+#define MCMC_EXP_FLOAT_LDS_KEEP(tuned) (tuned)
+#endif
+// Round 6: general bounds (MODE 1, 2) at dq >= 13 -- the two-wave kernels, where the per-dimension
+// bounds sit in LDS -- test the support on SINGLE-PRECISION copies of the bounds read from LDS,
+// two rows per ds_read_b128 (inc_float_lds below: a quarter of the bytes of the (lo, hi) double
+// pairs), and that frees the registers to keep the pairs like MODE 0 does.
+__host__ __device__ constexpr bool inc_float_lds(int dq, int mode, bool per);
 __host__ __device__ constexpr bool inc_keep_pairs(int dq, int mode, bool per = false)
 {
-    return (mode == 0 && dq >= 13) || inc_one_wave_regs(dq, mode, per);
+    return (mode == 0 && dq >= 13) || (inc_float_lds(dq, mode, per) && MCMC_EXP_FLOAT_LDS_KEEP(true)) ||
+           inc_one_wave_regs(dq, mode, per);
+}
+// Measured (round 6, same box, 65 536 walkers, step kernel ms per 40 d steps, round-5 form -> this one;
+// tools/cliff_bench.py d:1:-1, tools/config5_bench.py; profiles/r06_float_lds.txt).  MODE 1:
+//   d = 52: 3.45 -> 3.07 | 56: 4.12 -> 3.80 | 60: 4.48 -> 4.33 | 64: 5.03 -> 4.73 | 68: 5.66 -> 5.32 | 76: 6.28 -> 6.07
+//   84: 7.50 -> 7.03 | 88: 8.38 -> 7.88 | 92: 10.55 -> 9.27 | 96: 11.35 -> 9.95 | 100: 13.79 -> 11.35 | 112: 16.44 -> 13.99
+//   120: 19.7 -> 19.8.  MODE 2 gains up to dq = 18 (d = 52: 5.27 -> 4.37, 64: 5.98 -> 5.67, 72: 7.23 -> 6.80) and
+//   spills above (d = 80: 10.1 -> 13.1, d = 96: 14.7 -> 49): it keeps the round-5 form there.
+// (The per-dimension test from LDS doubles was half of the kernel's time at d = 100: 13.9 ms against 6.1
+// with the test compiled out and the pairs kept, profiles/r06_margin_test.txt.)
+__host__ __device__ constexpr bool inc_float_lds(int dq, int mode, bool per)
+{
+    return MCMC_EXP_FLOAT_LDS(!per && !inc_one_wave_regs(dq, mode, per) &&
+                              ((mode == 1 && dq >= 13) || (mode == 2 && dq >= 13 && dq <= 18)));
+}
+// ... the verdict of that test gathered in a VECTOR register (v_med3_f32 + or, one compare per step)
+// where its three more registers fit -- MODE 1 at dq = 14 .. 22: the two waves of a SIMD no longer
+// wait on a chain of 2 dq scalar ANDs (d = 88: 8.58 -> 7.88) --, on the scalar unit elsewhere (dq = 13
+// runs four waves on 128 registers: 3.07 against 17.2 spilled; dq >= 23: d = 96: 9.95 against 17.6)
+__host__ __device__ constexpr bool inc_float_vec(int dq, int mode)
+{
+    return MCMC_EXP_FLOAT_VEC(mode == 1 && dq >= 14 && dq <= 22);
 }
 
 //   ONED: some parameter block has ONE parameter; the steps on its columns (a.colflag) draw the
@@ -134,8 +170,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     // ms per 40 d steps of 65 536 walkers: d = 56: 4.65 -> 4.18, 60: 5.37 -> 4.49, 64: 5.94 -> 5.15,
     // 68: 6.68 -> 5.66, 80: 8.34 -> 6.83, 88: 9.83 -> 8.22; d = 96 and 100 (dq = 24, 25) spill: 11.4 ->
     // 16.2, 13.9 -> 25.1; dq = 13 runs at four waves (128 registers): 3.33 -> 12.9
+    constexpr bool kFloatLds = kBoundsInLds && inc_float_lds(DQ, MODE, PER);
+    constexpr bool kFloatVec = kFloatLds && inc_float_vec(DQ, MODE);
     constexpr bool kFloatBounds =
-        kBoundsInLds &&
+        kBoundsInLds && !kFloatLds &&
         // (periodic parameters at dq = 14..20 as well: d = 56 with one 5.93 -> 5.07, d = 64 with two
         // 8.25 -> 6.75, d = 80 with two 11.74 -> 9.72; dq = 23 without: no difference)
         MCMC_EXP_FLOAT_BOUNDS(PER ? (DQ <= 8 || (DQ >= 14 && DQ <= 20))
@@ -173,6 +211,10 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
     // was waited for at once instead of at the end of the chunk
     __shared__ double2 sLHs[kBoundsInLds ? dpad : 1];
     double2* const sLH = sLHs;
+    // kFloatLds: single-precision copies of the bounds, rounded INWARD and moved in by one more ulp
+    // (a trial rounded to single precision that lies within them is inside for certain), two rows
+    // per 16 bytes: sFB[(kk / 2) * 4 + c] = (lo, hi of row kk & ~1; lo, hi of row kk | 1)
+    __shared__ float4 sFB[kFloatLds ? 4 * ((DQ + 1) / 2) : 1];
     // periodic parameters, behind that: the wrap moves of a step [walker of the workgroup][periodic
     // parameter], written by the lane that owns the dimension and read by its quad, and
     // L^-1[j][i_q] for j >= i_q, the q-th periodic dimension -- what a wrap moves y by
@@ -260,6 +302,26 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
         for (int i = tid; i < dpad; i += 256) {
             const double bh = a.prior[dpad + i];
             sLH[i] = make_double2(a.prior[i], (i < d && is_periodic(i)) ? pred_double(bh) : bh);
+        }
+    if (kFloatLds)
+        for (int e = tid; e < 4 * ((DQ + 1) / 2); e += 256) {
+            const int kk0 = 2 * (e >> 2), cc = e & 3;
+            float v[4];
+            for (int h = 0; h < 2; ++h) {
+                const int i = 4 * (kk0 + h) + cc;   // (beyond the padded rows: no bound)
+                float fl = -INFINITY, fh = INFINITY;
+                if (i < dpad) {
+                    // lo: rounded up, then one ulp further in; hi: rounded down, then one further in
+                    // (infinite bounds -- the padding, a dimension without a bound -- stay infinite)
+                    fl = __double2float_ru(a.prior[i]);
+                    fh = __double2float_rd(a.prior[dpad + i]);
+                    if (fl > -INFINITY) fl = nextafterf(fl, INFINITY);
+                    if (fh < INFINITY) fh = nextafterf(fh, -INFINITY);
+                }
+                v[2 * h] = fl;
+                v[2 * h + 1] = fh;
+            }
+            sFB[e] = make_float4(v[0], v[1], v[2], v[3]);
         }
     if (PER) {
         for (int i = tid; i < dpad; i += 256) {
@@ -441,6 +503,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
                     // beyond it, negative, -0) is decided by the exact comparisons below, a
                     // wave-uniform branch that a posterior away from the walls never takes
                     unsigned hmx = 0u;
+                    float4 fb2 = make_float4(0.f, 0.f, 0.f, 0.f);   // (kFloatLds) the bounds of two rows
+                    unsigned facc = 0u;   // (kFloatLds) 0: every trial coordinate so far is inside its float bounds
                     auto trial = [&](int kk, const pair_t p) {
                         const double t = fma(r, p.x, x[kk]);
                         if (MODE == 0) {
@@ -453,6 +517,22 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
                             // within bounds rounded INWARD and moved in by one more ulp)
                             const float tf = __double2float_rn(t);
                             inb &= lanes(tf <= fhi[kk]) & lanes(tf >= flo[kk]);
+                        }
+                        else if (kFloatLds) {
+                            // ... the same on copies read from LDS: the rows kk, kk + 1 share a read
+                            // (the verdict is gathered in a VECTOR register: the median of (trial, lo,
+                            // hi) IS the trial exactly when it lies within them -- one v_med3_f32 and
+                            // an or of the differing bits per dimension, one compare per step.  With
+                            // two compares and two scalar ANDs per dimension the two waves of a SIMD
+                            // waited on the chain through the scalar unit: d = 100, 11.4 ms per
+                            // 4 000 steps against 13.8 with the double-precision bounds)
+                            if ((kk & 1) == 0) fb2 = sFB[(kk >> 1) * 4 + c];
+                            const float tf = __double2float_rn(t);
+                            const float bl = (kk & 1) ? fb2.z : fb2.x, bh = (kk & 1) ? fb2.w : fb2.y;
+                            if (kFloatVec)
+                                facc |= __float_as_uint(__builtin_amdgcn_fmed3f(tf, bl, bh)) ^ __float_as_uint(tf);
+                            else   // (inc_float_vec: where the vector form's registers do not fit)
+                                inb &= lanes(tf <= bh) & lanes(tf >= bl);
                         }
                         else {
                             const double2 lh = sLH[4 * kk + c];
@@ -534,7 +614,8 @@ __global__ void __launch_bounds__(256, inc_min_waves(DQ, MODE, PER)) step_inc_ke
                             inside_m = quad_all_mask(inb);
                         }
                     } else {
-                        if constexpr (kFloatBounds && !PER) {
+                        if constexpr (kFloatVec) inb = lanes(facc == 0u);
+                        if constexpr ((kFloatBounds || kFloatLds) && !PER) {
                             // (wave-uniform, rare: some trial coordinate is not inside for certain
                             // -- within 2^-23 of a bound, or outside: the exact comparisons, rows
                             // from LDS; with periodic parameters the pass below does them)
