@@ -1928,10 +1928,12 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                     "incremental evaluation: %d modes at d=%d with %d periodic parameters do not "
                     "fit the LDS of a CU; use evaluation: full for this model", K, d, n_periodic);
     const bool emit = h->cfg.emit_capacity > 0;
-    if (emit && h->emit_thin > 1 && (K != 1 || n_periodic > 0 || P.drag))
+    // (round 6: the general incremental kernels thin too -- mixtures, periodic parameters, blocks of
+    // one parameter; dragging emits on the from-scratch kernels, which do not)
+    if (emit && h->emit_thin > 1 && P.drag)
         return fail(h, MCMC_HIP_ERR_ARG,
-                    "emit_thin: rows are thinned on the device by step_inc_kernel<.., emit> (one mode, "
-                    "non-periodic priors, blocks of at least two parameters); thin on the host");
+                    "emit_thin: rows are thinned on the device by the incremental Metropolis kernels; "
+                    "thin on the host");
     if (emit) {
         bool one_d = false;   // (a block of one parameter: its columns draw other variates)
         for (size_t b = 0; h->blocked && b < h->blk_size.size(); ++b) one_d = one_d || h->blk_size[b] == 1;
@@ -1942,9 +1944,6 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
         // step_inc_kernel<.., EMIT> emits for one mode with non-periodic priors and blocks of at
         // least two parameters; every other shape on the general kernels, which emit at run time
         if (K != 1 || n_periodic > 0 || one_d) P.any = true;
-        if (P.any && h->emit_thin > 1)
-            return fail(h, MCMC_HIP_ERR_ARG,
-                        "emit_thin: a block of one parameter emits on the general kernels; thin on the host");
         if (P.any && (!mcmc_hip_launch_inc_any || !mcmc_hip_inc_any_fits ||
                       !mcmc_hip_inc_any_fits(d, K, n_periodic, h->W, h->bgs)))
             return fail(h, MCMC_HIP_ERR_ARG,
@@ -2203,8 +2202,9 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
     if (h->own_basis && (h->blocked || drag))
         return fail(h, MCMC_HIP_ERR_ARG,
                     "shared_basis: False serves a single parameter block without dragging");
+    // (round 6: own bases at d <= 32 run on the tuned step kernel, step_kernel<.., OWN>)
     const bool general_big =
-        h->own_basis || big_blocked ||
+        (h->own_basis && h->kb) || big_blocked ||
         (h->kb && (h->K != 1 || h->any_periodic || h->cfg.emit_capacity > 0 ||
                    (h->W % 256 != 0 && (big_norm || h->d > 112))));
     // basis "groups": the walker groups, or every walker on its own
@@ -2280,6 +2280,7 @@ int mcmc_hip_step(mcmc_hip_ctx* h, int32_t n_steps)
             a.cnorm0 = h->K > 0 ? h->cnorm[0] : 0.0;
             a.cps = Lc; a.slab = (int)dd;
             a.vflag = any_1d ? h->vflag.p : nullptr;
+            a.own_basis = (h->own_basis && !h->kb) ? 1 : 0;
             if (drag) {
                 mcmc::DragArgs g{};
                 g.s = a;
@@ -2419,8 +2420,8 @@ int mcmc_hip_drain_samples(mcmc_hip_ctx* h, double* rows, int64_t cap_rows, int6
 }
 
 // Thinned emission on the device (round 5; collection.py:1373-1383, OneSamplePoint.add_to_collection
-// with output_thin > 1): step_inc_kernel<.., EMIT> only -- whatever else emits rows refuses at its
-// first step, and the caller thins on the host as before.
+// with output_thin > 1): every incremental Metropolis kernel that emits rows (round 6) -- the
+// from-scratch and dragging kernels refuse at their first step, and the caller thins on the host.
 int mcmc_hip_set_emit_thin(mcmc_hip_ctx* h, int32_t thin)
 {
     if (!h) return MCMC_HIP_ERR_ARG;
@@ -2428,14 +2429,13 @@ int mcmc_hip_set_emit_thin(mcmc_hip_ctx* h, int32_t thin)
     if (thin > 1 && h->cfg.emit_capacity <= 0)
         return fail(h, MCMC_HIP_ERR_ARG, "emit_thin needs emitted rows (emit_capacity > 0)");
     if (thin > 1) {   // (the configuration as it stands now; mcmc_hip_step checks again)
-        bool ok = h->incremental && h->K == 1 && h->drag_last_slow < 0;
-        for (int i = 0; i < h->d && ok; ++i) ok = !h->periodic[i];
-        for (size_t b = 0; h->blocked && b < h->blk_size.size() && ok; ++b) ok = h->blk_size[b] != 1;
+        const bool ok = h->incremental && h->K >= 1 && h->drag_last_slow < 0;
         if (!ok)
             return fail(h, MCMC_HIP_ERR_ARG,
-                        "emit_thin: rows are thinned on the device by step_inc_kernel<.., emit> (incremental "
-                        "evaluation of one mode, non-periodic priors, blocks of at least two parameters, "
-                        "Metropolis steps); thin on the host");
+                        "emit_thin: rows are thinned on the device by the incremental kernels (Gaussian "
+                        "mixtures with Metropolis steps: step_inc_kernel<.., emit> for one mode, the "
+                        "general incremental kernels for mixtures, periodic parameters and blocks of "
+                        "one parameter); thin on the host");
     }
     HIP_TRY(h, hipSetDevice(h->cfg.device));
     if (thin > 1 && !h->thin_acc.p) HIP_TRY(h, h->thin_acc.resize((size_t)h->W));

@@ -194,6 +194,13 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
     // `emit: chains` (run-time here: s.rows): every accepted step past the burn-in stores the
     // point it LEAVES with its weight (mcmc.py:691-707), as step_inc_kernel<.., EMIT> does
     int nrow = s.rows ? s.n_rows[w] : 0;
+    // thinned emission (round 6 here; collection.py:1373-1383 -- OneSamplePoint.add_to_collection with
+    // output_thin --, as step_inc_kernel<.., EMIT> does it): a walker's weights add up in thin_acc, a
+    // row goes out when the sum reaches `thin`, with weight sum / thin (the quotient by a
+    // reciprocal, set right by the remainder), the remainder carried
+    const bool thinning = s.rows && s.thin > 1;   // (wave-uniform)
+    int tacc = thinning ? s.thin_acc[w] : 0;
+    const double inv_thin = thinning ? 1.0 / (double)s.thin : 1.0;
     const uint32_t gid = s.walker0 + (uint32_t)w;
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
@@ -343,10 +350,23 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
             if (s.rows) {   // wave-uniform
                 const unsigned long long em_m = acc_m & lanes(burn <= 0);
                 if (em_m != 0ull) {   // some walker of the wave emits
-                    const bool em = __builtin_amdgcn_inverse_ballot_w64(em_m);
+                    bool em = __builtin_amdgcn_inverse_ballot_w64(em_m);
+                    int ew = wt;   // the weight the row is written with
+                    if (thinning) {
+                        const int tot = tacc + wt;
+                        int q = (int)((double)tot * inv_thin);
+                        int rem = tot - q * s.thin;
+                        q += rem >= s.thin ? 1 : 0;
+                        rem -= rem >= s.thin ? s.thin : 0;
+                        q -= rem < 0 ? 1 : 0;
+                        rem += rem < 0 ? s.thin : 0;
+                        tacc = em ? rem : tacc;
+                        ew = q;
+                        em = em & (q > 0);
+                    }
                     if (em & (nrow < s.row_cap)) {
                         double* __restrict__ row = s.rows + ((size_t)w * s.row_cap + nrow) * (size_t)(d + 4);
-                        row[c] = c == 0 ? (double)wt : c == 1 ? lpost : c == 2 ? lpri : llik;
+                        row[c] = c == 0 ? (double)ew : c == 1 ? lpost : c == 2 ? lpri : llik;
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk)
                             if (4 * kk + c < d) row[4 + 4 * kk + c] = x[kk];
@@ -413,6 +433,7 @@ __global__ void __launch_bounds__(256) step_inc_any_kernel(const IncStepArgs a, 
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;
         if (s.rows) s.n_rows[w] = nrow;
+        if (thinning) s.thin_acc[w] = tacc;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }
@@ -560,6 +581,13 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
     const long long nacc0 = s.n_accept[w];
     int nacc = 0;     // accepted steps of this launch
     int nrow = s.rows ? s.n_rows[w] : 0;   // `emit: chains`, a run-time property here (s.rows)
+    // thinned emission (round 6 here; collection.py:1373-1383 -- OneSamplePoint.add_to_collection with
+    // output_thin --, as step_inc_kernel<.., EMIT> does it): a walker's weights add up in thin_acc, a
+    // row goes out when the sum reaches `thin`, with weight sum / thin (the quotient by a
+    // reciprocal, set right by the remainder), the remainder carried
+    const bool thinning = s.rows && s.thin > 1;   // (wave-uniform)
+    int tacc = thinning ? s.thin_acc[w] : 0;
+    const double inv_thin = thinning ? 1.0 / (double)s.thin : 1.0;
     const uint32_t gid = s.walker0 + (uint32_t)w;
     const double mt10 = s.max_tries * 10.0;
     const int lim1 = s.max_tries < 2.0e9 ? (int)floor(s.max_tries) : 0x7fffffff;
@@ -729,11 +757,24 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
                 inside_m & lanes(lt != -INFINITY) & (lanes(lt > lpost) | lanes(Ea > delta));
             const bool accept = __builtin_amdgcn_inverse_ballot_w64(acc_m);
             if (s.rows) {   // wave-uniform: the point the walker leaves, with its weight
-                const bool em = accept & (burn <= 0);
+                bool em = accept & (burn <= 0);
                 if (lanes(em) != 0ull) {   // some walker of the wave emits
+                    int ew = wt;   // the weight the row is written with
+                    if (thinning) {
+                        const int tot = tacc + wt;
+                        int q = (int)((double)tot * inv_thin);
+                        int rem = tot - q * s.thin;
+                        q += rem >= s.thin ? 1 : 0;
+                        rem -= rem >= s.thin ? s.thin : 0;
+                        q -= rem < 0 ? 1 : 0;
+                        rem += rem < 0 ? s.thin : 0;
+                        tacc = em ? rem : tacc;
+                        ew = q;
+                        em = em & (q > 0);
+                    }
                     if (em & (nrow < s.row_cap)) {
                         double* __restrict__ row = s.rows + ((size_t)w * s.row_cap + nrow) * (size_t)(d + 4);
-                        row[c] = c == 0 ? (double)wt : c == 1 ? lpost : c == 2 ? lpri : llik;
+                        row[c] = c == 0 ? (double)ew : c == 1 ? lpost : c == 2 ? lpri : llik;
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk)
                             if (4 * kk + c < d) row[4 + 4 * kk + c] = x[kk];
@@ -800,6 +841,7 @@ __global__ void __launch_bounds__(256, regs_min_waves(DQ, KM)) step_inc_regs_ker
         s.weight[w] = wt; s.prior_rej[w] = prej; s.burn_left[w] = burn;
         s.n_accept[w] = nacc0 + nacc;
         if (s.rows) s.n_rows[w] = nrow;
+        if (thinning) s.thin_acc[w] = tacc;
     }
     wave_add_accepts(s.accept_total, (c == 0) ? nacc : 0);
 }

@@ -110,6 +110,9 @@ struct StepArgs {
     // RandProposer1D variates, proposal.py:85-93), or null
     const int* vflag;
     uint32_t norm_mask_hi;   // dimensions 32..63 (the two-wave kernel of 32 < d <= 56)
+    // MCMC_HIP_FLAG_OWN_BASIS at d <= 32 (round 6, step_kernel<.., OWN>): V is [W][ncyc][slab] -- every
+    // walker reads the columns of its OWN Haar basis (proposal.py:59-69 to the letter) from HBM
+    int own_basis;
 };
 
 // Directions of the blocked proposer (blocked_kernels.hip; any d <= 32).

@@ -416,9 +416,16 @@ __device__ __forceinline__ void axpy_stream(double (&out)[D], double r, lptr v,
 // nothing periodic, no row emission; no control flow inside a step, the trial is not kept in
 // registers but recomputed (same fma) when the step is accepted.  The GENERAL variants cover
 // everything else (normal priors, periodic parameters, `one`, mixtures, emitted rows).
-template <bool MULTI, bool GENERAL>
+// OWN (round 6; GENERAL only): `shared_basis: False`, the to-the-letter control -- every walker
+// proposes along the columns of its OWN Haar basis (proposal.py:59-69): no slab of directions in
+// LDS; lane w reads its column [w][cycle][col][0 .. D) straight from HBM -- D contiguous doubles,
+// fetched one step ahead into registers (one wave per SIMD: 512 of them) --, everything else is
+// the GENERAL step on registers.  (Rounds 1-5 ran this on step_general_kernel: state and trial in
+// LDS, L^-1 through the scalar cache row by row, 0.57 ms per cycle of 30 steps at 65 536 walkers.)
+template <bool MULTI, bool GENERAL, bool OWN = false>
 __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
 {
+    static_assert(!OWN || GENERAL, "own bases: the GENERAL step");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int SLAB = a.slab, cps = a.cps;
     const ConstLayout cl{D, a.n_modes};
@@ -437,7 +444,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     // LDS: two slabs of proposal directions per group of the block (current cycle and the
     // next one, which a global->LDS DMA fills while the current one is used), then sA.
     double* sV[2] = {smem, smem + gpb * SLAB};
-    double* const sA = smem + 2 * gpb * SLAB;                // MULTI only: [K][blockDim]
+    double* const sA = OWN ? smem : smem + 2 * gpb * SLAB;   // MULTI only: [K][blockDim]
     const double* const Vgrp = a.V + (size_t)group * a.ncyc * SLAB;
     auto stage_dma = [&](int cycle, double* dst) {
         // this wave moves every wpg-th KiB of its group's slab; each lane carries 16 bytes
@@ -449,10 +456,12 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
                 (__attribute__((address_space(3))) void*)l, 16, 0, 0);
         }
     };
-    stage_dma(0, sV[0]);
-    if (a.ncyc > 1) stage_dma(1, sV[1]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!OWN) {
+        stage_dma(0, sV[0]);
+        if (a.ncyc > 1) stage_dma(1, sV[1]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     int cur_buf = 0;
 
     double x[D];
@@ -467,6 +476,24 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
     unsigned long long step = a.step0;
     int col = (int)(step % (unsigned long long)cps);
     int cyc = 0;
+    // OWN: this walker's columns, and the one of the first step in registers
+    const double* const Vown = OWN ? a.V + (size_t)w * a.ncyc * (size_t)SLAB : nullptr;
+    double vown[OWN ? D : 1];
+    auto fetch_own = [&](int cy, int co, double (&dst)[OWN ? D : 1]) {
+        const double* __restrict__ p = Vown + (size_t)cy * SLAB + (size_t)co * D;
+        if (D % 2 == 0) {   // (slabs and even columns start on 16 bytes: two dimensions per load)
+#pragma unroll
+            for (int i = 0; i < D; i += 2) {
+                const double2 q = *(const double2*)(p + i);
+                dst[i] = q.x;
+                dst[i + 1 < D ? i + 1 : i] = q.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) dst[i] = p[i];
+        }
+    };
+    if (OWN) fetch_own(0, col, vown);
     StepRng rng;
     if (!MULTI && !GENERAL && D >= 2) {  // hot variant: the first step's variates up front
         rng.begin(a.key0, a.key1, gid, step);
@@ -514,6 +541,27 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
                 dev, C + cl.linv(0), dev[D - 1], nullptr, v, vhead, lfirst, rng);
             inb = chi2 < INFINITY;  // false for +inf and NaN: some dimension was out of bounds
             ll = -0.5 * (a.cnorm0 + chi2);
+        } else if (OWN) {
+            // the next step's column travels while this one is evaluated (a launch ends with its
+            // last column: nothing beyond it is read)
+            double vnext[OWN ? D : 1];
+            const bool more = s + 1 < a.n_steps;
+            const int ncol = col + 1 == cps ? 0 : col + 1, ncy = col + 1 == cps ? cyc + 1 : cyc;
+            if (more) fetch_own(ncy, ncol, vnext);
+#pragma unroll
+            for (int i = 0; i < D; ++i) t[i] = fma(r, vown[OWN ? i : 0], x[i]);
+            if (a.periodic_mask) {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                    if ((a.periodic_mask >> i) & 1u)
+                        t[i] = wrap_periodic(t[i], C[cl.lo() + i], C[cl.hi() + i]);
+            }
+            eval_point<MULTI, false, GENERAL>(t, C, cl, a.norm_mask, a.uniform_logp, sA + tid, gs,
+                                              inb, lp, ll, nullptr);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < (OWN ? D : 1); ++i) vown[i] = vnext[i];
+            }
         } else {
             axpy_stream<false>(t, r, v, x, vhead);
             if (GENERAL && a.periodic_mask) {
@@ -569,7 +617,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs a)
         if (++col == cps) {  // next cycle: its slab was DMA'd during this one
             col = 0;
             ++cyc;
-            if (s + 1 < a.n_steps) {
+            if (!OWN && s + 1 < a.n_steps) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (cyc + 1 < a.ncyc) stage_dma(cyc + 1, sV[cur_buf]);
@@ -1151,10 +1199,15 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
 {
     constexpr int NZ = (D + 2) * (D - 1) / 2;
     constexpr int LDH = D | 1;  // odd leading dimension: conflict-free column reads
-    __shared__ double sz[2][NZ + 2];
+    // (round 6: the normals and R share one buffer -- the normals are dead when R is written --, so a
+    // workgroup holds 17 KB of LDS instead of 24 at D = 30 and nine of them fit a CU instead of six:
+    // the kernel is one wave per workgroup of dependent fma chains, only more waves cover them)
+    constexpr int NZP = NZ + 2;
+    constexpr int kBuf = 2 * NZP > 2 * D * LDH ? 2 * NZP : 2 * D * LDH;
+    __shared__ double sbuf[kBuf];
+    double (*const sz)[NZP] = (double (*)[NZP])sbuf;
+    double (*const sR)[D * LDH] = (double (*)[D * LDH])sbuf;
     __shared__ double sx[2][D + 1];
-    __shared__ double sR[2][D * LDH];
-    __shared__ double sT[D * D];
     const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
     const int prob = 2 * blockIdx.x + half;          // (group, cycle) pair of this half-wave
     const bool valid = prob < n_problems;
@@ -1163,7 +1216,10 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
     const uint32_t cycle = a.cycle0 + (uint32_t)pc;
     double* __restrict__ Vout = a.V + ((size_t)pg * a.ncyc + pc) * v_slab(D);
 
-    for (int i = lane; i < D * D; i += 64) sT[i] = a.T[i];
+    // (round 6: the transform through the constant address space -- wave-uniform addresses, scalar
+    // loads, scalar operands of the fmas below -- instead of a copy in LDS read once per term:
+    // 465 ds_reads per lane and 7 KB of LDS per workgroup less at D = 30)
+    const cptr cT = as_const(a.T);
     if (D == 1) {
         if (valid && l == 0) Vout[0] = a.T[0];
         return;
@@ -1227,6 +1283,7 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
         ix += m;
     }
     if (l == D - 1) Dmine = (((D - 1) & 1) ? -1.0 : 1.0) * dprod;
+    __syncthreads();   // (the last reflection has read its normals: R may overwrite them)
     if (l < D) {
 #pragma unroll
         for (int k = 0; k < D; ++k) sR[half][l * LDH + k] = Dmine * H[k];
@@ -1241,7 +1298,7 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
         for (int i = 0; i < D; ++i) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k <= i; ++k) s = fma(sT[i * D + k], Rc[k], s);
+            for (int k = 0; k <= i; ++k) s = fma(cT[i * D + k], Rc[k], s);
             Vout[l * D + i] = s;
         }
     }
@@ -1425,6 +1482,26 @@ hipError_t launch_step(const StepArgs& a, int group_size, hipStream_t st)
     }
     const bool general = (a.norm_mask | a.periodic_mask) != 0u || a.n_modes == 0 ||
                          a.rows != nullptr || D == 1 || a.vflag != nullptr;
+    if (a.own_basis) {
+        // `shared_basis: False`: no directions in LDS (the mode log-densities of a mixture and the
+        // placement request only); the GENERAL step with every walker's own columns from HBM
+        size_t own_lds = sizeof(double) * (size_t)(multi ? a.n_modes * bs : 0);
+        const int per_cu = (int)((grid.x + 255) / 256);
+        size_t want = (((size_t)(160 * 1024) / (size_t)per_cu) / 1024) * 1024;
+        if (want > 64 * 1024) want = 64 * 1024;
+        if (want > own_lds) own_lds = want;
+        if (own_lds > kLdsMax) return hipErrorInvalidValue;
+        const void* ofn = multi ? (const void*)step_kernel<true, true, true> : (const void*)step_kernel<false, true, true>;
+        if (own_lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(ofn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)own_lds);
+            if (e != hipSuccess) return e;
+        }
+        mcmc_hip_note_step_kernel(multi ? "mcmc::step_kernel<true, true, own basis>"
+                                        : "mcmc::step_kernel<false, true, own basis>");
+        if (multi) hipLaunchKernelGGL((step_kernel<true, true, true>), grid, block, own_lds, st, a);
+        else hipLaunchKernelGGL((step_kernel<false, true, true>), grid, block, own_lds, st, a);
+        return hipGetLastError();
+    }
     if (lds > kLdsMax) return hipErrorInvalidValue;   // the cycle's directions do not fit LDS
     if (pair_fits(a)) return launch_pair(a, st);
     const void* fn = multi ? (general ? (const void*)step_kernel<true, true>

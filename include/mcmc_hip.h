@@ -220,9 +220,10 @@ MCMC_HIP_API int mcmc_hip_set_drain_slots(mcmc_hip_ctx* h, int32_t n_slots);
 /* Thinned emission ON THE DEVICE (round 5): OneSamplePoint.add_to_collection with output_thin > 1
  * (collection.py:1373-1383) -- the weights of a walker's accepted rows add up, a row is emitted when
  * the sum reaches `thin`, with weight sum / thin, the remainder carried to its next rows.  `emit:
- * chains` is bound by PCIe (54 GB/s of rows): thinned by T it moves T times fewer.  Served by the
- * incremental kernel of one Gaussian mode with non-periodic priors and blocks of at least two
- * parameters; anything else refuses at its first step (thin on the host as before).  thin = 1: off.
+ * chains` is bound by PCIe (54 GB/s of rows): thinned by T it moves T times fewer.  Served by every
+ * incremental Metropolis kernel (round 6: mixtures, periodic parameters and blocks of one parameter
+ * too, on the general incremental kernels); the from-scratch and dragging kernels refuse at their
+ * first step (thin on the host as before).  thin = 1: off.
  * get / set_thin_carry: the per-walker remainders [W] (part of the state of a resumed run). */
 MCMC_HIP_API int mcmc_hip_set_emit_thin(mcmc_hip_ctx* h, int32_t thin);
 MCMC_HIP_API int mcmc_hip_get_thin_carry(mcmc_hip_ctx* h, int32_t* carry);

@@ -248,15 +248,13 @@ class OracleEngine:
     emit_thin = 1
 
     def set_emit_thin(self, thin):
-        """The engine's rule (mcmc_hip_set_emit_thin): thinned on the device by the incremental
-        kernel of one mode with non-periodic priors and blocks of at least two parameters."""
+        """The engine's rule (mcmc_hip_set_emit_thin): thinned on the device by every incremental
+        Metropolis kernel (round 6); the from-scratch and dragging kernels thin on the host."""
         thin = int(thin)
         if thin < 1 or (thin > 1 and not self.cap):
             raise EngineError(ERR_ARG, "emit_thin needs emitted rows and thin >= 1")
-        periodic = self._prior is not None and self._prior[3] is not None and self._prior[3].any()
-        one_d = bool(self._blocking) and any(len(b) == 1 for b in self._blocking.get("blocks", []))
         drag = bool(self._blocking) and self._blocking["drag_last_slow"] >= 0
-        if thin > 1 and (not self.incremental or self.K != 1 or periodic or one_d or drag):
+        if thin > 1 and (not self.incremental or not self.K or self.K < 1 or drag):
             raise EngineError(ERR_ARG, "emit_thin: thin on the host")
         self.emit_thin = thin
         if self._state is not None:

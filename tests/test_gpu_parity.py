@@ -967,7 +967,15 @@ def test_incremental_emitted_rows_bit_exact(d, W, gs, kw):
 @pytest.mark.parametrize("d,W,gs,thin,kw", [
     (30, 256, 64, 3, {}), (8, 512, 128, 7, dict(burn_in=3, T=2.0)), (100, 128, 64, 2, {}),
     (27, 256, 64, 5, dict(kinds=[0] * 6 + [1] * 21, a=[0.0] * 6 + [0.5] * 21, b=[1.0] * 6 + [0.3] * 21)),
-    (12, 256, 64, 4, dict(blocks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]], over=[1, 3]))])
+    (12, 256, 64, 4, dict(blocks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9, 10, 11]], over=[1, 3])),
+    # round 6: the general incremental kernels thin too -- mixtures (register planes), a periodic
+    # parameter, a mixture with one, eight modes (LDS state), a block of ONE parameter
+    (9, 256, 64, 3, dict(K=2, weights=[0.3, 0.7])),
+    (30, 256, 64, 5, dict(K=3)),
+    (10, 256, 64, 4, dict(periodic=[1] + [0] * 9)),
+    (12, 256, 64, 3, dict(K=2, periodic=[0, 1] + [0] * 10)),
+    (16, 128, 64, 2, dict(K=8)),
+    (8, 256, 64, 3, dict(blocks=[[0], [1, 2, 3, 4, 5, 6, 7]], over=[1, 2]))])
 def test_rows_thinned_on_the_device_bit_exact(d, W, gs, thin, kw):
     """mcmc_hip_set_emit_thin (round 5): step_inc_kernel<.., emit> thins the rows where they are
     produced -- OneSamplePoint.add_to_collection with output_thin (collection.py:1373-1383): the
@@ -1002,11 +1010,7 @@ def test_rows_thinned_on_the_device_bit_exact(d, W, gs, thin, kw):
     eng.close()
 
 
-def test_device_thinning_is_refused_where_the_general_kernels_emit():
-    eng, prob, st = make_pair(9, 256, 64, incremental=True, cap=40, K=2, weights=[0.3, 0.7])
-    with pytest.raises(E.EngineError, match="thin on the host"):
-        eng.set_emit_thin(3)
-    eng.close()
+def test_device_thinning_is_refused_where_the_from_scratch_kernels_emit():
     eng, prob, st = make_pair(9, 256, 64, incremental=False, cap=40)
     with pytest.raises(E.EngineError, match="thin on the host"):
         eng.set_emit_thin(3)
@@ -1066,7 +1070,9 @@ def test_own_basis_steps_bit_exact(d, W, gs, K, extra):
         st.run(n, n_threads=8)
         compare_state(eng, st)
     assert eng.counters()["accepted"] == int(st.n_accept.sum())
-    assert "step_general_kernel" in eng.last_step_kernel()
+    # (round 6: the tuned d <= 32 step kernel with every walker's own columns from HBM; the general
+    # kernel above that)
+    assert ("own basis" if d <= 32 else "step_general_kernel") in eng.last_step_kernel()
     # the R-1 groups are still the walker groups
     shift = st.x.mean(0)
     eng.set_moment_shift(shift)

@@ -507,7 +507,8 @@ def test_thinned_chain_rows_follow_the_reference_rule():
     reached; remainders carry over between drains."""
     rng = np.random.default_rng(5)
     s = _bare_sampler(None, emit="chains")
-    s.output_thin, s._thin_carry = 3, {}
+    s.output_thin, s.rank, s.n_walkers = 3, 0, 4
+    s._thin_carry = np.zeros(4, dtype=np.int64)   # (dense [W], saved with the state)
     rows_all = []
     expect = {w: [] for w in range(4)}
     carry = {w: 0 for w in range(4)}
@@ -547,7 +548,8 @@ def test_rows_thinned_by_the_oracle_equal_rows_thinned_on_the_host():
     plain = O.State(p, x0, burn_in=2, row_cap=64)
     thinned = O.State(p, x0, burn_in=2, row_cap=64, thin=4)
     s = _bare_sampler(None, emit="chains")
-    s.output_thin, s._thin_carry = 4, {}
+    s.output_thin, s.rank, s.n_walkers = 4, 0, W
+    s._thin_carry = np.zeros(W, dtype=np.int64)
     n_thin = 0
     for n in (7, 30, 1, 44):
         plain.run(n, n_threads=2)
@@ -558,7 +560,7 @@ def test_rows_thinned_by_the_oracle_equal_rows_thinned_on_the_host():
         assert np.array_equal(got, want[order])
         n_thin += len(got)
     assert n_thin > W and np.array_equal(plain.x, thinned.x)
-    assert np.array_equal(thinned.thin_acc, [s._thin_carry.get(w, 0) for w in range(W)])
+    assert np.array_equal(thinned.thin_acc, s._thin_carry)
 
 
 def test_row_store_keeps_following_the_run():
