@@ -23,6 +23,7 @@ ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
 BIG_DPS = [48, 56, 64, 72, 80, 88, 96, 100, 112, 120, 128]  # padded sizes of the d > 32 kernels
 INC_DQ_RANGES = [(1, 8), (9, 16), (17, 24), (25, 32)]  # incremental_kernels.hip: ceil(d / 4)
+DUO_DQ_RANGES = [(1, 8)]  # incremental_duo.hip: two-mode mixtures, two lanes per walker, d <= 32
 PAIR_DIMS = list(range(33, 57))  # 32 < d <= 48: walker_kernels.hip's two-wave step kernel alone
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused
@@ -126,6 +127,11 @@ def build(dims=None, jobs=None, verbose=True):
     for part in (0, 1, 2):   # the LDS kernel + KM = 4 | KM = 8 | KM = 16 register planes
         tasks.append((anyk, os.path.join(OBJ, f"incremental_any_{part}.o"), [f"-DANY_PART={part}"],
                       _digest([anyk, inc_hdr] + hdrs, extra=f"any{part}|{' '.join(FLAGS)}")))
+    duo = os.path.join(CSRC, "incremental_duo.hip")   # two lanes per walker (round 6)
+    for lo_, hi_ in DUO_DQ_RANGES:
+        tasks.append((duo, os.path.join(OBJ, f"incremental_duo_{lo_}.o"),
+                      [f"-DMCMC_DUO_DQ_LO={lo_}", f"-DMCMC_DUO_DQ_HI={hi_}"],
+                      _digest([duo, inc_hdr] + hdrs, extra=f"duo{lo_}-{hi_}|{' '.join(FLAGS)}")))
     tasks.append((capi, os.path.join(OBJ, "capi.o"), [],
                   _digest([capi, root_hdr, pl_hdr, ck_hdr, comm_hdr] + hdrs, extra=" ".join(FLAGS))))
     jobs = jobs or min(len(tasks), os.cpu_count() or 4)

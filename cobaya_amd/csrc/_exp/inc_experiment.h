@@ -95,3 +95,11 @@ extern "C" __attribute__((visibility("default"))) int mcmc_hip_debug_wave_place(
 #ifdef EXP_FLOAT_VEC
 #define MCMC_EXP_FLOAT_VEC(tuned) (EXP_FLOAT_VEC != 0)
 #endif
+//   -DEXP_DUO_DEPK=k          (round 6) incremental_duo.hip: the element of a plane whose result the next plane's reads wait for
+//   -DEXP_DUO_KEEPV=1         ... the v plane of a step kept in registers from the trial to the commit
+#ifdef EXP_DUO_DEPK
+#define MCMC_DUO_DEPK(tuned) (EXP_DUO_DEPK)
+#endif
+#ifdef EXP_DUO_KEEPV
+#define MCMC_DUO_KEEPV(tuned) (EXP_DUO_KEEPV != 0)
+#endif

@@ -276,6 +276,8 @@ extern "C" hipError_t mcmc_hip_launch_inc_emit_17(const mcmc::IncStepArgs*, hipS
 extern "C" hipError_t mcmc_hip_launch_inc_emit_25(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 // incremental_any.hip: the general incremental kernel (any number of modes / periodic parameters)
 extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+// incremental_duo.hip (round 6): the incremental step of a two-mode mixture with TWO lanes per walker
+extern "C" hipError_t mcmc_hip_launch_inc_duo_1(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_whiten_directions_planes(const mcmc::IncDirArgs*, int,
                                                                hipStream_t) __attribute__((weak));
 extern "C" int mcmc_hip_inc_any_fits(int d, int n_modes, int n_periodic, int n_walkers,
@@ -375,6 +377,9 @@ struct mcmc_hip_ctx {
     bool lazy_dirs = true;
     // step_inc_kernel: calls whose directions are formed together (MCMC_HIP_LOOKAHEAD, default 4)
     int lookahead = 4;
+    // incremental_duo.hip (two lanes per walker): -1 = where the ensemble fills the chip with it
+    // (kDuoMinWalkers), 0 = never, 1 = wherever the kernel serves the model (MCMC_HIP_DUO)
+    int duo = -1;
     hipEvent_t T_event = nullptr;            // main stream: behind the last write of dT
     bool T_fresh = false;                    // ... which no direction set has been ordered behind yet
     // asynchronous checkpoint (mcmc_hip_request_moments / mcmc_hip_fetch_moments) and
@@ -1023,6 +1028,8 @@ int mcmc_hip_create(const mcmc_hip_config* cfg, mcmc_hip_ctx** out)
         if (const char* e = getenv("MCMC_HIP_EAGER_DIRECTIONS")) h->lazy_dirs = !(e[0] && e[0] != '0');
         // MCMC_HIP_LOOKAHEAD (developer switch): calls per direction set of step_inc_kernel; 1: a set per call
         if (const char* e = getenv("MCMC_HIP_LOOKAHEAD")) h->lookahead = std::max(1, atoi(e));
+        // MCMC_HIP_DUO (developer switch): 0 = the four-lane kernels always, 1 = the two-lane ones wherever they serve
+        if (const char* e = getenv("MCMC_HIP_DUO")) h->duo = (e[0] && e[0] != '0') ? 1 : 0;
         for (auto& D : h->dirs) acc(hipEventCreateWithFlags(&D.ready, hipEventDisableTiming));
         // MCMC_HIP_NO_PREFETCH (developer switch): directions on the main stream, in line
         h->prefetch = !getenv("MCMC_HIP_NO_PREFETCH");
@@ -1780,6 +1787,7 @@ bool inc_carries_prior(const mcmc_hip_ctx* h)
 // mcmc_hip_step in incremental mode (MCMC_HIP_FLAG_INCREMENTAL; incremental_kernels.hip).
 // Launches are cut at the multiples of refresh_every = 40 cycle lengths, where y = L^-1 (x - mu)
 // is recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
+constexpr int kDuoMinWalkers = 65536;   // two waves of 32 walkers on each of the 1 024 SIMDs
 struct IncPlan {   // what the cutting of launches depends on besides the step counter
     int d, dq, K, nd, chunk_steps, Lc, Lf, ld, max_cyc, max_cyc_f, max_steps_vu;
     size_t colb, dd, ddf;
@@ -1967,6 +1975,17 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                           : dq <= 24 ? mcmc_hip_launch_inc_emit_17 : mcmc_hip_launch_inc_emit_25)
                        : (dq <= 8 ? mcmc_hip_launch_inc_step_1 : dq <= 16 ? mcmc_hip_launch_inc_step_9
                           : dq <= 24 ? mcmc_hip_launch_inc_step_17 : mcmc_hip_launch_inc_step_25);
+    // Two lanes per walker (incremental_duo.hip, round 6): two and three modes at d <= 32, four at
+    // d <= 24 (kernels.h: duo_serves) with carried mode log-densities, no block of one parameter -- where the ensemble gives every SIMD its two waves
+    // of 32 walkers (65 536 walkers per device); smaller ensembles keep the four-lane kernel, whose
+    // twice as many waves cover their latencies
+    {
+        bool duo = h->duo != 0 && !P.any && !emit && !P.drag && n_periodic == 0 && mcmc::duo_serves(K, dq) &&
+                   P.carry_modes && h->W % 128 == 0 && h->bgs % 128 == 0 &&
+                   (h->duo == 1 || h->W >= kDuoMinWalkers);
+        for (size_t b = 0; h->blocked && b < h->blk_size.size() && duo; ++b) duo = h->blk_size[b] != 1;
+        if (duo && mcmc_hip_launch_inc_duo_1) launch = mcmc_hip_launch_inc_duo_1;
+    }
     if (!launch || !mcmc_hip_launch_whiten_directions)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);
     // columns (= steps) per cycle: d for one block, sum_b oversample_b n_b with blocks, the slow

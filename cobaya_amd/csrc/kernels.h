@@ -228,6 +228,17 @@ __host__ __device__ constexpr bool inc_mix_serves(int K, int dq)
     return K >= 2 && ((K <= 4 && dq <= 16) || (K <= 6 && dq <= kIncMixWideDq && dq * (K + 1) <= 50));
 }
 
+// step_duo_mix_kernel (incremental_duo.hip, round 6): the same step with TWO lanes per walker, each
+// holding 2 dq dimensions -- 2..4 modes while the residuals y_1 .. y_K of a lane (2 dq K doubles) leave
+// the body its registers at two waves per SIMD; x moves to LDS where it does not fit beside them
+// (duo_x_in_lds).  K = 2, 3: d <= 32; K = 4: d <= 24.
+constexpr int kDuoStateDoubles = 48;
+__host__ __device__ constexpr bool duo_serves(int K, int dq)
+{
+    return K >= 2 && K <= 4 && dq <= 8 && 2 * dq * K <= kDuoStateDoubles;
+}
+__host__ __device__ constexpr bool duo_x_in_lds(int K, int dq) { return 2 * dq * (K + 1) > kDuoStateDoubles; }
+
 // periodic parameters step_inc_kernel<.., PER> serves (one mode, Metropolis steps, no emitted rows);
 // more: the general incremental kernels (incremental_any.hip)
 constexpr int kIncMaxPeriodic = 16;

@@ -54,16 +54,25 @@ def _bench_target(d):
     return np.full(d, 0.5), c
 
 
-def _pair(d, W, gs, bgs, offset, seed=1):
+def _pair(d, W, gs, bgs, offset, seed=1, K=1):
     mean, cov = _bench_target(d)
     eng = E.Engine(d, W, group_size=gs, seed=seed, incremental=True, basis_group_size=bgs,
                    walker_offset=offset)
     eng.set_prior([0] * d, [0.0] * d, [1.0] * d)
-    eng.set_target_gaussian_mixture([mean], [cov])
+    if K == 1:
+        means, covs, weights = mean, cov, None
+        eng.set_target_gaussian_mixture([mean], [cov])
+    else:   # bench.py's mixture variants: the other modes a sigma or so away, the same covariance
+        r0 = np.random.default_rng(11)
+        means = [mean] + [np.clip(mean + r0.normal(size=d) * np.sqrt(np.diag(cov)), 0.05, 0.95)
+                          for _ in range(K - 1)]
+        covs, weights = [cov] * K, [1.0 / K] * K
+        eng.set_target_gaussian_mixture(means, covs, weights)
     eng.set_proposal_cov(cov)
-    prob = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=mean, covs=cov,
+    prob = O.Problem(d, [0] * d, [0.0] * d, [1.0] * d, means=means, covs=covs, weights=weights,
                      T=eng.get_proposal_transform(), group_size=bgs, seed=seed,
-                     derived=eng.derived_constants(), incremental=True)
+                     derived=eng.derived_constants(), incremental=True,
+                     carry_modes=eng.carries_modes())
     rng = np.random.default_rng(1 + offset)
     x0 = np.clip(mean + rng.standard_normal((W, d)) * np.sqrt(np.diag(cov)), 1e-6, 1 - 1e-6)
     eng.set_state(x0)
@@ -130,4 +139,26 @@ def test_config4_d100_bench_launch_bit_exact():
     st.run(spl, n_threads=O.max_threads())
     _compare(eng, st, "d = 100 launch")
     assert "step_inc_kernel" in eng.last_step_kernel()
+    eng.close()
+
+
+@pytest.mark.parametrize("K", [2, 3])
+def test_mixture_bench_launch_bit_exact_on_two_lanes(K):
+    """The mixture variants of bench.py (gaussian_mixture.py:156-163 with K modes at d = 30, 65 536
+    walkers): at this size the engine takes step_duo_mix_kernel (two lanes per walker, round 6) by
+    itself -- one bench launch of 1 200 steps and a second one behind a refreshed proposal, walker
+    by walker against the C oracle, the carried mode log-densities included."""
+    d, W, gs, bgs, spl = 30, 65536, 256, 1024, 1200
+    eng, prob, st, mean, cov = _pair(d, W, gs, bgs, 0, K=K)
+    threads = O.max_threads()
+    for launch in range(2):
+        eng.step(spl)
+        eng.sync()
+        st.run(spl, n_threads=threads)
+        _compare(eng, st, f"K = {K}, launch {launch}")
+        _same(eng.get_full_state()["amode"], st.amode, "carried mode log-densities")
+        assert "step_duo_mix_kernel" in eng.last_step_kernel(), eng.last_step_kernel()
+        if launch == 0:
+            eng.set_proposal_cov(np.cov(st.x.T))
+            prob.set_T(eng.get_proposal_transform())
     eng.close()

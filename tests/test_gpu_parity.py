@@ -1105,6 +1105,25 @@ def test_own_basis_periodic_rows_and_offsets_bit_exact():
     (30, 256, 64, 5, False, 1.0), (28, 128, 64, 6, True, 1.7), (32, 128, 64, 5, True, 1.0), (6, 256, 128, 6, False, 1.0),
     (27, 128, 64, 5, "bounds differ", 1.0)])
 def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
+    _mixture_case(d, W, gs, K, normal, T, "step_inc_mix_kernel")
+
+
+@pytest.mark.parametrize("d,W,gs,K,normal,T", [
+    (30, 256, 128, 2, False, 1.0), (30, 512, 256, 3, False, 1.0), (24, 256, 128, 4, False, 1.0),
+    (16, 256, 128, 4, True, 1.0), (27, 256, 128, 2, True, 1.7), (32, 256, 128, 3, "bounds differ", 1.0),
+    (30, 256, 128, 2, "box off the origin", 1.0), (5, 128, 128, 2, False, 1.0), (12, 256, 256, 3, True, 2.0),
+    (20, 128, 128, 4, "bounds differ", 1.0), (26, 256, 128, 3, True, 1.0), (2, 128, 128, 4, False, 1.0)])
+def test_two_lane_mixture_steps_bit_exact(d, W, gs, K, normal, T, monkeypatch):
+    """step_duo_mix_kernel (incremental_duo.hip, round 6): the mixture step with TWO lanes per walker
+    -- the layout large ensembles run on (65 536 walkers: tests/test_gpu_bench_geometry.py), forced
+    here for small ones (MCMC_HIP_DUO=1) -- bit for bit against the same oracle as the four-lane
+    kernel: two and three modes up to d = 32 (x in LDS from d = 25 on with three), four up to
+    d = 24; one box, a box off the origin, per-parameter bounds, normal priors, T != 1."""
+    monkeypatch.setenv("MCMC_HIP_DUO", "1")
+    _mixture_case(d, W, gs, K, normal, T, "step_duo_mix_kernel")
+
+
+def _mixture_case(d, W, gs, K, normal, T, kernel):
     """Mixtures of 2..4 modes (5 and 6 up to d = 32) in incremental mode (step_inc_mix_kernel): a carried residual and
     a whitened direction per mode, the log-sum-exp of eval_point -- bit for bit against the
     oracle, across the refresh at 40 d steps.  With one box for all dimensions the kernel takes
@@ -1131,7 +1150,7 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
         st.run(n, n_threads=8)
         compare_state(eng, st)
         assert_bit_equal(eng.get_full_state()["y"], st.y, "carried whitened residuals")
-    assert st.step > R and "step_inc_mix_kernel" in eng.last_step_kernel()
+    assert st.step > R and kernel in eng.last_step_kernel()
     assert eng.counters()["accepted"] == int(st.n_accept.sum())
     assert eng.carries_modes()
     # the carried a_k are part of the state (mcmc_hip_set_mode_logdensities): handed back with the
