@@ -968,8 +968,10 @@ def variant_list(a, d, mean, cov, m):
     # off the single-mode path: mixtures (gaussian_mixture.py:156-163, the metric's namesake)
     gauss("mix8", "8-mode gaussian_mixture at d = 30 (the general incremental kernels), 65536 walkers",
           d, 4, 2, info=lambda: mixture_info(8))
-    gauss("mix2", "2-mode gaussian_mixture at d = 30 (step_inc_mix_kernel), 65536 walkers",
+    gauss("mix2", "2-mode gaussian_mixture at d = 30 (step_duo_mix_kernel: two lanes per walker), 65536 walkers",
           d, 6, 2, info=lambda: mixture_info(2))
+    gauss("mix3", "3-mode gaussian_mixture at d = 30 (step_duo_mix_kernel, x in LDS), 65536 walkers",
+          d, 6, 2, info=lambda: mixture_info(3))
     gauss("mix4", "4-mode gaussian_mixture at d = 30 (step_inc_mix_kernel), 65536 walkers",
           d, 6, 2, info=lambda: mixture_info(4))
 

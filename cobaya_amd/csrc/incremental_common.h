@@ -186,17 +186,7 @@ __device__ __forceinline__ double pred_double(double x)
     return -4.9406564584124654e-324;
 }
 
-// a / w given R = RN(1 / w): the correctly rounded quotient without a division: q0 = a R,
-// q1 = fma(fma(-q0, w, a), R, q0), q2 = fma(fma(-q1, w, a), R, q1) (q1 is faithful -- its exact
-// argument is within 2^-52 ulp of a / w -- and a faithful quotient corrected once with the
-// correctly rounded reciprocal is the IEEE quotient: Markstein 1990) -- bit for bit the oracle's
-// `/`, 5 instructions instead of 30
-__device__ __forceinline__ double div_by(double a, double w, double R)
-{
-    double q = a * R;
-    q = fma(fma(-q, w, a), R, q);
-    return fma(fma(-q, w, a), R, q);
-}
+// (div_by -- the correctly rounded quotient from the correctly rounded reciprocal -- is in det_math.h)
 
 // LDS behind the column chunks of a launch with np periodic parameters: the wrap moves
 // [64 walkers][np] and the columns of L^-1 of the periodic dimensions [np][4 dq]

@@ -1245,7 +1245,11 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
     // sequential loop below (round 4: two dependent square roots per reflection were half of
     // the kernel's 25 us -- it is one wave per SIMD of pure latency).  Same operations in the same
     // order as before (orc_haar_from_normals): the results are bit-identical.
-    __shared__ double sPivot[2][D], sDen[2][D], sSign[2][D];
+    // (round 6) ... and RN(1 / den): the m normals of a reflection are divided by `den` through it
+    // (div_by, det_math.h: the IEEE quotient in 5 instructions instead of the ~35 of the division
+    // sequence -- 29 of those per lane were a fifth of this kernel's instructions; one true
+    // division per reflection is left, here)
+    __shared__ double sPivot[2][D], sDen[2][D], sSign[2][D], sRcp[2][D];
     if (l < D - 1) {
         const int n = l, m = D - n, ix = n * D - n * (n - 1) / 2;
         double norm2 = 0.0;
@@ -1256,7 +1260,9 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
         double tt = norm2 - x0 * x0;
         tt = tt + x0n * x0n;
         sPivot[half][n] = x0n;
-        sDen[half][n] = sqrt(0.5 * tt);
+        const double den_n = sqrt(0.5 * tt);
+        sDen[half][n] = den_n;
+        sRcp[half][n] = 1.0 / den_n;
         sSign[half][n] = Dn;
     }
     __syncthreads();
@@ -1271,9 +1277,9 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
         const double Dn = sSign[half][n];
         dprod *= Dn;
         if (l == n) Dmine = Dn;
-        const double x0n = sPivot[half][n], den = sDen[half][n];
+        const double x0n = sPivot[half][n], den = sDen[half][n], rcp = sRcp[half][n];
         if (n) __syncthreads();   // (the previous reflection's xs has been used)
-        if (l < m) xs[l] = ((l == 0) ? x0n : z[ix + l]) / den;
+        if (l < m) xs[l] = div_by((l == 0) ? x0n : z[ix + l], den, rcp);
         __syncthreads();
         double tmp = 0.0;
 #pragma unroll
@@ -1289,17 +1295,32 @@ __global__ void __launch_bounds__(64) basis_kernel(const BasisArgs a, int n_prob
         for (int k = 0; k < D; ++k) sR[half][l * LDH + k] = Dmine * H[k];
     }
     __syncthreads();
-    if (valid && l < D) {
-        // l = column c of R; V[c][i] for i ascending
-        double Rc[D];
+    // l = column c of R; V[c][i] for i ascending.  (round 6) The column goes back to LDS -- R is in
+    // registers by then -- and the slab leaves the half-wave as D * D CONTIGUOUS doubles: written
+    // straight from the lanes, Vout[l * D + i], every store touched 30 cache lines 240 bytes apart
+    // (with a basis per walker: 1.9 GB of such stores per 4 d steps, TCP_PENDING_STALL_CYCLES 82 % of the
+    // kernel's duration, profiles/r06_basis_kernel.txt)
+    double Rc[D];
+    if (l < D) {
 #pragma unroll
         for (int k = 0; k < D; ++k) Rc[k] = sR[half][k * LDH + l];
+    }
+    __syncthreads();   // (every column has been read: the buffer takes V)
+    if (l < D) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k <= i; ++k) s = fma(cT[i * D + k], Rc[k], s);
-            Vout[l * D + i] = s;
+            sR[half][l * LDH + i] = s;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        const double* __restrict__ sV = sR[half];
+        for (int j = l; j < D * D; j += 32) {
+            const int c = j / D, i = j - c * D;
+            Vout[j] = sV[c * LDH + i];
         }
     }
 }

@@ -184,7 +184,7 @@ def test_carried_mode_logdensities_at_the_end_of_an_interval():
     eng.step(R)
     eng.sync()
     s = eng.get_full_state()
-    assert "step_inc_mix_kernel" in eng.last_step_kernel() and "amode" in s
+    assert "mix_kernel" in eng.last_step_kernel() and "amode" in s   # (four lanes per walker, or two: step_duo_mix_kernel)
     dc = eng.derived_constants()
 
     def modes_of(x):

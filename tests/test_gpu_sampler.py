@@ -597,7 +597,8 @@ def test_three_mode_mixture_at_the_baseline_ensemble_size():
                                      "steps_per_launch": 600, "max_samples": 65536 * 600 * 22 * 0.45,
                                      "max_rows": 1 << 21}}}
     updated, sampler = run(info)
-    assert sampler.incremental and "step_inc" in sampler.engine.last_step_kernel()
+    name = sampler.engine.last_step_kernel()   # (65 536 walkers: two lanes per walker, step_duo_mix_kernel)
+    assert sampler.incremental and ("step_inc" in name or "step_duo_mix" in name)
     coll = sampler.products(skip_samples=0.4)["sample"]
     assert len(coll) >= 8 * 65536
     mean = w @ mus
