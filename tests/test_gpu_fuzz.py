@@ -336,3 +336,71 @@ def test_random_blocked_and_dragging_shapes_above_d32_bit_exact(seed):
         assert ("drag_general_kernel" if drag else "step_general_kernel") in kern, kern
     c = eng.counters()
     assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
+
+
+def draw_two_lane_case(seed):
+    """A random shape step_duo_mix_kernel serves (kernels.h: duo_serves): 2..4 modes with
+    2 dq K <= 48, whole workgroups of 128 walkers inside a basis group; uniform priors on one box
+    or on boxes that differ, normal priors, T != 1, burn-in, parameter blocks of >= 2 parameters
+    with oversampling."""
+    rng = np.random.default_rng(seed)
+    K = int(rng.integers(2, 5))
+    dq_max = min(8, 48 // (2 * K))
+    d = int(rng.integers(2, 4 * dq_max + 1))
+    gs = int(rng.choice([128, 256]))
+    W = gs * int(rng.integers(1, 3))
+    kw = {}
+    u = rng.random()
+    if u < 0.3:       # normal priors on some parameters
+        kinds = (rng.random(d) < 0.4).astype(int).tolist()
+        kw.update(kinds=kinds, a=[0.5 if k else 0.0 for k in kinds],
+                  b=[float(rng.uniform(0.1, 0.4)) if k else 1.0 for k in kinds])
+    elif u < 0.55:    # boxes that differ
+        kw.update(a=[-0.25 * (i % 3) for i in range(d)], b=[1.0 + 0.5 * (i % 2) for i in range(d)])
+    elif u < 0.7:     # tight boxes the walkers do reach (the exact comparisons behind the high-word test)
+        kw.update(a=[0.0] * d, b=[0.62] * d)
+    if rng.random() < 0.3:
+        kw["T"] = float(rng.choice([1.5, 2.0]))
+    if rng.random() < 0.3:
+        kw["burn_in"] = int(rng.integers(1, 4))
+    w = rng.uniform(0.2, 1.0, K)
+    kw["weights"] = (w / w.sum()).tolist()
+    L = d
+    if rng.random() < 0.35 and d >= 6:
+        perm = rng.permutation(d).tolist()
+        nb = int(rng.integers(2, 4))
+        sizes = [2] * nb
+        for _ in range(d - 2 * nb):
+            sizes[int(rng.integers(0, nb))] += 1
+        cuts = np.cumsum(sizes).tolist()
+        blocks = [perm[p:q] for p, q in zip([0] + cuts[:-1], cuts)]
+        over = sorted(int(v) for v in rng.integers(1, 4, size=nb))
+        kw.update(blocks=blocks, over=over)
+        L = sum(o * len(bl) for o, bl in zip(over, blocks))
+    steps = [int(rng.integers(1, 12)), 40 * L - int(rng.integers(0, 20)), int(rng.integers(1, 20)),
+             int(rng.integers(1, 3 * L))]
+    return d, W, gs, K, kw, steps
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MCMC_FUZZ_DUO_CASES", "24")))))
+def test_random_two_lane_mixture_shapes_bit_exact(seed, monkeypatch):
+    """step_duo_mix_kernel (incremental_duo.hip; two lanes per walker, forced with MCMC_HIP_DUO=1 at
+    these small ensembles) on randomly drawn shapes, bit for bit against the oracle: state, carried
+    residuals and mode log-densities, counters -- across the refresh at 40 cycle lengths."""
+    from tests.test_gpu_parity import assert_bit_equal
+    monkeypatch.setenv("MCMC_HIP_DUO", "1")
+    d, W, gs, K, kw, steps = draw_two_lane_case(15000 + seed)
+    eng, prob, st = make_pair(d, W, gs, K=K, incremental=True, rng=np.random.default_rng(seed), **kw)
+    compare_state(eng, st)
+    for n in steps:
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=8)
+        compare_state(eng, st)
+        full = eng.get_full_state()
+        assert_bit_equal(full["y"], st.y, "carried whitened residuals")
+        assert_bit_equal(full["amode"], st.amode, "carried mode log-densities")
+    c = eng.counters()
+    assert c["steps"] == sum(steps) and c["accepted"] == int(st.n_accept.sum())
+    assert "step_duo_mix_kernel" in eng.last_step_kernel(), eng.last_step_kernel()
+    eng.close()
