@@ -1787,7 +1787,12 @@ bool inc_carries_prior(const mcmc_hip_ctx* h)
 // mcmc_hip_step in incremental mode (MCMC_HIP_FLAG_INCREMENTAL; incremental_kernels.hip).
 // Launches are cut at the multiples of refresh_every = 40 cycle lengths, where y = L^-1 (x - mu)
 // is recomputed from x (the specification: oracle/mcmc_oracle.c, orc_run).
-constexpr int kDuoMinWalkers = 65536;   // two waves of 32 walkers on each of the 1 024 SIMDs
+// incremental_duo.hip (two lanes per walker) from this ensemble size on.  Measured (same box, d = 30,
+// K = 2, step kernel ms per 1200 steps, four lanes / two; profiles/r06_duo.txt): 16 384 walkers 1.17 / 1.41,
+// 32 768: 1.57 / 1.49 (K = 3, x in LDS: 1.85 / 2.13), 49 152: 2.06 / 1.77 (K = 3: 3.33 / 2.71; K = 4 at d = 24:
+// 2.55 / 2.11), 65 536: 2.91 / 1.85, 98 304: 3.94 / 3.35, 131 072: 5.14 / 3.68 -- two lanes win once the
+// four-lane kernel needs a second round of waves (49 152 walkers are its three waves per SIMD)
+constexpr int kDuoMinWalkers = 49152;
 struct IncPlan {   // what the cutting of launches depends on besides the step counter
     int d, dq, K, nd, chunk_steps, Lc, Lf, ld, max_cyc, max_cyc_f, max_steps_vu;
     size_t colb, dd, ddf;

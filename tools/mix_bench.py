@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the incremental step kernel on a K-mode mixture at d = 30 (engine level):
-tools/mix_bench.py [K ...]   or   tools/mix_bench.py d:K [d:K ...]  (incremental only)"""
+tools/mix_bench.py [K ...]   or   tools/mix_bench.py d:K [d:K ...]  (incremental only)
+MIX_W=<walkers> (default 65536); MCMC_HIP_DUO=0 / 1 forces four / two lanes per walker."""
 import os
 import sys
 
@@ -11,7 +12,7 @@ sys.path.insert(0, ROOT)
 from cobaya_amd.engine import Engine  # noqa: E402  (MCMC_HIP_LIB selects an experiment build)
 
 
-def run(K, inc, d=30, W=65536, gs=256, launches=4):
+def run(K, inc, d=30, W=int(os.environ.get("MIX_W", "65536")), gs=256, launches=4):
     g = np.load(os.path.join(ROOT, "tests", "golden", "targets.npz"))
     if d == 30:
         mean, cov = g["mean_d30"], g["cov_d30"]
