@@ -162,3 +162,18 @@ def test_mixture_bench_launch_bit_exact_on_two_lanes(K):
             eng.set_proposal_cov(np.cov(st.x.T))
             prob.set_T(eng.get_proposal_transform())
     eng.close()
+
+
+@pytest.mark.parametrize("W,want", [(32768, "step_inc_mix_kernel"), (49152, "step_duo_mix_kernel")])
+def test_the_launcher_takes_two_lanes_from_the_measured_size_on(W, want):
+    """capi.hip: kDuoMinWalkers = 49 152 (profiles/r06_duo.txt): below, a two-mode mixture runs with four
+    lanes per walker, from there on with two -- either way bit for bit the oracle's walkers."""
+    d, gs, bgs = 30, 256, 1024
+    eng, prob, st, mean, cov = _pair(d, W, gs, bgs, 0, K=2)
+    for n in (1, 75):
+        eng.step(n)
+        eng.sync()
+        st.run(n, n_threads=O.max_threads())
+        _compare(eng, st, f"{W} walkers")
+    assert want in eng.last_step_kernel(), eng.last_step_kernel()
+    eng.close()
