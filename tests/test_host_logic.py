@@ -35,6 +35,23 @@ def test_pl_fused_kernel_does_not_spill_where_it_hurts():
     assert max(p["scratch"] for p in producers) <= 8
 
 
+def test_two_lane_mixture_kernels_do_not_spill_inside_the_step_loop():
+    """step_duo_mix_kernel (incremental_duo.hip) runs at 256 VGPRs with up to 2 dq (K + 1) doubles of
+    state in them; whether the compiler spills inside the step loop was decided by details (round 6:
+    three modes with x in registers ran 2.2 x slower than the four-lane kernel).  The shipped source
+    must compile to step loops without scratch traffic at the top of its range (tools/check_duo_spills.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_duo_spills as C
+    rows = C.report(C.compile_to_asm(6, 8))
+    shapes = {(r["dq"], r["modes"]) for r in rows}
+    assert {(8, 2), (8, 3), (7, 3), (6, 4), (6, 2)} <= shapes and (8, 4) not in shapes and (7, 4) not in shapes
+    # (nothing stored to scratch inside the step loop; the kernels of the one-box prior touch it nowhere
+    # in the loop, those of general bounds reload one constant in the burn-in branch at most)
+    assert [r for r in rows if r["scratch_stores_in_loop"]] == []
+    assert [r for r in rows if r["scratch_in_loop"] > (0 if r["box"] else 1)] == []
+    assert all(r["vgprs"] <= 256 and r["spilled"] <= 16 for r in rows)   # (outside the loop: address temporaries)
+
+
 def test_capi_exports_every_declared_symbol():
     with open(os.path.join(ROOT, "include", "mcmc_hip.h")) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
