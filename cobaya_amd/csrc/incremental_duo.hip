@@ -17,7 +17,7 @@
 // (p0 + p1) + (p2 + p3): a lane adds its own two chains, one DPP swap adds the neighbour's.  The
 // planes (v, u_1 .. u_K) of a column give a lane the operands of both its chains in ONE ds_read_b128.
 // 65 536 walkers are 2 048 waves of this layout: two per SIMD in one round, 256 registers each --
-// which hold x and y_1, y_2 of a two-mode walker at d <= 32; with more modes (or K = 3 above d = 24) x
+// which hold x and y_1, y_2 of a two-mode walker at d <= 32; with three modes above d = 24 and four above d = 20 x
 // moves to LDS (XLDS below) and the registers hold y_1 .. y_K: three modes up to d = 32, four up to
 // d = 24 (kernels.h: duo_serves, duo_x_in_lds).
 //
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) step_duo_mix_kernel(const IncStepArgs 
     // the element of a plane whose result the next plane's reads wait for (measured at d = 30, K = 2:
     // first, middle and last element within 1 %)
     constexpr int DEPK = MCMC_DUO_DEPK(DQ / 2);
-    // XLDS (three modes from d = 25 on, four from d = 17 on): x lives in LDS, [kk][lane] pairs
+    // XLDS (three modes from d = 25 on, four from d = 21 on): x lives in LDS, [kk][lane] pairs
     // (x_even, x_odd) -- 16 reads and 8 writes of 16 bytes per lane and step --, so that the registers
     // hold y_1 .. y_KM as they hold x, y_1, y_2 of a two-mode walker (with x in registers too three
     // modes spilled ~45 doubles inside the step loop: 7.6 ms per 1200 steps at d = 30 against

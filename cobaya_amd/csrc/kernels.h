@@ -231,13 +231,18 @@ __host__ __device__ constexpr bool inc_mix_serves(int K, int dq)
 // step_duo_mix_kernel (incremental_duo.hip, round 6): the same step with TWO lanes per walker, each
 // holding 2 dq dimensions -- 2..4 modes while the residuals y_1 .. y_K of a lane (2 dq K doubles) leave
 // the body its registers at two waves per SIMD; x moves to LDS where it does not fit beside them
-// (duo_x_in_lds).  K = 2, 3: d <= 32; K = 4: d <= 24.
+// (duo_x_in_lds: three modes from d = 25 on, four from d = 21 on).  K = 2, 3: d <= 32; K = 4: d <= 24.
 constexpr int kDuoStateDoubles = 48;
 __host__ __device__ constexpr bool duo_serves(int K, int dq)
 {
     return K >= 2 && K <= 4 && dq <= 8 && 2 * dq * K <= kDuoStateDoubles;
 }
-__host__ __device__ constexpr bool duo_x_in_lds(int K, int dq) { return 2 * dq * (K + 1) > kDuoStateDoubles; }
+// x, y_1 .. y_K of a lane in registers up to 50 doubles, x in LDS above -- measured (65 536 walkers, ms per
+// 40 d steps, x in LDS / in registers): K = 4 at d = 20 (50 doubles) 1.64 / 1.53; K = 3 at d = 28 (56) 2.43 / 2.90
+#ifndef MCMC_DUO_XLDS_ABOVE
+#define MCMC_DUO_XLDS_ABOVE 50   // (experiment hook)
+#endif
+__host__ __device__ constexpr bool duo_x_in_lds(int K, int dq) { return 2 * dq * (K + 1) > MCMC_DUO_XLDS_ABOVE; }
 
 // periodic parameters step_inc_kernel<.., PER> serves (one mode, Metropolis steps, no emitted rows);
 // more: the general incremental kernels (incremental_any.hip)
