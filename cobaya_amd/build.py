@@ -23,7 +23,7 @@ ARCH = "gfx950"
 ALL_DIMS = list(range(1, 33))
 BIG_DPS = [48, 56, 64, 72, 80, 88, 96, 100, 112, 120, 128]  # padded sizes of the d > 32 kernels
 INC_DQ_RANGES = [(1, 8), (9, 16), (17, 24), (25, 32)]  # incremental_kernels.hip: ceil(d / 4)
-DUO_DQ_RANGES = [(1, 8)]  # incremental_duo.hip: two-mode mixtures, two lanes per walker, d <= 32
+DUO_DQ_RANGES = [(1, 8), (9, 12)]  # incremental_duo.hip: mixtures, two lanes per walker (two modes: d <= 48)
 PAIR_DIMS = list(range(33, 57))  # 32 < d <= 48: walker_kernels.hip's two-wave step kernel alone
 
 # -ffp-contract=off: the kernels' arithmetic order is part of the specification (fused

@@ -278,6 +278,7 @@ extern "C" hipError_t mcmc_hip_launch_inc_emit_25(const mcmc::IncStepArgs*, hipS
 extern "C" hipError_t mcmc_hip_launch_inc_any(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 // incremental_duo.hip (round 6): the incremental step of a two-mode mixture with TWO lanes per walker
 extern "C" hipError_t mcmc_hip_launch_inc_duo_1(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
+extern "C" hipError_t mcmc_hip_launch_inc_duo_9(const mcmc::IncStepArgs*, hipStream_t) __attribute__((weak));
 extern "C" hipError_t mcmc_hip_launch_whiten_directions_planes(const mcmc::IncDirArgs*, int,
                                                                hipStream_t) __attribute__((weak));
 extern "C" int mcmc_hip_inc_any_fits(int d, int n_modes, int n_periodic, int n_walkers,
@@ -1989,7 +1990,8 @@ int step_incremental(mcmc_hip_ctx* h, int n_steps)
                    P.carry_modes && h->W % 128 == 0 && h->bgs % 128 == 0 &&
                    (h->duo == 1 || h->W >= kDuoMinWalkers);
         for (size_t b = 0; h->blocked && b < h->blk_size.size() && duo; ++b) duo = h->blk_size[b] != 1;
-        if (duo && mcmc_hip_launch_inc_duo_1) launch = mcmc_hip_launch_inc_duo_1;
+        auto duo_launch = dq <= 8 ? mcmc_hip_launch_inc_duo_1 : mcmc_hip_launch_inc_duo_9;
+        if (duo && duo_launch) launch = duo_launch;
     }
     if (!launch || !mcmc_hip_launch_whiten_directions)
         return fail(h, MCMC_HIP_ERR_DEVICE, "the incremental kernels for d=%d are not linked in", d);

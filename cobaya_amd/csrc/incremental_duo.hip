@@ -18,13 +18,14 @@
 // planes (v, u_1 .. u_K) of a column give a lane the operands of both its chains in ONE ds_read_b128.
 // 65 536 walkers are 2 048 waves of this layout: two per SIMD in one round, 256 registers each --
 // which hold x and y_1, y_2 of a two-mode walker at d <= 32; with three modes above d = 24 and four above d = 20 x
-// moves to LDS (XLDS below) and the registers hold y_1 .. y_K: three modes up to d = 32, four up to
-// d = 24 (kernels.h: duo_serves, duo_x_in_lds).
+// moves to LDS (XLDS below) and the registers hold y_1 .. y_K: two modes up to d = 48, three up to d = 32,
+// four up to d = 24 (kernels.h: duo_serves, duo_x_in_lds).
 //
 // Measured (same box, 65 536 walkers, tools/mix_bench.py; step kernel ms per 40 d steps, four lanes ->
 // two; profiles/r06_duo.txt): d = 30: K = 2 2.907 -> 1.855 (2.71 -> 4.24e10 evals/s), K = 3 3.568 -> 2.815;
 // d = 24: K = 2 1.978 -> 1.250, K = 3 2.605 -> 1.527, K = 4 2.882 -> 2.222; d = 16: K = 3 1.359 -> 1.054,
-// K = 4 1.563 -> 1.019.  Four modes at d = 30 do not fit (y_1 .. y_4 alone are 128 registers: with x in
+// K = 4 1.563 -> 1.019; two modes above d = 32 (x in LDS): d = 36 3.66 -> 3.04, d = 40 4.38 -> 3.47, d = 48 5.66 -> 4.99.
+// Four modes at d = 30 do not fit (y_1 .. y_4 alone are 128 registers: with x in
 // registers as well the step loop spilled, 4.07 -> 19.9 ms) and stay on step_inc_mix_kernel.  One mode
 // gains nothing (0.893 -> 0.889 ms at d = 30: its per-lane work is small, the kernel is bound by its
 // FP64 fmas in either layout) and was not kept.
@@ -103,13 +104,21 @@ struct DuoVariates {
 // The log-sum-exp (gaussian_mixture.py:158-163; mixture_lse of the oracle): lane half h takes the
 // exponential of mode h and of mode h + 2, pair broadcasts hand them to the neighbour, the weighted sum runs in
 // the order of the specification.
-// columns of one LDS chunk (a multiple of 4): two workgroups per CU have 80 KB each -- 2 x 28 KB of
-// planes beside the staged variates (16.5 KB), the tables (2.5 KB) and the bounds; 2 x 12 KB where
-// x lives in LDS (duo_x_in_lds, kernels.h: 128 dq bytes per walker, 32 KB per workgroup at dq = 8)
+// columns of one LDS chunk (a multiple of 4): two workgroups per CU have 80 KB each -- what the staged
+// variates (16.5 KB), the tables (2.5 KB), the bounds (2 KB) and, where x lives in LDS (duo_x_in_lds,
+// kernels.h), its 128 dq bytes per walker leave, for two buffers of planes
 __host__ __device__ constexpr int duo_chunk_mix(int dq, int km)
 {
-    int c = ((duo_x_in_lds(km, dq) ? 1536 : 3584) / ((1 + km) * 4 * dq)) & ~3;
+    const int avail = 80 * 1024 - 16896 - 2560 - 2048 - (duo_x_in_lds(km, dq) ? dq * 4096 : 0);
+    int c = ((avail / 16) / ((1 + km) * 4 * dq)) & ~3;
     return c < 4 ? 4 : (c > 64 ? 64 : c);
+}
+// the v plane of a step kept in registers from the trial to the commit where the registers hold it
+// beside the state: up to 64 doubles of state + plane per lane (measured at d = 30, K = 2: 1.93 -> 1.83 ms
+// per 1200 steps)
+__host__ __device__ constexpr bool duo_keep_v(int dq, int km)
+{
+    return 2 * dq * (km + (duo_x_in_lds(km, dq) ? 0 : 1)) + 2 * dq <= 64;
 }
 
 template <int DQ, int KM, bool UNIT_T, bool BOX0>
@@ -124,15 +133,13 @@ __global__ void __launch_bounds__(256, 2) step_duo_mix_kernel(const IncStepArgs 
     // the element of a plane whose result the next plane's reads wait for (measured at d = 30, K = 2:
     // first, middle and last element within 1 %)
     constexpr int DEPK = MCMC_DUO_DEPK(DQ / 2);
-    // XLDS (three modes from d = 25 on, four from d = 21 on): x lives in LDS, [kk][lane] pairs
+    // XLDS (two modes from d = 33 on, three from d = 25 on, four from d = 21 on): x lives in LDS, [kk][lane] pairs
     // (x_even, x_odd) -- 16 reads and 8 writes of 16 bytes per lane and step --, so that the registers
     // hold y_1 .. y_KM as they hold x, y_1, y_2 of a two-mode walker (with x in registers too three
     // modes spilled ~45 doubles inside the step loop: 7.6 ms per 1200 steps at d = 30 against
     // step_inc_mix_kernel's 3.5; with x in LDS 2.8)
     constexpr bool XLDS = duo_x_in_lds(KM, DQ);
-    // the v plane of a step kept in registers from the trial to the commit (2 NE registers;
-    // measured at d = 30, K = 2: 1.93 -> 1.83 ms per 1200 steps)
-    constexpr bool KEEPV = MCMC_DUO_KEEPV(true);
+    constexpr bool KEEPV = MCMC_DUO_KEEPV(duo_keep_v(DQ, KM));
     const StepArgs& s = a.s;
     const int tid = threadIdx.x, h = tid & 1, wave = tid >> 6, lane = tid & 63;
     const int W = s.W, d = a.d;
@@ -372,15 +379,18 @@ __global__ void __launch_bounds__(256, 2) step_duo_mix_kernel(const IncStepArgs 
             // the commit reads the planes AGAIN (x, then y_1 .. y_KM): the pointer passes through
             // an empty asm behind the accept decision, nothing is kept from the trial
             if constexpr (XLDS) {
-                static_assert(KEEPV, "x in LDS: the v plane is kept");
-                unsigned xw = xoff0;
-                asm volatile("" : "+v"(xw) : "v"(ra));
+                unsigned xw = xoff0, poff = coff;
+                asm volatile("" : "+v"(xw), "+v"(poff) : "v"(ra));
                 const lds_pairs_rw px = (lds_pairs_rw)(unsigned long long)xw;
+                const lds_pairs pv = (lds_pairs)(unsigned long long)poff;
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {
                     pair_t xp = px[kk * 256];
-                    xp.x = fma(ra, vk[kk].x, xp.x);
-                    xp.y = fma(ra, vk[kk].y, xp.y);
+                    pair_t v;
+                    if constexpr (KEEPV) v = vk[kk];
+                    else v = pv[2 * kk];
+                    xp.x = fma(ra, v.x, xp.x);
+                    xp.y = fma(ra, v.y, xp.y);
                     px[kk * 256] = xp;
                 }
             } else if constexpr (KEEPV) {
@@ -404,7 +414,7 @@ __global__ void __launch_bounds__(256, 2) step_duo_mix_kernel(const IncStepArgs 
             for (int k = 0; k < KM; ++k) {
                 unsigned poff = coff + (unsigned)((1 + k) * dpad * 8);
                 // (behind the middle result of the plane before, as in the trial)
-                asm volatile("" : "+v"(poff) : "v"(k == 0 ? (KEEPV ? ra : x[XLDS ? 0 : 2 * DEPK]) : y[k > 0 ? k - 1 : 0][2 * DEPK]));
+                asm volatile("" : "+v"(poff) : "v"(k == 0 ? ((KEEPV || XLDS) ? ra : x[XLDS ? 0 : 2 * DEPK]) : y[k > 0 ? k - 1 : 0][2 * DEPK]));
                 const lds_pairs pu = (lds_pairs)(unsigned long long)poff;
 #pragma unroll
                 for (int kk = 0; kk < DQ; ++kk) {

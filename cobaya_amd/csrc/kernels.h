@@ -231,11 +231,16 @@ __host__ __device__ constexpr bool inc_mix_serves(int K, int dq)
 // step_duo_mix_kernel (incremental_duo.hip, round 6): the same step with TWO lanes per walker, each
 // holding 2 dq dimensions -- 2..4 modes while the residuals y_1 .. y_K of a lane (2 dq K doubles) leave
 // the body its registers at two waves per SIMD; x moves to LDS where it does not fit beside them
-// (duo_x_in_lds: three modes from d = 25 on, four from d = 21 on).  K = 2, 3: d <= 32; K = 4: d <= 24.
+// (duo_x_in_lds: two modes from d = 33 on, three from d = 25 on, four from d = 21 on).  K = 2: d <= 48;
+// K = 3: d <= 32; K = 4: d <= 24.
 constexpr int kDuoStateDoubles = 48;
+#ifndef MCMC_DUO_MAX_DQ
+#define MCMC_DUO_MAX_DQ 12
+#endif
+constexpr int kDuoMaxDq = MCMC_DUO_MAX_DQ;   // two modes up to d = 48 (round 6, late)
 __host__ __device__ constexpr bool duo_serves(int K, int dq)
 {
-    return K >= 2 && K <= 4 && dq <= 8 && 2 * dq * K <= kDuoStateDoubles;
+    return K >= 2 && K <= 4 && dq <= kDuoMaxDq && 2 * dq * K <= kDuoStateDoubles;
 }
 // x, y_1 .. y_K of a lane in registers up to 50 doubles, x in LDS above -- measured (65 536 walkers, ms per
 // 40 d steps, x in LDS / in registers): K = 4 at d = 20 (50 doubles) 1.64 / 1.53; K = 3 at d = 28 (56) 2.43 / 2.90

@@ -345,7 +345,7 @@ def draw_two_lane_case(seed):
     with oversampling."""
     rng = np.random.default_rng(seed)
     K = int(rng.integers(2, 5))
-    dq_max = min(8, 48 // (2 * K))
+    dq_max = min(12, 48 // (2 * K))
     d = int(rng.integers(2, 4 * dq_max + 1))
     gs = int(rng.choice([128, 256]))
     W = gs * int(rng.integers(1, 3))

@@ -1112,7 +1112,10 @@ def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     (30, 256, 128, 2, False, 1.0), (30, 512, 256, 3, False, 1.0), (24, 256, 128, 4, False, 1.0),
     (16, 256, 128, 4, True, 1.0), (27, 256, 128, 2, True, 1.7), (32, 256, 128, 3, "bounds differ", 1.0),
     (30, 256, 128, 2, "box off the origin", 1.0), (5, 128, 128, 2, False, 1.0), (12, 256, 256, 3, True, 2.0),
-    (20, 128, 128, 4, "bounds differ", 1.0), (26, 256, 128, 3, True, 1.0), (2, 128, 128, 4, False, 1.0)])
+    (20, 128, 128, 4, "bounds differ", 1.0), (26, 256, 128, 3, True, 1.0), (2, 128, 128, 4, False, 1.0),
+    # two modes above d = 32 (x in LDS; from d = 41 on the v plane is read again at the commit)
+    (36, 256, 128, 2, False, 1.0), (40, 128, 128, 2, True, 1.0), (44, 256, 128, 2, "bounds differ", 2.0),
+    (48, 128, 128, 2, False, 1.0), (33, 128, 128, 2, "box off the origin", 1.0)])
 def test_two_lane_mixture_steps_bit_exact(d, W, gs, K, normal, T, monkeypatch):
     """step_duo_mix_kernel (incremental_duo.hip, round 6): the mixture step with TWO lanes per walker
     -- the layout large ensembles run on (65 536 walkers: tests/test_gpu_bench_geometry.py), forced

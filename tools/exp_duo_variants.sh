@@ -7,10 +7,11 @@ set -e
 cd "$(dirname "$0")/.."
 CS=cobaya_amd/csrc; mkdir -p $CS/_exp
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fvisibility=hidden -mllvm -pragma-unroll-threshold=1000000 -include $CS/_exp/inc_experiment.h"
-OBJS=$(ls $CS/_obj/*.o | grep -v incremental_duo_1.o)
+LO=${DQ_LO:-1}; HI=${DQ_HI:-8}
+OBJS=$(ls $CS/_obj/*.o | grep -v incremental_duo_$LO.o)
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2
-  ( hipcc $FL $flags -DMCMC_DUO_DQ_LO=1 -DMCMC_DUO_DQ_HI=8 -c $CS/incremental_duo.hip -o $CS/_exp/duo_$name.o 2>/dev/null &&
+  ( hipcc $FL $flags -DMCMC_DUO_DQ_LO=$LO -DMCMC_DUO_DQ_HI=$HI -c $CS/incremental_duo.hip -o $CS/_exp/duo_$name.o 2>/dev/null &&
     hipcc -shared -fPIC --offload-arch=gfx950 $CS/_exp/duo_$name.o $OBJS -ldl -o $CS/_exp/lib_$name.so &&
     echo "built $name" ) &
 done
