@@ -91,6 +91,9 @@ __host__ __device__ constexpr bool inc_bounds_in_lds(int dq, int mode, bool per)
 #ifndef MCMC_EXP_FLOAT_LDS
 #define MCMC_EXP_FLOAT_LDS(tuned) (tuned)
 #endif
+#ifndef MCMC_EXP_MIX_XLDS
+#define MCMC_EXP_MIX_XLDS(tuned) (tuned)   // step_inc_mix_kernel: x in LDS where that buys a second wave per SIMD
+#endif
 #ifndef MCMC_EXP_FLOAT_VEC
 #define MCMC_EXP_FLOAT_VEC(tuned) (tuned)
 #endif
@@ -1398,6 +1401,14 @@ __host__ __device__ constexpr int inc_chunk_mix(int dq, int km)
 
 // five and six modes: up to dq = kIncMixWideDq (d <= 32) -- 7 dq doubles of state per lane
 constexpr int kMixWideDq = kIncMixWideDq;
+// Round 6 (late): where the state -- dq (km + 1) doubles per lane -- would hold the kernel to ONE wave
+// per SIMD but the residuals alone (dq km) leave it two, x lives in LDS ([kk][lane] doubles, read for
+// the trial, read and written at the commit; its offset passes through an empty asm at every use, as
+// in step_duo_mix_kernel): three modes at d = 49 .. 64, four at d = 41 .. 48
+__host__ __device__ constexpr bool inc_mix_x_in_lds(int dq, int km)
+{
+    return MCMC_EXP_MIX_XLDS(km <= 4 && dq * (km + 1) > 50 && dq * km <= 50);
+}
 __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
 {
     // measured (round 5, tools/mix_bench.py d:K over builds held to 2..4 waves, 65 536 walkers; ms per
@@ -1410,7 +1421,7 @@ __host__ __device__ constexpr int inc_mix_min_waves(int dq, int km)
     // (round 5 late, after the box test moved to the high words: two modes at three waves 2.81 against
     // 2.91 ms per 1200 steps at d = 30; three and more modes still spill there)
     return MCMC_EXP_WAVES(MIX, dq * (km + 1) <= 12 ? 4 : (km == 2 && dq * (km + 1) <= 24) ? 3
-                                                      : dq * (km + 1) <= 50 ? 2 : 1);
+                                                      : (dq * (km + 1) <= 50 || inc_mix_x_in_lds(dq, km)) ? 2 : 1);
 }
 
 #ifndef MCMC_MIX_FRESH_EPILOGUE
@@ -1462,13 +1473,19 @@ step_inc_mix_kernel(const IncStepArgs a)
         sNA[i] = make_double2(a.prior[2 * dpad + i], a.prior[3 * dpad + i]);
         sNM[i] = a.prior[4 * dpad + i];
     }
-    double x[DQ], y[KM][DQ];
+    constexpr bool XLDS = inc_mix_x_in_lds(DQ, KM);
+    double x[XLDS ? 1 : DQ], y[KM][DQ];
+    __shared__ double sXq[XLDS ? DQ * 256 : 1];
+    typedef double __attribute__((address_space(3))) * lds_doubles_rw;
+    const unsigned xoff0 = lds_offset(sXq + tid);
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
         const bool in = i < d;
         // (one box for all dimensions: a padded dimension rests at its middle, inside for every step)
-        x[kk] = in ? s.x[(size_t)i * W + w] : (a.box ? 0.5 * (a.box_lo + a.box_hi) : 0.0);
+        const double xv = in ? s.x[(size_t)i * W + w] : (a.box ? 0.5 * (a.box_lo + a.box_hi) : 0.0);
+        if (XLDS) sXq[kk * 256 + tid] = xv;
+        else x[XLDS ? 0 : kk] = xv;
 #pragma unroll
         for (int k = 0; k < KM; ++k) y[k][kk] = in ? a.y[((size_t)k * d + i) * W + w] : 0.0;
     }
@@ -1586,6 +1603,15 @@ step_inc_mix_kernel(const IncStepArgs a)
                 unsigned coff = lds_offset(cur + sl * COL + c);
                 asm volatile("" : "+v"(coff));
                 const lds_doubles col = (lds_doubles)(unsigned long long)coff;
+                // (XLDS: a new address for the compiler at every use -- nothing is promoted back to
+                // registers, and the reads stay behind the writes of the step before)
+                unsigned xo = xoff0;
+                if (XLDS) asm volatile("" : "+v"(xo));
+                const lds_doubles xs = (lds_doubles)(unsigned long long)xo;
+                auto xat = [&](int kk) {
+                    if constexpr (XLDS) return xs[kk * 256];
+                    else return x[kk];
+                };
                 unsigned long long inb = ~0ull;   // the support test as a lane mask
                 double sc = 0.0;
                 double dep;                       // what the next group of reads is ordered behind
@@ -1598,7 +1624,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                     double t = 0.0;
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
-                        t = fma(r, col[4 * kk], x[kk]);
+                        t = fma(r, col[4 * kk], xat(kk));
                         const unsigned h = (unsigned)__double2hiint(t);
                         hmx = hmx > h ? hmx : h;
                     }
@@ -1611,7 +1637,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                         inb = ~0ull;
 #pragma unroll
                         for (int kk = 0; kk < DQ; ++kk) {
-                            const double tx = fma(r, colx[4 * kk], x[kk]);
+                            const double tx = fma(r, colx[4 * kk], xat(kk));
                             inb &= lanes(tx <= a.box_hi) & lanes(tx >= a.box_lo);
                         }
                     }
@@ -1621,7 +1647,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                     double tmx = -INFINITY, tmn = INFINITY;
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
-                        const double t = fma(r, col[4 * kk], x[kk]);
+                        const double t = fma(r, col[4 * kk], xat(kk));
                         tmx = __builtin_fmax(tmx, t);
                         tmn = __builtin_fmin(tmn, t);
                     }
@@ -1630,7 +1656,7 @@ step_inc_mix_kernel(const IncStepArgs a)
                 } else {
 #pragma unroll
                     for (int kk = 0; kk < DQ; ++kk) {
-                        const double t = fma(r, col[4 * kk], x[kk]);
+                        const double t = fma(r, col[4 * kk], xat(kk));
                         const double2 lh = sLH[4 * kk + c];
                         inb &= lanes(t <= lh.y) & lanes(t >= lh.x);
                         if (a.has_norm) {   // wave-uniform; branch-free inside (1/scale = 0: no term)
@@ -1679,14 +1705,22 @@ step_inc_mix_kernel(const IncStepArgs a)
                     unsigned poff = coff;
                     asm volatile("" : "+v"(poff) : "v"(ra));   // (re-read: not kept from the trial)
                     const lds_doubles pv = (lds_doubles)(unsigned long long)poff;
+                    if constexpr (XLDS) {
+                        unsigned xw = xoff0;
+                        asm volatile("" : "+v"(xw) : "v"(ra));
+                        const lds_doubles_rw px = (lds_doubles_rw)(unsigned long long)xw;
 #pragma unroll
-                    for (int kk = 0; kk < DQ; ++kk) x[kk] = fma(ra, pv[4 * kk], x[kk]);
+                        for (int kk = 0; kk < DQ; ++kk) px[kk * 256] = fma(ra, pv[4 * kk], px[kk * 256]);
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < DQ; ++kk) x[XLDS ? 0 : kk] = fma(ra, pv[4 * kk], x[XLDS ? 0 : kk]);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < KM; ++k) {
                     unsigned poff = coff + (unsigned)((1 + k) * dpad * 8);
 #if MCMC_MIX_ORDERED_READS
-                    asm volatile("" : "+v"(poff) : "v"(k == 0 ? x[DQ - 1] : y[k > 0 ? k - 1 : 0][DQ - 1]));
+                    asm volatile("" : "+v"(poff) : "v"(k == 0 ? (XLDS ? ra : x[XLDS ? 0 : DQ - 1]) : y[k > 0 ? k - 1 : 0][DQ - 1]));
 #else
                     asm volatile("" : "+v"(poff) : "v"(ra));
 #endif
@@ -1721,7 +1755,7 @@ step_inc_mix_kernel(const IncStepArgs a)
     for (int kk = 0; kk < DQ; ++kk) {
         const int i = 4 * kk + c;
         if (i < d) {
-            s.x[(size_t)i * W + we] = x[kk];
+            s.x[(size_t)i * W + we] = XLDS ? sXq[kk * 256 + tid] : x[XLDS ? 0 : kk];
 #pragma unroll
             for (int k = 0; k < KM; ++k) a.y[((size_t)k * d + i) * W + we] = y[k][kk];
         }

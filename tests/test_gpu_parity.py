@@ -1103,7 +1103,11 @@ def test_own_basis_periodic_rows_and_offsets_bit_exact():
     (9, 128, 64, 4, True, 1.0), (64, 128, 64, 2, False, 2.0), (27, 256, 128, 2, True, 1.0),
     (30, 256, 64, 2, "box off the origin", 1.0), (30, 256, 64, 4, "bounds differ", 1.0),
     (30, 256, 64, 5, False, 1.0), (28, 128, 64, 6, True, 1.7), (32, 128, 64, 5, True, 1.0), (6, 256, 128, 6, False, 1.0),
-    (27, 128, 64, 5, "bounds differ", 1.0)])
+    (27, 128, 64, 5, "bounds differ", 1.0),
+    # round 6: x in LDS where that buys step_inc_mix_kernel a second wave per SIMD (three modes at
+    # d = 49 .. 64, four at d = 41 .. 48)
+    (52, 128, 64, 3, False, 1.0), (64, 128, 64, 3, True, 1.0), (44, 128, 64, 4, "bounds differ", 1.0),
+    (48, 256, 128, 4, False, 1.7), (60, 64, 64, 3, "box off the origin", 1.0)])
 def test_incremental_mixture_steps_bit_exact(d, W, gs, K, normal, T):
     _mixture_case(d, W, gs, K, normal, T, "step_inc_mix_kernel")
 
